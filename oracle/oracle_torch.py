@@ -1,0 +1,330 @@
+"""ORACLE (test infrastructure — NOT the product): CPU restatement of Text2NeRF's TensoRF VM-split
+ray-marching path in plain PyTorch tensor arithmetic.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module, and only as the checker. The shipped renderer (text2nerf_amd) never imports it.
+
+Parity status: PINNED. Every function below is checked against golden vectors produced by importing the
+reference itself on CPU (tests/golden/make_golden.py -> tests/golden/*.npz; tests/test_oracle_golden.py).
+The arithmetic lives in a third-party dependency of the reference (PyTorch ATen, pinned
+torch==1.13.1+cu116, requirements.txt:164): ``F.grid_sample`` (bilinear, zeros padding,
+align_corners=True), ``F.softplus``, ``torch.cumprod``, ``nn.Linear``. Those are restated here as
+explicit floor / tap-gather / lerp arithmetic (no grid_sample call), following the published ATen
+algorithm: unnormalise ``((g+1)/2)*(size-1)``, corner = floor, weights by subtraction, out-of-range taps
+contribute zero.
+
+Each function cites the reference lines it follows. Everything is float32 unless ``dtype`` says
+otherwise (float64 runs are used by tests to size tolerances).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Sequence
+
+import torch
+
+MAT_MODE = ((0, 1), (0, 2), (1, 2))   # models/tensorBase.py:190
+VEC_MODE = (2, 1, 0)                  # models/tensorBase.py:191
+
+# models/sh.py:4-14 (degree <= 2 constants)
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+
+
+@dataclass
+class FieldConfig:
+    """Scalars that parameterise the path (models/tensorBase.py:163-231)."""
+    aabb: Sequence[Sequence[float]]
+    grid_size: Sequence[int]
+    near_far: Sequence[float] = (0.5, 8.0)
+    density_shift: float = -10.0
+    distance_scale: float = 25.0
+    ray_march_weight_thres: float = 1e-4
+    step_ratio: float = 1.0
+    fea_pe: int = 6
+    shading_mode: str = "MLP_Fea_noview"
+    fea2dense_act: str = "softplus"
+    z_gate: float = 2.0   # models/tensorBase.py:460 (hard-coded 2.)
+    step_size: float = field(init=False)
+    n_samples: int = field(init=False)
+
+    def __post_init__(self):
+        self.step_size, self.n_samples = update_step_size(self.aabb, self.grid_size, self.step_ratio)
+
+
+def update_step_size(aabb, grid_size, step_ratio):
+    """models/tensorBase.py:220-231 — all in float32 tensors like the reference."""
+    a = torch.tensor(aabb, dtype=torch.float32)
+    size = a[1] - a[0]
+    g = torch.tensor(list(grid_size), dtype=torch.int64)
+    units = size / (g - 1)
+    step = torch.mean(units) * step_ratio
+    diag = torch.sqrt(torch.sum(torch.square(size)))
+    n = int((diag / step).item()) + 1
+    return float(step.item()), n
+
+
+# ------------------------------------------------------------------------------------------------
+# a-1 / a-2  ray generation
+# ------------------------------------------------------------------------------------------------
+def ray_directions(H, W, focal, center=None, dtype=torch.float32):
+    """dataLoader/ray_utils.py:24-42: pixel centres (+0.5), ((i-cx)/fx, (j-cy)/fy, 1). Not normalised."""
+    xs = torch.arange(W, dtype=dtype) + 0.5
+    ys = torch.arange(H, dtype=dtype) + 0.5
+    i = xs[None, :].expand(H, W)
+    j = ys[:, None].expand(H, W)
+    cent = center if center is not None else [W / 2, H / 2]
+    return torch.stack([(i - cent[0]) / focal[0], (j - cent[1]) / focal[1], torch.ones_like(i)], -1)
+
+
+def normalize_directions(d):
+    """dataLoader/scene_gen.py:45."""
+    return d / torch.sqrt((d * d).sum(-1, keepdim=True))
+
+
+def get_rays(directions, c2w):
+    """dataLoader/ray_utils.py:66-87: rotate, no re-normalisation; origin broadcast."""
+    c2w = torch.as_tensor(c2w, dtype=directions.dtype)
+    rd = directions @ c2w[:3, :3].T
+    ro = c2w[:3, 3].expand(rd.shape)
+    return ro.reshape(-1, 3), rd.reshape(-1, 3)
+
+
+# ------------------------------------------------------------------------------------------------
+# a-5  sampling
+# ------------------------------------------------------------------------------------------------
+def sample_ray(cfg: FieldConfig, rays_o, rays_d, n_samples, jitter=None):
+    """models/tensorBase.py:304-323. ``jitter`` [R,1] in [0,1) reproduces the train-time draw."""
+    dt = rays_o.dtype
+    aabb = torch.tensor(cfg.aabb, dtype=dt)
+    near, far = cfg.near_far
+    vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+    rate_a = (aabb[1] - rays_o) / vec
+    rate_b = (aabb[0] - rays_o) / vec
+    t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near, max=far)
+    rng = torch.arange(n_samples, dtype=dt)[None]
+    if jitter is not None:
+        rng = rng.repeat(rays_d.shape[0], 1) + jitter.to(dt)
+    step = torch.tensor(cfg.step_size, dtype=dt) * rng
+    z = t_min[:, None] + step
+    pts = rays_o[:, None, :] + rays_d[:, None, :] * z[..., None]
+    outside = ((aabb[0] > pts) | (pts > aabb[1])).any(-1)
+    return pts, z, ~outside
+
+
+def normalize_coord(cfg: FieldConfig, xyz):
+    """models/tensorBase.py:224,245-246."""
+    aabb = torch.tensor(cfg.aabb, dtype=xyz.dtype)
+    inv = 2.0 / (aabb[1] - aabb[0])
+    return (xyz - aabb[0]) * inv - 1
+
+
+# ------------------------------------------------------------------------------------------------
+# a-9 / a-12  factor lookup (ATen grid_sampler_2d, bilinear / zeros / align_corners=True, restated)
+# ------------------------------------------------------------------------------------------------
+def _unnormalize(g, size):
+    return ((g + 1) / 2) * (size - 1)
+
+
+def bilinear_plane(plane, gx, gy):
+    """plane [1,C,H,W]; gx->W axis, gy->H axis; returns [C,V]."""
+    _, C, H, W = plane.shape
+    ix, iy = _unnormalize(gx, W), _unnormalize(gy, H)
+    x0, y0 = torch.floor(ix), torch.floor(iy)
+    wx1, wy1 = ix - x0, iy - y0
+    wx0, wy0 = 1 - wx1, 1 - wy1
+    x0, y0 = x0.long(), y0.long()
+    out = None
+    for dy, wy in ((0, wy0), (1, wy1)):
+        for dx, wx in ((0, wx0), (1, wx1)):
+            xx, yy = x0 + dx, y0 + dy
+            ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+            v = plane[0][:, yy.clamp(0, H - 1), xx.clamp(0, W - 1)] * ok.to(plane.dtype)
+            term = v * (wy * wx)
+            out = term if out is None else out + term
+    return out
+
+
+def linear_line(line, gv):
+    """line [1,C,L,1] sampled at grid (x=0, y=gv) -> [C,V] (the W=1 axis degenerates to weight 1)."""
+    _, C, L, _ = line.shape
+    iy = _unnormalize(gv, L)
+    y0 = torch.floor(iy)
+    w1 = iy - y0
+    w0 = 1 - w1
+    y0 = y0.long()
+    out = None
+    for dy, w in ((0, w0), (1, w1)):
+        yy = y0 + dy
+        ok = (yy >= 0) & (yy < L)
+        v = line[0, :, :, 0][:, yy.clamp(0, L - 1)] * ok.to(line.dtype)
+        out = v * w if out is None else out + v * w
+    return out
+
+
+def density_feature(params: Dict[str, torch.Tensor], xyz_norm):
+    """models/tensoRF.py:205-220."""
+    feat = torch.zeros(xyz_norm.shape[0], dtype=xyz_norm.dtype)
+    c = xyz_norm.detach()
+    for k in range(3):
+        m0, m1 = MAT_MODE[k]
+        p = bilinear_plane(params[f"density_plane.{k}"], c[:, m0], c[:, m1])
+        l = linear_line(params[f"density_line.{k}"], c[:, VEC_MODE[k]])
+        feat = feat + (p * l).sum(0)
+    return feat
+
+
+def feature2density(cfg: FieldConfig, feat):
+    """models/tensorBase.py:406-410 (softplus beta=1, threshold=20)."""
+    if cfg.fea2dense_act == "relu":
+        return torch.relu(feat)
+    x = feat + cfg.density_shift
+    return torch.where(x > 20, x, torch.log1p(torch.exp(torch.clamp(x, max=20.0))))
+
+
+def app_feature(params, xyz_norm):
+    """models/tensoRF.py:223-239: [A,144] products -> basis_mat (no bias) -> [A,app_dim]."""
+    c = xyz_norm.detach()
+    prods = []
+    for k in range(3):
+        m0, m1 = MAT_MODE[k]
+        p = bilinear_plane(params[f"app_plane.{k}"], c[:, m0], c[:, m1])
+        l = linear_line(params[f"app_line.{k}"], c[:, VEC_MODE[k]])
+        prods.append(p * l)
+    x = torch.cat(prods, 0).T
+    return x @ params["basis_mat.weight"].T
+
+
+# ------------------------------------------------------------------------------------------------
+# a-13  shading heads
+# ------------------------------------------------------------------------------------------------
+def positional_encoding(x, freqs):
+    """models/tensorBase.py:11-17: feature-major, frequency-minor; all sines then all cosines."""
+    bands = (2 ** torch.arange(freqs, dtype=torch.float32)).to(x.dtype)
+    p = (x[..., None] * bands).reshape(x.shape[:-1] + (freqs * x.shape[-1],))
+    return torch.cat([torch.sin(p), torch.cos(p)], -1)
+
+
+def mlp_fea_noview(params, feat, fea_pe):
+    """models/tensorBase.py:88-109."""
+    x = torch.cat([feat, positional_encoding(feat, fea_pe)], -1) if fea_pe > 0 else feat
+    h = torch.relu(x @ params["renderModule.mlp.0.weight"].T + params["renderModule.mlp.0.bias"])
+    h = torch.relu(h @ params["renderModule.mlp.2.weight"].T + params["renderModule.mlp.2.bias"])
+    o = h @ params["renderModule.mlp.4.weight"].T + params["renderModule.mlp.4.bias"]
+    return torch.sigmoid(o)
+
+
+def sh_bases_deg2(d):
+    """models/sh.py:87-112 for deg=2."""
+    x, y, z = d.unbind(-1)
+    xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+    return torch.stack([torch.full_like(x, SH_C0), -SH_C1 * y, SH_C1 * z, -SH_C1 * x,
+                        SH_C2[0] * xy, SH_C2[1] * yz, SH_C2[2] * (2.0 * zz - xx - yy),
+                        SH_C2[3] * xz, SH_C2[4] * (xx - yy)], -1)
+
+
+def sh_render(viewdirs, feat):
+    """models/tensorBase.py:29-33."""
+    b = sh_bases_deg2(viewdirs)[:, None]
+    return torch.relu((b * feat.view(-1, 3, b.shape[-1])).sum(-1) + 0.5)
+
+
+def shade(cfg: FieldConfig, params, viewdirs, feat):
+    if cfg.shading_mode == "MLP_Fea_noview":
+        return mlp_fea_noview(params, feat, cfg.fea_pe)
+    if cfg.shading_mode == "SH":
+        return sh_render(viewdirs, feat)
+    if cfg.shading_mode == "RGB":
+        return feat
+    raise NotImplementedError(cfg.shading_mode)
+
+
+# ------------------------------------------------------------------------------------------------
+# a-11  transmittance
+# ------------------------------------------------------------------------------------------------
+def raw2alpha(sigma, dist):
+    """models/tensorBase.py:19-26; sequential product like torch.cumprod."""
+    alpha = 1.0 - torch.exp(-sigma * dist)
+    T = torch.cumprod(torch.cat([torch.ones(alpha.shape[0], 1, dtype=alpha.dtype), 1.0 - alpha + 1e-10], -1), -1)
+    return alpha, alpha * T[:, :-1], T[:, -1:]
+
+
+# ------------------------------------------------------------------------------------------------
+# a-4  forward, a-3 chunked harness
+# ------------------------------------------------------------------------------------------------
+def forward(cfg: FieldConfig, params, rays, white_bg=True, is_train=False, n_samples=-1, jitter=None,
+            bg_coin: Optional[bool] = None, return_aux=False):
+    """models/tensorBase.py:436-507 (ndc_ray=False, alphaMask=None — the driver's configuration).
+
+    ``jitter``: [R,1] uniform draw used when is_train. ``bg_coin``: outcome of the reference's
+    ``torch.rand((1,)) < 0.5`` (only consulted when white_bg is False and is_train)."""
+    n = n_samples if n_samples > 0 else cfg.n_samples
+    if is_train and jitter is None:
+        raise ValueError("train-mode oracle needs the captured jitter draw")
+    ro, rd = rays[:, :3], rays[:, 3:6]
+    pts, z, valid = sample_ray(cfg, ro, rd, n, jitter if is_train else None)
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])], -1)
+    if not is_train:
+        valid = valid & (pts[:, :, -1] > cfg.z_gate)
+    sigma = torch.zeros(pts.shape[:-1], dtype=pts.dtype)
+    rgb = torch.zeros(pts.shape[:2] + (3,), dtype=pts.dtype)
+    xn = normalize_coord(cfg, pts)
+    if valid.any():
+        s = feature2density(cfg, density_feature(params, xn[valid]))
+        sigma = _scatter(sigma, valid, s)
+    alpha, weight, bg = raw2alpha(sigma, dists * cfg.distance_scale)
+    app_mask = weight > cfg.ray_march_weight_thres
+    if app_mask.any():
+        vd = rd[:, None, :].expand(pts.shape)
+        f = app_feature(params, xn[app_mask])
+        c = shade(cfg, params, vd[app_mask], f)
+        rgb = _scatter(rgb, app_mask, c)
+    acc = weight.sum(-1)
+    rgb_map = (weight[..., None] * rgb).sum(-2)
+    if white_bg or (is_train and bool(bg_coin)):
+        rgb_map = rgb_map + (1.0 - acc[..., None])
+    rgb_map = rgb_map.clamp(0, 1)
+    depth = (weight * z).sum(-1) + (1.0 - acc) * rays[..., -1]
+    if return_aux:
+        return rgb_map, depth, z, weight, dict(sigma=sigma, valid=valid, app_mask=app_mask, acc=acc, alpha=alpha)
+    return rgb_map, depth, z, weight
+
+
+def _scatter(dst, mask, src):
+    out = dst.clone()
+    out[mask] = src
+    return out
+
+
+def render(cfg, params, rays, chunk=4096, n_samples=-1, white_bg=True, is_train=False, jitter=None):
+    """renderer.py:28-42: chunk loop + cat; 5-tuple with None in slot 1."""
+    outs = [[], [], [], []]
+    R = rays.shape[0]
+    for k in range(R // chunk + int(R % chunk > 0)):
+        sl = slice(k * chunk, (k + 1) * chunk)
+        o = forward(cfg, params, rays[sl], white_bg, is_train, n_samples, None if jitter is None else jitter[sl])
+        for lst, t in zip(outs, o):
+            lst.append(t)
+    rgb, depth, z, w = [torch.cat(x) for x in outs]
+    return rgb, None, depth, w, z
+
+
+def tv_loss(x, weight=1.0):
+    """utils.py:488-504."""
+    b, c, h, w = x.shape
+    count_h = c * (h - 1) * w
+    count_w = c * h * (w - 1)
+    h_tv = ((x[:, :, 1:, :] - x[:, :, :h - 1, :]) ** 2).sum()
+    w_tv = ((x[:, :, :, 1:] - x[:, :, :, :w - 1]) ** 2).sum()
+    return weight * 2 * (h_tv / count_h + w_tv / count_w) / b
+
+
+def params_from_numpy(sd, dtype=torch.float32, requires_grad=False):
+    out = {}
+    for k, v in sd.items():
+        t = torch.as_tensor(v).to(dtype).clone()
+        t.requires_grad_(requires_grad)
+        out[k] = t
+    return out

@@ -1,0 +1,39 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+TINY = dict(grid=[24, 20, 16], aabb=[[-8.0, -6.0, -7.0], [8.0, 7.0, 6.5]], near_far=[0.5, 8.0])
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def tiny():
+    return dict(np.load(os.path.join(GOLDEN, "tiny.npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def big300():
+    return dict(np.load(os.path.join(GOLDEN, "big300.npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def tiny_params():
+    from text2nerf_amd import synth
+    return synth.make_field_params(11, TINY["grid"], density_scale=0.9, aabb=TINY["aabb"])
+
+
+@pytest.fixture(scope="session")
+def tiny_params_sh():
+    from text2nerf_amd import synth
+    return synth.make_field_params(11, TINY["grid"], density_scale=0.9, aabb=TINY["aabb"], shading_mode="SH")
