@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py — render throughput of the HIP TensoRF VM-split ray marcher on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): TensorVMSplit 300^3, one 800x800 view (640 000 rays), N_samples=-1 => 518
+samples/ray, render_only, synthetic scene S1-soft (seed 0), white background. A step = one full frame through the hot
+path (march -> shade -> composite) with rays and weights resident in HBM. With --gpus N every rank renders its own view
+of a small-baseline trajectory (weak scaling: independent ray tiles) and the rgb+depth tiles are all-gathered with
+RCCL inside the timed region.
+
+Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json plus `roofline` for the dominant kernel and
+`cpu_baseline` (the oracle — a PyTorch CPU restatement of the reference path — on a bounded sample of the workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_EVAL = 1152   # 3 planes x 4 taps x 64 B + 3 lines x 2 taps x 64 B
+BYTES_PER_APP = 3456
+BYTES_PER_RAY = 40
+
+
+def build_field(dev, scene="S1-soft", seed=0, grid=300):
+    from text2nerf_amd import TensorVMSplit, synth
+    aabb = [[-8.0] * 3, [8.0] * 3]
+    params = synth.make_field_params(seed, [grid] * 3, scene=scene, aabb=aabb)
+    m = TensorVMSplit(torch.tensor(aabb), [grid] * 3, dev, density_n_comp=[16] * 3, appearance_n_comp=[48] * 3,
+                      app_dim=27, near_far=[0.5, 8.0], shadingMode="MLP_Fea_noview", alphaMask_thres=1e-4,
+                      density_shift=-10, distance_scale=25, pos_pe=0, view_pe=0, fea_pe=6, featureC=128, step_ratio=1.0,
+                      fea2denseAct="softplus")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    return m, params, aabb
+
+
+def cpu_baseline(params, aabb, grid, n_samples, budget_s=20.0):
+    """The oracle timed on the host cores on a bounded sample of the same frame (every 5th pixel, chunk 16384 like the
+    reference driver)."""
+    from oracle import oracle_torch as O
+    from text2nerf_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.FieldConfig(aabb=aabb, grid_size=[grid] * 3)
+    P = O.params_from_numpy(params)
+    rays = torch.from_numpy(synth.frame_rays_np(800, 800, stride=5))   # 25 600 rays
+    done, t0 = 0, time.time()
+    with torch.no_grad():
+        for k in range(0, rays.shape[0], 4096):
+            O.forward(cfg, P, rays[k:k + 4096], n_samples=n_samples)
+            done += min(4096, rays.shape[0] - k)
+            if time.time() - t0 > budget_s:
+                break
+    dt = time.time() - t0
+    return {"value": done * n_samples / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
+            "sample": f"{done} rays (800x800 frame, every 5th pixel) x {n_samples} samples, oracle_torch, "
+                      f"{torch.get_num_threads()} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="S1-soft")
+    ap.add_argument("--weights", type=int, default=0, help="1: also materialise weights/z_vals [R,N] like the reference")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from text2nerf_amd import generate_rays, synth
+    from text2nerf_amd.parallel import all_gather_tiles
+
+    H = W = 800
+    field, params, aabb = build_field(dev, scene=args.scene, seed=0 if args.scene.startswith("S1") else 1)
+    field.materialize_weights = bool(args.weights)
+    N = field.nSamples
+    poses = synth.local_fixed_like_poses(max(world, 9))
+    pose = poses[rank % len(poses)] if world > 1 else np.eye(4, dtype=np.float32)
+    f = float(max(H, W))
+    rays = generate_rays(H, W, [f, f, W // 2, H // 2], pose, device=dev)   # resident in HBM before the timed region
+    R = rays.shape[0]
+
+    def step():
+        with torch.no_grad():
+            rgb, depth, z, w = field(rays, white_bg=True, is_train=False, N_samples=-1)
+            if world > 1:
+                return all_gather_tiles(torch.cat([rgb, depth[:, None]], 1))
+            return rgb
+
+    for _ in range(args.warmup):
+        step()
+    st = field.stats()
+    field.timing(True)
+    field.read_timing(reset=True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timing = field.read_timing(reset=True)
+    field.timing(False)
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        V, A = st["evaluated"], st["appearance"]
+        ms_step = dt / args.steps * 1e3
+        nominal = world * R * N * args.steps / dt
+        k_ms = {k: v[0] / max(v[1], 1) for k, v in timing.items()}        # avg ms per launch
+        k_per_step = {k: v[1] / args.steps for k, v in timing.items()}     # launches per step
+        alg = {"march": BYTES_PER_EVAL * V + BYTES_PER_RAY * R, "shade": BYTES_PER_APP * A}
+        frame_ms = {k: v[0] / args.steps for k, v in timing.items()}       # kernel ms per frame
+        dom = max(("march", "shade"), key=lambda k: frame_ms.get(k, 0.0))
+        launches = max(k_per_step.get(dom, 1.0), 1.0)
+        achieved = (alg[dom] / launches) / (k_ms[dom] * 1e-3) / 1e9 if dom in k_ms else None
+        out = {
+            "metric": "ray-samples/s (render), 300^3 VM-split, 800x800",
+            "value": nominal, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"C2: TensorVMSplit 300^3, 800x800 view/GPU, {N} samples/ray, render_only, scene "
+                                   f"{args.scene} seed 0, white_bg, weights/z_vals materialised: {bool(args.weights)}",
+                       "rays_per_gpu": R, "samples_per_ray": N, "evaluated_samples_per_frame": V,
+                       "appearance_samples_per_frame": A, "rays_per_s": world * R * args.steps / dt,
+                       "evaluated_samples_per_s": world * V * args.steps / dt,
+                       "parallelism": f"ray-tile x{world}" + (" + RCCL all-gather of rgb+depth tiles" if world > 1 else ""),
+                       "kernel_ms_per_frame": frame_ms,
+                       "path_roofline_frac": ((BYTES_PER_EVAL * V + BYTES_PER_APP * A + BYTES_PER_RAY * R) /
+                                              (ms_step * 1e-3) / 1e9) / HBM_PEAK_GBS},
+            "roofline": {"bound": "hbm", "kernel": f"k_{dom}", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": k_ms.get(dom)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params, aabb, 300, N)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,180 @@
+/*
+ * t2n.h — C-ABI of libt2n_hip.so: the MI355X (gfx950) TensoRF VM-split ray-marching renderer that replaces the
+ * PyTorch op sequence behind Text2NeRF's  OctreeRender_trilinear_fast(rays, tensorf, ...)  /  TensorVMSplit.forward.
+ *
+ * The reference has no native code on this path (it is ~30 eager ATen ops per chunk), so there is no foreign-function
+ * interface to mirror; each entry point below cites the reference Python it replaces (paths relative to the reference
+ * repository). INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only; every pointer is a DEVICE pointer owned by the caller unless marked "host".
+ *   - every call returns 0 on success or a negative T2N_ERR_* code; t2n_last_error() gives a thread-local message.
+ *     Nothing throws across the boundary. Unsupported configurations are rejected loudly (T2N_ERR_UNSUPPORTED): there is
+ *     no CPU fallback in this library.
+ *   - work is enqueued on the caller's HIP stream (pass torch.cuda.current_stream().cuda_stream); calls do not
+ *     synchronise unless documented. The library allocates device memory only inside t2n_field_create/_upload (the
+ *     channel-last copy of the factor tensors); per-call scratch comes from the caller's workspace.
+ *   - a handle may be used from one host thread at a time.
+ */
+#ifndef T2N_H_
+#define T2N_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct t2n_field t2n_field;      /* opaque */
+typedef void* t2n_stream;                /* hipStream_t */
+
+enum {
+    T2N_OK = 0,
+    T2N_ERR_INVALID = -1,      /* bad argument */
+    T2N_ERR_UNSUPPORTED = -2,  /* configuration the HIP path does not implement */
+    T2N_ERR_HIP = -3,          /* a HIP runtime call failed */
+    T2N_ERR_WORKSPACE = -4,    /* caller workspace too small */
+    T2N_ERR_STATE = -5         /* e.g. render before upload, backward without a kept context */
+};
+
+/* shading heads: models/tensorBase.py:200-216 */
+enum { T2N_SHADE_MLP_FEA_NOVIEW = 0, T2N_SHADE_SH = 1, T2N_SHADE_RGB = 2 };
+/* fea2denseAct: models/tensorBase.py:406-410 */
+enum { T2N_ACT_SOFTPLUS = 0, T2N_ACT_RELU = 1 };
+
+/* render flags */
+enum {
+    T2N_FLAG_TRAIN = 1u,      /* is_train: per-ray jitter, no z gate (models/tensorBase.py:314-316,459) */
+    T2N_FLAG_ADD_BG = 2u,     /* rgb_map += 1-acc  (white_bg, or the train-time coin; models/tensorBase.py:497-498) */
+    T2N_FLAG_KEEP_CTX = 4u    /* keep the per-call context in the workspace for t2n_render_backward */
+};
+
+/* Scalars of TensorBase.__init__/update_stepSize (models/tensorBase.py:163-231), computed by the host mirror. */
+typedef struct t2n_field_desc {
+    float aabb_min[3], aabb_max[3];
+    float inv_aabb_size[3];        /* 2/(aabb_max-aabb_min), fp32 as the reference computes it (:224) */
+    int32_t grid[3];               /* gridSize (x,y,z) */
+    int32_t density_n_comp;        /* per plane; the three planes must agree */
+    int32_t app_n_comp;
+    int32_t app_dim;               /* 27 (MLP/SH heads) or 3 (RGB head) */
+    int32_t shading;               /* T2N_SHADE_* */
+    int32_t fea_pe;                /* 6 */
+    int32_t feature_c;             /* 128 */
+    int32_t act;                   /* T2N_ACT_* */
+    float density_shift;           /* -10 */
+    float distance_scale;          /* 25 */
+    float weight_thres;            /* rayMarch_weight_thres 1e-4 */
+    float step_size;               /* stepSize */
+    float near, far;               /* near_far */
+    float z_gate;                  /* 2.0: the eval-only world-z gate (models/tensorBase.py:459-462) */
+} t2n_field_desc;
+
+/* Reference-layout parameter pointers (device, fp32), i.e. the tensors of TensorVMSplit.state_dict()
+ * (models/tensoRF.py:144-160): plane k is [1,C,grid[matMode[k][1]],grid[matMode[k][0]]], line k is [1,C,grid[vecMode[k]],1],
+ * basis_mat.weight [app_dim, 3*app_n_comp], renderModule.mlp.{0,2,4}.{weight,bias} (NULL for SH / RGB heads). */
+typedef struct t2n_field_params {
+    const float* density_plane[3];
+    const float* density_line[3];
+    const float* app_plane[3];
+    const float* app_line[3];
+    const float* basis_weight;
+    const float* mlp_w0; const float* mlp_b0;
+    const float* mlp_w1; const float* mlp_b1;
+    const float* mlp_w2; const float* mlp_b2;
+} t2n_field_params;
+
+/* Gradient buffers in the SAME reference layouts (device, fp32, caller-zeroed or accumulated into). */
+typedef struct t2n_field_grads {
+    float* density_plane[3];
+    float* density_line[3];
+    float* app_plane[3];
+    float* app_line[3];
+    float* basis_weight;
+    float* mlp_w0; float* mlp_b0;
+    float* mlp_w1; float* mlp_b1;
+    float* mlp_w2; float* mlp_b2;
+} t2n_field_grads;
+
+/* Per-call counters written by the render kernels (device memory, 8 x uint64): the units of the roofline model. */
+enum { T2N_STAT_EVALUATED = 0,   /* V: in-box (and z-gated) samples that read the density factors */
+       T2N_STAT_APPEARANCE = 1,  /* A: samples with weight > weight_thres that read the appearance factors */
+       T2N_STAT_RAYS = 2,
+       T2N_STAT_OVERFLOW = 3,    /* must stay 0 */
+       T2N_STAT_COUNT = 8 };
+
+const char* t2n_last_error(void);
+int t2n_version(void);
+
+/* ---- field lifetime: replaces TensorVMSplit.__init__ containers + the implicit "weights are where ATen reads them" */
+int t2n_field_create(const t2n_field_desc* desc, t2n_field** out);
+int t2n_field_destroy(t2n_field* f);
+/* Re-read the reference-layout parameters into the internal channel-last / MFMA-packed device copy. Call after
+ * construction, after load_state_dict, and after every optimiser step. Asynchronous on `stream`. */
+int t2n_field_upload(t2n_field* f, const t2n_field_params* p, t2n_stream stream);
+/* Update scalars only (step size, near/far, ...): TensorBase.update_stepSize (models/tensorBase.py:220-231). */
+int t2n_field_set_desc(t2n_field* f, const t2n_field_desc* desc);
+
+/* ---- a-1/a-2: get_ray_directions (dataLoader/ray_utils.py:24-42), normalisation (dataLoader/scene_gen.py:45),
+ *      get_rays (dataLoader/ray_utils.py:66-87) */
+int t2n_ray_directions(int H, int W, float fx, float fy, float cx, float cy, int normalize, float* dirs /*[H*W,3]*/,
+                       t2n_stream stream);
+int t2n_get_rays(const float* dirs /*[n,3]*/, int64_t n, const float* c2w_host /*[3 rows x 4] row-major, host*/,
+                 float* rays_o /*[n,3] or NULL*/, float* rays_d /*[n,3] or NULL*/, float* rays6 /*[n,6] or NULL*/,
+                 t2n_stream stream);
+/* fused: pixel -> [H*W,6] ray rows (ox,oy,oz,dx,dy,dz), SceneGen recipe (scene_gen.py:44-45,92-94) */
+int t2n_generate_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_host, float* rays6,
+                      t2n_stream stream);
+
+/* ---- a-16: TensorBase.filtering_rays(bbox_only=True) slab test (models/tensorBase.py:385-391) */
+int t2n_filter_rays_bbox(const t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, uint8_t* mask,
+                         t2n_stream stream);
+
+/* ---- stage entry points (mirrors of TensorVMSplit methods, used by the Python mirror and the stage parity tests)
+ * a-9 + a-10: compute_densityfeature (models/tensoRF.py:205-220) [+ feature2density (tensorBase.py:406-410)].
+ *   xyz_norm [n,3] normalised to [-1,1]; feat/sigma [n] (either may be NULL). */
+int t2n_density_at(const t2n_field* f, const float* xyz_norm, int64_t n, float* feat, float* sigma, t2n_stream stream);
+/* a-12 + a-13: compute_appfeature (models/tensoRF.py:223-239) and renderModule (models/tensorBase.py:29-33,88-109).
+ *   viewdirs [n,3] (SH head only, else NULL); app_feat [n,app_dim] and rgb [n,3] (either may be NULL).
+ *   workspace: t2n_shade_workspace_bytes(n). */
+size_t t2n_shade_workspace_bytes(int64_t n);
+int t2n_shade_at(const t2n_field* f, const float* xyz_norm, const float* viewdirs, int64_t n, float* app_feat, float* rgb,
+                 void* workspace, size_t workspace_bytes, t2n_stream stream);
+/* a-11: raw2alpha (models/tensorBase.py:19-26): sigma,dist [R,N] -> alpha, weights [R,N], bg [R] (any output NULL). */
+int t2n_raw2alpha(const float* sigma, const float* dist, int64_t n_rays, int n_samples, float* alpha, float* weights,
+                  float* bg, t2n_stream stream);
+
+/* ---- a-3/a-4: the render call. Replaces the chunk loop of OctreeRender_trilinear_fast (renderer.py:28-42) and
+ * TensorBase.forward (models/tensorBase.py:436-507) for ndc_ray=False, alphaMask=None.
+ *   rays      [n_rays, ray_stride] fp32 rows, first 6 = (o, d); the LAST channel feeds depth's background term (:505)
+ *   jitter    [n_rays] U[0,1) draws (required iff T2N_FLAG_TRAIN; the reference draws them on the CPU generator, :313-316)
+ *   rgb [n_rays,3], depth [n_rays]   required
+ *   weights, z_vals [n_rays, n_samples]   optional (NULL = not materialised; the reference always returns them)
+ *   stats     optional device uint64[T2N_STAT_COUNT], zeroed by the call
+ *   workspace caller scratch; the call splits n_rays into sub-launches that fit (see t2n_render_workspace_bytes).
+ */
+size_t t2n_render_workspace_bytes(int64_t rays_per_launch, int n_samples);
+int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
+                       const float* jitter, float* rgb, float* depth, float* weights, float* z_vals, uint64_t* stats,
+                       void* workspace, size_t workspace_bytes, t2n_stream stream);
+
+/* ---- a-15: backward of the render call w.r.t. all field parameters (what autograd derives in the reference,
+ * text2nerf_main.py:589). Requires the forward to have run with T2N_FLAG_KEEP_CTX as ONE launch on the same workspace,
+ * with weights and z_vals materialised. d_weights may be NULL. Gradients are ACCUMULATED into `g` (reference layouts). */
+int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
+                        const float* jitter, const float* weights, const float* z_vals, const float* d_rgb,
+                        const float* d_depth, const float* d_weights, const t2n_field_grads* g, void* workspace,
+                        size_t workspace_bytes, t2n_stream stream);
+
+/* ---- measurement hooks (bench.py): when enabled, each kernel launch of the render call is bracketed by HIP events on
+ * the launch stream. t2n_timing_read synchronises those events and returns accumulated milliseconds and launch counts
+ * per kernel since the last reset. Kernel ids: */
+enum { T2N_K_MARCH = 0, T2N_K_SHADE = 1, T2N_K_COMPOSITE = 2, T2N_K_UPLOAD = 3, T2N_K_BWD_MARCH = 4, T2N_K_BWD_SHADE = 5,
+       T2N_K_COUNT = 8 };
+int t2n_timing_enable(t2n_field* f, int on);
+int t2n_timing_read(t2n_field* f, double* ms /*[T2N_K_COUNT]*/, int64_t* launches /*[T2N_K_COUNT]*/, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2N_H_ */

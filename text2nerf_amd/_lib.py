@@ -1,0 +1,114 @@
+"""ctypes binding of libt2n_hip.so (include/t2n.h). No CPU fallback: a missing library or a failing call raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libt2n_hip.so")
+
+T2N_STAT_COUNT = 8
+T2N_K_COUNT = 8
+KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_shade", "_6", "_7")
+STAT_EVALUATED, STAT_APPEARANCE, STAT_RAYS, STAT_OVERFLOW = 0, 1, 2, 3
+
+FLAG_TRAIN, FLAG_ADD_BG, FLAG_KEEP_CTX = 1, 2, 4
+SHADE_IDS = {"MLP_Fea_noview": 0, "SH": 1, "RGB": 2}
+ACT_IDS = {"softplus": 0, "relu": 1}
+
+
+class T2NError(RuntimeError):
+    pass
+
+
+class FieldDesc(C.Structure):
+    _fields_ = [("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3), ("inv_aabb_size", C.c_float * 3),
+                ("grid", C.c_int32 * 3), ("density_n_comp", C.c_int32), ("app_n_comp", C.c_int32),
+                ("app_dim", C.c_int32), ("shading", C.c_int32), ("fea_pe", C.c_int32), ("feature_c", C.c_int32),
+                ("act", C.c_int32), ("density_shift", C.c_float), ("distance_scale", C.c_float),
+                ("weight_thres", C.c_float), ("step_size", C.c_float), ("near", C.c_float), ("far", C.c_float),
+                ("z_gate", C.c_float)]
+
+
+class FieldParams(C.Structure):
+    _fields_ = [("density_plane", C.c_void_p * 3), ("density_line", C.c_void_p * 3), ("app_plane", C.c_void_p * 3),
+                ("app_line", C.c_void_p * 3), ("basis_weight", C.c_void_p),
+                ("mlp_w0", C.c_void_p), ("mlp_b0", C.c_void_p), ("mlp_w1", C.c_void_p), ("mlp_b1", C.c_void_p),
+                ("mlp_w2", C.c_void_p), ("mlp_b2", C.c_void_p)]
+
+
+FieldGrads = FieldParams  # same shape: pointers in reference layouts
+
+_lib = None
+_lock = threading.Lock()
+
+# name -> (restype, argtypes); also the list the symbol test checks against include/t2n.h
+SIGNATURES = {
+    "t2n_last_error": (C.c_char_p, []),
+    "t2n_version": (C.c_int, []),
+    "t2n_field_create": (C.c_int, [C.POINTER(FieldDesc), C.POINTER(C.c_void_p)]),
+    "t2n_field_destroy": (C.c_int, [C.c_void_p]),
+    "t2n_field_upload": (C.c_int, [C.c_void_p, C.POINTER(FieldParams), C.c_void_p]),
+    "t2n_field_set_desc": (C.c_int, [C.c_void_p, C.POINTER(FieldDesc)]),
+    "t2n_ray_directions": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                                     C.c_void_p, C.c_void_p]),
+    "t2n_get_rays": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p]),
+    "t2n_generate_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
+    "t2n_filter_rays_bbox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "t2n_density_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2n_shade_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "t2n_shade_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_size_t, C.c_void_p]),
+    "t2n_raw2alpha": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p]),
+    "t2n_render_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "t2n_render_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
+    "t2n_render_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.POINTER(FieldGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "t2n_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "t2n_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
+}
+
+
+def load(path: str = LIB_PATH):
+    """dlopen the C-ABI library (after torch, so both share one HIP runtime) and bind every declared symbol."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(path):
+            raise T2NError(f"{path} is missing: build it with `python -m text2nerf_amd.build` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            import torch  # noqa: F401  (loads torch's libamdhip64 first; SONAME-matched by ours)
+        except Exception:  # pragma: no cover
+            pass
+        lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().t2n_last_error()
+        raise T2NError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

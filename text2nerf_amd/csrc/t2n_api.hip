@@ -1,0 +1,333 @@
+// extern "C" surface of libt2n_hip.so: field lifetime, parameter upload (reference layout -> channel-last), ray
+// generation, the render call orchestration (march -> shade -> composite per sub-launch) and the timing hooks.
+#include <stdarg.h>
+
+#include "t2n_device.h"
+
+namespace t2n {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return T2N_ERR_HIP;
+}
+
+void timing_begin(t2n_field* f, int k, hipStream_t s) {
+    if (!f->timing) return;
+    TimingSlot& t = f->slots[k];
+    if (t.used >= 64) return;
+    if (!t.start[t.used]) {
+        (void)hipEventCreate(&t.start[t.used]);
+        (void)hipEventCreate(&t.stop[t.used]);
+    }
+    (void)hipEventRecord(t.start[t.used], s);
+}
+void timing_end(t2n_field* f, int k, hipStream_t s) {
+    if (!f->timing) return;
+    TimingSlot& t = f->slots[k];
+    if (t.used >= 64) return;
+    (void)hipEventRecord(t.stop[t.used], s);
+    t.used++;
+}
+
+static void timing_flush(t2n_field* f) {
+    for (int k = 0; k < T2N_K_COUNT; ++k) {
+        TimingSlot& t = f->slots[k];
+        for (int i = 0; i < t.used; ++i) {
+            (void)hipEventSynchronize(t.stop[i]);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, t.start[i], t.stop[i]) == hipSuccess) { t.ms += ms; t.launches++; }
+        }
+        t.used = 0;
+    }
+}
+
+// [1,C,H,W] -> [H][W][C]   (lines: W == 1)
+__global__ __launch_bounds__(256) void k_relayout(const float* __restrict__ src, float* __restrict__ dst, int C, long long HW) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= HW * C) return;
+    const long long pix = t / C;
+    const int c = (int)(t - pix * C);
+    dst[t] = src[(long long)c * HW + pix];
+}
+
+static int relayout_one(const float* src, float** dst, int C, long long HW, hipStream_t s) {
+    if (!src) { set_error("t2n_field_upload: NULL factor tensor"); return T2N_ERR_INVALID; }
+    if (!*dst) T2N_HIP(hipMalloc((void**)dst, (size_t)HW * C * sizeof(float)));
+    const long long n = HW * C;
+    hipLaunchKernelGGL(k_relayout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, *dst, C, HW);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+int launch_relayout(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
+    const int* g = f->desc.grid;
+    for (int k = 0; k < 3; ++k) {
+        const long long HW = (long long)g[mat1(k)] * g[mat0(k)];
+        const long long L = g[vecm(k)];
+        int rc;
+        if ((rc = relayout_one(p->density_plane[k], &f->buf_den_plane[k], f->desc.density_n_comp, HW, s))) return rc;
+        if ((rc = relayout_one(p->density_line[k], &f->buf_den_line[k], f->desc.density_n_comp, L, s))) return rc;
+        if ((rc = relayout_one(p->app_plane[k], &f->buf_app_plane[k], f->desc.app_n_comp, HW, s))) return rc;
+        if ((rc = relayout_one(p->app_line[k], &f->buf_app_line[k], f->desc.app_n_comp, L, s))) return rc;
+        f->dev.den.plane[k] = f->buf_den_plane[k]; f->dev.den.line[k] = f->buf_den_line[k];
+        f->dev.app.plane[k] = f->buf_app_plane[k]; f->dev.app.line[k] = f->buf_app_line[k];
+    }
+    return T2N_OK;
+}
+
+static int apply_desc(t2n_field* f, const t2n_field_desc* d) {
+    if (d->density_n_comp != 16 || d->app_n_comp != 48) {
+        set_error("unsupported n_comp: density %d (need 16), appearance %d (need 48)", d->density_n_comp, d->app_n_comp);
+        return T2N_ERR_UNSUPPORTED;
+    }
+    if (d->shading == T2N_SHADE_MLP_FEA_NOVIEW) {
+        if (d->app_dim != 27 || d->fea_pe != 6 || d->feature_c != 128) {
+            set_error("unsupported MLP_Fea_noview shape: app_dim %d fea_pe %d featureC %d (need 27/6/128)", d->app_dim, d->fea_pe, d->feature_c);
+            return T2N_ERR_UNSUPPORTED;
+        }
+    } else if (d->shading == T2N_SHADE_SH) {
+        if (d->app_dim != 27) { set_error("SH head needs app_dim 27"); return T2N_ERR_UNSUPPORTED; }
+    } else if (d->shading == T2N_SHADE_RGB) {
+        if (d->app_dim != 3) { set_error("RGB head needs app_dim 3"); return T2N_ERR_UNSUPPORTED; }
+    } else {
+        set_error("unsupported shading head %d", d->shading);
+        return T2N_ERR_UNSUPPORTED;
+    }
+    for (int k = 0; k < 3; ++k)
+        if (d->grid[k] < 2 || d->grid[k] > 4096) { set_error("grid[%d]=%d out of range [2,4096]", k, d->grid[k]); return T2N_ERR_INVALID; }
+    f->desc = *d;
+    FieldDev& D = f->dev;
+    for (int k = 0; k < 3; ++k) {
+        D.aabb0[k] = d->aabb_min[k]; D.aabb1[k] = d->aabb_max[k]; D.inv[k] = d->inv_aabb_size[k];
+        D.den.W[k] = D.app.W[k] = d->grid[mat0(k)];
+        D.den.H[k] = D.app.H[k] = d->grid[mat1(k)];
+        D.den.L[k] = D.app.L[k] = d->grid[vecm(k)];
+    }
+    D.den.C = d->density_n_comp; D.app.C = d->app_n_comp;
+    D.shift = d->density_shift; D.dscale = d->distance_scale; D.thres = d->weight_thres; D.step = d->step_size;
+    D.near = d->near; D.far = d->far; D.zgate = d->z_gate; D.act = d->act; D.shading = d->shading; D.app_dim = d->app_dim;
+    return T2N_OK;
+}
+
+// ---- ray generation ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ray_dirs(int H, int W, float fx, float fy, float cx, float cy, int normalize, float* dirs) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)H * W) return;
+    const int y = (int)(t / W), x = (int)(t - (long long)y * W);
+    const float i = (float)x + 0.5f, j = (float)y + 0.5f;
+    float dx = (i - cx) / fx, dy = (j - cy) / fy, dz = 1.f;
+    if (normalize) {
+        const float n = sqrtf((dx * dx + dy * dy) + dz * dz);
+        dx = dx / n; dy = dy / n; dz = dz / n;
+    }
+    dirs[t * 3] = dx; dirs[t * 3 + 1] = dy; dirs[t * 3 + 2] = dz;
+}
+
+struct Pose { float m[12]; };
+
+__device__ __forceinline__ void rotate(const Pose& P, float dx, float dy, float dz, float& rx, float& ry, float& rz) {
+    // rays_d = directions @ c2w[:3,:3].T  (dataLoader/ray_utils.py:79)
+    rx = fmaf(dz, P.m[2], fmaf(dy, P.m[1], dx * P.m[0]));
+    ry = fmaf(dz, P.m[6], fmaf(dy, P.m[5], dx * P.m[4]));
+    rz = fmaf(dz, P.m[10], fmaf(dy, P.m[9], dx * P.m[8]));
+}
+
+__global__ __launch_bounds__(256) void k_get_rays(const float* __restrict__ dirs, long long n, const Pose P, float* ro, float* rd, float* r6) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float rx, ry, rz;
+    rotate(P, dirs[t * 3], dirs[t * 3 + 1], dirs[t * 3 + 2], rx, ry, rz);
+    if (ro) { ro[t * 3] = P.m[3]; ro[t * 3 + 1] = P.m[7]; ro[t * 3 + 2] = P.m[11]; }
+    if (rd) { rd[t * 3] = rx; rd[t * 3 + 1] = ry; rd[t * 3 + 2] = rz; }
+    if (r6) { r6[t * 6] = P.m[3]; r6[t * 6 + 1] = P.m[7]; r6[t * 6 + 2] = P.m[11]; r6[t * 6 + 3] = rx; r6[t * 6 + 4] = ry; r6[t * 6 + 5] = rz; }
+}
+
+__global__ __launch_bounds__(256) void k_generate_rays(int H, int W, float fx, float fy, float cx, float cy, const Pose P, float* r6) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)H * W) return;
+    const int y = (int)(t / W), x = (int)(t - (long long)y * W);
+    const float i = (float)x + 0.5f, j = (float)y + 0.5f;
+    float dx = (i - cx) / fx, dy = (j - cy) / fy, dz = 1.f;
+    const float n = sqrtf((dx * dx + dy * dy) + dz * dz);
+    dx = dx / n; dy = dy / n; dz = dz / n;
+    float rx, ry, rz;
+    rotate(P, dx, dy, dz, rx, ry, rz);
+    r6[t * 6] = P.m[3]; r6[t * 6 + 1] = P.m[7]; r6[t * 6 + 2] = P.m[11]; r6[t * 6 + 3] = rx; r6[t * 6 + 4] = ry; r6[t * 6 + 5] = rz;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Carve { size_t acc, ray_app, counter, app_pos, app_ray, app_rgb, total; };
+static Carve carve(int64_t rays, int n_samples) {
+    Carve c;
+    const size_t cap = (size_t)rays * (size_t)n_samples;
+    size_t o = 0;
+    c.counter = o; o = align_up(o + 256, 256);
+    c.acc = o; o = align_up(o + (size_t)rays * 4, 256);
+    c.ray_app = o; o = align_up(o + (size_t)rays * 8, 256);
+    c.app_pos = o; o = align_up(o + cap * 16, 256);
+    c.app_rgb = o; o = align_up(o + cap * 16, 256);
+    c.app_ray = o; o = align_up(o + cap * 4, 256);
+    c.total = o;
+    return c;
+}
+
+}  // namespace t2n
+
+using namespace t2n;
+
+extern "C" const char* t2n_last_error(void) { return g_err; }
+extern "C" int t2n_version(void) { return 100; }
+
+extern "C" int t2n_field_create(const t2n_field_desc* desc, t2n_field** out) {
+    if (!desc || !out) { set_error("t2n_field_create: NULL argument"); return T2N_ERR_INVALID; }
+    t2n_field* f = new t2n_field();
+    memset(&f->dev, 0, sizeof(f->dev));
+    for (int k = 0; k < T2N_K_COUNT; ++k) { memset(f->slots[k].start, 0, sizeof(f->slots[k].start)); memset(f->slots[k].stop, 0, sizeof(f->slots[k].stop)); }
+    const int rc = apply_desc(f, desc);
+    if (rc) { delete f; return rc; }
+    *out = f;
+    return T2N_OK;
+}
+
+extern "C" int t2n_field_set_desc(t2n_field* f, const t2n_field_desc* d) {
+    if (!f || !d) { set_error("t2n_field_set_desc: NULL argument"); return T2N_ERR_INVALID; }
+    if (f->uploaded && (d->grid[0] != f->desc.grid[0] || d->grid[1] != f->desc.grid[1] || d->grid[2] != f->desc.grid[2] ||
+                        d->density_n_comp != f->desc.density_n_comp || d->app_n_comp != f->desc.app_n_comp)) {
+        set_error("t2n_field_set_desc: grid/n_comp change needs a new field handle");
+        return T2N_ERR_STATE;
+    }
+    return apply_desc(f, d);
+}
+
+extern "C" int t2n_field_destroy(t2n_field* f) {
+    if (!f) return T2N_OK;
+    for (int k = 0; k < 3; ++k) {
+        if (f->buf_den_plane[k]) (void)hipFree(f->buf_den_plane[k]);
+        if (f->buf_den_line[k]) (void)hipFree(f->buf_den_line[k]);
+        if (f->buf_app_plane[k]) (void)hipFree(f->buf_app_plane[k]);
+        if (f->buf_app_line[k]) (void)hipFree(f->buf_app_line[k]);
+    }
+    if (f->buf_mlp) (void)hipFree(f->buf_mlp);
+    for (int k = 0; k < T2N_K_COUNT; ++k)
+        for (int i = 0; i < 64; ++i) {
+            if (f->slots[k].start[i]) (void)hipEventDestroy(f->slots[k].start[i]);
+            if (f->slots[k].stop[i]) (void)hipEventDestroy(f->slots[k].stop[i]);
+        }
+    delete f;
+    return T2N_OK;
+}
+
+extern "C" int t2n_field_upload(t2n_field* f, const t2n_field_params* p, t2n_stream stream) {
+    if (!f || !p) { set_error("t2n_field_upload: NULL argument"); return T2N_ERR_INVALID; }
+    if (!p->basis_weight) { set_error("t2n_field_upload: NULL basis_weight"); return T2N_ERR_INVALID; }
+    if (f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW && (!p->mlp_w0 || !p->mlp_b0 || !p->mlp_w1 || !p->mlp_b1 || !p->mlp_w2 || !p->mlp_b2)) {
+        set_error("t2n_field_upload: MLP head needs all six renderModule tensors");
+        return T2N_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    timing_begin(f, T2N_K_UPLOAD, s);
+    int rc = launch_relayout(f, p, s);
+    if (!rc) rc = launch_pack_mlp(f, p, s);
+    timing_end(f, T2N_K_UPLOAD, s);
+    if (rc) return rc;
+    f->uploaded = true;
+    return T2N_OK;
+}
+
+extern "C" int t2n_ray_directions(int H, int W, float fx, float fy, float cx, float cy, int normalize, float* dirs, t2n_stream stream) {
+    if (H <= 0 || W <= 0 || !dirs) { set_error("t2n_ray_directions: bad argument"); return T2N_ERR_INVALID; }
+    const long long n = (long long)H * W;
+    hipLaunchKernelGGL(k_ray_dirs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, H, W, fx, fy, cx, cy, normalize, dirs);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_get_rays(const float* dirs, int64_t n, const float* c2w_host, float* rays_o, float* rays_d, float* rays6, t2n_stream stream) {
+    if (!dirs || !c2w_host || n < 0) { set_error("t2n_get_rays: bad argument"); return T2N_ERR_INVALID; }
+    if (n == 0) return T2N_OK;
+    Pose P;
+    memcpy(P.m, c2w_host, sizeof(P.m));
+    hipLaunchKernelGGL(k_get_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dirs, (long long)n, P, rays_o, rays_d, rays6);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_generate_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_host, float* rays6, t2n_stream stream) {
+    if (H <= 0 || W <= 0 || !c2w_host || !rays6) { set_error("t2n_generate_rays: bad argument"); return T2N_ERR_INVALID; }
+    Pose P;
+    memcpy(P.m, c2w_host, sizeof(P.m));
+    const long long n = (long long)H * W;
+    hipLaunchKernelGGL(k_generate_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, H, W, fx, fy, cx, cy, P, rays6);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" size_t t2n_render_workspace_bytes(int64_t rays_per_launch, int n_samples) {
+    if (rays_per_launch <= 0 || n_samples <= 0) return 0;
+    return carve(rays_per_launch, n_samples).total;
+}
+
+extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
+                                  const float* jitter, float* rgb, float* depth, float* weights, float* z_vals, uint64_t* stats,
+                                  void* workspace, size_t workspace_bytes, t2n_stream stream) {
+    if (!f || !rays || !rgb || !depth || !workspace || n_rays < 0 || ray_stride < 6) { set_error("t2n_render_forward: bad argument"); return T2N_ERR_INVALID; }
+    if (!f->uploaded) { set_error("t2n_render_forward: field has no uploaded parameters"); return T2N_ERR_STATE; }
+    if (n_samples <= 0 || n_samples > 2048) { set_error("t2n_render_forward: n_samples %d outside [1,2048]", n_samples); return T2N_ERR_UNSUPPORTED; }
+    if ((flags & T2N_FLAG_TRAIN) && !jitter) { set_error("t2n_render_forward: train mode needs the jitter draws"); return T2N_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    if (stats) T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s));
+    if (n_rays == 0) return T2N_OK;
+    // largest sub-launch whose worst case (every sample an appearance sample) fits the workspace
+    int64_t per = n_rays;
+    while (per > 1 && carve(per, n_samples).total > workspace_bytes) per = (per + 1) / 2;
+    if (carve(per, n_samples).total > workspace_bytes) { set_error("t2n_render_forward: workspace %zu B too small", workspace_bytes); return T2N_ERR_WORKSPACE; }
+    if ((flags & T2N_FLAG_KEEP_CTX) && per < n_rays) { set_error("t2n_render_forward: KEEP_CTX needs the whole call in one launch"); return T2N_ERR_WORKSPACE; }
+    if ((uint64_t)per * (uint64_t)n_samples > 0xffffffffull) per = (int64_t)(0xffffffffull / (uint64_t)n_samples);
+    char* ws = (char*)workspace;
+    for (int64_t off = 0; off < n_rays; off += per) {
+        const int64_t cnt = (n_rays - off) < per ? (n_rays - off) : per;
+        const Carve c = carve(per, n_samples);
+        RenderLaunch L;
+        L.rays = rays + off * ray_stride; L.n_rays = cnt; L.ray_stride = ray_stride; L.n_samples = n_samples; L.flags = flags;
+        L.jitter = jitter ? jitter + off : nullptr;
+        L.rgb = rgb + off * 3; L.depth = depth + off;
+        L.weights = weights ? weights + off * n_samples : nullptr;
+        L.z_vals = z_vals ? z_vals + off * n_samples : nullptr;
+        L.stats = stats;
+        L.counter = (unsigned*)(ws + c.counter); L.acc = (float*)(ws + c.acc); L.ray_app = (int2*)(ws + c.ray_app);
+        L.app_pos = (float4*)(ws + c.app_pos); L.app_rgb = (float4*)(ws + c.app_rgb); L.app_ray = (int*)(ws + c.app_ray);
+        L.cap = (unsigned)((uint64_t)per * (uint64_t)n_samples);
+        T2N_HIP(hipMemsetAsync(L.counter, 0, 256, s));
+        int rc;
+        if ((rc = launch_march(f, L, s))) return rc;
+        if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counter, L.cap, L.app_rgb, nullptr, s))) return rc;
+        if ((rc = launch_composite(f, L, s))) return rc;
+    }
+    return T2N_OK;
+}
+
+extern "C" int t2n_timing_enable(t2n_field* f, int on) {
+    if (!f) return T2N_ERR_INVALID;
+    f->timing = on ? 1 : 0;
+    return T2N_OK;
+}
+
+extern "C" int t2n_timing_read(t2n_field* f, double* ms, int64_t* launches, int reset) {
+    if (!f || !ms || !launches) { set_error("t2n_timing_read: NULL argument"); return T2N_ERR_INVALID; }
+    timing_flush(f);
+    for (int k = 0; k < T2N_K_COUNT; ++k) {
+        ms[k] = f->slots[k].ms; launches[k] = f->slots[k].launches;
+        if (reset) { f->slots[k].ms = 0.0; f->slots[k].launches = 0; }
+    }
+    return T2N_OK;
+}

@@ -1,0 +1,185 @@
+// Device-side building blocks shared by the march / shade / backward kernels (gfx950, wave64).
+// All arithmetic that decides WHICH samples exist (t_min, z, point, box test, z gate, normalisation) is written as
+// separately rounded fp32 operations in the reference's order (this library is compiled with -ffp-contract=off);
+// FMAs appear only where written explicitly.
+#pragma once
+#include "t2n_internal.h"
+
+namespace t2n {
+
+__device__ __forceinline__ float dpp_quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+}
+
+// Sum over the LPS consecutive lanes that share one sample (LPS = channels/4).
+template <int LPS>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (LPS >= 2) v += dpp_quad_xor1(v);
+    if constexpr (LPS >= 4) v += dpp_quad_xor2(v);
+    if constexpr (LPS >= 8) v += __shfl_xor(v, 4);
+    if constexpr (LPS >= 16) v += __shfl_xor(v, 8);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Inclusive product scan over the 64 lanes of a wave (lane 0 first).
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o);
+        if (lane >= o) v *= t;
+    }
+    return v;
+}
+
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, tmin, last;
+};
+
+// models/tensorBase.py:308-311
+__device__ __forceinline__ float ray_tmin(const FieldDev& F, float ox, float oy, float oz, float dx, float dy, float dz) {
+    const float vx = dx == 0.f ? 1e-6f : dx, vy = dy == 0.f ? 1e-6f : dy, vz = dz == 0.f ? 1e-6f : dz;
+    const float ax = (F.aabb1[0] - ox) / vx, bx = (F.aabb0[0] - ox) / vx;
+    const float ay = (F.aabb1[1] - oy) / vy, by = (F.aabb0[1] - oy) / vy;
+    const float az = (F.aabb1[2] - oz) / vz, bz = (F.aabb0[2] - oz) / vz;
+    float t = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    return fminf(fmaxf(t, F.near), F.far);
+}
+
+__device__ __forceinline__ Ray load_ray(const FieldDev& F, const float* __restrict__ rp, int stride) {
+    Ray r;
+    r.ox = rp[0]; r.oy = rp[1]; r.oz = rp[2]; r.dx = rp[3]; r.dy = rp[4]; r.dz = rp[5];
+    r.last = rp[stride - 1];
+    r.tmin = ray_tmin(F, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz);
+    return r;
+}
+
+// models/tensorBase.py:313-318: z_i = t_min + stepSize * (i [+ u])
+template <bool TRAIN>
+__device__ __forceinline__ float sample_z(const FieldDev& F, const Ray& r, int i, float u) {
+    float rng = (float)i;
+    if (TRAIN) rng = rng + u;
+    const float st = F.step * rng;
+    return r.tmin + st;
+}
+
+// Point, box mask (:320-321), eval z gate (:459-462), normalisation (:245-246). Returns validity.
+template <bool TRAIN>
+__device__ __forceinline__ bool sample_point(const FieldDev& F, const Ray& r, float z, float& xn, float& yn, float& zn) {
+    const float mx = r.dx * z, my = r.dy * z, mz = r.dz * z;
+    const float px = r.ox + mx, py = r.oy + my, pz = r.oz + mz;
+    bool out = (F.aabb0[0] > px) | (px > F.aabb1[0]) | (F.aabb0[1] > py) | (py > F.aabb1[1]) | (F.aabb0[2] > pz) |
+               (pz > F.aabb1[2]);
+    bool ok = !out;
+    if (!TRAIN) ok = ok & (pz > F.zgate);
+    const float sx = px - F.aabb0[0], sy = py - F.aabb0[1], sz = pz - F.aabb0[2];
+    const float tx = sx * F.inv[0], ty = sy * F.inv[1], tz = sz * F.inv[2];
+    xn = tx - 1.f; yn = ty - 1.f; zn = tz - 1.f;
+    return ok;
+}
+
+// ATen grid_sampler_2d (bilinear, zeros, align_corners=True) restated for one axis:
+// unnormalise ((g+1)/2)*(size-1), corner = floor, weights by subtraction, out-of-range taps weigh 0.
+struct Axis {
+    int i0, i1;     // clamped tap indices
+    float w0, w1;   // weights (0 for out-of-range taps)
+};
+__device__ __forceinline__ Axis axis_taps(float g, int size) {
+    const float h = (g + 1.f) / 2.f;
+    const float ix = h * (float)(size - 1);
+    const float f0 = floorf(ix);
+    const float w1 = ix - f0;
+    const float w0 = 1.f - w1;
+    const float hi = (float)(size - 1);
+    Axis a;
+    const bool ok0 = (f0 >= 0.f) & (f0 <= hi);
+    const bool ok1 = (f0 >= -1.f) & (f0 <= hi - 1.f);
+    const float fc = fminf(fmaxf(f0, -1.f), hi);
+    const int i = (int)fc;
+    a.i0 = max(i, 0);
+    a.i1 = min(i + 1, size - 1);
+    a.w0 = ok0 ? w0 : 0.f;
+    a.w1 = ok1 ? w1 : 0.f;
+    return a;
+}
+
+__device__ __forceinline__ float4 f4_mul(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 f4_fma(float4 a, float s, float4 c) {
+    return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
+}
+
+// One channel-quad q of plane k's bilinear value and line k's linear value at normalised point (xn,yn,zn).
+// CQ = channels/4 (float4 per tap).
+struct QuadTaps {
+    float4 nw, ne, sw, se, l0, l1;
+    float wnw, wne, wsw, wse, wl0, wl1;
+};
+
+template <int K>
+__device__ __forceinline__ void plane_line_coords(const float xn, const float yn, const float zn, float& gx, float& gy,
+                                                  float& gv) {
+    // matMode = [[0,1],[0,2],[1,2]], vecMode = [2,1,0]
+    if constexpr (K == 0) { gx = xn; gy = yn; gv = zn; }
+    if constexpr (K == 1) { gx = xn; gy = zn; gv = yn; }
+    if constexpr (K == 2) { gx = yn; gy = zn; gv = xn; }
+}
+
+template <int K>
+__device__ __forceinline__ void issue_taps(const FactorSet& S, int CQ, int q, float xn, float yn, float zn, QuadTaps& t) {
+    float gx, gy, gv;
+    plane_line_coords<K>(xn, yn, zn, gx, gy, gv);
+    const Axis ax = axis_taps(gx, S.W[K]);
+    const Axis ay = axis_taps(gy, S.H[K]);
+    const Axis al = axis_taps(gv, S.L[K]);
+    const float4* __restrict__ P = reinterpret_cast<const float4*>(S.plane[K]);
+    const float4* __restrict__ Ln = reinterpret_cast<const float4*>(S.line[K]);
+    const int W = S.W[K];
+    const size_t r0 = (size_t)ay.i0 * W, r1 = (size_t)ay.i1 * W;
+    t.nw = P[(r0 + ax.i0) * CQ + q];
+    t.ne = P[(r0 + ax.i1) * CQ + q];
+    t.sw = P[(r1 + ax.i0) * CQ + q];
+    t.se = P[(r1 + ax.i1) * CQ + q];
+    t.l0 = Ln[(size_t)al.i0 * CQ + q];
+    t.l1 = Ln[(size_t)al.i1 * CQ + q];
+    t.wnw = ay.w0 * ax.w0; t.wne = ay.w0 * ax.w1; t.wsw = ay.w1 * ax.w0; t.wse = ay.w1 * ax.w1;
+    t.wl0 = al.w0; t.wl1 = al.w1;
+}
+
+__device__ __forceinline__ float4 taps_plane(const QuadTaps& t) {
+    float4 v = f4_mul(t.nw, t.wnw);
+    v = f4_fma(t.ne, t.wne, v);
+    v = f4_fma(t.sw, t.wsw, v);
+    v = f4_fma(t.se, t.wse, v);
+    return v;
+}
+__device__ __forceinline__ float4 taps_line(const QuadTaps& t) {
+    float4 v = f4_mul(t.l0, t.wl0);
+    v = f4_fma(t.l1, t.wl1, v);
+    return v;
+}
+
+// feature2density (models/tensorBase.py:406-410): softplus(beta=1, threshold=20) of feat+shift, or relu(feat).
+__device__ __forceinline__ float feature2density(const FieldDev& F, float feat) {
+    if (F.act == T2N_ACT_RELU) return fmaxf(feat, 0.f);
+    const float x = feat + F.shift;
+    return x > 20.f ? x : log1pf(expf(x));
+}
+
+// XCD-aware block -> logical tile map: the dispatcher places block b on XCD b % 8; give every XCD a contiguous run of
+// logical tiles so neighbouring rays (which read neighbouring texels) share one L2. Bijective for any nblocks.
+__device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned nblocks) {
+    const unsigned xcd = b & 7u, j = b >> 3;
+    const unsigned q = nblocks >> 3, rem = nblocks & 7u;
+    const unsigned start = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    return start + j;
+}
+
+}  // namespace t2n

@@ -1,0 +1,94 @@
+// Internal declarations shared by the translation units of libt2n_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/t2n.h"
+
+namespace t2n {
+
+constexpr int kWave = 64;
+constexpr int kMaxSamples = 8192;      // LDS window: 2 floats per sample per wave
+constexpr int kAppDimMax = 32;
+
+// matMode / vecMode of models/tensorBase.py:190-191
+__host__ __device__ constexpr int mat0(int k) { return k == 2 ? 1 : 0; }
+__host__ __device__ constexpr int mat1(int k) { return k == 0 ? 1 : 2; }
+__host__ __device__ constexpr int vecm(int k) { return 2 - k; }
+
+// Internal (channel-last) view of one VM factor set. plane k: [H=grid[mat1]][W=grid[mat0]][C]; line k: [L=grid[vec]][C].
+struct FactorSet {
+    const float* plane[3];
+    const float* line[3];
+    int W[3], H[3], L[3];
+    int C;
+};
+
+struct FieldDev {
+    FactorSet den, app;
+    float aabb0[3], aabb1[3], inv[3];
+    float shift, dscale, thres, step, near, far, zgate;
+    int act, shading, app_dim;
+    // MFMA-packed operands (see t2n_shade.hip for the layout)
+    const float* basisA;   // [72][64]
+    const float* w0A;      // [196][4][64]
+    const float* w1A;      // [65][4][64]
+    const float* w2A;      // [65][64]
+};
+
+struct TimingSlot {
+    hipEvent_t start[64], stop[64];
+    int used = 0;
+    double ms = 0.0;
+    int64_t launches = 0;
+};
+
+}  // namespace t2n
+
+struct t2n_field {
+    t2n_field_desc desc;
+    t2n::FieldDev dev;
+    // owned device buffers
+    float* buf_den_plane[3] = {nullptr, nullptr, nullptr};
+    float* buf_den_line[3] = {nullptr, nullptr, nullptr};
+    float* buf_app_plane[3] = {nullptr, nullptr, nullptr};
+    float* buf_app_line[3] = {nullptr, nullptr, nullptr};
+    float* buf_mlp = nullptr;  // basisA | w0A | w1A | w2A
+    bool uploaded = false;
+    int timing = 0;
+    t2n::TimingSlot slots[T2N_K_COUNT];
+};
+
+namespace t2n {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define T2N_HIP(call)                                        \
+    do {                                                     \
+        hipError_t e__ = (call);                             \
+        if (e__ != hipSuccess) return t2n::hip_fail(e__, #call); \
+    } while (0)
+
+// timing helpers (t2n_api.hip)
+void timing_begin(t2n_field* f, int k, hipStream_t s);
+void timing_end(t2n_field* f, int k, hipStream_t s);
+
+// launchers implemented per translation unit
+int launch_relayout(t2n_field* f, const t2n_field_params* p, hipStream_t s);
+int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s);
+
+struct RenderLaunch {
+    const float* rays; int64_t n_rays; int ray_stride; int n_samples; uint32_t flags;
+    const float* jitter; float* rgb; float* depth; float* weights; float* z_vals; uint64_t* stats;
+    // workspace carve (one sub-launch)
+    float* acc; int2* ray_app; unsigned* counter; float4* app_pos; int* app_ray; float4* app_rgb; unsigned cap;
+};
+int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s);
+int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
+                      const unsigned* count_dev, unsigned count_max, float4* app_rgb, float* feat_out, hipStream_t s);
+int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s);
+
+}  // namespace t2n

@@ -1,0 +1,352 @@
+// Ray marching: sampling + density lookup + transmittance scan + appearance-sample compaction (K1), the per-ray
+// composite (K3), and the point-wise density / raw2alpha / ray-filter entry points.
+//
+// Replaces (reference, relative paths): models/tensorBase.py:304-323 (sample_ray), :448 (dists), :459-462 (z gate),
+// :245-246 (normalize_coord), models/tensoRF.py:205-220 (compute_densityfeature), models/tensorBase.py:406-410
+// (feature2density), :19-26 (raw2alpha), :477 (app mask), :494-505 (composite).
+//
+// K1 mapping (gfx950, wave64): one wave per ray, four waves per workgroup.
+//   pass A  64 samples per step, one lane each: exact box/z-gate test -> first/last valid sample of the ray (the mask is
+//           an interval because every coordinate is monotone in the sample index); writes z_vals when asked.
+//   pass B  16 samples per step, 4 lanes per sample: lane q of a sample loads channel quad q (16 B) of each of the
+//           4 plane taps + 2 line taps of the 3 factor pairs -> every tap is one contiguous 64-B read; bilinear / linear
+//           combine in registers, DPP quad reduction -> sigma into the wave's LDS window.
+//   pass C  64 samples per step: alpha, wave-level product scan for the transmittance (carry across steps), weights into
+//           the LDS window, acc/depth partial sums, appearance-sample count.
+//   pass D  one atomicAdd per ray reserves a contiguous, sample-ordered slice of the appearance list; ballot/prefix
+//           compaction writes (normalised point, weight) there.
+#include "t2n_device.h"
+
+namespace t2n {
+
+struct MarchArgs {
+    FieldDev F;
+    const float* rays; long long n_rays; int ray_stride; int n_samples; int npad;
+    const float* jitter;
+    float* depth; float* acc; float* weights; float* z_vals;
+    float4* app_pos; int* app_ray; int2* ray_app; unsigned* counter; unsigned cap;
+    unsigned long long* stats;
+    unsigned nblocks;
+};
+
+template <bool TRAIN, int DC>
+__global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LPS = DC / 4;          // lanes per sample
+    constexpr int SPW = kWave / LPS;     // samples per wave step in pass B
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    float* __restrict__ sig = smem + (size_t)wid * 2 * a.npad;
+    float* __restrict__ wts = sig + a.npad;
+    const FieldDev& F = a.F;
+
+    const long long r = (long long)xcd_tile(blockIdx.x, a.nblocks) * 4 + wid;
+    if (r >= a.n_rays) return;
+    const int N = a.n_samples;
+    const Ray ray = load_ray(F, a.rays + r * a.ray_stride, a.ray_stride);
+    const float u = TRAIN ? a.jitter[r] : 0.f;
+
+    // ---- pass A: validity interval (exact per-sample test), optional z_vals ------------------------------------
+    int first = N, last = -1;
+    unsigned nvalid = 0;
+    for (int base = 0; base < N; base += 64) {
+        const int i = base + lane;
+        bool ok = false;
+        if (i < N) {
+            const float z = sample_z<TRAIN>(F, ray, i, u);
+            float xn, yn, zn;
+            ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
+            if (a.z_vals) a.z_vals[r * N + i] = z;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m) {
+            if (first == N) first = base + (int)__ffsll((long long)m) - 1;
+            last = base + 63 - (int)__clzll((long long)m);
+            nvalid += (unsigned)__popcll(m);
+        }
+    }
+
+    float acc = 0.f, dep = 0.f;
+    unsigned napp = 0;
+    const int Lw = last - first + 1;   // window length (<= 0: empty ray)
+
+    if (Lw > 0) {
+        // ---- pass B: density -------------------------------------------------------------------------------------
+        const int q = lane & (LPS - 1);
+        const int sl = lane / LPS;
+        for (int base = 0; base < Lw; base += SPW) {
+            const int j = base + sl;
+            const int i = first + j;
+            float xn = 0.f, yn = 0.f, zn = 0.f;
+            bool ok = false;
+            if (j < Lw) {
+                const float z = sample_z<TRAIN>(F, ray, i, u);
+                ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
+            }
+            float part = 0.f;
+            if (ok) {
+                QuadTaps t0, t1, t2;
+                issue_taps<0>(F.den, LPS, q, xn, yn, zn, t0);
+                issue_taps<1>(F.den, LPS, q, xn, yn, zn, t1);
+                issue_taps<2>(F.den, LPS, q, xn, yn, zn, t2);
+                float4 p, l;
+                p = taps_plane(t0); l = taps_line(t0);
+                part = p.x * l.x; part = fmaf(p.y, l.y, part); part = fmaf(p.z, l.z, part); part = fmaf(p.w, l.w, part);
+                p = taps_plane(t1); l = taps_line(t1);
+                part = fmaf(p.x, l.x, part); part = fmaf(p.y, l.y, part); part = fmaf(p.z, l.z, part); part = fmaf(p.w, l.w, part);
+                p = taps_plane(t2); l = taps_line(t2);
+                part = fmaf(p.x, l.x, part); part = fmaf(p.y, l.y, part); part = fmaf(p.z, l.z, part); part = fmaf(p.w, l.w, part);
+            }
+            const float feat = group_sum<LPS>(part);
+            if (q == 0 && j < Lw) sig[j] = ok ? feature2density(F, feat) : 0.f;
+        }
+        // LDS window written by lanes of this wave only; a wave is in lock-step, but the compiler needs the fence.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- pass C: alpha, transmittance scan, weights ------------------------------------------------------------
+        float carry = 1.f;
+        for (int base = 0; base < Lw; base += 64) {
+            const int j = base + lane;
+            const int i = first + j;
+            float sg = 0.f, z = 0.f, dist = 0.f;
+            if (j < Lw) {
+                sg = sig[j];
+                z = sample_z<TRAIN>(F, ray, i, u);
+                if (i < N - 1) dist = sample_z<TRAIN>(F, ray, i + 1, u) - z;   // :448, last sample gets 0
+            }
+            const float d = dist * F.dscale;
+            const float nsd = (-sg) * d;
+            const float alpha = 1.f - expf(nsd);
+            const float f = (1.f - alpha) + 1e-10f;
+            const float incl = wave_scan_mul(f, lane);
+            float excl = __shfl_up(incl, 1);
+            if (lane == 0) excl = 1.f;
+            const float T = carry * excl;
+            const float w = alpha * T;
+            carry = carry * __shfl(incl, 63);
+            if (j < Lw) {
+                wts[j] = w;
+                acc += w;
+                dep = fmaf(w, z, dep);
+            }
+            napp += (unsigned)__popcll(__ballot((j < Lw) & (w > F.thres)));
+        }
+        acc = wave_sum(acc);
+        dep = wave_sum(dep);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- outputs per ray ---------------------------------------------------------------------------------------------
+    unsigned slot0 = 0;
+    if (lane == 0) {
+        if (napp) slot0 = atomicAdd(a.counter, napp);
+        a.ray_app[r] = make_int2((int)slot0, (int)napp);
+        a.acc[r] = acc;
+        a.depth[r] = dep + (1.f - acc) * ray.last;   // :504-505
+        if (a.stats) {
+            atomicAdd(&a.stats[T2N_STAT_EVALUATED], (unsigned long long)nvalid);
+            if (napp) atomicAdd(&a.stats[T2N_STAT_APPEARANCE], (unsigned long long)napp);
+            if (napp && slot0 + napp > a.cap) atomicAdd(&a.stats[T2N_STAT_OVERFLOW], 1ull);
+        }
+    }
+    slot0 = __shfl(slot0, 0);
+
+    if (a.weights) {
+        for (int base = 0; base < N; base += 64) {
+            const int i = base + lane;
+            if (i < N) {
+                const int j = i - first;
+                a.weights[r * N + i] = (j >= 0 && j < Lw) ? wts[j] : 0.f;
+            }
+        }
+    }
+
+    // ---- pass D: appearance list -------------------------------------------------------------------------------------
+    if (napp && slot0 + napp <= a.cap) {
+        unsigned run = 0;
+        for (int base = 0; base < Lw; base += 64) {
+            const int j = base + lane;
+            const float w = j < Lw ? wts[j] : 0.f;
+            const bool m = (j < Lw) & (w > F.thres);
+            const unsigned long long bal = __ballot(m);
+            if (m) {
+                const unsigned pre = (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+                const float z = sample_z<TRAIN>(F, ray, first + j, u);
+                float xn, yn, zn;
+                sample_point<TRAIN>(F, ray, z, xn, yn, zn);
+                const unsigned s = slot0 + run + pre;
+                a.app_pos[s] = make_float4(xn, yn, zn, w);
+                a.app_ray[s] = (int)r;
+            }
+            run += (unsigned)__popcll(bal);
+        }
+    }
+}
+
+// K3: per-ray composite of the shaded appearance samples, in sample order (models/tensorBase.py:494-501).
+struct CompositeArgs {
+    long long n_rays; const int2* ray_app; const float4* app_pos; const float4* app_rgb; const float* acc; float* rgb;
+    int add_bg;
+};
+__global__ __launch_bounds__(256) void k_composite(const CompositeArgs a) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_rays) return;
+    const int2 ra = a.ray_app[r];
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+    for (int k = 0; k < ra.y; ++k) {
+        const float w = a.app_pos[ra.x + k].w;
+        const float4 c = a.app_rgb[ra.x + k];
+        cr = fmaf(w, c.x, cr); cg = fmaf(w, c.y, cg); cb = fmaf(w, c.z, cb);
+    }
+    if (a.add_bg) {
+        const float bg = 1.f - a.acc[r];
+        cr += bg; cg += bg; cb += bg;
+    }
+    a.rgb[r * 3 + 0] = fminf(fmaxf(cr, 0.f), 1.f);
+    a.rgb[r * 3 + 1] = fminf(fmaxf(cg, 0.f), 1.f);
+    a.rgb[r * 3 + 2] = fminf(fmaxf(cb, 0.f), 1.f);
+}
+
+// Point-wise density: 4 lanes per point (same gather as pass B).
+template <int DC>
+__global__ __launch_bounds__(256) void k_density_at(const FieldDev F, const float* __restrict__ xyz, long long n,
+                                                    float* feat_out, float* sigma_out) {
+    constexpr int LPS = DC / 4;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long p = t / LPS;
+    const int q = (int)(t % LPS);
+    const bool ok = p < n;
+    float part = 0.f;
+    if (ok) {
+        const float xn = xyz[p * 3 + 0], yn = xyz[p * 3 + 1], zn = xyz[p * 3 + 2];
+        QuadTaps t0, t1, t2;
+        issue_taps<0>(F.den, LPS, q, xn, yn, zn, t0);
+        issue_taps<1>(F.den, LPS, q, xn, yn, zn, t1);
+        issue_taps<2>(F.den, LPS, q, xn, yn, zn, t2);
+        float4 pv, l;
+        pv = taps_plane(t0); l = taps_line(t0);
+        part = pv.x * l.x; part = fmaf(pv.y, l.y, part); part = fmaf(pv.z, l.z, part); part = fmaf(pv.w, l.w, part);
+        pv = taps_plane(t1); l = taps_line(t1);
+        part = fmaf(pv.x, l.x, part); part = fmaf(pv.y, l.y, part); part = fmaf(pv.z, l.z, part); part = fmaf(pv.w, l.w, part);
+        pv = taps_plane(t2); l = taps_line(t2);
+        part = fmaf(pv.x, l.x, part); part = fmaf(pv.y, l.y, part); part = fmaf(pv.z, l.z, part); part = fmaf(pv.w, l.w, part);
+    }
+    const float feat = group_sum<LPS>(part);
+    if (ok && q == 0) {
+        if (feat_out) feat_out[p] = feat;
+        if (sigma_out) sigma_out[p] = feature2density(F, feat);
+    }
+}
+
+// raw2alpha on explicit [R,N] tensors: one wave per ray.
+__global__ __launch_bounds__(256) void k_raw2alpha(const float* __restrict__ sigma, const float* __restrict__ dist,
+                                                   long long R, int N, float* alpha_o, float* w_o, float* bg_o) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float carry = 1.f;
+    for (int base = 0; base < N; base += 64) {
+        const int i = base + lane;
+        float sg = 0.f, d = 0.f;
+        if (i < N) { sg = sigma[r * N + i]; d = dist[r * N + i]; }
+        const float nsd = (-sg) * d;
+        const float alpha = 1.f - expf(nsd);
+        const float f = (1.f - alpha) + 1e-10f;
+        const float incl = wave_scan_mul(f, lane);
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.f;
+        const float T = carry * excl;
+        carry = carry * __shfl(incl, 63);
+        if (i < N) {
+            if (alpha_o) alpha_o[r * N + i] = alpha;
+            if (w_o) w_o[r * N + i] = alpha * T;
+        }
+    }
+    if (bg_o && lane == 0) bg_o[r] = carry;
+}
+
+// filtering_rays(bbox_only=True): models/tensorBase.py:385-391
+__global__ __launch_bounds__(256) void k_filter_bbox(const FieldDev F, const float* __restrict__ rays, long long n,
+                                                     int stride, uint8_t* mask) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float* rp = rays + r * stride;
+    const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5];
+    const float vx = dx == 0.f ? 1e-6f : dx, vy = dy == 0.f ? 1e-6f : dy, vz = dz == 0.f ? 1e-6f : dz;
+    const float ax = (F.aabb1[0] - ox) / vx, bx = (F.aabb0[0] - ox) / vx;
+    const float ay = (F.aabb1[1] - oy) / vy, by = (F.aabb0[1] - oy) / vy;
+    const float az = (F.aabb1[2] - oz) / vz, bz = (F.aabb0[2] - oz) / vz;
+    const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    mask[r] = tmax > tmin ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
+    MarchArgs a;
+    a.F = f->dev;
+    a.rays = L.rays; a.n_rays = L.n_rays; a.ray_stride = L.ray_stride; a.n_samples = L.n_samples;
+    a.npad = (L.n_samples + 63) & ~63;
+    a.jitter = L.jitter;
+    a.depth = L.depth; a.acc = L.acc; a.weights = L.weights; a.z_vals = L.z_vals;
+    a.app_pos = L.app_pos; a.app_ray = L.app_ray; a.ray_app = L.ray_app; a.counter = L.counter; a.cap = L.cap;
+    a.stats = (unsigned long long*)L.stats;
+    a.nblocks = (unsigned)((L.n_rays + 3) / 4);
+    const size_t lds = (size_t)4 * 2 * a.npad * sizeof(float);
+    const bool train = (L.flags & T2N_FLAG_TRAIN) != 0;
+    timing_begin(f, T2N_K_MARCH, s);
+    if (train) hipLaunchKernelGGL((k_march<true, 16>), dim3(a.nblocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((k_march<false, 16>), dim3(a.nblocks), dim3(256), lds, s, a);
+    timing_end(f, T2N_K_MARCH, s);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
+    CompositeArgs c;
+    c.n_rays = L.n_rays; c.ray_app = L.ray_app; c.app_pos = L.app_pos; c.app_rgb = L.app_rgb; c.acc = L.acc; c.rgb = L.rgb;
+    c.add_bg = (L.flags & T2N_FLAG_ADD_BG) ? 1 : 0;
+    timing_begin(f, T2N_K_COMPOSITE, s);
+    hipLaunchKernelGGL(k_composite, dim3((unsigned)((L.n_rays + 255) / 256)), dim3(256), 0, s, c);
+    timing_end(f, T2N_K_COMPOSITE, s);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+}  // namespace t2n
+
+using namespace t2n;
+
+extern "C" int t2n_density_at(const t2n_field* f, const float* xyz_norm, int64_t n, float* feat, float* sigma,
+                              t2n_stream stream) {
+    if (!f || !xyz_norm || n < 0) { set_error("t2n_density_at: bad argument"); return T2N_ERR_INVALID; }
+    if (!f->uploaded) { set_error("t2n_density_at: field has no uploaded parameters"); return T2N_ERR_STATE; }
+    if (n == 0) return T2N_OK;
+    const long long threads = (long long)n * 4;
+    hipLaunchKernelGGL((k_density_at<16>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       f->dev, xyz_norm, (long long)n, feat, sigma);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_raw2alpha(const float* sigma, const float* dist, int64_t n_rays, int n_samples, float* alpha,
+                             float* weights, float* bg, t2n_stream stream) {
+    if (!sigma || !dist || n_rays < 0 || n_samples <= 0) { set_error("t2n_raw2alpha: bad argument"); return T2N_ERR_INVALID; }
+    if (n_rays == 0) return T2N_OK;
+    hipLaunchKernelGGL(k_raw2alpha, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, (hipStream_t)stream, sigma, dist,
+                       (long long)n_rays, n_samples, alpha, weights, bg);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_filter_rays_bbox(const t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, uint8_t* mask,
+                                    t2n_stream stream) {
+    if (!f || !rays || !mask || n_rays < 0 || ray_stride < 6) { set_error("t2n_filter_rays_bbox: bad argument"); return T2N_ERR_INVALID; }
+    if (n_rays == 0) return T2N_OK;
+    hipLaunchKernelGGL(k_filter_bbox, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f->dev,
+                       rays, (long long)n_rays, ray_stride, mask);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}

@@ -1,0 +1,455 @@
+"""Host-side mirror of the reference's radiance-field interface for the VM-split path.
+
+``TensorVMSplit(aabb, gridSize, device, **kargs)`` keeps the reference call surface (models/tensoRF.py:139-239,
+models/tensorBase.py:163-507): same constructor keywords, ``forward`` signature and return tuple, parameter names /
+logical shapes (``state_dict`` interchange with reference ``.th`` checkpoints), ``get_optparam_groups``, ``TV_loss_*``,
+``filtering_rays``, ``save`` / ``load`` / ``get_kwargs``.  All arithmetic of the ray-marching path runs in
+libt2n_hip.so (hand-written gfx950 kernels) through the C-ABI in include/t2n.h; torch is used for device memory,
+streams and autograd plumbing only.  There is no CPU execution path: calling the renderer without the HIP library or
+a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import FLAG_ADD_BG, FLAG_KEEP_CTX, FLAG_TRAIN, T2NError
+
+MAT_MODE = [[0, 1], [0, 2], [1, 2]]
+VEC_MODE = [2, 1, 0]
+
+_WORKSPACE = {}
+
+
+def workspace(device, nbytes: int) -> torch.Tensor:
+    """Grow-only per-device scratch buffer handed to the C-ABI calls."""
+    key = str(device)
+    buf = _WORKSPACE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _WORKSPACE[key] = buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return buf
+
+
+def workspace_budget() -> int:
+    return int(float(os.environ.get("T2N_WORKSPACE_GIB", "8")) * (1 << 30))
+
+
+def raw2alpha(sigma: torch.Tensor, dist: torch.Tensor):
+    """models/tensorBase.py:19-26 on the GPU: ``(alpha, weights, T[:, -1:])``."""
+    lib = _lib.load()
+    sigma = sigma.contiguous().float()
+    dist = dist.contiguous().float()
+    R, N = sigma.shape
+    alpha = torch.empty_like(sigma)
+    w = torch.empty_like(sigma)
+    bg = torch.empty(R, 1, device=sigma.device, dtype=torch.float32)
+    _lib.check(lib.t2n_raw2alpha(_lib.ptr(sigma), _lib.ptr(dist), R, N, _lib.ptr(alpha), _lib.ptr(w), _lib.ptr(bg),
+                                 _lib.current_stream_ptr(sigma.device)), "t2n_raw2alpha")
+    return alpha, w, bg
+
+
+class MLPRender_Fea_noview(nn.Module):
+    """Parameter container with the reference's key names (models/tensorBase.py:88-99). The arithmetic of
+    ``forward`` (:101-109) lives in the fused HIP shade kernel; it is reached through TensorVMSplit."""
+
+    def __init__(self, inChanel, feape=6, featureC=128):
+        super().__init__()
+        self.in_mlpC = 2 * feape * inChanel + inChanel
+        self.feape = feape
+        l0, l1, l2 = nn.Linear(self.in_mlpC, featureC), nn.Linear(featureC, featureC), nn.Linear(featureC, 3)
+        self.mlp = nn.Sequential(l0, nn.ReLU(inplace=True), l1, nn.ReLU(inplace=True), l2)
+        nn.init.constant_(self.mlp[-1].bias, 0)
+
+    def forward(self, pts, viewdirs, features):
+        raise T2NError("MLPRender_Fea_noview runs fused inside TensorVMSplit's HIP shade kernel; call "
+                       "TensorVMSplit.shade(xyz_norm) / forward(rays) instead")
+
+
+class TensorVMSplit(nn.Module):
+    def __init__(self, aabb, gridSize, device, density_n_comp=8, appearance_n_comp=24, app_dim=27,
+                 shadingMode="MLP_PE", alphaMask=None, near_far=[2.0, 6.0], density_shift=-10, alphaMask_thres=0.001,
+                 distance_scale=25, rayMarch_weight_thres=0.0001, pos_pe=6, view_pe=6, fea_pe=6, featureC=128,
+                 step_ratio=2.0, fea2denseAct="softplus"):
+        super().__init__()
+        if isinstance(density_n_comp, int):
+            density_n_comp = [density_n_comp] * 3
+        if isinstance(appearance_n_comp, int):
+            appearance_n_comp = [appearance_n_comp] * 3
+        self.density_n_comp = list(density_n_comp)
+        self.app_n_comp = list(appearance_n_comp)
+        self.app_dim = app_dim
+        self.aabb = torch.as_tensor(aabb, dtype=torch.float32).to(device)
+        self.alphaMask = alphaMask
+        self.device = device
+        self.density_shift = density_shift
+        self.alphaMask_thres = alphaMask_thres
+        self.distance_scale = distance_scale
+        self.rayMarch_weight_thres = rayMarch_weight_thres
+        self.fea2denseAct = fea2denseAct
+        self.near_far = near_far
+        self.step_ratio = step_ratio
+        self.matMode, self.vecMode, self.comp_w = MAT_MODE, VEC_MODE, [1, 1, 1]
+        self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC = shadingMode, pos_pe, view_pe, fea_pe, featureC
+        self.materialize_weights = True   # the reference always returns weights/z_vals; set False to skip 8*N B/ray
+        self.z_gate = 2.0                 # models/tensorBase.py:460
+        self._handle = None
+        self._uploaded_key = None
+        self.last_stats = None
+
+        if shadingMode not in _lib.SHADE_IDS:
+            raise T2NError(f"shadingMode {shadingMode!r} is not implemented by the HIP renderer "
+                           f"(supported: {sorted(_lib.SHADE_IDS)})")
+        self.update_stepSize(gridSize)
+        self.init_svd_volume(gridSize[0], device)
+        if shadingMode == "MLP_Fea_noview":
+            self.renderModule = MLPRender_Fea_noview(self.app_dim, fea_pe, featureC).to(device)
+        else:
+            self.renderModule = None
+
+    # ---- containers (models/tensoRF.py:144-160) -------------------------------------------------------------------
+    def init_svd_volume(self, res, device):
+        self.density_plane, self.density_line = self.init_one_svd(self.density_n_comp, self.gridSize, 0.1, device)
+        self.app_plane, self.app_line = self.init_one_svd(self.app_n_comp, self.gridSize, 0.1, device)
+        self.basis_mat = nn.Linear(sum(self.app_n_comp), self.app_dim, bias=False).to(device)
+
+    def init_one_svd(self, n_component, gridSize, scale, device):
+        planes, lines = [], []
+        g = [int(x) for x in gridSize]
+        for i in range(3):
+            m0, m1 = MAT_MODE[i]
+            planes.append(nn.Parameter(scale * torch.randn((1, n_component[i], g[m1], g[m0]))))
+            lines.append(nn.Parameter(scale * torch.randn((1, n_component[i], g[VEC_MODE[i]], 1))))
+        return nn.ParameterList(planes).to(device), nn.ParameterList(lines).to(device)
+
+    def update_stepSize(self, gridSize):
+        """models/tensorBase.py:220-231 (same fp32 tensor arithmetic)."""
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invaabbSize = 2.0 / self.aabbSize
+        self.gridSize = torch.LongTensor([int(x) for x in gridSize]).to(self.device)
+        self.units = self.aabbSize / (self.gridSize - 1)
+        self.stepSize = torch.mean(self.units) * self.step_ratio
+        self.aabbDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize)))
+        self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
+        if self._handle is not None:
+            lib = _lib.load()
+            d = self._desc()
+            _lib.check(lib.t2n_field_set_desc(self._handle, C.byref(d)), "t2n_field_set_desc")
+
+    # ---- optimiser / regulariser surface ----------------------------------------------------------------------------
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        groups = [{"params": self.density_line, "lr": lr_init_spatialxyz},
+                  {"params": self.density_plane, "lr": lr_init_spatialxyz},
+                  {"params": self.app_line, "lr": lr_init_spatialxyz},
+                  {"params": self.app_plane, "lr": lr_init_spatialxyz},
+                  {"params": self.basis_mat.parameters(), "lr": lr_init_network}]
+        if isinstance(self.renderModule, nn.Module):
+            groups += [{"params": self.renderModule.parameters(), "lr": lr_init_network}]
+        return groups
+
+    def TV_loss_density(self, reg):
+        total = 0
+        for p in self.density_plane:
+            total = total + reg(p) * 1e-2
+        return total
+
+    def TV_loss_app(self, reg):
+        total = 0
+        for p in self.app_plane:
+            total = total + reg(p) * 1e-2
+        return total
+
+    def density_L1(self):
+        total = 0
+        for p, l in zip(self.density_plane, self.density_line):
+            total = total + torch.mean(torch.abs(p)) + torch.mean(torch.abs(l))
+        return total
+
+    def vectorDiffs(self, vector_comps):
+        total = 0
+        for v in vector_comps:
+            n_comp, n_size = v.shape[1:-1]
+            m = v.view(n_comp, n_size)
+            dotp = m @ m.transpose(-1, -2)
+            total = total + torch.mean(torch.abs(dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]))
+        return total
+
+    def vector_comp_diffs(self):
+        return self.vectorDiffs(self.density_line) + self.vectorDiffs(self.app_line)
+
+    # ---- checkpoint surface (models/tensorBase.py:251-290) --------------------------------------------------------------
+    def get_kwargs(self):
+        return {"aabb": self.aabb, "gridSize": self.gridSize.tolist(), "density_n_comp": self.density_n_comp,
+                "appearance_n_comp": self.app_n_comp, "app_dim": self.app_dim, "density_shift": self.density_shift,
+                "alphaMask_thres": self.alphaMask_thres, "distance_scale": self.distance_scale,
+                "rayMarch_weight_thres": self.rayMarch_weight_thres, "fea2denseAct": self.fea2denseAct,
+                "near_far": self.near_far, "step_ratio": self.step_ratio, "shadingMode": self.shadingMode,
+                "pos_pe": self.pos_pe, "view_pe": self.view_pe, "fea_pe": self.fea_pe, "featureC": self.featureC}
+
+    def save(self, path):
+        ckpt = {"kwargs": self.get_kwargs(), "state_dict": self.state_dict()}
+        torch.save(ckpt, path)
+
+    def load(self, ckpt):
+        if "alphaMask.aabb" in ckpt.keys():
+            raise T2NError("checkpoints carrying an alphaMask are not supported by the HIP renderer yet")
+        self.load_state_dict(ckpt["state_dict"])
+
+    # ---- C-ABI plumbing ------------------------------------------------------------------------------------------------
+    def _desc(self) -> _lib.FieldDesc:
+        d = _lib.FieldDesc()
+        a = self.aabb.detach().float().cpu()
+        inv = self.invaabbSize.detach().float().cpu()
+        for k in range(3):
+            d.aabb_min[k], d.aabb_max[k], d.inv_aabb_size[k] = float(a[0, k]), float(a[1, k]), float(inv[k])
+            d.grid[k] = int(self.gridSize[k])
+        if len(set(self.density_n_comp)) != 1 or len(set(self.app_n_comp)) != 1:
+            raise T2NError("the HIP renderer needs equal n_comp on the three planes")
+        d.density_n_comp, d.app_n_comp, d.app_dim = self.density_n_comp[0], self.app_n_comp[0], self.app_dim
+        d.shading = _lib.SHADE_IDS[self.shadingMode]
+        d.fea_pe, d.feature_c = self.fea_pe, self.featureC
+        d.act = _lib.ACT_IDS[self.fea2denseAct]
+        d.density_shift, d.distance_scale = float(self.density_shift), float(self.distance_scale)
+        d.weight_thres = float(self.rayMarch_weight_thres)
+        d.step_size = float(self.stepSize)
+        d.near, d.far = float(self.near_far[0]), float(self.near_far[1])
+        d.z_gate = float(self.z_gate)
+        return d
+
+    def _all_params(self):
+        ps = list(self.density_plane) + list(self.density_line) + list(self.app_plane) + list(self.app_line)
+        ps.append(self.basis_mat.weight)
+        if self.renderModule is not None:
+            ps += [self.renderModule.mlp[0].weight, self.renderModule.mlp[0].bias, self.renderModule.mlp[2].weight,
+                   self.renderModule.mlp[2].bias, self.renderModule.mlp[4].weight, self.renderModule.mlp[4].bias]
+        return ps
+
+    def _param_struct(self, tensors, cls=_lib.FieldParams):
+        s = cls()
+        t = [x if x is None else x for x in tensors]
+        for k in range(3):
+            s.density_plane[k] = t[k].data_ptr()
+            s.density_line[k] = t[3 + k].data_ptr()
+            s.app_plane[k] = t[6 + k].data_ptr()
+            s.app_line[k] = t[9 + k].data_ptr()
+        s.basis_weight = t[12].data_ptr()
+        if len(t) > 13:
+            s.mlp_w0, s.mlp_b0, s.mlp_w1, s.mlp_b1, s.mlp_w2, s.mlp_b2 = [x.data_ptr() for x in t[13:19]]
+        return s
+
+    def sync_params(self, force=False):
+        """Create the native field on first use and re-upload when any parameter changed (in-place optimiser steps
+        and load_state_dict bump tensor versions)."""
+        lib = _lib.load()
+        ps = self._all_params()
+        dev = ps[0].device
+        if dev.type != "cuda":
+            raise T2NError(f"TensorVMSplit parameters live on {dev}; the renderer runs on an MI355X (cuda/HIP) only")
+        for p in ps:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise T2NError("parameters must be contiguous float32")
+        if self._handle is None:
+            h = C.c_void_p()
+            d = self._desc()
+            _lib.check(lib.t2n_field_create(C.byref(d), C.byref(h)), "t2n_field_create")
+            self._handle = h
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if force or key != self._uploaded_key:
+            with torch.cuda.device(dev):
+                st = self._param_struct([p.detach() for p in ps])
+                _lib.check(lib.t2n_field_upload(self._handle, C.byref(st), _lib.current_stream_ptr(dev)),
+                           "t2n_field_upload")
+            self._uploaded_key = key
+        return self._handle
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                _lib.load().t2n_field_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def timing(self, on=True):
+        _lib.check(_lib.load().t2n_timing_enable(self.sync_params(), 1 if on else 0), "t2n_timing_enable")
+
+    def read_timing(self, reset=True):
+        ms = (C.c_double * _lib.T2N_K_COUNT)()
+        n = (C.c_int64 * _lib.T2N_K_COUNT)()
+        _lib.check(_lib.load().t2n_timing_read(self.sync_params(), ms, n, 1 if reset else 0), "t2n_timing_read")
+        return {_lib.KERNEL_NAMES[k]: (ms[k], n[k]) for k in range(_lib.T2N_K_COUNT) if n[k]}
+
+    # ---- stage methods (reference names) ---------------------------------------------------------------------------------
+    def normalize_coord(self, xyz_sampled):
+        return (xyz_sampled - self.aabb[0]) * self.invaabbSize - 1
+
+    def compute_densityfeature(self, xyz_sampled):
+        """models/tensoRF.py:205-220 — xyz already normalised to [-1,1]."""
+        return self._density_at(xyz_sampled, want_sigma=False)
+
+    def feature2density(self, density_features):
+        if self.fea2denseAct == "softplus":
+            return torch.nn.functional.softplus(density_features + self.density_shift)
+        return torch.relu(density_features)
+
+    def _density_at(self, xyz, want_sigma):
+        lib = _lib.load()
+        h = self.sync_params()
+        xyz = xyz.detach().reshape(-1, 3).contiguous().float().to(self.basis_mat.weight.device)
+        n = xyz.shape[0]
+        out = torch.empty(n, device=xyz.device, dtype=torch.float32)
+        with torch.cuda.device(xyz.device):
+            _lib.check(lib.t2n_density_at(h, _lib.ptr(xyz), n, None if want_sigma else _lib.ptr(out),
+                                          _lib.ptr(out) if want_sigma else None, _lib.current_stream_ptr(xyz.device)),
+                       "t2n_density_at")
+        return out
+
+    def compute_sigma(self, xyz_norm):
+        """compute_densityfeature + feature2density fused in the kernel."""
+        return self._density_at(xyz_norm, want_sigma=True)
+
+    def shade(self, xyz_norm, viewdirs=None, want_features=True, want_rgb=True):
+        """compute_appfeature (+ renderModule) at normalised points: returns (app_features [n,app_dim], rgb [n,3])."""
+        lib = _lib.load()
+        h = self.sync_params()
+        dev = self.basis_mat.weight.device
+        xyz = xyz_norm.detach().reshape(-1, 3).contiguous().float().to(dev)
+        n = xyz.shape[0]
+        vd = None if viewdirs is None else viewdirs.detach().reshape(-1, 3).contiguous().float().to(dev)
+        feat = torch.empty(n, self.app_dim, device=dev, dtype=torch.float32) if want_features else None
+        rgb = torch.empty(n, 3, device=dev, dtype=torch.float32) if want_rgb else None
+        ws = workspace(dev, 256)
+        with torch.cuda.device(dev):
+            _lib.check(lib.t2n_shade_at(h, _lib.ptr(xyz), _lib.ptr(vd), n, _lib.ptr(feat), _lib.ptr(rgb), _lib.ptr(ws),
+                                        ws.numel(), _lib.current_stream_ptr(dev)), "t2n_shade_at")
+        return feat, rgb
+
+    def compute_appfeature(self, xyz_sampled):
+        """models/tensoRF.py:223-239."""
+        return self.shade(xyz_sampled, want_rgb=False)[0]
+
+    @torch.no_grad()
+    def filtering_rays(self, all_rays, all_rgbs, all_depth=None, N_samples=256, chunk=10240 * 5, bbox_only=False):
+        """models/tensorBase.py:372-404 (bbox_only=True is the driver's call, text2nerf_main.py:477)."""
+        if not bbox_only:
+            raise T2NError("filtering_rays(bbox_only=False) needs an alphaMask, which this renderer does not build")
+        lib = _lib.load()
+        h = self.sync_params()
+        dev = self.basis_mat.weight.device
+        tt = time.time()
+        flat = all_rays.reshape(-1, all_rays.shape[-1])
+        masks = []
+        for idx in torch.split(torch.arange(flat.shape[0]), chunk):
+            r = flat[idx].to(dev).contiguous().float()
+            m = torch.empty(r.shape[0], dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.t2n_filter_rays_bbox(h, _lib.ptr(r), r.shape[0], r.shape[1], _lib.ptr(m),
+                                                    _lib.current_stream_ptr(dev)), "t2n_filter_rays_bbox")
+            masks.append(m.bool().cpu())
+        mask = torch.cat(masks).view(all_rgbs.shape[:-1])
+        print(f"Ray filtering done! takes {time.time() - tt} s. ray mask ratio: {torch.sum(mask) / flat.shape[0]}")
+        if all_depth is not None:
+            return all_rays[mask], all_rgbs[mask], all_depth[mask]
+        return all_rays[mask], all_rgbs[mask]
+
+    # ---- the render call ----------------------------------------------------------------------------------------------------
+    def forward(self, rays_chunk, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1):
+        """models/tensorBase.py:436-507: returns (rgb_map [R,3], depth_map [R], z_vals [R,N], weight [R,N])."""
+        if ndc_ray:
+            raise T2NError("ndc_ray=True is not on the Text2NeRF path (ndc_ray=0 in every run) and is not implemented")
+        if self.alphaMask is not None:
+            raise T2NError("alphaMask is not supported by the HIP renderer (the driver never builds one)")
+        dev = self.basis_mat.weight.device
+        rays = rays_chunk.to(dev)
+        if rays.dtype != torch.float32 or not rays.is_contiguous():
+            rays = rays.contiguous().float()
+        R = rays.shape[0]
+        N = int(N_samples) if N_samples > 0 else self.nSamples
+        if R == 0:
+            e = torch.empty(0, N, device=dev) if self.materialize_weights or is_train else None
+            return torch.empty(0, 3, device=dev), torch.empty(0, device=dev), e, e
+        jitter = None
+        add_bg = bool(white_bg)
+        if is_train:
+            # the reference draws on the CPU default generator even for GPU runs (models/tensorBase.py:313-317)
+            jitter = torch.rand(R, 1).to(dev).reshape(-1).contiguous()
+            if not white_bg:
+                add_bg = bool(torch.rand((1,)) < 0.5)   # models/tensorBase.py:497
+        flags = (FLAG_TRAIN if is_train else 0) | (FLAG_ADD_BG if add_bg else 0)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._all_params())
+        if needs_grad:
+            out = _RenderFn.apply(self, rays, N, flags, jitter, *self._all_params())
+            return out
+        rgb, depth, z, w = self._render_raw(rays, N, flags, jitter, self.materialize_weights)
+        return rgb, depth, z, w
+
+    def _render_raw(self, rays, N, flags, jitter, want_wz, keep_ctx=False):
+        lib = _lib.load()
+        h = self.sync_params()
+        dev = rays.device
+        R = rays.shape[0]
+        rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
+        depth = torch.empty(R, device=dev, dtype=torch.float32)
+        w = torch.empty(R, N, device=dev, dtype=torch.float32) if want_wz else None
+        z = torch.empty(R, N, device=dev, dtype=torch.float32) if want_wz else None
+        stats = torch.empty(_lib.T2N_STAT_COUNT, device=dev, dtype=torch.int64)
+        need = int(lib.t2n_render_workspace_bytes(max(R, 1), N))
+        ws = workspace(dev, need if keep_ctx else min(need, max(workspace_budget(),
+                                                                int(lib.t2n_render_workspace_bytes(1024, N)))))
+        if keep_ctx:
+            flags |= FLAG_KEEP_CTX
+        with torch.cuda.device(dev):
+            _lib.check(lib.t2n_render_forward(h, _lib.ptr(rays), R, rays.shape[1], N, flags, _lib.ptr(jitter),
+                                              _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(w), _lib.ptr(z), _lib.ptr(stats),
+                                              _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr(dev)),
+                       "t2n_render_forward")
+        self.last_stats = stats
+        return rgb, depth, z, w
+
+    def stats(self):
+        """Counters of the last render call (one device->host copy): evaluated / appearance samples, overflow."""
+        s = self.last_stats.cpu().tolist()
+        if s[_lib.STAT_OVERFLOW]:
+            raise T2NError("appearance list overflow — workspace sizing bug")
+        return {"evaluated": s[_lib.STAT_EVALUATED], "appearance": s[_lib.STAT_APPEARANCE]}
+
+
+class _RenderFn(torch.autograd.Function):
+    """Autograd bridge: forward = t2n_render_forward (context kept in the workspace), backward = t2n_render_backward."""
+
+    @staticmethod
+    def forward(ctx, field, rays, N, flags, jitter, *params):
+        rgb, depth, z, w = field._render_raw(rays, N, flags, jitter, True, keep_ctx=True)
+        ctx.field, ctx.N, ctx.flags = field, N, flags
+        ctx.save_for_backward(rays, jitter, w, z)
+        ctx.mark_non_differentiable(z)
+        return rgb, depth, z, w
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d_z, d_w):
+        field = ctx.field
+        rays, jitter, w, z = ctx.saved_tensors
+        lib = _lib.load()
+        dev = rays.device
+        params = field._all_params()
+        grads = [torch.zeros_like(p) for p in params]
+        gs = field._param_struct(grads, _lib.FieldGrads)
+        R = rays.shape[0]
+        d_rgb = torch.zeros(R, 3, device=dev) if d_rgb is None else d_rgb.contiguous().float()
+        d_depth = torch.zeros(R, device=dev) if d_depth is None else d_depth.contiguous().float()
+        d_w = None if d_w is None else d_w.contiguous().float()
+        ws = workspace(dev, int(lib.t2n_render_workspace_bytes(max(R, 1), ctx.N)))
+        with torch.cuda.device(dev):
+            _lib.check(lib.t2n_render_backward(field._handle, _lib.ptr(rays), R, rays.shape[1], ctx.N,
+                                               ctx.flags | FLAG_KEEP_CTX, _lib.ptr(jitter), _lib.ptr(w), _lib.ptr(z),
+                                               _lib.ptr(d_rgb), _lib.ptr(d_depth), _lib.ptr(d_w), C.byref(gs),
+                                               _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr(dev)),
+                       "t2n_render_backward")
+        return (None, None, None, None, None) + tuple(grads)
