@@ -166,14 +166,15 @@ __global__ __launch_bounds__(256) void k_generate_rays(int H, int W, float fx, f
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-struct Carve { size_t acc, ray_app, counter, app_pos, app_ray, app_rgb, total; };
+struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, total; unsigned list_cap; };
 static Carve carve(int64_t rays, int n_samples) {
     Carve c;
-    const size_t cap = (size_t)rays * (size_t)n_samples;
+    c.list_cap = list_capacity(rays, n_samples);
+    const size_t cap = (size_t)c.list_cap * kLists;
     size_t o = 0;
-    c.counter = o; o = align_up(o + 256, 256);
+    c.counters = o; o = align_up(o + 256, 256);
     c.acc = o; o = align_up(o + (size_t)rays * 4, 256);
-    c.ray_app = o; o = align_up(o + (size_t)rays * 8, 256);
+    c.ray_app = o; o = align_up(o + (size_t)rays * 16, 256);
     c.app_pos = o; o = align_up(o + cap * 16, 256);
     c.app_rgb = o; o = align_up(o + cap * 16, 256);
     c.app_ray = o; o = align_up(o + cap * 4, 256);
@@ -292,7 +293,7 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     while (per > 1 && carve(per, n_samples).total > workspace_bytes) per = (per + 1) / 2;
     if (carve(per, n_samples).total > workspace_bytes) { set_error("t2n_render_forward: workspace %zu B too small", workspace_bytes); return T2N_ERR_WORKSPACE; }
     if ((flags & T2N_FLAG_KEEP_CTX) && per < n_rays) { set_error("t2n_render_forward: KEEP_CTX needs the whole call in one launch"); return T2N_ERR_WORKSPACE; }
-    if ((uint64_t)per * (uint64_t)n_samples > 0xffffffffull) per = (int64_t)(0xffffffffull / (uint64_t)n_samples);
+    while ((uint64_t)list_capacity(per, n_samples) * kLists > 0x7fffffffull) per = (per + 1) / 2;   // int slots
     char* ws = (char*)workspace;
     for (int64_t off = 0; off < n_rays; off += per) {
         const int64_t cnt = (n_rays - off) < per ? (n_rays - off) : per;
@@ -304,13 +305,13 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         L.weights = weights ? weights + off * n_samples : nullptr;
         L.z_vals = z_vals ? z_vals + off * n_samples : nullptr;
         L.stats = stats;
-        L.counter = (unsigned*)(ws + c.counter); L.acc = (float*)(ws + c.acc); L.ray_app = (int2*)(ws + c.ray_app);
+        L.counters = (unsigned*)(ws + c.counters); L.acc = (float*)(ws + c.acc); L.ray_app = (int4*)(ws + c.ray_app);
         L.app_pos = (float4*)(ws + c.app_pos); L.app_rgb = (float4*)(ws + c.app_rgb); L.app_ray = (int*)(ws + c.app_ray);
-        L.cap = (unsigned)((uint64_t)per * (uint64_t)n_samples);
-        T2N_HIP(hipMemsetAsync(L.counter, 0, 256, s));
+        L.list_cap = c.list_cap;
+        T2N_HIP(hipMemsetAsync(L.counters, 0, 256, s));
         int rc;
         if ((rc = launch_march(f, L, s))) return rc;
-        if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counter, L.cap, L.app_rgb, nullptr, s))) return rc;
+        if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, s))) return rc;
         if ((rc = launch_composite(f, L, s))) return rc;
     }
     return T2N_OK;

@@ -84,11 +84,17 @@ struct RenderLaunch {
     const float* rays; int64_t n_rays; int ray_stride; int n_samples; uint32_t flags;
     const float* jitter; float* rgb; float* depth; float* weights; float* z_vals; uint64_t* stats;
     // workspace carve (one sub-launch)
-    float* acc; int2* ray_app; unsigned* counter; float4* app_pos; int* app_ray; float4* app_rgb; unsigned cap;
+    float* acc; int4* ray_app; unsigned* counters; float4* app_pos; int* app_ray; float4* app_rgb; unsigned list_cap;
 };
 int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s);
+constexpr int kLists = 8;   // appearance sub-lists per sub-launch
+// list_cap(n_rays, N): worst-case entries of one sub-list = rays of the largest XCD run x samples
+inline unsigned list_capacity(long long n_rays, int n_samples) {
+    const unsigned nblocks = (unsigned)((n_rays + 3) / 4);
+    return ((nblocks >> 3) + ((nblocks & 7u) ? 1u : 0u)) * 4u * (unsigned)n_samples;
+}
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
-                      const unsigned* count_dev, unsigned count_max, float4* app_rgb, float* feat_out, hipStream_t s);
+                      const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, hipStream_t s);
 int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s);
 
 }  // namespace t2n

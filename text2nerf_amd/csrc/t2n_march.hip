@@ -24,7 +24,7 @@ struct MarchArgs {
     const float* rays; long long n_rays; int ray_stride; int n_samples; int npad;
     const float* jitter;
     float* depth; float* acc; float* weights; float* z_vals;
-    float4* app_pos; int* app_ray; int2* ray_app; unsigned* counter; unsigned cap;
+    float4* app_pos; int* app_ray; int4* ray_app; unsigned* counters; unsigned list_cap;
     unsigned long long* stats;
     unsigned nblocks;
 };
@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
     float* __restrict__ wts = sig + a.npad;
     const FieldDev& F = a.F;
 
+    // Appearance list: 8 independent sub-lists (one per XCD-contiguous run of ray tiles, see xcd_tile) so that the
+    // per-ray reservation atomics of concurrently running workgroups spread over 8 addresses instead of one.
+    const unsigned list = blockIdx.x & 7u;
     const long long r = (long long)xcd_tile(blockIdx.x, a.nblocks) * 4 + wid;
     if (r >= a.n_rays) return;
     const int N = a.n_samples;
@@ -141,16 +144,16 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
     // ---- outputs per ray ---------------------------------------------------------------------------------------------
     unsigned slot0 = 0;
     if (lane == 0) {
-        if (napp) slot0 = atomicAdd(a.counter, napp);
-        a.ray_app[r] = make_int2((int)slot0, (int)napp);
+        if (napp) slot0 = atomicAdd(&a.counters[list], napp);
+        const bool fits = slot0 + napp <= a.list_cap;
+        slot0 += list * a.list_cap;
+        a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, (int)nvalid, 0);
         a.acc[r] = acc;
         a.depth[r] = dep + (1.f - acc) * ray.last;   // :504-505
-        if (a.stats) {
-            atomicAdd(&a.stats[T2N_STAT_EVALUATED], (unsigned long long)nvalid);
-            if (napp) atomicAdd(&a.stats[T2N_STAT_APPEARANCE], (unsigned long long)napp);
-            if (napp && slot0 + napp > a.cap) atomicAdd(&a.stats[T2N_STAT_OVERFLOW], 1ull);
-        }
+        if (!fits && a.stats) a.stats[T2N_STAT_OVERFLOW] = 1ull;   // cannot happen: list_cap is the worst case
+        if (!fits) napp = 0;
     }
+    napp = __shfl(napp, 0);
     slot0 = __shfl(slot0, 0);
 
     if (a.weights) {
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
     }
 
     // ---- pass D: appearance list -------------------------------------------------------------------------------------
-    if (napp && slot0 + napp <= a.cap) {
+    if (napp) {
         unsigned run = 0;
         for (int base = 0; base < Lw; base += 64) {
             const int j = base + lane;
@@ -187,13 +190,13 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
 
 // K3: per-ray composite of the shaded appearance samples, in sample order (models/tensorBase.py:494-501).
 struct CompositeArgs {
-    long long n_rays; const int2* ray_app; const float4* app_pos; const float4* app_rgb; const float* acc; float* rgb;
+    long long n_rays; const int4* ray_app; const float4* app_pos; const float4* app_rgb; const float* acc; float* rgb;
     int add_bg;
 };
 __global__ __launch_bounds__(256) void k_composite(const CompositeArgs a) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_rays) return;
-    const int2 ra = a.ray_app[r];
+    const int4 ra = a.ray_app[r];
     float cr = 0.f, cg = 0.f, cb = 0.f;
     for (int k = 0; k < ra.y; ++k) {
         const float w = a.app_pos[ra.x + k].w;
@@ -207,6 +210,25 @@ __global__ __launch_bounds__(256) void k_composite(const CompositeArgs a) {
     a.rgb[r * 3 + 0] = fminf(fmaxf(cr, 0.f), 1.f);
     a.rgb[r * 3 + 1] = fminf(fmaxf(cg, 0.f), 1.f);
     a.rgb[r * 3 + 2] = fminf(fmaxf(cb, 0.f), 1.f);
+}
+
+// Per-call counters: V (evaluated samples) and A (appearance samples) summed over the rays of one sub-launch.
+__global__ __launch_bounds__(256) void k_ray_stats(const int4* __restrict__ ray_app, long long n, unsigned long long* stats) {
+    unsigned long long v = 0, ap = 0;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
+        const int4 ra = ray_app[r];
+        v += (unsigned)ra.z; ap += (unsigned)ra.y;
+    }
+    // wave reduction on 64-bit counters
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v += __shfl_xor((long long)v, o);
+        ap += __shfl_xor((long long)ap, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&stats[T2N_STAT_EVALUATED], v);
+        atomicAdd(&stats[T2N_STAT_APPEARANCE], ap);
+    }
 }
 
 // Point-wise density: 4 lanes per point (same gather as pass B).
@@ -291,7 +313,7 @@ int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
     a.npad = (L.n_samples + 63) & ~63;
     a.jitter = L.jitter;
     a.depth = L.depth; a.acc = L.acc; a.weights = L.weights; a.z_vals = L.z_vals;
-    a.app_pos = L.app_pos; a.app_ray = L.app_ray; a.ray_app = L.ray_app; a.counter = L.counter; a.cap = L.cap;
+    a.app_pos = L.app_pos; a.app_ray = L.app_ray; a.ray_app = L.ray_app; a.counters = L.counters; a.list_cap = L.list_cap;
     a.stats = (unsigned long long*)L.stats;
     a.nblocks = (unsigned)((L.n_rays + 3) / 4);
     const size_t lds = (size_t)4 * 2 * a.npad * sizeof(float);
@@ -301,6 +323,13 @@ int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
     else hipLaunchKernelGGL((k_march<false, 16>), dim3(a.nblocks), dim3(256), lds, s, a);
     timing_end(f, T2N_K_MARCH, s);
     T2N_HIP(hipGetLastError());
+    if (L.stats) {
+        unsigned nb = (unsigned)((L.n_rays + 255) / 256);
+        if (nb > 1024) nb = 1024;
+        hipLaunchKernelGGL(k_ray_stats, dim3(nb), dim3(256), 0, s, (const int4*)L.ray_app, (long long)L.n_rays,
+                           (unsigned long long*)L.stats);
+        T2N_HIP(hipGetLastError());
+    }
     return T2N_OK;
 }
 

@@ -48,7 +48,7 @@ struct ShadeArgs {
     FieldDev F;
     const float4* app_pos; const int* app_ray; const float* rays; int ray_stride;
     const float* xyz; const float* viewdirs;      // explicit-point mode (t2n_shade_at): xyz [n,3], viewdirs [n,3] or null
-    const unsigned* count_dev; unsigned count_max;
+    const unsigned* counters; unsigned list_cap; int nlists; unsigned count_max;   // list mode: counters[nlists]; point mode: count_max
     float4* app_rgb; float* feat_out; float* rgb_out;   // rgb_out: packed [n,3] (explicit-point mode)
 };
 
@@ -85,13 +85,27 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
     float* __restrict__ X = smem + (size_t)wid * kTileFloats;
     float* __restrict__ Fe = X;   // reused after the basis contraction
     const FieldDev& F = a.F;
-    unsigned count = a.count_dev ? *a.count_dev : a.count_max;
-    if (count > a.count_max) count = a.count_max;
-    const unsigned ntiles = (count + 31u) / 32u;
+    // tile enumeration over the appearance sub-lists (list l occupies [l*list_cap, l*list_cap + counters[l]))
+    unsigned cnt_l = 0;
+    if (lane < a.nlists) {
+        cnt_l = a.counters ? a.counters[lane] : a.count_max;
+        if (a.counters && cnt_l > a.list_cap) cnt_l = a.list_cap;
+    }
+    unsigned incl = (cnt_l + 31u) / 32u;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const unsigned ntiles = __shfl(incl, a.nlists - 1);
     const unsigned wave_stride = gridDim.x * 4u;
 
     for (unsigned tile = blockIdx.x * 4u + wid; tile < ntiles; tile += wave_stride) {
-        const unsigned base = tile * 32u;
+        const int li = (int)__popcll(__ballot((lane < a.nlists) & (incl <= tile)));
+        const unsigned before = li ? __shfl(incl, li - 1) : 0u;
+        const unsigned lbase = (unsigned)li * a.list_cap;
+        const unsigned base = lbase + (tile - before) * 32u;
+        const unsigned count = lbase + __shfl(cnt_l, li);      // one past the last live entry of this sub-list
         // ---- gather: plane x line products for 32 samples x 144 channels -> X ---------------------------------------
         gather_plane<0>(F.app, X, lane, a.app_pos, a.xyz, base, count);
         gather_plane<1>(F.app, X, lane, a.app_pos, a.xyz, base, count);
@@ -305,9 +319,9 @@ int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
     return T2N_OK;
 }
 
-static int shade_grid(unsigned count_max) {
-    const unsigned tiles = (count_max + 31u) / 32u;
-    unsigned blocks = (tiles + 3u) / 4u;
+static int shade_grid(unsigned long long count_max) {
+    const unsigned long long tiles = (count_max + 31u) / 32u;
+    unsigned long long blocks = (tiles + 3u) / 4u;
     const unsigned cap = 256u * 2u;   // 2 workgroups per CU (LDS: 4 x 19 KB each)
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
@@ -315,12 +329,12 @@ static int shade_grid(unsigned count_max) {
 }
 
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
-                      const unsigned* count_dev, unsigned count_max, float4* app_rgb, float* feat_out, hipStream_t s) {
+                      const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, hipStream_t s) {
     ShadeArgs a;
     memset(&a, 0, sizeof(a));
     a.F = f->dev;
     a.app_pos = app_pos; a.app_ray = app_ray; a.rays = rays; a.ray_stride = ray_stride;
-    a.count_dev = count_dev; a.count_max = count_max; a.app_rgb = app_rgb; a.feat_out = feat_out;
+    a.counters = counters_dev; a.list_cap = list_cap; a.nlists = kLists; a.app_rgb = app_rgb;
     const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -328,7 +342,7 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
         attr_set = true;
     }
     timing_begin(f, T2N_K_SHADE, s);
-    hipLaunchKernelGGL(k_shade, dim3(shade_grid(count_max)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k_shade, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
     timing_end(f, T2N_K_SHADE, s);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
@@ -351,7 +365,7 @@ extern "C" int t2n_shade_at(const t2n_field* fc, const float* xyz_norm, const fl
     ShadeArgs a;
     memset(&a, 0, sizeof(a));
     a.F = f->dev;
-    a.xyz = xyz_norm; a.viewdirs = viewdirs; a.count_max = (unsigned)n; a.feat_out = app_feat; a.rgb_out = rgb;
+    a.xyz = xyz_norm; a.viewdirs = viewdirs; a.count_max = (unsigned)n; a.nlists = 1; a.feat_out = app_feat; a.rgb_out = rgb;
     const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
     T2N_HIP(hipFuncSetAttribute((const void*)k_shade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_shade, dim3(shade_grid((unsigned)n)), dim3(256), lds, (hipStream_t)stream, a);

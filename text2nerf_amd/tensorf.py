@@ -130,14 +130,22 @@ class TensorVMSplit(nn.Module):
         return nn.ParameterList(planes).to(device), nn.ParameterList(lines).to(device)
 
     def update_stepSize(self, gridSize):
-        """models/tensorBase.py:220-231 (same fp32 tensor arithmetic)."""
-        self.aabbSize = self.aabb[1] - self.aabb[0]
-        self.invaabbSize = 2.0 / self.aabbSize
-        self.gridSize = torch.LongTensor([int(x) for x in gridSize]).to(self.device)
-        self.units = self.aabbSize / (self.gridSize - 1)
-        self.stepSize = torch.mean(self.units) * self.step_ratio
-        self.aabbDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize)))
-        self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
+        """models/tensorBase.py:220-231, same fp32 tensor arithmetic — evaluated on the HOST so that the scalars that
+        decide which samples exist (step size, sample count) do not depend on the device's reduction order
+        (a device-side mean multiplies by 1/3 where the CPU divides by 3: one ulp of step size)."""
+        aabb = self.aabb.detach().float().cpu()
+        size = aabb[1] - aabb[0]
+        grid = torch.LongTensor([int(x) for x in gridSize])
+        units = size / (grid - 1)
+        step = torch.mean(units) * self.step_ratio
+        diag = torch.sqrt(torch.sum(torch.square(size)))
+        self.aabbSize = size.to(self.device)
+        self.invaabbSize = (2.0 / size).to(self.device)
+        self.gridSize = grid.to(self.device)
+        self.units = units.to(self.device)
+        self.stepSize = step.to(self.device)
+        self.aabbDiag = diag.to(self.device)
+        self.nSamples = int((diag / step).item()) + 1
         if self._handle is not None:
             lib = _lib.load()
             d = self._desc()
@@ -407,7 +415,8 @@ class TensorVMSplit(nn.Module):
             flags |= FLAG_KEEP_CTX
         with torch.cuda.device(dev):
             _lib.check(lib.t2n_render_forward(h, _lib.ptr(rays), R, rays.shape[1], N, flags, _lib.ptr(jitter),
-                                              _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(w), _lib.ptr(z), _lib.ptr(stats),
+                                              _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(w), _lib.ptr(z),
+                                              _lib.ptr(stats) if getattr(self, 'collect_stats', True) else None,
                                               _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr(dev)),
                        "t2n_render_forward")
         self.last_stats = stats
