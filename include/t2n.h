@@ -159,18 +159,25 @@ int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_
                        void* workspace, size_t workspace_bytes, t2n_stream stream);
 
 /* ---- a-15: backward of the render call w.r.t. all field parameters (what autograd derives in the reference,
- * text2nerf_main.py:589). Requires the forward to have run with T2N_FLAG_KEEP_CTX as ONE launch on the same workspace,
- * with weights and z_vals materialised. d_weights may be NULL. Gradients are ACCUMULATED into `g` (reference layouts). */
+ * text2nerf_main.py:589; coordinates are detached there, models/tensoRF.py:208-210,226-228, so no ray gradients exist).
+ * Protocol: (1) forward with T2N_FLAG_KEEP_CTX as ONE launch (workspace >= t2n_render_workspace_bytes_ctx), weights and
+ * z_vals materialised; (2) t2n_render_ctx_rows reads the appearance-sample count back (SYNCHRONISES the stream) and
+ * returns the padded activation row count; (3) t2n_render_backward with a second workspace of
+ * t2n_backward_workspace_bytes(rows). Only the MLP_Fea_noview head is differentiable here (the driver's head).
+ * d_weights may be NULL. Gradients are ACCUMULATED into `g` (reference layouts; NULL members are skipped). */
+size_t t2n_render_workspace_bytes_ctx(int64_t n_rays, int n_samples);
+int t2n_render_ctx_rows(const void* fwd_workspace, int64_t n_rays, int n_samples, t2n_stream stream, int64_t* rows);
+size_t t2n_backward_workspace_bytes(int64_t rows);
 int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
-                        const float* jitter, const float* weights, const float* z_vals, const float* d_rgb,
-                        const float* d_depth, const float* d_weights, const t2n_field_grads* g, void* workspace,
-                        size_t workspace_bytes, t2n_stream stream);
+                        const float* jitter, const float* d_rgb, const float* d_depth, const float* d_weights,
+                        const t2n_field_grads* g, void* fwd_workspace, size_t fwd_workspace_bytes, void* bwd_workspace,
+                        size_t bwd_workspace_bytes, t2n_stream stream);
 
 /* ---- measurement hooks (bench.py): when enabled, each kernel launch of the render call is bracketed by HIP events on
  * the launch stream. t2n_timing_read synchronises those events and returns accumulated milliseconds and launch counts
  * per kernel since the last reset. Kernel ids: */
-enum { T2N_K_MARCH = 0, T2N_K_SHADE = 1, T2N_K_COMPOSITE = 2, T2N_K_UPLOAD = 3, T2N_K_BWD_MARCH = 4, T2N_K_BWD_SHADE = 5,
-       T2N_K_COUNT = 8 };
+enum { T2N_K_MARCH = 0, T2N_K_SHADE = 1, T2N_K_COMPOSITE = 2, T2N_K_UPLOAD = 3, T2N_K_BWD_MARCH = 4, T2N_K_BWD_MLP = 5,
+       T2N_K_BWD_SCATTER = 6, T2N_K_COUNT = 8 };
 int t2n_timing_enable(t2n_field* f, int on);
 int t2n_timing_read(t2n_field* f, double* ms /*[T2N_K_COUNT]*/, int64_t* launches /*[T2N_K_COUNT]*/, int reset);
 

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libt2n_hip.so")
 
 T2N_STAT_COUNT = 8
 T2N_K_COUNT = 8
-KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_shade", "_6", "_7")
+KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_mlp", "bwd_scatter", "_7")
 STAT_EVALUATED, STAT_APPEARANCE, STAT_RAYS, STAT_OVERFLOW = 0, 1, 2, 3
 
 FLAG_TRAIN, FLAG_ADD_BG, FLAG_KEEP_CTX = 1, 2, 4
@@ -68,9 +68,12 @@ SIGNATURES = {
     "t2n_render_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
+    "t2n_render_workspace_bytes_ctx": (C.c_size_t, [C.c_int64, C.c_int]),
+    "t2n_render_ctx_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
+    "t2n_backward_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "t2n_render_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.POINTER(FieldGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FieldGrads), C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "t2n_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "t2n_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
 }

@@ -166,8 +166,7 @@ __global__ __launch_bounds__(256) void k_generate_rays(int H, int W, float fx, f
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, total; unsigned list_cap; };
-static Carve carve(int64_t rays, int n_samples) {
+Carve carve_workspace(int64_t rays, int n_samples, bool ctx) {
     Carve c;
     c.list_cap = list_capacity(rays, n_samples);
     const size_t cap = (size_t)c.list_cap * kLists;
@@ -178,9 +177,12 @@ static Carve carve(int64_t rays, int n_samples) {
     c.app_pos = o; o = align_up(o + cap * 16, 256);
     c.app_rgb = o; o = align_up(o + cap * 16, 256);
     c.app_ray = o; o = align_up(o + cap * 4, 256);
+    c.sigma = o; if (ctx) o = align_up(o + (size_t)rays * n_samples * 4, 256);
+    c.rgb_raw = o; if (ctx) o = align_up(o + (size_t)rays * 16, 256);
     c.total = o;
     return c;
 }
+static Carve carve(int64_t rays, int n_samples) { return carve_workspace(rays, n_samples, false); }
 
 }  // namespace t2n
 
@@ -217,6 +219,10 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
         if (f->buf_den_line[k]) (void)hipFree(f->buf_den_line[k]);
         if (f->buf_app_plane[k]) (void)hipFree(f->buf_app_plane[k]);
         if (f->buf_app_line[k]) (void)hipFree(f->buf_app_line[k]);
+        if (f->gbuf_den_plane[k]) (void)hipFree(f->gbuf_den_plane[k]);
+        if (f->gbuf_den_line[k]) (void)hipFree(f->gbuf_den_line[k]);
+        if (f->gbuf_app_plane[k]) (void)hipFree(f->gbuf_app_plane[k]);
+        if (f->gbuf_app_line[k]) (void)hipFree(f->gbuf_app_line[k]);
     }
     if (f->buf_mlp) (void)hipFree(f->buf_mlp);
     for (int k = 0; k < T2N_K_COUNT; ++k)
@@ -241,6 +247,7 @@ extern "C" int t2n_field_upload(t2n_field* f, const t2n_field_params* p, t2n_str
     if (!rc) rc = launch_pack_mlp(f, p, s);
     timing_end(f, T2N_K_UPLOAD, s);
     if (rc) return rc;
+    f->params_ref = *p;
     f->uploaded = true;
     return T2N_OK;
 }
@@ -278,6 +285,11 @@ extern "C" size_t t2n_render_workspace_bytes(int64_t rays_per_launch, int n_samp
     return carve(rays_per_launch, n_samples).total;
 }
 
+extern "C" size_t t2n_render_workspace_bytes_ctx(int64_t n_rays, int n_samples) {
+    if (n_rays <= 0 || n_samples <= 0) return 0;
+    return carve_workspace(n_rays, n_samples, true).total;
+}
+
 extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
                                   const float* jitter, float* rgb, float* depth, float* weights, float* z_vals, uint64_t* stats,
                                   void* workspace, size_t workspace_bytes, t2n_stream stream) {
@@ -288,16 +300,24 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     hipStream_t s = (hipStream_t)stream;
     if (stats) T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s));
     if (n_rays == 0) return T2N_OK;
+    const bool keep = (flags & T2N_FLAG_KEEP_CTX) != 0;
+    if (keep) {
+        if (carve_workspace(n_rays, n_samples, true).total > workspace_bytes || (uint64_t)list_capacity(n_rays, n_samples) * kLists > 0x7fffffffull) {
+            set_error("t2n_render_forward: KEEP_CTX needs the whole call in one launch (workspace %zu B < %zu B)", workspace_bytes,
+                      carve_workspace(n_rays, n_samples, true).total);
+            return T2N_ERR_WORKSPACE;
+        }
+        if (!weights || !z_vals) { set_error("t2n_render_forward: KEEP_CTX needs weights and z_vals materialised"); return T2N_ERR_INVALID; }
+    }
     // largest sub-launch whose worst case (every sample an appearance sample) fits the workspace
     int64_t per = n_rays;
     while (per > 1 && carve(per, n_samples).total > workspace_bytes) per = (per + 1) / 2;
     if (carve(per, n_samples).total > workspace_bytes) { set_error("t2n_render_forward: workspace %zu B too small", workspace_bytes); return T2N_ERR_WORKSPACE; }
-    if ((flags & T2N_FLAG_KEEP_CTX) && per < n_rays) { set_error("t2n_render_forward: KEEP_CTX needs the whole call in one launch"); return T2N_ERR_WORKSPACE; }
     while ((uint64_t)list_capacity(per, n_samples) * kLists > 0x7fffffffull) per = (per + 1) / 2;   // int slots
     char* ws = (char*)workspace;
     for (int64_t off = 0; off < n_rays; off += per) {
         const int64_t cnt = (n_rays - off) < per ? (n_rays - off) : per;
-        const Carve c = carve(per, n_samples);
+        const Carve c = carve_workspace(per, n_samples, keep);
         RenderLaunch L;
         L.rays = rays + off * ray_stride; L.n_rays = cnt; L.ray_stride = ray_stride; L.n_samples = n_samples; L.flags = flags;
         L.jitter = jitter ? jitter + off : nullptr;
@@ -308,10 +328,12 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         L.counters = (unsigned*)(ws + c.counters); L.acc = (float*)(ws + c.acc); L.ray_app = (int4*)(ws + c.ray_app);
         L.app_pos = (float4*)(ws + c.app_pos); L.app_rgb = (float4*)(ws + c.app_rgb); L.app_ray = (int*)(ws + c.app_ray);
         L.list_cap = c.list_cap;
+        L.sigma_ctx = keep ? (float*)(ws + c.sigma) : nullptr;
+        L.rgb_raw = keep ? (float4*)(ws + c.rgb_raw) : nullptr;
         T2N_HIP(hipMemsetAsync(L.counters, 0, 256, s));
         int rc;
         if ((rc = launch_march(f, L, s))) return rc;
-        if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, s))) return rc;
+        if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, nullptr, s))) return rc;
         if ((rc = launch_composite(f, L, s))) return rc;
     }
     return T2N_OK;

@@ -1,14 +1,585 @@
-// Backward of the render call (a-15). Implemented in a later milestone; until then the entry point fails loudly.
+// Backward of the render call w.r.t. every field parameter: what autograd derives for the reference's
+// TensorBase.forward (text2nerf_main.py:589). Sample coordinates are detached in the reference
+// (models/tensoRF.py:208-210,226-228), so gradients flow only into the factor tensors, basis_mat and the MLP.
+//
+// Pipeline (all on the caller's stream; `rows` = padded appearance-sample rows, 32 per shade tile):
+//   1  k_shade (ctx mode)      re-run the appearance forward, keeping X[rows,144], feat[rows,32], h0/h1[rows,128]
+//   2  k_bwd_march             per ray: recompute alpha/T/w from the kept sigma, dL/dw -> dL/dalpha (reverse scan) -> dL/dsigma
+//                              -> dL/dfeature; scatter-add into the channel-last density gradient planes/lines (fp32 atomics);
+//                              emits per appearance sample go = dL/d(pre-sigmoid rgb)
+//   3  k_bwd_l2                layer 2 (3 outputs): dW2, db2, g1 = (go W2) * [h1 > 0]
+//   4  gemm_tn / gemm_nn       fp32-MFMA GEMMs: dW1 = g1^T h0, g0 = (g1 W1) * [h0 > 0], dW0 = g0^T PE(feat), gx = g0 W0,
+//                              PE backward -> gf, dWb = gf^T X, gX = gf Wb; k_colsum for the biases
+//   5  k_bwd_app_scatter       re-gather appearance taps, scatter-add plane/line gradients
+//   6  k_relayout_add          channel-last gradient buffers -> += reference-layout [1,C,H,W] gradient tensors
 #include "t2n_device.h"
+
+namespace t2n {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__host__ __device__ constexpr int unit_of(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct TilePrefix { unsigned t[kLists + 1]; };   // tiles before each sub-list (host-computed from the counters)
+struct GradSet { float* plane[3]; float* line[3]; };
+
+__device__ __forceinline__ unsigned slot_to_row(unsigned slot, unsigned list_cap, const TilePrefix& tp) {
+    const unsigned l = slot / list_cap;
+    return tp.t[l] * 32u + (slot - l * list_cap);
+}
+
+__device__ __forceinline__ void atomic_add4(float* p, float4 v) {
+    atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+
+// Scatter d(feature)/d(plane taps, line taps) for factor pair K: value quads P (plane) and L (line) are re-gathered.
+template <int K>
+__device__ __forceinline__ void scatter_pair(const FactorSet& S, const GradSet& G, int CQ, int q, float xn, float yn, float zn,
+                                             float4 g /* dL/d(P*L) per channel */) {
+    TapIdx o;
+    compute_taps<K>(S, CQ, q, xn, yn, zn, o);
+    const float4* __restrict__ P = reinterpret_cast<const float4*>(S.plane[K]);
+    const float4* __restrict__ Ln = reinterpret_cast<const float4*>(S.line[K]);
+    QuadTaps t;
+    t.nw = P[o.nw]; t.ne = P[o.ne]; t.sw = P[o.sw]; t.se = P[o.se]; t.l0 = Ln[o.l0]; t.l1 = Ln[o.l1];
+    t.wnw = o.wnw; t.wne = o.wne; t.wsw = o.wsw; t.wse = o.wse; t.wl0 = o.wl0; t.wl1 = o.wl1;
+    const float4 pv = taps_plane(t), lv = taps_line(t);
+    const float4 gp = make_float4(g.x * lv.x, g.y * lv.y, g.z * lv.z, g.w * lv.w);   // dL/dP
+    const float4 gl = make_float4(g.x * pv.x, g.y * pv.y, g.z * pv.z, g.w * pv.w);   // dL/dL
+    float* gP = G.plane[K];
+    float* gL = G.line[K];
+    if (o.wnw != 0.f) atomic_add4(gP + (size_t)o.nw * 4, f4_mul(gp, o.wnw));
+    if (o.wne != 0.f) atomic_add4(gP + (size_t)o.ne * 4, f4_mul(gp, o.wne));
+    if (o.wsw != 0.f) atomic_add4(gP + (size_t)o.sw * 4, f4_mul(gp, o.wsw));
+    if (o.wse != 0.f) atomic_add4(gP + (size_t)o.se * 4, f4_mul(gp, o.wse));
+    if (o.wl0 != 0.f) atomic_add4(gL + (size_t)o.l0 * 4, f4_mul(gl, o.wl0));
+    if (o.wl1 != 0.f) atomic_add4(gL + (size_t)o.l1 * 4, f4_mul(gl, o.wl1));
+}
+
+struct BwdMarchArgs {
+    FieldDev F;
+    GradSet gden;
+    const float* rays; long long n_rays; int ray_stride; int n_samples; int npad;
+    const float* jitter; const float* sigma; const int4* ray_app; const float4* app_rgb; const float4* rgb_raw;
+    const float* d_rgb; const float* d_depth; const float* d_w;
+    float4* go;   // [rows] dL/d(pre-sigmoid rgb) per appearance row
+    unsigned list_cap; TilePrefix tp; int add_bg;
+};
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float* __restrict__ Sg = smem + (size_t)wid * 4 * a.npad;   // sigma
+    float* __restrict__ Al = Sg + a.npad;                       // alpha
+    float* __restrict__ Tw = Al + a.npad;                       // transmittance before the sample
+    float* __restrict__ Gw = Tw + a.npad;                       // dL/dw, later dL/dfeature
+    const FieldDev& F = a.F;
+    const long long r = (long long)blockIdx.x * 4 + wid;
+    if (r >= a.n_rays) return;
+    const int4 ra = a.ray_app[r];
+    const int first = ra.w & 2047, Lw = ra.w >> 11;
+    if (Lw <= 0) return;
+    const int N = a.n_samples;
+    const Ray ray = load_ray(F, a.rays + r * a.ray_stride, a.ray_stride);
+    const float u = TRAIN ? a.jitter[r] : 0.f;
+    // upstream gradients of this ray; clamp(0,1) passes gradient on the closed interval
+    const float4 rr = a.rgb_raw[r];
+    const float gr = (rr.x >= 0.f && rr.x <= 1.f) ? a.d_rgb[r * 3 + 0] : 0.f;
+    const float gg = (rr.y >= 0.f && rr.y <= 1.f) ? a.d_rgb[r * 3 + 1] : 0.f;
+    const float gb = (rr.z >= 0.f && rr.z <= 1.f) ? a.d_rgb[r * 3 + 2] : 0.f;
+    const float gd = a.d_depth[r];
+    const float bg = a.add_bg ? 1.f : 0.f;
+
+    // ---- forward recompute (same arithmetic as k_march pass C) + dL/dw ---------------------------------------------------
+    float carry = 1.f;
+    unsigned run = 0;
+    for (int base = 0; base < Lw; base += 64) {
+        const int j = base + lane, i = first + j;
+        float sg = 0.f, z = 0.f, dist = 0.f;
+        if (j < Lw) {
+            sg = a.sigma[r * N + i];
+            z = sample_z<TRAIN>(F, ray, i, u);
+            if (i < N - 1) dist = sample_z<TRAIN>(F, ray, i + 1, u) - z;
+        }
+        const float d = dist * F.dscale;
+        const float alpha = 1.f - expf((-sg) * d);
+        const float f = (1.f - alpha) + 1e-10f;
+        const float incl = wave_scan_mul(f, lane);
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.f;
+        const float T = carry * excl;
+        const float w = alpha * T;
+        carry = carry * __shfl(incl, 63);
+        const bool app = (j < Lw) & (w > F.thres);
+        const unsigned long long bal = __ballot(app);
+        float cr = 0.f, cg = 0.f, cb = 0.f;
+        if (app) {
+            const unsigned slot = (unsigned)ra.x + run + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+            const float4 c = a.app_rgb[slot];
+            cr = c.x; cg = c.y; cb = c.z;
+            // rgb = sigmoid(o): dL/do = dL/drgb * rgb (1 - rgb), dL/drgb_sample = g_c * w
+            a.go[slot_to_row(slot, a.list_cap, a.tp)] =
+                make_float4(gr * w * cr * (1.f - cr), gg * w * cg * (1.f - cg), gb * w * cb * (1.f - cb), 0.f);
+        }
+        run += (unsigned)__popcll(bal);
+        if (j < Lw) {
+            float G = gr * (cr - bg) + gg * (cg - bg) + gb * (cb - bg) + gd * (z - ray.last);
+            if (a.d_w) G += a.d_w[r * N + i];
+            Sg[j] = sg; Al[j] = alpha; Tw[j] = T; Gw[j] = G;
+        }
+    }
+    wave_lds_sync();
+
+    // ---- reverse scan: dL/dalpha_i = G_i T_i - (sum_{k>i} G_k w_k) / f_i ---------------------------------------------------
+    float suffix = 0.f;
+    const int nchunk = (Lw + 63) / 64;
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int j = c * 64 + lane, i = first + j;
+        float sg = 0.f, al = 0.f, T = 0.f, G = 0.f, dist = 0.f;
+        if (j < Lw) {
+            sg = Sg[j]; al = Al[j]; T = Tw[j]; G = Gw[j];
+            const float z = sample_z<TRAIN>(F, ray, i, u);
+            if (i < N - 1) dist = sample_z<TRAIN>(F, ray, i + 1, u) - z;
+        }
+        const float val = G * (al * T);
+        float s = val;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float t = __shfl_down(s, o);
+            if (lane + o < 64) s += t;
+        }
+        const float after = suffix + (s - val);
+        suffix += __shfl(s, 0);
+        if (j < Lw) {
+            const float f = (1.f - al) + 1e-10f;
+            const float dalpha = G * T - after / f;
+            const float dsigma = dalpha * (dist * F.dscale) * (1.f - al);
+            const float dact = F.act == T2N_ACT_RELU ? (sg > 0.f ? 1.f : 0.f) : (1.f - expf(-sg));
+            Gw[j] = dsigma * dact;
+        }
+    }
+    wave_lds_sync();
+
+    // ---- scatter: 4 lanes per sample (channel quads), same taps as the forward gather --------------------------------------
+    const int q = lane & 3, sl = lane >> 2;
+    for (int base = 0; base < Lw; base += 16) {
+        const int j = base + sl, i = first + j;
+        if (j < Lw) {
+            const float gf = Gw[j];
+            float xn, yn, zn;
+            const float z = sample_z<TRAIN>(F, ray, i, u);
+            const bool ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
+            if (ok && gf != 0.f) {
+                const float4 g4 = make_float4(gf, gf, gf, gf);
+                scatter_pair<0>(F.den, a.gden, 4, q, xn, yn, zn, g4);
+                scatter_pair<1>(F.den, a.gden, 4, q, xn, yn, zn, g4);
+                scatter_pair<2>(F.den, a.gden, 4, q, xn, yn, zn, g4);
+            }
+        }
+    }
+}
+
+// ---- layer 2 (3 outputs): VALU ------------------------------------------------------------------------------------------
+// go [rows,4], h1 [rows,128] -> g1 [rows,128] = (go W2) * [h1>0]; dW2[3,128] += go^T h1; db2[3] += colsum(go)
+__global__ __launch_bounds__(256) void k_bwd_l2(const float4* __restrict__ go, const float* __restrict__ h1, long long rows,
+                                                const float* __restrict__ w2, float* g1, float* dw2, float* db2) {
+    const int u = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const float w0 = w2[u], w1 = w2[128 + u], w2v = w2[256 + u];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    const long long r0 = (long long)blockIdx.x * 64 + half * 32;
+    for (int k = 0; k < 32; ++k) {
+        const long long r = r0 + k;
+        if (r >= rows) break;
+        const float4 g = go[r];
+        const float h = h1[r * 128 + u];
+        a0 = fmaf(g.x, h, a0); a1 = fmaf(g.y, h, a1); a2 = fmaf(g.z, h, a2);
+        s0 += g.x; s1 += g.y; s2 += g.z;
+        const float v = fmaf(g.z, w2v, fmaf(g.y, w1, g.x * w0));
+        g1[r * 128 + u] = h > 0.f ? v : 0.f;
+    }
+    if (dw2) { atomicAdd(&dw2[u], a0); atomicAdd(&dw2[128 + u], a1); atomicAdd(&dw2[256 + u], a2); }
+    if (db2 && u == 0) { atomicAdd(&db2[0], s0); atomicAdd(&db2[1], s1); atomicAdd(&db2[2], s2); }
+}
+
+// ---- fp32 MFMA GEMMs -----------------------------------------------------------------------------------------------------
+// C[M,N] += A^T B over a chunk of rows: A [rows, lda] (gradients), B [rows, ldb] (activations). One wave = one 32-column
+// block of N x all MB 32-row blocks of M x one row chunk; partial sums are added atomically into row-major C (ldc).
+template <int MB>
+__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                 long long rows, int M, int N, float* C, int ldc, int chunk_rows) {
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int NB = (N + 31) / 32;
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nb = (int)(gw % NB);
+    const long long r0 = (gw / NB) * chunk_rows;
+    if (r0 >= rows) return;
+    const long long r1 = (r0 + chunk_rows < rows) ? r0 + chunk_rows : rows;
+    const int col = nb * 32 + i;
+    const bool colok = col < N;
+    f32x16 acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = f32x16{0};
+    for (long long rr = r0; rr < r1; rr += 2) {
+        const long long r = rr + h;
+        const bool rok = r < r1;
+        const float b = (rok && colok) ? B[r * ldb + col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int mi = m * 32 + i;
+            const float av = (rok && mi < M) ? A[r * lda + mi] : 0.f;
+            acc[m] = mfma(av, b, acc[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = m * 32 + unit_of(v, h);
+            if (row < M && colok) atomicAdd(&C[(size_t)row * ldc + col], acc[m][v]);
+        }
+}
+
+// OUT[rows, N] = (IN[rows, K] W[K, N]) (* [ACT > 0] if ACT). One wave = 32 rows x up to 128 output columns (4 blocks);
+// rows sit on the MFMA N axis (lanes), output columns on M. ldo must be a multiple of 4 and >= round_up(N, 4).
+__global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ IN, int ldin, const float* __restrict__ W, int ldw,
+                                                 long long rows, int K, int N, const float* __restrict__ ACT, int ldact,
+                                                 float* OUT, int ldo) {
+    const int lane = threadIdx.x & 63, s = lane & 31, h = lane >> 5;
+    const int NG = (N + 127) / 128;
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ng = (int)(gw % NG);
+    const long long r0 = (gw / NG) * 32;
+    if (r0 >= rows) return;
+    const long long r = r0 + s;
+    const bool rok = r < rows;
+    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+    const int K2 = (K + 1) & ~1;
+    for (int k0 = 0; k0 < K2; k0 += 2) {
+        const int k = k0 + h;
+        const bool kok = k < K;
+        const float b = (rok && kok) ? IN[r * ldin + k] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int n = ng * 128 + m * 32 + s;
+            const float av = (kok && n < N) ? W[(size_t)k * ldw + n] : 0.f;
+            acc[m] = mfma(av, b, acc[m]);
+        }
+    }
+    if (!rok) return;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = ng * 128 + m * 32 + 8 * g + 4 * h;
+            if (n >= ldo) continue;
+            float4 v = make_float4(acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]);
+            if (ACT) {
+                const float4 t = *reinterpret_cast<const float4*>(ACT + r * ldact + n);
+                v.x = t.x > 0.f ? v.x : 0.f; v.y = t.y > 0.f ? v.y : 0.f; v.z = t.z > 0.f ? v.z : 0.f; v.w = t.w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(OUT + r * ldo + n) = v;
+        }
+}
+
+// db[n] += sum_rows G[rows, ld]
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ G, int ld, long long rows, int N, float* db, int chunk) {
+    const int n = threadIdx.x;
+    if (n >= N) return;
+    const long long r0 = (long long)blockIdx.x * chunk;
+    const long long r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
+    float s = 0.f;
+    for (long long r = r0; r < r1; ++r) s += G[r * ld + n];
+    atomicAdd(&db[n], s);
+}
+
+// positional encoding forward: feat [rows,32] -> x [rows,352] in the reference's column order (tensorBase.py:11-17)
+__global__ __launch_bounds__(256) void k_pe_fwd(const float* __restrict__ feat, long long rows, float* x) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long r = t / 32;
+    const int f = (int)(t % 32);
+    if (r >= rows) return;
+    float* xr = x + r * 352;
+    if (f == 31) xr[351] = 0.f;
+    if (f >= 27) return;
+    const float v = feat[r * 32 + f];
+    xr[f] = v;
+    float sc = 1.f;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        float sn, cs;
+        sincosf(v * sc, &sn, &cs);
+        xr[27 + f * 6 + q] = sn;
+        xr[189 + f * 6 + q] = cs;
+        sc *= 2.f;
+    }
+}
+
+// positional encoding backward: gx [rows,352], feat [rows,32] -> gf [rows,32]
+__global__ __launch_bounds__(256) void k_pe_bwd(const float* __restrict__ gx, const float* __restrict__ feat, long long rows, float* gf) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long r = t / 32;
+    const int f = (int)(t % 32);
+    if (r >= rows) return;
+    float g = 0.f;
+    if (f < 27) {
+        const float* gr = gx + r * 352;
+        const float v = feat[r * 32 + f];
+        g = gr[f];
+        float sc = 1.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            float sn, cs;
+            sincosf(v * sc, &sn, &cs);
+            g = fmaf(gr[27 + f * 6 + q] * sc, cs, g);
+            g = fmaf(-(gr[189 + f * 6 + q] * sc), sn, g);
+            sc *= 2.f;
+        }
+    }
+    gf[r * 32 + f] = g;
+}
+
+// appearance taps: re-gather and scatter-add with gX [rows,144]
+struct AppScatterArgs {
+    FieldDev F; GradSet gapp; const float4* app_pos; const unsigned* counters; unsigned list_cap; const float* gxapp;
+};
+template <int K>
+__device__ __forceinline__ void app_scatter_plane(const AppScatterArgs& a, int lane, unsigned base, unsigned count, unsigned row0) {
+    for (int it = 0; it < 6; ++it) {
+        const int item = it * 64 + lane;
+        const int s = item / 12, q = item - s * 12;
+        const unsigned idx = base + (unsigned)s;
+        if (idx < count) {
+            const float4 p = a.app_pos[idx];
+            const float4 g = *reinterpret_cast<const float4*>(a.gxapp + (size_t)(row0 + s) * 144 + K * 48 + q * 4);
+            if (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f) scatter_pair<K>(a.F.app, a.gapp, 12, q, p.x, p.y, p.z, g);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_bwd_app_scatter(const AppScatterArgs a) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned cnt_l = 0;
+    if (lane < kLists) { cnt_l = a.counters[lane]; if (cnt_l > a.list_cap) cnt_l = a.list_cap; }
+    unsigned incl = (cnt_l + 31u) / 32u;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const unsigned ntiles = __shfl(incl, kLists - 1);
+    for (unsigned tile = blockIdx.x * 4u + wid; tile < ntiles; tile += gridDim.x * 4u) {
+        const int li = (int)__popcll(__ballot((lane < kLists) & (incl <= tile)));
+        const unsigned before = li ? __shfl(incl, li - 1) : 0u;
+        const unsigned lbase = (unsigned)li * a.list_cap;
+        const unsigned base = lbase + (tile - before) * 32u;
+        const unsigned count = lbase + __shfl(cnt_l, li);
+        app_scatter_plane<0>(a, lane, base, count, tile * 32u);
+        app_scatter_plane<1>(a, lane, base, count, tile * 32u);
+        app_scatter_plane<2>(a, lane, base, count, tile * 32u);
+    }
+}
+
+// channel-last gradient buffer [HW][C] -> += reference layout [1,C,H,W]
+__global__ __launch_bounds__(256) void k_relayout_add(const float* __restrict__ src, float* dst, int C, long long HW) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= HW * C) return;
+    const long long c = t / HW, pix = t - c * HW;
+    dst[t] += src[pix * C + c];
+}
+
+struct BwdCarve { size_t x144, feat32, h0, h1, go, g1, g0, xpe, gx, gf, gxapp, total; };
+static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+static BwdCarve bwd_carve(int64_t rows) {
+    BwdCarve c;
+    size_t o = 0;
+    const size_t R = (size_t)rows;
+    c.x144 = o; o = al256(o + R * 144 * 4);
+    c.feat32 = o; o = al256(o + R * 32 * 4);
+    c.h0 = o; o = al256(o + R * 128 * 4);
+    c.h1 = o; o = al256(o + R * 128 * 4);
+    c.go = o; o = al256(o + R * 16);
+    c.g1 = o; o = al256(o + R * 128 * 4);
+    c.g0 = o; o = al256(o + R * 128 * 4);
+    c.xpe = o; o = al256(o + R * 352 * 4);
+    c.gx = o; o = al256(o + R * 352 * 4);
+    c.gf = o; o = al256(o + R * 32 * 4);
+    c.gxapp = o; o = al256(o + R * 144 * 4);
+    c.total = o;
+    return c;
+}
+
+static int ensure_grad_buffers(t2n_field* f) {
+    const int* g = f->desc.grid;
+    for (int k = 0; k < 3; ++k) {
+        const size_t HW = (size_t)g[mat1(k)] * g[mat0(k)], L = (size_t)g[vecm(k)];
+        if (!f->gbuf_den_plane[k]) T2N_HIP(hipMalloc((void**)&f->gbuf_den_plane[k], HW * 16 * 4));
+        if (!f->gbuf_den_line[k]) T2N_HIP(hipMalloc((void**)&f->gbuf_den_line[k], L * 16 * 4));
+        if (!f->gbuf_app_plane[k]) T2N_HIP(hipMalloc((void**)&f->gbuf_app_plane[k], HW * 48 * 4));
+        if (!f->gbuf_app_line[k]) T2N_HIP(hipMalloc((void**)&f->gbuf_app_line[k], L * 48 * 4));
+    }
+    return T2N_OK;
+}
+
+template <int MB>
+static void launch_gemm_tn(const float* A, int lda, const float* B, int ldb, long long rows, int M, int N, float* C, int ldc,
+                           hipStream_t s) {
+    const int chunk = 1024;
+    const long long waves = (long long)((N + 31) / 32) * ((rows + chunk - 1) / chunk);
+    hipLaunchKernelGGL((k_gemm_tn<MB>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, A, lda, B, ldb, rows, M, N, C, ldc, chunk);
+}
+static void launch_gemm_nn(const float* IN, int ldin, const float* W, int ldw, long long rows, int K, int N, const float* ACT,
+                           int ldact, float* OUT, int ldo, hipStream_t s) {
+    const long long waves = (long long)((N + 127) / 128) * ((rows + 31) / 32);
+    hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, IN, ldin, W, ldw, rows, K, N, ACT, ldact, OUT, ldo);
+}
+
+}  // namespace t2n
 
 using namespace t2n;
 
+static int read_counts(const void* fwd_ws, int64_t n_rays, int n_samples, hipStream_t s, unsigned counts[kLists], TilePrefix* tp,
+                       int64_t* rows) {
+    const Carve c = carve_workspace(n_rays, n_samples, true);
+    T2N_HIP(hipMemcpyAsync(counts, (const char*)fwd_ws + c.counters, sizeof(unsigned) * kLists, hipMemcpyDeviceToHost, s));
+    T2N_HIP(hipStreamSynchronize(s));
+    unsigned t = 0;
+    for (int l = 0; l < kLists; ++l) {
+        if (counts[l] > c.list_cap) counts[l] = c.list_cap;
+        if (tp) tp->t[l] = t;
+        t += (counts[l] + 31u) / 32u;
+    }
+    if (tp) tp->t[kLists] = t;
+    *rows = (int64_t)t * 32;
+    return T2N_OK;
+}
+
+extern "C" int t2n_render_ctx_rows(const void* fwd_workspace, int64_t n_rays, int n_samples, t2n_stream stream, int64_t* rows) {
+    if (!fwd_workspace || !rows || n_rays <= 0 || n_samples <= 0) { set_error("t2n_render_ctx_rows: bad argument"); return T2N_ERR_INVALID; }
+    unsigned counts[kLists];
+    return read_counts(fwd_workspace, n_rays, n_samples, (hipStream_t)stream, counts, nullptr, rows);
+}
+
+extern "C" size_t t2n_backward_workspace_bytes(int64_t rows) { return bwd_carve(rows < 32 ? 32 : rows).total; }
+
 extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
-                                   const float* jitter, const float* weights, const float* z_vals, const float* d_rgb,
-                                   const float* d_depth, const float* d_weights, const t2n_field_grads* g, void* workspace,
-                                   size_t workspace_bytes, t2n_stream stream) {
-    (void)f; (void)rays; (void)n_rays; (void)ray_stride; (void)n_samples; (void)flags; (void)jitter; (void)weights; (void)z_vals;
-    (void)d_rgb; (void)d_depth; (void)d_weights; (void)g; (void)workspace; (void)workspace_bytes; (void)stream;
-    set_error("t2n_render_backward: not implemented in this build");
-    return T2N_ERR_UNSUPPORTED;
+                                   const float* jitter, const float* d_rgb, const float* d_depth, const float* d_weights,
+                                   const t2n_field_grads* g, void* fwd_workspace, size_t fwd_workspace_bytes, void* bwd_workspace,
+                                   size_t bwd_workspace_bytes, t2n_stream stream) {
+    if (!f || !rays || !d_rgb || !d_depth || !g || !fwd_workspace || !bwd_workspace || n_rays <= 0 || ray_stride < 6) {
+        set_error("t2n_render_backward: bad argument");
+        return T2N_ERR_INVALID;
+    }
+    if (!f->uploaded) { set_error("t2n_render_backward: field has no uploaded parameters"); return T2N_ERR_STATE; }
+    if (f->desc.shading != T2N_SHADE_MLP_FEA_NOVIEW) { set_error("t2n_render_backward: only the MLP_Fea_noview head is differentiable"); return T2N_ERR_UNSUPPORTED; }
+    if (!(flags & T2N_FLAG_KEEP_CTX)) { set_error("t2n_render_backward: forward was not run with T2N_FLAG_KEEP_CTX"); return T2N_ERR_STATE; }
+    if ((flags & T2N_FLAG_TRAIN) && !jitter) { set_error("t2n_render_backward: train mode needs the jitter draws"); return T2N_ERR_INVALID; }
+    if (n_samples > 1024) { set_error("t2n_render_backward: n_samples %d > 1024", n_samples); return T2N_ERR_UNSUPPORTED; }
+    const Carve c = carve_workspace(n_rays, n_samples, true);
+    if (c.total > fwd_workspace_bytes) { set_error("t2n_render_backward: forward workspace too small"); return T2N_ERR_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    unsigned counts[kLists];
+    TilePrefix tp;
+    int64_t rows = 0;
+    int rc = read_counts(fwd_workspace, n_rays, n_samples, s, counts, &tp, &rows);
+    if (rc) return rc;
+    const int64_t rows_alloc = rows < 32 ? 32 : rows;
+    const BwdCarve b = bwd_carve(rows_alloc);
+    if (b.total > bwd_workspace_bytes) { set_error("t2n_render_backward: backward workspace %zu B < %zu B", bwd_workspace_bytes, b.total); return T2N_ERR_WORKSPACE; }
+    if ((rc = ensure_grad_buffers(f))) return rc;
+
+    char* fw = (char*)fwd_workspace;
+    char* bw = (char*)bwd_workspace;
+    float* x144 = (float*)(bw + b.x144); float* feat32 = (float*)(bw + b.feat32); float* h0 = (float*)(bw + b.h0);
+    float* h1 = (float*)(bw + b.h1); float4* go = (float4*)(bw + b.go); float* g1 = (float*)(bw + b.g1); float* g0 = (float*)(bw + b.g0);
+    float* xpe = (float*)(bw + b.xpe); float* gx = (float*)(bw + b.gx); float* gf = (float*)(bw + b.gf); float* gxapp = (float*)(bw + b.gxapp);
+    const float4* app_pos = (const float4*)(fw + c.app_pos);
+    const int* app_ray = (const int*)(fw + c.app_ray);
+    float4* app_rgb = (float4*)(fw + c.app_rgb);
+    const unsigned* counters = (const unsigned*)(fw + c.counters);
+
+    const int* gr = f->desc.grid;
+    for (int k = 0; k < 3; ++k) {
+        const size_t HW = (size_t)gr[mat1(k)] * gr[mat0(k)], L = (size_t)gr[vecm(k)];
+        T2N_HIP(hipMemsetAsync(f->gbuf_den_plane[k], 0, HW * 16 * 4, s));
+        T2N_HIP(hipMemsetAsync(f->gbuf_den_line[k], 0, L * 16 * 4, s));
+        T2N_HIP(hipMemsetAsync(f->gbuf_app_plane[k], 0, HW * 48 * 4, s));
+        T2N_HIP(hipMemsetAsync(f->gbuf_app_line[k], 0, L * 48 * 4, s));
+    }
+    T2N_HIP(hipMemsetAsync(go, 0, (size_t)rows_alloc * 16, s));
+
+    // 1. appearance forward recompute with activations kept
+    timing_begin(f, T2N_K_BWD_MLP, s);
+    if (rows > 0) {
+        ShadeCtx ctx{x144, feat32, h0, h1};
+        if ((rc = launch_shade_list(f, app_pos, app_ray, rays, ray_stride, counters, c.list_cap, app_rgb, &ctx, s))) return rc;
+    }
+    timing_end(f, T2N_K_BWD_MLP, s);
+
+    // 2. per-ray backward + density scatter
+    {
+        BwdMarchArgs a;
+        a.F = f->dev;
+        for (int k = 0; k < 3; ++k) { a.gden.plane[k] = f->gbuf_den_plane[k]; a.gden.line[k] = f->gbuf_den_line[k]; }
+        a.rays = rays; a.n_rays = n_rays; a.ray_stride = ray_stride; a.n_samples = n_samples; a.npad = (n_samples + 63) & ~63;
+        a.jitter = jitter; a.sigma = (const float*)(fw + c.sigma); a.ray_app = (const int4*)(fw + c.ray_app);
+        a.app_rgb = app_rgb; a.rgb_raw = (const float4*)(fw + c.rgb_raw);
+        a.d_rgb = d_rgb; a.d_depth = d_depth; a.d_w = d_weights; a.go = go; a.list_cap = c.list_cap; a.tp = tp;
+        a.add_bg = (flags & T2N_FLAG_ADD_BG) ? 1 : 0;
+        const size_t lds = (size_t)4 * 4 * a.npad * sizeof(float);
+        const unsigned nb = (unsigned)((n_rays + 3) / 4);
+        timing_begin(f, T2N_K_BWD_MARCH, s);
+        if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true>), dim3(nb), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_bwd_march<false>), dim3(nb), dim3(256), lds, s, a);
+        timing_end(f, T2N_K_BWD_MARCH, s);
+        T2N_HIP(hipGetLastError());
+    }
+
+    if (rows > 0) {
+        const t2n_field_params* P = &f->params_ref;
+        timing_begin(f, T2N_K_BWD_MLP, s);
+        // 3. layer 2
+        hipLaunchKernelGGL(k_bwd_l2, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, (const float4*)go, (const float*)h1,
+                           (long long)rows, P->mlp_w2, g1, g->mlp_w2, g->mlp_b2);
+        // 4. layers 1, 0, PE, basis
+        if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, s);
+        if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 2047) / 2048)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 2048);
+        launch_gemm_nn(g1, 128, P->mlp_w1, 128, rows, 128, 128, h0, 128, g0, 128, s);
+        hipLaunchKernelGGL(k_pe_fwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)feat32, (long long)rows, xpe);
+        if (g->mlp_w0) launch_gemm_tn<4>(g0, 128, xpe, 352, rows, 128, 351, g->mlp_w0, 351, s);
+        if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 2047) / 2048)), dim3(256), 0, s, (const float*)g0, 128, (long long)rows, 128, g->mlp_b0, 2048);
+        launch_gemm_nn(g0, 128, P->mlp_w0, 351, rows, 128, 351, nullptr, 0, gx, 352, s);
+        hipLaunchKernelGGL(k_pe_bwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)gx, (const float*)feat32, (long long)rows, gf);
+        if (g->basis_weight) launch_gemm_tn<1>(gf, 32, x144, 144, rows, 27, 144, g->basis_weight, 144, s);
+        launch_gemm_nn(gf, 32, P->basis_weight, 144, rows, 27, 144, nullptr, 0, gxapp, 144, s);
+        timing_end(f, T2N_K_BWD_MLP, s);
+        T2N_HIP(hipGetLastError());
+        // 5. appearance scatter
+        AppScatterArgs sa;
+        sa.F = f->dev;
+        for (int k = 0; k < 3; ++k) { sa.gapp.plane[k] = f->gbuf_app_plane[k]; sa.gapp.line[k] = f->gbuf_app_line[k]; }
+        sa.app_pos = app_pos; sa.counters = counters; sa.list_cap = c.list_cap; sa.gxapp = gxapp;
+        unsigned blocks = (unsigned)((rows / 32 + 3) / 4);
+        if (blocks > 2048) blocks = 2048;
+        if (blocks == 0) blocks = 1;
+        timing_begin(f, T2N_K_BWD_SCATTER, s);
+        hipLaunchKernelGGL(k_bwd_app_scatter, dim3(blocks), dim3(256), 0, s, sa);
+        timing_end(f, T2N_K_BWD_SCATTER, s);
+        T2N_HIP(hipGetLastError());
+    }
+
+    // 6. channel-last gradient buffers -> += reference layouts
+    for (int k = 0; k < 3; ++k) {
+        const long long HW = (long long)gr[mat1(k)] * gr[mat0(k)], L = gr[vecm(k)];
+        if (g->density_plane[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((HW * 16 + 255) / 256)), dim3(256), 0, s, (const float*)f->gbuf_den_plane[k], g->density_plane[k], 16, HW);
+        if (g->density_line[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((L * 16 + 255) / 256)), dim3(256), 0, s, (const float*)f->gbuf_den_line[k], g->density_line[k], 16, L);
+        if (g->app_plane[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((HW * 48 + 255) / 256)), dim3(256), 0, s, (const float*)f->gbuf_app_plane[k], g->app_plane[k], 48, HW);
+        if (g->app_line[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((L * 48 + 255) / 256)), dim3(256), 0, s, (const float*)f->gbuf_app_line[k], g->app_line[k], 48, L);
+    }
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
 }

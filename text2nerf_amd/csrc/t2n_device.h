@@ -132,25 +132,40 @@ __device__ __forceinline__ void plane_line_coords(const float xn, const float yn
     if constexpr (K == 2) { gx = yn; gy = zn; gv = xn; }
 }
 
+// Tap addresses (in float4 units inside the channel-last plane / line of factor pair K) and interpolation weights.
+struct TapIdx {
+    unsigned nw, ne, sw, se, l0, l1;
+    float wnw, wne, wsw, wse, wl0, wl1;
+};
+
 template <int K>
-__device__ __forceinline__ void issue_taps(const FactorSet& S, int CQ, int q, float xn, float yn, float zn, QuadTaps& t) {
+__device__ __forceinline__ void compute_taps(const FactorSet& S, int CQ, int q, float xn, float yn, float zn, TapIdx& o) {
     float gx, gy, gv;
     plane_line_coords<K>(xn, yn, zn, gx, gy, gv);
     const Axis ax = axis_taps(gx, S.W[K]);
     const Axis ay = axis_taps(gy, S.H[K]);
     const Axis al = axis_taps(gv, S.L[K]);
+    const unsigned W = (unsigned)S.W[K];
+    const unsigned r0 = (unsigned)ay.i0 * W, r1 = (unsigned)ay.i1 * W;
+    o.nw = (r0 + (unsigned)ax.i0) * CQ + q;
+    o.ne = (r0 + (unsigned)ax.i1) * CQ + q;
+    o.sw = (r1 + (unsigned)ax.i0) * CQ + q;
+    o.se = (r1 + (unsigned)ax.i1) * CQ + q;
+    o.l0 = (unsigned)al.i0 * CQ + q;
+    o.l1 = (unsigned)al.i1 * CQ + q;
+    o.wnw = ay.w0 * ax.w0; o.wne = ay.w0 * ax.w1; o.wsw = ay.w1 * ax.w0; o.wse = ay.w1 * ax.w1;
+    o.wl0 = al.w0; o.wl1 = al.w1;
+}
+
+template <int K>
+__device__ __forceinline__ void issue_taps(const FactorSet& S, int CQ, int q, float xn, float yn, float zn, QuadTaps& t) {
+    TapIdx o;
+    compute_taps<K>(S, CQ, q, xn, yn, zn, o);
     const float4* __restrict__ P = reinterpret_cast<const float4*>(S.plane[K]);
     const float4* __restrict__ Ln = reinterpret_cast<const float4*>(S.line[K]);
-    const int W = S.W[K];
-    const size_t r0 = (size_t)ay.i0 * W, r1 = (size_t)ay.i1 * W;
-    t.nw = P[(r0 + ax.i0) * CQ + q];
-    t.ne = P[(r0 + ax.i1) * CQ + q];
-    t.sw = P[(r1 + ax.i0) * CQ + q];
-    t.se = P[(r1 + ax.i1) * CQ + q];
-    t.l0 = Ln[(size_t)al.i0 * CQ + q];
-    t.l1 = Ln[(size_t)al.i1 * CQ + q];
-    t.wnw = ay.w0 * ax.w0; t.wne = ay.w0 * ax.w1; t.wsw = ay.w1 * ax.w0; t.wse = ay.w1 * ax.w1;
-    t.wl0 = al.w0; t.wl1 = al.w1;
+    t.nw = P[o.nw]; t.ne = P[o.ne]; t.sw = P[o.sw]; t.se = P[o.se];
+    t.l0 = Ln[o.l0]; t.l1 = Ln[o.l1];
+    t.wnw = o.wnw; t.wne = o.wne; t.wsw = o.wsw; t.wse = o.wse; t.wl0 = o.wl0; t.wl1 = o.wl1;
 }
 
 __device__ __forceinline__ float4 taps_plane(const QuadTaps& t) {

@@ -56,6 +56,12 @@ struct t2n_field {
     float* buf_app_plane[3] = {nullptr, nullptr, nullptr};
     float* buf_app_line[3] = {nullptr, nullptr, nullptr};
     float* buf_mlp = nullptr;  // basisA | w0A | w1A | w2A
+    // channel-last gradient accumulators (backward), allocated on first use
+    float* gbuf_den_plane[3] = {nullptr, nullptr, nullptr};
+    float* gbuf_den_line[3] = {nullptr, nullptr, nullptr};
+    float* gbuf_app_plane[3] = {nullptr, nullptr, nullptr};
+    float* gbuf_app_line[3] = {nullptr, nullptr, nullptr};
+    t2n_field_params params_ref;   // reference-layout parameter pointers of the last upload (backward reads W^T operands)
     bool uploaded = false;
     int timing = 0;
     t2n::TimingSlot slots[T2N_K_COUNT];
@@ -85,6 +91,7 @@ struct RenderLaunch {
     const float* jitter; float* rgb; float* depth; float* weights; float* z_vals; uint64_t* stats;
     // workspace carve (one sub-launch)
     float* acc; int4* ray_app; unsigned* counters; float4* app_pos; int* app_ray; float4* app_rgb; unsigned list_cap;
+    float* sigma_ctx; float4* rgb_raw;   // KEEP_CTX only, else NULL
 };
 int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s);
 constexpr int kLists = 8;   // appearance sub-lists per sub-launch
@@ -93,8 +100,14 @@ inline unsigned list_capacity(long long n_rays, int n_samples) {
     const unsigned nblocks = (unsigned)((n_rays + 3) / 4);
     return ((nblocks >> 3) + ((nblocks & 7u) ? 1u : 0u)) * 4u * (unsigned)n_samples;
 }
+// Activation rows kept by the shade kernel in ctx mode (row = tile * 32 + lane sample; zero rows past a sub-list's end)
+struct ShadeCtx { float* x144; float* feat32; float* h0; float* h1; };
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
-                      const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, hipStream_t s);
+                      const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s);
+
+// forward-workspace carve shared by forward and backward (t2n_api.hip)
+struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, total; unsigned list_cap; };
+Carve carve_workspace(int64_t rays, int n_samples, bool ctx);
 int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s);
 
 }  // namespace t2n

@@ -26,6 +26,7 @@ struct MarchArgs {
     float* depth; float* acc; float* weights; float* z_vals;
     float4* app_pos; int* app_ray; int4* ray_app; unsigned* counters; unsigned list_cap;
     unsigned long long* stats;
+    float* sigma_ctx;    // [n_rays, n_samples] kept for the backward pass (KEEP_CTX) or NULL
     unsigned nblocks;
 };
 
@@ -101,7 +102,11 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
                 part = fmaf(p.x, l.x, part); part = fmaf(p.y, l.y, part); part = fmaf(p.z, l.z, part); part = fmaf(p.w, l.w, part);
             }
             const float feat = group_sum<LPS>(part);
-            if (q == 0 && j < Lw) sig[j] = ok ? feature2density(F, feat) : 0.f;
+            if (q == 0 && j < Lw) {
+                const float sg = ok ? feature2density(F, feat) : 0.f;
+                sig[j] = sg;
+                if (a.sigma_ctx) a.sigma_ctx[r * N + i] = sg;
+            }
         }
         // LDS window written by lanes of this wave only; a wave is in lock-step, but the compiler needs the fence.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
         if (napp) slot0 = atomicAdd(&a.counters[list], napp);
         const bool fits = slot0 + napp <= a.list_cap;
         slot0 += list * a.list_cap;
-        a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, (int)nvalid, 0);
+        a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, (int)nvalid, Lw > 0 ? (first | (Lw << 11)) : 0);
         a.acc[r] = acc;
         a.depth[r] = dep + (1.f - acc) * ray.last;   // :504-505
         if (!fits && a.stats) a.stats[T2N_STAT_OVERFLOW] = 1ull;   // cannot happen: list_cap is the worst case
@@ -191,6 +196,7 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
 // K3: per-ray composite of the shaded appearance samples, in sample order (models/tensorBase.py:494-501).
 struct CompositeArgs {
     long long n_rays; const int4* ray_app; const float4* app_pos; const float4* app_rgb; const float* acc; float* rgb;
+    float4* rgb_raw;   // pre-clamp colour kept for the backward pass, or NULL
     int add_bg;
 };
 __global__ __launch_bounds__(256) void k_composite(const CompositeArgs a) {
@@ -207,6 +213,7 @@ __global__ __launch_bounds__(256) void k_composite(const CompositeArgs a) {
         const float bg = 1.f - a.acc[r];
         cr += bg; cg += bg; cb += bg;
     }
+    if (a.rgb_raw) a.rgb_raw[r] = make_float4(cr, cg, cb, 0.f);
     a.rgb[r * 3 + 0] = fminf(fmaxf(cr, 0.f), 1.f);
     a.rgb[r * 3 + 1] = fminf(fmaxf(cg, 0.f), 1.f);
     a.rgb[r * 3 + 2] = fminf(fmaxf(cb, 0.f), 1.f);
@@ -315,6 +322,7 @@ int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
     a.depth = L.depth; a.acc = L.acc; a.weights = L.weights; a.z_vals = L.z_vals;
     a.app_pos = L.app_pos; a.app_ray = L.app_ray; a.ray_app = L.ray_app; a.counters = L.counters; a.list_cap = L.list_cap;
     a.stats = (unsigned long long*)L.stats;
+    a.sigma_ctx = L.sigma_ctx;
     a.nblocks = (unsigned)((L.n_rays + 3) / 4);
     const size_t lds = (size_t)4 * 2 * a.npad * sizeof(float);
     const bool train = (L.flags & T2N_FLAG_TRAIN) != 0;
@@ -335,7 +343,7 @@ int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
 
 int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
     CompositeArgs c;
-    c.n_rays = L.n_rays; c.ray_app = L.ray_app; c.app_pos = L.app_pos; c.app_rgb = L.app_rgb; c.acc = L.acc; c.rgb = L.rgb;
+    c.n_rays = L.n_rays; c.ray_app = L.ray_app; c.app_pos = L.app_pos; c.app_rgb = L.app_rgb; c.acc = L.acc; c.rgb = L.rgb; c.rgb_raw = L.rgb_raw;
     c.add_bg = (L.flags & T2N_FLAG_ADD_BG) ? 1 : 0;
     timing_begin(f, T2N_K_COMPOSITE, s);
     hipLaunchKernelGGL(k_composite, dim3((unsigned)((L.n_rays + 255) / 256)), dim3(256), 0, s, c);

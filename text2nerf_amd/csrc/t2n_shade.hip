@@ -50,11 +50,12 @@ struct ShadeArgs {
     const float* xyz; const float* viewdirs;      // explicit-point mode (t2n_shade_at): xyz [n,3], viewdirs [n,3] or null
     const unsigned* counters; unsigned list_cap; int nlists; unsigned count_max;   // list mode: counters[nlists]; point mode: count_max
     float4* app_rgb; float* feat_out; float* rgb_out;   // rgb_out: packed [n,3] (explicit-point mode)
+    ShadeCtx ctx;   // activation rows for the backward pass (all NULL in the normal forward)
 };
 
 template <int K>
 __device__ __forceinline__ void gather_plane(const FactorSet& S, float* __restrict__ X, int lane, const float4* pos_l,
-                                             const float* xyz, unsigned base, unsigned count) {
+                                             const float* xyz, unsigned base, unsigned count, float* ctx_x, unsigned row0) {
     constexpr int CQ = 12;   // 48 channels / 4
 #pragma unroll 2
     for (int it = 0; it < 6; ++it) {
@@ -73,6 +74,7 @@ __device__ __forceinline__ void gather_plane(const FactorSet& S, float* __restri
         }
         float* dst = X + (size_t)(K * 48 + q * 4) * kXld + s;
         dst[0] = v.x; dst[kXld] = v.y; dst[2 * kXld] = v.z; dst[3 * kXld] = v.w;
+        if (ctx_x) *reinterpret_cast<float4*>(ctx_x + (size_t)(row0 + s) * kAppK + K * 48 + q * 4) = v;
     }
 }
 
@@ -107,9 +109,10 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         const unsigned base = lbase + (tile - before) * 32u;
         const unsigned count = lbase + __shfl(cnt_l, li);      // one past the last live entry of this sub-list
         // ---- gather: plane x line products for 32 samples x 144 channels -> X ---------------------------------------
-        gather_plane<0>(F.app, X, lane, a.app_pos, a.xyz, base, count);
-        gather_plane<1>(F.app, X, lane, a.app_pos, a.xyz, base, count);
-        gather_plane<2>(F.app, X, lane, a.app_pos, a.xyz, base, count);
+        const unsigned row0 = tile * 32u;   // activation row of lane sample 0 (ctx mode)
+        gather_plane<0>(F.app, X, lane, a.app_pos, a.xyz, base, count, a.ctx.x144, row0);
+        gather_plane<1>(F.app, X, lane, a.app_pos, a.xyz, base, count, a.ctx.x144, row0);
+        gather_plane<2>(F.app, X, lane, a.app_pos, a.xyz, base, count, a.ctx.x144, row0);
         wave_lds_sync();
 
         // ---- basis_mat: feat[i][s] = sum_k Wb[i][k] X[k][s] ----------------------------------------------------------
@@ -127,6 +130,12 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
 
         const unsigned idx = base + (unsigned)s;
         const bool live = idx < count;
+        if (a.ctx.feat32) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(a.ctx.feat32 + (size_t)(row0 + s) * 32 + 8 * g + 4 * h) =
+                    make_float4(accb[4 * g], accb[4 * g + 1], accb[4 * g + 2], accb[4 * g + 3]);
+        }
         if (a.feat_out && live) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
@@ -177,6 +186,15 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) Hs[(ms * 32 + unit_of(v, h)) * kXld + s] = fmaxf(acc0[ms][v], 0.f);
             }
+            if (a.ctx.h0) {
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(a.ctx.h0 + (size_t)(row0 + s) * 128 + ms * 32 + 8 * g + 4 * h) =
+                            make_float4(fmaxf(acc0[ms][4 * g], 0.f), fmaxf(acc0[ms][4 * g + 1], 0.f),
+                                        fmaxf(acc0[ms][4 * g + 2], 0.f), fmaxf(acc0[ms][4 * g + 3], 0.f));
+            }
             wave_lds_sync();
             f32x16 acc1[4] = {{0}, {0}, {0}, {0}};
             {
@@ -199,6 +217,15 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
             for (int ms = 0; ms < 4; ++ms) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) Hs[(ms * 32 + unit_of(v, h)) * kXld + s] = fmaxf(acc1[ms][v], 0.f);
+            }
+            if (a.ctx.h1) {
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(a.ctx.h1 + (size_t)(row0 + s) * 128 + ms * 32 + 8 * g + 4 * h) =
+                            make_float4(fmaxf(acc1[ms][4 * g], 0.f), fmaxf(acc1[ms][4 * g + 1], 0.f),
+                                        fmaxf(acc1[ms][4 * g + 2], 0.f), fmaxf(acc1[ms][4 * g + 3], 0.f));
             }
             wave_lds_sync();
             f32x16 acc2 = {0};
@@ -329,9 +356,10 @@ static int shade_grid(unsigned long long count_max) {
 }
 
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
-                      const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, hipStream_t s) {
+                      const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s) {
     ShadeArgs a;
     memset(&a, 0, sizeof(a));
+    if (ctx) a.ctx = *ctx;
     a.F = f->dev;
     a.app_pos = app_pos; a.app_ray = app_ray; a.rays = rays; a.ray_stride = ray_stride;
     a.counters = counters_dev; a.list_cap = list_cap; a.nlists = kLists; a.app_rgb = app_rgb;

@@ -408,11 +408,13 @@ class TensorVMSplit(nn.Module):
         w = torch.empty(R, N, device=dev, dtype=torch.float32) if want_wz else None
         z = torch.empty(R, N, device=dev, dtype=torch.float32) if want_wz else None
         stats = torch.empty(_lib.T2N_STAT_COUNT, device=dev, dtype=torch.int64)
-        need = int(lib.t2n_render_workspace_bytes(max(R, 1), N))
-        ws = workspace(dev, need if keep_ctx else min(need, max(workspace_budget(),
-                                                                int(lib.t2n_render_workspace_bytes(1024, N)))))
         if keep_ctx:
+            # the kept context must survive until backward: a private buffer, not the shared scratch
+            ws = torch.empty(int(lib.t2n_render_workspace_bytes_ctx(R, N)), dtype=torch.uint8, device=dev)
             flags |= FLAG_KEEP_CTX
+        else:
+            need = int(lib.t2n_render_workspace_bytes(max(R, 1), N))
+            ws = workspace(dev, min(need, max(workspace_budget(), int(lib.t2n_render_workspace_bytes(1024, N)))))
         with torch.cuda.device(dev):
             _lib.check(lib.t2n_render_forward(h, _lib.ptr(rays), R, rays.shape[1], N, flags, _lib.ptr(jitter),
                                               _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(w), _lib.ptr(z),
@@ -420,6 +422,8 @@ class TensorVMSplit(nn.Module):
                                               _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr(dev)),
                        "t2n_render_forward")
         self.last_stats = stats
+        if keep_ctx:
+            return rgb, depth, z, w, ws
         return rgb, depth, z, w
 
     def stats(self):
@@ -431,20 +435,25 @@ class TensorVMSplit(nn.Module):
 
 
 class _RenderFn(torch.autograd.Function):
-    """Autograd bridge: forward = t2n_render_forward (context kept in the workspace), backward = t2n_render_backward."""
+    """Autograd bridge: forward = t2n_render_forward (context kept in a private workspace), backward =
+    t2n_render_backward. Gradients come back in the reference parameter layouts, so torch.optim / TVLoss see ordinary
+    dense .grad tensors."""
 
     @staticmethod
     def forward(ctx, field, rays, N, flags, jitter, *params):
-        rgb, depth, z, w = field._render_raw(rays, N, flags, jitter, True, keep_ctx=True)
-        ctx.field, ctx.N, ctx.flags = field, N, flags
-        ctx.save_for_backward(rays, jitter, w, z)
+        rgb, depth, z, w, ws = field._render_raw(rays, N, flags, jitter, True, keep_ctx=True)
+        ctx.field, ctx.N, ctx.flags, ctx.ws = field, N, flags | FLAG_KEEP_CTX, ws
+        ctx.key = field._uploaded_key
+        ctx.save_for_backward(rays, jitter)
         ctx.mark_non_differentiable(z)
         return rgb, depth, z, w
 
     @staticmethod
     def backward(ctx, d_rgb, d_depth, d_z, d_w):
         field = ctx.field
-        rays, jitter, w, z = ctx.saved_tensors
+        rays, jitter = ctx.saved_tensors
+        if field._uploaded_key != ctx.key:
+            raise T2NError("parameters changed between forward and backward")
         lib = _lib.load()
         dev = rays.device
         params = field._all_params()
@@ -454,11 +463,14 @@ class _RenderFn(torch.autograd.Function):
         d_rgb = torch.zeros(R, 3, device=dev) if d_rgb is None else d_rgb.contiguous().float()
         d_depth = torch.zeros(R, device=dev) if d_depth is None else d_depth.contiguous().float()
         d_w = None if d_w is None else d_w.contiguous().float()
-        ws = workspace(dev, int(lib.t2n_render_workspace_bytes(max(R, 1), ctx.N)))
+        st = _lib.current_stream_ptr(dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.t2n_render_backward(field._handle, _lib.ptr(rays), R, rays.shape[1], ctx.N,
-                                               ctx.flags | FLAG_KEEP_CTX, _lib.ptr(jitter), _lib.ptr(w), _lib.ptr(z),
-                                               _lib.ptr(d_rgb), _lib.ptr(d_depth), _lib.ptr(d_w), C.byref(gs),
-                                               _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr(dev)),
-                       "t2n_render_backward")
+            rows = C.c_int64(0)
+            _lib.check(lib.t2n_render_ctx_rows(_lib.ptr(ctx.ws), R, ctx.N, st, C.byref(rows)), "t2n_render_ctx_rows")
+            bws = torch.empty(int(lib.t2n_backward_workspace_bytes(rows.value)), dtype=torch.uint8, device=dev)
+            _lib.check(lib.t2n_render_backward(field._handle, _lib.ptr(rays), R, rays.shape[1], ctx.N, ctx.flags,
+                                               _lib.ptr(jitter), _lib.ptr(d_rgb), _lib.ptr(d_depth), _lib.ptr(d_w),
+                                               C.byref(gs), _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.ptr(bws), bws.numel(),
+                                               st), "t2n_render_backward")
+        ctx.ws = None
         return (None, None, None, None, None) + tuple(grads)
