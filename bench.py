@@ -45,7 +45,7 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=20.0):
     reference driver)."""
     from oracle import oracle_torch as O
     from text2nerf_amd import synth
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)   # more threads only add contention on these op sizes
     torch.set_num_threads(cores)
     cfg = O.FieldConfig(aabb=aabb, grid_size=[grid] * 3)
     P = O.params_from_numpy(params)
@@ -63,6 +63,51 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=20.0):
                       f"{torch.get_num_threads()} threads, {dt:.1f} s"}
 
 
+def train_bench(dev, iters=20, warmup=3):
+    """C3-shaped optimisation step (text2nerf_main.py:547-601): 16 384 random rays of 9 small-baseline 512x512 views,
+    N=259, is_train, MSE(rgb)+0.005 MSE(depth)+1e3 transmittance+TV(density 0.1, app 0.01), Adam(0.02/1e-3)."""
+    from text2nerf_amd import OctreeRender_trilinear_fast, synth
+    from text2nerf_amd.losses import TVLoss, TransMittanceLoss_mask
+    field, params, aabb = build_field(dev)
+    n_samples = min(int(1e6), int(synth.cal_n_samples([300] * 3, 1.0) / 2))          # text2nerf_main.py:439 -> 259
+    poses = synth.local_fixed_like_poses(9)
+    allrays = torch.from_numpy(np.concatenate([synth.frame_rays_np(512, 512, c2w=p) for p in poses]))   # CPU, like the driver
+    g = np.random.Generator(np.random.PCG64(1024))
+    allrgb = torch.from_numpy(g.uniform(0, 1, (allrays.shape[0], 3)).astype(np.float32))
+    alldepth = torch.from_numpy(g.uniform(2, 7, (allrays.shape[0],)).astype(np.float32))
+    opt = torch.optim.Adam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    tv, tl = TVLoss(), TransMittanceLoss_mask(dev)
+    np.random.seed(1024)
+    torch.manual_seed(1024)
+    batch = 16384
+    perm = torch.from_numpy(np.random.permutation(allrays.shape[0]))
+
+    def it(k):
+        idx = perm[(k * batch) % (perm.numel() - batch):][:batch]
+        rays, rgb_t, dep_t = allrays[idx], allrgb[idx].to(dev), alldepth[idx].to(dev)
+        rgb, _, depth, w, z = OctreeRender_trilinear_fast(rays, field, chunk=batch, N_samples=n_samples, white_bg=True,
+                                                          ndc_ray=False, device=dev, is_train=True)
+        loss = torch.mean((rgb - rgb_t) ** 2) + 0.005 * torch.mean((depth - dep_t) ** 2)
+        loss = loss + 1e3 * tl(w, (z - dep_t[:, None] + 0.1) < 0)
+        loss = loss + field.TV_loss_density(tv) * 0.1 + field.TV_loss_app(tv) * 0.01
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for k in range(warmup):
+        it(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(iters):
+        loss = it(warmup + k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"train_iters_per_s": iters / dt, "train_ms_per_iter": dt / iters * 1e3, "train_iters": iters,
+            "train_step": f"C3-shaped: {batch} rays x {n_samples} samples, fwd+bwd HIP, TV+Adam torch, loss {float(loss):.4f}",
+            "train_appearance_samples": field.stats()["appearance"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +116,7 @@ def main():
     ap.add_argument("--scene", default="S1-soft")
     ap.add_argument("--weights", type=int, default=0, help="1: also materialise weights/z_vals [R,N] like the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the C3-shaped train-step timing (iters/s)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,7 +154,7 @@ def main():
                 return all_gather_tiles(torch.cat([rgb, depth[:, None]], 1))
             return rgb
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):   # at least one untimed frame: allocations + the per-frame sample counters
         step()
     st = field.stats()
     field.timing(True)
@@ -142,7 +188,7 @@ def main():
         launches = max(k_per_step.get(dom, 1.0), 1.0)
         achieved = (alg[dom] / launches) / (k_ms[dom] * 1e-3) / 1e9 if dom in k_ms else None
         out = {
-            "metric": "ray-samples/s (render), 300^3 VM-split, 800x800",
+            "metric": "ray-samples/s (render) + iters/s (train), 300^3 VM-split, 800x800",
             "value": nominal, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
@@ -159,6 +205,9 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                          "algorithmic_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": k_ms.get(dom)},
         }
+        if world == 1 and not args.no_train:
+            del rays
+            out["config"].update(train_bench(dev))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, aabb, 300, N)
         print(json.dumps(out))

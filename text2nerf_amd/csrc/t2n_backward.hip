@@ -33,32 +33,31 @@ __device__ __forceinline__ unsigned slot_to_row(unsigned slot, unsigned list_cap
     return tp.t[l] * 32u + (slot - l * list_cap);
 }
 
-__device__ __forceinline__ void atomic_add4(float* p, float4 v) {
-    atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
-}
-
-// Scatter d(feature)/d(plane taps, line taps) for factor pair K: value quads P (plane) and L (line) are re-gathered.
+// Scatter d(feature)/d(plane taps, line taps) for factor pair K, ONE CHANNEL PER LANE: the 16 lanes of a sample cover 16
+// consecutive channels = one 64-B line per tap, so every atomic instruction touches 4 lines x 16 lanes (a 4-lane/float4
+// mapping would visit each line four times). `coff` = channel index of this lane inside the C-channel texel, `g` =
+// dL/d(P_c * L_c) for that channel. Value taps are re-gathered (scalar, coalesced per 16 lanes).
 template <int K>
-__device__ __forceinline__ void scatter_pair(const FactorSet& S, const GradSet& G, int CQ, int q, float xn, float yn, float zn,
-                                             float4 g /* dL/d(P*L) per channel */) {
+__device__ __forceinline__ void scatter_chan(const FactorSet& S, const GradSet& G, int C, int coff, float xn, float yn, float zn,
+                                             float g) {
     TapIdx o;
-    compute_taps<K>(S, CQ, q, xn, yn, zn, o);
-    const float4* __restrict__ P = reinterpret_cast<const float4*>(S.plane[K]);
-    const float4* __restrict__ Ln = reinterpret_cast<const float4*>(S.line[K]);
-    QuadTaps t;
-    t.nw = P[o.nw]; t.ne = P[o.ne]; t.sw = P[o.sw]; t.se = P[o.se]; t.l0 = Ln[o.l0]; t.l1 = Ln[o.l1];
-    t.wnw = o.wnw; t.wne = o.wne; t.wsw = o.wsw; t.wse = o.wse; t.wl0 = o.wl0; t.wl1 = o.wl1;
-    const float4 pv = taps_plane(t), lv = taps_line(t);
-    const float4 gp = make_float4(g.x * lv.x, g.y * lv.y, g.z * lv.z, g.w * lv.w);   // dL/dP
-    const float4 gl = make_float4(g.x * pv.x, g.y * pv.y, g.z * pv.z, g.w * pv.w);   // dL/dL
+    compute_taps<K>(S, C / 4, 0, xn, yn, zn, o);   // float4-unit offsets of channel 0 of each tap
+    const float* __restrict__ P = S.plane[K];
+    const float* __restrict__ Ln = S.line[K];
+    const unsigned nw = o.nw * 4 + coff, ne = o.ne * 4 + coff, sw = o.sw * 4 + coff, se = o.se * 4 + coff;
+    const unsigned l0 = o.l0 * 4 + coff, l1 = o.l1 * 4 + coff;
+    float pv = P[nw] * o.wnw;
+    pv = fmaf(P[ne], o.wne, pv); pv = fmaf(P[sw], o.wsw, pv); pv = fmaf(P[se], o.wse, pv);
+    const float lv = fmaf(Ln[l1], o.wl1, Ln[l0] * o.wl0);
+    const float gp = g * lv, gl = g * pv;
     float* gP = G.plane[K];
     float* gL = G.line[K];
-    if (o.wnw != 0.f) atomic_add4(gP + (size_t)o.nw * 4, f4_mul(gp, o.wnw));
-    if (o.wne != 0.f) atomic_add4(gP + (size_t)o.ne * 4, f4_mul(gp, o.wne));
-    if (o.wsw != 0.f) atomic_add4(gP + (size_t)o.sw * 4, f4_mul(gp, o.wsw));
-    if (o.wse != 0.f) atomic_add4(gP + (size_t)o.se * 4, f4_mul(gp, o.wse));
-    if (o.wl0 != 0.f) atomic_add4(gL + (size_t)o.l0 * 4, f4_mul(gl, o.wl0));
-    if (o.wl1 != 0.f) atomic_add4(gL + (size_t)o.l1 * 4, f4_mul(gl, o.wl1));
+    if (o.wnw != 0.f) atomicAdd(gP + nw, gp * o.wnw);
+    if (o.wne != 0.f) atomicAdd(gP + ne, gp * o.wne);
+    if (o.wsw != 0.f) atomicAdd(gP + sw, gp * o.wsw);
+    if (o.wse != 0.f) atomicAdd(gP + se, gp * o.wse);
+    if (o.wl0 != 0.f) atomicAdd(gL + l0, gl * o.wl0);
+    if (o.wl1 != 0.f) atomicAdd(gL + l1, gl * o.wl1);
 }
 
 struct BwdMarchArgs {
@@ -166,9 +165,9 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
     }
     wave_lds_sync();
 
-    // ---- scatter: 4 lanes per sample (channel quads), same taps as the forward gather --------------------------------------
-    const int q = lane & 3, sl = lane >> 2;
-    for (int base = 0; base < Lw; base += 16) {
+    // ---- scatter: 16 lanes per sample (one channel each), 4 samples per step ---------------------------------------------
+    const int ch = lane & 15, sl = lane >> 4;
+    for (int base = 0; base < Lw; base += 4) {
         const int j = base + sl, i = first + j;
         if (j < Lw) {
             const float gf = Gw[j];
@@ -176,10 +175,9 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
             const float z = sample_z<TRAIN>(F, ray, i, u);
             const bool ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
             if (ok && gf != 0.f) {
-                const float4 g4 = make_float4(gf, gf, gf, gf);
-                scatter_pair<0>(F.den, a.gden, 4, q, xn, yn, zn, g4);
-                scatter_pair<1>(F.den, a.gden, 4, q, xn, yn, zn, g4);
-                scatter_pair<2>(F.den, a.gden, 4, q, xn, yn, zn, g4);
+                scatter_chan<0>(F.den, a.gden, 16, ch, xn, yn, zn, gf);
+                scatter_chan<1>(F.den, a.gden, 16, ch, xn, yn, zn, gf);
+                scatter_chan<2>(F.den, a.gden, 16, ch, xn, yn, zn, gf);
             }
         }
     }
@@ -350,14 +348,18 @@ struct AppScatterArgs {
 };
 template <int K>
 __device__ __forceinline__ void app_scatter_plane(const AppScatterArgs& a, int lane, unsigned base, unsigned count, unsigned row0) {
-    for (int it = 0; it < 6; ++it) {
-        const int item = it * 64 + lane;
-        const int s = item / 12, q = item - s * 12;
+    const int ch = lane & 15, sl = lane >> 4;
+    for (int s0 = 0; s0 < 32; s0 += 4) {
+        const int s = s0 + sl;
         const unsigned idx = base + (unsigned)s;
         if (idx < count) {
             const float4 p = a.app_pos[idx];
-            const float4 g = *reinterpret_cast<const float4*>(a.gxapp + (size_t)(row0 + s) * 144 + K * 48 + q * 4);
-            if (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f) scatter_pair<K>(a.F.app, a.gapp, 12, q, p.x, p.y, p.z, g);
+            const float* gr = a.gxapp + (size_t)(row0 + s) * 144 + K * 48 + ch;
+#pragma unroll
+            for (int cg = 0; cg < 3; ++cg) {
+                const float g = gr[cg * 16];
+                if (g != 0.f) scatter_chan<K>(a.F.app, a.gapp, 48, cg * 16 + ch, p.x, p.y, p.z, g);
+            }
         }
     }
 }
