@@ -47,7 +47,9 @@ enum { T2N_ACT_SOFTPLUS = 0, T2N_ACT_RELU = 1 };
 enum {
     T2N_FLAG_TRAIN = 1u,      /* is_train: per-ray jitter, no z gate (models/tensorBase.py:314-316,459) */
     T2N_FLAG_ADD_BG = 2u,     /* rgb_map += 1-acc  (white_bg, or the train-time coin; models/tensorBase.py:497-498) */
-    T2N_FLAG_KEEP_CTX = 4u    /* keep the per-call context in the workspace for t2n_render_backward */
+    T2N_FLAG_KEEP_CTX = 4u,   /* keep the per-call context in the workspace for t2n_render_backward */
+    T2N_FLAG_COHERENT = 8u    /* hint: consecutive rays are neighbouring pixels (image order): evaluate density 16 rays at a
+                                 time with LDS-staged shared taps. Results are bitwise identical with or without the hint */
 };
 
 /* Scalars of TensorBase.__init__/update_stepSize (models/tensorBase.py:163-231), computed by the host mirror. */
@@ -114,6 +116,11 @@ int t2n_field_destroy(t2n_field* f);
 int t2n_field_upload(t2n_field* f, const t2n_field_params* p, t2n_stream stream);
 /* Update scalars only (step size, near/far, ...): TensorBase.update_stepSize (models/tensorBase.py:220-231). */
 int t2n_field_set_desc(t2n_field* f, const t2n_field_desc* desc);
+/* Arithmetic of the basis/MLP contractions (nn.Linear in the reference, models/tensoRF.py:239, tensorBase.py:94-106):
+ * exact_fp32 = 0 (default): every fp32 product as three f16 MFMA products of hi/lo splits (22-bit mantissa), fp32
+ * accumulation; exact_fp32 = 1: v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains (5x the matrix-core time). The backward
+ * pass always recomputes activations with the exact path. */
+int t2n_field_set_mlp_precision(t2n_field* f, int exact_fp32);
 
 /* ---- a-1/a-2: get_ray_directions (dataLoader/ray_utils.py:24-42), normalisation (dataLoader/scene_gen.py:45),
  *      get_rays (dataLoader/ray_utils.py:66-87) */
@@ -177,7 +184,7 @@ int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray
  * the launch stream. t2n_timing_read synchronises those events and returns accumulated milliseconds and launch counts
  * per kernel since the last reset. Kernel ids: */
 enum { T2N_K_MARCH = 0, T2N_K_SHADE = 1, T2N_K_COMPOSITE = 2, T2N_K_UPLOAD = 3, T2N_K_BWD_MARCH = 4, T2N_K_BWD_MLP = 5,
-       T2N_K_BWD_SCATTER = 6, T2N_K_COUNT = 8 };
+       T2N_K_BWD_SCATTER = 6, T2N_K_DENSITY = 7, T2N_K_COUNT = 8 };
 int t2n_timing_enable(t2n_field* f, int on);
 int t2n_timing_read(t2n_field* f, double* ms /*[T2N_K_COUNT]*/, int64_t* launches /*[T2N_K_COUNT]*/, int reset);
 

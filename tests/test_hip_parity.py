@@ -85,12 +85,21 @@ def test_g4_raw2alpha(tiny):
     close(bg, tiny["g4_bg"], atol=5e-7, rtol=1e-5)
 
 
-def test_g5_appearance_mlp(tiny, field):
+@pytest.mark.parametrize("exact", [False, True])
+def test_g5_appearance_mlp(tiny, field, exact):
+    """basis_mat + PE + MLP on the matrix cores: default = f16 two-way-split products (22-bit mantissa, fp32 accumulate),
+    exact = fp32 MFMA. Both must sit far inside the 1e-4 RGB budget."""
     xyz = torch.from_numpy(tiny["g3_xyz"][:1024]).to(dev())
-    feat, rgb = field.shade(xyz)
-    close(feat, tiny["g5_appfeat"], atol=5e-6, rtol=1e-5, msg="app features (gather + basis_mat)")
-    close(rgb, tiny["g5_rgb_mlp"], atol=2e-5, msg="PE + MLP + sigmoid")
-    close(field.compute_appfeature(xyz[:77]), tiny["g5_appfeat"][:77], atol=5e-6, rtol=1e-5)   # ragged tile
+    field.mlp_exact_fp32 = exact
+    try:
+        feat, rgb = field.shade(xyz)
+        close(feat, tiny["g5_appfeat"], atol=5e-6, rtol=1e-5, msg="app features (gather + basis_mat)")
+        close(rgb, tiny["g5_rgb_mlp"], atol=1e-5 if not exact else 2e-6, msg="PE + MLP + sigmoid")
+        close(field.compute_appfeature(xyz[:77]), tiny["g5_appfeat"][:77], atol=5e-6, rtol=1e-5)   # ragged tile
+        err = float((rgb.cpu() - torch.from_numpy(tiny["g5_rgb_mlp"])).abs().max())
+        print(f"MLP head max |rgb - reference| ({'fp32 MFMA' if exact else 'f16x2 split'}): {err:.2e}")
+    finally:
+        field.mlp_exact_fp32 = False
 
 
 def test_g5_sh_head(tiny, tiny_params_sh):

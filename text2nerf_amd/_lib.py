@@ -10,10 +10,10 @@ LIB_PATH = os.path.join(_HERE, "libt2n_hip.so")
 
 T2N_STAT_COUNT = 8
 T2N_K_COUNT = 8
-KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_mlp", "bwd_scatter", "_7")
+KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_mlp", "bwd_scatter", "density")
 STAT_EVALUATED, STAT_APPEARANCE, STAT_RAYS, STAT_OVERFLOW = 0, 1, 2, 3
 
-FLAG_TRAIN, FLAG_ADD_BG, FLAG_KEEP_CTX = 1, 2, 4
+FLAG_TRAIN, FLAG_ADD_BG, FLAG_KEEP_CTX, FLAG_COHERENT = 1, 2, 4, 8
 SHADE_IDS = {"MLP_Fea_noview": 0, "SH": 1, "RGB": 2}
 ACT_IDS = {"softplus": 0, "relu": 1}
 
@@ -51,6 +51,7 @@ SIGNATURES = {
     "t2n_field_destroy": (C.c_int, [C.c_void_p]),
     "t2n_field_upload": (C.c_int, [C.c_void_p, C.POINTER(FieldParams), C.c_void_p]),
     "t2n_field_set_desc": (C.c_int, [C.c_void_p, C.POINTER(FieldDesc)]),
+    "t2n_field_set_mlp_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "t2n_ray_directions": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                      C.c_void_p, C.c_void_p]),
     "t2n_get_rays": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p,

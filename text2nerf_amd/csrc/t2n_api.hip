@@ -171,7 +171,7 @@ Carve carve_workspace(int64_t rays, int n_samples, bool ctx) {
     c.list_cap = list_capacity(rays, n_samples);
     const size_t cap = (size_t)c.list_cap * kLists;
     size_t o = 0;
-    c.counters = o; o = align_up(o + 256, 256);
+    c.counters = o; o = align_up(o + (size_t)kLists * kCounterStride * 4, 256);
     c.acc = o; o = align_up(o + (size_t)rays * 4, 256);
     c.ray_app = o; o = align_up(o + (size_t)rays * 16, 256);
     c.app_pos = o; o = align_up(o + cap * 16, 256);
@@ -182,7 +182,7 @@ Carve carve_workspace(int64_t rays, int n_samples, bool ctx) {
     c.total = o;
     return c;
 }
-static Carve carve(int64_t rays, int n_samples) { return carve_workspace(rays, n_samples, false); }
+static Carve carve(int64_t rays, int n_samples) { return carve_workspace(rays, n_samples, true); }
 
 }  // namespace t2n
 
@@ -225,6 +225,7 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
         if (f->gbuf_app_line[k]) (void)hipFree(f->gbuf_app_line[k]);
     }
     if (f->buf_mlp) (void)hipFree(f->buf_mlp);
+    if (f->buf_mlp_h) (void)hipFree(f->buf_mlp_h);
     for (int k = 0; k < T2N_K_COUNT; ++k)
         for (int i = 0; i < 64; ++i) {
             if (f->slots[k].start[i]) (void)hipEventDestroy(f->slots[k].start[i]);
@@ -301,6 +302,7 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     if (stats) T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s));
     if (n_rays == 0) return T2N_OK;
     const bool keep = (flags & T2N_FLAG_KEEP_CTX) != 0;
+    const bool coherent = (flags & T2N_FLAG_COHERENT) != 0 && !keep;
     if (keep) {
         if (carve_workspace(n_rays, n_samples, true).total > workspace_bytes || (uint64_t)list_capacity(n_rays, n_samples) * kLists > 0x7fffffffull) {
             set_error("t2n_render_forward: KEEP_CTX needs the whole call in one launch (workspace %zu B < %zu B)", workspace_bytes,
@@ -317,7 +319,7 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     char* ws = (char*)workspace;
     for (int64_t off = 0; off < n_rays; off += per) {
         const int64_t cnt = (n_rays - off) < per ? (n_rays - off) : per;
-        const Carve c = carve_workspace(per, n_samples, keep);
+        const Carve c = carve_workspace(per, n_samples, true);
         RenderLaunch L;
         L.rays = rays + off * ray_stride; L.n_rays = cnt; L.ray_stride = ray_stride; L.n_samples = n_samples; L.flags = flags;
         L.jitter = jitter ? jitter + off : nullptr;
@@ -330,12 +332,24 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         L.list_cap = c.list_cap;
         L.sigma_ctx = keep ? (float*)(ws + c.sigma) : nullptr;
         L.rgb_raw = keep ? (float4*)(ws + c.rgb_raw) : nullptr;
-        T2N_HIP(hipMemsetAsync(L.counters, 0, 256, s));
+        L.sigma_in = nullptr;
+        T2N_HIP(hipMemsetAsync(L.counters, 0, (size_t)kLists * kCounterStride * 4, s));
         int rc;
+        if (coherent) {
+            float* sg = (float*)(ws + c.sigma);
+            if ((rc = launch_density_tiles(f, L, sg, s))) return rc;
+            L.sigma_in = sg;
+        }
         if ((rc = launch_march(f, L, s))) return rc;
         if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, nullptr, s))) return rc;
         if ((rc = launch_composite(f, L, s))) return rc;
     }
+    return T2N_OK;
+}
+
+extern "C" int t2n_field_set_mlp_precision(t2n_field* f, int exact_fp32) {
+    if (!f) { set_error("t2n_field_set_mlp_precision: NULL field"); return T2N_ERR_INVALID; }
+    f->mlp_split = exact_fp32 ? 0 : 1;
     return T2N_OK;
 }
 

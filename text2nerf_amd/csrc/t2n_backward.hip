@@ -366,7 +366,7 @@ __device__ __forceinline__ void app_scatter_plane(const AppScatterArgs& a, int l
 __global__ __launch_bounds__(256) void k_bwd_app_scatter(const AppScatterArgs a) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     unsigned cnt_l = 0;
-    if (lane < kLists) { cnt_l = a.counters[lane]; if (cnt_l > a.list_cap) cnt_l = a.list_cap; }
+    if (lane < kLists) { cnt_l = a.counters[lane * kCounterStride]; if (cnt_l > a.list_cap) cnt_l = a.list_cap; }
     unsigned incl = (cnt_l + 31u) / 32u;
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) {
@@ -447,8 +447,10 @@ using namespace t2n;
 static int read_counts(const void* fwd_ws, int64_t n_rays, int n_samples, hipStream_t s, unsigned counts[kLists], TilePrefix* tp,
                        int64_t* rows) {
     const Carve c = carve_workspace(n_rays, n_samples, true);
-    T2N_HIP(hipMemcpyAsync(counts, (const char*)fwd_ws + c.counters, sizeof(unsigned) * kLists, hipMemcpyDeviceToHost, s));
+    unsigned raw[kLists * kCounterStride];
+    T2N_HIP(hipMemcpyAsync(raw, (const char*)fwd_ws + c.counters, sizeof(raw), hipMemcpyDeviceToHost, s));
     T2N_HIP(hipStreamSynchronize(s));
+    for (int l = 0; l < kLists; ++l) counts[l] = raw[l * kCounterStride];
     unsigned t = 0;
     for (int l = 0; l < kLists; ++l) {
         if (counts[l] > c.list_cap) counts[l] = c.list_cap;

@@ -36,6 +36,8 @@ struct FieldDev {
     const float* w0A;      // [196][4][64]
     const float* w1A;      // [65][4][64]
     const float* w2A;      // [65][64]
+    // split-f16 operands (t2n_shade.hip): uint4 = 8 halves per lane per (chunk, block, part)
+    const uint4* basisH; const uint4* w0H; const uint4* w1H; const uint4* w2H; const float* biasH;
 };
 
 struct TimingSlot {
@@ -56,6 +58,8 @@ struct t2n_field {
     float* buf_app_plane[3] = {nullptr, nullptr, nullptr};
     float* buf_app_line[3] = {nullptr, nullptr, nullptr};
     float* buf_mlp = nullptr;  // basisA | w0A | w1A | w2A
+    void* buf_mlp_h = nullptr; // split-f16 operands + scaled biases
+    int mlp_split = 1;         // 1: f16 two-way split products (default), 0: exact fp32 MFMA
     // channel-last gradient accumulators (backward), allocated on first use
     float* gbuf_den_plane[3] = {nullptr, nullptr, nullptr};
     float* gbuf_den_line[3] = {nullptr, nullptr, nullptr};
@@ -92,9 +96,12 @@ struct RenderLaunch {
     // workspace carve (one sub-launch)
     float* acc; int4* ray_app; unsigned* counters; float4* app_pos; int* app_ray; float4* app_rgb; unsigned list_cap;
     float* sigma_ctx; float4* rgb_raw;   // KEEP_CTX only, else NULL
+    const float* sigma_in;               // COHERENT: density precomputed by k_density_tiles, else NULL
 };
 int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s);
+int launch_density_tiles(t2n_field* f, const RenderLaunch& L, float* sigma, hipStream_t s);
 constexpr int kLists = 8;   // appearance sub-lists per sub-launch
+constexpr int kCounterStride = 64;   // unsigned words between sub-list counters: one 256-B line each (same-line atomics serialise)
 // list_cap(n_rays, N): worst-case entries of one sub-list = rays of the largest XCD run x samples
 inline unsigned list_capacity(long long n_rays, int n_samples) {
     const unsigned nblocks = (unsigned)((n_rays + 3) / 4);
@@ -107,7 +114,7 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
 
 // forward-workspace carve shared by forward and backward (t2n_api.hip)
 struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, total; unsigned list_cap; };
-Carve carve_workspace(int64_t rays, int n_samples, bool ctx);
+Carve carve_workspace(int64_t rays, int n_samples, bool ctx);   // ctx: also room for sigma [rays,N] and rgb_raw [rays]
 int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s);
 
 }  // namespace t2n

@@ -29,8 +29,19 @@ constexpr int kAppK = 144;               // 3 * 48
 constexpr int kTileFloats = kAppK * kXld;  // per wave
 constexpr int kPE = 6;
 constexpr int kL0Pairs = 14;
-constexpr int kL0Steps = kL0Pairs * (1 + 2 * kPE) + 1;   // 183
-constexpr int kL1Steps = 65, kL2Steps = 65, kBasisSteps = kAppK / 2;
+// K-step counts of the four contractions (2 input units per step) and their software-pipeline stages.
+// Layer 0 order: 14 raw-feature steps, then per feature pair 6 x (sin, cos) steps, then the bias step.
+constexpr int kBasisReal = kAppK / 2;                       // 72
+constexpr int kL0Real = kL0Pairs * (1 + 2 * kPE) + 1;        // 183 (incl. bias)
+constexpr int kL1Real = 65, kL2Real = 65;                    // 64 + bias
+constexpr int kKS1 = 8, kKS4 = 2;                            // K-steps per stage for 1-block / 4-block contractions
+constexpr int kBasisStages = 9, kL0Stages = 93, kL1Stages = 33, kL2Stages = 9;   // multiples of 3 (triple-buffered)
+constexpr int kPadStages = 2;                                // zero stages the prefetcher may over-read
+constexpr int kBasisSteps = (kBasisStages + kPadStages) * kKS1;
+constexpr int kL0Steps = (kL0Stages + kPadStages) * kKS4;
+constexpr int kL1Steps = (kL1Stages + kPadStages) * kKS4;
+constexpr int kL2Steps = (kL2Stages + kPadStages) * kKS1;
+static_assert(kBasisStages * kKS1 >= kBasisReal && kL0Stages * kKS4 >= kL0Real && kL1Stages * kKS4 >= kL1Real && kL2Stages * kKS1 >= kL2Real, "stages");
 
 __host__ __device__ constexpr int unit_of(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
 
@@ -42,6 +53,179 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Software-pipelined contraction: acc[m] += A_t,m x B_t over nstages*KS K-steps. The A operands (one dword per lane per
+// (step, block), contiguous) are prefetched two stages ahead into a rotating set of three register groups, so their L2
+// latency hides under the MFMAs of the stages in between (hipcc issues a load where it is written and waits at first use;
+// it does not pipeline across loop iterations by itself). `bf(t)` supplies the B operand of K-step t, called in order.
+template <int NMB, int KS, class BF>
+__device__ __forceinline__ void mfma_stream(f32x16 (&acc)[NMB], const float* __restrict__ ap, int nstages, BF& bf) {
+    constexpr int NR = NMB * KS;
+    float A0[NR], A1[NR], A2[NR];
+    auto fetch = [&](float (&A)[NR], int st) {
+        const float* p = ap + (size_t)st * NR * 64;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) A[i] = p[i * 64];
+    };
+    auto run = [&](const float (&A)[NR], int st) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const float b = bf(st * KS + k);
+#pragma unroll
+            for (int m = 0; m < NMB; ++m) acc[m] = mfma(A[k * NMB + m], b, acc[m]);
+        }
+    };
+    fetch(A0, 0);
+    fetch(A1, 1);
+#pragma unroll 1
+    for (int st = 0; st < nstages; st += 3) {
+        fetch(A2, st + 2); run(A0, st);
+        fetch(A0, st + 3); run(A1, st + 1);
+        fetch(A1, st + 4); run(A2, st + 2);
+    }
+}
+
+// B operand from the wave's LDS tile T[unit][kXld]: K-step t pairs units 2t (low half-wave) and 2t+1 (high half-wave);
+// step `nreal` is the bias step (B = 1 on the low half), later steps are zero padding.
+struct LdsB {
+    const float* base;   // T + h * kXld + s
+    int nreal, h;
+    __device__ __forceinline__ float operator()(int t) const {
+        if (t < nreal) return base[(size_t)2 * t * kXld];
+        return (t == nreal && h == 0) ? 1.f : 0.f;
+    }
+};
+struct LdsBNoBias {
+    const float* base;
+    int nreal;
+    __device__ __forceinline__ float operator()(int t) const { return t < nreal ? base[(size_t)2 * t * kXld] : 0.f; }
+};
+
+// B operand of layer 0: positional encoding generated on the fly from the feature tile Fe[32][kXld].
+struct PeB {
+    const float* fe;   // Fe + h * kXld + s  (feature 2r+h of this lane's sample at fe[2r * kXld])
+    int h;
+    float fv, cs, scale;
+    __device__ __forceinline__ float operator()(int t) {
+        if (t < kL0Pairs) return fe[(size_t)2 * t * kXld];
+        const int u = t - kL0Pairs;
+        if (u < kL0Pairs * 2 * kPE) {
+            const int j = u % (2 * kPE);
+            if (j == 0) { fv = fe[(size_t)2 * (u / (2 * kPE)) * kXld]; scale = 1.f; }
+            if ((j & 1) == 0) {
+                float sn;
+                sincosf(fv * scale, &sn, &cs);
+                scale *= 2.f;
+                return sn;
+            }
+            return cs;
+        }
+        return (u == kL0Pairs * 2 * kPE && h == 0) ? 1.f : 0.f;   // bias step, then zero padding
+    }
+};
+
+// ---- f16 two-way split contraction ------------------------------------------------------------------------------------
+// x = hi + lo with hi = f16(x), lo = f16(x - hi): 22 effective mantissa bits. a*b ~ ahi*bhi + ahi*blo + alo*bhi on
+// v_mfma_f32_32x32x16_f16 (fp32 accumulate): 3 x 32 cycles per 16 K-values against 8 x 64 for the fp32 MFMA, with a
+// relative product error ~2^-21 (the dropped lo*lo term). Weights are pre-split (and pre-scaled by 2^8 so their lo halves
+// stay in the f16 normal range) at upload; activations are split in registers. Lane (s, h) feeds K-values 8h..8h+7 of
+// every 16-value chunk.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr float kWScale = 256.f, kWUnscale = 1.f / 256.f;
+constexpr int kBasisChunks = 10, kL0Chunks = 24, kL1Chunks = 8, kL2Chunks = 8;   // even (double-buffered), zero-padded
+constexpr int kBasisChunksReal = 9, kL0ChunksReal = 23;
+
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 a = (_Float16)x[e];
+        hi[e] = a;
+        lo[e] = (_Float16)(x[e] - (float)a);
+    }
+}
+
+// acc[m] += W_chunk,m (split) x B_chunk (split on the fly); A operands double-buffered one chunk ahead.
+template <int NMB, class BF>
+__device__ __forceinline__ void f16_stream(f32x16 (&acc)[NMB], const uint4* __restrict__ ap, int nchunks, BF& bf) {
+    constexpr int NR = NMB * 2;
+    uint4 A0[NR], A1[NR];
+    auto fetch = [&](uint4 (&A)[NR], int c) {
+        const uint4* p = ap + (size_t)c * NR * 64;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) A[i] = p[i * 64];
+    };
+    auto run = [&](const uint4 (&A)[NR], int c) {
+        float x[8];
+        bf(c, x);
+        h8 bhi, blo;
+        split8(x, bhi, blo);
+#pragma unroll
+        for (int m = 0; m < NMB; ++m) {
+            const h8 ahi = __builtin_bit_cast(h8, A[2 * m]), alo = __builtin_bit_cast(h8, A[2 * m + 1]);
+            acc[m] = mfma16(ahi, bhi, acc[m]);
+            acc[m] = mfma16(ahi, blo, acc[m]);
+            acc[m] = mfma16(alo, bhi, acc[m]);
+        }
+    };
+    fetch(A0, 0);
+#pragma unroll 1
+    for (int c = 0; c < nchunks; c += 2) {
+        fetch(A1, c + 1); run(A0, c);
+        fetch(A0, c + 2); run(A1, c + 1);   // the last prefetch reads the zero pad chunk
+    }
+}
+
+// B chunk from the wave's LDS tile T[unit][kXld]
+struct LdsChunk {
+    const float* base;   // T + s
+    int h, nreal;
+    __device__ __forceinline__ void operator()(int c, float (&x)[8]) const {
+        if (c < nreal) {
+            const float* p = base + (size_t)(16 * c + 8 * h) * kXld;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = p[e * kXld];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = 0.f;
+        }
+    }
+};
+// B chunk of layer 0: chunks 0-1 raw features (32 rows of Fe, rows >= 27 are zero), chunks 2.. : (sin, cos) pairs
+// pi = f*6 + q in order, four pairs per half-wave per chunk.
+struct PeChunk {
+    const float* fe;   // Fe + s
+    int h;
+    __device__ __forceinline__ void operator()(int c, float (&x)[8]) const {
+        if (c < 2) {
+            const float* p = fe + (size_t)(16 * c + 8 * h) * kXld;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = p[e * kXld];
+        } else if (c < kL0ChunksReal) {
+            const int pi0 = 8 * (c - 2) + 4 * h;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int pi = pi0 + p;
+                const int f = (pi * 171) >> 10;          // pi / 6 for pi < 504
+                const int qo = pi - 6 * f;
+                const float v = fe[(size_t)f * kXld] * (float)(1 << qo);
+                sincosf(v, &x[2 * p], &x[2 * p + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = 0.f;
+        }
+    }
+};
+
+// accumulator init with the (pre-scaled) bias of block m: lane (s, h) register v <- bias[m*32 + unit_of(v, h)]
+__device__ __forceinline__ f32x16 bias_init(const float* __restrict__ bp, int m, int h) {
+    const float4* p = reinterpret_cast<const float4*>(bp + (size_t)(m * 2 + h) * 16);
+    const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    f32x16 r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    return r;
 }
 
 struct ShadeArgs {
@@ -80,6 +264,7 @@ __device__ __forceinline__ void gather_plane(const FactorSet& S, float* __restri
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -90,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
     // tile enumeration over the appearance sub-lists (list l occupies [l*list_cap, l*list_cap + counters[l]))
     unsigned cnt_l = 0;
     if (lane < a.nlists) {
-        cnt_l = a.counters ? a.counters[lane] : a.count_max;
+        cnt_l = a.counters ? a.counters[lane * kCounterStride] : a.count_max;
         if (a.counters && cnt_l > a.list_cap) cnt_l = a.list_cap;
     }
     unsigned incl = (cnt_l + 31u) / 32u;
@@ -116,13 +301,16 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         wave_lds_sync();
 
         // ---- basis_mat: feat[i][s] = sum_k Wb[i][k] X[k][s] ----------------------------------------------------------
-        f32x16 accb = {0};
-        {
-            const float* __restrict__ ap = F.basisA + lane;
-            const float* __restrict__ bp = X + (size_t)h * kXld + s;
-#pragma unroll 8
-            for (int t = 0; t < kBasisSteps; ++t) accb = mfma(ap[t * 64], bp[(size_t)2 * t * kXld], accb);
+        f32x16 accb1[1] = {{0}};
+        if constexpr (SPLIT) {
+            LdsChunk bf{X + s, h, kBasisChunksReal};
+            f16_stream<1>(accb1, F.basisH + lane, kBasisChunks, bf);
+            accb1[0] *= kWUnscale;
+        } else {
+            LdsBNoBias bf{X + (size_t)h * kXld + s, kBasisReal};
+            mfma_stream<1, kKS1>(accb1, F.basisA + lane, kBasisStages, bf);
         }
+        const f32x16 accb = accb1[0];
         wave_lds_sync();
 #pragma unroll
         for (int v = 0; v < 16; ++v) Fe[unit_of(v, h) * kXld + s] = accb[v];
@@ -148,35 +336,16 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         if (F.shading == T2N_SHADE_MLP_FEA_NOVIEW) {
             // ---- layer 0: PE on the fly, 4 M-blocks -------------------------------------------------------------------
             f32x16 acc0[4] = {{0}, {0}, {0}, {0}};
-            const float* __restrict__ wp = F.w0A + lane;
-#pragma unroll 1
-            for (int r = 0; r < kL0Pairs; ++r) {
-                const float fv = Fe[(2 * r + h) * kXld + s];
-                {
-                    const float a0 = wp[0], a1 = wp[64], a2 = wp[128], a3 = wp[192];
-                    acc0[0] = mfma(a0, fv, acc0[0]); acc0[1] = mfma(a1, fv, acc0[1]);
-                    acc0[2] = mfma(a2, fv, acc0[2]); acc0[3] = mfma(a3, fv, acc0[3]);
-                    wp += 256;
-                }
-                float scale = 1.f;
-#pragma unroll 1
-                for (int q = 0; q < kPE; ++q) {
-                    float sn, cs;
-                    sincosf(fv * scale, &sn, &cs);
-                    scale *= 2.f;
-                    const float a0 = wp[0], a1 = wp[64], a2 = wp[128], a3 = wp[192];
-                    const float c0 = wp[256], c1 = wp[320], c2 = wp[384], c3 = wp[448];
-                    acc0[0] = mfma(a0, sn, acc0[0]); acc0[1] = mfma(a1, sn, acc0[1]);
-                    acc0[2] = mfma(a2, sn, acc0[2]); acc0[3] = mfma(a3, sn, acc0[3]);
-                    acc0[0] = mfma(c0, cs, acc0[0]); acc0[1] = mfma(c1, cs, acc0[1]);
-                    acc0[2] = mfma(c2, cs, acc0[2]); acc0[3] = mfma(c3, cs, acc0[3]);
-                    wp += 512;
-                }
-            }
-            {   // bias step: B = 1 on the low half-wave
-                const float one = h == 0 ? 1.f : 0.f;
-                acc0[0] = mfma(wp[0], one, acc0[0]); acc0[1] = mfma(wp[64], one, acc0[1]);
-                acc0[2] = mfma(wp[128], one, acc0[2]); acc0[3] = mfma(wp[192], one, acc0[3]);
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc0[m] = bias_init(F.biasH, m, h);
+                PeChunk bf{Fe + s, h};
+                f16_stream<4>(acc0, F.w0H + lane, kL0Chunks, bf);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc0[m] *= kWUnscale;
+            } else {
+                PeB bf{Fe + (size_t)h * kXld + s, h, 0.f, 0.f, 1.f};
+                mfma_stream<4, kKS4>(acc0, F.w0A + lane, kL0Stages, bf);
             }
             // ---- layer 1: relu(h0) through LDS, 64 K-steps --------------------------------------------------------------
             float* __restrict__ Hs = X;
@@ -197,19 +366,16 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
             }
             wave_lds_sync();
             f32x16 acc1[4] = {{0}, {0}, {0}, {0}};
-            {
-                const float* __restrict__ p = F.w1A + lane;
-                const float* __restrict__ bp = Hs + (size_t)h * kXld + s;
-#pragma unroll 4
-                for (int t = 0; t < 64; ++t) {
-                    const float b = bp[(size_t)2 * t * kXld];
-                    acc1[0] = mfma(p[0], b, acc1[0]); acc1[1] = mfma(p[64], b, acc1[1]);
-                    acc1[2] = mfma(p[128], b, acc1[2]); acc1[3] = mfma(p[192], b, acc1[3]);
-                    p += 256;
-                }
-                const float one = h == 0 ? 1.f : 0.f;
-                acc1[0] = mfma(p[0], one, acc1[0]); acc1[1] = mfma(p[64], one, acc1[1]);
-                acc1[2] = mfma(p[128], one, acc1[2]); acc1[3] = mfma(p[192], one, acc1[3]);
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc1[m] = bias_init(F.biasH + 128, m, h);
+                LdsChunk bf{Hs + s, h, kL1Chunks};
+                f16_stream<4>(acc1, F.w1H + lane, kL1Chunks, bf);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc1[m] *= kWUnscale;
+            } else {
+                LdsB bf{Hs + (size_t)h * kXld + s, 64, h};
+                mfma_stream<4, kKS4>(acc1, F.w1A + lane, kL1Stages, bf);
             }
             // ---- layer 2 (3 live rows) ---------------------------------------------------------------------------------
             wave_lds_sync();   // h0 reads done
@@ -228,14 +394,17 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
                                         fmaxf(acc1[ms][4 * g + 2], 0.f), fmaxf(acc1[ms][4 * g + 3], 0.f));
             }
             wave_lds_sync();
-            f32x16 acc2 = {0};
-            {
-                const float* __restrict__ p = F.w2A + lane;
-                const float* __restrict__ bp = Hs + (size_t)h * kXld + s;
-#pragma unroll 8
-                for (int t = 0; t < 64; ++t) acc2 = mfma(p[t * 64], bp[(size_t)2 * t * kXld], acc2);
-                acc2 = mfma(p[64 * 64], h == 0 ? 1.f : 0.f, acc2);
+            f32x16 acc2a[1] = {{0}};
+            if constexpr (SPLIT) {
+                acc2a[0] = bias_init(F.biasH + 256, 0, h);
+                LdsChunk bf{Hs + s, h, kL2Chunks};
+                f16_stream<1>(acc2a, F.w2H + lane, kL2Chunks, bf);
+                acc2a[0] *= kWUnscale;
+            } else {
+                LdsB bf{Hs + (size_t)h * kXld + s, 64, h};
+                mfma_stream<1, kKS1>(acc2a, F.w2A + lane, kL2Stages, bf);
             }
+            const f32x16 acc2 = acc2a[0];
             cr = sigmoidf_(acc2[0]); cg = sigmoidf_(acc2[1]); cb = sigmoidf_(acc2[2]);   // rows 0..2 live on h == 0
         } else if (F.shading == T2N_SHADE_SH) {
             if (h == 0 && live) {
@@ -283,7 +452,7 @@ __global__ __launch_bounds__(256) void k_pack_mlp(const PackArgs a) {
     const int nb = kBasisSteps * 64, n0 = kL0Steps * 256, n1 = kL1Steps * 256, n2 = kL2Steps * 64;
     if (gid < nb) {
         const int t = gid / 64, l = gid % 64, i = l & 31, h = l >> 5;
-        a.basisA[gid] = i < a.app_dim ? a.basis[i * kAppK + 2 * t + h] : 0.f;
+        a.basisA[gid] = (t < kBasisReal && i < a.app_dim) ? a.basis[i * kAppK + 2 * t + h] : 0.f;
         return;
     }
     if (!a.has_mlp) return;
@@ -291,15 +460,16 @@ __global__ __launch_bounds__(256) void k_pack_mlp(const PackArgs a) {
     if (g < n0) {
         const int t = g / 256, mb = (g / 64) % 4, l = g % 64, i = l & 31, h = l >> 5;
         const int out = mb * 32 + i;
-        float v;
-        if (t == kL0Steps - 1) v = h == 0 ? a.b0[out] : 0.f;
-        else {
-            const int r = t / 13, j = t % 13;
+        float v = 0.f;
+        if (t < kL0Pairs) {                                   // raw feature steps
+            const int f = 2 * t + h;
+            if (f < 27) v = a.w0[out * 351 + f];
+        } else if (t < kL0Real - 1) {                          // (sin, cos) steps: reference columns 27 + f*6 + q / 189 + f*6 + q
+            const int u = t - kL0Pairs, r = u / (2 * kPE), j = u % (2 * kPE), q = j >> 1;
             const int f = 2 * r + h;
-            int col;
-            if (j == 0) col = f;
-            else { const int q = (j - 1) >> 1; col = ((j - 1) & 1) ? 27 + 27 * kPE + f * kPE + q : 27 + f * kPE + q; }
-            v = f < 27 ? a.w0[out * (27 + 2 * 27 * kPE) + col] : 0.f;
+            if (f < 27) v = a.w0[out * 351 + ((j & 1) ? 27 + 27 * kPE : 27) + f * kPE + q];
+        } else if (t == kL0Real - 1) {
+            v = h == 0 ? a.b0[out] : 0.f;
         }
         a.w0A[g] = v;
         return;
@@ -308,9 +478,9 @@ __global__ __launch_bounds__(256) void k_pack_mlp(const PackArgs a) {
     if (g < n1) {
         const int t = g / 256, mb = (g / 64) % 4, l = g % 64, i = l & 31, h = l >> 5;
         const int out = mb * 32 + i;
-        float v;
-        if (t == 64) v = h == 0 ? a.b1[out] : 0.f;
-        else v = a.w1[out * 128 + 2 * t + h];
+        float v = 0.f;
+        if (t < 64) v = a.w1[out * 128 + 2 * t + h];
+        else if (t == 64) v = h == 0 ? a.b1[out] : 0.f;
         a.w1A[g] = v;
         return;
     }
@@ -319,10 +489,84 @@ __global__ __launch_bounds__(256) void k_pack_mlp(const PackArgs a) {
         const int t = g / 64, l = g % 64, i = l & 31, h = l >> 5;
         float v = 0.f;
         if (i < 3) {
-            if (t == 64) v = h == 0 ? a.b2[i] : 0.f;
-            else v = a.w2[i * 128 + 2 * t + h];
+            if (t < 64) v = a.w2[i * 128 + 2 * t + h];
+            else if (t == 64) v = h == 0 ? a.b2[i] : 0.f;
         }
         a.w2A[g] = v;
+    }
+}
+
+// Split-f16 operand packing: for layer L, chunk c, block m, part p (0 hi, 1 lo), lane l: 8 halves = W[m*32 + (l&31)][k],
+// k = 16c + 8(l>>5) + e, scaled by 2^8. K orders: basis/layer1/layer2 natural; layer 0: 32 raw (27 real), then
+// (sin, cos) pairs pi = f*6 + q. Biases are stored as fp32 * 2^8 in accumulator order.
+__device__ __forceinline__ float l0_weight(const float* w0, int out, int k) {
+    if (k < 32) return k < 27 ? w0[out * 351 + k] : 0.f;
+    const int pi = (k - 32) >> 1, sc = (k - 32) & 1;
+    if (pi >= 162) return 0.f;
+    const int f = pi / 6, q = pi - 6 * f;
+    return w0[out * 351 + (sc ? 189 : 27) + f * 6 + q];
+}
+struct PackHArgs {
+    const float* basis; const float* w0; const float* b0; const float* w1; const float* b1; const float* w2; const float* b2;
+    _Float16* basisH; _Float16* w0H; _Float16* w1H; _Float16* w2H; float* biasH;
+    int app_dim, has_mlp;
+};
+__device__ __forceinline__ void store_split(_Float16* dst, float w, int part) {
+    const float x = w * kWScale;
+    const _Float16 hi = (_Float16)x;
+    *dst = part == 0 ? hi : (_Float16)(x - (float)hi);
+}
+__global__ __launch_bounds__(256) void k_pack_mlp_h(const PackHArgs a) {
+    // one thread per half element; element index -> (layer, chunk, block, part, lane, e)
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nb = (long long)(kBasisChunks + 1) * 1 * 2 * 64 * 8, n0 = (long long)(kL0Chunks + 1) * 4 * 2 * 64 * 8,
+                    n1 = (long long)(kL1Chunks + 1) * 4 * 2 * 64 * 8, n2 = (long long)(kL2Chunks + 1) * 1 * 2 * 64 * 8;
+    long long g = gid;
+    auto decode = [](long long g, int nmb, int& c, int& m, int& part, int& i, int& h, int& e) {
+        e = (int)(g & 7); g >>= 3;
+        const int l = (int)(g & 63); g >>= 6;
+        part = (int)(g & 1); g >>= 1;
+        m = (int)(g % nmb); c = (int)(g / nmb);
+        i = l & 31; h = l >> 5;
+    };
+    int c, m, part, i, h, e;
+    if (g < nb) {
+        decode(g, 1, c, m, part, i, h, e);
+        const int k = 16 * c + 8 * h + e;
+        store_split(a.basisH + g, (c < kBasisChunksReal && i < a.app_dim) ? a.basis[i * kAppK + k] : 0.f, part);
+        return;
+    }
+    g -= nb;
+    if (!a.has_mlp) return;
+    if (g < n0) {
+        decode(g, 4, c, m, part, i, h, e);
+        store_split(a.w0H + g, c < kL0ChunksReal ? l0_weight(a.w0, m * 32 + i, 16 * c + 8 * h + e) : 0.f, part);
+        return;
+    }
+    g -= n0;
+    if (g < n1) {
+        decode(g, 4, c, m, part, i, h, e);
+        store_split(a.w1H + g, c < kL1Chunks ? a.w1[(m * 32 + i) * 128 + 16 * c + 8 * h + e] : 0.f, part);
+        return;
+    }
+    g -= n1;
+    if (g < n2) {
+        decode(g, 1, c, m, part, i, h, e);
+        store_split(a.w2H + g, (c < kL2Chunks && i < 3) ? a.w2[i * 128 + 16 * c + 8 * h + e] : 0.f, part);
+        return;
+    }
+    g -= n2;
+    if (g < 128 + 128 + 32) {   // biases in accumulator order: [layer][m][h][v]
+        const int idx = (int)g;
+        const int layer = idx < 128 ? 0 : (idx < 256 ? 1 : 2);
+        const int r = idx - (layer == 0 ? 0 : (layer == 1 ? 128 : 256));
+        const int mm = r / 32, hh = (r / 16) & 1, v = r & 15;
+        const int u = mm * 32 + unit_of(v, hh);
+        float b = 0.f;
+        if (layer == 0) b = a.b0[u];
+        else if (layer == 1) b = a.b1[u];
+        else if (u < 3) b = a.b2[u];
+        a.biasH[idx] = b * kWScale;
     }
 }
 
@@ -342,6 +586,23 @@ int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
     a.has_mlp = f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW;
     const size_t total = nb + n0 + n1 + n2;
     hipLaunchKernelGGL(k_pack_mlp, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    T2N_HIP(hipGetLastError());
+    // split-f16 operands
+    const size_t hb = (size_t)(kBasisChunks + 1) * 1 * 2 * 64 * 8, h0 = (size_t)(kL0Chunks + 1) * 4 * 2 * 64 * 8,
+                 h1 = (size_t)(kL1Chunks + 1) * 4 * 2 * 64 * 8, h2 = (size_t)(kL2Chunks + 1) * 1 * 2 * 64 * 8;
+    if (!f->buf_mlp_h) {
+        T2N_HIP(hipMalloc((void**)&f->buf_mlp_h, (hb + h0 + h1 + h2) * sizeof(_Float16) + 288 * sizeof(float)));
+    }
+    _Float16* hbase = (_Float16*)f->buf_mlp_h;
+    PackHArgs ha;
+    ha.basis = p->basis_weight; ha.w0 = p->mlp_w0; ha.b0 = p->mlp_b0; ha.w1 = p->mlp_w1; ha.b1 = p->mlp_b1; ha.w2 = p->mlp_w2; ha.b2 = p->mlp_b2;
+    ha.basisH = hbase; ha.w0H = hbase + hb; ha.w1H = hbase + hb + h0; ha.w2H = hbase + hb + h0 + h1;
+    ha.biasH = (float*)(hbase + hb + h0 + h1 + h2);
+    ha.app_dim = f->desc.app_dim; ha.has_mlp = a.has_mlp;
+    f->dev.basisH = (const uint4*)ha.basisH; f->dev.w0H = (const uint4*)ha.w0H; f->dev.w1H = (const uint4*)ha.w1H;
+    f->dev.w2H = (const uint4*)ha.w2H; f->dev.biasH = ha.biasH;
+    const size_t htotal = hb + h0 + h1 + h2 + 288;
+    hipLaunchKernelGGL(k_pack_mlp_h, dim3((unsigned)((htotal + 255) / 256)), dim3(256), 0, s, ha);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }
@@ -366,11 +627,13 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
     const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        T2N_HIP(hipFuncSetAttribute((const void*)k_shade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        T2N_HIP(hipFuncSetAttribute((const void*)k_shade<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     timing_begin(f, T2N_K_SHADE, s);
-    hipLaunchKernelGGL(k_shade, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
+    if (f->mlp_split && !ctx) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
     timing_end(f, T2N_K_SHADE, s);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
@@ -395,8 +658,10 @@ extern "C" int t2n_shade_at(const t2n_field* fc, const float* xyz_norm, const fl
     a.F = f->dev;
     a.xyz = xyz_norm; a.viewdirs = viewdirs; a.count_max = (unsigned)n; a.nlists = 1; a.feat_out = app_feat; a.rgb_out = rgb;
     const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
-    T2N_HIP(hipFuncSetAttribute((const void*)k_shade, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_shade, dim3(shade_grid((unsigned)n)), dim3(256), lds, (hipStream_t)stream, a);
+    T2N_HIP(hipFuncSetAttribute((const void*)k_shade<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (f->mlp_split) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid((unsigned)n)), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid((unsigned)n)), dim3(256), lds, (hipStream_t)stream, a);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

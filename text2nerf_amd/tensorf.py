@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import FLAG_ADD_BG, FLAG_KEEP_CTX, FLAG_TRAIN, T2NError
+from ._lib import FLAG_ADD_BG, FLAG_COHERENT, FLAG_KEEP_CTX, FLAG_TRAIN, T2NError
 
 MAT_MODE = [[0, 1], [0, 2], [1, 2]]
 VEC_MODE = [2, 1, 0]
@@ -100,6 +100,8 @@ class TensorVMSplit(nn.Module):
         self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC = shadingMode, pos_pe, view_pe, fea_pe, featureC
         self.materialize_weights = True   # the reference always returns weights/z_vals; set False to skip 8*N B/ray
         self.z_gate = 2.0                 # models/tensorBase.py:460
+        self.coherent_eval = False        # opt-in: LDS-staged density kernel for image-ordered eval rays (same results)
+        self.mlp_exact_fp32 = os.environ.get("T2N_MLP_EXACT", "0") == "1"   # False: f16 two-way-split MFMA products
         self._handle = None
         self._uploaded_key = None
         self.last_stats = None
@@ -268,6 +270,11 @@ class TensorVMSplit(nn.Module):
             d = self._desc()
             _lib.check(lib.t2n_field_create(C.byref(d), C.byref(h)), "t2n_field_create")
             self._handle = h
+            self._precision_set = None
+        if self._precision_set != bool(self.mlp_exact_fp32):
+            _lib.check(lib.t2n_field_set_mlp_precision(self._handle, 1 if self.mlp_exact_fp32 else 0),
+                       "t2n_field_set_mlp_precision")
+            self._precision_set = bool(self.mlp_exact_fp32)
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if force or key != self._uploaded_key:
             with torch.cuda.device(dev):
@@ -391,6 +398,8 @@ class TensorVMSplit(nn.Module):
             if not white_bg:
                 add_bg = bool(torch.rand((1,)) < 0.5)   # models/tensorBase.py:497
         flags = (FLAG_TRAIN if is_train else 0) | (FLAG_ADD_BG if add_bg else 0)
+        if not is_train and self.coherent_eval:
+            flags |= FLAG_COHERENT
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._all_params())
         if needs_grad:
             out = _RenderFn.apply(self, rays, N, flags, jitter, *self._all_params())
