@@ -168,6 +168,37 @@ __device__ __forceinline__ void issue_taps(const FactorSet& S, int CQ, int q, fl
     t.wnw = o.wnw; t.wne = o.wne; t.wsw = o.wsw; t.wse = o.wse; t.wl0 = o.wl0; t.wl1 = o.wl1;
 }
 
+// Axis a of the grid always pairs with coordinate a (plane k: W = grid[mat0], H = grid[mat1]; line: L = grid[vec]), so a
+// sample needs only THREE distinct tap computations, shared by its three plane/line pairs.
+struct Axes3 { Axis a[3]; };
+__device__ __forceinline__ Axes3 sample_axes(const FactorSet& S, float xn, float yn, float zn) {
+    Axes3 A;
+    A.a[0] = axis_taps(xn, S.W[0]);   // grid[0] = W of planes 0 and 1, L of line 2
+    A.a[1] = axis_taps(yn, S.H[0]);   // grid[1] = H of plane 0, W of plane 2, L of line 1
+    A.a[2] = axis_taps(zn, S.H[1]);   // grid[2] = H of planes 1 and 2, L of line 0
+    return A;
+}
+template <int K>
+__device__ __forceinline__ void issue_taps_ax(const FactorSet& S, int CQ, int q, const Axes3& A, QuadTaps& t) {
+    const Axis& ax = A.a[mat0(K)];
+    const Axis& ay = A.a[mat1(K)];
+    const Axis& al = A.a[vecm(K)];
+    // 32-bit BYTE offsets from the (scalar) plane base: lets the loads use the SGPR-base + VGPR-offset addressing form
+    const unsigned W = (unsigned)S.W[K];
+    const unsigned tb = (unsigned)CQ * 16u, qb = (unsigned)q * 16u;
+    const unsigned r0 = (unsigned)ay.i0 * W, r1 = (unsigned)ay.i1 * W;
+    const char* __restrict__ P = reinterpret_cast<const char*>(S.plane[K]);
+    const char* __restrict__ Ln = reinterpret_cast<const char*>(S.line[K]);
+    t.nw = *reinterpret_cast<const float4*>(P + ((r0 + (unsigned)ax.i0) * tb + qb));
+    t.ne = *reinterpret_cast<const float4*>(P + ((r0 + (unsigned)ax.i1) * tb + qb));
+    t.sw = *reinterpret_cast<const float4*>(P + ((r1 + (unsigned)ax.i0) * tb + qb));
+    t.se = *reinterpret_cast<const float4*>(P + ((r1 + (unsigned)ax.i1) * tb + qb));
+    t.l0 = *reinterpret_cast<const float4*>(Ln + ((unsigned)al.i0 * tb + qb));
+    t.l1 = *reinterpret_cast<const float4*>(Ln + ((unsigned)al.i1 * tb + qb));
+    t.wnw = ay.w0 * ax.w0; t.wne = ay.w0 * ax.w1; t.wsw = ay.w1 * ax.w0; t.wse = ay.w1 * ax.w1;
+    t.wl0 = al.w0; t.wl1 = al.w1;
+}
+
 __device__ __forceinline__ float4 taps_plane(const QuadTaps& t) {
     float4 v = f4_mul(t.nw, t.wnw);
     v = f4_fma(t.ne, t.wne, v);
@@ -179,6 +210,35 @@ __device__ __forceinline__ float4 taps_line(const QuadTaps& t) {
     float4 v = f4_mul(t.l0, t.wl0);
     v = f4_fma(t.l1, t.wl1, v);
     return v;
+}
+
+
+// Conservative sample-index interval [lo, hi] outside of which no sample of the ray can pass the box test (and the eval
+// z gate): slab test in t with a +-3 sample margin (fp32 rounding of the analytic bounds is ~1e-6 relative, the jitter
+// shifts samples by < 1). Exact validity is always re-tested per sample; hi < lo means "no candidate".
+template <bool TRAIN>
+__device__ __forceinline__ void ray_interval(const FieldDev& F, const Ray& ray, int N, int& lo, int& hi) {
+    lo = N; hi = -1;
+    float t0 = -3.0e38f, t1 = 3.0e38f;
+    const float o[3] = {ray.ox, ray.oy, ray.oz}, d[3] = {ray.dx, ray.dy, ray.dz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (d[k] != 0.f) {
+            const float ta = (F.aabb0[k] - o[k]) / d[k], tb = (F.aabb1[k] - o[k]) / d[k];
+            t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+        } else if (o[k] < F.aabb0[k] || o[k] > F.aabb1[k]) { t1 = -3.0e38f; }
+    }
+    if (!TRAIN) {   // eval gate: world z > zgate
+        if (ray.dz != 0.f) {
+            const float tg = (F.zgate - ray.oz) / ray.dz;
+            if (ray.dz > 0.f) t0 = fmaxf(t0, tg); else t1 = fminf(t1, tg);
+        } else if (!(ray.oz > F.zgate)) { t1 = -3.0e38f; }
+    }
+    if (t1 >= t0) {
+        const float flo = floorf((t0 - ray.tmin) / F.step) - 3.f, fhi = ceilf((t1 - ray.tmin) / F.step) + 3.f;
+        lo = (int)fminf(fmaxf(flo, 0.f), (float)N);
+        hi = (int)fminf(fmaxf(fhi, -1.f), (float)(N - 1));
+    }
 }
 
 // feature2density (models/tensorBase.py:406-410): softplus(beta=1, threshold=20) of feat+shift, or relu(feat).

@@ -51,23 +51,65 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
     const Ray ray = load_ray(F, a.rays + r * a.ray_stride, a.ray_stride);
     const float u = TRAIN ? a.jitter[r] : 0.f;
 
-    // ---- pass A: validity interval (exact per-sample test), optional z_vals ------------------------------------
+    // ---- pass A: validity interval. The mask is an interval (every coordinate is monotone in the sample index), so its
+    // ends are found by exact per-sample tests on the 32 candidates at either end of a conservative analytic range; the
+    // full exact scan is kept as the fallback for rays where that does not bracket the interval.
     int first = N, last = -1;
-    unsigned nvalid = 0;
-    for (int base = 0; base < N; base += 64) {
-        const int i = base + lane;
-        bool ok = false;
-        if (i < N) {
-            const float z = sample_z<TRAIN>(F, ray, i, u);
-            float xn, yn, zn;
-            ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
-            if (a.z_vals) a.z_vals[r * N + i] = z;
+    {
+        int lo, hi;
+        ray_interval<TRAIN>(F, ray, N, lo, hi);
+        bool done = hi < lo;
+        if (!done) {
+            const bool narrow = hi - lo < 64;
+            const int i = narrow ? lo + lane : (lane < 32 ? lo + lane : hi - (lane - 32));
+            bool ok = false;
+            if (i >= lo && i <= hi) {
+                const float z = sample_z<TRAIN>(F, ray, i, u);
+                float xn, yn, zn;
+                ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
+            }
+            const unsigned long long m = __ballot(ok);
+            if (narrow) {
+                if (m) { first = lo + (int)__ffsll((long long)m) - 1; last = lo + 63 - (int)__clzll((long long)m); }
+                // exact if the range's ends are invalid or are the ray's first / last sample
+                const bool lo_ok = !(m & 1ull) || lo == 0;
+                const bool hi_ok = !((m >> (hi - lo)) & 1ull) || hi == N - 1;
+                done = lo_ok && hi_ok;
+                if (!done) { first = N; last = -1; }
+            } else {
+                const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+                // provably exact only if both ends are bracketed: the outermost candidates are invalid (or are the
+                // first / last sample of the ray) and each group holds a valid sample; otherwise scan everything
+                const bool lo_ok = !(mlo & 1u) || lo == 0, hi_ok = !(mhi & 1u) || hi == N - 1;
+                if (mlo && mhi && lo_ok && hi_ok) {
+                    first = lo + (int)__ffs((int)mlo) - 1;
+                    last = hi - ((int)__ffs((int)mhi) - 1);
+                    done = true;
+                }
+            }
         }
-        const unsigned long long m = __ballot(ok);
-        if (m) {
-            if (first == N) first = base + (int)__ffsll((long long)m) - 1;
-            last = base + 63 - (int)__clzll((long long)m);
-            nvalid += (unsigned)__popcll(m);
+        if (!done) {   // exact scan over all samples
+            for (int base = 0; base < N; base += 64) {
+                const int i = base + lane;
+                bool ok = false;
+                if (i < N) {
+                    const float z = sample_z<TRAIN>(F, ray, i, u);
+                    float xn, yn, zn;
+                    ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
+                }
+                const unsigned long long m = __ballot(ok);
+                if (m) {
+                    if (first == N) first = base + (int)__ffsll((long long)m) - 1;
+                    last = base + 63 - (int)__clzll((long long)m);
+                }
+            }
+        }
+    }
+    const unsigned nvalid = last >= first ? (unsigned)(last - first + 1) : 0u;
+    if (a.z_vals) {
+        for (int base = 0; base < N; base += 64) {
+            const int i = base + lane;
+            if (i < N) a.z_vals[r * N + i] = sample_z<TRAIN>(F, ray, i, u);
         }
     }
 
@@ -92,9 +134,10 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
             float part = 0.f;
             if (ok) {
                 QuadTaps t0, t1, t2;
-                issue_taps<0>(F.den, LPS, q, xn, yn, zn, t0);
-                issue_taps<1>(F.den, LPS, q, xn, yn, zn, t1);
-                issue_taps<2>(F.den, LPS, q, xn, yn, zn, t2);
+                const Axes3 A = sample_axes(F.den, xn, yn, zn);
+                issue_taps_ax<0>(F.den, LPS, q, A, t0);
+                issue_taps_ax<1>(F.den, LPS, q, A, t1);
+                issue_taps_ax<2>(F.den, LPS, q, A, t2);
                 float4 p, l;
                 p = taps_plane(t0); l = taps_line(t0);
                 part = p.x * l.x; part = fmaf(p.y, l.y, part); part = fmaf(p.z, l.z, part); part = fmaf(p.w, l.w, part);
@@ -259,9 +302,10 @@ __global__ __launch_bounds__(256) void k_density_at(const FieldDev F, const floa
     if (ok) {
         const float xn = xyz[p * 3 + 0], yn = xyz[p * 3 + 1], zn = xyz[p * 3 + 2];
         QuadTaps t0, t1, t2;
-        issue_taps<0>(F.den, LPS, q, xn, yn, zn, t0);
-        issue_taps<1>(F.den, LPS, q, xn, yn, zn, t1);
-        issue_taps<2>(F.den, LPS, q, xn, yn, zn, t2);
+        const Axes3 A = sample_axes(F.den, xn, yn, zn);
+        issue_taps_ax<0>(F.den, LPS, q, A, t0);
+        issue_taps_ax<1>(F.den, LPS, q, A, t1);
+        issue_taps_ax<2>(F.den, LPS, q, A, t2);
         float4 pv, l;
         pv = taps_plane(t0); l = taps_line(t0);
         part = pv.x * l.x; part = fmaf(pv.y, l.y, part); part = fmaf(pv.z, l.z, part); part = fmaf(pv.w, l.w, part);
