@@ -26,6 +26,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_EVAL = 1152   # 3 planes x 4 taps x 64 B + 3 lines x 2 taps x 64 B
 BYTES_PER_APP = 3456
 BYTES_PER_RAY = 40
+FLOP_PER_APP = 131168    # 2*(144*27 + 351*128 + 128*128 + 128*3)
+MFMA_F32_PEAK_TF = 157.3
+MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def build_field(dev, scene="S1-soft", seed=0, grid=300):
@@ -41,15 +44,14 @@ def build_field(dev, scene="S1-soft", seed=0, grid=300):
 
 
 def cpu_baseline(params, aabb, grid, n_samples, budget_s=20.0):
-    """The oracle timed on the host cores on a bounded sample of the same frame (every 5th pixel, chunk 16384 like the
-    reference driver)."""
+    """The oracle timed on the host cores on a bounded sample of the same frame (every 2nd pixel, chunks of 4096 rays)."""
     from oracle import oracle_torch as O
     from text2nerf_amd import synth
     cores = min(os.cpu_count() or 1, 32)   # more threads only add contention on these op sizes
     torch.set_num_threads(cores)
     cfg = O.FieldConfig(aabb=aabb, grid_size=[grid] * 3)
     P = O.params_from_numpy(params)
-    rays = torch.from_numpy(synth.frame_rays_np(800, 800, stride=5))   # 25 600 rays
+    rays = torch.from_numpy(synth.frame_rays_np(800, 800, stride=2))   # 160 000 rays: ~10-20 s of host work
     done, t0 = 0, time.time()
     with torch.no_grad():
         for k in range(0, rays.shape[0], 4096):
@@ -59,7 +61,7 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=20.0):
                 break
     dt = time.time() - t0
     return {"value": done * n_samples / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
-            "sample": f"{done} rays (800x800 frame, every 5th pixel) x {n_samples} samples, oracle_torch, "
+            "sample": f"{done} rays (800x800 frame, every 2nd pixel) x {n_samples} samples, oracle_torch, "
                       f"{torch.get_num_threads()} threads, {dt:.1f} s"}
 
 
@@ -182,15 +184,40 @@ def main():
         nominal = world * R * N * args.steps / dt
         k_ms = {k: v[0] / max(v[1], 1) for k, v in timing.items()}        # avg ms per launch
         k_per_step = {k: v[1] / args.steps for k, v in timing.items()}     # launches per step
-        alg = {"march": BYTES_PER_EVAL * V + BYTES_PER_RAY * R, "shade": BYTES_PER_APP * A}
         frame_ms = {k: v[0] / args.steps for k, v in timing.items()}       # kernel ms per frame
         dom = max(("march", "shade"), key=lambda k: frame_ms.get(k, 0.0))
         launches = max(k_per_step.get(dom, 1.0), 1.0)
-        achieved = (alg[dom] / launches) / (k_ms[dom] * 1e-3) / 1e9 if dom in k_ms else None
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "round1_traffic.json")) as fh:
+                traffic = json.load(fh).get(f"k_{dom}", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+        alg_bytes = {"march": BYTES_PER_EVAL * V + BYTES_PER_RAY * R, "shade": BYTES_PER_APP * A}
+        split = not field.mlp_exact_fp32
+        if dom == "march":
+            achieved = (alg_bytes["march"] / launches) / (k_ms["march"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_march", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": alg_bytes["march"] / launches, "avg_launch_ms": k_ms["march"],
+                    "note": "field (69.6 MB) is cache-resident: achieved > HBM peak means the gather runs from L1/L2, "
+                            "traffic = PMC HBM bytes per launch from profiles/round1_traffic.json"}
+        else:
+            # executed matrix-core work: 3 f16 products per fp32 product on the split path, 1 on the exact fp32 path
+            exec_flop = FLOP_PER_APP * A * (3 if split else 1)
+            peak = MFMA_F16_PEAK_TF if split else MFMA_F32_PEAK_TF
+            achieved = (exec_flop / launches) / (k_ms["shade"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "k_shade", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                    "frac": achieved / peak, "traffic": traffic,
+                    "algorithmic_flop_per_launch": FLOP_PER_APP * A / launches, "avg_launch_ms": k_ms["shade"],
+                    "note": ("fp32 products executed as 3 f16 MFMA products of hi/lo splits (fp32 accumulate); "
+                             "fp32-equivalent rate = achieved / 3" if split else "exact fp32 MFMA")}
+        other = "shade" if dom == "march" else "march"
         out = {
             "metric": "ray-samples/s (render) + iters/s (train), 300^3 VM-split, 800x800",
             "value": nominal, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" + (" (basis/MLP products as f16x2-split MFMA, fp32 accumulate)" if split else ""),
             "data": "synthetic",
             "config": {"workload": f"C2: TensorVMSplit 300^3, 800x800 view/GPU, {N} samples/ray, render_only, scene "
                                    f"{args.scene} seed 0, white_bg, weights/z_vals materialised: {bool(args.weights)}",
@@ -199,11 +226,13 @@ def main():
                        "evaluated_samples_per_s": world * V * args.steps / dt,
                        "parallelism": f"ray-tile x{world}" + (" + RCCL all-gather of rgb+depth tiles" if world > 1 else ""),
                        "kernel_ms_per_frame": frame_ms,
+                       "march_algorithmic_GBps": (alg_bytes["march"] / max(k_per_step.get("march", 1.0), 1.0)) /
+                                                 (k_ms["march"] * 1e-3) / 1e9 if "march" in k_ms else None,
+                       "shade_fp32_equiv_TFLOPs": (FLOP_PER_APP * A / max(k_per_step.get("shade", 1.0), 1.0)) /
+                                                  (k_ms["shade"] * 1e-3) / 1e12 if "shade" in k_ms else None,
                        "path_roofline_frac": ((BYTES_PER_EVAL * V + BYTES_PER_APP * A + BYTES_PER_RAY * R) /
                                               (ms_step * 1e-3) / 1e9) / HBM_PEAK_GBS},
-            "roofline": {"bound": "hbm", "kernel": f"k_{dom}", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": k_ms.get(dom)},
+            "roofline": roof,
         }
         if world == 1 and not args.no_train:
             del rays

@@ -272,20 +272,23 @@ __global__ __launch_bounds__(256) void k_composite(const CompositeArgs a) {
 
 // Per-call counters: V (evaluated samples) and A (appearance samples) summed over the rays of one sub-launch.
 __global__ __launch_bounds__(256) void k_ray_stats(const int4* __restrict__ ray_app, long long n, unsigned long long* stats) {
+    __shared__ unsigned long long part[8];
     unsigned long long v = 0, ap = 0;
     for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
         const int4 ra = ray_app[r];
         v += (unsigned)ra.z; ap += (unsigned)ra.y;
     }
-    // wave reduction on 64-bit counters
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         v += __shfl_xor((long long)v, o);
         ap += __shfl_xor((long long)ap, o);
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&stats[T2N_STAT_EVALUATED], v);
-        atomicAdd(&stats[T2N_STAT_APPEARANCE], ap);
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[wid] = v; part[4 + wid] = ap; }
+    __syncthreads();
+    if (threadIdx.x == 0) {   // one atomic pair per block: same-address atomics serialise (~88 per microsecond)
+        atomicAdd(&stats[T2N_STAT_EVALUATED], part[0] + part[1] + part[2] + part[3]);
+        atomicAdd(&stats[T2N_STAT_APPEARANCE], part[4] + part[5] + part[6] + part[7]);
     }
 }
 
@@ -391,7 +394,7 @@ int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
     T2N_HIP(hipGetLastError());
     if (L.stats) {
         unsigned nb = (unsigned)((L.n_rays + 255) / 256);
-        if (nb > 1024) nb = 1024;
+        if (nb > 64) nb = 64;
         hipLaunchKernelGGL(k_ray_stats, dim3(nb), dim3(256), 0, s, (const int4*)L.ray_app, (long long)L.n_rays,
                            (unsigned long long*)L.stats);
         T2N_HIP(hipGetLastError());
