@@ -43,26 +43,30 @@ def build_field(dev, scene="S1-soft", seed=0, grid=300):
     return m, params, aabb
 
 
-def cpu_baseline(params, aabb, grid, n_samples, budget_s=20.0):
-    """The oracle timed on the host cores on a bounded sample of the same frame (every 2nd pixel, chunks of 4096 rays)."""
+def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0):
+    """The oracle's plain-C port (oracle/oracle_c.c, OpenMP over rays) timed on the host cores on the SAME workload: whole
+    800x800 frames, repeated until ~budget_s of host work (at most 4 frames; fewer rays if one frame would take minutes)."""
     from oracle import oracle_torch as O
+    from oracle.oracle_c import COracle
     from text2nerf_amd import synth
-    cores = min(os.cpu_count() or 1, 32)   # more threads only add contention on these op sizes
-    torch.set_num_threads(cores)
     cfg = O.FieldConfig(aabb=aabb, grid_size=[grid] * 3)
-    P = O.params_from_numpy(params)
-    rays = torch.from_numpy(synth.frame_rays_np(800, 800, stride=2))   # 160 000 rays: ~10-20 s of host work
-    done, t0 = 0, time.time()
-    with torch.no_grad():
-        for k in range(0, rays.shape[0], 4096):
-            O.forward(cfg, P, rays[k:k + 4096], n_samples=n_samples)
-            done += min(4096, rays.shape[0] - k)
-            if time.time() - t0 > budget_s:
-                break
+    co = COracle(cfg, params)
+    cores = co.threads()
+    probe = synth.frame_rays_np(800, 800, stride=8)            # 10 000 rays: calibrates the sample size
+    t0 = time.time()
+    co.render(probe, n_samples=n_samples, want_weights=False)
+    rate = probe.shape[0] / max(time.time() - t0, 1e-6)          # rays / s
+    stride = 1 if 640000 / rate < 2 * budget_s else (2 if 160000 / rate < 2 * budget_s else 4)
+    rays = synth.frame_rays_np(800, 800, stride=stride)
+    done, frames, t0 = 0, 0, time.time()
+    while frames < 4 and (frames == 0 or time.time() - t0 < budget_s):
+        co.render(rays, n_samples=n_samples, want_weights=False)
+        done += rays.shape[0]
+        frames += 1
     dt = time.time() - t0
     return {"value": done * n_samples / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
-            "sample": f"{done} rays (800x800 frame, every 2nd pixel) x {n_samples} samples, oracle_torch, "
-                      f"{torch.get_num_threads()} threads, {dt:.1f} s"}
+            "sample": f"{frames} x {rays.shape[0]} rays (800x800 frame, pixel stride {stride}) x {n_samples} samples, "
+                      f"oracle_c (plain C, OpenMP {cores} threads), {dt:.1f} s"}
 
 
 def train_bench(dev, iters=20, warmup=3):
