@@ -204,14 +204,23 @@ struct PeChunk {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = p[e * kXld];
         } else if (c < kL0ChunksReal) {
+            // four consecutive (feature, octave) pairs: an accurate sincos at the first pair (and wherever the octave wraps
+            // to a new feature), the following octaves of the same feature by the double-angle identities
+            // sin 2a = 2 sin a cos a, cos 2a = (cos a - sin a)(cos a + sin a): at most three doublings (error x8 of ~1e-7)
             const int pi0 = 8 * (c - 2) + 4 * h;
+            int f = (pi0 * 171) >> 10;                   // pi0 / 6 for pi0 < 504
+            int qo = pi0 - 6 * f;
+            float sn = 0.f, cs = 1.f;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const int pi = pi0 + p;
-                const int f = (pi * 171) >> 10;          // pi / 6 for pi < 504
-                const int qo = pi - 6 * f;
-                const float v = fe[(size_t)f * kXld] * (float)(1 << qo);
-                sincosf(v, &x[2 * p], &x[2 * p + 1]);
+                if (p == 0 || qo == 0) {
+                    sincosf(fe[(size_t)f * kXld] * (float)(1 << qo), &sn, &cs);
+                } else {
+                    const float s2 = 2.f * sn * cs, c2 = (cs - sn) * (cs + sn);
+                    sn = s2; cs = c2;
+                }
+                x[2 * p] = sn; x[2 * p + 1] = cs;
+                if (++qo == kPE) { qo = 0; ++f; }
             }
         } else {
 #pragma unroll
@@ -237,28 +246,42 @@ struct ShadeArgs {
     ShadeCtx ctx;   // activation rows for the backward pass (all NULL in the normal forward)
 };
 
+// Gather: 384 (sample, channel-quad) items over 64 lanes, 6 per lane; an item computes its sample's three axis taps once
+// and fetches quad q of the 4 plane taps + 2 line taps of all three factor pairs (each tap = 192 contiguous bytes across
+// the 12 lanes of a sample); plane x line products go to X[k*48 + 4q + c][s] (and to the ctx rows in backward mode).
 template <int K>
-__device__ __forceinline__ void gather_plane(const FactorSet& S, float* __restrict__ X, int lane, const float4* pos_l,
-                                             const float* xyz, unsigned base, unsigned count, float* ctx_x, unsigned row0) {
+__device__ __forceinline__ void gather_store(const FactorSet& S, const Axes3& A, int q, int s, bool live, float* __restrict__ X,
+                                             float* ctx_x, unsigned row0) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        QuadTaps t;
+        issue_taps_ax<K>(S, 12, q, A, t);
+        const float4 p = taps_plane(t), l = taps_line(t);
+        v = make_float4(p.x * l.x, p.y * l.y, p.z * l.z, p.w * l.w);
+    }
+    float* dst = X + (size_t)(K * 48 + q * 4) * kXld + s;
+    dst[0] = v.x; dst[kXld] = v.y; dst[2 * kXld] = v.z; dst[3 * kXld] = v.w;
+    if (ctx_x) *reinterpret_cast<float4*>(ctx_x + (size_t)(row0 + s) * kAppK + K * 48 + q * 4) = v;
+}
+
+__device__ __forceinline__ void gather_all(const FactorSet& S, float* __restrict__ X, int lane, const float4* pos_l,
+                                           const float* xyz, unsigned base, unsigned count, float* ctx_x, unsigned row0) {
     constexpr int CQ = 12;   // 48 channels / 4
-#pragma unroll 2
+#pragma unroll 1
     for (int it = 0; it < 6; ++it) {
         const int item = it * 64 + lane;
         const int s = item / CQ, q = item - s * CQ;
         const unsigned idx = base + (unsigned)s;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < count) {
-            float xn, yn, zn;
+        const bool live = idx < count;
+        float xn = 0.f, yn = 0.f, zn = 0.f;
+        if (live) {
             if (pos_l) { const float4 p = pos_l[idx]; xn = p.x; yn = p.y; zn = p.z; }
             else { xn = xyz[(size_t)idx * 3]; yn = xyz[(size_t)idx * 3 + 1]; zn = xyz[(size_t)idx * 3 + 2]; }
-            QuadTaps t;
-            issue_taps<K>(S, CQ, q, xn, yn, zn, t);
-            const float4 p = taps_plane(t), l = taps_line(t);
-            v = make_float4(p.x * l.x, p.y * l.y, p.z * l.z, p.w * l.w);
         }
-        float* dst = X + (size_t)(K * 48 + q * 4) * kXld + s;
-        dst[0] = v.x; dst[kXld] = v.y; dst[2 * kXld] = v.z; dst[3 * kXld] = v.w;
-        if (ctx_x) *reinterpret_cast<float4*>(ctx_x + (size_t)(row0 + s) * kAppK + K * 48 + q * 4) = v;
+        const Axes3 A = sample_axes(S, xn, yn, zn);
+        gather_store<0>(S, A, q, s, live, X, ctx_x, row0);
+        gather_store<1>(S, A, q, s, live, X, ctx_x, row0);
+        gather_store<2>(S, A, q, s, live, X, ctx_x, row0);
     }
 }
 
@@ -295,9 +318,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         const unsigned count = lbase + __shfl(cnt_l, li);      // one past the last live entry of this sub-list
         // ---- gather: plane x line products for 32 samples x 144 channels -> X ---------------------------------------
         const unsigned row0 = tile * 32u;   // activation row of lane sample 0 (ctx mode)
-        gather_plane<0>(F.app, X, lane, a.app_pos, a.xyz, base, count, a.ctx.x144, row0);
-        gather_plane<1>(F.app, X, lane, a.app_pos, a.xyz, base, count, a.ctx.x144, row0);
-        gather_plane<2>(F.app, X, lane, a.app_pos, a.xyz, base, count, a.ctx.x144, row0);
+        gather_all(F.app, X, lane, a.app_pos, a.xyz, base, count, a.ctx.x144, row0);
         wave_lds_sync();
 
         // ---- basis_mat: feat[i][s] = sum_k Wb[i][k] X[k][s] ----------------------------------------------------------
