@@ -60,6 +60,105 @@ __device__ __forceinline__ void scatter_chan(const FactorSet& S, const GradSet& 
     if (o.wl1 != 0.f) atomicAdd(gL + l1, gl * o.wl1);
 }
 
+// Sliding-window scatter: consecutive samples of a ray (and consecutive appearance samples of the list) move by less
+// than a texel per step, so their 2x2 plane footprints and 2-row line footprints mostly coincide or shift by one. Each
+// lane (one channel) keeps the footprint's accumulators in registers and issues a global atomic only when a texel leaves
+// the window — the L2 fp32-atomic rate (~1 dword / 2.7 clk / channel) bounds this pass, so fewer atomics is the lever.
+constexpr int kWinEmpty = -(1 << 30);
+struct PlaneWin {
+    int x, y;                    // base texel (x0, y0), may be -1 at the low border; kWinEmpty: empty
+    float a00, a01, a10, a11;    // [dy][dx]
+};
+struct LineWin {
+    int r;                       // base row; kWinEmpty: empty
+    float a0, a1;
+};
+__device__ __forceinline__ void flush1(float* g, int W, int C, int x, int y, int coff, float v) {
+    if (v != 0.f && x >= 0 && y >= 0) atomicAdd(g + ((size_t)y * W + x) * C + coff, v);
+}
+__device__ __forceinline__ void plane_flush(PlaneWin& w, float* g, int W, int C, int coff) {
+    if (w.x != kWinEmpty) {
+        flush1(g, W, C, w.x, w.y, coff, w.a00); flush1(g, W, C, w.x + 1, w.y, coff, w.a01);
+        flush1(g, W, C, w.x, w.y + 1, coff, w.a10); flush1(g, W, C, w.x + 1, w.y + 1, coff, w.a11);
+    }
+    w.x = kWinEmpty; w.a00 = w.a01 = w.a10 = w.a11 = 0.f;
+}
+// add the contributions (v00 v01 / v10 v11) of a sample whose footprint starts at (x, y)
+__device__ __forceinline__ void plane_add(PlaneWin& w, float* g, int W, int C, int coff, int x, int y, float v00, float v01,
+                                          float v10, float v11) {
+    if (w.x != kWinEmpty && !(x == w.x && y == w.y)) {
+        const int dx = x - w.x, dy = y - w.y;
+        if (dy == 0 && dx == 1) {           // shift right: column x leaves
+            flush1(g, W, C, w.x, w.y, coff, w.a00); flush1(g, W, C, w.x, w.y + 1, coff, w.a10);
+            w.a00 = w.a01; w.a10 = w.a11; w.a01 = 0.f; w.a11 = 0.f; w.x = x;
+        } else if (dy == 0 && dx == -1) {
+            flush1(g, W, C, w.x + 1, w.y, coff, w.a01); flush1(g, W, C, w.x + 1, w.y + 1, coff, w.a11);
+            w.a01 = w.a00; w.a11 = w.a10; w.a00 = 0.f; w.a10 = 0.f; w.x = x;
+        } else if (dx == 0 && dy == 1) {
+            flush1(g, W, C, w.x, w.y, coff, w.a00); flush1(g, W, C, w.x + 1, w.y, coff, w.a01);
+            w.a00 = w.a10; w.a01 = w.a11; w.a10 = 0.f; w.a11 = 0.f; w.y = y;
+        } else if (dx == 0 && dy == -1) {
+            flush1(g, W, C, w.x, w.y + 1, coff, w.a10); flush1(g, W, C, w.x + 1, w.y + 1, coff, w.a11);
+            w.a10 = w.a00; w.a11 = w.a01; w.a00 = 0.f; w.a01 = 0.f; w.y = y;
+        } else {
+            plane_flush(w, g, W, C, coff);
+        }
+    }
+    w.x = x; w.y = y;
+    w.a00 += v00; w.a01 += v01; w.a10 += v10; w.a11 += v11;
+}
+__device__ __forceinline__ void line_flush(LineWin& w, float* g, int C, int coff) {
+    if (w.r != kWinEmpty) {
+        if (w.a0 != 0.f && w.r >= 0) atomicAdd(g + (size_t)w.r * C + coff, w.a0);
+        if (w.a1 != 0.f) atomicAdd(g + (size_t)(w.r + 1) * C + coff, w.a1);
+    }
+    w.r = kWinEmpty; w.a0 = w.a1 = 0.f;
+}
+__device__ __forceinline__ void line_add(LineWin& w, float* g, int C, int coff, int r, float v0, float v1) {
+    if (w.r != kWinEmpty && r != w.r) {
+        if (r == w.r + 1) {
+            if (w.a0 != 0.f && w.r >= 0) atomicAdd(g + (size_t)w.r * C + coff, w.a0);
+            w.a0 = w.a1; w.a1 = 0.f;
+        } else if (r == w.r - 1) {
+            if (w.a1 != 0.f) atomicAdd(g + (size_t)(w.r + 1) * C + coff, w.a1);
+            w.a1 = w.a0; w.a0 = 0.f;
+        } else {
+            line_flush(w, g, C, coff);
+        }
+    }
+    w.r = r;
+    w.a0 += v0; w.a1 += v1;
+}
+
+// One channel of factor pair K for one sample: re-gather the value taps, form dL/dP and dL/dL for this channel and push
+// them into the sliding windows. The footprint origin is the UNCLAMPED floor index (taps outside the grid carry weight 0
+// and accumulate exact zeros, which flush1 never writes).
+template <int K>
+__device__ __forceinline__ void scatter_win(const FactorSet& S, const GradSet& G, int C, int coff, float xn, float yn, float zn,
+                                            float g, PlaneWin& pw, LineWin& lw) {
+    float gx, gy, gv;
+    plane_line_coords<K>(xn, yn, zn, gx, gy, gv);
+    const Axis ax = axis_taps(gx, S.W[K]);
+    const Axis ay = axis_taps(gy, S.H[K]);
+    const Axis al = axis_taps(gv, S.L[K]);
+    const int W = S.W[K];
+    const float* __restrict__ P = S.plane[K];
+    const float* __restrict__ Ln = S.line[K];
+    const float w00 = ay.w0 * ax.w0, w01 = ay.w0 * ax.w1, w10 = ay.w1 * ax.w0, w11 = ay.w1 * ax.w1;
+    float pv = P[((size_t)ay.i0 * W + ax.i0) * C + coff] * w00;
+    pv = fmaf(P[((size_t)ay.i0 * W + ax.i1) * C + coff], w01, pv);
+    pv = fmaf(P[((size_t)ay.i1 * W + ax.i0) * C + coff], w10, pv);
+    pv = fmaf(P[((size_t)ay.i1 * W + ax.i1) * C + coff], w11, pv);
+    const float lv = fmaf(Ln[(size_t)al.i1 * C + coff], al.w1, Ln[(size_t)al.i0 * C + coff] * al.w0);
+    const float gp = g * lv, gl = g * pv;
+    // window origins: i1 - 1 where the high tap is live, else i0 (clamped borders: the dead tap's weight is 0)
+    const int ox = ax.w1 != 0.f ? ax.i1 - 1 : ax.i0, oy = ay.w1 != 0.f ? ay.i1 - 1 : ay.i0, ol = al.w1 != 0.f ? al.i1 - 1 : al.i0;
+    // re-express the four products on the window grid (a clamped low tap at the -1 border sits at origin + 0 with weight 0)
+    const float vx0 = ax.i0 == ox ? 1.f : 0.f, vy0 = ay.i0 == oy ? 1.f : 0.f;
+    plane_add(pw, G.plane[K], W, C, coff, ox, oy, gp * w00 * vx0 * vy0, gp * w01 * vy0, gp * w10 * vx0, gp * w11);
+    line_add(lw, G.line[K], C, coff, ol, al.i0 == ol ? gl * al.w0 : 0.f, gl * al.w1);
+}
+
 struct BwdMarchArgs {
     FieldDev F;
     GradSet gden;
@@ -165,22 +264,31 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
     }
     wave_lds_sync();
 
-    // ---- scatter: 16 lanes per sample (one channel each), 4 samples per step ---------------------------------------------
+    // ---- scatter: 16 lanes per sample (one channel each); each 16-lane group walks a CONTIGUOUS quarter of the window
+    // so that successive samples are neighbours along the ray and the sliding windows merge their shared texels ----------
     const int ch = lane & 15, sl = lane >> 4;
-    for (int base = 0; base < Lw; base += 4) {
-        const int j = base + sl, i = first + j;
+    const int Q = (Lw + 3) >> 2;
+    PlaneWin pw0, pw1, pw2;
+    LineWin lw0, lw1, lw2;
+    pw0.x = kWinEmpty; pw0.y = 0; pw0.a00 = pw0.a01 = pw0.a10 = pw0.a11 = 0.f; pw1 = pw0; pw2 = pw0;
+    lw0.r = kWinEmpty; lw0.a0 = lw0.a1 = 0.f; lw1 = lw0; lw2 = lw0;
+    for (int t = 0; t < Q; ++t) {
+        const int j = sl * Q + t, i = first + j;
         if (j < Lw) {
             const float gf = Gw[j];
             float xn, yn, zn;
             const float z = sample_z<TRAIN>(F, ray, i, u);
             const bool ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
             if (ok && gf != 0.f) {
-                scatter_chan<0>(F.den, a.gden, 16, ch, xn, yn, zn, gf);
-                scatter_chan<1>(F.den, a.gden, 16, ch, xn, yn, zn, gf);
-                scatter_chan<2>(F.den, a.gden, 16, ch, xn, yn, zn, gf);
+                scatter_win<0>(F.den, a.gden, 16, ch, xn, yn, zn, gf, pw0, lw0);
+                scatter_win<1>(F.den, a.gden, 16, ch, xn, yn, zn, gf, pw1, lw1);
+                scatter_win<2>(F.den, a.gden, 16, ch, xn, yn, zn, gf, pw2, lw2);
             }
         }
     }
+    plane_flush(pw0, a.gden.plane[0], F.den.W[0], 16, ch); plane_flush(pw1, a.gden.plane[1], F.den.W[1], 16, ch);
+    plane_flush(pw2, a.gden.plane[2], F.den.W[2], 16, ch);
+    line_flush(lw0, a.gden.line[0], 16, ch); line_flush(lw1, a.gden.line[1], 16, ch); line_flush(lw2, a.gden.line[2], 16, ch);
 }
 
 // ---- layer 2 (3 outputs): VALU ------------------------------------------------------------------------------------------
@@ -348,9 +456,14 @@ struct AppScatterArgs {
 };
 template <int K>
 __device__ __forceinline__ void app_scatter_plane(const AppScatterArgs& a, int lane, unsigned base, unsigned count, unsigned row0) {
+    // 16 lanes per sample; each 16-lane group walks 8 CONSECUTIVE list entries (neighbouring samples of a ray)
     const int ch = lane & 15, sl = lane >> 4;
-    for (int s0 = 0; s0 < 32; s0 += 4) {
-        const int s = s0 + sl;
+    PlaneWin pw[3];
+    LineWin lw[3];
+#pragma unroll
+    for (int cg = 0; cg < 3; ++cg) { pw[cg].x = kWinEmpty; pw[cg].y = 0; pw[cg].a00 = pw[cg].a01 = pw[cg].a10 = pw[cg].a11 = 0.f; lw[cg].r = kWinEmpty; lw[cg].a0 = lw[cg].a1 = 0.f; }
+    for (int t = 0; t < 8; ++t) {
+        const int s = sl * 8 + t;
         const unsigned idx = base + (unsigned)s;
         if (idx < count) {
             const float4 p = a.app_pos[idx];
@@ -358,9 +471,14 @@ __device__ __forceinline__ void app_scatter_plane(const AppScatterArgs& a, int l
 #pragma unroll
             for (int cg = 0; cg < 3; ++cg) {
                 const float g = gr[cg * 16];
-                if (g != 0.f) scatter_chan<K>(a.F.app, a.gapp, 48, cg * 16 + ch, p.x, p.y, p.z, g);
+                if (g != 0.f) scatter_win<K>(a.F.app, a.gapp, 48, cg * 16 + ch, p.x, p.y, p.z, g, pw[cg], lw[cg]);
             }
         }
+    }
+#pragma unroll
+    for (int cg = 0; cg < 3; ++cg) {
+        plane_flush(pw[cg], a.gapp.plane[K], a.F.app.W[K], 48, cg * 16 + ch);
+        line_flush(lw[cg], a.gapp.line[K], 48, cg * 16 + ch);
     }
 }
 __global__ __launch_bounds__(256) void k_bwd_app_scatter(const AppScatterArgs a) {
