@@ -19,6 +19,24 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def host_cores():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return n
+
+
+HOST_CORES = host_cores()
+# host-side thread pools sized to the usable cores BEFORE torch / OpenMP start: oversubscribed pools stall the training
+# loop's CPU indexing for tens of milliseconds at a time and make the CPU baseline meaningless
+os.environ.setdefault("OMP_NUM_THREADS", str(HOST_CORES))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -78,9 +96,17 @@ def train_bench(dev, iters=20, warmup=3):
     n_samples = min(int(1e6), int(synth.cal_n_samples([300] * 3, 1.0) / 2))          # text2nerf_main.py:439 -> 259
     poses = synth.local_fixed_like_poses(9)
     allrays = torch.from_numpy(np.concatenate([synth.frame_rays_np(512, 512, c2w=p) for p in poses]))   # CPU, like the driver
+    # targets: the scene's own colours/depths (eval render of every 4th ray, nearest-assigned) + noise, so that the step
+    # has realistic gradients but the field stays a scene; i.i.d. uniform targets turn the field into fog within ~10
+    # Adam steps (2 M appearance samples per batch instead of ~1e5), which benchmarks nothing the driver ever does
     g = np.random.Generator(np.random.PCG64(1024))
-    allrgb = torch.from_numpy(g.uniform(0, 1, (allrays.shape[0], 3)).astype(np.float32))
-    alldepth = torch.from_numpy(g.uniform(2, 7, (allrays.shape[0],)).astype(np.float32))
+    with torch.no_grad():
+        sub = allrays[::4].to(dev)
+        rgb_s, dep_s, _, _ = field(sub, white_bg=True, is_train=False, N_samples=n_samples)
+    allrgb = (rgb_s.cpu().repeat_interleave(4, 0)[: allrays.shape[0]] +
+              torch.from_numpy(g.normal(0, 0.05, (allrays.shape[0], 3)).astype(np.float32))).clamp(0, 1)
+    alldepth = dep_s.cpu().repeat_interleave(4, 0)[: allrays.shape[0]] + torch.from_numpy(
+        g.normal(0, 0.05, (allrays.shape[0],)).astype(np.float32))
     opt = torch.optim.Adam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
     tv, tl = TVLoss(), TransMittanceLoss_mask(dev)
     np.random.seed(1024)
@@ -132,6 +158,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.set_num_threads(max(1, min(HOST_CORES // max(world, 1), 16)))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

@@ -393,15 +393,18 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ IN, i
         }
 }
 
-// db[n] += sum_rows G[rows, ld]
+// db[n] += sum_rows G[rows, ld]   (N <= 128; 256 threads: two row phases per block, `chunk` rows per block)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ G, int ld, long long rows, int N, float* db, int chunk) {
-    const int n = threadIdx.x;
-    if (n >= N) return;
+    __shared__ float part[256];
+    const int n = threadIdx.x & 127, ph = threadIdx.x >> 7;
     const long long r0 = (long long)blockIdx.x * chunk;
     const long long r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
     float s = 0.f;
-    for (long long r = r0; r < r1; ++r) s += G[r * ld + n];
-    atomicAdd(&db[n], s);
+    if (n < N)
+        for (long long r = r0 + ph; r < r1; r += 2) s += G[r * ld + n];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (ph == 0 && n < N) atomicAdd(&db[n], part[n] + part[128 + n]);
 }
 
 // positional encoding forward: feat [rows,32] -> x [rows,352] in the reference's column order (tensorBase.py:11-17)
@@ -512,7 +515,9 @@ __global__ __launch_bounds__(256) void k_relayout_add(const float* __restrict__ 
     dst[t] += src[pix * C + c];
 }
 
-struct BwdCarve { size_t x144, feat32, h0, h1, go, g1, g0, xpe, gx, gf, gxapp, total; };
+// Activation / gradient rows of the backward pass. Buffers whose lifetimes do not overlap (or that are rewritten
+// element-in-place by the same thread) share storage: g1 over h1, g0 over h0, gx over xpe, gf over feat32, gX over x144.
+struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, total; };
 static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 static BwdCarve bwd_carve(int64_t rows) {
     BwdCarve c;
@@ -523,12 +528,7 @@ static BwdCarve bwd_carve(int64_t rows) {
     c.h0 = o; o = al256(o + R * 128 * 4);
     c.h1 = o; o = al256(o + R * 128 * 4);
     c.go = o; o = al256(o + R * 16);
-    c.g1 = o; o = al256(o + R * 128 * 4);
-    c.g0 = o; o = al256(o + R * 128 * 4);
     c.xpe = o; o = al256(o + R * 352 * 4);
-    c.gx = o; o = al256(o + R * 352 * 4);
-    c.gf = o; o = al256(o + R * 32 * 4);
-    c.gxapp = o; o = al256(o + R * 144 * 4);
     c.total = o;
     return c;
 }
@@ -617,8 +617,12 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     char* fw = (char*)fwd_workspace;
     char* bw = (char*)bwd_workspace;
     float* x144 = (float*)(bw + b.x144); float* feat32 = (float*)(bw + b.feat32); float* h0 = (float*)(bw + b.h0);
-    float* h1 = (float*)(bw + b.h1); float4* go = (float4*)(bw + b.go); float* g1 = (float*)(bw + b.g1); float* g0 = (float*)(bw + b.g0);
-    float* xpe = (float*)(bw + b.xpe); float* gx = (float*)(bw + b.gx); float* gf = (float*)(bw + b.gf); float* gxapp = (float*)(bw + b.gxapp);
+    float* h1 = (float*)(bw + b.h1); float4* go = (float4*)(bw + b.go); float* xpe = (float*)(bw + b.xpe);
+    float* g1 = h1;      // k_bwd_l2 rewrites each element in place
+    float* g0 = h0;      // gemm_nn reads the ReLU mask and writes the masked product at the same element
+    float* gx = xpe;     // xpe is dead once dW0 has been accumulated
+    float* gf = feat32;  // k_pe_bwd: element-in-place
+    float* gxapp = x144; // x144 is dead once dWb has been accumulated
     const float4* app_pos = (const float4*)(fw + c.app_pos);
     const int* app_ray = (const int*)(fw + c.app_ray);
     float4* app_rgb = (float4*)(fw + c.app_rgb);
@@ -669,11 +673,11 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
                            (long long)rows, P->mlp_w2, g1, g->mlp_w2, g->mlp_b2);
         // 4. layers 1, 0, PE, basis
         if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, s);
-        if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 2047) / 2048)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 2048);
+        if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
         launch_gemm_nn(g1, 128, P->mlp_w1, 128, rows, 128, 128, h0, 128, g0, 128, s);
         hipLaunchKernelGGL(k_pe_fwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)feat32, (long long)rows, xpe);
         if (g->mlp_w0) launch_gemm_tn<4>(g0, 128, xpe, 352, rows, 128, 351, g->mlp_w0, 351, s);
-        if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 2047) / 2048)), dim3(256), 0, s, (const float*)g0, 128, (long long)rows, 128, g->mlp_b0, 2048);
+        if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, s, (const float*)g0, 128, (long long)rows, 128, g->mlp_b0, 128);
         launch_gemm_nn(g0, 128, P->mlp_w0, 351, rows, 128, 351, nullptr, 0, gx, 352, s);
         hipLaunchKernelGGL(k_pe_bwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)gx, (const float*)feat32, (long long)rows, gf);
         if (g->basis_weight) launch_gemm_tn<1>(gf, 32, x144, 144, rows, 27, 144, g->basis_weight, 144, s);

@@ -476,7 +476,11 @@ class _RenderFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             rows = C.c_int64(0)
             _lib.check(lib.t2n_render_ctx_rows(_lib.ptr(ctx.ws), R, ctx.N, st, C.byref(rows)), "t2n_render_ctx_rows")
-            bws = torch.empty(int(lib.t2n_backward_workspace_bytes(rows.value)), dtype=torch.uint8, device=dev)
+            # shared grow-only scratch (geometric growth): the row count changes every iteration, and a fresh
+            # multi-GB torch.empty per backward would hit hipMalloc each time
+            need = int(lib.t2n_backward_workspace_bytes(rows.value))
+            bws = workspace(dev, need) if _WORKSPACE.get(str(dev)) is not None and _WORKSPACE[str(dev)].numel() >= need \
+                else workspace(dev, int(need * 1.5))
             _lib.check(lib.t2n_render_backward(field._handle, _lib.ptr(rays), R, rays.shape[1], ctx.N, ctx.flags,
                                                _lib.ptr(jitter), _lib.ptr(d_rgb), _lib.ptr(d_depth), _lib.ptr(d_w),
                                                C.byref(gs), _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.ptr(bws), bws.numel(),
