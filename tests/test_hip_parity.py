@@ -349,3 +349,24 @@ def test_train_batch_gradients_vs_oracle_300():
     ref = {k: v.grad.numpy() for k, v in P.items()}
     worst = _grad_check(f, ref, rel=1e-3)
     print("300^3 train-batch max relative gradient errors:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+def test_coherent_density_path_is_bitwise_identical():
+    """The opt-in LDS-staged density kernel (T2N_FLAG_COHERENT: 16 adjacent rays per wave, shared taps fetched once) must
+    reproduce the fused march kernel bit for bit — on an image-ordered frame (staged path) and on shuffled rays (per-step
+    fallback to direct gathers)."""
+    aabb = [[-8.0] * 3, [8.0] * 3]
+    f = make_field(synth.make_field_params(0, [300] * 3, scene="S1-soft", aabb=aabb), [300] * 3, aabb, [0.5, 8.0])
+    rays = torch.from_numpy(synth.frame_rays_np(200, 200, c2w=synth.look_pose(0.2, -0.1, (0.3, 0.1, -0.5)))).to(dev())
+    perm = torch.from_numpy(np.random.Generator(np.random.PCG64(3)).permutation(rays.shape[0])).to(dev())
+    for r in (rays, rays[perm].contiguous()):
+        with torch.no_grad():
+            f.coherent_eval = False
+            a = f(r)
+            sa = f.stats()
+            f.coherent_eval = True
+            b = f(r)
+            sb = f.stats()
+        assert sa == sb
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
