@@ -196,6 +196,20 @@ def main():
         out["g6_train_jitter"] = jit.numpy()
         out["g6_train_rgb"], out["g6_train_depth"] = rgb.numpy(), depth.numpy()
         out["g6_train_z"], out["g6_train_w"] = zv.numpy(), wt.numpy()
+        # train + white_bg=False: the reference then flips a coin on the CPU generator AFTER the jitter draw (:497)
+        for seed in (7, 8, 9, 10):
+            torch.manual_seed(seed)
+            _ = torch.rand(rays.shape[0], 1)
+            coin = bool(torch.rand((1,)) < 0.5)
+            torch.manual_seed(seed)
+            rgb, depth, zv, wt = m(rays, is_train=True, white_bg=False, ndc_ray=False, N_samples=40)
+            out[f"g6_trainblack{seed}_coin"] = np.array(coin)
+            out[f"g6_trainblack{seed}_rgb"], out[f"g6_trainblack{seed}_depth"] = rgb.numpy(), depth.numpy()
+        # filtering_rays(bbox_only=True) on the edge rays (:385-391)
+        frays = torch.cat([rays, rays[:, [3, 4, 5, 0, 1, 2]] * 3.0], 0)
+        kept = quiet(m.filtering_rays, frays, torch.zeros(frays.shape[0], 3), bbox_only=True)
+        out["g16_rays"] = frays.numpy()
+        out["g16_kept"] = kept[0].numpy()
 
     # G7 renderer harness: R not divisible by chunk
     with torch.no_grad():

@@ -370,3 +370,49 @@ def test_coherent_density_path_is_bitwise_identical():
         assert sa == sb
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9, 10])
+def test_g6_train_black_background_coin(tiny, field, seed):
+    """RNG stream parity: jitter draw, then the background coin (models/tensorBase.py:313-317,497), both on the CPU generator."""
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        rgb, depth, _, _ = field(torch.from_numpy(tiny["tiny_rays"]), is_train=True, white_bg=False, N_samples=40)
+    close(rgb, tiny[f"g6_trainblack{seed}_rgb"], atol=RGB_ATOL)
+    close(depth, tiny[f"g6_trainblack{seed}_depth"], atol=DEPTH_ATOL)
+
+
+def test_g16_filtering_rays_bbox(tiny, field):
+    rays = torch.from_numpy(tiny["g16_rays"])
+    kept, rgbs = field.filtering_rays(rays, torch.zeros(rays.shape[0], 3), bbox_only=True)
+    assert np.array_equal(kept.numpy(), tiny["g16_kept"]) and rgbs.shape[0] == kept.shape[0]
+
+
+def test_anisotropic_grid_outside_rays_and_long_sampling():
+    """Grid 96x64x48 in a non-cubic box, rays starting OUTSIDE the box from all sides, N up to 1500 (> one LDS chunk many
+    times over) and N = 1: vs the oracle."""
+    from oracle import oracle_torch as O
+    grid, aabb, nf = [96, 64, 48], [[-3.0, -2.0, -1.5], [3.0, 2.0, 1.5]], [0.1, 12.0]
+    params = synth.make_field_params(21, grid, density_scale=0.8, aabb=aabb)
+    f = make_field(params, grid, aabb, nf)
+    f.z_gate = -100.0          # the hard-coded eval gate (world z > 2) would hide this small box: move it out of the way
+    f._handle = None           # re-create the native field with the new scalar
+    f._uploaded_key = None
+    g = np.random.Generator(np.random.PCG64(17))
+    o = g.normal(0, 1, (600, 3)).astype(np.float32)
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * 7.0
+    tgt = g.uniform(-1, 1, (600, 3)).astype(np.float32) * np.array([2.5, 1.5, 1.0], np.float32)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = torch.from_numpy(np.concatenate([o, d], 1).astype(np.float32))
+    cfg = O.FieldConfig(aabb=aabb, grid_size=grid, near_far=nf, z_gate=-100.0)
+    P = O.params_from_numpy(params)
+    for n in (-1, 1500, 1, 64, 65):
+        o_rgb, o_depth, o_z, o_w = O.forward(cfg, P, rays, n_samples=n)
+        with torch.no_grad():
+            rgb, depth, z, w = f(rays, N_samples=n)
+        close(z, o_z.numpy(), atol=0)
+        close(w, o_w.numpy(), atol=W_ATOL, rtol=W_RTOL, msg=f"N={n}")
+        close(rgb, o_rgb.numpy(), atol=RGB_ATOL)
+        close(depth, o_depth.numpy(), atol=DEPTH_ATOL)
+        assert f.stats()["appearance"] == int((o_w > 1e-4).sum()) or abs(f.stats()["appearance"] - int((o_w > 1e-4).sum())) <= 2

@@ -167,3 +167,16 @@ def test_big300_spot(big300, scene, seed):
     close(rgb, big300[f"{scene}_train_rgb"], atol=1e-5)
     close(depth, big300[f"{scene}_train_depth"], atol=5e-5)
     close(w.sum(-1), big300[f"{scene}_train_acc"], atol=1e-5)
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9, 10])
+def test_g6_train_black_background_coin(tiny, cfg, P, seed):
+    """white_bg=False in train mode: the reference adds the background iff torch.rand((1,)) < 0.5, drawn after the jitter."""
+    torch.manual_seed(seed)
+    jit = torch.rand(tiny["tiny_rays"].shape[0], 1)
+    coin = bool(torch.rand((1,)) < 0.5)
+    assert coin == bool(tiny[f"g6_trainblack{seed}_coin"])
+    rgb, depth, _, _ = O.forward(cfg, P, T(tiny["tiny_rays"]), white_bg=False, is_train=True, n_samples=40, jitter=jit,
+                                 bg_coin=coin)
+    close(rgb, tiny[f"g6_trainblack{seed}_rgb"], atol=5e-6)
+    close(depth, tiny[f"g6_trainblack{seed}_depth"], atol=2e-5)
