@@ -87,7 +87,7 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0):
                       f"oracle_c (plain C, OpenMP {cores} threads), {dt:.1f} s"}
 
 
-def train_bench(dev, iters=20, warmup=3):
+def train_bench(dev, iters=20, warmup=3, fused_optim=False):
     """C3-shaped optimisation step (text2nerf_main.py:547-601): 16 384 random rays of 9 small-baseline 512x512 views,
     N=259, is_train, MSE(rgb)+0.005 MSE(depth)+1e3 transmittance+TV(density 0.1, app 0.01), Adam(0.02/1e-3)."""
     from text2nerf_amd import OctreeRender_trilinear_fast, synth
@@ -107,7 +107,11 @@ def train_bench(dev, iters=20, warmup=3):
               torch.from_numpy(g.normal(0, 0.05, (allrays.shape[0], 3)).astype(np.float32))).clamp(0, 1)
     alldepth = dep_s.cpu().repeat_interleave(4, 0)[: allrays.shape[0]] + torch.from_numpy(
         g.normal(0, 0.05, (allrays.shape[0],)).astype(np.float32))
-    opt = torch.optim.Adam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    if fused_optim:   # TV gradient + Adam as HIP streaming kernels (text2nerf_amd/optim.py)
+        from text2nerf_amd.optim import TVAdam
+        opt = TVAdam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    else:
+        opt = torch.optim.Adam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
     tv, tl = TVLoss(), TransMittanceLoss_mask(dev)
     np.random.seed(1024)
     torch.manual_seed(1024)
@@ -121,10 +125,14 @@ def train_bench(dev, iters=20, warmup=3):
                                                           ndc_ray=False, device=dev, is_train=True)
         loss = torch.mean((rgb - rgb_t) ** 2) + 0.005 * torch.mean((depth - dep_t) ** 2)
         loss = loss + 1e3 * tl(w, (z - dep_t[:, None] + 0.1) < 0)
-        loss = loss + field.TV_loss_density(tv) * 0.1 + field.TV_loss_app(tv) * 0.01
+        if not fused_optim:
+            loss = loss + field.TV_loss_density(tv) * 0.1 + field.TV_loss_app(tv) * 0.01
         opt.zero_grad()
         loss.backward()
-        opt.step()
+        if fused_optim:
+            opt.step(tv=[(field.density_plane, 0.1), (field.app_plane, 0.01)])
+        else:
+            opt.step()
         return loss
 
     for k in range(warmup):
@@ -135,8 +143,11 @@ def train_bench(dev, iters=20, warmup=3):
         loss = it(warmup + k)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if fused_optim:
+        return {"train_iters_per_s_fused_optim": iters / dt, "train_ms_per_iter_fused_optim": dt / iters * 1e3}
     return {"train_iters_per_s": iters / dt, "train_ms_per_iter": dt / iters * 1e3, "train_iters": iters,
-            "train_step": f"C3-shaped: {batch} rays x {n_samples} samples, fwd+bwd HIP, TV+Adam torch, loss {float(loss):.4f}",
+            "train_step": f"C3-shaped: {batch} rays x {n_samples} samples, fwd+bwd HIP, TV+Adam torch (reference-form "
+                          f"step), loss {float(loss.detach()):.4f}; *_fused_optim: TV gradient + Adam as HIP kernels",
             "train_appearance_samples": field.stats()["appearance"]}
 
 
@@ -268,6 +279,7 @@ def main():
         if world == 1 and not args.no_train:
             del rays
             out["config"].update(train_bench(dev))
+            out["config"].update(train_bench(dev, fused_optim=True))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params, aabb, 300, N)
         print(json.dumps(out))

@@ -180,6 +180,16 @@ int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray
                         const t2n_field_grads* g, void* fwd_workspace, size_t fwd_workspace_bytes, void* bwd_workspace,
                         size_t bwd_workspace_bytes, t2n_stream stream);
 
+/* ---- SURVEY.md 8(f-1), optional: the dense tail of the training step as streaming kernels.
+ * t2n_tv_grad_add: grad += d/dparam [ weight * TVLoss(param) ] for one reference-layout plane [1,C,H,W]
+ *   (utils.py:488-504; the driver's term is TV_loss_*(tvreg) * TV_weight with TV_loss_* = sum_planes 1e-2 * TVLoss,
+ *   models/tensoRF.py:193-203 — pass weight = 1e-2 * TV_weight).
+ * t2n_adam_step: torch.optim.Adam's update (betas, eps; no weight decay, no amsgrad) on one tensor, `step` = 1-based
+ *   step count of that tensor (text2nerf_main.py:453-454,590). */
+int t2n_tv_grad_add(const float* param, float* grad, int C, int H, int W, float weight, t2n_stream stream);
+int t2n_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int64_t step, t2n_stream stream);
+
 /* ---- measurement hooks (bench.py): when enabled, each kernel launch of the render call is bracketed by HIP events on
  * the launch stream. t2n_timing_read synchronises those events and returns accumulated milliseconds and launch counts
  * per kernel since the last reset. Kernel ids: */

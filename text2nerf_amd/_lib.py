@@ -75,6 +75,9 @@ SIGNATURES = {
     "t2n_render_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FieldGrads), C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "t2n_tv_grad_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "t2n_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                C.c_float, C.c_int64, C.c_void_p]),
     "t2n_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "t2n_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
 }
