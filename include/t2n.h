@@ -48,8 +48,9 @@ enum {
     T2N_FLAG_TRAIN = 1u,      /* is_train: per-ray jitter, no z gate (models/tensorBase.py:314-316,459) */
     T2N_FLAG_ADD_BG = 2u,     /* rgb_map += 1-acc  (white_bg, or the train-time coin; models/tensorBase.py:497-498) */
     T2N_FLAG_KEEP_CTX = 4u,   /* keep the per-call context in the workspace for t2n_render_backward */
-    T2N_FLAG_COHERENT = 8u    /* hint: consecutive rays are neighbouring pixels (image order): evaluate density 16 rays at a
-                                 time with LDS-staged shared taps. Results are bitwise identical with or without the hint */
+    T2N_FLAG_COHERENT = 8u    /* hint (eval): rays are a row-major image whose width was given by t2n_field_set_frame_width:
+                                 march 8x8-pixel tiles with LDS-staged shared taps. Same samples, same arithmetic per sample;
+                                 the transmittance is a sequential product instead of a wave scan (weights agree to ~1e-7) */
 };
 
 /* Scalars of TensorBase.__init__/update_stepSize (models/tensorBase.py:163-231), computed by the host mirror. */
@@ -121,6 +122,8 @@ int t2n_field_set_desc(t2n_field* f, const t2n_field_desc* desc);
  * accumulation; exact_fp32 = 1: v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains (5x the matrix-core time). The backward
  * pass always recomputes activations with the exact path. */
 int t2n_field_set_mlp_precision(t2n_field* f, int exact_fp32);
+/* Image width of the row-major frames passed with T2N_FLAG_COHERENT (0 = unknown: the flag is ignored). */
+int t2n_field_set_frame_width(t2n_field* f, int width);
 
 /* ---- a-1/a-2: get_ray_directions (dataLoader/ray_utils.py:24-42), normalisation (dataLoader/scene_gen.py:45),
  *      get_rays (dataLoader/ray_utils.py:66-87) */

@@ -351,25 +351,47 @@ def test_train_batch_gradients_vs_oracle_300():
     print("300^3 train-batch max relative gradient errors:", {k: f"{v:.1e}" for k, v in worst.items()})
 
 
-def test_coherent_density_path_is_bitwise_identical():
-    """The opt-in LDS-staged density kernel (T2N_FLAG_COHERENT: 16 adjacent rays per wave, shared taps fetched once) must
-    reproduce the fused march kernel bit for bit — on an image-ordered frame (staged path) and on shuffled rays (per-step
-    fallback to direct gathers)."""
+def test_tile_marcher_matches_per_ray_marcher(big300):
+    """frame_width hint -> 8x8-pixel tile marcher (LDS-staged shared taps, sequential transmittance): same samples (exact
+    counts, bit-exact z), weights/rgb/depth equal to the per-ray marcher within fp32 scan re-association, goldens hold,
+    ragged image sizes (not multiples of 8) and multi-band sub-launches covered."""
+    import os
+    from text2nerf_amd import tensorf as tf
     aabb = [[-8.0] * 3, [8.0] * 3]
     f = make_field(synth.make_field_params(0, [300] * 3, scene="S1-soft", aabb=aabb), [300] * 3, aabb, [0.5, 8.0])
-    rays = torch.from_numpy(synth.frame_rays_np(200, 200, c2w=synth.look_pose(0.2, -0.1, (0.3, 0.1, -0.5)))).to(dev())
-    perm = torch.from_numpy(np.random.Generator(np.random.PCG64(3)).permutation(rays.shape[0])).to(dev())
-    for r in (rays, rays[perm].contiguous()):
+    for (H, W) in ((200, 200), (37, 53)):
+        rays = torch.from_numpy(synth.frame_rays_np(H, W, c2w=synth.look_pose(0.2, -0.1, (0.3, 0.1, -0.5)))).to(dev())
         with torch.no_grad():
-            f.coherent_eval = False
-            a = f(r)
+            f.frame_width = 0
+            a = f(rays)
             sa = f.stats()
-            f.coherent_eval = True
-            b = f(r)
+            f.frame_width = W
+            b = f(rays)
             sb = f.stats()
-        assert sa == sb
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
+        assert sa["evaluated"] == sb["evaluated"] and abs(sa["appearance"] - sb["appearance"]) <= 2
+        assert torch.equal(a[2], b[2])                                   # z_vals
+        close(b[3], a[3].cpu().numpy(), atol=2e-6, rtol=2e-5)            # weights
+        close(b[0], a[0].cpu().numpy(), atol=2e-5)
+        close(b[1], a[1].cpu().numpy(), atol=5e-5)
+    # golden rays embedded in a full 800x800 frame rendered by the tile marcher through several sub-launches
+    full = torch.from_numpy(synth.frame_rays_np(800, 800)).to(dev())
+    f.frame_width = 800
+    f.materialize_weights = False
+    old = os.environ.get("T2N_WORKSPACE_GIB")
+    os.environ["T2N_WORKSPACE_GIB"] = "1.0"
+    try:
+        tf._WORKSPACE.clear()
+        with torch.no_grad():
+            rgb, depth, _, _ = f(full)
+    finally:
+        if old is None:
+            os.environ.pop("T2N_WORKSPACE_GIB")
+        else:
+            os.environ["T2N_WORKSPACE_GIB"] = old
+        tf._WORKSPACE.clear()
+    idx = torch.from_numpy(big300["S1-soft_idx"]).to(dev())
+    close(rgb[idx], big300["S1-soft_rgb"], atol=RGB_ATOL)
+    close(depth[idx], big300["S1-soft_depth"], atol=DEPTH_ATOL)
 
 
 @pytest.mark.parametrize("seed", [7, 8, 9, 10])

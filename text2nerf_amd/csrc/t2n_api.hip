@@ -302,7 +302,9 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     if (stats) T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s));
     if (n_rays == 0) return T2N_OK;
     const bool keep = (flags & T2N_FLAG_KEEP_CTX) != 0;
-    const bool coherent = (flags & T2N_FLAG_COHERENT) != 0 && !keep;
+    // tile marcher: image-ordered eval rays with a known width (hint), whole rows per sub-launch
+    const bool tiles = (flags & T2N_FLAG_COHERENT) != 0 && !keep && !(flags & T2N_FLAG_TRAIN) && f->frame_w >= 8 &&
+                       n_rays % f->frame_w == 0 && n_rays / f->frame_w >= 8;
     if (keep) {
         if (carve_workspace(n_rays, n_samples, true).total > workspace_bytes || (uint64_t)list_capacity(n_rays, n_samples) * kLists > 0x7fffffffull) {
             set_error("t2n_render_forward: KEEP_CTX needs the whole call in one launch (workspace %zu B < %zu B)", workspace_bytes,
@@ -316,6 +318,11 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     while (per > 1 && carve(per, n_samples).total > workspace_bytes) per = (per + 1) / 2;
     if (carve(per, n_samples).total > workspace_bytes) { set_error("t2n_render_forward: workspace %zu B too small", workspace_bytes); return T2N_ERR_WORKSPACE; }
     while ((uint64_t)list_capacity(per, n_samples) * kLists > 0x7fffffffull) per = (per + 1) / 2;   // int slots
+    if (tiles && per < n_rays) {   // sub-launches must cover whole 8-row bands of the image
+        const int64_t band = (int64_t)8 * f->frame_w;
+        per = per / band * band;
+        if (per <= 0) { set_error("t2n_render_forward: workspace too small for one 8-row band"); return T2N_ERR_WORKSPACE; }
+    }
     char* ws = (char*)workspace;
     for (int64_t off = 0; off < n_rays; off += per) {
         const int64_t cnt = (n_rays - off) < per ? (n_rays - off) : per;
@@ -332,18 +339,22 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         L.list_cap = c.list_cap;
         L.sigma_ctx = keep ? (float*)(ws + c.sigma) : nullptr;
         L.rgb_raw = keep ? (float4*)(ws + c.rgb_raw) : nullptr;
-        L.sigma_in = nullptr;
         T2N_HIP(hipMemsetAsync(L.counters, 0, (size_t)kLists * kCounterStride * 4, s));
         int rc;
-        if (coherent) {
-            float* sg = (float*)(ws + c.sigma);
-            if ((rc = launch_density_tiles(f, L, sg, s))) return rc;
-            L.sigma_in = sg;
-        }
-        if ((rc = launch_march(f, L, s))) return rc;
+        if (tiles) {
+            // weights go straight to the caller's tensor when it was requested, else to the scratch region
+            float* wbuf = L.weights ? L.weights : (float*)(ws + c.sigma);
+            if ((rc = launch_march_tiles(f, L, f->frame_w, (int)(cnt / f->frame_w), wbuf, L.weights != nullptr, s))) return rc;
+        } else if ((rc = launch_march(f, L, s))) return rc;
         if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, nullptr, s))) return rc;
         if ((rc = launch_composite(f, L, s))) return rc;
     }
+    return T2N_OK;
+}
+
+extern "C" int t2n_field_set_frame_width(t2n_field* f, int width) {
+    if (!f || width < 0) { set_error("t2n_field_set_frame_width: bad argument"); return T2N_ERR_INVALID; }
+    f->frame_w = width;
     return T2N_OK;
 }
 

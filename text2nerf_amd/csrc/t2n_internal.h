@@ -68,6 +68,7 @@ struct t2n_field {
     t2n_field_params params_ref;   // reference-layout parameter pointers of the last upload (backward reads W^T operands)
     bool uploaded = false;
     int timing = 0;
+    int frame_w = 0;           // image width hint for the tile marcher (0: unknown)
     t2n::TimingSlot slots[T2N_K_COUNT];
 };
 
@@ -96,10 +97,10 @@ struct RenderLaunch {
     // workspace carve (one sub-launch)
     float* acc; int4* ray_app; unsigned* counters; float4* app_pos; int* app_ray; float4* app_rgb; unsigned list_cap;
     float* sigma_ctx; float4* rgb_raw;   // KEEP_CTX only, else NULL
-    const float* sigma_in;               // COHERENT: density precomputed by k_density_tiles, else NULL
 };
 int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s);
-int launch_density_tiles(t2n_field* f, const RenderLaunch& L, float* sigma, hipStream_t s);
+int launch_ray_stats(const RenderLaunch& L, hipStream_t s);
+int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h, float* wbuf, bool wbuf_is_output, hipStream_t s);
 constexpr int kLists = 8;   // appearance sub-lists per sub-launch
 constexpr int kCounterStride = 64;   // unsigned words between sub-list counters: one 256-B line each (same-line atomics serialise)
 // list_cap(n_rays, N): worst-case entries of one sub-list = rays of the largest XCD run x samples

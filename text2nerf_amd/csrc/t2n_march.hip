@@ -27,11 +27,10 @@ struct MarchArgs {
     float4* app_pos; int* app_ray; int4* ray_app; unsigned* counters; unsigned list_cap;
     unsigned long long* stats;
     float* sigma_ctx;    // [n_rays, n_samples] kept for the backward pass (KEEP_CTX) or NULL
-    const float* sigma_in;   // [n_rays, n_samples] written by k_density_tiles (SIGMA_IN variant)
     unsigned nblocks;
 };
 
-template <bool TRAIN, int DC, bool SIGMA_IN>
+template <bool TRAIN, int DC>
 __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LPS = DC / 4;          // lanes per sample
@@ -118,7 +117,6 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
     const int Lw = last - first + 1;   // window length (<= 0: empty ray)
 
     if (Lw > 0) {
-      if constexpr (!SIGMA_IN) {
         // ---- pass B: density -------------------------------------------------------------------------------------
         const int q = lane & (LPS - 1);
         const int sl = lane / LPS;
@@ -156,7 +154,6 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
         // LDS window written by lanes of this wave only; a wave is in lock-step, but the compiler needs the fence.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-      }
 
         // ---- pass C: alpha, transmittance scan, weights ------------------------------------------------------------
         float carry = 1.f;
@@ -165,13 +162,8 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
             const int i = first + j;
             float sg = 0.f, z = 0.f, dist = 0.f;
             if (j < Lw) {
+                sg = sig[j];
                 z = sample_z<TRAIN>(F, ray, i, u);
-                if constexpr (SIGMA_IN) {
-                    float xn, yn, zn;
-                    sg = sample_point<TRAIN>(F, ray, z, xn, yn, zn) ? a.sigma_in[r * N + i] : 0.f;
-                } else {
-                    sg = sig[j];
-                }
                 if (i < N - 1) dist = sample_z<TRAIN>(F, ray, i + 1, u) - z;   // :448, last sample gets 0
             }
             const float d = dist * F.dscale;
@@ -382,16 +374,14 @@ int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
     const size_t lds = (size_t)4 * 2 * a.npad * sizeof(float);
     const bool train = (L.flags & T2N_FLAG_TRAIN) != 0;
     timing_begin(f, T2N_K_MARCH, s);
-    a.sigma_in = L.sigma_in;
-    if (L.sigma_in) {
-        if (train) hipLaunchKernelGGL((k_march<true, 16, true>), dim3(a.nblocks), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((k_march<false, 16, true>), dim3(a.nblocks), dim3(256), lds, s, a);
-    } else {
-        if (train) hipLaunchKernelGGL((k_march<true, 16, false>), dim3(a.nblocks), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((k_march<false, 16, false>), dim3(a.nblocks), dim3(256), lds, s, a);
-    }
+    if (train) hipLaunchKernelGGL((k_march<true, 16>), dim3(a.nblocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((k_march<false, 16>), dim3(a.nblocks), dim3(256), lds, s, a);
     timing_end(f, T2N_K_MARCH, s);
     T2N_HIP(hipGetLastError());
+    return launch_ray_stats(L, s);
+}
+
+int launch_ray_stats(const RenderLaunch& L, hipStream_t s) {
     if (L.stats) {
         unsigned nb = (unsigned)((L.n_rays + 255) / 256);
         if (nb > 64) nb = 64;

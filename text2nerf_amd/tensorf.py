@@ -100,7 +100,8 @@ class TensorVMSplit(nn.Module):
         self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC = shadingMode, pos_pe, view_pe, fea_pe, featureC
         self.materialize_weights = True   # the reference always returns weights/z_vals; set False to skip 8*N B/ray
         self.z_gate = 2.0                 # models/tensorBase.py:460
-        self.coherent_eval = False        # opt-in: LDS-staged density kernel for image-ordered eval rays (same results)
+        self.frame_width = 0              # set to the image width when eval rays are whole row-major frames: enables the
+                                          # 8x8-tile marcher (LDS-staged shared taps); 0 = unknown -> per-ray marcher
         self.mlp_exact_fp32 = os.environ.get("T2N_MLP_EXACT", "0") == "1"   # False: f16 two-way-split MFMA products
         self._handle = None
         self._uploaded_key = None
@@ -271,6 +272,10 @@ class TensorVMSplit(nn.Module):
             _lib.check(lib.t2n_field_create(C.byref(d), C.byref(h)), "t2n_field_create")
             self._handle = h
             self._precision_set = None
+            self._frame_w_set = None
+        if getattr(self, "_frame_w_set", None) != int(self.frame_width):
+            _lib.check(lib.t2n_field_set_frame_width(self._handle, int(self.frame_width)), "t2n_field_set_frame_width")
+            self._frame_w_set = int(self.frame_width)
         if self._precision_set != bool(self.mlp_exact_fp32):
             _lib.check(lib.t2n_field_set_mlp_precision(self._handle, 1 if self.mlp_exact_fp32 else 0),
                        "t2n_field_set_mlp_precision")
@@ -398,7 +403,7 @@ class TensorVMSplit(nn.Module):
             if not white_bg:
                 add_bg = bool(torch.rand((1,)) < 0.5)   # models/tensorBase.py:497
         flags = (FLAG_TRAIN if is_train else 0) | (FLAG_ADD_BG if add_bg else 0)
-        if not is_train and self.coherent_eval:
+        if not is_train and self.frame_width and R % int(self.frame_width) == 0:
             flags |= FLAG_COHERENT
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._all_params())
         if needs_grad:

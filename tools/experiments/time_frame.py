@@ -7,8 +7,8 @@ dev = torch.device("cuda:0")
 field, params, aabb = build_field(dev)
 field.materialize_weights = False
 rays = torch.from_numpy(synth.frame_rays_np(800, 800)).to(dev)
-for coh in (True, False):
-  field.coherent_eval = coh
+for coh in (800, 0):
+  field.frame_width = coh
   with torch.no_grad():
     for _ in range(2): field(rays)
     field.timing(True); field.read_timing(True)
