@@ -139,12 +139,24 @@ constexpr int kBasisChunksReal = 9, kL0ChunksReal = 23;
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
+    // hi = x truncated to an 11-bit significand (mask), exactly representable in f16, so the packed round-toward-zero
+    // conversion is exact and no convert-back is needed for the residual; lo = f16(x - hi) carries the next 11 bits.
+    typedef __fp16 hh2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    float t[8], r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const _Float16 a = (_Float16)x[e];
-        hi[e] = a;
-        lo[e] = (_Float16)(x[e] - (float)a);
+        t[e] = __uint_as_float(__float_as_uint(x[e]) & 0xffffe000u);
+        r[e] = x[e] - t[e];
     }
+    u4 uh, ul;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        uh[e] = __builtin_bit_cast(unsigned, (hh2)__builtin_amdgcn_cvt_pkrtz(t[2 * e], t[2 * e + 1]));
+        ul[e] = __builtin_bit_cast(unsigned, (hh2)__builtin_amdgcn_cvt_pkrtz(r[2 * e], r[2 * e + 1]));
+    }
+    hi = __builtin_bit_cast(h8, uh);
+    lo = __builtin_bit_cast(h8, ul);
 }
 
 // acc[m] += W_chunk,m (split) x B_chunk (split on the fly); A operands double-buffered one chunk ahead.
@@ -176,6 +188,24 @@ __device__ __forceinline__ void f16_stream(f32x16 (&acc)[NMB], const uint4* __re
         fetch(A1, c + 1); run(A0, c);
         fetch(A0, c + 2); run(A1, c + 1);   // the last prefetch reads the zero pad chunk
     }
+}
+
+// Branch-free sincos for the positional encoding: two-constant Cody-Waite reduction by pi/2 with FMAs, cephes minimax
+// polynomials on [-pi/4, pi/4], quadrant fix-up by selects. Max abs error 9.4e-8 for |x| <= 5000 (libm-class); no control
+// flow, so the compiler can interleave it with the MFMAs of the neighbouring chunk (ocml's sincosf carries a
+// large-argument branch that splits the basic block). Callers route |x| > 8192 to sincosf.
+__device__ __forceinline__ void fast_sincosf(float x, float* sn, float* cs) {
+    const float k = rintf(x * 0.6366197723675814f);
+    float r = fmaf(-k, 1.5707963705062866f, x);
+    r = fmaf(-k, -4.371138828673793e-8f, r);
+    const float z = r * r;
+    const float s = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float c = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                         fmaf(z, -0.5f, 1.f));
+    const int q = (int)k & 3;
+    const float s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
 }
 
 // B chunk from the wave's LDS tile T[unit][kXld]
@@ -214,7 +244,9 @@ struct PeChunk {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 if (p == 0 || qo == 0) {
-                    sincosf(fe[(size_t)f * kXld] * (float)(1 << qo), &sn, &cs);
+                    const float arg = fe[(size_t)f * kXld] * (float)(1 << qo);
+                    if (__builtin_expect(__any(fabsf(arg) > 8192.f), 0)) sincosf(arg, &sn, &cs);
+                    else fast_sincosf(arg, &sn, &cs);
                 } else {
                     const float s2 = 2.f * sn * cs, c2 = (cs - sn) * (cs + sn);
                     sn = s2; cs = c2;
