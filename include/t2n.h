@@ -122,6 +122,13 @@ int t2n_field_set_desc(t2n_field* f, const t2n_field_desc* desc);
  * accumulation; exact_fp32 = 1: v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains (5x the matrix-core time). The backward
  * pass always recomputes activations with the exact path. */
 int t2n_field_set_mlp_precision(t2n_field* f, int exact_fp32);
+/* a-7 (optional): AlphaGridMask (models/tensorBase.py:41-59). volume = device fp32 [D(z),H(y),W(x)] occupancy (copied);
+ * aabb_min / inv_size (= 1/aabbSize*2, fp32 as the reference computes it) are HOST float[3]. Samples whose trilinear
+ * mask value is not > 0 are dropped from ray_valid (:451-456). volume = NULL removes the mask. The tile marcher is
+ * bypassed while a mask is set. t2n_alpha_at = AlphaGridMask.sample_alpha at world points. */
+int t2n_field_set_alpha_mask(t2n_field* f, const float* volume, int D, int H, int W, const float* aabb_min_host,
+                             const float* inv_size_host, t2n_stream stream);
+int t2n_alpha_at(const t2n_field* f, const float* xyz_world, int64_t n, float* alpha, t2n_stream stream);
 /* Image width of the row-major frames passed with T2N_FLAG_COHERENT (0 = unknown: the flag is ignored). */
 int t2n_field_set_frame_width(t2n_field* f, int width);
 

@@ -47,6 +47,8 @@ class FieldConfig:
     shading_mode: str = "MLP_Fea_noview"
     fea2dense_act: str = "softplus"
     z_gate: float = 2.0   # models/tensorBase.py:460 (hard-coded 2.)
+    alpha_volume: Optional[torch.Tensor] = None   # AlphaGridMask volume [D(z), H(y), W(x)] or None (models/tensorBase.py:41-59)
+    alpha_aabb: Optional[Sequence[Sequence[float]]] = None
     step_size: float = field(init=False)
     n_samples: int = field(init=False)
 
@@ -119,6 +121,28 @@ def normalize_coord(cfg: FieldConfig, xyz):
     aabb = torch.tensor(cfg.aabb, dtype=xyz.dtype)
     inv = 2.0 / (aabb[1] - aabb[0])
     return (xyz - aabb[0]) * inv - 1
+
+
+def sample_alpha(cfg: FieldConfig, xyz):
+    """AlphaGridMask.sample_alpha (models/tensorBase.py:52-59): 3-D grid_sample (trilinear, zeros padding,
+    align_corners=True) of the occupancy volume at world points, restated as 8 explicit taps."""
+    vol = cfg.alpha_volume.to(xyz.dtype)
+    D, H, W = vol.shape
+    a = torch.tensor(cfg.alpha_aabb, dtype=xyz.dtype)
+    g = (xyz - a[0]) * (1.0 / (a[1] - a[0]) * 2) - 1
+    ix, iy, iz = _unnormalize(g[..., 0], W), _unnormalize(g[..., 1], H), _unnormalize(g[..., 2], D)
+    x0, y0, z0 = torch.floor(ix), torch.floor(iy), torch.floor(iz)
+    fx, fy, fz = ix - x0, iy - y0, iz - z0
+    x0, y0, z0 = x0.long(), y0.long(), z0.long()
+    out = torch.zeros_like(ix)
+    for dz, wz in ((0, 1 - fz), (1, fz)):
+        for dy, wy in ((0, 1 - fy), (1, fy)):
+            for dx, wx in ((0, 1 - fx), (1, fx)):
+                xx, yy, zz = x0 + dx, y0 + dy, z0 + dz
+                ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H) & (zz >= 0) & (zz < D)
+                v = vol[zz.clamp(0, D - 1), yy.clamp(0, H - 1), xx.clamp(0, W - 1)] * ok.to(vol.dtype)
+                out = out + v * (wx * wy * wz)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -266,6 +290,10 @@ def forward(cfg: FieldConfig, params, rays, white_bg=True, is_train=False, n_sam
     ro, rd = rays[:, :3], rays[:, 3:6]
     pts, z, valid = sample_ray(cfg, ro, rd, n, jitter if is_train else None)
     dists = torch.cat([z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])], -1)
+    if cfg.alpha_volume is not None and valid.any():      # models/tensorBase.py:451-456
+        keep = sample_alpha(cfg, pts[valid]) > 0
+        valid = valid.clone()
+        valid[valid.clone()] = keep
     if not is_train:
         valid = valid & (pts[:, :, -1] > cfg.z_gate)
     sigma = torch.zeros(pts.shape[:-1], dtype=pts.dtype)

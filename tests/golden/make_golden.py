@@ -211,6 +211,25 @@ def main():
         out["g16_rays"] = frays.numpy()
         out["g16_kept"] = kept[0].numpy()
 
+    # a-7 alpha mask branch (models/tensorBase.py:41-59,451-456): synthetic occupancy volume on a slightly smaller box
+    from models.tensorBase import AlphaGridMask
+    ag = np.random.Generator(np.random.PCG64(99))
+    vol = (ag.uniform(0, 1, (9, 11, 13)) < 0.30).astype(np.float32)          # [D(z), H(y), W(x)]
+    vol[:, 4:6, 6] = 1.0
+    mask_aabb = torch.tensor([[-7.5, -5.5, -6.5], [7.5, 6.5, 6.0]])
+    out["g7a_volume"], out["g7a_aabb"] = vol, mask_aabb.numpy()
+    m.alphaMask = AlphaGridMask("cpu", mask_aabb, torch.from_numpy(vol))
+    with torch.no_grad():
+        pw = torch.from_numpy(p[:2048]) * torch.tensor([8.5, 7.0, 7.5])
+        out["g7a_pts"] = pw.numpy()
+        out["g7a_alpha"] = m.alphaMask.sample_alpha(pw).numpy()
+        rgb, depth, zv, wt = m(rays, is_train=False, white_bg=True, ndc_ray=False, N_samples=-1)
+        out["g7a_eval_rgb"], out["g7a_eval_depth"], out["g7a_eval_w"] = rgb.numpy(), depth.numpy(), wt.numpy()
+        torch.manual_seed(321)
+        rgb, depth, zv, wt = m(rays, is_train=True, white_bg=True, ndc_ray=False, N_samples=40)
+        out["g7a_train_rgb"], out["g7a_train_depth"], out["g7a_train_w"] = rgb.numpy(), depth.numpy(), wt.numpy()
+    m.alphaMask = None
+
     # G7 renderer harness: R not divisible by chunk
     with torch.no_grad():
         r5 = ref_renderer.OctreeRender_trilinear_fast(rays, m, chunk=64, N_samples=-1, ndc_ray=False,

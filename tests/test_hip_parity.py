@@ -475,3 +475,72 @@ def test_f1_fused_tv_adam_matches_torch(tiny, tiny_params):
         lr = 0.02 if ("plane" in k or "line" in k) else 1e-3
         frac = float(((a[k] - b[k]).abs() > 0.02 * lr).float().mean())
         assert d <= 2.5 * lr * 4 and frac < 1e-3, (k, d, frac)
+
+
+def test_render_views_and_wide_ray_rows(tiny, field):
+    """render_views (device-side rays per pose) equals rendering host-built rays; rays with extra channels use their
+    LAST channel for the depth background term (models/tensorBase.py:505)."""
+    from text2nerf_amd import render_views
+    from oracle import oracle_torch as O
+    poses = [synth.look_pose(0.35, -0.2, (0.4, -0.3, -1.0)), synth.look_pose(-0.2, 0.1, (0.0, 0.2, -0.5))]
+    H, W = 12, 16
+    rgb, depth = render_views(field, poses, [16.0, 16.0, 8, 6], H, W)
+    assert rgb.shape == (2, H, W, 3) and depth.shape == (2, H, W)
+    close(rgb[0].reshape(-1, 3), tiny["g6_eval_rgb"][:192], atol=RGB_ATOL)
+    close(depth[0].reshape(-1), tiny["g6_eval_depth"][:192], atol=DEPTH_ATOL)
+    rays8 = torch.cat([torch.from_numpy(tiny["tiny_rays"]), torch.full((200, 2), 3.25)], 1)
+    cfg = O.FieldConfig(aabb=TINY["aabb"], grid_size=TINY["grid"], near_far=TINY["near_far"])
+    P = O.params_from_numpy({k: v.detach().cpu().numpy() for k, v in field.state_dict().items()})
+    o = O.forward(cfg, P, rays8)
+    with torch.no_grad():
+        g = field(rays8)
+    close(g[1], o[1].numpy(), atol=DEPTH_ATOL)
+    close(g[0], o[0].numpy(), atol=RGB_ATOL)
+
+
+def test_g7a_alpha_mask_branch(tiny, tiny_params):
+    """a-7: AlphaGridMask (models/tensorBase.py:41-59,451-456) — sample_alpha, forward eval/train with a mask, gradients with
+    a mask vs the oracle, checkpoint round trip with the bit-packed volume."""
+    import io
+    from oracle import oracle_torch as O
+    from text2nerf_amd import AlphaGridMask, TensorVMSplit
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    f.alphaMask = AlphaGridMask(dev(), torch.from_numpy(tiny["g7a_aabb"]), torch.from_numpy(tiny["g7a_volume"]))
+    rays = torch.from_numpy(tiny["tiny_rays"])
+    with torch.no_grad():
+        rgb, depth, z, w = f(rays)
+    al = f.alphaMask.sample_alpha(torch.from_numpy(tiny["g7a_pts"]).to(dev()))
+    close(al, tiny["g7a_alpha"], atol=1e-6)
+    assert np.array_equal(al.cpu().numpy() > 0, tiny["g7a_alpha"] > 0)
+    close(w, tiny["g7a_eval_w"], atol=W_ATOL, rtol=W_RTOL)
+    close(rgb, tiny["g7a_eval_rgb"], atol=RGB_ATOL)
+    close(depth, tiny["g7a_eval_depth"], atol=DEPTH_ATOL)
+    torch.manual_seed(321)
+    with torch.no_grad():
+        rgb, depth, z, w = f(rays, is_train=True, N_samples=40)
+    close(w, tiny["g7a_train_w"], atol=W_ATOL, rtol=W_RTOL)
+    close(rgb, tiny["g7a_train_rgb"], atol=RGB_ATOL)
+    # gradients through a masked field vs the oracle's autograd
+    cfg = O.FieldConfig(aabb=TINY["aabb"], grid_size=TINY["grid"], near_far=TINY["near_far"],
+                        alpha_volume=torch.from_numpy(tiny["g7a_volume"]), alpha_aabb=tiny["g7a_aabb"].tolist())
+    P = O.params_from_numpy(tiny_params, requires_grad=True)
+    torch.manual_seed(321)
+    jit = torch.rand(rays.shape[0], 1)
+    o = O.forward(cfg, P, rays, is_train=True, n_samples=40, jitter=jit)
+    ((o[0] ** 2).sum() + (o[1] * 0.1).sum() + (o[3] ** 2).sum()).backward()
+    torch.manual_seed(321)
+    g = f(rays, is_train=True, N_samples=40)
+    ((g[0] ** 2).sum() + (g[1] * 0.1).sum() + (g[3] ** 2).sum()).backward()
+    _grad_check(f, {k: v.grad.numpy() for k, v in P.items()}, rel=2e-4)
+    # checkpoint round trip (bit-packed mask, models/tensorBase.py:275-290)
+    buf = io.BytesIO()
+    f.save(buf)
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=False)
+    assert "alphaMask.mask" in ck and not any(k.startswith("alphaMask") for k in ck["state_dict"])
+    f2 = TensorVMSplit(**{**ck["kwargs"], "device": dev()})
+    f2.load(ck)
+    with torch.no_grad():
+        r2 = f2(rays)
+        r1 = f(rays)
+    assert torch.equal(r1[0], r2[0]) and torch.equal(r1[3], r2[3])

@@ -180,3 +180,21 @@ def test_g6_train_black_background_coin(tiny, cfg, P, seed):
                                  bg_coin=coin)
     close(rgb, tiny[f"g6_trainblack{seed}_rgb"], atol=5e-6)
     close(depth, tiny[f"g6_trainblack{seed}_depth"], atol=2e-5)
+
+
+def test_g7a_alpha_mask_branch(tiny, P):
+    """a-7: AlphaGridMask.sample_alpha and its use in forward (eval + train)."""
+    cfg = O.FieldConfig(aabb=TINY["aabb"], grid_size=TINY["grid"], near_far=TINY["near_far"],
+                        alpha_volume=T(tiny["g7a_volume"]), alpha_aabb=tiny["g7a_aabb"].tolist())
+    close(O.sample_alpha(cfg, T(tiny["g7a_pts"])), tiny["g7a_alpha"], atol=1e-6)
+    assert np.array_equal(O.sample_alpha(cfg, T(tiny["g7a_pts"])).numpy() > 0, tiny["g7a_alpha"] > 0)
+    rgb, depth, z, w = O.forward(cfg, P, T(tiny["tiny_rays"]))
+    close(w, tiny["g7a_eval_w"], atol=2e-6, rtol=1e-5)
+    close(rgb, tiny["g7a_eval_rgb"], atol=5e-6)
+    close(depth, tiny["g7a_eval_depth"], atol=2e-5)
+    torch.manual_seed(321)
+    jit = torch.rand(tiny["tiny_rays"].shape[0], 1)
+    rgb, depth, z, w = O.forward(cfg, P, T(tiny["tiny_rays"]), is_train=True, n_samples=40, jitter=jit)
+    close(w, tiny["g7a_train_w"], atol=2e-6, rtol=1e-5)
+    close(rgb, tiny["g7a_train_rgb"], atol=5e-6)
+    close(depth, tiny["g7a_train_depth"], atol=2e-5)

@@ -53,6 +53,9 @@ SIGNATURES = {
     "t2n_field_set_desc": (C.c_int, [C.c_void_p, C.POINTER(FieldDesc)]),
     "t2n_field_set_mlp_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "t2n_field_set_frame_width": (C.c_int, [C.c_void_p, C.c_int]),
+    "t2n_field_set_alpha_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                           C.POINTER(C.c_float), C.c_void_p]),
+    "t2n_alpha_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "t2n_ray_directions": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                      C.c_void_p, C.c_void_p]),
     "t2n_get_rays": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p,

@@ -226,6 +226,7 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     }
     if (f->buf_mlp) (void)hipFree(f->buf_mlp);
     if (f->buf_mlp_h) (void)hipFree(f->buf_mlp_h);
+    if (f->buf_alpha) (void)hipFree(f->buf_alpha);
     for (int k = 0; k < T2N_K_COUNT; ++k)
         for (int i = 0; i < 64; ++i) {
             if (f->slots[k].start[i]) (void)hipEventDestroy(f->slots[k].start[i]);
@@ -303,7 +304,7 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     if (n_rays == 0) return T2N_OK;
     const bool keep = (flags & T2N_FLAG_KEEP_CTX) != 0;
     // tile marcher: image-ordered eval rays with a known width (hint), whole rows per sub-launch
-    const bool tiles = (flags & T2N_FLAG_COHERENT) != 0 && !keep && !(flags & T2N_FLAG_TRAIN) && f->frame_w >= 8 &&
+    const bool tiles = (flags & T2N_FLAG_COHERENT) != 0 && !keep && !(flags & T2N_FLAG_TRAIN) && !f->dev.alpha && f->frame_w >= 8 &&
                        n_rays % f->frame_w == 0 && n_rays / f->frame_w >= 8;
     if (keep) {
         if (carve_workspace(n_rays, n_samples, true).total > workspace_bytes || (uint64_t)list_capacity(n_rays, n_samples) * kLists > 0x7fffffffull) {
@@ -349,6 +350,21 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, nullptr, s))) return rc;
         if ((rc = launch_composite(f, L, s))) return rc;
     }
+    return T2N_OK;
+}
+
+extern "C" int t2n_field_set_alpha_mask(t2n_field* f, const float* volume, int D, int H, int W, const float* aabb_min_host,
+                                        const float* inv_size_host, t2n_stream stream) {
+    if (!f) { set_error("t2n_field_set_alpha_mask: NULL field"); return T2N_ERR_INVALID; }
+    if (f->buf_alpha) { T2N_HIP(hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(f->buf_alpha); f->buf_alpha = nullptr; }
+    f->dev.alpha = nullptr;
+    if (!volume) return T2N_OK;   // clear
+    if (D < 1 || H < 1 || W < 1 || !aabb_min_host || !inv_size_host) { set_error("t2n_field_set_alpha_mask: bad argument"); return T2N_ERR_INVALID; }
+    const size_t bytes = (size_t)D * H * W * sizeof(float);
+    T2N_HIP(hipMalloc((void**)&f->buf_alpha, bytes));
+    T2N_HIP(hipMemcpyAsync(f->buf_alpha, volume, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    f->dev.alpha = f->buf_alpha; f->dev.aD = D; f->dev.aH = H; f->dev.aW = W;
+    for (int k = 0; k < 3; ++k) { f->dev.a_min[k] = aabb_min_host[k]; f->dev.a_inv[k] = inv_size_host[k]; }
     return T2N_OK;
 }
 

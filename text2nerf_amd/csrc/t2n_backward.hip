@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
             const float gf = Gw[j];
             float xn, yn, zn;
             const float z = sample_z<TRAIN>(F, ray, i, u);
-            const bool ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
+            bool ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
+            if (F.alpha && ok) ok = alpha_pass(F, ray, z);
             if (ok && gf != 0.f) {
                 scatter_win<0>(F.den, a.gden, 16, ch, xn, yn, zn, gf, pw0, lw0);
                 scatter_win<1>(F.den, a.gden, 16, ch, xn, yn, zn, gf, pw1, lw1);

@@ -213,6 +213,30 @@ __device__ __forceinline__ float4 taps_line(const QuadTaps& t) {
 }
 
 
+// AlphaGridMask.sample_alpha(xyz) > 0 (models/tensorBase.py:52-59,451-456): 3-D grid_sample, trilinear, zeros padding,
+// align_corners=True, of the occupancy volume at a WORLD point. Called only when the field carries a mask.
+__device__ __forceinline__ float alpha_value(const FieldDev& F, float px, float py, float pz) {
+    const float sx = px - F.a_min[0], sy = py - F.a_min[1], sz = pz - F.a_min[2];
+    const float tx = sx * F.a_inv[0], ty = sy * F.a_inv[1], tz = sz * F.a_inv[2];
+    const Axis ax = axis_taps(tx - 1.f, F.aW), ay = axis_taps(ty - 1.f, F.aH), az = axis_taps(tz - 1.f, F.aD);
+    const float* __restrict__ V = F.alpha;
+    const size_t r00 = ((size_t)az.i0 * F.aH + ay.i0) * F.aW, r01 = ((size_t)az.i0 * F.aH + ay.i1) * F.aW;
+    const size_t r10 = ((size_t)az.i1 * F.aH + ay.i0) * F.aW, r11 = ((size_t)az.i1 * F.aH + ay.i1) * F.aW;
+    float v = V[r00 + ax.i0] * (ax.w0 * ay.w0 * az.w0);
+    v += V[r00 + ax.i1] * (ax.w1 * ay.w0 * az.w0);
+    v += V[r01 + ax.i0] * (ax.w0 * ay.w1 * az.w0);
+    v += V[r01 + ax.i1] * (ax.w1 * ay.w1 * az.w0);
+    v += V[r10 + ax.i0] * (ax.w0 * ay.w0 * az.w1);
+    v += V[r10 + ax.i1] * (ax.w1 * ay.w0 * az.w1);
+    v += V[r11 + ax.i0] * (ax.w0 * ay.w1 * az.w1);
+    v += V[r11 + ax.i1] * (ax.w1 * ay.w1 * az.w1);
+    return v;
+}
+__device__ __forceinline__ bool alpha_pass(const FieldDev& F, const Ray& r, float z) {
+    const float mx = r.dx * z, my = r.dy * z, mz = r.dz * z;
+    return alpha_value(F, r.ox + mx, r.oy + my, r.oz + mz) > 0.f;
+}
+
 // Conservative sample-index interval [lo, hi] outside of which no sample of the ray can pass the box test (and the eval
 // z gate): slab test in t with a +-3 sample margin (fp32 rounding of the analytic bounds is ~1e-6 relative, the jitter
 // shifts samples by < 1). Exact validity is always re-tested per sample; hi < lo means "no candidate".

@@ -36,6 +36,8 @@ struct FieldDev {
     const float* w0A;      // [196][4][64]
     const float* w1A;      // [65][4][64]
     const float* w2A;      // [65][64]
+    // optional AlphaGridMask occupancy volume [D][H][W] (models/tensorBase.py:41-59); NULL when the field has none
+    const float* alpha; int aW, aH, aD; float a_min[3], a_inv[3];
     // split-f16 operands (t2n_shade.hip): uint4 = 8 halves per lane per (chunk, block, part)
     const uint4* basisH; const uint4* w0H; const uint4* w1H; const uint4* w2H; const float* biasH;
 };
@@ -59,6 +61,7 @@ struct t2n_field {
     float* buf_app_line[3] = {nullptr, nullptr, nullptr};
     float* buf_mlp = nullptr;  // basisA | w0A | w1A | w2A
     void* buf_mlp_h = nullptr; // split-f16 operands + scaled biases
+    float* buf_alpha = nullptr; // alpha-mask volume copy
     int mlp_split = 1;         // 1: f16 two-way split products (default), 0: exact fp32 MFMA
     // channel-last gradient accumulators (backward), allocated on first use
     float* gbuf_den_plane[3] = {nullptr, nullptr, nullptr};

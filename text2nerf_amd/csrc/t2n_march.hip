@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
     unsigned napp = 0;
     const int Lw = last - first + 1;   // window length (<= 0: empty ray)
 
+    unsigned nmask = 0;   // in-interval samples rejected by the alpha mask
     if (Lw > 0) {
         // ---- pass B: density -------------------------------------------------------------------------------------
         const int q = lane & (LPS - 1);
@@ -128,7 +129,9 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
             if (j < Lw) {
                 const float z = sample_z<TRAIN>(F, ray, i, u);
                 ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
+                if (F.alpha && ok) ok = alpha_pass(F, ray, z);      // models/tensorBase.py:451-456
             }
+            if (F.alpha) nmask += (unsigned)__popcll(__ballot((j < Lw) & !ok & (q == 0)));
             float part = 0.f;
             if (ok) {
                 QuadTaps t0, t1, t2;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
         if (napp) slot0 = atomicAdd(&a.counters[list * kCounterStride], napp);
         const bool fits = slot0 + napp <= a.list_cap;
         slot0 += list * a.list_cap;
-        a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, (int)nvalid, Lw > 0 ? (first | (Lw << 11)) : 0);
+        a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, (int)(nvalid - nmask), Lw > 0 ? (first | (Lw << 11)) : 0);
         a.acc[r] = acc;
         a.depth[r] = dep + (1.f - acc) * ray.last;   // :504-505
         if (!fits && a.stats) a.stats[T2N_STAT_OVERFLOW] = 1ull;   // cannot happen: list_cap is the worst case
@@ -343,6 +346,12 @@ __global__ __launch_bounds__(256) void k_raw2alpha(const float* __restrict__ sig
     if (bg_o && lane == 0) bg_o[r] = carry;
 }
 
+__global__ __launch_bounds__(256) void k_alpha_at(const FieldDev F, const float* __restrict__ xyz, long long n, float* out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    out[t] = alpha_value(F, xyz[t * 3], xyz[t * 3 + 1], xyz[t * 3 + 2]);
+}
+
 // filtering_rays(bbox_only=True): models/tensorBase.py:385-391
 __global__ __launch_bounds__(256) void k_filter_bbox(const FieldDev F, const float* __restrict__ rays, long long n,
                                                      int stride, uint8_t* mask) {
@@ -435,6 +444,16 @@ extern "C" int t2n_filter_rays_bbox(const t2n_field* f, const float* rays, int64
     if (n_rays == 0) return T2N_OK;
     hipLaunchKernelGGL(k_filter_bbox, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f->dev,
                        rays, (long long)n_rays, ray_stride, mask);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_alpha_at(const t2n_field* f, const float* xyz_world, int64_t n, float* alpha, t2n_stream stream) {
+    if (!f || !xyz_world || !alpha || n < 0) { set_error("t2n_alpha_at: bad argument"); return T2N_ERR_INVALID; }
+    if (!f->dev.alpha) { set_error("t2n_alpha_at: the field has no alpha mask"); return T2N_ERR_STATE; }
+    if (n == 0) return T2N_OK;
+    hipLaunchKernelGGL(k_alpha_at, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f->dev, xyz_world,
+                       (long long)n, alpha);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

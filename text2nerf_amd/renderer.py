@@ -40,3 +40,25 @@ def OctreeRender_trilinear_fast(rays, tensorf, chunk=4096, N_samples=-1, ndc_ray
             lst.append(t)
     rgb, depth, z, w = [torch.cat(x) if x[0] is not None else None for x in outs]
     return rgb, None, depth, w, z
+
+
+@torch.no_grad()
+def render_views(tensorf, poses, intrinsic, H, W, N_samples=-1, white_bg=True):
+    """Device-side counterpart of the per-view loop of ``evaluation`` / ``evaluation_path`` (renderer.py:85-93,160-170)
+    without its file I/O: for every camera-to-world pose generate the [H*W,6] rays on the GPU
+    (dataLoader/scene_gen.py:44-45,92-94), render the whole frame in one call and return ``rgb [V,H,W,3]`` (clamped) and
+    ``depth [V,H,W]``. Nothing crosses PCIe per view. ``intrinsic`` = [fx, fy, cx, cy]."""
+    from .ray_utils import generate_rays
+    dev = tensorf.basis_mat.weight.device
+    keep = tensorf.materialize_weights
+    tensorf.materialize_weights = False            # evaluation discards weights / z_vals (renderer.py:89)
+    rgbs, depths = [], []
+    try:
+        for c2w in poses:
+            rays = generate_rays(H, W, intrinsic, c2w, device=dev)
+            rgb, depth, _, _ = tensorf(rays, is_train=False, white_bg=white_bg, N_samples=N_samples)
+            rgbs.append(rgb.clamp(0.0, 1.0).reshape(H, W, 3))
+            depths.append(depth.reshape(H, W))
+    finally:
+        tensorf.materialize_weights = keep
+    return torch.stack(rgbs), torch.stack(depths)

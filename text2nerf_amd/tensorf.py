@@ -56,6 +56,29 @@ def raw2alpha(sigma: torch.Tensor, dist: torch.Tensor):
     return alpha, w, bg
 
 
+class AlphaGridMask(nn.Module):
+    """Occupancy volume with the reference's attributes (models/tensorBase.py:41-59). ``sample_alpha`` runs the trilinear
+    lookup on the GPU through the owning field (t2n_alpha_at); the render kernels apply the mask themselves."""
+
+    def __init__(self, device, aabb, alpha_volume):
+        super().__init__()
+        self.device = device
+        self.aabb = torch.as_tensor(aabb, dtype=torch.float32).to(device)
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invgridSize = 1.0 / self.aabbSize * 2
+        self.alpha_volume = alpha_volume.view(1, 1, *alpha_volume.shape[-3:]).float().to(device)
+        self.gridSize = torch.LongTensor([alpha_volume.shape[-1], alpha_volume.shape[-2], alpha_volume.shape[-3]]).to(device)
+        object.__setattr__(self, "_field", None)
+
+    def normalize_coord(self, xyz_sampled):
+        return (xyz_sampled - self.aabb[0]) * self.invgridSize - 1
+
+    def sample_alpha(self, xyz_sampled):
+        if self._field is None:
+            raise T2NError("AlphaGridMask.sample_alpha needs the mask to be attached to a TensorVMSplit (tensorf.alphaMask = mask)")
+        return self._field._alpha_at(xyz_sampled)
+
+
 class MLPRender_Fea_noview(nn.Module):
     """Parameter container with the reference's key names (models/tensorBase.py:88-99). The arithmetic of
     ``forward`` (:101-109) lives in the fused HIP shade kernel; it is reached through TensorVMSplit."""
@@ -204,14 +227,27 @@ class TensorVMSplit(nn.Module):
                 "near_far": self.near_far, "step_ratio": self.step_ratio, "shadingMode": self.shadingMode,
                 "pos_pe": self.pos_pe, "view_pe": self.view_pe, "fea_pe": self.fea_pe, "featureC": self.featureC}
 
+    def state_dict(self, *a, **k):
+        sd = super().state_dict(*a, **k)
+        return type(sd)((key, v) for key, v in sd.items() if not key.startswith("alphaMask."))   # the reference's mask holds no parameters
+
     def save(self, path):
+        """models/tensorBase.py:275-283: kwargs + state_dict (+ bit-packed alpha mask)."""
         ckpt = {"kwargs": self.get_kwargs(), "state_dict": self.state_dict()}
+        if self.alphaMask is not None:
+            vol = self.alphaMask.alpha_volume.bool().cpu().numpy()
+            ckpt.update({"alphaMask.shape": vol.shape})
+            ckpt.update({"alphaMask.mask": np.packbits(vol.reshape(-1))})
+            ckpt.update({"alphaMask.aabb": self.alphaMask.aabb.cpu()})
         torch.save(ckpt, path)
 
     def load(self, ckpt):
+        """models/tensorBase.py:285-290."""
         if "alphaMask.aabb" in ckpt.keys():
-            raise T2NError("checkpoints carrying an alphaMask are not supported by the HIP renderer yet")
-        self.load_state_dict(ckpt["state_dict"])
+            length = int(np.prod(ckpt["alphaMask.shape"]))
+            vol = torch.from_numpy(np.unpackbits(ckpt["alphaMask.mask"])[:length].reshape(ckpt["alphaMask.shape"]))
+            self.alphaMask = AlphaGridMask(self.device, ckpt["alphaMask.aabb"].to(self.device), vol.float().to(self.device))
+        self.load_state_dict(ckpt["state_dict"], strict=False)
 
     # ---- C-ABI plumbing ------------------------------------------------------------------------------------------------
     def _desc(self) -> _lib.FieldDesc:
@@ -273,6 +309,23 @@ class TensorVMSplit(nn.Module):
             self._handle = h
             self._precision_set = None
             self._frame_w_set = None
+            self._alpha_key = "unset"
+        mask = self.alphaMask
+        mkey = None if mask is None else (mask.alpha_volume.data_ptr(), mask.alpha_volume._version, tuple(mask.alpha_volume.shape))
+        if getattr(self, "_alpha_key", "unset") != mkey:
+            with torch.cuda.device(dev):
+                if mask is None:
+                    _lib.check(lib.t2n_field_set_alpha_mask(self._handle, None, 0, 0, 0, None, None, _lib.current_stream_ptr(dev)),
+                               "t2n_field_set_alpha_mask")
+                else:
+                    vol = mask.alpha_volume.reshape(mask.alpha_volume.shape[-3:]).contiguous().float().to(dev)
+                    amin = (C.c_float * 3)(*mask.aabb[0].float().cpu().tolist())
+                    ainv = (C.c_float * 3)(*mask.invgridSize.float().cpu().tolist())
+                    D, H, W = vol.shape
+                    _lib.check(lib.t2n_field_set_alpha_mask(self._handle, _lib.ptr(vol), D, H, W, amin, ainv,
+                                                            _lib.current_stream_ptr(dev)), "t2n_field_set_alpha_mask")
+                    object.__setattr__(mask, "_field", self)   # plain attribute: a Module attribute would register a cycle
+            self._alpha_key = mkey
         if getattr(self, "_frame_w_set", None) != int(self.frame_width):
             _lib.check(lib.t2n_field_set_frame_width(self._handle, int(self.frame_width)), "t2n_field_set_frame_width")
             self._frame_w_set = int(self.frame_width)
@@ -331,6 +384,16 @@ class TensorVMSplit(nn.Module):
                        "t2n_density_at")
         return out
 
+    def _alpha_at(self, xyz_world):
+        lib = _lib.load()
+        h = self.sync_params()
+        dev = self.basis_mat.weight.device
+        xyz = xyz_world.detach().reshape(-1, 3).contiguous().float().to(dev)
+        out = torch.empty(xyz.shape[0], device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.t2n_alpha_at(h, _lib.ptr(xyz), xyz.shape[0], _lib.ptr(out), _lib.current_stream_ptr(dev)), "t2n_alpha_at")
+        return out
+
     def compute_sigma(self, xyz_norm):
         """compute_densityfeature + feature2density fused in the kernel."""
         return self._density_at(xyz_norm, want_sigma=True)
@@ -384,8 +447,6 @@ class TensorVMSplit(nn.Module):
         """models/tensorBase.py:436-507: returns (rgb_map [R,3], depth_map [R], z_vals [R,N], weight [R,N])."""
         if ndc_ray:
             raise T2NError("ndc_ray=True is not on the Text2NeRF path (ndc_ray=0 in every run) and is not implemented")
-        if self.alphaMask is not None:
-            raise T2NError("alphaMask is not supported by the HIP renderer (the driver never builds one)")
         dev = self.basis_mat.weight.device
         rays = rays_chunk.to(dev)
         if rays.dtype != torch.float32 or not rays.is_contiguous():
