@@ -208,51 +208,57 @@ __device__ __forceinline__ void fast_sincosf(float x, float* sn, float* cs) {
     *cs = ((q + 1) & 2) ? -c1 : c1;
 }
 
-// B chunk from the wave's LDS tile T[unit][kXld]
-struct LdsChunk {
+// B chunk from the wave's LDS tile T[unit][LD]
+template <int LD>
+struct LdsChunkT {
     const float* base;   // T + s
     int h, nreal;
     __device__ __forceinline__ void operator()(int c, float (&x)[8]) const {
         if (c < nreal) {
-            const float* p = base + (size_t)(16 * c + 8 * h) * kXld;
+            const float* p = base + (size_t)(16 * c + 8 * h) * LD;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = p[e * kXld];
+            for (int e = 0; e < 8; ++e) x[e] = p[e * LD];
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = 0.f;
         }
     }
 };
-// B chunk of layer 0: chunks 0-1 raw features (32 rows of Fe, rows >= 27 are zero), chunks 2.. : (sin, cos) pairs
-// pi = f*6 + q in order, four pairs per half-wave per chunk.
+typedef LdsChunkT<kXld> LdsChunk;
+// B chunk of layer 0: chunks 0-1 raw features (32 rows of Fe, rows >= 27 are zero); chunks 2..22 carry the positional
+// encoding as (sin, cos) pairs. Half-wave h owns features 14h .. 14h+13 and walks them in order, six octaves each, four
+// pairs per chunk: pair j = 4(c-2) + p of half h is (feature 14h + j/6, octave j%6). An accurate sincos is taken at octaves
+// 0 and 3, the octaves in between by the double-angle identities sin 2a = 2 sin a cos a, cos 2a = (cos a - sin a)(cos a +
+// sin a): at most two doublings (error x4 of ~1e-7).
+__device__ __forceinline__ void pe_double(float& sn, float& cs) {
+    const float s2 = 2.f * sn * cs, c2 = (cs - sn) * (cs + sn);
+    sn = s2; cs = c2;
+}
 struct PeChunk {
     const float* fe;   // Fe + s
     int h;
-    __device__ __forceinline__ void operator()(int c, float (&x)[8]) const {
+    float sn, cs;      // running pair, carried from chunk to chunk
+    __device__ __forceinline__ void operator()(int c, float (&x)[8]) {
         if (c < 2) {
             const float* p = fe + (size_t)(16 * c + 8 * h) * kXld;
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = p[e * kXld];
         } else if (c < kL0ChunksReal) {
-            // four consecutive (feature, octave) pairs: an accurate sincos at the first pair (and wherever the octave wraps
-            // to a new feature), the following octaves of the same feature by the double-angle identities
-            // sin 2a = 2 sin a cos a, cos 2a = (cos a - sin a)(cos a + sin a): at most three doublings (error x8 of ~1e-7)
-            const int pi0 = 8 * (c - 2) + 4 * h;
-            int f = (pi0 * 171) >> 10;                   // pi0 / 6 for pi0 < 504
-            int qo = pi0 - 6 * f;
-            float sn = 0.f, cs = 1.f;
+            const int j0 = 4 * (c - 2);
+            int f = (j0 * 171) >> 10;                    // j0 / 6 for j0 < 504
+            int q = j0 - 6 * f;
+            f += 14 * h;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                if (p == 0 || qo == 0) {
-                    const float arg = fe[(size_t)f * kXld] * (float)(1 << qo);
+                if (q == 0 || q == 3) {                  // wave-uniform
+                    const float arg = fe[(size_t)f * kXld] * (float)(1 << q);
                     if (__builtin_expect(__any(fabsf(arg) > 8192.f), 0)) sincosf(arg, &sn, &cs);
                     else fast_sincosf(arg, &sn, &cs);
                 } else {
-                    const float s2 = 2.f * sn * cs, c2 = (cs - sn) * (cs + sn);
-                    sn = s2; cs = c2;
+                    pe_double(sn, cs);
                 }
                 x[2 * p] = sn; x[2 * p + 1] = cs;
-                if (++qo == kPE) { qo = 0; ++f; }
+                if (++q == kPE) { q = 0; ++f; }
             }
         } else {
 #pragma unroll
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
             if constexpr (SPLIT) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc0[m] = bias_init(F.biasH, m, h);
-                PeChunk bf{Fe + s, h};
+                PeChunk bf{Fe + s, h, 0.f, 1.f};
                 f16_stream<4>(acc0, F.w0H + lane, kL0Chunks, bf);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc0[m] *= kWUnscale;
@@ -493,6 +499,276 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
     }
 }
 
+// ---- block-cooperative variant (default render path, split-f16 MLP head) ---------------------------------------------
+// k_shade streams every weight chunk from L2 once per wave: 292 KB per 32-sample tile, ~39 GB per 800x800 frame, which is
+// the cache fabric's whole budget for the kernel. Here the four waves of a block walk their four tiles in lockstep and
+// share the layer-0/1 weight stream through a two-deep LDS ring: each thread fetches 32 B of the next-but-two chunk into
+// registers, drops it into the ring one chunk ahead, and every wave reads its A operands from LDS (ds_read_b128, lane-linear,
+// conflict-free). Weight traffic from L2 drops 4x for the two big layers; one workgroup barrier per chunk.
+// LDS map (80 KB per block, two blocks per CU): wave w owns floats [w*5120, (w+1)*5120): [0, 4096) activation tile
+// (X[144][33] spills into the tail during gather/basis only), [4096, 5120) slice w of the ring (ring buffer b = slices 2b, 2b+1).
+constexpr int kWaveFloats = 5120, kRingOff = 4096, kHld = 32;
+
+// Weight ring: at chunk c every wave reads its A operands from ring buffer c&1, the block pushes chunk c+1 (fetched two
+// steps earlier into registers) into the other buffer and fetches chunk c+3. One __syncthreads() per chunk, by the caller.
+struct CoopRing {
+    float* smem; const uint4* wp; int tid, lane, last;   // last: highest chunk index that may be fetched
+    uint4 n0, n1, nn0, nn1;                              // chunks c+1 and c+2 in flight
+    __device__ __forceinline__ uint4* slot(int b, int i) const {
+        return reinterpret_cast<uint4*>(smem + (size_t)(2 * b + (i >> 8)) * kWaveFloats + kRingOff) + (i & 255);
+    }
+    __device__ __forceinline__ void gload(uint4& ga, uint4& gb, int c) const {
+        c = c < last ? c : last;
+        const uint4* p = wp + (size_t)c * 512 + tid;
+        ga = p[0]; gb = p[256];
+    }
+    __device__ __forceinline__ void start() {   // callers guarantee nobody still reads the ring
+        gload(n0, n1, 0);
+        gload(nn0, nn1, 1);
+        *slot(0, tid) = n0; *slot(0, 256 + tid) = n1;
+        n0 = nn0; n1 = nn1;
+        gload(nn0, nn1, 2);
+        __syncthreads();
+    }
+    __device__ __forceinline__ void advance(int c, uint4 (&A)[8]) {
+        const int b = c & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) A[i] = *slot(b, i * 64 + lane);
+        *slot(b ^ 1, tid) = n0; *slot(b ^ 1, 256 + tid) = n1;
+        n0 = nn0; n1 = nn1;
+        gload(nn0, nn1, c + 3);
+    }
+};
+
+// One pipelined chunk: the 12 MFMAs of chunk c on the B operand prepared during the previous step, with the VALU work that
+// builds chunk c+1's B operand (`prep`) in the same basic block so the two interleave; the four accumulators are visited
+// round-robin so consecutive MFMAs never chain on one accumulator.
+template <class Prep>
+__device__ __forceinline__ void coop_step(CoopRing& R, int c, f32x16 (&acc)[4], h8& bhi, h8& blo, Prep&& prep) {
+    uint4 A[8];
+    R.advance(c, A);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = mfma16(__builtin_bit_cast(h8, A[2 * m]), bhi, acc[m]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = mfma16(__builtin_bit_cast(h8, A[2 * m]), blo, acc[m]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = mfma16(__builtin_bit_cast(h8, A[2 * m + 1]), bhi, acc[m]);
+    float x[8];
+    prep(x);
+    h8 nhi, nlo;
+    split8(x, nhi, nlo);
+    bhi = nhi; blo = nlo;
+    __syncthreads();
+}
+
+// Layer-0 B operands in PeChunk's order, unrolled over the three-chunk period of (four pairs per chunk, six octaves per
+// feature): chunk types A = octaves 0-3 of feature fa, B = octaves 4-5 of fa + 0-1 of fb = fa+1, C = octaves 2-5 of fb.
+struct PePipe {
+    const float* feh;   // Fe + s + 14 h kXld
+    float sn, cs, v;
+    __device__ __forceinline__ void fresh(float arg) { fast_sincosf(arg, &sn, &cs); }
+    __device__ __forceinline__ void put(float (&x)[8], int p) { x[2 * p] = sn; x[2 * p + 1] = cs; }
+    __device__ __forceinline__ void type_a(int fa, float (&x)[8]) {
+        v = feh[(size_t)fa * kXld];
+        fresh(v); put(x, 0);
+        pe_double(sn, cs); put(x, 1);
+        pe_double(sn, cs); put(x, 2);
+        fresh(v * 8.f); put(x, 3);
+    }
+    __device__ __forceinline__ void type_b(int fa, float (&x)[8]) {
+        pe_double(sn, cs); put(x, 0);
+        pe_double(sn, cs); put(x, 1);
+        v = feh[(size_t)(fa + 1) * kXld];
+        fresh(v); put(x, 2);
+        pe_double(sn, cs); put(x, 3);
+    }
+    __device__ __forceinline__ void type_c(float (&x)[8]) {
+        pe_double(sn, cs); put(x, 0);
+        fresh(v * 8.f); put(x, 1);
+        pe_double(sn, cs); put(x, 2);
+        pe_double(sn, cs); put(x, 3);
+    }
+};
+
+__device__ __forceinline__ void coop_layer0(f32x16 (&acc)[4], const uint4* __restrict__ w0H, const float* __restrict__ fe_s, int h,
+                                            float* __restrict__ smem, int tid, int lane) {
+    CoopRing R{smem, w0H, tid, lane, kL0ChunksReal};   // chunk 23 is the zero pad
+    R.start();
+    auto raw = [&](int c, float (&x)[8]) {
+        const float* p = fe_s + (size_t)(16 * c + 8 * h) * kXld;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = p[e * kXld];
+    };
+    PePipe P{fe_s + (size_t)14 * h * kXld, 0.f, 1.f, 0.f};
+    h8 bhi, blo;
+    {
+        float x[8];
+        raw(0, x);
+        split8(x, bhi, blo);
+    }
+    coop_step(R, 0, acc, bhi, blo, [&](float (&x)[8]) { raw(1, x); });
+    coop_step(R, 1, acc, bhi, blo, [&](float (&x)[8]) { P.type_a(0, x); });
+#pragma unroll 1
+    for (int it = 0; it < 7; ++it) {   // chunks 2+3it .. 4+3it = features 2it, 2it+1 of each half
+        const int c = 2 + 3 * it;
+        coop_step(R, c, acc, bhi, blo, [&](float (&x)[8]) { P.type_b(2 * it, x); });
+        coop_step(R, c + 1, acc, bhi, blo, [&](float (&x)[8]) { P.type_c(x); });
+        // the last trip prepares a chunk past the end from zero feature rows (<= row 28 + 14 < 32 rows + pad): unused
+        coop_step(R, c + 2, acc, bhi, blo, [&](float (&x)[8]) { P.type_a(it < 6 ? 2 * it + 2 : 0, x); });
+    }
+}
+
+// Same contraction without the software pipeline, PE through PeChunk (libm sincos wherever an argument leaves the fast
+// routine's range): the path for tiles with |feature| > 1024. Same number of barriers as coop_layer0.
+__device__ __forceinline__ void coop_layer0_plain(f32x16 (&acc)[4], const uint4* __restrict__ w0H, const float* __restrict__ fe_s, int h,
+                                                  float* __restrict__ smem, int tid, int lane) {
+    CoopRing R{smem, w0H, tid, lane, kL0ChunksReal};
+    R.start();
+    PeChunk bf{fe_s, h, 0.f, 1.f};
+#pragma unroll 1
+    for (int c = 0; c < kL0ChunksReal; ++c) {
+        uint4 A[8];
+        R.advance(c, A);
+        float x[8];
+        bf(c, x);
+        h8 bhi, blo;
+        split8(x, bhi, blo);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const h8 ahi = __builtin_bit_cast(h8, A[2 * m]), alo = __builtin_bit_cast(h8, A[2 * m + 1]);
+            acc[m] = mfma16(ahi, bhi, acc[m]);
+            acc[m] = mfma16(ahi, blo, acc[m]);
+            acc[m] = mfma16(alo, bhi, acc[m]);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void coop_layer1(f32x16 (&acc)[4], const uint4* __restrict__ w1H, const float* __restrict__ hs_s, int h,
+                                            float* __restrict__ smem, int tid, int lane) {
+    CoopRing R{smem, w1H, tid, lane, kL1Chunks};
+    R.start();
+    auto rows = [&](int c, float (&x)[8]) {
+        const float* p = hs_s + (size_t)(16 * c + 8 * h) * kHld;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = p[e * kHld];
+    };
+    h8 bhi, blo;
+    {
+        float x[8];
+        rows(0, x);
+        split8(x, bhi, blo);
+    }
+#pragma unroll 1
+    for (int c = 0; c < kL1Chunks; ++c)
+        coop_step(R, c, acc, bhi, blo, [&](float (&x)[8]) { rows(c < kL1Chunks - 1 ? c + 1 : c, x); });
+}
+
+__global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int s = lane & 31, h = lane >> 5;
+    float* __restrict__ X = smem + (size_t)wid * kWaveFloats;
+    float* __restrict__ Fe = X;
+    float* __restrict__ Hs = X;
+    const FieldDev& F = a.F;
+    unsigned cnt_l = 0;
+    if (lane < a.nlists) {
+        cnt_l = a.counters ? a.counters[lane * kCounterStride] : a.count_max;
+        if (a.counters && cnt_l > a.list_cap) cnt_l = a.list_cap;
+    }
+    unsigned incl = (cnt_l + 31u) / 32u;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const unsigned ntiles = __shfl(incl, a.nlists - 1);
+    const unsigned block_stride = gridDim.x * 4u;
+
+    // the block's four waves take tiles tile0 .. tile0+3 together; a wave past the end runs an all-dead tile
+    for (unsigned tile0 = blockIdx.x * 4u; tile0 < ntiles; tile0 += block_stride) {
+        const unsigned tile = tile0 + wid;
+        unsigned base = 0, count = 0;
+        if (tile < ntiles) {
+            const int li = (int)__popcll(__ballot((lane < a.nlists) & (incl <= tile)));
+            const unsigned before = li ? __shfl(incl, li - 1) : 0u;
+            const unsigned lbase = (unsigned)li * a.list_cap;
+            base = lbase + (tile - before) * 32u;
+            count = lbase + __shfl(cnt_l, li);
+        }
+        gather_all(F.app, X, lane, a.app_pos, a.xyz, base, count, nullptr, 0);
+        wave_lds_sync();
+
+        f32x16 accb1[1] = {{0}};
+        {
+            LdsChunk bf{X + s, h, kBasisChunksReal};
+            f16_stream<1>(accb1, F.basisH + lane, kBasisChunks, bf);
+            accb1[0] *= kWUnscale;
+        }
+        const f32x16 accb = accb1[0];
+        __syncthreads();   // every wave is done with X (whose tail overlaps the ring slices)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) Fe[unit_of(v, h) * kXld + s] = accb[v];
+        wave_lds_sync();
+
+        const unsigned idx = base + (unsigned)s;
+        const bool live = idx < count;
+        if (a.feat_out && live) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int fidx = unit_of(v, h);
+                if (fidx < F.app_dim) a.feat_out[(size_t)idx * F.app_dim + fidx] = accb[v];
+            }
+        }
+
+        // ---- layer 0 ---------------------------------------------------------------------------------------------------
+        f32x16 acc0[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc0[m] = bias_init(F.biasH, m, h);
+        {
+            float fmax_ = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) fmax_ = fmaxf(fmax_, fabsf(accb[v]));
+            // |feature| * 2^3 beyond the fast sincos' range (never, for a trained field): unpipelined libm path
+            if (__builtin_expect(__any(fmax_ * 8.f > 8192.f) != 0, 0)) coop_layer0_plain(acc0, F.w0H, Fe + s, h, smem, tid, lane);
+            else coop_layer0(acc0, F.w0H, Fe + s, h, smem, tid, lane);
+        }
+        // the stream's last barrier also orders every wave's Fe reads before the H writes below
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) Hs[(ms * 32 + unit_of(v, h)) * kHld + s] = fmaxf(acc0[ms][v] * kWUnscale, 0.f);
+        }
+        wave_lds_sync();
+        // ---- layer 1 ---------------------------------------------------------------------------------------------------
+        f32x16 acc1[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc1[m] = bias_init(F.biasH + 128, m, h);
+        coop_layer1(acc1, F.w1H, Hs + s, h, smem, tid, lane);
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) Hs[(ms * 32 + unit_of(v, h)) * kHld + s] = fmaxf(acc1[ms][v] * kWUnscale, 0.f);
+        }
+        wave_lds_sync();
+        // ---- layer 2 (3 live rows), wave-private weight stream -----------------------------------------------------------
+        f32x16 acc2a[1];
+        acc2a[0] = bias_init(F.biasH + 256, 0, h);
+        {
+            LdsChunkT<kHld> bf{Hs + s, h, kL2Chunks};
+            f16_stream<1>(acc2a, F.w2H + lane, kL2Chunks, bf);
+        }
+        const f32x16 acc2 = acc2a[0] * kWUnscale;
+        if (h == 0 && live) {
+            const float cr = sigmoidf_(acc2[0]), cg = sigmoidf_(acc2[1]), cb = sigmoidf_(acc2[2]);
+            if (a.app_rgb) a.app_rgb[idx] = make_float4(cr, cg, cb, 0.f);
+            if (a.rgb_out) { a.rgb_out[(size_t)idx * 3] = cr; a.rgb_out[(size_t)idx * 3 + 1] = cg; a.rgb_out[(size_t)idx * 3 + 2] = cb; }
+        }
+        wave_lds_sync();   // H reads done before the next tile's gather overwrites the tile
+    }
+}
+
 // ---- parameter packing ------------------------------------------------------------------------------------------------
 struct PackArgs {
     const float* basis; const float* w0; const float* b0; const float* w1; const float* b1; const float* w2; const float* b2;
@@ -551,12 +827,12 @@ __global__ __launch_bounds__(256) void k_pack_mlp(const PackArgs a) {
 
 // Split-f16 operand packing: for layer L, chunk c, block m, part p (0 hi, 1 lo), lane l: 8 halves = W[m*32 + (l&31)][k],
 // k = 16c + 8(l>>5) + e, scaled by 2^8. K orders: basis/layer1/layer2 natural; layer 0: 32 raw (27 real), then
-// (sin, cos) pairs pi = f*6 + q. Biases are stored as fp32 * 2^8 in accumulator order.
-__device__ __forceinline__ float l0_weight(const float* w0, int out, int k) {
-    if (k < 32) return k < 27 ? w0[out * 351 + k] : 0.f;
-    const int pi = (k - 32) >> 1, sc = (k - 32) & 1;
-    if (pi >= 162) return 0.f;
-    const int f = pi / 6, q = pi - 6 * f;
+// (sin, cos) pairs in the per-half-wave order of PeChunk. Biases are stored as fp32 * 2^8 in accumulator order.
+__device__ __forceinline__ float l0_weight(const float* w0, int out, int c, int h, int e) {
+    if (c < 2) { const int k = 16 * c + 8 * h + e; return k < 27 ? w0[out * 351 + k] : 0.f; }
+    const int j = 4 * (c - 2) + (e >> 1), sc = e & 1;
+    const int f = 14 * h + j / 6, q = j % 6;
+    if (f >= 27) return 0.f;
     return w0[out * 351 + (sc ? 189 : 27) + f * 6 + q];
 }
 struct PackHArgs {
@@ -593,7 +869,7 @@ __global__ __launch_bounds__(256) void k_pack_mlp_h(const PackHArgs a) {
     if (!a.has_mlp) return;
     if (g < n0) {
         decode(g, 4, c, m, part, i, h, e);
-        store_split(a.w0H + g, c < kL0ChunksReal ? l0_weight(a.w0, m * 32 + i, 16 * c + 8 * h + e) : 0.f, part);
+        store_split(a.w0H + g, c < kL0ChunksReal ? l0_weight(a.w0, m * 32 + i, c, h, e) : 0.f, part);
         return;
     }
     g -= n0;
@@ -669,6 +945,12 @@ static int shade_grid(unsigned long long count_max) {
     return (int)blocks;
 }
 
+constexpr size_t kCoopLds = (size_t)4 * kWaveFloats * sizeof(float);
+static bool use_coop(const t2n_field* f) {
+    static const bool off = getenv("T2N_SHADE_NO_COOP") != nullptr;   // A/B switch for profiling
+    return !off && f->mlp_split && f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW;
+}
+
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
                       const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s) {
     ShadeArgs a;
@@ -682,10 +964,12 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
     if (!attr_set) {
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
         attr_set = true;
     }
     timing_begin(f, T2N_K_SHADE, s);
-    if (f->mlp_split && !ctx) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
+    if (use_coop(f) && !ctx) hipLaunchKernelGGL(k_shade_coop, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), kCoopLds, s, a);
+    else if (f->mlp_split && !ctx) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
     timing_end(f, T2N_K_SHADE, s);
     T2N_HIP(hipGetLastError());
@@ -713,7 +997,9 @@ extern "C" int t2n_shade_at(const t2n_field* fc, const float* xyz_norm, const fl
     const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
     T2N_HIP(hipFuncSetAttribute((const void*)k_shade<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (f->mlp_split) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid((unsigned)n)), dim3(256), lds, (hipStream_t)stream, a);
+    T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
+    if (use_coop(f)) hipLaunchKernelGGL(k_shade_coop, dim3(shade_grid((unsigned)n)), dim3(256), kCoopLds, (hipStream_t)stream, a);
+    else if (f->mlp_split) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid((unsigned)n)), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid((unsigned)n)), dim3(256), lds, (hipStream_t)stream, a);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
