@@ -287,40 +287,57 @@ struct ShadeArgs {
 // Gather: 384 (sample, channel-quad) items over 64 lanes, 6 per lane; an item computes its sample's three axis taps once
 // and fetches quad q of the 4 plane taps + 2 line taps of all three factor pairs (each tap = 192 contiguous bytes across
 // the 12 lanes of a sample); plane x line products go to X[k*48 + 4q + c][s] (and to the ctx rows in backward mode).
-template <int K>
-__device__ __forceinline__ void gather_store(const FactorSet& S, const Axes3& A, int q, int s, bool live, float* __restrict__ X,
-                                             float* ctx_x, unsigned row0) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) {
-        QuadTaps t;
-        issue_taps_ax<K>(S, 12, q, A, t);
-        const float4 p = taps_plane(t), l = taps_line(t);
-        v = make_float4(p.x * l.x, p.y * l.y, p.z * l.z, p.w * l.w);
+// The 18 loads of an item are issued together, branch-free (dead lanes fetch the volume centre and store zeros), and two
+// items are kept in flight, so a tile costs ~3 memory round trips instead of 18 (appearance planes mostly miss the L2).
+struct GatherItem {
+    QuadTaps t[3];
+    int s, q;
+    bool live;
+};
+__device__ __forceinline__ void gather_issue(const FactorSet& S, int it, int lane, const float4* pos_l, const float* xyz,
+                                             unsigned base, unsigned count, GatherItem& g) {
+    constexpr int CQ = 12;   // 48 channels / 4
+    const int item = it * 64 + lane;
+    g.s = item / CQ; g.q = item - g.s * CQ;
+    const unsigned idx = base + (unsigned)g.s;
+    g.live = idx < count;
+    float xn = 0.f, yn = 0.f, zn = 0.f;
+    if (g.live) {
+        if (pos_l) { const float4 p = pos_l[idx]; xn = p.x; yn = p.y; zn = p.z; }
+        else { xn = xyz[(size_t)idx * 3]; yn = xyz[(size_t)idx * 3 + 1]; zn = xyz[(size_t)idx * 3 + 2]; }
     }
-    float* dst = X + (size_t)(K * 48 + q * 4) * kXld + s;
-    dst[0] = v.x; dst[kXld] = v.y; dst[2 * kXld] = v.z; dst[3 * kXld] = v.w;
-    if (ctx_x) *reinterpret_cast<float4*>(ctx_x + (size_t)(row0 + s) * kAppK + K * 48 + q * 4) = v;
+    const Axes3 A = sample_axes(S, xn, yn, zn);
+    issue_taps_ax<0>(S, CQ, g.q, A, g.t[0]);
+    issue_taps_ax<1>(S, CQ, g.q, A, g.t[1]);
+    issue_taps_ax<2>(S, CQ, g.q, A, g.t[2]);
+}
+__device__ __forceinline__ void gather_consume(const GatherItem& g, float* __restrict__ X, float* ctx_x, unsigned row0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 p = taps_plane(g.t[k]), l = taps_line(g.t[k]);
+        float4 v = make_float4(p.x * l.x, p.y * l.y, p.z * l.z, p.w * l.w);
+        if (!g.live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* dst = X + (size_t)(k * 48 + g.q * 4) * kXld + g.s;
+        dst[0] = v.x; dst[kXld] = v.y; dst[2 * kXld] = v.z; dst[3 * kXld] = v.w;
+        if (ctx_x) *reinterpret_cast<float4*>(ctx_x + (size_t)(row0 + g.s) * kAppK + k * 48 + g.q * 4) = v;
+    }
 }
 
 __device__ __forceinline__ void gather_all(const FactorSet& S, float* __restrict__ X, int lane, const float4* pos_l,
                                            const float* xyz, unsigned base, unsigned count, float* ctx_x, unsigned row0) {
-    constexpr int CQ = 12;   // 48 channels / 4
-#pragma unroll 1
-    for (int it = 0; it < 6; ++it) {
-        const int item = it * 64 + lane;
-        const int s = item / CQ, q = item - s * CQ;
-        const unsigned idx = base + (unsigned)s;
-        const bool live = idx < count;
-        float xn = 0.f, yn = 0.f, zn = 0.f;
-        if (live) {
-            if (pos_l) { const float4 p = pos_l[idx]; xn = p.x; yn = p.y; zn = p.z; }
-            else { xn = xyz[(size_t)idx * 3]; yn = xyz[(size_t)idx * 3 + 1]; zn = xyz[(size_t)idx * 3 + 2]; }
-        }
-        const Axes3 A = sample_axes(S, xn, yn, zn);
-        gather_store<0>(S, A, q, s, live, X, ctx_x, row0);
-        gather_store<1>(S, A, q, s, live, X, ctx_x, row0);
-        gather_store<2>(S, A, q, s, live, X, ctx_x, row0);
-    }
+    GatherItem g0, g1;
+    gather_issue(S, 0, lane, pos_l, xyz, base, count, g0);
+    gather_issue(S, 1, lane, pos_l, xyz, base, count, g1);
+    gather_consume(g0, X, ctx_x, row0);
+    gather_issue(S, 2, lane, pos_l, xyz, base, count, g0);
+    gather_consume(g1, X, ctx_x, row0);
+    gather_issue(S, 3, lane, pos_l, xyz, base, count, g1);
+    gather_consume(g0, X, ctx_x, row0);
+    gather_issue(S, 4, lane, pos_l, xyz, base, count, g0);
+    gather_consume(g1, X, ctx_x, row0);
+    gather_issue(S, 5, lane, pos_l, xyz, base, count, g1);
+    gather_consume(g0, X, ctx_x, row0);
+    gather_consume(g1, X, ctx_x, row0);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -664,6 +681,13 @@ __device__ __forceinline__ void coop_layer1(f32x16 (&acc)[4], const uint4* __res
         coop_step(R, c, acc, bhi, blo, [&](float (&x)[8]) { rows(c < kL1Chunks - 1 ? c + 1 : c, x); });
 }
 
+#ifdef T2N_PHASE_TIMING
+__device__ unsigned long long g_phase[8];
+#define T2N_PHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); phacc[i] += t_ - tph; tph = t_; } while (0)
+#else
+#define T2N_PHASE(i) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -685,6 +709,9 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
     }
     const unsigned ntiles = __shfl(incl, a.nlists - 1);
     const unsigned block_stride = gridDim.x * 4u;
+#ifdef T2N_PHASE_TIMING
+    unsigned long long phacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     // the block's four waves take tiles tile0 .. tile0+3 together; a wave past the end runs an all-dead tile
     for (unsigned tile0 = blockIdx.x * 4u; tile0 < ntiles; tile0 += block_stride) {
@@ -697,8 +724,12 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
             base = lbase + (tile - before) * 32u;
             count = lbase + __shfl(cnt_l, li);
         }
+#ifdef T2N_PHASE_TIMING
+        unsigned long long tph = __builtin_amdgcn_s_memtime();
+#endif
         gather_all(F.app, X, lane, a.app_pos, a.xyz, base, count, nullptr, 0);
         wave_lds_sync();
+        T2N_PHASE(0);
 
         f32x16 accb1[1] = {{0}};
         {
@@ -707,7 +738,9 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
             accb1[0] *= kWUnscale;
         }
         const f32x16 accb = accb1[0];
+        T2N_PHASE(1);
         __syncthreads();   // every wave is done with X (whose tail overlaps the ring slices)
+        T2N_PHASE(2);
 #pragma unroll
         for (int v = 0; v < 16; ++v) Fe[unit_of(v, h) * kXld + s] = accb[v];
         wave_lds_sync();
@@ -734,6 +767,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
             if (__builtin_expect(__any(fmax_ * 8.f > 8192.f) != 0, 0)) coop_layer0_plain(acc0, F.w0H, Fe + s, h, smem, tid, lane);
             else coop_layer0(acc0, F.w0H, Fe + s, h, smem, tid, lane);
         }
+        T2N_PHASE(3);
         // the stream's last barrier also orders every wave's Fe reads before the H writes below
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
@@ -745,7 +779,9 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
         f32x16 acc1[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc1[m] = bias_init(F.biasH + 128, m, h);
+        T2N_PHASE(4);
         coop_layer1(acc1, F.w1H, Hs + s, h, smem, tid, lane);
+        T2N_PHASE(5);
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
 #pragma unroll
@@ -766,7 +802,11 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
             if (a.rgb_out) { a.rgb_out[(size_t)idx * 3] = cr; a.rgb_out[(size_t)idx * 3 + 1] = cg; a.rgb_out[(size_t)idx * 3 + 2] = cb; }
         }
         wave_lds_sync();   // H reads done before the next tile's gather overwrites the tile
+        T2N_PHASE(6);
     }
+#ifdef T2N_PHASE_TIMING
+    if (lane == 0) for (int i = 0; i < 7; ++i) atomicAdd(&g_phase[i], phacc[i]);
+#endif
 }
 
 // ---- parameter packing ------------------------------------------------------------------------------------------------
@@ -979,6 +1019,14 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
 }  // namespace t2n
 
 using namespace t2n;
+
+#ifdef T2N_PHASE_TIMING
+extern "C" int t2n_debug_phase_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(t2n::g_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(t2n::g_phase), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 extern "C" size_t t2n_shade_workspace_bytes(int64_t n) { (void)n; return 256; }
 
