@@ -200,6 +200,27 @@ int t2n_tv_grad_add(const float* param, float* grad, int C, int H, int W, float 
 int t2n_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, int64_t step, t2n_stream stream);
 
+/* ---- coarse-to-fine / occupancy-mask maintenance between training stages.
+ * t2n_compute_alpha: models/tensorBase.py:412-434 — alpha = 1 - exp(-sigma * length) at world-space points [n,3]; sigma = 0
+ *   where the field's AlphaGridMask (if one is set) samples <= 0.
+ * t2n_dense_alpha: models/tensorBase.py:328-344 (getDenseAlpha) — the same at the nodes aabb0*(1-s) + aabb1*s of a dense
+ *   grid, s = (lin_x[i], lin_y[j], lin_z[k]) (device arrays holding torch.linspace(0,1,g)); alpha is [gx][gy][gz].
+ * t2n_alpha_volume: models/tensorBase.py:349-363 (updateAlphaMask) — clamp, transpose to [gz][gy][gx], 3x3x3 max pool,
+ *   binarise at `thres`; bbox_idx (device int[6]) receives the index box of the kept voxels (min x,y,z, max x,y,z;
+ *   INT_MAX / -1 when nothing is kept).
+ * t2n_upsample_bilinear: models/tensoRF.py:258-272 (up_sampling_VM) — F.interpolate(mode='bilinear', align_corners=True)
+ *   of one [C,Hin,Win] factor to [C,Hout,Wout] (lines are [C,L,1]). */
+int t2n_compute_alpha(const t2n_field* f, const float* xyz_world, int64_t n, float length, float* alpha, t2n_stream stream);
+int t2n_dense_alpha(const t2n_field* f, const float* lin_x, const float* lin_y, const float* lin_z, int gx, int gy, int gz,
+                    float length, float* alpha, t2n_stream stream);
+int t2n_alpha_volume(const float* dense_alpha, int gx, int gy, int gz, float thres, float* volume, int* bbox_idx,
+                     t2n_stream stream);
+int t2n_upsample_bilinear(const float* src, int C, int Hin, int Win, float* dst, int Hout, int Wout, t2n_stream stream);
+/* filtering_rays(bbox_only=False), models/tensorBase.py:393-395: mask[r] = any of the ray's first n_samples eval samples
+ * reads the field's AlphaGridMask > 0 (needs a mask set with t2n_field_set_alpha_mask). */
+int t2n_filter_rays_alpha(const t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint8_t* mask,
+                          t2n_stream stream);
+
 /* ---- measurement hooks (bench.py): when enabled, each kernel launch of the render call is bracketed by HIP events on
  * the launch stream. t2n_timing_read synchronises those events and returns accumulated milliseconds and launch counts
  * per kernel since the last reset. Kernel ids: */

@@ -356,3 +356,106 @@ def params_from_numpy(sd, dtype=torch.float32, requires_grad=False):
         t.requires_grad_(requires_grad)
         out[k] = t
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# occupancy mask maintenance and coarse-to-fine resampling
+# ------------------------------------------------------------------------------------------------
+def compute_alpha(cfg: FieldConfig, params, xyz_world, length=1.0):
+    """models/tensorBase.py:412-434."""
+    xyz = xyz_world.reshape(-1, 3)
+    mask = torch.ones(xyz.shape[0], dtype=torch.bool)
+    if cfg.alpha_volume is not None:
+        mask = sample_alpha(cfg, xyz) > 0
+    sigma = torch.zeros(xyz.shape[0], dtype=xyz.dtype)
+    if mask.any():
+        sigma[mask] = feature2density(cfg, density_feature(params, normalize_coord(cfg, xyz[mask])))
+    return (1 - torch.exp(-sigma * length)).view(xyz_world.shape[:-1])
+
+
+def dense_alpha(cfg: FieldConfig, params, grid_size):
+    """models/tensorBase.py:328-344 (getDenseAlpha): nodes aabb0*(1-s) + aabb1*s, s = linspace(0,1,g) per axis."""
+    g = [int(x) for x in grid_size]
+    samples = torch.stack(torch.meshgrid(*[torch.linspace(0, 1, n) for n in g], indexing="ij"), -1)
+    aabb = torch.tensor(cfg.aabb, dtype=torch.float32)
+    dense_xyz = aabb[0] * (1 - samples) + aabb[1] * samples
+    alpha = compute_alpha(cfg, params, dense_xyz.view(-1, 3), cfg.step_size).view(g)
+    return alpha, dense_xyz
+
+
+def alpha_volume(alpha, dense_xyz, thres):
+    """models/tensorBase.py:349-368 (updateAlphaMask): clamp, transpose(0,2), 3x3x3 max pool with -inf padding restated
+    as the max over 27 shifted copies, binarise, bounding box of the kept nodes. Returns (volume [gz,gy,gx], new_aabb)."""
+    a = alpha.clamp(0, 1).transpose(0, 2).contiguous()
+    D, H, W = a.shape
+    pad = torch.full((D + 2, H + 2, W + 2), -math.inf, dtype=a.dtype)
+    pad[1:-1, 1:-1, 1:-1] = a
+    m = torch.full_like(a, -math.inf)
+    for dz in range(3):
+        for dy in range(3):
+            for dx in range(3):
+                m = torch.maximum(m, pad[dz:dz + D, dy:dy + H, dx:dx + W])
+    vol = (m >= thres).to(a.dtype)
+    xyz = dense_xyz.transpose(0, 2).contiguous()[vol > 0.5]
+    return vol, torch.stack((xyz.amin(0), xyz.amax(0)))
+
+
+def upsample_bilinear(x, h_out, w_out):
+    """F.interpolate(x [1,C,H,W], size=(h_out,w_out), mode='bilinear', align_corners=True) restated (ATen
+    upsample_bilinear2d): src = dst*(in-1)/(out-1), taps floor / floor+1 (clamped), weights by subtraction."""
+    _, C, H, W = x.shape
+
+    def taps(n_in, n_out):
+        scale = torch.tensor((n_in - 1) / (n_out - 1) if n_out > 1 else 0.0, dtype=torch.float32)
+        src = scale * torch.arange(n_out, dtype=torch.float32)
+        i0 = src.to(torch.int64)
+        i1 = i0 + (i0 < n_in - 1).to(torch.int64)
+        l1 = src - i0.to(torch.float32)
+        return i0, i1, 1 - l1, l1
+
+    y0, y1, h0, h1 = taps(H, h_out)
+    x0, x1, w0, w1 = taps(W, w_out)
+    r0, r1 = x[0][:, y0], x[0][:, y1]                         # [C, h_out, W]
+    top = w0 * r0[:, :, x0] + w1 * r0[:, :, x1]
+    bot = w0 * r1[:, :, x0] + w1 * r1[:, :, x1]
+    return (h0[None, :, None] * top + h1[None, :, None] * bot)[None]
+
+
+def upsample_field(params, res_target):
+    """models/tensoRF.py:258-280 (up_sampling_VM / upsample_volume_grid) on a state_dict-shaped dict; returns a new dict."""
+    out = dict(params)
+    r = [int(v) for v in res_target]
+    for i in range(3):
+        m0, m1 = MAT_MODE[i]
+        for kind in ("density", "app"):
+            out[f"{kind}_plane.{i}"] = upsample_bilinear(params[f"{kind}_plane.{i}"], r[m1], r[m0])
+            out[f"{kind}_line.{i}"] = upsample_bilinear(params[f"{kind}_line.{i}"], r[VEC_MODE[i]], 1)
+    return out
+
+
+def shrink_field(cfg: FieldConfig, params, new_aabb, mask_grid=None):
+    """models/tensoRF.py:282-320: crop range per axis, cropped factors, corrected aabb and new grid size."""
+    aabb = torch.tensor(cfg.aabb, dtype=torch.float32)
+    grid = torch.tensor([int(g) for g in cfg.grid_size])
+    units = (aabb[1] - aabb[0]) / (grid - 1)
+    new_aabb = torch.as_tensor(new_aabb, dtype=torch.float32)
+    t_l, b_r = (new_aabb[0] - aabb[0]) / units, (new_aabb[1] - aabb[0]) / units
+    t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+    b_r = torch.stack([b_r, grid]).amin(0)
+    out = dict(params)
+    for i in range(3):
+        v = VEC_MODE[i]
+        m0, m1 = MAT_MODE[i]
+        for kind in ("density", "app"):
+            out[f"{kind}_line.{i}"] = params[f"{kind}_line.{i}"][..., t_l[v]:b_r[v], :]
+            out[f"{kind}_plane.{i}"] = params[f"{kind}_plane.{i}"][..., t_l[m1]:b_r[m1], t_l[m0]:b_r[m0]]
+    if mask_grid is None or not bool(torch.all(torch.tensor(mask_grid) == grid)):
+        t_l_r, b_r_r = t_l / (grid - 1), (b_r - 1) / (grid - 1)
+        new_aabb = torch.stack(((1 - t_l_r) * aabb[0] + t_l_r * aabb[1], (1 - b_r_r) * aabb[0] + b_r_r * aabb[1]))
+    return out, new_aabb, (b_r - t_l).tolist()
+
+
+def filter_rays_alpha(cfg: FieldConfig, rays, n_samples):
+    """filtering_rays(bbox_only=False), models/tensorBase.py:393-395."""
+    pts, _, _ = sample_ray(cfg, rays[:, :3], rays[:, 3:6], n_samples, jitter=None)
+    return (sample_alpha(cfg, pts.reshape(-1, 3)).view(pts.shape[:-1]) > 0).any(-1)

@@ -28,6 +28,11 @@ def big300():
 
 
 @pytest.fixture(scope="session")
+def grid_ops():
+    return dict(np.load(os.path.join(GOLDEN, "grid_ops.npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
 def tiny_params():
     from text2nerf_amd import synth
     return synth.make_field_params(11, TINY["grid"], density_scale=0.9, aabb=TINY["aabb"])

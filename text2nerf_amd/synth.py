@@ -147,3 +147,28 @@ def n_to_reso(n_voxels, aabb):
 def cal_n_samples(reso, step_ratio=0.5):
     """utils.py:298-299."""
     return int(np.linalg.norm(reso) / step_ratio)
+
+
+def concentrate_density(sd, lo_frac=(0.25, 0.3, 0.2), hi_frac=(0.7, 0.8, 0.65)):
+    """Zero the density factors outside an index window per axis (in place on a state_dict of numpy arrays): every term
+    of the density feature then vanishes outside a box, which gives updateAlphaMask / shrink tests a non-trivial bounding
+    box."""
+    mat_mode, vec_mode = ((0, 1), (0, 2), (1, 2)), (2, 1, 0)
+
+    def window(n, ax):
+        return int(round(lo_frac[ax] * (n - 1))), int(round(hi_frac[ax] * (n - 1)))
+
+    for i in range(3):
+        line = sd[f"density_line.{i}"]
+        a, b = window(line.shape[2], vec_mode[i])
+        line[:, :, :a] = 0
+        line[:, :, b + 1:] = 0
+        plane = sd[f"density_plane.{i}"]          # [1, C, g[m1], g[m0]]
+        m0, m1 = mat_mode[i]
+        a, b = window(plane.shape[2], m1)
+        plane[:, :, :a] = 0
+        plane[:, :, b + 1:] = 0
+        a, b = window(plane.shape[3], m0)
+        plane[:, :, :, :a] = 0
+        plane[:, :, :, b + 1:] = 0
+    return sd

@@ -420,9 +420,10 @@ class TensorVMSplit(nn.Module):
 
     @torch.no_grad()
     def filtering_rays(self, all_rays, all_rgbs, all_depth=None, N_samples=256, chunk=10240 * 5, bbox_only=False):
-        """models/tensorBase.py:372-404 (bbox_only=True is the driver's call, text2nerf_main.py:477)."""
-        if not bbox_only:
-            raise T2NError("filtering_rays(bbox_only=False) needs an alphaMask, which this renderer does not build")
+        """models/tensorBase.py:372-404: slab test (bbox_only=True, the driver's call, text2nerf_main.py:477) or "any of the
+        ray's N_samples samples lies in an occupied cell of the alphaMask"."""
+        if not bbox_only and self.alphaMask is None:
+            raise T2NError("filtering_rays(bbox_only=False) needs an alphaMask (updateAlphaMask() or a checkpoint's)")
         lib = _lib.load()
         h = self.sync_params()
         dev = self.basis_mat.weight.device
@@ -433,14 +434,141 @@ class TensorVMSplit(nn.Module):
             r = flat[idx].to(dev).contiguous().float()
             m = torch.empty(r.shape[0], dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
-                _lib.check(lib.t2n_filter_rays_bbox(h, _lib.ptr(r), r.shape[0], r.shape[1], _lib.ptr(m),
-                                                    _lib.current_stream_ptr(dev)), "t2n_filter_rays_bbox")
+                if bbox_only:
+                    _lib.check(lib.t2n_filter_rays_bbox(h, _lib.ptr(r), r.shape[0], r.shape[1], _lib.ptr(m),
+                                                        _lib.current_stream_ptr(dev)), "t2n_filter_rays_bbox")
+                else:
+                    _lib.check(lib.t2n_filter_rays_alpha(h, _lib.ptr(r), r.shape[0], r.shape[1], int(N_samples), _lib.ptr(m),
+                                                         _lib.current_stream_ptr(dev)), "t2n_filter_rays_alpha")
             masks.append(m.bool().cpu())
         mask = torch.cat(masks).view(all_rgbs.shape[:-1])
         print(f"Ray filtering done! takes {time.time() - tt} s. ray mask ratio: {torch.sum(mask) / flat.shape[0]}")
         if all_depth is not None:
             return all_rays[mask], all_rgbs[mask], all_depth[mask]
         return all_rays[mask], all_rgbs[mask]
+
+    # ---- coarse-to-fine / occupancy maintenance ----------------------------------------------------------
+    def _drop_handle(self):
+        """Grid shape or aabb changed: the native field is rebuilt on the next use."""
+        if self._handle is not None:
+            _lib.load().t2n_field_destroy(self._handle)
+            self._handle = None
+        self._uploaded_key = None
+
+    @torch.no_grad()
+    def compute_alpha(self, xyz_locs, length=1):
+        """models/tensorBase.py:412-434: 1 - exp(-sigma * length) at world-space points (sigma = 0 outside the alphaMask)."""
+        lib = _lib.load()
+        h = self.sync_params()
+        dev = self.basis_mat.weight.device
+        xyz = xyz_locs.detach().reshape(-1, 3).contiguous().float().to(dev)
+        out = torch.empty(xyz.shape[0], device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.t2n_compute_alpha(h, _lib.ptr(xyz), xyz.shape[0], float(length), _lib.ptr(out),
+                                             _lib.current_stream_ptr(dev)), "t2n_compute_alpha")
+        return out.view(xyz_locs.shape[:-1])
+
+    @torch.no_grad()
+    def getDenseAlpha(self, gridSize=None):
+        """models/tensorBase.py:328-344: alpha at the nodes of a dense grid over the aabb, one step long; returns
+        (alpha [gx,gy,gz], dense_xyz [gx,gy,gz,3]). Node positions are generated inside the kernel from the same
+        torch.linspace(0, 1, g) values the reference lerps with."""
+        lib = _lib.load()
+        h = self.sync_params()
+        dev = self.basis_mat.weight.device
+        g = [int(x) for x in (self.gridSize if gridSize is None else gridSize)]
+        lins = [torch.linspace(0, 1, n).to(dev) for n in g]
+        alpha = torch.empty(g, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.t2n_dense_alpha(h, _lib.ptr(lins[0]), _lib.ptr(lins[1]), _lib.ptr(lins[2]), g[0], g[1], g[2],
+                                           float(self.stepSize), _lib.ptr(alpha), _lib.current_stream_ptr(dev)),
+                       "t2n_dense_alpha")
+        samples = torch.stack(torch.meshgrid(*lins, indexing="ij"), -1)
+        dense_xyz = self.aabb[0] * (1 - samples) + self.aabb[1] * samples
+        return alpha, dense_xyz
+
+    @torch.no_grad()
+    def updateAlphaMask(self, gridSize=(200, 200, 200)):
+        """models/tensorBase.py:346-370: rebuild the occupancy mask from the current density (3x3x3 dilation, threshold
+        alphaMask_thres) and return the bounding box of the occupied voxels."""
+        lib = _lib.load()
+        dev = self.basis_mat.weight.device
+        g = [int(x) for x in gridSize]
+        alpha, _ = self.getDenseAlpha(g)
+        vol = torch.empty((g[2], g[1], g[0]), device=dev, dtype=torch.float32)
+        box = torch.empty(6, device=dev, dtype=torch.int32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.t2n_alpha_volume(_lib.ptr(alpha), g[0], g[1], g[2], float(self.alphaMask_thres), _lib.ptr(vol),
+                                            _lib.ptr(box), _lib.current_stream_ptr(dev)), "t2n_alpha_volume")
+        self.alphaMask = AlphaGridMask(self.device, self.aabb, vol)
+        b = box.cpu().tolist()
+        if b[3] < 0:
+            raise T2NError("updateAlphaMask: no voxel reaches alphaMask_thres (the reference fails on the empty amin too)")
+        lins = [torch.linspace(0, 1, n) for n in g]
+        a = self.aabb.detach().float().cpu()
+        lo = torch.stack([a[0, k] * (1 - lins[k][b[k]]) + a[1, k] * lins[k][b[k]] for k in range(3)])
+        hi = torch.stack([a[0, k] * (1 - lins[k][b[3 + k]]) + a[1, k] * lins[k][b[3 + k]] for k in range(3)])
+        new_aabb = torch.stack((lo, hi)).to(self.aabb.device)
+        total = int(g[0] * g[1] * g[2])
+        print(f"bbox: {lo, hi} alpha rest %%%f" % (float(vol.sum()) / total * 100))
+        return new_aabb
+
+    @torch.no_grad()
+    def up_sampling_VM(self, plane_coef, line_coef, res_target):
+        """models/tensoRF.py:258-272: bilinear (align_corners=True) resize of the three planes and lines."""
+        lib = _lib.load()
+        res = [int(x) for x in res_target]
+
+        def resize(t, Hout, Wout):
+            t = t.detach().contiguous().float()
+            _, Cn, Hin, Win = t.shape
+            out = torch.empty((1, Cn, Hout, Wout), device=t.device, dtype=torch.float32)
+            with torch.cuda.device(t.device):
+                _lib.check(lib.t2n_upsample_bilinear(_lib.ptr(t), Cn, Hin, Win, _lib.ptr(out), Hout, Wout,
+                                                     _lib.current_stream_ptr(t.device)), "t2n_upsample_bilinear")
+            return out
+
+        for i in range(3):
+            m0, m1 = MAT_MODE[i]
+            plane_coef[i] = nn.Parameter(resize(plane_coef[i].data, res[m1], res[m0]))
+            line_coef[i] = nn.Parameter(resize(line_coef[i].data, res[VEC_MODE[i]], 1))
+        return plane_coef, line_coef
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        """models/tensoRF.py:274-280."""
+        self.app_plane, self.app_line = self.up_sampling_VM(self.app_plane, self.app_line, res_target)
+        self.density_plane, self.density_line = self.up_sampling_VM(self.density_plane, self.density_line, res_target)
+        self._drop_handle()
+        self.update_stepSize(res_target)
+        print(f"upsamping to {res_target}")
+
+    @torch.no_grad()
+    def shrink(self, new_aabb):
+        """models/tensoRF.py:282-320: crop every factor to the voxel range covering new_aabb (host index arithmetic +
+        tensor slicing; nothing to compute on the device)."""
+        new_aabb = torch.as_tensor(new_aabb, dtype=torch.float32).to(self.aabb.device)
+        xyz_min, xyz_max = new_aabb
+        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
+        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+        b_r = torch.stack([b_r, self.gridSize]).amin(0)
+        for i in range(3):
+            v = VEC_MODE[i]
+            self.density_line[i] = nn.Parameter(self.density_line[i].data[..., t_l[v]:b_r[v], :].contiguous())
+            self.app_line[i] = nn.Parameter(self.app_line[i].data[..., t_l[v]:b_r[v], :].contiguous())
+            m0, m1 = MAT_MODE[i]
+            self.density_plane[i] = nn.Parameter(self.density_plane[i].data[..., t_l[m1]:b_r[m1], t_l[m0]:b_r[m0]].contiguous())
+            self.app_plane[i] = nn.Parameter(self.app_plane[i].data[..., t_l[m1]:b_r[m1], t_l[m0]:b_r[m0]].contiguous())
+        if self.alphaMask is None or not torch.all(self.alphaMask.gridSize.to(self.gridSize.device) == self.gridSize):
+            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
+            correct_aabb = torch.zeros_like(new_aabb)
+            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
+            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
+            new_aabb = correct_aabb
+        newSize = b_r - t_l
+        self.aabb = new_aabb
+        self._drop_handle()
+        self.update_stepSize((int(newSize[0]), int(newSize[1]), int(newSize[2])))
 
     # ---- the render call ----------------------------------------------------------------------------------------------------
     def forward(self, rays_chunk, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1):
