@@ -315,41 +315,79 @@ __global__ __launch_bounds__(256) void k_bwd_l2(const float4* __restrict__ go, c
 }
 
 // ---- fp32 MFMA GEMMs -----------------------------------------------------------------------------------------------------
-// C[M,N] += A^T B over a chunk of rows: A [rows, lda] (gradients), B [rows, ldb] (activations). One wave = one 32-column
-// block of N x all MB 32-row blocks of M x one row chunk; partial sums are added atomically into row-major C (ldc).
+// C[M,N] += A^T B, split over row chunks: A [rows, lda] (gradients, M <= MB*32 <= lda), B [rows, ldb] (activations, ldb % 4 == 0,
+// columns >= N up to ldb are zero or ignored). A workgroup (4 waves) owns one row chunk x one 128-column group of N: 32-row
+// tiles of A and B go global -> registers (float4, coalesced; the next tile's loads are in flight while the current one is
+// multiplied) -> LDS; wave w multiplies all MB row blocks of M against its 32-column block. The chunk's partial product
+// is stored to `part` [chunks][MB*32][ldp] and k_gemm_tn_reduce sums the chunks into C (deterministic, no atomics).
 template <int MB>
 __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                 long long rows, int M, int N, float* C, int ldc, int chunk_rows) {
-    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-    const int NB = (N + 31) / 32;
-    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nb = (int)(gw % NB);
-    const long long r0 = (gw / NB) * chunk_rows;
-    if (r0 >= rows) return;
+                                                 long long rows, int N, float* __restrict__ part, int ldp, int chunk_rows) {
+    constexpr int MA = MB * 32;            // staged A columns
+    constexpr int A4 = MA / 4;             // float4 per staged A row
+    constexpr int NA = (32 * A4) / 256;    // float4 loads per thread for the A tile (MB=4: 4, MB=1: 1)
+    __shared__ __attribute__((aligned(16))) float sA[32 * MA];
+    __shared__ __attribute__((aligned(16))) float sB[32 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, h = lane >> 5;
+    const int ng = blockIdx.x;
+    const long long r0 = (long long)blockIdx.y * chunk_rows;
     const long long r1 = (r0 + chunk_rows < rows) ? r0 + chunk_rows : rows;
-    const int col = nb * 32 + i;
-    const bool colok = col < N;
+    float4 ra[NA], rb[4];
+    auto fetch = [&](long long kt) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int u = tid + q * 256, row = u / A4, c4 = u % A4;
+            const long long r = kt + row;
+            ra[q] = r < r1 ? *reinterpret_cast<const float4*>(A + r * lda + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int u = tid + q * 256, row = u >> 5, c4 = u & 31;
+            const long long r = kt + row;
+            const int col = ng * 128 + c4 * 4;
+            rb[q] = (r < r1 && col < ldb) ? *reinterpret_cast<const float4*>(B + r * ldb + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
     f32x16 acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[m] = f32x16{0};
-    for (long long rr = r0; rr < r1; rr += 2) {
-        const long long r = rr + h;
-        const bool rok = r < r1;
-        const float b = (rok && colok) ? B[r * ldb + col] : 0.f;
+    if (r0 < r1) fetch(r0);
+    for (long long kt = r0; kt < r1; kt += 32) {
+        __syncthreads();   // the previous tile has been consumed
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int mi = m * 32 + i;
-            const float av = (rok && mi < M) ? A[r * lda + mi] : 0.f;
-            acc[m] = mfma(av, b, acc[m]);
+        for (int q = 0; q < NA; ++q) *reinterpret_cast<float4*>(sA + (size_t)(tid + q * 256) * 4) = ra[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(sB + (size_t)(tid + q * 256) * 4) = rb[q];
+        __syncthreads();
+        if (kt + 32 < r1) fetch(kt + 32);
+#pragma unroll 4
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const int k = 2 * k2 + h;
+            const float b = sB[k * 128 + w * 32 + i];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[m] = mfma(sA[k * MA + m * 32 + i], b, acc[m]);
         }
     }
+    float* __restrict__ P = part + (size_t)blockIdx.y * MA * ldp + ng * 128 + w * 32 + i;
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int row = m * 32 + unit_of(v, h);
-            if (row < M && colok) atomicAdd(&C[(size_t)row * ldc + col], acc[m][v]);
-        }
+        for (int v = 0; v < 16; ++v) P[(size_t)(m * 32 + unit_of(v, h)) * ldp] = acc[m][v];
+}
+
+// C[M,N] (row-major, ldc) += sum over chunks of part[chunk][MA][ldp]
+__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict__ part, int chunks, int MA, int ldp, int M, int N,
+                                                        float* __restrict__ C, int ldc) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int row = t / ldp, col = t - row * ldp;
+    if (row >= M || col >= N) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* p = part + (size_t)row * ldp + col;
+    const size_t st = (size_t)MA * ldp;
+    int c = 0;
+    for (; c + 4 <= chunks; c += 4) { s0 += p[c * st]; s1 += p[(c + 1) * st]; s2 += p[(c + 2) * st]; s3 += p[(c + 3) * st]; }
+    for (; c < chunks; ++c) s0 += p[c * st];
+    C[(size_t)row * ldc + col] += (s0 + s1) + (s2 + s3);
 }
 
 // OUT[rows, N] = (IN[rows, K] W[K, N]) (* [ACT > 0] if ACT). One wave = 32 rows x up to 128 output columns (4 blocks);
@@ -518,7 +556,31 @@ __global__ __launch_bounds__(256) void k_relayout_add(const float* __restrict__ 
 
 // Activation / gradient rows of the backward pass. Buffers whose lifetimes do not overlap (or that are rewritten
 // element-in-place by the same thread) share storage: g1 over h1, g0 over h0, gx over xpe, gf over feat32, gX over x144.
-struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, total; };
+struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, total; };
+// split of a [rows] x (M<=128) x N weight-gradient GEMM into row chunks: ~768 workgroups, chunk a multiple of 32 rows
+struct TnPlan { int chunk_rows, chunks, ng, ldp; };
+static TnPlan tn_plan(int64_t rows, int N) {
+    TnPlan p;
+    p.ng = (N + 127) / 128;
+    p.ldp = p.ng * 128;
+    int64_t c = (rows * p.ng + 767) / 768;
+    c = (c + 31) / 32 * 32;
+    if (c < 64) c = 64;
+    p.chunk_rows = (int)c;
+    p.chunks = (int)((rows + c - 1) / c);
+    if (p.chunks < 1) p.chunks = 1;
+    return p;
+}
+static size_t tn_part_bytes(int64_t rows) {
+    size_t m = 0;
+    const int shapes[3][2] = {{128, 128}, {128, 351}, {32, 144}};
+    for (auto& sh : shapes) {
+        const TnPlan p = tn_plan(rows, sh[1]);
+        const size_t b = (size_t)p.chunks * sh[0] * p.ldp * 4;
+        if (b > m) m = b;
+    }
+    return m;
+}
 static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 static BwdCarve bwd_carve(int64_t rows) {
     BwdCarve c;
@@ -530,6 +592,7 @@ static BwdCarve bwd_carve(int64_t rows) {
     c.h1 = o; o = al256(o + R * 128 * 4);
     c.go = o; o = al256(o + R * 16);
     c.xpe = o; o = al256(o + R * 352 * 4);
+    c.part = o; o = al256(o + tn_part_bytes(rows));
     c.total = o;
     return c;
 }
@@ -548,10 +611,12 @@ static int ensure_grad_buffers(t2n_field* f) {
 
 template <int MB>
 static void launch_gemm_tn(const float* A, int lda, const float* B, int ldb, long long rows, int M, int N, float* C, int ldc,
-                           hipStream_t s) {
-    const int chunk = 1024;
-    const long long waves = (long long)((N + 31) / 32) * ((rows + chunk - 1) / chunk);
-    hipLaunchKernelGGL((k_gemm_tn<MB>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, A, lda, B, ldb, rows, M, N, C, ldc, chunk);
+                           float* part, hipStream_t s) {
+    const TnPlan p = tn_plan(rows, N);
+    hipLaunchKernelGGL((k_gemm_tn<MB>), dim3((unsigned)p.ng, (unsigned)p.chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part,
+                       p.ldp, p.chunk_rows);
+    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((MB * 32 * p.ldp + 255) / 256)), dim3(256), 0, s, (const float*)part,
+                       p.chunks, MB * 32, p.ldp, M, N, C, ldc);
 }
 static void launch_gemm_nn(const float* IN, int ldin, const float* W, int ldw, long long rows, int K, int N, const float* ACT,
                            int ldact, float* OUT, int ldo, hipStream_t s) {
@@ -619,6 +684,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     char* bw = (char*)bwd_workspace;
     float* x144 = (float*)(bw + b.x144); float* feat32 = (float*)(bw + b.feat32); float* h0 = (float*)(bw + b.h0);
     float* h1 = (float*)(bw + b.h1); float4* go = (float4*)(bw + b.go); float* xpe = (float*)(bw + b.xpe);
+    float* part = (float*)(bw + b.part);
     float* g1 = h1;      // k_bwd_l2 rewrites each element in place
     float* g0 = h0;      // gemm_nn reads the ReLU mask and writes the masked product at the same element
     float* gx = xpe;     // xpe is dead once dW0 has been accumulated
@@ -673,15 +739,15 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         hipLaunchKernelGGL(k_bwd_l2, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, (const float4*)go, (const float*)h1,
                            (long long)rows, P->mlp_w2, g1, g->mlp_w2, g->mlp_b2);
         // 4. layers 1, 0, PE, basis
-        if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, s);
+        if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s);
         if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
         launch_gemm_nn(g1, 128, P->mlp_w1, 128, rows, 128, 128, h0, 128, g0, 128, s);
         hipLaunchKernelGGL(k_pe_fwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)feat32, (long long)rows, xpe);
-        if (g->mlp_w0) launch_gemm_tn<4>(g0, 128, xpe, 352, rows, 128, 351, g->mlp_w0, 351, s);
+        if (g->mlp_w0) launch_gemm_tn<4>(g0, 128, xpe, 352, rows, 128, 351, g->mlp_w0, 351, part, s);
         if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, s, (const float*)g0, 128, (long long)rows, 128, g->mlp_b0, 128);
         launch_gemm_nn(g0, 128, P->mlp_w0, 351, rows, 128, 351, nullptr, 0, gx, 352, s);
         hipLaunchKernelGGL(k_pe_bwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)gx, (const float*)feat32, (long long)rows, gf);
-        if (g->basis_weight) launch_gemm_tn<1>(gf, 32, x144, 144, rows, 27, 144, g->basis_weight, 144, s);
+        if (g->basis_weight) launch_gemm_tn<1>(gf, 32, x144, 144, rows, 27, 144, g->basis_weight, 144, part, s);
         launch_gemm_nn(gf, 32, P->basis_weight, 144, rows, 27, 144, nullptr, 0, gxapp, 144, s);
         timing_end(f, T2N_K_BWD_MLP, s);
         T2N_HIP(hipGetLastError());
