@@ -180,11 +180,11 @@ int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_
  * Protocol: (1) forward with T2N_FLAG_KEEP_CTX as ONE launch (workspace >= t2n_render_workspace_bytes_ctx), weights and
  * z_vals materialised; (2) t2n_render_ctx_rows reads the appearance-sample count back (SYNCHRONISES the stream) and
  * returns the padded activation row count; (3) t2n_render_backward with a second workspace of
- * t2n_backward_workspace_bytes(rows). Only the MLP_Fea_noview head is differentiable here (the driver's head).
+ * t2n_backward_workspace_bytes(field, rows, n_rays, n_samples). Only the MLP_Fea_noview head is differentiable here (the driver's head).
  * d_weights may be NULL. Gradients are ACCUMULATED into `g` (reference layouts; NULL members are skipped). */
 size_t t2n_render_workspace_bytes_ctx(int64_t n_rays, int n_samples);
 int t2n_render_ctx_rows(const void* fwd_workspace, int64_t n_rays, int n_samples, t2n_stream stream, int64_t* rows);
-size_t t2n_backward_workspace_bytes(int64_t rows);
+size_t t2n_backward_workspace_bytes(const t2n_field* f, int64_t rows, int64_t n_rays, int n_samples);
 int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
                         const float* jitter, const float* d_rgb, const float* d_depth, const float* d_weights,
                         const t2n_field_grads* g, void* fwd_workspace, size_t fwd_workspace_bytes, void* bwd_workspace,

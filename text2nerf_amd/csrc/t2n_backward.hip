@@ -12,6 +12,8 @@
 //                              PE backward -> gf, dWb = gf^T X, gX = gf Wb; k_colsum for the biases
 //   5  k_bwd_app_scatter       re-gather appearance taps, scatter-add plane/line gradients
 //   6  k_relayout_add          channel-last gradient buffers -> += reference-layout [1,C,H,W] gradient tensors
+#include <stdlib.h>
+
 #include "t2n_device.h"
 
 namespace t2n {
@@ -159,6 +161,50 @@ __device__ __forceinline__ void scatter_win(const FactorSet& S, const GradSet& G
     line_add(lw, G.line[K], C, coff, ol, al.i0 == ol ? gl * al.w0 : 0.f, gl * al.w1);
 }
 
+
+// ---- tile-binned scatter ---------------------------------------------------------------------------------------------------
+// A training batch puts ~28 samples into every texel of every density plane, from unrelated rays: global fp32 atomics per
+// tap (even merged along a ray) run at the L2 atomic rate. Instead: (1) count the samples of every 16x16-texel plane tile,
+// (2) prefix-sum, (3) write a 16-B record (x, y, z, dL/dfeature) per sample and plane into its tile's run, (4) one
+// workgroup per <= kBinSeg records of one tile accumulates plane AND line gradients in LDS (ds_add_f32 on a staged
+// 17x17xC tile + the whole line) and flushes the non-zero texels once. Global atomics drop ~15x.
+constexpr int kBinTile = 16;      // texels per tile edge (footprints reach one texel further: 17 staged)
+constexpr int kBinCopies = 32;    // privatised histogram / cursor copies (every ray starts in the camera's tile)
+constexpr int kBinSeg = 8192;     // records per accumulate workgroup
+
+struct BinGeom { int tw[3], before[3], total; };
+static BinGeom bin_geom(const FactorSet& S) {
+    BinGeom g;
+    int t = 0;
+    for (int k = 0; k < 3; ++k) {
+        g.tw[k] = (S.W[k] + kBinTile) / kBinTile;              // cell + 1 in [0, W]
+        g.before[k] = t;
+        t += g.tw[k] * ((S.H[k] + kBinTile) / kBinTile);
+    }
+    g.total = t;
+    return g;
+}
+// tile ids (global over the three planes) of a sample; axis a of the grid pairs with coordinate a (see sample_axes)
+__device__ __forceinline__ void bin_keys(const FactorSet& S, const BinGeom& G, float xn, float yn, float zn, int key[3]) {
+    const int cx = (axis_cell(xn, S.W[0]) + 1) / kBinTile, cy = (axis_cell(yn, S.H[0]) + 1) / kBinTile,
+              cz = (axis_cell(zn, S.H[1]) + 1) / kBinTile;
+    key[0] = G.before[0] + cy * G.tw[0] + cx;
+    key[1] = G.before[1] + cz * G.tw[1] + cx;
+    key[2] = G.before[2] + cz * G.tw[2] + cy;
+}
+// Runs of equal keys along the 64 lanes (consecutive samples of a ray stay in a tile for many steps): the first lane of a
+// run is its leader and reserves for the whole run. Must be called by all 64 lanes.
+__device__ __forceinline__ void run_leader(int key, int lane, bool& leader, int& runlen, int& ll) {
+    const int prev = __shfl_up(key, 1);
+    leader = (lane == 0) | (key != prev);
+    const unsigned long long lm = __ballot(leader);
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const unsigned long long higher = lm & ~upto;
+    const int nxt = higher ? (__ffsll((long long)higher) - 1) : 64;
+    runlen = nxt - lane;
+    ll = 63 - __clzll((long long)(lm & upto));
+}
+
 struct BwdMarchArgs {
     FieldDev F;
     GradSet gden;
@@ -167,9 +213,12 @@ struct BwdMarchArgs {
     const float* d_rgb; const float* d_depth; const float* d_w;
     float4* go;   // [rows] dL/d(pre-sigmoid rgb) per appearance row
     unsigned list_cap; TilePrefix tp; int add_bg;
+    // BIN: dL/dfeature per sample goes to gfeat [n_rays, N] (aliases sigma) and the (plane, tile) histogram is counted
+    float* gfeat; unsigned* hist; BinGeom geom;
 };
 
-template <bool TRAIN>
+// BIN = false: scatter with sliding windows + global atomics (any grid). BIN = true: first pass of the tile-binned scatter.
+template <bool TRAIN, bool BIN>
 __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -264,6 +313,31 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
     }
     wave_lds_sync();
 
+    if constexpr (BIN) {
+        // ---- dL/dfeature of every live sample -> gfeat; count the samples of each (plane, tile) bin ------------------------
+        const unsigned copy = (unsigned)(r >> 2) & (kBinCopies - 1);
+        for (int base = 0; base < Lw; base += 64) {
+            const int j = base + lane, i = first + j;
+            int key[3] = {-1, -1, -1};
+            if (j < Lw) {
+                float gf = Gw[j];
+                float xn, yn, zn;
+                const float z = sample_z<TRAIN>(F, ray, i, u);
+                bool ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
+                if (F.alpha && ok) ok = alpha_pass(F, ray, z);
+                if (ok && gf != 0.f) bin_keys(F.den, a.geom, xn, yn, zn, key); else gf = 0.f;
+                a.gfeat[r * N + i] = gf;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                bool leader; int runlen, ll;
+                run_leader(key[k], lane, leader, runlen, ll);
+                if (leader && key[k] >= 0) atomicAdd(&a.hist[(unsigned)key[k] * kBinCopies + copy], (unsigned)runlen);
+            }
+        }
+        return;
+    }
+
     // ---- scatter: 16 lanes per sample (one channel each); each 16-lane group walks a CONTIGUOUS quarter of the window
     // so that successive samples are neighbours along the ray and the sliding windows merge their shared texels ----------
     const int ch = lane & 15, sl = lane >> 4;
@@ -290,6 +364,214 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
     plane_flush(pw0, a.gden.plane[0], F.den.W[0], 16, ch); plane_flush(pw1, a.gden.plane[1], F.den.W[1], 16, ch);
     plane_flush(pw2, a.gden.plane[2], F.den.W[2], 16, ch);
     line_flush(lw0, a.gden.line[0], 16, ch); line_flush(lw1, a.gden.line[1], 16, ch); line_flush(lw2, a.gden.line[2], 16, ch);
+}
+
+
+// (2) single workgroup: exclusive scan of the [tile][copy] histogram -> absolute cursors (in place), tile starts, and the
+// segment list of the accumulate pass.
+__global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, unsigned* tile_start, int4* segs, unsigned* nseg_out,
+                                                   unsigned seg_cap) {
+    __shared__ unsigned sh[1024];
+    const int t = threadIdx.x;
+    const int n = n_tiles * kBinCopies;
+    const int per = (n + 1023) / 1024;
+    const int b = t * per, e = min(n, b + per);
+    unsigned sum = 0;
+    for (int i = b; i < e; ++i) sum += hist[i];
+    sh[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = t >= o ? sh[t - o] : 0u;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    unsigned run = sh[t] - sum;
+    for (int i = b; i < e; ++i) {
+        const unsigned c = hist[i];
+        hist[i] = run;
+        if ((i & (kBinCopies - 1)) == 0) tile_start[i / kBinCopies] = run;
+        run += c;
+    }
+    if (t == 1023) tile_start[n_tiles] = sh[1023];
+    __syncthreads();
+    // segments: tile j -> ceil(count / kBinSeg) work items
+    const int pt = (n_tiles + 1023) / 1024;
+    const int tb = t * pt, te = min(n_tiles, tb + pt);
+    unsigned ns = 0;
+    for (int j = tb; j < te; ++j) ns += (tile_start[j + 1] - tile_start[j] + kBinSeg - 1) / kBinSeg;
+    __syncthreads();
+    sh[t] = ns;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = t >= o ? sh[t - o] : 0u;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    unsigned si = sh[t] - ns;
+    for (int j = tb; j < te; ++j) {
+        const unsigned s0 = tile_start[j], s1 = tile_start[j + 1];
+        for (unsigned s = s0; s < s1; s += kBinSeg) {
+            if (si < seg_cap) segs[si] = make_int4(j, (int)s, (int)min(s1, s + kBinSeg), 0);
+            ++si;
+        }
+    }
+    if (t == 1023) *nseg_out = min(sh[1023], seg_cap);
+}
+
+// (3) per ray (same ray -> wave -> copy map as the counting pass): write the records into their tiles' runs
+struct BinArgs {
+    FieldDev F; BinGeom geom;
+    const float* rays; long long n_rays; int ray_stride; int n_samples;
+    const float* jitter; const float* gfeat; const int4* ray_app; unsigned* cursor; float4* recs;
+};
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void k_bwd_bin(const BinArgs a) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const FieldDev& F = a.F;
+    const long long r = (long long)blockIdx.x * 4 + wid;
+    if (r >= a.n_rays) return;
+    const int4 ra = a.ray_app[r];
+    const int first = ra.w & 2047, Lw = ra.w >> 11;
+    if (Lw <= 0) return;
+    const int N = a.n_samples;
+    const Ray ray = load_ray(F, a.rays + r * a.ray_stride, a.ray_stride);
+    const float u = TRAIN ? a.jitter[r] : 0.f;
+    const unsigned copy = (unsigned)(r >> 2) & (kBinCopies - 1);
+    for (int base = 0; base < Lw; base += 64) {
+        const int j = base + lane, i = first + j;
+        int key[3] = {-1, -1, -1};
+        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < Lw) {
+            rec.w = a.gfeat[r * N + i];
+            if (rec.w != 0.f) {
+                const float z = sample_z<TRAIN>(F, ray, i, u);
+                (void)sample_point<TRAIN>(F, ray, z, rec.x, rec.y, rec.z);
+                bin_keys(F.den, a.geom, rec.x, rec.y, rec.z, key);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            bool leader; int runlen, ll;
+            run_leader(key[k], lane, leader, runlen, ll);
+            unsigned pos = 0;
+            if (leader && key[k] >= 0) pos = atomicAdd(&a.cursor[(unsigned)key[k] * kBinCopies + copy], (unsigned)runlen);
+            pos = __shfl(pos, ll) + (unsigned)(lane - ll);
+            if (key[k] >= 0) a.recs[pos] = rec;
+        }
+    }
+}
+
+// (4) accumulate one segment of one tile in LDS. Measured on gfx950 (tools/experiments/lds_atomic_bench.hip): ds_add_f32
+// retires ~1 lane per 3 clocks (194 clk per wave instruction, whatever the addresses) while ds_add_f64 / ds_add_u64 run at
+// 8-9 clk conflict-free — so the tile and line accumulators are DOUBLES. Per wave and batch of 64 records: lane = record
+// computes the taps once (cell offset, line row, six weights, g) into a wave-private LDS table; then 16 lanes per record
+// (one channel each, C/16 channel groups in turn) read their record's table entry (broadcast), the staged plane / line
+// values, and issue 4 + 2 ds_add_f64.
+constexpr int kAccThreads = 512;
+struct TileAccumArgs {
+    FactorSet S; GradSet G; BinGeom geom; const int4* segs; const unsigned* nseg; const float4* recs; int dbg;
+};
+template <int C, int K>
+__device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const int4 sg, int x0, int y0, const float* Pv, double* Pa,
+                                                   const float* Lv, double* La, float4* tab) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, ch = lane & 15, sub = lane >> 4;
+    constexpr int NW = kAccThreads / 64;
+    const int W = a.S.W[K], H = a.S.H[K], L = a.S.L[K];
+    const int per = ((sg.z - sg.y + NW * 64 - 1) / (NW * 64)) * 64;     // records per wave, whole batches
+    const int rb = sg.y + wid * per, re = min(sg.z, rb + per);
+    float4* T = tab + wid * 64 * 3;
+    float4 p = rb + lane < re ? a.recs[rb + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b0 = rb; b0 < re; b0 += 64) {
+        float gx, gy, gv;
+        plane_line_coords<K>(p.x, p.y, p.z, gx, gy, gv);
+        const Axis ax = axis_taps(gx, W), ay = axis_taps(gy, H), al = axis_taps(gv, L);
+        const int lx = axis_cell(gx, W) - x0, ly = axis_cell(gy, H) - y0, fl = axis_cell(gv, L);
+        const bool live = b0 + lane < re;
+        const float g = live ? p.w : 0.f;
+        T[lane * 3 + 0] = make_float4(__int_as_float(live ? (ly * (kBinTile + 1) + lx) * C : 0), __int_as_float(live ? (fl + 1) * C : 0), g, 0.f);
+        T[lane * 3 + 1] = make_float4(ay.w0 * ax.w0, ay.w0 * ax.w1, ay.w1 * ax.w0, ay.w1 * ax.w1);
+        T[lane * 3 + 2] = make_float4(al.w0, al.w1, 0.f, 0.f);
+        if (b0 + 64 + lane < re) p = a.recs[b0 + 64 + lane];   // next batch in flight while this one is accumulated
+        wave_lds_sync();
+        const int nrec = min(64, re - b0);
+#pragma unroll 2
+        for (int q = 0; q * 4 < nrec; ++q) {
+            const int ri = q * 4 + sub;
+            const float4 t0 = T[ri * 3], wp = T[ri * 3 + 1], wl = T[ri * 3 + 2];
+            const int c00 = __float_as_int(t0.x) + ch, c01 = c00 + C, c10 = c00 + (kBinTile + 1) * C, c11 = c10 + C;
+            const int r0 = __float_as_int(t0.y) + ch, r1 = r0 + C;
+            const float g2 = t0.z;
+            if (g2 != 0.f) {
+#pragma unroll
+                for (int cg = 0; cg < C / 16; ++cg) {
+                    const int o = cg * 16;
+                    float pv = Pv[c00 + o] * wp.x;
+                    pv = fmaf(Pv[c01 + o], wp.y, pv); pv = fmaf(Pv[c10 + o], wp.z, pv); pv = fmaf(Pv[c11 + o], wp.w, pv);
+                    const float lv = fmaf(Lv[r1 + o], wl.y, Lv[r0 + o] * wl.x);
+                    const float gp = g2 * lv, gl = g2 * pv;
+                    atomicAdd(&Pa[c00 + o], (double)(gp * wp.x)); atomicAdd(&Pa[c01 + o], (double)(gp * wp.y));
+                    atomicAdd(&Pa[c10 + o], (double)(gp * wp.z)); atomicAdd(&Pa[c11 + o], (double)(gp * wp.w));
+                    atomicAdd(&La[r0 + o], (double)(gl * wl.x)); atomicAdd(&La[r1 + o], (double)(gl * wl.y));
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+}
+template <int C>
+__global__ __launch_bounds__(kAccThreads) void k_bwd_tile_accum(const TileAccumArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (blockIdx.x >= *a.nseg) return;
+    const int4 sg = a.segs[blockIdx.x];
+    const int k = sg.x >= a.geom.before[2] ? 2 : (sg.x >= a.geom.before[1] ? 1 : 0);
+    const int tile = sg.x - a.geom.before[k];
+    int W, H, L, tw; const float* __restrict__ P; const float* __restrict__ Ln; float* gP; float* gL;
+    // (no dynamic indexing of the by-value argument struct: that would move it to scratch)
+    if (k == 0) { W = a.S.W[0]; H = a.S.H[0]; L = a.S.L[0]; tw = a.geom.tw[0]; P = a.S.plane[0]; Ln = a.S.line[0]; gP = a.G.plane[0]; gL = a.G.line[0]; }
+    else if (k == 1) { W = a.S.W[1]; H = a.S.H[1]; L = a.S.L[1]; tw = a.geom.tw[1]; P = a.S.plane[1]; Ln = a.S.line[1]; gP = a.G.plane[1]; gL = a.G.line[1]; }
+    else { W = a.S.W[2]; H = a.S.H[2]; L = a.S.L[2]; tw = a.geom.tw[2]; P = a.S.plane[2]; Ln = a.S.line[2]; gP = a.G.plane[2]; gL = a.G.line[2]; }
+    const int x0 = (tile % tw) * kBinTile - 1, y0 = (tile / tw) * kBinTile - 1;   // texel of local (0, 0)
+    constexpr int T1 = kBinTile + 1, TP = T1 * T1 * C, C4 = C / 4;
+    double* Pa = reinterpret_cast<double*>(smem);
+    double* La = Pa + TP;
+    float* Pv = reinterpret_cast<float*>(La + (size_t)(L + 2) * C);
+    float* Lv = Pv + TP;
+    float4* tab = reinterpret_cast<float4*>(Lv + (size_t)(L + 2) * C);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int idx = threadIdx.x; idx < TP / 4; idx += kAccThreads) {
+        const int cell = idx / C4, q = idx - cell * C4, ly = cell / T1, lx = cell - ly * T1, y = y0 + ly, x = x0 + lx;
+        reinterpret_cast<float4*>(Pv)[idx] = (x >= 0 && x < W && y >= 0 && y < H)
+            ? *reinterpret_cast<const float4*>(P + ((size_t)y * W + x) * C + q * 4) : zero4;
+    }
+    for (int idx = threadIdx.x; idx < (L + 2) * C4; idx += kAccThreads) {
+        const int row = idx / C4 - 1, q = idx % C4;
+        reinterpret_cast<float4*>(Lv)[idx] = (row >= 0 && row < L) ? *reinterpret_cast<const float4*>(Ln + (size_t)row * C + q * 4) : zero4;
+    }
+    for (int idx = threadIdx.x; idx < (TP + (L + 2) * C) / 2; idx += kAccThreads) reinterpret_cast<float4*>(Pa)[idx] = zero4;
+    __syncthreads();
+    if (a.dbg & 8) {}
+    else if (k == 0) tile_accum_records<C, 0>(a, sg, x0, y0, Pv, Pa, Lv, La, tab);
+    else if (k == 1) tile_accum_records<C, 1>(a, sg, x0, y0, Pv, Pa, Lv, La, tab);
+    else tile_accum_records<C, 2>(a, sg, x0, y0, Pv, Pa, Lv, La, tab);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < TP; idx += kAccThreads) {
+        const float v = (float)Pa[idx];
+        if (v != 0.f && !(a.dbg & 2)) {
+            const int cell = idx / C, c = idx - cell * C, ly = cell / T1, lx = cell - ly * T1, y = y0 + ly, x = x0 + lx;
+            if (x >= 0 && x < W && y >= 0 && y < H) atomicAdd(gP + ((size_t)y * W + x) * C + c, v);
+        }
+    }
+    for (int idx = threadIdx.x; idx < L * C; idx += kAccThreads) {
+        const float v = (float)La[C + idx];
+        if (v != 0.f && !(a.dbg & 1)) atomicAdd(gL + idx, v);
+    }
+}
+// doubles: tile + line accumulators; floats: staged values; per-wave tap tables (64 records x 3 float4)
+static size_t tile_accum_lds(int C, int Lmax) {
+    const size_t cells = (size_t)(kBinTile + 1) * (kBinTile + 1) * C + (size_t)(Lmax + 2) * C;
+    return cells * 8 + cells * 4 + (size_t)(kAccThreads / 64) * 64 * 3 * 16;
 }
 
 // ---- layer 2 (3 outputs): VALU ------------------------------------------------------------------------------------------
@@ -556,7 +838,7 @@ __global__ __launch_bounds__(256) void k_relayout_add(const float* __restrict__ 
 
 // Activation / gradient rows of the backward pass. Buffers whose lifetimes do not overlap (or that are rewritten
 // element-in-place by the same thread) share storage: g1 over h1, g0 over h0, gx over xpe, gf over feat32, gX over x144.
-struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, total; };
+struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, hist, tile_start, nseg, segs, recs, total; unsigned seg_cap; };
 // split of a [rows] x (M<=128) x N weight-gradient GEMM into row chunks: ~768 workgroups, chunk a multiple of 32 rows
 struct TnPlan { int chunk_rows, chunks, ng, ldp; };
 static TnPlan tn_plan(int64_t rows, int N) {
@@ -582,7 +864,7 @@ static size_t tn_part_bytes(int64_t rows) {
     return m;
 }
 static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
-static BwdCarve bwd_carve(int64_t rows) {
+static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_tiles) {
     BwdCarve c;
     size_t o = 0;
     const size_t R = (size_t)rows;
@@ -593,6 +875,14 @@ static BwdCarve bwd_carve(int64_t rows) {
     c.go = o; o = al256(o + R * 16);
     c.xpe = o; o = al256(o + R * 352 * 4);
     c.part = o; o = al256(o + tn_part_bytes(rows));
+    // tile-binned density scatter: worst case one record per sample and plane
+    const size_t cap = (size_t)n_rays * (size_t)n_samples;
+    c.seg_cap = (unsigned)(3 * cap / kBinSeg + (size_t)n_tiles + 1);
+    c.hist = o; o = al256(o + (size_t)n_tiles * kBinCopies * 4);
+    c.tile_start = o; o = al256(o + ((size_t)n_tiles + 1) * 4);
+    c.nseg = o; o = al256(o + 4);
+    c.segs = o; o = al256(o + (size_t)c.seg_cap * 16);
+    c.recs = o; o = al256(o + 3 * cap * 16);
     c.total = o;
     return c;
 }
@@ -652,7 +942,10 @@ extern "C" int t2n_render_ctx_rows(const void* fwd_workspace, int64_t n_rays, in
     return read_counts(fwd_workspace, n_rays, n_samples, (hipStream_t)stream, counts, nullptr, rows);
 }
 
-extern "C" size_t t2n_backward_workspace_bytes(int64_t rows) { return bwd_carve(rows < 32 ? 32 : rows).total; }
+extern "C" size_t t2n_backward_workspace_bytes(const t2n_field* f, int64_t rows, int64_t n_rays, int n_samples) {
+    if (!f || n_rays <= 0 || n_samples <= 0) return 0;
+    return bwd_carve(rows < 32 ? 32 : rows, n_rays, n_samples, bin_geom(f->dev.den).total).total;
+}
 
 extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
                                    const float* jitter, const float* d_rgb, const float* d_depth, const float* d_weights,
@@ -676,7 +969,8 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     int rc = read_counts(fwd_workspace, n_rays, n_samples, s, counts, &tp, &rows);
     if (rc) return rc;
     const int64_t rows_alloc = rows < 32 ? 32 : rows;
-    const BwdCarve b = bwd_carve(rows_alloc);
+    const BinGeom geom = bin_geom(f->dev.den);
+    const BwdCarve b = bwd_carve(rows_alloc, n_rays, n_samples, geom.total);
     if (b.total > bwd_workspace_bytes) { set_error("t2n_render_backward: backward workspace %zu B < %zu B", bwd_workspace_bytes, b.total); return T2N_ERR_WORKSPACE; }
     if ((rc = ensure_grad_buffers(f))) return rc;
 
@@ -725,9 +1019,36 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         a.add_bg = (flags & T2N_FLAG_ADD_BG) ? 1 : 0;
         const size_t lds = (size_t)4 * 4 * a.npad * sizeof(float);
         const unsigned nb = (unsigned)((n_rays + 3) / 4);
+        // tile-binned scatter unless the grid's lines do not fit the LDS budget (or T2N_BWD_ATOMIC_SCATTER=1 asks for the
+        // sliding-window global-atomic path)
+        int Lmax = 0;
+        for (int k = 0; k < 3; ++k) Lmax = f->dev.den.L[k] > Lmax ? f->dev.den.L[k] : Lmax;
+        const size_t lds_acc = tile_accum_lds(16, Lmax);
+        static const bool force_atomic = getenv("T2N_BWD_ATOMIC_SCATTER") && atoi(getenv("T2N_BWD_ATOMIC_SCATTER")) != 0;
+        const bool bin = !force_atomic && lds_acc <= 160 * 1024 && (uint64_t)n_rays * n_samples * 3 < 0x7fffffffull;
+        a.gfeat = (float*)(fw + c.sigma); a.hist = (unsigned*)(bw + b.hist); a.geom = geom;
         timing_begin(f, T2N_K_BWD_MARCH, s);
-        if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true>), dim3(nb), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((k_bwd_march<false>), dim3(nb), dim3(256), lds, s, a);
+        if (!bin) {
+            if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true, false>), dim3(nb), dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((k_bwd_march<false, false>), dim3(nb), dim3(256), lds, s, a);
+        } else {
+            T2N_HIP(hipMemsetAsync(a.hist, 0, (size_t)geom.total * kBinCopies * 4, s));
+            if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true, true>), dim3(nb), dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((k_bwd_march<false, true>), dim3(nb), dim3(256), lds, s, a);
+            hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, a.hist, geom.total, (unsigned*)(bw + b.tile_start),
+                               (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap);
+            BinArgs ba;
+            ba.F = f->dev; ba.geom = geom; ba.rays = rays; ba.n_rays = n_rays; ba.ray_stride = ray_stride; ba.n_samples = n_samples;
+            ba.jitter = jitter; ba.gfeat = a.gfeat; ba.ray_app = a.ray_app; ba.cursor = a.hist; ba.recs = (float4*)(bw + b.recs);
+            if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_bin<true>), dim3(nb), dim3(256), 0, s, ba);
+            else hipLaunchKernelGGL((k_bwd_bin<false>), dim3(nb), dim3(256), 0, s, ba);
+            TileAccumArgs ta;
+            ta.S = f->dev.den; ta.G = a.gden; ta.geom = geom; ta.segs = (const int4*)(bw + b.segs);
+            ta.nseg = (const unsigned*)(bw + b.nseg); ta.recs = (const float4*)(bw + b.recs);
+            ta.dbg = getenv("T2N_DEBUG_ACCUM") ? atoi(getenv("T2N_DEBUG_ACCUM")) : 0;
+            T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
+            hipLaunchKernelGGL((k_bwd_tile_accum<16>), dim3(b.seg_cap), dim3(kAccThreads), lds_acc, s, ta);
+        }
         timing_end(f, T2N_K_BWD_MARCH, s);
         T2N_HIP(hipGetLastError());
     }

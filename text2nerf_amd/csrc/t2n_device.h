@@ -111,6 +111,15 @@ __device__ __forceinline__ Axis axis_taps(float g, int size) {
     return a;
 }
 
+// The clamped floor index of axis_taps (same arithmetic): low tap at cell i (weight 0 when i == -1), high tap at i + 1
+// (weight 0 when i == size - 1).
+__device__ __forceinline__ int axis_cell(float g, int size) {
+    const float h = (g + 1.f) / 2.f;
+    const float ix = h * (float)(size - 1);
+    const float f0 = floorf(ix);
+    return (int)fminf(fmaxf(f0, -1.f), (float)(size - 1));
+}
+
 __device__ __forceinline__ float4 f4_mul(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 f4_fma(float4 a, float s, float4 c) {
     return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));

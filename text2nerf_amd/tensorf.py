@@ -672,7 +672,7 @@ class _RenderFn(torch.autograd.Function):
             _lib.check(lib.t2n_render_ctx_rows(_lib.ptr(ctx.ws), R, ctx.N, st, C.byref(rows)), "t2n_render_ctx_rows")
             # shared grow-only scratch (geometric growth): the row count changes every iteration, and a fresh
             # multi-GB torch.empty per backward would hit hipMalloc each time
-            need = int(lib.t2n_backward_workspace_bytes(rows.value))
+            need = int(lib.t2n_backward_workspace_bytes(field._handle, rows.value, R, ctx.N))
             bws = workspace(dev, need) if _WORKSPACE.get(str(dev)) is not None and _WORKSPACE[str(dev)].numel() >= need \
                 else workspace(dev, int(need * 1.5))
             _lib.check(lib.t2n_render_backward(field._handle, _lib.ptr(rays), R, rays.shape[1], ctx.N, ctx.flags,
