@@ -672,46 +672,55 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict_
     C[(size_t)row * ldc + col] += (s0 + s1) + (s2 + s3);
 }
 
-// OUT[rows, N] = (IN[rows, K] W[K, N]) (* [ACT > 0] if ACT). One wave = 32 rows x up to 128 output columns (4 blocks);
-// rows sit on the MFMA N axis (lanes), output columns on M. ldo must be a multiple of 4 and >= round_up(N, 4).
+// OUT[rows, N] = (IN[rows, K] W[K, N]) (* [ACT > 0] if ACT). A workgroup owns one 128-column group of N: its K x 128 slab
+// of W is staged in LDS once (zero-padded), then its 4 waves walk 32-row tiles (grid-stride): rows sit on the MFMA N axis
+// (lanes), output columns on M; a lane reads its row of IN as float4 along K (two K-steps per load).
+// Requires: K <= 128, ldin % 4 == 0 with IN columns K..round_up(K,4) finite (zero-weighted), ldo % 4 == 0, ldo >= round_up(N, 4).
 __global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ IN, int ldin, const float* __restrict__ W, int ldw,
                                                  long long rows, int K, int N, const float* __restrict__ ACT, int ldact,
                                                  float* OUT, int ldo) {
-    const int lane = threadIdx.x & 63, s = lane & 31, h = lane >> 5;
-    const int NG = (N + 127) / 128;
-    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int ng = (int)(gw % NG);
-    const long long r0 = (gw / NG) * 32;
-    if (r0 >= rows) return;
-    const long long r = r0 + s;
-    const bool rok = r < rows;
-    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
-    const int K2 = (K + 1) & ~1;
-    for (int k0 = 0; k0 < K2; k0 += 2) {
-        const int k = k0 + h;
-        const bool kok = k < K;
-        const float b = (rok && kok) ? IN[r * ldin + k] : 0.f;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int n = ng * 128 + m * 32 + s;
-            const float av = (kok && n < N) ? W[(size_t)k * ldw + n] : 0.f;
-            acc[m] = mfma(av, b, acc[m]);
-        }
+    extern __shared__ __attribute__((aligned(16))) float sW[];   // [K4][128], K4 = round_up(K, 4)
+    const int lane = threadIdx.x & 63, s = lane & 31, h = lane >> 5, w = threadIdx.x >> 6;
+    const int ng = blockIdx.x;
+    const int K4 = (K + 3) & ~3;
+    for (int idx = threadIdx.x; idx < K4 * 128; idx += 256) {
+        const int k = idx >> 7, n = ng * 128 + (idx & 127);
+        sW[idx] = (k < K && n < N) ? W[(size_t)k * ldw + n] : 0.f;
     }
-    if (!rok) return;
+    __syncthreads();
+    const long long ntiles = (rows + 31) / 32;
+    for (long long tile = (long long)blockIdx.y * 4 + w; tile < ntiles; tile += (long long)gridDim.y * 4) {
+        const long long r = tile * 32 + s;
+        const bool rok = r < rows;
+        const float* __restrict__ inr = IN + (rok ? r : 0) * ldin;
+        f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+        float4 cur = *reinterpret_cast<const float4*>(inr);
+        for (int k0 = 0; k0 < K4; k0 += 4) {
+            const float4 nxt = k0 + 4 < K4 ? *reinterpret_cast<const float4*>(inr + k0 + 4) : cur;
+            const float b0 = h ? cur.y : cur.x, b1 = h ? cur.w : cur.z;
+            const float* w0 = sW + (k0 + h) * 128 + s;
+            const float* w1 = w0 + 256;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m) acc[m] = mfma(w0[m * 32], b0, acc[m]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = ng * 128 + m * 32 + 8 * g + 4 * h;
-            if (n >= ldo) continue;
-            float4 v = make_float4(acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]);
-            if (ACT) {
-                const float4 t = *reinterpret_cast<const float4*>(ACT + r * ldact + n);
-                v.x = t.x > 0.f ? v.x : 0.f; v.y = t.y > 0.f ? v.y : 0.f; v.z = t.z > 0.f ? v.z : 0.f; v.w = t.w > 0.f ? v.w : 0.f;
-            }
-            *reinterpret_cast<float4*>(OUT + r * ldo + n) = v;
+            for (int m = 0; m < 4; ++m) acc[m] = mfma(w1[m * 32], b1, acc[m]);
+            cur = nxt;
         }
+        if (!rok) continue;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = ng * 128 + m * 32 + 8 * g + 4 * h;
+                if (n >= ldo) continue;
+                float4 v = make_float4(acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]);
+                if (ACT) {
+                    const float4 t = *reinterpret_cast<const float4*>(ACT + r * ldact + n);
+                    v.x = t.x > 0.f ? v.x : 0.f; v.y = t.y > 0.f ? v.y : 0.f; v.z = t.z > 0.f ? v.z : 0.f; v.w = t.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(OUT + r * ldo + n) = v;
+            }
+    }
 }
 
 // db[n] += sum_rows G[rows, ld]   (N <= 128; 256 threads: two row phases per block, `chunk` rows per block)
@@ -910,8 +919,15 @@ static void launch_gemm_tn(const float* A, int lda, const float* B, int ldb, lon
 }
 static void launch_gemm_nn(const float* IN, int ldin, const float* W, int ldw, long long rows, int K, int N, const float* ACT,
                            int ldact, float* OUT, int ldo, hipStream_t s) {
-    const long long waves = (long long)((N + 127) / 128) * ((rows + 31) / 32);
-    hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, IN, ldin, W, ldw, rows, K, N, ACT, ldact, OUT, ldo);
+    const int ng = (N + 127) / 128;
+    const long long tiles4 = ((rows + 31) / 32 + 3) / 4;
+    long long by = 768 / ng;                       // ~3 workgroups per CU in flight, each staging W once
+    if (by > tiles4) by = tiles4;
+    if (by < 1) by = 1;
+    const size_t lds = (size_t)((K + 3) & ~3) * 128 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_gemm_nn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 4); attr_set = true; }
+    hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)ng, (unsigned)by), dim3(256), lds, s, IN, ldin, W, ldw, rows, K, N, ACT, ldact, OUT, ldo);
 }
 
 }  // namespace t2n
