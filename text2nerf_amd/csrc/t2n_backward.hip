@@ -472,10 +472,15 @@ __global__ __launch_bounds__(256) void k_bwd_bin(const BinArgs a) {
 constexpr int kAccThreads = 512;
 struct TileAccumArgs {
     FactorSet S; GradSet G; BinGeom geom; const int4* segs; const unsigned* nseg; const float4* recs; int dbg;
+    // appearance: rec.w holds the activation row (int bits) and the gradient of channel c of pair K is gx[row * gx_ld + K * CT + c];
+    // density (gx == NULL): rec.w is dL/dfeature itself, the same for all channels
+    const float* gx; int gx_ld;
 };
-template <int C, int K>
-__device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const int4 sg, int x0, int y0, const float* Pv, double* Pa,
-                                                   const float* Lv, double* La, float4* tab) {
+// CT = channels of the factor set (texel stride); a workgroup covers the 16 channels [coff, coff + 16).
+template <int CT, int K>
+__device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const int4 sg, int x0, int y0, int coff, const float* Pv,
+                                                   double* Pa, const float* Lv, double* La, float4* tab) {
+    constexpr int C = 16;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, ch = lane & 15, sub = lane >> 4;
     constexpr int NW = kAccThreads / 64;
     const int W = a.S.W[K], H = a.S.H[K], L = a.S.L[K];
@@ -489,8 +494,8 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
         const Axis ax = axis_taps(gx, W), ay = axis_taps(gy, H), al = axis_taps(gv, L);
         const int lx = axis_cell(gx, W) - x0, ly = axis_cell(gy, H) - y0, fl = axis_cell(gv, L);
         const bool live = b0 + lane < re;
-        const float g = live ? p.w : 0.f;
-        T[lane * 3 + 0] = make_float4(__int_as_float(live ? (ly * (kBinTile + 1) + lx) * C : 0), __int_as_float(live ? (fl + 1) * C : 0), g, 0.f);
+        T[lane * 3 + 0] = make_float4(__int_as_float(live ? (ly * (kBinTile + 1) + lx) * C : 0), __int_as_float(live ? (fl + 1) * C : 0),
+                                      live ? p.w : 0.f, live ? 1.f : 0.f);
         T[lane * 3 + 1] = make_float4(ay.w0 * ax.w0, ay.w0 * ax.w1, ay.w1 * ax.w0, ay.w1 * ax.w1);
         T[lane * 3 + 2] = make_float4(al.w0, al.w1, 0.f, 0.f);
         if (b0 + 64 + lane < re) p = a.recs[b0 + 64 + lane];   // next batch in flight while this one is accumulated
@@ -502,29 +507,28 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
             const float4 t0 = T[ri * 3], wp = T[ri * 3 + 1], wl = T[ri * 3 + 2];
             const int c00 = __float_as_int(t0.x) + ch, c01 = c00 + C, c10 = c00 + (kBinTile + 1) * C, c11 = c10 + C;
             const int r0 = __float_as_int(t0.y) + ch, r1 = r0 + C;
-            const float g2 = t0.z;
+            float g2 = t0.z;
+            if (a.gx) g2 = t0.w != 0.f ? a.gx[(size_t)__float_as_int(t0.z) * a.gx_ld + K * CT + coff + ch] : 0.f;
             if (g2 != 0.f) {
-#pragma unroll
-                for (int cg = 0; cg < C / 16; ++cg) {
-                    const int o = cg * 16;
-                    float pv = Pv[c00 + o] * wp.x;
-                    pv = fmaf(Pv[c01 + o], wp.y, pv); pv = fmaf(Pv[c10 + o], wp.z, pv); pv = fmaf(Pv[c11 + o], wp.w, pv);
-                    const float lv = fmaf(Lv[r1 + o], wl.y, Lv[r0 + o] * wl.x);
-                    const float gp = g2 * lv, gl = g2 * pv;
-                    atomicAdd(&Pa[c00 + o], (double)(gp * wp.x)); atomicAdd(&Pa[c01 + o], (double)(gp * wp.y));
-                    atomicAdd(&Pa[c10 + o], (double)(gp * wp.z)); atomicAdd(&Pa[c11 + o], (double)(gp * wp.w));
-                    atomicAdd(&La[r0 + o], (double)(gl * wl.x)); atomicAdd(&La[r1 + o], (double)(gl * wl.y));
-                }
+                float pv = Pv[c00] * wp.x;
+                pv = fmaf(Pv[c01], wp.y, pv); pv = fmaf(Pv[c10], wp.z, pv); pv = fmaf(Pv[c11], wp.w, pv);
+                const float lv = fmaf(Lv[r1], wl.y, Lv[r0] * wl.x);
+                const float gp = g2 * lv, gl = g2 * pv;
+                atomicAdd(&Pa[c00], (double)(gp * wp.x)); atomicAdd(&Pa[c01], (double)(gp * wp.y));
+                atomicAdd(&Pa[c10], (double)(gp * wp.z)); atomicAdd(&Pa[c11], (double)(gp * wp.w));
+                atomicAdd(&La[r0], (double)(gl * wl.x)); atomicAdd(&La[r1], (double)(gl * wl.y));
             }
         }
         wave_lds_sync();
     }
 }
-template <int C>
+// grid: (segments, CT / 16)
+template <int CT>
 __global__ __launch_bounds__(kAccThreads) void k_bwd_tile_accum(const TileAccumArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (blockIdx.x >= *a.nseg) return;
     const int4 sg = a.segs[blockIdx.x];
+    const int coff = blockIdx.y * 16;
     const int k = sg.x >= a.geom.before[2] ? 2 : (sg.x >= a.geom.before[1] ? 1 : 0);
     const int tile = sg.x - a.geom.before[k];
     int W, H, L, tw; const float* __restrict__ P; const float* __restrict__ Ln; float* gP; float* gL;
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(kAccThreads) void k_bwd_tile_accum(const TileAccumA
     else if (k == 1) { W = a.S.W[1]; H = a.S.H[1]; L = a.S.L[1]; tw = a.geom.tw[1]; P = a.S.plane[1]; Ln = a.S.line[1]; gP = a.G.plane[1]; gL = a.G.line[1]; }
     else { W = a.S.W[2]; H = a.S.H[2]; L = a.S.L[2]; tw = a.geom.tw[2]; P = a.S.plane[2]; Ln = a.S.line[2]; gP = a.G.plane[2]; gL = a.G.line[2]; }
     const int x0 = (tile % tw) * kBinTile - 1, y0 = (tile / tw) * kBinTile - 1;   // texel of local (0, 0)
-    constexpr int T1 = kBinTile + 1, TP = T1 * T1 * C, C4 = C / 4;
+    constexpr int C = 16, T1 = kBinTile + 1, TP = T1 * T1 * C, C4 = C / 4;
     double* Pa = reinterpret_cast<double*>(smem);
     double* La = Pa + TP;
     float* Pv = reinterpret_cast<float*>(La + (size_t)(L + 2) * C);
@@ -543,29 +547,73 @@ __global__ __launch_bounds__(kAccThreads) void k_bwd_tile_accum(const TileAccumA
     for (int idx = threadIdx.x; idx < TP / 4; idx += kAccThreads) {
         const int cell = idx / C4, q = idx - cell * C4, ly = cell / T1, lx = cell - ly * T1, y = y0 + ly, x = x0 + lx;
         reinterpret_cast<float4*>(Pv)[idx] = (x >= 0 && x < W && y >= 0 && y < H)
-            ? *reinterpret_cast<const float4*>(P + ((size_t)y * W + x) * C + q * 4) : zero4;
+            ? *reinterpret_cast<const float4*>(P + ((size_t)y * W + x) * CT + coff + q * 4) : zero4;
     }
     for (int idx = threadIdx.x; idx < (L + 2) * C4; idx += kAccThreads) {
         const int row = idx / C4 - 1, q = idx % C4;
-        reinterpret_cast<float4*>(Lv)[idx] = (row >= 0 && row < L) ? *reinterpret_cast<const float4*>(Ln + (size_t)row * C + q * 4) : zero4;
+        reinterpret_cast<float4*>(Lv)[idx] = (row >= 0 && row < L) ? *reinterpret_cast<const float4*>(Ln + (size_t)row * CT + coff + q * 4) : zero4;
     }
     for (int idx = threadIdx.x; idx < (TP + (L + 2) * C) / 2; idx += kAccThreads) reinterpret_cast<float4*>(Pa)[idx] = zero4;
     __syncthreads();
     if (a.dbg & 8) {}
-    else if (k == 0) tile_accum_records<C, 0>(a, sg, x0, y0, Pv, Pa, Lv, La, tab);
-    else if (k == 1) tile_accum_records<C, 1>(a, sg, x0, y0, Pv, Pa, Lv, La, tab);
-    else tile_accum_records<C, 2>(a, sg, x0, y0, Pv, Pa, Lv, La, tab);
+    else if (k == 0) tile_accum_records<CT, 0>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
+    else if (k == 1) tile_accum_records<CT, 1>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
+    else tile_accum_records<CT, 2>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
     __syncthreads();
     for (int idx = threadIdx.x; idx < TP; idx += kAccThreads) {
         const float v = (float)Pa[idx];
         if (v != 0.f && !(a.dbg & 2)) {
             const int cell = idx / C, c = idx - cell * C, ly = cell / T1, lx = cell - ly * T1, y = y0 + ly, x = x0 + lx;
-            if (x >= 0 && x < W && y >= 0 && y < H) atomicAdd(gP + ((size_t)y * W + x) * C + c, v);
+            if (x >= 0 && x < W && y >= 0 && y < H) atomicAdd(gP + ((size_t)y * W + x) * CT + coff + c, v);
         }
     }
     for (int idx = threadIdx.x; idx < L * C; idx += kAccThreads) {
         const float v = (float)La[C + idx];
-        if (v != 0.f && !(a.dbg & 1)) atomicAdd(gL + idx, v);
+        if (v != 0.f && !(a.dbg & 1)) atomicAdd(gL + (size_t)(idx / C) * CT + coff + (idx % C), v);
+    }
+}
+
+// Appearance records: one per appearance-list entry and plane. PASS 0 counts, PASS 1 writes (same lane -> entry -> copy map).
+// Row r of the activation buffers <-> list entry: tile r / 32 belongs to sub-list l (tp.t[l] <= tile < tp.t[l + 1]).
+struct AppBinArgs {
+    FactorSet S; BinGeom geom; const float4* app_pos; const unsigned* counters; unsigned list_cap; TilePrefix tp; long long rows;
+    unsigned* hist; float4* recs;
+};
+template <int PASS>
+__global__ __launch_bounds__(256) void k_app_bin(const AppBinArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long row = wv * 64 + lane;
+    if (wv * 64 >= a.rows) return;
+    int key[3] = {-1, -1, -1};
+    float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < a.rows) {
+        const unsigned tile = (unsigned)(row >> 5);
+        int l = 0;
+#pragma unroll
+        for (int q = 1; q < kLists; ++q) l += (a.tp.t[q] <= tile) ? 1 : 0;
+        const unsigned slot = (unsigned)(row - (long long)a.tp.t[l] * 32);
+        unsigned cnt = a.counters[l * kCounterStride];
+        if (cnt > a.list_cap) cnt = a.list_cap;
+        if (slot < cnt) {
+            const float4 p = a.app_pos[(size_t)l * a.list_cap + slot];
+            rec = make_float4(p.x, p.y, p.z, __int_as_float((int)row));
+            bin_keys(a.S, a.geom, p.x, p.y, p.z, key);
+        }
+    }
+    const unsigned copy = (unsigned)wv & (kBinCopies - 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        bool leader; int runlen, ll;
+        run_leader(key[k], lane, leader, runlen, ll);
+        if (PASS == 0) {
+            if (leader && key[k] >= 0) atomicAdd(&a.hist[(unsigned)key[k] * kBinCopies + copy], (unsigned)runlen);
+        } else {
+            unsigned pos = 0;
+            if (leader && key[k] >= 0) pos = atomicAdd(&a.hist[(unsigned)key[k] * kBinCopies + copy], (unsigned)runlen);
+            pos = __shfl(pos, ll) + (unsigned)(lane - ll);
+            if (key[k] >= 0) a.recs[pos] = rec;
+        }
     }
 }
 // doubles: tile + line accumulators; floats: staged values; per-wave tap tables (64 records x 3 float4)
@@ -847,7 +895,7 @@ __global__ __launch_bounds__(256) void k_relayout_add(const float* __restrict__ 
 
 // Activation / gradient rows of the backward pass. Buffers whose lifetimes do not overlap (or that are rewritten
 // element-in-place by the same thread) share storage: g1 over h1, g0 over h0, gx over xpe, gf over feat32, gX over x144.
-struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, hist, tile_start, nseg, segs, recs, total; unsigned seg_cap; };
+struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, hist, tile_start, nseg, segs, recs, a_hist, a_tile_start, a_nseg, a_segs, a_recs, total; unsigned seg_cap, a_seg_cap; };
 // split of a [rows] x (M<=128) x N weight-gradient GEMM into row chunks: ~768 workgroups, chunk a multiple of 32 rows
 struct TnPlan { int chunk_rows, chunks, ng, ldp; };
 static TnPlan tn_plan(int64_t rows, int N) {
@@ -892,6 +940,13 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
     c.nseg = o; o = al256(o + 4);
     c.segs = o; o = al256(o + (size_t)c.seg_cap * 16);
     c.recs = o; o = al256(o + 3 * cap * 16);
+    // the same for the appearance samples (one record per activation row and plane)
+    c.a_seg_cap = (unsigned)(3 * R / kBinSeg + (size_t)n_tiles + 1);
+    c.a_hist = o; o = al256(o + (size_t)n_tiles * kBinCopies * 4);
+    c.a_tile_start = o; o = al256(o + ((size_t)n_tiles + 1) * 4);
+    c.a_nseg = o; o = al256(o + 4);
+    c.a_segs = o; o = al256(o + (size_t)c.a_seg_cap * 16);
+    c.a_recs = o; o = al256(o + 3 * R * 16);
     c.total = o;
     return c;
 }
@@ -1024,6 +1079,8 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     timing_end(f, T2N_K_BWD_MLP, s);
 
     // 2. per-ray backward + density scatter
+    bool bin = false;
+    size_t lds_bin = 0;
     {
         BwdMarchArgs a;
         a.F = f->dev;
@@ -1041,7 +1098,8 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         for (int k = 0; k < 3; ++k) Lmax = f->dev.den.L[k] > Lmax ? f->dev.den.L[k] : Lmax;
         const size_t lds_acc = tile_accum_lds(16, Lmax);
         static const bool force_atomic = getenv("T2N_BWD_ATOMIC_SCATTER") && atoi(getenv("T2N_BWD_ATOMIC_SCATTER")) != 0;
-        const bool bin = !force_atomic && lds_acc <= 160 * 1024 && (uint64_t)n_rays * n_samples * 3 < 0x7fffffffull;
+        bin = !force_atomic && lds_acc <= 160 * 1024 && (uint64_t)n_rays * n_samples * 3 < 0x7fffffffull;
+        lds_bin = lds_acc;
         a.gfeat = (float*)(fw + c.sigma); a.hist = (unsigned*)(bw + b.hist); a.geom = geom;
         timing_begin(f, T2N_K_BWD_MARCH, s);
         if (!bin) {
@@ -1062,8 +1120,9 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             ta.S = f->dev.den; ta.G = a.gden; ta.geom = geom; ta.segs = (const int4*)(bw + b.segs);
             ta.nseg = (const unsigned*)(bw + b.nseg); ta.recs = (const float4*)(bw + b.recs);
             ta.dbg = getenv("T2N_DEBUG_ACCUM") ? atoi(getenv("T2N_DEBUG_ACCUM")) : 0;
+            ta.gx = nullptr; ta.gx_ld = 0;
             T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
-            hipLaunchKernelGGL((k_bwd_tile_accum<16>), dim3(b.seg_cap), dim3(kAccThreads), lds_acc, s, ta);
+            hipLaunchKernelGGL((k_bwd_tile_accum<16>), dim3(b.seg_cap, 1), dim3(kAccThreads), lds_acc, s, ta);
         }
         timing_end(f, T2N_K_BWD_MARCH, s);
         T2N_HIP(hipGetLastError());
@@ -1093,11 +1152,30 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         sa.F = f->dev;
         for (int k = 0; k < 3; ++k) { sa.gapp.plane[k] = f->gbuf_app_plane[k]; sa.gapp.line[k] = f->gbuf_app_line[k]; }
         sa.app_pos = app_pos; sa.counters = counters; sa.list_cap = c.list_cap; sa.gxapp = gxapp;
-        unsigned blocks = (unsigned)((rows / 32 + 3) / 4);
-        if (blocks > 2048) blocks = 2048;
-        if (blocks == 0) blocks = 1;
         timing_begin(f, T2N_K_BWD_SCATTER, s);
-        hipLaunchKernelGGL(k_bwd_app_scatter, dim3(blocks), dim3(256), 0, s, sa);
+        if (bin && f->dev.app.C == 48) {
+            // tile-binned: count -> scan -> write records -> LDS accumulate, 16 channels per workgroup
+            AppBinArgs ab;
+            ab.S = f->dev.app; ab.geom = bin_geom(f->dev.app); ab.app_pos = app_pos; ab.counters = counters; ab.list_cap = c.list_cap;
+            ab.tp = tp; ab.rows = rows; ab.hist = (unsigned*)(bw + b.a_hist); ab.recs = (float4*)(bw + b.a_recs);
+            T2N_HIP(hipMemsetAsync(ab.hist, 0, (size_t)ab.geom.total * kBinCopies * 4, s));
+            const unsigned nbk = (unsigned)((rows + 255) / 256);
+            hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, s, ab);
+            hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, ab.hist, ab.geom.total, (unsigned*)(bw + b.a_tile_start),
+                               (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg), b.a_seg_cap);
+            hipLaunchKernelGGL((k_app_bin<1>), dim3(nbk), dim3(256), 0, s, ab);
+            TileAccumArgs ta;
+            ta.S = f->dev.app; ta.G = sa.gapp; ta.geom = ab.geom; ta.segs = (const int4*)(bw + b.a_segs);
+            ta.nseg = (const unsigned*)(bw + b.a_nseg); ta.recs = (const float4*)(bw + b.a_recs);
+            ta.dbg = 0; ta.gx = gxapp; ta.gx_ld = 144;
+            T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin));
+            hipLaunchKernelGGL((k_bwd_tile_accum<48>), dim3(b.a_seg_cap, 3), dim3(kAccThreads), lds_bin, s, ta);
+        } else {
+            unsigned blocks = (unsigned)((rows / 32 + 3) / 4);
+            if (blocks > 2048) blocks = 2048;
+            if (blocks == 0) blocks = 1;
+            hipLaunchKernelGGL(k_bwd_app_scatter, dim3(blocks), dim3(256), 0, s, sa);
+        }
         timing_end(f, T2N_K_BWD_SCATTER, s);
         T2N_HIP(hipGetLastError());
     }
