@@ -87,9 +87,13 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0):
                       f"oracle_c (plain C, OpenMP {cores} threads), {dt:.1f} s"}
 
 
-def train_bench(dev, iters=20, warmup=3, fused_optim=False):
+def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None):
     """C3-shaped optimisation step (text2nerf_main.py:547-601): 16 384 random rays of 9 small-baseline 512x512 views,
-    N=259, is_train, MSE(rgb)+0.005 MSE(depth)+1e3 transmittance+TV(density 0.1, app 0.01), Adam(0.02/1e-3)."""
+    N=259, is_train, MSE(rgb)+0.005 MSE(depth)+1e3 transmittance+TV(density 0.1, app 0.01), Adam(0.02/1e-3).
+    With `dist` (world > 1): data-parallel — the SAME 16 384-ray batch is split into equal shards (strong scaling), local
+    forward/backward, one flat gradient all-reduce (text2nerf_amd.parallel.allreduce_gradients), identical optimiser step."""
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
     from text2nerf_amd import OctreeRender_trilinear_fast, synth
     from text2nerf_amd.losses import TVLoss, TransMittanceLoss_mask
     field, params, aabb = build_field(dev)
@@ -118,10 +122,18 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False):
     batch = 16384
     perm = torch.from_numpy(np.random.permutation(allrays.shape[0]))
 
+    if dist is not None:
+        from text2nerf_amd.parallel import allreduce_gradients, broadcast_parameters, shard_batch
+        broadcast_parameters(field.parameters())
+        all_params = [p for p in field.parameters() if p.requires_grad]
+        lo, hi = shard_batch(batch, world, rank)
+
     def it(k):
         idx = perm[(k * batch) % (perm.numel() - batch):][:batch]
+        if dist is not None:
+            idx = idx[lo:hi]
         rays, rgb_t, dep_t = allrays[idx], allrgb[idx].to(dev), alldepth[idx].to(dev)
-        rgb, _, depth, w, z = OctreeRender_trilinear_fast(rays, field, chunk=batch, N_samples=n_samples, white_bg=True,
+        rgb, _, depth, w, z = OctreeRender_trilinear_fast(rays, field, chunk=max(int(rays.shape[0]), 1), N_samples=n_samples, white_bg=True,
                                                           ndc_ray=False, device=dev, is_train=True)
         loss = torch.mean((rgb - rgb_t) ** 2) + 0.005 * torch.mean((depth - dep_t) ** 2)
         loss = loss + 1e3 * tl(w, (z - dep_t[:, None] + 0.1) < 0)
@@ -129,6 +141,8 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False):
             loss = loss + field.TV_loss_density(tv) * 0.1 + field.TV_loss_app(tv) * 0.01
         opt.zero_grad()
         loss.backward()
+        if dist is not None:
+            allreduce_gradients(all_params, average=True)
         if fused_optim:
             opt.step(tv=[(field.density_plane, 0.1), (field.app_plane, 0.01)])
         else:
@@ -137,12 +151,24 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False):
 
     for k in range(warmup):
         it(k)
+    if dist is not None:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(iters):
         loss = it(warmup + k)
+    if dist is not None:
+        dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        return {"train_dp_iters_per_s": iters / dt, "train_dp_ms_per_iter": dt / iters * 1e3,
+                "train_dp_step": f"data-parallel x{world}: {batch} rays split into {hi - lo}/GPU (strong scaling), one flat "
+                                 f"{sum(p.numel() for p in all_params) * 4 / 1e6:.1f} MB gradient all-reduce, "
+                                 f"{'fused TV+Adam' if fused_optim else 'torch TV+Adam'}, loss {float(loss.detach()):.4f}"}
     if fused_optim:
         return {"train_iters_per_s_fused_optim": iters / dt, "train_ms_per_iter_fused_optim": dt / iters * 1e3}
     return {"train_iters_per_s": iters / dt, "train_ms_per_iter": dt / iters * 1e3, "train_iters": iters,
@@ -170,13 +196,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.set_num_threads(max(1, min(HOST_CORES // max(world, 1), 16)))
+    if os.environ.get("T2N_BENCH_SAME_DEVICE"):   # functional test of the N>1 path on a 1-GPU box (with T2N_BENCH_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("T2N_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from text2nerf_amd import generate_rays, synth
     from text2nerf_amd.parallel import all_gather_tiles
@@ -220,6 +252,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    dp = {}
+    if dist is not None and not args.no_train:   # every rank takes part in the data-parallel train step
+        try:
+            dp = train_bench(dev, fused_optim=True, dist=dist)
+        except Exception as e:  # noqa: BLE001 - the render line must still be printed
+            dp = {"train_dp_error": repr(e)[:300]}
     if rank == 0:
         V, A = st["evaluated"], st["appearance"]
         ms_step = dt / args.steps * 1e3
@@ -276,6 +314,7 @@ def main():
                                               (ms_step * 1e-3) / 1e9) / HBM_PEAK_GBS},
             "roofline": roof,
         }
+        out["config"].update(dp)
         if world == 1 and not args.no_train:
             del rays
             out["config"].update(train_bench(dev))

@@ -140,3 +140,58 @@ def test_ray_tile_sharding_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"OK {r}" in o, o
+
+
+DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["T2N_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from text2nerf_amd.parallel import shard_batch, allreduce_gradients, broadcast_parameters
+from text2nerf_amd import synth
+from oracle import oracle_torch as O          # CPU stand-in for the HIP forward/backward: the test checks the DP algebra
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+grid, aabb = [24, 20, 16], [[-8.0, -6.0, -7.0], [8.0, 7.0, 6.5]]
+cfg = O.FieldConfig(aabb=aabb, grid_size=grid)
+P = O.params_from_numpy(synth.make_field_params(11 + rank, grid, density_scale=0.9, aabb=aabb))   # ranks start DIFFERENT
+names = sorted(P.keys())
+params = [P[k].requires_grad_(True) for k in names]
+broadcast_parameters(params, src=0)
+ref = O.params_from_numpy(synth.make_field_params(11, grid, density_scale=0.9, aabb=aabb))
+assert all(torch.equal(P[k].detach(), ref[k]) for k in names), "broadcast must reproduce rank 0's parameters"
+rays = torch.from_numpy(synth.frame_rays_np(8, 8, c2w=synth.look_pose(0.3, -0.1, (0.2, 0.1, -1.0))))   # 64-ray batch
+g = torch.Generator().manual_seed(3)
+target = torch.rand(rays.shape[0], 3, generator=g)
+def loss_of(p, lo, hi):
+    rgb, depth, _, _ = O.forward(cfg, p, rays[lo:hi])
+    return torch.mean((rgb - target[lo:hi]) ** 2) + 0.005 * torch.mean(depth ** 2)
+lo, hi = shard_batch(rays.shape[0], world, rank)
+loss_of(P, lo, hi).backward()
+allreduce_gradients(params, average=True)
+# single-process reference: the whole batch
+refp = [ref[k].requires_grad_(True) for k in names]
+loss_of(ref, 0, rays.shape[0]).backward()
+for k, a, b in zip(names, params, refp):
+    gb = b.grad if b.grad is not None else torch.zeros_like(b)
+    tol = 1e-6 * float(gb.abs().max()) + 1e-12
+    assert float((a.grad - gb).abs().max()) <= tol, (k, float((a.grad - gb).abs().max()), tol)
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+def test_data_parallel_gradient_allreduce_gloo_world2(tmp_path):
+    """SURVEY 8(e) train partitioning: shard the batch, local backward, one flat all-reduce == the full-batch gradient."""
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   T2N_ROOT=ROOT, OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"OK {r}" in o, o

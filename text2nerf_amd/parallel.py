@@ -50,3 +50,52 @@ def render_sharded(rays: torch.Tensor, render_fn, group=None):
         parts.append(full[r, : h - l])
     out = torch.cat(parts, 0)
     return out[:, :3].contiguous(), out[:, 3].contiguous()
+
+
+# ---- data-parallel training (SURVEY.md §8 e, C5) -----------------------------------------------------------------------------
+# The 16 384-ray batch of text2nerf_main.py:547-601 is split into equal contiguous shards (one per GPU); every rank runs the
+# HIP forward/backward on its shard, then ONE all-reduce sums the whole 17.4 M-element fp32 gradient (69.6 MB) as a single
+# flat message — on point-to-point xGMI the per-link bandwidth, not the launch count, is the cost, so one large
+# collective beats per-tensor ones (19 tensors, most of them tiny). The TV regulariser does not depend on the rays: its
+# gradient is identical on every rank and is added AFTER the all-reduce (or by the fused TVAdam step), not reduced.
+
+def shard_batch(n: int, world: int, rank: int):
+    """Equal-sized contiguous shard [lo, hi) of an n-ray batch (n is truncated to a multiple of world, like DistributedSampler
+    with drop_last): equal shards keep mean-reduced losses consistent with the single-GPU batch mean."""
+    per = n // world
+    return rank * per, (rank + 1) * per
+
+
+def allreduce_gradients(params, group=None, average=True):
+    """Sum (or average) the .grad of `params` over the ranks with one flat all-reduce. Parameters whose grad is None are
+    treated as zero on this rank (every rank must pass the same parameter list)."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    world = dist.get_world_size(group)
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat.div_(world)
+    off = 0
+    for p in params:
+        n = p.grad.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+
+
+def broadcast_parameters(params, src=0, group=None):
+    """Make every rank start from rank `src`'s parameters (one flat broadcast)."""
+    params = list(params)
+    if not params:
+        return
+    flat = torch.cat([p.data.reshape(-1) for p in params])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.data.copy_(flat[off:off + n].view_as(p.data))
+        off += n
