@@ -184,6 +184,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="S1-soft")
     ap.add_argument("--weights", type=int, default=0, help="1: also materialise weights/z_vals [R,N] like the reference")
+    ap.add_argument("--factor-storage", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: BASELINE configs[4] storage mode (render == fp32 render of the bf16-rounded factor tensors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the C3-shaped train-step timing (iters/s)")
     args = ap.parse_args()
@@ -216,6 +218,7 @@ def main():
     H = W = 800
     field, params, aabb = build_field(dev, scene=args.scene, seed=0 if args.scene.startswith("S1") else 1)
     field.materialize_weights = bool(args.weights)
+    field.factor_storage = args.factor_storage
     N = field.nSamples
     poses = synth.local_fixed_like_poses(max(world, 9))
     pose = poses[rank % len(poses)] if world > 1 else np.eye(4, dtype=np.float32)
@@ -297,7 +300,8 @@ def main():
             "metric": "ray-samples/s (render) + iters/s (train), 300^3 VM-split, 800x800",
             "value": nominal, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" + (" (basis/MLP products as f16x2-split MFMA, fp32 accumulate)" if split else ""),
+            "dtype": "f32" + (" (basis/MLP products as f16x2-split MFMA, fp32 accumulate)" if split else "") +
+                     ("; factor tensors stored as bf16" if args.factor_storage == "bf16" else ""),
             "data": "synthetic",
             "config": {"workload": f"C2: TensorVMSplit 300^3, 800x800 view/GPU, {N} samples/ray, render_only, scene "
                                    f"{args.scene} seed 0, white_bg, weights/z_vals materialised: {bool(args.weights)}",
@@ -315,6 +319,18 @@ def main():
             "roofline": roof,
         }
         out["config"].update(dp)
+        if world == 1 and args.factor_storage == "fp32":
+            # the same frame with bf16 factor storage (configs[4] mode; not the headline value: it renders the ROUNDED field)
+            field.factor_storage = "bf16"
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            out["config"]["bf16_factor_storage_ms_per_step"] = (time.perf_counter() - t0) / args.steps * 1e3
+            field.factor_storage = "fp32"
         if world == 1 and not args.no_train:
             del rays
             out["config"].update(train_bench(dev))

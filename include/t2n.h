@@ -117,6 +117,13 @@ int t2n_field_destroy(t2n_field* f);
 int t2n_field_upload(t2n_field* f, const t2n_field_params* p, t2n_stream stream);
 /* Update scalars only (step size, near/far, ...): TensorBase.update_stepSize (models/tensorBase.py:220-231). */
 int t2n_field_set_desc(t2n_field* f, const t2n_field_desc* desc);
+/* Factor storage for the forward render: 0 = fp32 (default), 1 = bf16 (BASELINE.json configs[4]). In bf16 mode
+ * t2n_field_upload rounds the 12 plane / line tensors to bf16 (nearest-even) and keeps two device copies: 2-byte texels for
+ * the march / shade gathers (half the bytes through L1) and the rounded values as fp32 for every other entry point, so a
+ * render equals the fp32 render of the bf16-rounded tensors BIT FOR BIT; gradients are taken at the rounded values and
+ * returned in fp32 for the caller's fp32 master copy. basis_mat / MLP stay fp32. Call before t2n_field_upload. */
+int t2n_field_set_factor_storage(t2n_field* f, int bf16);
+
 /* Arithmetic of the basis/MLP contractions (nn.Linear in the reference, models/tensoRF.py:239, tensorBase.py:94-106):
  * exact_fp32 = 0 (default): every fp32 product as three f16 MFMA products of hi/lo splits (22-bit mantissa), fp32
  * accumulation; exact_fp32 = 1: v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains (5x the matrix-core time). The backward

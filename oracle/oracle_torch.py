@@ -459,3 +459,20 @@ def filter_rays_alpha(cfg: FieldConfig, rays, n_samples):
     """filtering_rays(bbox_only=False), models/tensorBase.py:393-395."""
     pts, _, _ = sample_ray(cfg, rays[:, :3], rays[:, 3:6], n_samples, jitter=None)
     return (sample_alpha(cfg, pts.reshape(-1, 3)).view(pts.shape[:-1]) > 0).any(-1)
+
+
+# ---- bf16 factor storage (BASELINE.json configs[4]; golden G11) ------------------------------------------------------------
+FACTOR_PREFIXES = ("density_plane", "density_line", "app_plane", "app_line")
+
+
+def round_factors_bf16(params):
+    """The 12 plane / line tensors rounded to bf16 (nearest-even) and widened back to fp32; basis_mat / MLP untouched.
+    This is the field a bf16-storage render must reproduce (tests/golden/make_golden_bf16.py does the same to the
+    reference's own parameters)."""
+    out = {}
+    for k, v in params.items():
+        if k.startswith(FACTOR_PREFIXES):
+            out[k] = v.detach().to(torch.bfloat16).to(torch.float32).requires_grad_(v.requires_grad)
+        else:
+            out[k] = v
+    return out

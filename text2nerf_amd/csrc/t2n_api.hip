@@ -51,19 +51,30 @@ static void timing_flush(t2n_field* f) {
 }
 
 // [1,C,H,W] -> [H][W][C]   (lines: W == 1)
-__global__ __launch_bounds__(256) void k_relayout(const float* __restrict__ src, float* __restrict__ dst, int C, long long HW) {
+// dsth != NULL (bf16 factor storage): round to nearest-even bf16; dst gets the rounded value as fp32, dsth the 2-byte texel
+__global__ __launch_bounds__(256) void k_relayout(const float* __restrict__ src, float* __restrict__ dst, unsigned short* __restrict__ dsth,
+                                                  int C, long long HW) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= HW * C) return;
     const long long pix = t / C;
     const int c = (int)(t - pix * C);
-    dst[t] = src[(long long)c * HW + pix];
+    float v = src[(long long)c * HW + pix];
+    if (dsth) {
+        unsigned b = __float_as_uint(v);
+        if ((b & 0x7fffffffu) <= 0x7f800000u) b += 0x7fffu + ((b >> 16) & 1u);   // RNE (NaN payloads pass through truncated)
+        b &= 0xffff0000u;
+        dsth[t] = (unsigned short)(b >> 16);
+        v = __uint_as_float(b);
+    }
+    dst[t] = v;
 }
 
-static int relayout_one(const float* src, float** dst, int C, long long HW, hipStream_t s) {
+static int relayout_one(const float* src, float** dst, void** dsth, bool half, int C, long long HW, hipStream_t s) {
     if (!src) { set_error("t2n_field_upload: NULL factor tensor"); return T2N_ERR_INVALID; }
     if (!*dst) T2N_HIP(hipMalloc((void**)dst, (size_t)HW * C * sizeof(float)));
+    if (half && !*dsth) T2N_HIP(hipMalloc(dsth, (size_t)HW * C * 2 + 16));
     const long long n = HW * C;
-    hipLaunchKernelGGL(k_relayout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, *dst, C, HW);
+    hipLaunchKernelGGL(k_relayout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, *dst, half ? (unsigned short*)*dsth : nullptr, C, HW);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }
@@ -74,12 +85,15 @@ int launch_relayout(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
         const long long HW = (long long)g[mat1(k)] * g[mat0(k)];
         const long long L = g[vecm(k)];
         int rc;
-        if ((rc = relayout_one(p->density_plane[k], &f->buf_den_plane[k], f->desc.density_n_comp, HW, s))) return rc;
-        if ((rc = relayout_one(p->density_line[k], &f->buf_den_line[k], f->desc.density_n_comp, L, s))) return rc;
-        if ((rc = relayout_one(p->app_plane[k], &f->buf_app_plane[k], f->desc.app_n_comp, HW, s))) return rc;
-        if ((rc = relayout_one(p->app_line[k], &f->buf_app_line[k], f->desc.app_n_comp, L, s))) return rc;
+        const bool hf = f->factor_bf16 != 0;
+        if ((rc = relayout_one(p->density_plane[k], &f->buf_den_plane[k], &f->hbuf_den_plane[k], hf, f->desc.density_n_comp, HW, s))) return rc;
+        if ((rc = relayout_one(p->density_line[k], &f->buf_den_line[k], &f->hbuf_den_line[k], hf, f->desc.density_n_comp, L, s))) return rc;
+        if ((rc = relayout_one(p->app_plane[k], &f->buf_app_plane[k], &f->hbuf_app_plane[k], hf, f->desc.app_n_comp, HW, s))) return rc;
+        if ((rc = relayout_one(p->app_line[k], &f->buf_app_line[k], &f->hbuf_app_line[k], hf, f->desc.app_n_comp, L, s))) return rc;
         f->dev.den.plane[k] = f->buf_den_plane[k]; f->dev.den.line[k] = f->buf_den_line[k];
         f->dev.app.plane[k] = f->buf_app_plane[k]; f->dev.app.line[k] = f->buf_app_line[k];
+        f->dev.den.plane_h[k] = hf ? f->hbuf_den_plane[k] : nullptr; f->dev.den.line_h[k] = hf ? f->hbuf_den_line[k] : nullptr;
+        f->dev.app.plane_h[k] = hf ? f->hbuf_app_plane[k] : nullptr; f->dev.app.line_h[k] = hf ? f->hbuf_app_line[k] : nullptr;
     }
     return T2N_OK;
 }
@@ -219,6 +233,10 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
         if (f->buf_den_line[k]) (void)hipFree(f->buf_den_line[k]);
         if (f->buf_app_plane[k]) (void)hipFree(f->buf_app_plane[k]);
         if (f->buf_app_line[k]) (void)hipFree(f->buf_app_line[k]);
+        if (f->hbuf_den_plane[k]) (void)hipFree(f->hbuf_den_plane[k]);
+        if (f->hbuf_den_line[k]) (void)hipFree(f->hbuf_den_line[k]);
+        if (f->hbuf_app_plane[k]) (void)hipFree(f->hbuf_app_plane[k]);
+        if (f->hbuf_app_line[k]) (void)hipFree(f->hbuf_app_line[k]);
         if (f->gbuf_den_plane[k]) (void)hipFree(f->gbuf_den_plane[k]);
         if (f->gbuf_den_line[k]) (void)hipFree(f->gbuf_den_line[k]);
         if (f->gbuf_app_plane[k]) (void)hipFree(f->gbuf_app_plane[k]);
@@ -371,6 +389,17 @@ extern "C" int t2n_field_set_alpha_mask(t2n_field* f, const float* volume, int D
 extern "C" int t2n_field_set_frame_width(t2n_field* f, int width) {
     if (!f || width < 0) { set_error("t2n_field_set_frame_width: bad argument"); return T2N_ERR_INVALID; }
     f->frame_w = width;
+    return T2N_OK;
+}
+
+extern "C" int t2n_field_set_factor_storage(t2n_field* f, int bf16) {
+    if (!f) { set_error("t2n_field_set_factor_storage: NULL field"); return T2N_ERR_INVALID; }
+    if ((bf16 != 0) != (f->factor_bf16 != 0)) f->uploaded = false;   // the next render needs a fresh t2n_field_upload
+    f->factor_bf16 = bf16 ? 1 : 0;
+    if (!f->factor_bf16)
+        for (int k = 0; k < 3; ++k) {
+            f->dev.den.plane_h[k] = f->dev.den.line_h[k] = f->dev.app.plane_h[k] = f->dev.app.line_h[k] = nullptr;
+        }
     return T2N_OK;
 }
 

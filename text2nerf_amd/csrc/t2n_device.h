@@ -187,23 +187,43 @@ __device__ __forceinline__ Axes3 sample_axes(const FactorSet& S, float xn, float
     A.a[2] = axis_taps(zn, S.H[1]);   // grid[2] = H of planes 1 and 2, L of line 0
     return A;
 }
-template <int K>
+// four bf16 channels (8 B, channel 4q in the low half of .x) -> fp32: exact (bf16 is the upper half of an fp32)
+__device__ __forceinline__ float4 bf16x4_to_f4(uint2 u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+// HALF: the factor set is read from its bf16 copy (8-B quads, half the bytes through the texture addresser / L1).
+template <int K, bool HALF = false>
 __device__ __forceinline__ void issue_taps_ax(const FactorSet& S, int CQ, int q, const Axes3& A, QuadTaps& t) {
     const Axis& ax = A.a[mat0(K)];
     const Axis& ay = A.a[mat1(K)];
     const Axis& al = A.a[vecm(K)];
     // 32-bit BYTE offsets from the (scalar) plane base: lets the loads use the SGPR-base + VGPR-offset addressing form
     const unsigned W = (unsigned)S.W[K];
-    const unsigned tb = (unsigned)CQ * 16u, qb = (unsigned)q * 16u;
+    constexpr unsigned QB = HALF ? 8u : 16u;
+    const unsigned tb = (unsigned)CQ * QB, qb = (unsigned)q * QB;
     const unsigned r0 = (unsigned)ay.i0 * W, r1 = (unsigned)ay.i1 * W;
-    const char* __restrict__ P = reinterpret_cast<const char*>(S.plane[K]);
-    const char* __restrict__ Ln = reinterpret_cast<const char*>(S.line[K]);
-    t.nw = *reinterpret_cast<const float4*>(P + ((r0 + (unsigned)ax.i0) * tb + qb));
-    t.ne = *reinterpret_cast<const float4*>(P + ((r0 + (unsigned)ax.i1) * tb + qb));
-    t.sw = *reinterpret_cast<const float4*>(P + ((r1 + (unsigned)ax.i0) * tb + qb));
-    t.se = *reinterpret_cast<const float4*>(P + ((r1 + (unsigned)ax.i1) * tb + qb));
-    t.l0 = *reinterpret_cast<const float4*>(Ln + ((unsigned)al.i0 * tb + qb));
-    t.l1 = *reinterpret_cast<const float4*>(Ln + ((unsigned)al.i1 * tb + qb));
+    if constexpr (HALF) {
+        const char* __restrict__ P = reinterpret_cast<const char*>(S.plane_h[K]);
+        const char* __restrict__ Ln = reinterpret_cast<const char*>(S.line_h[K]);
+        const uint2 nw = *reinterpret_cast<const uint2*>(P + ((r0 + (unsigned)ax.i0) * tb + qb));
+        const uint2 ne = *reinterpret_cast<const uint2*>(P + ((r0 + (unsigned)ax.i1) * tb + qb));
+        const uint2 sw = *reinterpret_cast<const uint2*>(P + ((r1 + (unsigned)ax.i0) * tb + qb));
+        const uint2 se = *reinterpret_cast<const uint2*>(P + ((r1 + (unsigned)ax.i1) * tb + qb));
+        const uint2 l0 = *reinterpret_cast<const uint2*>(Ln + ((unsigned)al.i0 * tb + qb));
+        const uint2 l1 = *reinterpret_cast<const uint2*>(Ln + ((unsigned)al.i1 * tb + qb));
+        t.nw = bf16x4_to_f4(nw); t.ne = bf16x4_to_f4(ne); t.sw = bf16x4_to_f4(sw); t.se = bf16x4_to_f4(se);
+        t.l0 = bf16x4_to_f4(l0); t.l1 = bf16x4_to_f4(l1);
+    } else {
+        const char* __restrict__ P = reinterpret_cast<const char*>(S.plane[K]);
+        const char* __restrict__ Ln = reinterpret_cast<const char*>(S.line[K]);
+        t.nw = *reinterpret_cast<const float4*>(P + ((r0 + (unsigned)ax.i0) * tb + qb));
+        t.ne = *reinterpret_cast<const float4*>(P + ((r0 + (unsigned)ax.i1) * tb + qb));
+        t.sw = *reinterpret_cast<const float4*>(P + ((r1 + (unsigned)ax.i0) * tb + qb));
+        t.se = *reinterpret_cast<const float4*>(P + ((r1 + (unsigned)ax.i1) * tb + qb));
+        t.l0 = *reinterpret_cast<const float4*>(Ln + ((unsigned)al.i0 * tb + qb));
+        t.l1 = *reinterpret_cast<const float4*>(Ln + ((unsigned)al.i1 * tb + qb));
+    }
     t.wnw = ay.w0 * ax.w0; t.wne = ay.w0 * ax.w1; t.wsw = ay.w1 * ax.w0; t.wse = ay.w1 * ax.w1;
     t.wl0 = al.w0; t.wl1 = al.w1;
 }

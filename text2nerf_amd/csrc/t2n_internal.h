@@ -24,6 +24,11 @@ struct FactorSet {
     const float* line[3];
     int W[3], H[3], L[3];
     int C;
+    // bf16 factor storage (t2n_field_set_factor_storage): the same channel-last layouts with 2-byte texels, read by the
+    // forward march / shade gathers; plane[] / line[] then hold the bf16-ROUNDED values as fp32 (backward, point queries,
+    // grid operators). NULL in fp32 mode.
+    const void* plane_h[3];
+    const void* line_h[3];
 };
 
 struct FieldDev {
@@ -59,6 +64,12 @@ struct t2n_field {
     float* buf_den_line[3] = {nullptr, nullptr, nullptr};
     float* buf_app_plane[3] = {nullptr, nullptr, nullptr};
     float* buf_app_line[3] = {nullptr, nullptr, nullptr};
+    // bf16 copies of the factor buffers (factor_bf16 mode only)
+    void* hbuf_den_plane[3] = {nullptr, nullptr, nullptr};
+    void* hbuf_den_line[3] = {nullptr, nullptr, nullptr};
+    void* hbuf_app_plane[3] = {nullptr, nullptr, nullptr};
+    void* hbuf_app_line[3] = {nullptr, nullptr, nullptr};
+    int factor_bf16 = 0;
     float* buf_mlp = nullptr;  // basisA | w0A | w1A | w2A
     void* buf_mlp_h = nullptr; // split-f16 operands + scaled biases
     float* buf_alpha = nullptr; // alpha-mask volume copy

@@ -30,7 +30,8 @@ struct MarchArgs {
     unsigned nblocks;
 };
 
-template <bool TRAIN, int DC>
+// HALF: density factors are read from their bf16 copies (t2n_field_set_factor_storage)
+template <bool TRAIN, int DC, bool HALF>
 __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LPS = DC / 4;          // lanes per sample
@@ -136,9 +137,9 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
             if (ok) {
                 QuadTaps t0, t1, t2;
                 const Axes3 A = sample_axes(F.den, xn, yn, zn);
-                issue_taps_ax<0>(F.den, LPS, q, A, t0);
-                issue_taps_ax<1>(F.den, LPS, q, A, t1);
-                issue_taps_ax<2>(F.den, LPS, q, A, t2);
+                issue_taps_ax<0, HALF>(F.den, LPS, q, A, t0);
+                issue_taps_ax<1, HALF>(F.den, LPS, q, A, t1);
+                issue_taps_ax<2, HALF>(F.den, LPS, q, A, t2);
                 float4 p, l;
                 p = taps_plane(t0); l = taps_line(t0);
                 part = p.x * l.x; part = fmaf(p.y, l.y, part); part = fmaf(p.z, l.z, part); part = fmaf(p.w, l.w, part);
@@ -383,8 +384,14 @@ int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
     const size_t lds = (size_t)4 * 2 * a.npad * sizeof(float);
     const bool train = (L.flags & T2N_FLAG_TRAIN) != 0;
     timing_begin(f, T2N_K_MARCH, s);
-    if (train) hipLaunchKernelGGL((k_march<true, 16>), dim3(a.nblocks), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((k_march<false, 16>), dim3(a.nblocks), dim3(256), lds, s, a);
+    const bool half = f->factor_bf16 && f->dev.den.plane_h[0];
+    if (train) {
+        if (half) hipLaunchKernelGGL((k_march<true, 16, true>), dim3(a.nblocks), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_march<true, 16, false>), dim3(a.nblocks), dim3(256), lds, s, a);
+    } else {
+        if (half) hipLaunchKernelGGL((k_march<false, 16, true>), dim3(a.nblocks), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_march<false, 16, false>), dim3(a.nblocks), dim3(256), lds, s, a);
+    }
     timing_end(f, T2N_K_MARCH, s);
     T2N_HIP(hipGetLastError());
     return launch_ray_stats(L, s);

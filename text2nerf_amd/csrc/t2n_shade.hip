@@ -294,6 +294,7 @@ struct GatherItem {
     int s, q;
     bool live;
 };
+template <bool HALF = false>
 __device__ __forceinline__ void gather_issue(const FactorSet& S, int it, int lane, const float4* pos_l, const float* xyz,
                                              unsigned base, unsigned count, GatherItem& g) {
     constexpr int CQ = 12;   // 48 channels / 4
@@ -307,9 +308,9 @@ __device__ __forceinline__ void gather_issue(const FactorSet& S, int it, int lan
         else { xn = xyz[(size_t)idx * 3]; yn = xyz[(size_t)idx * 3 + 1]; zn = xyz[(size_t)idx * 3 + 2]; }
     }
     const Axes3 A = sample_axes(S, xn, yn, zn);
-    issue_taps_ax<0>(S, CQ, g.q, A, g.t[0]);
-    issue_taps_ax<1>(S, CQ, g.q, A, g.t[1]);
-    issue_taps_ax<2>(S, CQ, g.q, A, g.t[2]);
+    issue_taps_ax<0, HALF>(S, CQ, g.q, A, g.t[0]);
+    issue_taps_ax<1, HALF>(S, CQ, g.q, A, g.t[1]);
+    issue_taps_ax<2, HALF>(S, CQ, g.q, A, g.t[2]);
 }
 __device__ __forceinline__ void gather_consume(const GatherItem& g, float* __restrict__ X, float* ctx_x, unsigned row0) {
 #pragma unroll
@@ -323,19 +324,20 @@ __device__ __forceinline__ void gather_consume(const GatherItem& g, float* __res
     }
 }
 
+template <bool HALF = false>
 __device__ __forceinline__ void gather_all(const FactorSet& S, float* __restrict__ X, int lane, const float4* pos_l,
                                            const float* xyz, unsigned base, unsigned count, float* ctx_x, unsigned row0) {
     GatherItem g0, g1;
-    gather_issue(S, 0, lane, pos_l, xyz, base, count, g0);
-    gather_issue(S, 1, lane, pos_l, xyz, base, count, g1);
+    gather_issue<HALF>(S, 0, lane, pos_l, xyz, base, count, g0);
+    gather_issue<HALF>(S, 1, lane, pos_l, xyz, base, count, g1);
     gather_consume(g0, X, ctx_x, row0);
-    gather_issue(S, 2, lane, pos_l, xyz, base, count, g0);
+    gather_issue<HALF>(S, 2, lane, pos_l, xyz, base, count, g0);
     gather_consume(g1, X, ctx_x, row0);
-    gather_issue(S, 3, lane, pos_l, xyz, base, count, g1);
+    gather_issue<HALF>(S, 3, lane, pos_l, xyz, base, count, g1);
     gather_consume(g0, X, ctx_x, row0);
-    gather_issue(S, 4, lane, pos_l, xyz, base, count, g0);
+    gather_issue<HALF>(S, 4, lane, pos_l, xyz, base, count, g0);
     gather_consume(g1, X, ctx_x, row0);
-    gather_issue(S, 5, lane, pos_l, xyz, base, count, g1);
+    gather_issue<HALF>(S, 5, lane, pos_l, xyz, base, count, g1);
     gather_consume(g0, X, ctx_x, row0);
     gather_consume(g1, X, ctx_x, row0);
 }
@@ -688,6 +690,7 @@ __device__ unsigned long long g_phase[8];
 #define T2N_PHASE(i) do {} while (0)
 #endif
 
+template <bool HALF>
 __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
 #ifdef T2N_PHASE_TIMING
         unsigned long long tph = __builtin_amdgcn_s_memtime();
 #endif
-        gather_all(F.app, X, lane, a.app_pos, a.xyz, base, count, nullptr, 0);
+        gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, nullptr, 0);
         wave_lds_sync();
         T2N_PHASE(0);
 
@@ -1004,11 +1007,14 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
     if (!attr_set) {
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
+        T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
+        T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
         attr_set = true;
     }
     timing_begin(f, T2N_K_SHADE, s);
-    if (use_coop(f) && !ctx) hipLaunchKernelGGL(k_shade_coop, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), kCoopLds, s, a);
+    const bool half = f->factor_bf16 && f->dev.app.plane_h[0];
+    if (use_coop(f) && !ctx && half) hipLaunchKernelGGL(k_shade_coop<true>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), kCoopLds, s, a);
+    else if (use_coop(f) && !ctx) hipLaunchKernelGGL(k_shade_coop<false>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), kCoopLds, s, a);
     else if (f->mlp_split && !ctx) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
     timing_end(f, T2N_K_SHADE, s);
@@ -1045,8 +1051,9 @@ extern "C" int t2n_shade_at(const t2n_field* fc, const float* xyz_norm, const fl
     const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
     T2N_HIP(hipFuncSetAttribute((const void*)k_shade<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
-    if (use_coop(f)) hipLaunchKernelGGL(k_shade_coop, dim3(shade_grid((unsigned)n)), dim3(256), kCoopLds, (hipStream_t)stream, a);
+    T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
+        T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
+    if (use_coop(f)) hipLaunchKernelGGL(k_shade_coop<false>, dim3(shade_grid((unsigned)n)), dim3(256), kCoopLds, (hipStream_t)stream, a);
     else if (f->mlp_split) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid((unsigned)n)), dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid((unsigned)n)), dim3(256), lds, (hipStream_t)stream, a);
     T2N_HIP(hipGetLastError());

@@ -126,6 +126,9 @@ class TensorVMSplit(nn.Module):
         self.frame_width = 0              # set to the image width when eval rays are whole row-major frames: enables the
                                           # 8x8-tile marcher (LDS-staged shared taps); 0 = unknown -> per-ray marcher
         self.mlp_exact_fp32 = os.environ.get("T2N_MLP_EXACT", "0") == "1"   # False: f16 two-way-split MFMA products
+        # 'fp32' (default) or 'bf16' (BASELINE configs[4]): the forward gathers read bf16 copies of the 12 factor tensors;
+        # the render equals the fp32 render of the bf16-rounded tensors bit for bit, the parameters stay fp32 masters
+        self.factor_storage = os.environ.get("T2N_FACTOR_STORAGE", "fp32")
         self._handle = None
         self._uploaded_key = None
         self.last_stats = None
@@ -308,6 +311,7 @@ class TensorVMSplit(nn.Module):
             _lib.check(lib.t2n_field_create(C.byref(d), C.byref(h)), "t2n_field_create")
             self._handle = h
             self._precision_set = None
+            self._storage_set = None
             self._frame_w_set = None
             self._alpha_key = "unset"
         mask = self.alphaMask
@@ -333,6 +337,13 @@ class TensorVMSplit(nn.Module):
             _lib.check(lib.t2n_field_set_mlp_precision(self._handle, 1 if self.mlp_exact_fp32 else 0),
                        "t2n_field_set_mlp_precision")
             self._precision_set = bool(self.mlp_exact_fp32)
+        if self.factor_storage not in ("fp32", "bf16"):
+            raise T2NError(f"factor_storage {self.factor_storage!r}: expected 'fp32' or 'bf16'")
+        if getattr(self, "_storage_set", None) != self.factor_storage:
+            _lib.check(lib.t2n_field_set_factor_storage(self._handle, 1 if self.factor_storage == "bf16" else 0),
+                       "t2n_field_set_factor_storage")
+            self._storage_set = self.factor_storage
+            force = True
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if force or key != self._uploaded_key:
             with torch.cuda.device(dev):
