@@ -182,6 +182,14 @@ int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_
                        const float* jitter, float* rgb, float* depth, float* weights, float* z_vals, uint64_t* stats,
                        void* workspace, size_t workspace_bytes, t2n_stream stream);
 
+/* ---- f-2: frame post-processing of `evaluation` / `evaluation_path` (renderer.py:91-113,168-176; utils.py:241-257) on the
+ * device: rgb8 [n,3] = uint8(255 * clamp(rgb,0,1)) (truncation); depth8 [n,3] = OpenCV COLORMAP_JET (B,G,R) of
+ * uint8(255 * max((nan_to_num(d) - mi) / (ma - mi + 1e-8), 0)) with d = max((depth - depth_sub) + depth_add, 0) when
+ * shift_clamp (the `evaluation` form: push_depth, 0.8) else d = depth (`evaluation_path`); when gt_rgb is given, *sq_err_sum += sum((clamp(rgb) - gt)^2) (double; PSNR = -10 log10(sum / (3 n))). Any output may be NULL. */
+int t2n_frame_postprocess(const float* rgb /*[n,3]*/, const float* depth /*[n]*/, int64_t n, float depth_sub, float depth_add,
+                          int shift_clamp, float mi, float ma, uint8_t* rgb8, uint8_t* depth8, const float* gt_rgb, double* sq_err_sum,
+                          t2n_stream stream);
+
 /* ---- a-15: backward of the render call w.r.t. all field parameters (what autograd derives in the reference,
  * text2nerf_main.py:589; coordinates are detached there, models/tensoRF.py:208-210,226-228, so no ray gradients exist).
  * Protocol: (1) forward with T2N_FLAG_KEEP_CTX as ONE launch (workspace >= t2n_render_workspace_bytes_ctx), weights and

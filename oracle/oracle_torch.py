@@ -476,3 +476,46 @@ def round_factors_bf16(params):
         else:
             out[k] = v
     return out
+
+
+# ---- f-2: frame post-processing of `evaluation` / `evaluation_path` ------------------------------------------------------
+def jet_table_bgr():
+    """OpenCV COLORMAP_JET as a [256,3] uint8 table in B,G,R order. cv2 is absent from this image, so this is a restatement
+    of OpenCV's published table (imgproc/src/colormap.cpp: r,g,b = clamp(1.5 - |4x - {3,2,1}|, 0, 1) at x = i/255, scaled by
+    255 and rounded half-to-even by saturate_cast) — PARITY UNPINNED for this table: entries that fall on exact .5 ties
+    may differ from cv2 by one level."""
+    import numpy as np
+    i = np.arange(256, dtype=np.int64)
+    out = np.zeros((256, 3), np.uint8)
+    for ch, centre in enumerate((1, 2, 3)):           # B, G, R
+        twice = np.clip(765 - 2 * np.abs(4 * i - 255 * centre), 0, 510)
+        r = twice >> 1
+        r = r + ((twice & 1) & (r & 1))
+        out[:, ch] = r.astype(np.uint8)
+    return out
+
+
+def postprocess_frame(rgb, depth, near_far, push_depth=None, gt_rgb=None):
+    """renderer.py:91-113 (push_depth given) / :168-176 (None) + utils.py:241-257 in numpy, as the reference runs them on
+    the host. Returns (rgb8, depth8_bgr, psnr|None)."""
+    import numpy as np
+    rgb = np.clip(np.asarray(rgb, np.float32), 0.0, 1.0)
+    d = np.asarray(depth, np.float32)
+    if push_depth is not None:
+        d = (d - np.float32(push_depth)) + np.float32(0.8)          # torch: two fp32 ops (renderer.py:94)
+        d = np.maximum(d, 0)
+    x = np.nan_to_num(d)
+    mi, ma = near_far
+    x = (x - np.float32(mi)) / np.float32(ma - mi + 1e-8)
+    x = np.maximum(x, 0)
+    with np.errstate(over='ignore', invalid='ignore'):
+        y = 255 * x
+    # x86 float->uint8 cast (cvttss2si + truncation): wraps modulo 256, out-of-int32-range values give 0
+    idx = np.where(y < 2147483648.0, np.minimum(y, 2147483520.0).astype(np.int64) & 255, 0).astype(np.uint8)
+    depth8 = jet_table_bgr()[idx]
+    psnr = None
+    if gt_rgb is not None:
+        loss = float(np.mean((rgb.astype(np.float64) - np.asarray(gt_rgb, np.float64)) ** 2))
+        psnr = -10.0 * np.log(loss) / np.log(10.0)
+    rgb8 = (rgb * 255).astype(np.uint8)
+    return rgb8, depth8, psnr

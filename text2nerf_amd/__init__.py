@@ -2,6 +2,7 @@
 
 Host-side mirror of the reference interface for this path; the arithmetic runs in libt2n_hip.so (include/t2n.h).
 """
-from .renderer import OctreeRender_trilinear_fast, SimpleSampler, render_views  # noqa: F401
+from .renderer import (OctreeRender_trilinear_fast, SimpleSampler, render_views, postprocess_frame,  # noqa: F401
+                       evaluation_frames)
 from .tensorf import AlphaGridMask, TensorVMSplit, raw2alpha  # noqa: F401
 from .ray_utils import get_ray_directions, get_rays, generate_rays  # noqa: F401

@@ -178,6 +178,60 @@ __global__ __launch_bounds__(256) void k_generate_rays(int H, int W, float fx, f
     r6[t * 6] = P.m[3]; r6[t * 6 + 1] = P.m[7]; r6[t * 6 + 2] = P.m[11]; r6[t * 6 + 3] = rx; r6[t * 6 + 4] = ry; r6[t * 6 + 5] = rz;
 }
 
+
+// ---- f-2: per-frame post-processing of `evaluation` / `evaluation_path` on the device (renderer.py:91-113,168-176,
+// utils.py:241-257): rgb -> uint8 by truncation of 255 * clamp(rgb), depth -> (d + offset [, max 0]) -> nan_to_num ->
+// (x - mi) / (ma - mi + 1e-8) -> max 0 -> uint8 by truncation (wrapping modulo 256 above 1.0 like the x86 float->uint8
+// cast numpy performs) -> JET colour table in OpenCV's BGR channel order, optional sum of squared errors against a
+// ground-truth frame for the PSNR.
+__device__ __forceinline__ unsigned char jet_channel(int i, float centre) {
+    // OpenCV's COLORMAP_JET table is the piecewise-linear clamp(1.5 - |4 x - centre|, 0, 1) sampled at x = i / 255
+    // = clamp(382.5 - |4 i - 255 centre|, 0, 255) in exact integer halves, rounded half-to-even like cv::saturate_cast
+    int twice = 765 - 2 * abs(4 * i - 255 * (int)centre);       // 2 * value, always odd before clamping
+    twice = min(max(twice, 0), 510);
+    int r = twice >> 1;                                          // floor
+    if ((twice & 1) && (r & 1)) r += 1;                          // tie -> even
+    return (unsigned char)r;
+}
+__global__ __launch_bounds__(256) void k_frame_post(const float* __restrict__ rgb, const float* __restrict__ depth, long long n,
+                                                    float sub, float add, int clamp0, float mi, float den,
+                                                    unsigned char* rgb8, unsigned char* depth8, const float* __restrict__ gt,
+                                                    double* sq_sum) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float se = 0.f;
+    if (t < n) {
+        float c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            c[k] = fminf(fmaxf(rgb[t * 3 + k], 0.f), 1.f);
+            if (rgb8) rgb8[t * 3 + k] = (unsigned char)(int)(c[k] * 255.f);
+            if (gt) { const float d = c[k] - gt[t * 3 + k]; se += d * d; }
+        }
+        if (depth8) {
+            float d = depth[t];
+            if (clamp0) { d = d - sub; d = d + add; d = fmaxf(d, 0.f); }   // renderer.py:94-95 (two fp32 roundings)
+            if (d != d) d = 0.f;
+            else if (isinf(d)) d = d > 0.f ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+            float x = (d - mi) / den;
+            x = fmaxf(x, 0.f);
+            const float y = 255.f * x;
+            const int i = y < 2147483648.f ? ((int)y & 255) : 0;   // cvttss2si: out-of-range -> 0x80000000 -> low byte 0
+            depth8[t * 3 + 0] = jet_channel(i, 1.f);   // B
+            depth8[t * 3 + 1] = jet_channel(i, 2.f);   // G
+            depth8[t * 3 + 2] = jet_channel(i, 3.f);   // R
+        }
+    }
+    if (sq_sum) {
+        float s = se;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        __shared__ float part[4];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sq_sum, (double)part[0] + (double)part[1] + (double)part[2] + (double)part[3]);
+    }
+}
+
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx) {
@@ -296,6 +350,18 @@ extern "C" int t2n_generate_rays(int H, int W, float fx, float fy, float cx, flo
     memcpy(P.m, c2w_host, sizeof(P.m));
     const long long n = (long long)H * W;
     hipLaunchKernelGGL(k_generate_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, H, W, fx, fy, cx, cy, P, rays6);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_frame_postprocess(const float* rgb, const float* depth, int64_t n, float depth_sub, float depth_add, int shift_clamp,
+                                     float mi, float ma, uint8_t* rgb8, uint8_t* depth8, const float* gt_rgb, double* sq_err_sum,
+                                     t2n_stream stream) {
+    if (!rgb || n < 0 || (depth8 && !depth) || (gt_rgb && !sq_err_sum)) { set_error("t2n_frame_postprocess: bad argument"); return T2N_ERR_INVALID; }
+    if (n == 0) return T2N_OK;
+    const float den = (float)((double)ma - (double)mi + 1e-8);   // numpy: python-float scalar rounded to the array's fp32
+    hipLaunchKernelGGL(k_frame_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rgb, depth, (long long)n,
+                       depth_sub, depth_add, shift_clamp, mi, den, rgb8, depth8, gt_rgb, gt_rgb ? sq_err_sum : nullptr);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

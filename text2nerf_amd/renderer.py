@@ -62,3 +62,52 @@ def render_views(tensorf, poses, intrinsic, H, W, N_samples=-1, white_bg=True):
     finally:
         tensorf.materialize_weights = keep
     return torch.stack(rgbs), torch.stack(depths)
+
+
+
+@torch.no_grad()
+def postprocess_frame(rgb, depth, near_far, push_depth=None, gt_rgb=None):
+    """Device-side form of the per-view post-processing of ``evaluation`` (renderer.py:91-113) / ``evaluation_path``
+    (:168-176) with ``visualize_depth_numpy`` (utils.py:241-257): returns ``(rgb8 [..,3] uint8, depth8 [..,3] uint8 JET in
+    OpenCV's BGR order, psnr or None)`` as device tensors — one elementwise HIP kernel instead of a D2H copy + numpy per
+    view. ``push_depth`` given: the ``evaluation`` form ``max(depth - push_depth + 0.8, 0)``; ``None``: ``evaluation_path``."""
+    from . import _lib
+    import ctypes as C
+    lib = _lib.load()
+    dev = rgb.device
+    if dev.type != "cuda":
+        raise _lib.T2NError("postprocess_frame runs on the MI355X only (no CPU fallback)")
+    shape = tuple(depth.shape)
+    rgb_c = rgb.reshape(-1, 3).contiguous().float()
+    dep_c = depth.reshape(-1).contiguous().float()
+    n = dep_c.numel()
+    rgb8 = torch.empty(n, 3, dtype=torch.uint8, device=dev)
+    dep8 = torch.empty(n, 3, dtype=torch.uint8, device=dev)
+    sq = torch.zeros(1, dtype=torch.float64, device=dev) if gt_rgb is not None else None
+    gt = gt_rgb.reshape(-1, 3).to(dev).contiguous().float() if gt_rgb is not None else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.t2n_frame_postprocess(_lib.ptr(rgb_c), _lib.ptr(dep_c), n, float(push_depth or 0.0), 0.8,
+                                             1 if push_depth is not None else 0, float(near_far[0]), float(near_far[1]),
+                                             _lib.ptr(rgb8), _lib.ptr(dep8), _lib.ptr(gt), _lib.ptr(sq),
+                                             _lib.current_stream_ptr(dev)), "t2n_frame_postprocess")
+    psnr = None
+    if sq is not None:
+        loss = float(sq.item()) / (3 * n)
+        psnr = -10.0 * float(np.log(loss)) / float(np.log(10.0))
+    return rgb8.reshape(shape + (3,)), dep8.reshape(shape + (3,)), psnr
+
+
+@torch.no_grad()
+def evaluation_frames(tensorf, poses, intrinsic, H, W, near_far, N_samples=-1, white_bg=True, push_depth=2.0, gt_rgbs=None):
+    """``evaluation`` (renderer.py:45-140) without its file I/O, entirely on the device: rays from ``(c2w, intrinsics)``,
+    one render call per view, post-processing kernel; returns ``(rgb8 [V,H,W,3], depth8 [V,H,W,3], PSNRs)``."""
+    rgbs, depths = render_views(tensorf, poses, intrinsic, H, W, N_samples=N_samples, white_bg=white_bg)
+    out_rgb, out_dep, psnrs = [], [], []
+    for v in range(rgbs.shape[0]):
+        r8, d8, p = postprocess_frame(rgbs[v], depths[v], near_far, push_depth=push_depth,
+                                      gt_rgb=None if gt_rgbs is None else gt_rgbs[v])
+        out_rgb.append(r8)
+        out_dep.append(d8)
+        if p is not None:
+            psnrs.append(p)
+    return torch.stack(out_rgb), torch.stack(out_dep), psnrs
