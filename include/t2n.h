@@ -190,6 +190,29 @@ int t2n_frame_postprocess(const float* rgb /*[n,3]*/, const float* depth /*[n]*/
                           int shift_clamp, float mi, float ma, uint8_t* rgb8, uint8_t* depth8, const float* gt_rgb, double* sq_err_sum,
                           t2n_stream stream);
 
+/* ---- f-3: the image-space steps either side of the renderer in render_warping_inapinting (text2nerf_main.py:102-141).
+ * t2n_sparse_bilateral_filtering = dataLoader/bilateral_filtering.py:5-35 with mask=None, HR=False: per pass the depth
+ * discontinuity map (:64-136; 4-neighbour disparity jumps > depth_threshold, or original depth == 0) and the median of the
+ * window's non-discontinuity pixels (:138-196) on depth and the three colour channels. Outputs what the driver keeps
+ * (:119-120): photo_out [H,W,3] after ALL num_iter passes and depth_out [num_iter,H,W] = the depth BEFORE each pass, i.e.
+ * save_depths; its last entry has seen num_iter - 1 passes (reference quirk: the image list aliases one in-place array,
+ * the depth list does not). filter_sizes_host: num_iter odd windows <= 7. Bit-exact. */
+size_t t2n_image_filter_workspace_bytes(int H, int W);
+int t2n_sparse_bilateral_filtering(const float* depth /*[H,W]*/, const float* image /*[H,W,3]*/, int H, int W,
+                                   const int* filter_sizes_host, int num_iter, float depth_threshold, float* photo_out,
+                                   float* depth_out, void* workspace, size_t workspace_bytes, t2n_stream stream);
+/* DIBR: one source view of bilinear_splat_warping_multiview (utils.py:83-119) = Warper.forward_warp (scripts/Warper.py:21-186:
+ * per-pixel reprojection in fp64, inverse-bilinear splat with depth-softmax weights into an (H+2, W+2) canvas with fp64
+ * atomics) merged into the running target (filled [H,W] u8, image_u8 [H,W,3], depth_out [H,W] f64; caller-zeroed before
+ * the first view; earlier views win). Ki9 = inv(K1), T12 = first three rows of T2 inv(T1), K9 = K2 (row-major doubles,
+ * host). t2n_warp_finish: white where nothing landed, image / 255 -> fp32, int64 mask. */
+size_t t2n_warp_workspace_bytes(int H, int W);
+int t2n_warp_view(const float* rgb /*[H,W,3] in [0,1]*/, const float* depth /*[H,W]*/, const uint8_t* mask1 /*[H,W] or NULL*/, int H,
+                  int W, const double* Ki9_host, const double* T12_host, const double* K9_host, uint8_t* filled, uint8_t* image_u8,
+                  double* depth_out, void* workspace, size_t workspace_bytes, t2n_stream stream);
+int t2n_warp_finish(const uint8_t* filled, const uint8_t* image_u8, int H, int W, float* image_out /*[H,W,3]*/,
+                    int64_t* mask_out /*[H,W] or NULL*/, t2n_stream stream);
+
 /* ---- a-15: backward of the render call w.r.t. all field parameters (what autograd derives in the reference,
  * text2nerf_main.py:589; coordinates are detached there, models/tensoRF.py:208-210,226-228, so no ray gradients exist).
  * Protocol: (1) forward with T2N_FLAG_KEEP_CTX as ONE launch (workspace >= t2n_render_workspace_bytes_ctx), weights and

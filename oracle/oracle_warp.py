@@ -1,0 +1,146 @@
+"""Oracle for SURVEY.md 8 f-3: CPU restatements (numpy) of the two image-space steps around the renderer in
+`render_warping_inapinting` (text2nerf_main.py:102-141). TEST INFRASTRUCTURE ONLY: imported by tests/ (and nothing else);
+the product path is the HIP code behind text2nerf_amd/warp.py. Pinned against goldens produced by the reference itself
+(tests/golden/make_golden_warp.py -> warp.npz; tests/test_oracle_warp.py).
+
+  depth_discontinuities / median_filter_pass / sparse_bilateral_filtering
+      dataLoader/bilateral_filtering.py:5-35 (driver), :64-136 (vis_depth_discontinuity), :138-228 (bilateral_filter,
+      discontinuity branch with mask=None: an unweighted median over the window's non-discontinuity pixels)
+  forward_warp / bilinear_splat_warping_multiview
+      scripts/Warper.py:21-186 (compute_transformed_points, bilinear_splatting), utils.py:83-119
+"""
+import numpy as np
+from numpy.lib.stride_tricks import sliding_window_view
+
+
+# ---- sparse_bilateral_filtering ---------------------------------------------------------------------------------------------
+def depth_discontinuities(vis_depth, orig_depth, thr):
+    """bilateral_filtering.py:17-20,78-97,115-118: 4-neighbour disparity jumps > thr on interior pixels (border = 0), union
+    clipped to [0,1], plus every pixel whose ORIGINAL depth is 0."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        disp = (1.0 / vis_depth).astype(vis_depth.dtype)
+        H, W = disp.shape
+        over = np.zeros((H, W), np.float32)
+        c = disp[1:-1, 1:-1]
+        for nb in (disp[:-2, 1:-1], disp[2:, 1:-1], disp[1:-1, :-2], disp[1:-1, 2:]):   # up, below, left, right
+            over[1:-1, 1:-1] += (np.abs(c - nb) > thr).astype(np.float32)
+    over = np.clip(over, 0.0, 1.0)
+    over[orig_depth == 0] = 1
+    return over
+
+
+def median_filter_pass(x, disc, window):
+    """bilateral_filtering.py:138-196 with discontinuity_map given and mask=None. The border ring of `x` and `disc` is first
+    replaced by its inner neighbours (:149-154); pixels whose window holds no discontinuity keep that value; the others take
+    the weighted median of the window with weight 1/n on the n non-discontinuity pixels: values sorted ascending, fp32
+    running sum of the weights, first element whose running sum exceeds 0.5 (np.digitize(0.5, cumsum))."""
+    m = window // 2
+    xi = np.pad(x[1:-1, 1:-1], 1, mode="edge")
+    di = np.pad(disc[1:-1, 1:-1], 1, mode="edge")
+    px = sliding_window_view(np.pad(xi, m, mode="edge"), (window, window)).reshape(x.shape + (-1,))
+    pd = sliding_window_view(np.pad(di, m, mode="edge"), (window, window)).reshape(x.shape + (-1,))
+    out = xi.copy()
+    ys, xs = np.nonzero(pd.any(-1))
+    for y, xx in zip(ys, xs):
+        vals, hole = px[y, xx], (1.0 - pd[y, xx]).astype(np.float32)
+        if hole.max() == 0:
+            continue                                      # output = window centre = xi[y, xx]
+        order = np.argsort(vals, kind="stable")
+        w = (hole / hole.sum())[order]
+        k = int(np.searchsorted(np.cumsum(w), 0.5, side="right"))
+        out[y, xx] = vals[order][k]
+    return out
+
+
+def sparse_bilateral_filtering(depth, image, filter_size, depth_threshold, num_iter):
+    """bilateral_filtering.py:5-35 (mask=None). Returns (photo, depth_kept, depth_states): the reference appends the SAME
+    image array every iteration and filters it in place, so `save_images[-1]` is the image after ALL num_iter passes, while
+    the depth array is re-bound, so `save_depths[-1]` is the depth after num_iter - 1 passes (the last depth pass is
+    discarded) — both quirks are what the driver consumes (text2nerf_main.py:119-120)."""
+    vis_depth, vis_image = depth.copy(), image.copy()
+    states = []
+    for i in range(num_iter):
+        window = filter_size[i] if isinstance(filter_size, (list, tuple)) else filter_size
+        states.append(vis_depth)
+        disc = depth_discontinuities(vis_depth, depth, depth_threshold)
+        vis_depth = median_filter_pass(vis_depth, disc, window)
+        for ch in range(3):
+            vis_image[:, :, ch] = median_filter_pass(vis_image[:, :, ch], disc, window)
+    return vis_image, states[-1], states
+
+
+# ---- DIBR forward warp ------------------------------------------------------------------------------------------------------
+def transformed_points(depth1, T1, T2, K1, K2):
+    """Warper.py:64-95 per pixel: X = depth * K1^-1 (x, y, 1); X' = (T2 T1^-1) X; p = K2 X'. Returns (u, v, z) float64 maps.
+    dtype rules of the reference: inverses / the 4x4 product stay in the inputs' dtype (fp32 from the driver), the per-pixel
+    products run in fp64."""
+    h, w = depth1.shape
+    T = np.matmul(T2, np.linalg.inv(T1))
+    Ki = np.linalg.inv(K1)
+    x, y = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    Ki, T, K2 = Ki.astype(np.float64), T.astype(np.float64), K2.astype(np.float64)
+    d = depth1.astype(np.float64)
+    cam = [d * (Ki[r, 0] * x + Ki[r, 1] * y + Ki[r, 2] * 1.0) for r in range(3)]
+    w2 = [T[r, 0] * cam[0] + T[r, 1] * cam[1] + T[r, 2] * cam[2] + T[r, 3] * 1.0 for r in range(3)]
+    p = [K2[r, 0] * w2[0] + K2[r, 1] * w2[1] + K2[r, 2] * w2[2] for r in range(3)]
+    return p[0] / p[2], p[1] / p[2], p[2]
+
+
+def splat(values, u, v, z, mask1=None):
+    """Warper.py:97-186: inverse-bilinear splat of `values` [h,w,c] to (u, v) with weights proximity x mask / depth weight,
+    depth weight = exp(50 * log(1 + clip(z,0,1000)) / max(log(1 + ...))), fp64 accumulation on an (h+2, w+2) canvas whose
+    outer ring is cropped. Returns (sum / weight where weight > 0 else 0, weight > 0)."""
+    h, w, c = values.shape
+    ox, oy = u + 1.0, v + 1.0
+    fx, fy = np.floor(ox).astype(np.int64), np.floor(oy).astype(np.int64)
+    cx, cy = np.ceil(ox).astype(np.int64), np.ceil(oy).astype(np.int64)
+    ox, oy = np.clip(ox, 0, w + 1), np.clip(oy, 0, h + 1)
+    fx, cx = np.clip(fx, 0, w + 1), np.clip(cx, 0, w + 1)
+    fy, cy = np.clip(fy, 0, h + 1), np.clip(cy, 0, h + 1)
+    logd = np.log(1 + np.clip(z, 0, 1000))
+    dw = np.exp(logd / logd.max() * 50)
+    m = np.ones((h, w)) if mask1 is None else mask1.astype(np.float64)
+    canvas = np.zeros((h + 2, w + 2, c), np.float64)
+    wsum = np.zeros((h + 2, w + 2), np.float64)
+    for (iy, ix, py, px) in ((fy, fx, 1 - (oy - fy), 1 - (ox - fx)), (cy, fx, 1 - (cy - oy), 1 - (ox - fx)),
+                             (fy, cx, 1 - (oy - fy), 1 - (cx - ox)), (cy, cx, 1 - (cy - oy), 1 - (cx - ox))):
+        wt = py * px * m / dw
+        np.add.at(canvas, (iy, ix), values * wt[:, :, None])
+        np.add.at(wsum, (iy, ix), wt)
+    canvas, wsum = canvas[1:-1, 1:-1], wsum[1:-1, 1:-1]
+    known = wsum > 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        out = np.where(known[:, :, None], canvas / wsum[:, :, None], 0)
+    return out, known
+
+
+def forward_warp(frame1_u8, depth1, T1, T2, K1, K2=None, mask1=None):
+    """Warper.forward_warp (Warper.py:21-62): (warped uint8 frame, known mask, warped fp64 depth, flow)."""
+    K2 = K1 if K2 is None else K2
+    u, v, z = transformed_points(depth1, T1, T2, K1, K2)
+    img, known = splat(frame1_u8.astype(np.float64), u, v, z, mask1)
+    img8 = np.round(np.clip(img, 0, 255)).astype(np.uint8)
+    dep, _ = splat(z[:, :, None], u, v, z, mask1)
+    h, w = depth1.shape
+    x, y = np.meshgrid(np.arange(w), np.arange(h))
+    return img8, known, dep[:, :, 0], np.stack([u - x, v - y], -1)
+
+
+def bilinear_splat_warping_multiview(rgbs, depths, poses, pose_tar, H, W, intrinsic, masks=None):
+    """utils.py:83-119: warp every known view into the target, earlier views win, white where nothing landed.
+    Returns (mask_final [H,W] int, image [H,W,3] fp32 in [0,1], depth [H,W] fp64)."""
+    T2 = np.linalg.inv(pose_tar)
+    K = np.eye(3, dtype=np.float32)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = intrinsic[0], intrinsic[1], intrinsic[2], intrinsic[3]
+    filled = np.zeros((H, W), bool)
+    image = np.zeros((H, W, 3), np.uint8)
+    depth = np.zeros((H, W))
+    for v in range(len(rgbs)):
+        f8, known, d2, _ = forward_warp((rgbs[v] * 255).astype(np.uint8), depths[v], np.linalg.inv(poses[v]), T2, K, None,
+                                        None if masks is None else masks[v])
+        new = known & ~filled
+        image[new] = f8[new]
+        depth[new] = d2[new]
+        filled |= known
+    image[~filled] = 255
+    return filled.astype(np.int64), (image / 255).astype(np.float32), depth

@@ -1,0 +1,58 @@
+"""Pin oracle/oracle_warp.py (f-3: depth-aware median filtering, DIBR forward warp) against goldens produced by the
+reference itself (tests/golden/make_golden_warp.py). CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle_warp as OW
+from tests.conftest import GOLDEN
+from text2nerf_amd import synth
+
+sys.path.insert(0, GOLDEN)
+from make_golden_warp_cases import FILTER_CASES, H, W, pose44, warp_poses  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gw():
+    return dict(np.load(os.path.join(GOLDEN, "warp.npz"), allow_pickle=False))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_sparse_bilateral_filtering_bit_exact(gw, tag):
+    c = FILTER_CASES[tag]
+    rgb, depth = synth.rgbd_frame(c["seed"], H, W, holes=c["holes"])
+    photo, dkeep, states = OW.sparse_bilateral_filtering(depth, rgb, c["filter_size"], 0.02, c["num_iter"])
+    assert np.array_equal(states[1], gw[f"filt_{tag}_depth1"])
+    assert np.array_equal(dkeep, gw[f"filt_{tag}_depth"])
+    assert np.array_equal(photo, gw[f"filt_{tag}_photo"])
+    assert (dkeep != depth).sum() > 100          # the filter did something
+
+
+def _views():
+    poses = [pose44(p) for p in warp_poses()]
+    frames = [synth.rgbd_frame(31 + v, H, W) for v in range(3)]
+    intrinsic = [float(max(H, W)), float(max(H, W)), W // 2, H // 2]
+    return poses, frames, intrinsic
+
+
+def test_forward_warp_vs_reference(gw):
+    poses, frames, intr = _views()
+    K = np.eye(3, dtype=np.float32)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = intr
+    f8, known, dep, flow = OW.forward_warp((frames[1][0] * 255).astype(np.uint8), frames[1][1], np.linalg.inv(poses[1]),
+                                           np.linalg.inv(poses[3]), K)
+    np.testing.assert_allclose(flow, gw["fw_flow"], atol=1e-9)
+    assert np.array_equal(known, gw["fw_mask"])
+    assert np.abs(f8.astype(int) - gw["fw_frame"].astype(int)).max() <= 1 and (f8 != gw["fw_frame"]).mean() < 1e-3
+    np.testing.assert_allclose(dep, gw["fw_depth"], rtol=1e-9, atol=1e-12)
+
+
+def test_multiview_warp_vs_reference(gw):
+    poses, frames, intr = _views()
+    mask, img, dep = OW.bilinear_splat_warping_multiview([f[0] for f in frames], [f[1] for f in frames], np.stack(poses[:3]),
+                                                         poses[3], H, W, intr)
+    assert np.array_equal(mask, gw["warp_mask"])
+    assert np.abs(img - gw["warp_image"]).max() <= 1.0 / 255 + 1e-7 and (img != gw["warp_image"]).mean() < 1e-3
+    np.testing.assert_allclose(dep, gw["warp_depth"], rtol=1e-9, atol=1e-12)

@@ -77,6 +77,13 @@ SIGNATURES = {
     "t2n_field_set_factor_storage": (C.c_int, [C.c_void_p, C.c_int]),
     "t2n_frame_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2n_image_filter_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "t2n_sparse_bilateral_filtering": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_float,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "t2n_warp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "t2n_warp_view": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "t2n_warp_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2n_render_ctx_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "t2n_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int64, C.c_int]),
     "t2n_render_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p,

@@ -1,0 +1,271 @@
+// Image-space steps either side of the renderer in `render_warping_inapinting` (SURVEY.md 8 f-3,
+// text2nerf_main.py:102-141), as HBM-bound stencil / scatter kernels:
+//   sparse_bilateral_filtering   dataLoader/bilateral_filtering.py:5-35 (driver), :64-136 (vis_depth_discontinuity),
+//                                :138-228 (bilateral_filter, discontinuity branch, mask=None): an O(H W) Python loop in the
+//                                reference (seconds per view)
+//   forward warp + merge         scripts/Warper.py:21-186 (compute_transformed_points, bilinear_splatting: numpy add.at in
+//                                fp64), utils.py:83-119 (bilinear_splat_warping_multiview)
+#include "t2n_internal.h"
+
+namespace t2n {
+
+// ---- depth-aware median filter ------------------------------------------------------------------------------------------------
+// planar state [4][H][W]: channel 0 = depth, 1..3 = r, g, b
+__global__ __launch_bounds__(256) void k_img_pack(const float* __restrict__ depth, const float* __restrict__ image, int n, float* st) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    st[t] = depth[t];
+    st[n + t] = image[t * 3]; st[2 * n + t] = image[t * 3 + 1]; st[3 * n + t] = image[t * 3 + 2];
+}
+__global__ __launch_bounds__(256) void k_img_unpack(const float* __restrict__ st, int n, float* image) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    image[t * 3] = st[n + t]; image[t * 3 + 1] = st[2 * n + t]; image[t * 3 + 2] = st[3 * n + t];
+}
+
+// bilateral_filtering.py:17-20,78-97,115-118: |1/d - 1/d_neighbour| > thr for any 4-neighbour (interior pixels only), or
+// original depth == 0. inf - inf = nan compares false, like numpy.
+__global__ __launch_bounds__(256) void k_img_disc(const float* __restrict__ vis, const float* __restrict__ orig, int H, int W, float thr,
+                                                  unsigned char* disc) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= H * W) return;
+    const int y = t / W, x = t - y * W;
+    bool d = false;
+    if (y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2) {
+        const float c = 1.f / vis[t];
+        const float u = 1.f / vis[t - W], b = 1.f / vis[t + W], l = 1.f / vis[t - 1], r = 1.f / vis[t + 1];
+        d = (fabsf(c - u) > thr) | (fabsf(c - b) > thr) | (fabsf(c - l) > thr) | (fabsf(c - r) > thr);
+    }
+    if (orig[t] == 0.f) d = true;
+    disc[t] = d ? 1 : 0;
+}
+
+// One pass of the filter on all four channels (blockIdx.z). 16x16 pixels per workgroup, window <= 7: the (16+6)^2 halo tile
+// of values and flags is staged in LDS. The border ring of the image is replaced by its inner neighbours before the
+// edge padding (:149-154), i.e. every read is at (clamp(y,1,H-2), clamp(x,1,W-2)). Pixels whose window holds no
+// discontinuity keep the (ring-replaced) value; the others take the t-th smallest of the n non-discontinuity values,
+// t = first count whose fp32 running sum of 1/n exceeds 0.5 (np.digitize(0.5, np.cumsum(coef[order]))).
+constexpr int kMedT = 16, kMedHalo = 3, kMedS = kMedT + 2 * kMedHalo;
+__global__ __launch_bounds__(256) void k_img_median(const float* __restrict__ in, const unsigned char* __restrict__ disc, int H, int W,
+                                                    int window, float* __restrict__ out) {
+    __shared__ float sv[kMedS * kMedS];
+    __shared__ unsigned char sd[kMedS * kMedS];
+    const size_t plane = (size_t)blockIdx.z * H * W;
+    const int bx = blockIdx.x * kMedT, by = blockIdx.y * kMedT;
+    for (int i = threadIdx.x; i < kMedS * kMedS; i += 256) {
+        const int ly = i / kMedS, lx = i - ly * kMedS;
+        const int y = min(max(by + ly - kMedHalo, 1), H - 2), x = min(max(bx + lx - kMedHalo, 1), W - 2);
+        sv[i] = in[plane + (size_t)y * W + x];
+        sd[i] = disc[(size_t)y * W + x];
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = bx + tx, y = by + ty;
+    if (x >= W || y >= H) return;
+    const int m = window / 2;
+    const int c0 = (ty + kMedHalo) * kMedS + tx + kMedHalo;
+    int n = 0, nd = 0;
+    for (int dy = -m; dy <= m; ++dy)
+        for (int dx = -m; dx <= m; ++dx) {
+            const int d = sd[c0 + dy * kMedS + dx];
+            nd += d; n += 1 - d;
+        }
+    float res = sv[c0];
+    if (nd > 0 && n > 0) {
+        const float w = 1.0f / (float)n;
+        float cum = 0.f;
+        int t = 0;
+        while (t < n) { cum = cum + w; ++t; if (cum > 0.5f) break; }   // t-th smallest (1-based)
+        // rank selection among the non-discontinuity values; ties broken by window position (any order gives the same value)
+        int idx_i = 0;
+        for (int dy = -m; dy <= m; ++dy)
+            for (int dx = -m; dx <= m; ++dx, ++idx_i) {
+                const int o = c0 + dy * kMedS + dx;
+                if (sd[o]) continue;
+                const float vi = sv[o];
+                int rank = 0, idx_k = 0;
+                for (int ey = -m; ey <= m; ++ey)
+                    for (int ex = -m; ex <= m; ++ex, ++idx_k) {
+                        const int p = c0 + ey * kMedS + ex;
+                        if (sd[p]) continue;
+                        const float vk = sv[p];
+                        rank += (vk < vi) | ((vk == vi) & (idx_k < idx_i));
+                    }
+                if (rank == t - 1) res = vi;
+            }
+    }
+    out[plane + (size_t)y * W + x] = res;
+}
+
+// ---- DIBR forward warp ----------------------------------------------------------------------------------------------------------
+struct WarpMats { double Ki[9], T[12], K2[9]; };
+
+// Warper.py:64-95: X = depth * Ki (x, y, 1); X' = T (X, 1); p = K2 X'  ->  (u, v, z) in fp64; also max log(1 + clip(z, 0, 1000))
+__global__ __launch_bounds__(256) void k_warp_points(const float* __restrict__ depth, int H, int W, const WarpMats M, double* uvz,
+                                                     unsigned long long* logmax_bits) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    double lg = 0.0;
+    if (t < H * W) {
+        const int yi = t / W, xi = t - yi * W;
+        const double x = (double)xi, y = (double)yi, d = (double)depth[t];
+        double cam[3], w2[3], p[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cam[r] = d * (M.Ki[r * 3] * x + M.Ki[r * 3 + 1] * y + M.Ki[r * 3 + 2] * 1.0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) w2[r] = M.T[r * 4] * cam[0] + M.T[r * 4 + 1] * cam[1] + M.T[r * 4 + 2] * cam[2] + M.T[r * 4 + 3] * 1.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) p[r] = M.K2[r * 3] * w2[0] + M.K2[r * 3 + 1] * w2[1] + M.K2[r * 3 + 2] * w2[2];
+        uvz[(size_t)t * 3] = p[0] / p[2]; uvz[(size_t)t * 3 + 1] = p[1] / p[2]; uvz[(size_t)t * 3 + 2] = p[2];
+        lg = log(1.0 + fmin(fmax(p[2], 0.0), 1000.0));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lg = fmax(lg, __shfl_xor(lg, o));
+    if ((threadIdx.x & 63) == 0 && lg > 0.0) atomicMax(logmax_bits, (unsigned long long)__double_as_longlong(lg));   // lg >= 0: bit order = value order
+}
+
+// Warper.py:97-160: inverse-bilinear splat of (r, g, b, z) and the weight into the (H+2, W+2) canvas, fp64 atomics
+__global__ __launch_bounds__(256) void k_warp_splat(const float* __restrict__ rgb, const unsigned char* __restrict__ mask1, int H, int W,
+                                                    const double* __restrict__ uvz, const unsigned long long* logmax_bits, double* canvas) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= H * W) return;
+    const double u = uvz[(size_t)t * 3], v = uvz[(size_t)t * 3 + 1], z = uvz[(size_t)t * 3 + 2];
+    const double logmax = __longlong_as_double((long long)*logmax_bits);
+    double ox = u + 1.0, oy = v + 1.0;
+    // floor / ceil -> integer -> clip, in the reference's order (a NaN / huge coordinate clips to the canvas ring)
+    const double fxd = floor(ox), fyd = floor(oy), cxd = ceil(ox), cyd = ceil(oy);
+    auto to_idx = [](double a, int hi) { if (!(a > 0.0)) return 0; if (a > (double)hi) return hi; return (int)a; };
+    const int fx = to_idx(fxd, W + 1), cx = to_idx(cxd, W + 1), fy = to_idx(fyd, H + 1), cy = to_idx(cyd, H + 1);
+    ox = fmin(fmax(ox, 0.0), (double)(W + 1)); oy = fmin(fmax(oy, 0.0), (double)(H + 1));
+    const double logd = log(1.0 + fmin(fmax(z, 0.0), 1000.0));
+    const double dw = exp(logd / logmax * 50.0);
+    const double mk = mask1 ? (mask1[t] ? 1.0 : 0.0) : 1.0;
+    double val[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) val[k] = (double)(unsigned char)(int)(rgb[(size_t)t * 3 + k] * 255.f);   // (rgb * 255).astype(uint8)
+    val[3] = z;
+    const int iy[4] = {fy, cy, fy, cy}, ix[4] = {fx, fx, cx, cx};
+    const double py[4] = {1.0 - (oy - fy), 1.0 - (cy - oy), 1.0 - (oy - fy), 1.0 - (cy - oy)};
+    const double px[4] = {1.0 - (ox - fx), 1.0 - (ox - fx), 1.0 - (cx - ox), 1.0 - (cx - ox)};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double wt = py[q] * px[q] * mk / dw;
+        double* c = canvas + ((size_t)iy[q] * (W + 2) + ix[q]) * 5;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(c + k, val[k] * wt);
+        atomicAdd(c + 4, wt);
+    }
+}
+
+// Warper.py:162-186 + utils.py:106-113: normalise, round the image to uint8 (half-to-even), earlier views win
+__global__ __launch_bounds__(256) void k_warp_resolve(const double* __restrict__ canvas, int H, int W, unsigned char* filled,
+                                                      unsigned char* image, double* depth) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= H * W) return;
+    const int y = t / W, x = t - y * W;
+    const double* c = canvas + ((size_t)(y + 1) * (W + 2) + (x + 1)) * 5;
+    const double w = c[4];
+    if (!(w > 0.0) || filled[t]) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) image[(size_t)t * 3 + k] = (unsigned char)(int)rint(fmin(fmax(c[k] / w, 0.0), 255.0));
+    depth[t] = c[3] / w;
+    filled[t] = 2;   // newly filled by this view (normalised to 1 by k_warp_mark)
+}
+__global__ __launch_bounds__(256) void k_warp_mark(unsigned char* filled, int n) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n && filled[t]) filled[t] = 1;
+}
+// utils.py:115-118: white where nothing landed, image / 255 -> fp32
+__global__ __launch_bounds__(256) void k_warp_finish(const unsigned char* __restrict__ filled, const unsigned char* __restrict__ image, int n,
+                                                     float* out_image, long long* out_mask) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const bool f = filled[t] != 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out_image[(size_t)t * 3 + k] = (float)((double)(f ? image[(size_t)t * 3 + k] : 255) / 255.0);
+    if (out_mask) out_mask[t] = f ? 1 : 0;
+}
+
+}  // namespace t2n
+
+using namespace t2n;
+
+static size_t al256i(size_t x) { return (x + 255) / 256 * 256; }
+
+extern "C" size_t t2n_image_filter_workspace_bytes(int H, int W) {
+    if (H < 3 || W < 3) return 0;
+    const size_t n = (size_t)H * W;
+    return al256i(n * 16) * 2 + al256i(n);
+}
+
+extern "C" int t2n_sparse_bilateral_filtering(const float* depth, const float* image, int H, int W, const int* filter_sizes_host, int num_iter,
+                                              float depth_threshold, float* photo_out, float* depth_out, void* workspace,
+                                              size_t workspace_bytes, t2n_stream stream) {
+    if (!depth || !image || !filter_sizes_host || !photo_out || !depth_out || !workspace || H < 3 || W < 3 || num_iter < 1) {
+        set_error("t2n_sparse_bilateral_filtering: bad argument");
+        return T2N_ERR_INVALID;
+    }
+    for (int i = 0; i < num_iter; ++i)
+        if (filter_sizes_host[i] < 1 || filter_sizes_host[i] > 2 * kMedHalo + 1 || !(filter_sizes_host[i] & 1)) {
+            set_error("t2n_sparse_bilateral_filtering: window %d not in {1,3,5,7}", filter_sizes_host[i]);
+            return T2N_ERR_UNSUPPORTED;
+        }
+    if (workspace_bytes < t2n_image_filter_workspace_bytes(H, W)) { set_error("t2n_sparse_bilateral_filtering: workspace too small"); return T2N_ERR_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    const int n = H * W;
+    float* A = (float*)workspace;
+    float* B = (float*)((char*)workspace + al256i((size_t)n * 16));
+    unsigned char* disc = (unsigned char*)workspace + 2 * al256i((size_t)n * 16);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_img_pack, dim3(nb), dim3(256), 0, s, depth, image, n, A);
+    for (int i = 0; i < num_iter; ++i) {
+        // save_depths[i] = the depth BEFORE pass i (the image list aliases ONE array, filtered in place: only its final state exists)
+        T2N_HIP(hipMemcpyAsync(depth_out + (size_t)i * n, A, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_img_disc, dim3(nb), dim3(256), 0, s, (const float*)A, depth, H, W, depth_threshold, disc);
+        hipLaunchKernelGGL(k_img_median, dim3((unsigned)((W + kMedT - 1) / kMedT), (unsigned)((H + kMedT - 1) / kMedT), 4), dim3(256), 0, s,
+                           (const float*)A, (const unsigned char*)disc, H, W, filter_sizes_host[i], B);
+        float* tmp = A; A = B; B = tmp;
+    }
+    hipLaunchKernelGGL(k_img_unpack, dim3(nb), dim3(256), 0, s, (const float*)A, n, photo_out);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" size_t t2n_warp_workspace_bytes(int H, int W) {
+    if (H < 1 || W < 1) return 0;
+    return al256i((size_t)H * W * 24) + al256i((size_t)(H + 2) * (W + 2) * 40) + 256;
+}
+
+extern "C" int t2n_warp_view(const float* rgb, const float* depth, const uint8_t* mask1, int H, int W, const double* Ki9_host,
+                             const double* T12_host, const double* K9_host, uint8_t* filled, uint8_t* image_u8, double* depth_out,
+                             void* workspace, size_t workspace_bytes, t2n_stream stream) {
+    if (!rgb || !depth || !Ki9_host || !T12_host || !K9_host || !filled || !image_u8 || !depth_out || !workspace || H < 1 || W < 1) {
+        set_error("t2n_warp_view: bad argument");
+        return T2N_ERR_INVALID;
+    }
+    if (workspace_bytes < t2n_warp_workspace_bytes(H, W)) { set_error("t2n_warp_view: workspace too small"); return T2N_ERR_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    WarpMats M;
+    memcpy(M.Ki, Ki9_host, sizeof(M.Ki)); memcpy(M.T, T12_host, sizeof(M.T)); memcpy(M.K2, K9_host, sizeof(M.K2));
+    const int n = H * W;
+    double* uvz = (double*)workspace;
+    double* canvas = (double*)((char*)workspace + al256i((size_t)n * 24));
+    unsigned long long* logmax = (unsigned long long*)((char*)canvas + al256i((size_t)(H + 2) * (W + 2) * 40));
+    T2N_HIP(hipMemsetAsync(canvas, 0, al256i((size_t)(H + 2) * (W + 2) * 40) + 256, s));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_warp_points, dim3(nb), dim3(256), 0, s, depth, H, W, M, uvz, logmax);
+    hipLaunchKernelGGL(k_warp_splat, dim3(nb), dim3(256), 0, s, rgb, mask1, H, W, (const double*)uvz, (const unsigned long long*)logmax, canvas);
+    hipLaunchKernelGGL(k_warp_resolve, dim3(nb), dim3(256), 0, s, (const double*)canvas, H, W, filled, image_u8, depth_out);
+    hipLaunchKernelGGL(k_warp_mark, dim3(nb), dim3(256), 0, s, filled, n);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_warp_finish(const uint8_t* filled, const uint8_t* image_u8, int H, int W, float* image_out, int64_t* mask_out,
+                               t2n_stream stream) {
+    if (!filled || !image_u8 || !image_out || H < 1 || W < 1) { set_error("t2n_warp_finish: bad argument"); return T2N_ERR_INVALID; }
+    const int n = H * W;
+    hipLaunchKernelGGL(k_warp_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, filled, image_u8, n, image_out,
+                       (long long*)mask_out);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}

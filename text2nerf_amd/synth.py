@@ -172,3 +172,26 @@ def concentrate_density(sd, lo_frac=(0.25, 0.3, 0.2), hi_frac=(0.7, 0.8, 0.65)):
         plane[:, :, :, :a] = 0
         plane[:, :, :, b + 1:] = 0
     return sd
+
+
+def rgbd_frame(seed, H, W, n_boxes=3, holes=0):
+    """Synthetic RGB-D view for the warp / depth-filter tests (numpy PCG64): a slanted background plane with `n_boxes`
+    fronto-parallel boxes in front of it (depth discontinuities), smooth colour gradients plus per-object tints, fp32.
+    `holes` > 0 zeroes that many random depth pixels (the filters treat depth == 0 as a discontinuity). Returns
+    (rgb [H,W,3] in [0,1], depth [H,W] in ~[2,7])."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    depth = (5.5 + 1.2 * (xx / W - 0.5) + 0.8 * (yy / H - 0.5)).astype(np.float32)
+    depth += (0.01 * g.standard_normal((H, W))).astype(np.float32)
+    rgb = np.stack([0.2 + 0.6 * xx / W, 0.3 + 0.5 * yy / H, 0.5 + 0.3 * np.sin(xx / 7.0) * np.cos(yy / 5.0)], -1).astype(np.float32)
+    for _ in range(n_boxes):
+        x0, y0 = int(g.integers(0, W - 8)), int(g.integers(0, H - 8))
+        w, h = int(g.integers(6, max(7, W // 3))), int(g.integers(6, max(7, H // 3)))
+        d = np.float32(g.uniform(2.2, 4.5))
+        sl = (slice(y0, min(H, y0 + h)), slice(x0, min(W, x0 + w)))
+        depth[sl] = d + (0.005 * g.standard_normal(depth[sl].shape)).astype(np.float32)
+        rgb[sl] = (0.5 * rgb[sl] + 0.5 * g.uniform(0, 1, 3).astype(np.float32)).astype(np.float32)
+    rgb = np.clip(rgb + (0.02 * g.standard_normal(rgb.shape)).astype(np.float32), 0, 1).astype(np.float32)
+    for _ in range(holes):
+        depth[int(g.integers(0, H)), int(g.integers(0, W))] = 0.0
+    return rgb, depth
