@@ -237,6 +237,10 @@ int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray
 int t2n_tv_grad_add(const float* param, float* grad, int C, int H, int W, float weight, t2n_stream stream);
 int t2n_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, int64_t step, t2n_stream stream);
+/* the same update for `count` tensors in one launch (host arrays of device pointers / sizes / learning rates / step numbers) */
+int t2n_adam_step_multi(int count, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                        const int64_t* sizes, const float* lrs, float beta1, float beta2, float eps, const int64_t* steps,
+                        t2n_stream stream);
 
 /* ---- coarse-to-fine / occupancy-mask maintenance between training stages.
  * t2n_compute_alpha: models/tensorBase.py:412-434 — alpha = 1 - exp(-sigma * length) at world-space points [n,3]; sigma = 0

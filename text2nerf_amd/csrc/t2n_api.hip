@@ -51,30 +51,39 @@ static void timing_flush(t2n_field* f) {
 }
 
 // [1,C,H,W] -> [H][W][C]   (lines: W == 1)
-// dsth != NULL (bf16 factor storage): round to nearest-even bf16; dst gets the rounded value as fp32, dsth the 2-byte texel
+// Reference layout [C][HW] -> channel-last [HW][C] through an LDS tile of 64 texels (coalesced on both sides).
+// dsth != NULL (bf16 factor storage): round to nearest-even bf16; dst gets the rounded value as fp32, dsth the 2-byte texel.
 __global__ __launch_bounds__(256) void k_relayout(const float* __restrict__ src, float* __restrict__ dst, unsigned short* __restrict__ dsth,
                                                   int C, long long HW) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= HW * C) return;
-    const long long pix = t / C;
-    const int c = (int)(t - pix * C);
-    float v = src[(long long)c * HW + pix];
-    if (dsth) {
-        unsigned b = __float_as_uint(v);
-        if ((b & 0x7fffffffu) <= 0x7f800000u) b += 0x7fffu + ((b >> 16) & 1u);   // RNE (NaN payloads pass through truncated)
-        b &= 0xffff0000u;
-        dsth[t] = (unsigned short)(b >> 16);
-        v = __uint_as_float(b);
+    __shared__ float tile[64 * 49];                      // [64 texels][C + 1], C <= 48
+    const long long pix0 = (long long)blockIdx.x * 64;
+    const int lp = threadIdx.x & 63, cs = threadIdx.x >> 6;
+    const int ld = C + 1;
+    if (pix0 + lp < HW)
+        for (int c = cs; c < C; c += 4) tile[lp * ld + c] = src[(long long)c * HW + pix0 + lp];
+    __syncthreads();
+    const long long n = (HW - pix0 < 64 ? HW - pix0 : 64) * C;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int px = i / C, c = i - px * C;
+        float v = tile[px * ld + c];
+        const long long t = pix0 * C + i;
+        if (dsth) {
+            unsigned b = __float_as_uint(v);
+            if ((b & 0x7fffffffu) <= 0x7f800000u) b += 0x7fffu + ((b >> 16) & 1u);   // RNE (NaN payloads pass through truncated)
+            b &= 0xffff0000u;
+            dsth[t] = (unsigned short)(b >> 16);
+            v = __uint_as_float(b);
+        }
+        dst[t] = v;
     }
-    dst[t] = v;
 }
 
 static int relayout_one(const float* src, float** dst, void** dsth, bool half, int C, long long HW, hipStream_t s) {
     if (!src) { set_error("t2n_field_upload: NULL factor tensor"); return T2N_ERR_INVALID; }
     if (!*dst) T2N_HIP(hipMalloc((void**)dst, (size_t)HW * C * sizeof(float)));
     if (half && !*dsth) T2N_HIP(hipMalloc(dsth, (size_t)HW * C * 2 + 16));
-    const long long n = HW * C;
-    hipLaunchKernelGGL(k_relayout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, *dst, half ? (unsigned short*)*dsth : nullptr, C, HW);
+    if (C > 48) { set_error("t2n_field_upload: %d channels > 48", C); return T2N_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(k_relayout, dim3((unsigned)((HW + 63) / 64)), dim3(256), 0, s, src, *dst, half ? (unsigned short*)*dsth : nullptr, C, HW);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

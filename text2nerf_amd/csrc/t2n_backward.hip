@@ -885,12 +885,20 @@ __global__ __launch_bounds__(256) void k_bwd_app_scatter(const AppScatterArgs a)
     }
 }
 
-// channel-last gradient buffer [HW][C] -> += reference layout [1,C,H,W]
+// channel-last gradient buffer [HW][C] -> += reference layout [1,C,H,W], through an LDS tile of 64 texels
 __global__ __launch_bounds__(256) void k_relayout_add(const float* __restrict__ src, float* dst, int C, long long HW) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= HW * C) return;
-    const long long c = t / HW, pix = t - c * HW;
-    dst[t] += src[pix * C + c];
+    __shared__ float tile[64 * 49];
+    const long long pix0 = (long long)blockIdx.x * 64;
+    const int ld = C + 1;
+    const long long n = (HW - pix0 < 64 ? HW - pix0 : 64) * C;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int px = i / C, c = i - px * C;
+        tile[px * ld + c] = src[pix0 * C + i];
+    }
+    __syncthreads();
+    const int lp = threadIdx.x & 63, cs = threadIdx.x >> 6;
+    if (pix0 + lp < HW)
+        for (int c = cs; c < C; c += 4) dst[(long long)c * HW + pix0 + lp] += tile[lp * ld + c];
 }
 
 // Activation / gradient rows of the backward pass. Buffers whose lifetimes do not overlap (or that are rewritten
@@ -1183,10 +1191,10 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     // 6. channel-last gradient buffers -> += reference layouts
     for (int k = 0; k < 3; ++k) {
         const long long HW = (long long)gr[mat1(k)] * gr[mat0(k)], L = gr[vecm(k)];
-        if (g->density_plane[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((HW * 16 + 255) / 256)), dim3(256), 0, s, (const float*)f->gbuf_den_plane[k], g->density_plane[k], 16, HW);
-        if (g->density_line[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((L * 16 + 255) / 256)), dim3(256), 0, s, (const float*)f->gbuf_den_line[k], g->density_line[k], 16, L);
-        if (g->app_plane[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((HW * 48 + 255) / 256)), dim3(256), 0, s, (const float*)f->gbuf_app_plane[k], g->app_plane[k], 48, HW);
-        if (g->app_line[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((L * 48 + 255) / 256)), dim3(256), 0, s, (const float*)f->gbuf_app_line[k], g->app_line[k], 48, L);
+        if (g->density_plane[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((HW + 63) / 64)), dim3(256), 0, s, (const float*)f->gbuf_den_plane[k], g->density_plane[k], 16, HW);
+        if (g->density_line[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((L + 63) / 64)), dim3(256), 0, s, (const float*)f->gbuf_den_line[k], g->density_line[k], 16, L);
+        if (g->app_plane[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((HW + 63) / 64)), dim3(256), 0, s, (const float*)f->gbuf_app_plane[k], g->app_plane[k], 48, HW);
+        if (g->app_line[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((L + 63) / 64)), dim3(256), 0, s, (const float*)f->gbuf_app_line[k], g->app_line[k], 48, L);
     }
     T2N_HIP(hipGetLastError());
     return T2N_OK;

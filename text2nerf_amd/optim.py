@@ -44,9 +44,15 @@ class TVAdam(torch.optim.Optimizer):
                 with torch.cuda.device(p.device):
                     _lib.check(lib.t2n_tv_grad_add(_lib.ptr(p), _lib.ptr(p.grad), C, H, W, float(weight) * 1e-2,
                                                    _lib.current_stream_ptr(p.device)), "t2n_tv_grad_add")
-        # 2. Adam
+        # 2. Adam: every parameter tensor in one launch (same betas / eps across groups, per-tensor lr and step)
+        import ctypes as C
+        ps, lrs, steps = [], [], []
+        betas, eps, dev = None, None, None
         for group in self.param_groups:
-            b1, b2 = group["betas"]
+            if betas is None:
+                betas, eps = tuple(group["betas"]), float(group["eps"])
+            elif tuple(group["betas"]) != betas or float(group["eps"]) != eps:
+                raise _lib.T2NError("TVAdam: all parameter groups must share betas and eps")
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -58,9 +64,19 @@ class TVAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
-                with torch.cuda.device(p.device):
-                    _lib.check(lib.t2n_adam_step(_lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(st["exp_avg"]),
-                                                 _lib.ptr(st["exp_avg_sq"]), p.numel(), float(group["lr"]), float(b1),
-                                                 float(b2), float(group["eps"]), st["step"],
-                                                 _lib.current_stream_ptr(p.device)), "t2n_adam_step")
-                _bump_version(p)   # changed in place through a raw pointer: the field keys its re-upload on _version
+                ps.append(p); lrs.append(float(group["lr"])); steps.append(int(st["step"]))
+                dev = p.device
+        if not ps:
+            return
+        n = len(ps)
+        VP = C.c_void_p * n
+        arr = lambda f: VP(*[f(p) for p in ps])      # noqa: E731
+        with torch.cuda.device(dev):
+            _lib.check(lib.t2n_adam_step_multi(n, arr(lambda p: p.data_ptr()), arr(lambda p: p.grad.data_ptr()),
+                                               arr(lambda p: self.state[p]["exp_avg"].data_ptr()),
+                                               arr(lambda p: self.state[p]["exp_avg_sq"].data_ptr()),
+                                               (C.c_int64 * n)(*[p.numel() for p in ps]), (C.c_float * n)(*lrs), float(betas[0]),
+                                               float(betas[1]), eps, (C.c_int64 * n)(*steps), _lib.current_stream_ptr(dev)),
+                       "t2n_adam_step_multi")
+        for p in ps:
+            _bump_version(p)   # changed in place through a raw pointer: the field keys its re-upload on _version
