@@ -94,7 +94,7 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None):
     forward/backward, one flat gradient all-reduce (text2nerf_amd.parallel.allreduce_gradients), identical optimiser step."""
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    from text2nerf_amd import OctreeRender_trilinear_fast, synth
+    from text2nerf_amd import OctreeRender_trilinear_fast, synth, to_device_async
     from text2nerf_amd.losses import TVLoss, TransMittanceLoss_mask
     field, params, aabb = build_field(dev)
     n_samples = min(int(1e6), int(synth.cal_n_samples([300] * 3, 1.0) / 2))          # text2nerf_main.py:439 -> 259
@@ -132,7 +132,9 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None):
         idx = perm[(k * batch) % (perm.numel() - batch):][:batch]
         if dist is not None:
             idx = idx[lo:hi]
-        rays, rgb_t, dep_t = allrays[idx], allrgb[idx].to(dev), alldepth[idx].to(dev)
+        # targets go host -> device like text2nerf_main.py:550-553, through the pinned staging ring (a pageable .to(device)
+        # drains the stream first and idles the GPU for the rest of the host-side batch preparation)
+        rays, rgb_t, dep_t = allrays[idx], to_device_async(allrgb[idx], dev), to_device_async(alldepth[idx], dev)
         rgb, _, depth, w, z = OctreeRender_trilinear_fast(rays, field, chunk=max(int(rays.shape[0]), 1), N_samples=n_samples, white_bg=True,
                                                           ndc_ray=False, device=dev, is_train=True)
         loss = torch.mean((rgb - rgb_t) ** 2) + 0.005 * torch.mean((depth - dep_t) ** 2)
