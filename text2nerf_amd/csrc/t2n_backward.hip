@@ -368,16 +368,24 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
 
 
 // (2) single workgroup: exclusive scan of the [tile][copy] histogram -> absolute cursors (in place), tile starts, and the
-// segment list of the accumulate pass.
+// segment list of the accumulate pass. The histogram is pulled into LDS with coalesced loads first (LDS = true) so the
+// per-thread serial runs do not chain ~70 dependent global round trips.
+template <bool LDS>
 __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, unsigned* tile_start, int4* segs, unsigned* nseg_out,
                                                    unsigned seg_cap) {
+    extern __shared__ unsigned sh_hist[];
     __shared__ unsigned sh[1024];
     const int t = threadIdx.x;
     const int n = n_tiles * kBinCopies;
+    if (LDS) {
+        for (int i = t; i < n; i += 1024) sh_hist[i] = hist[i];
+        __syncthreads();
+    }
+    unsigned* H = LDS ? sh_hist : hist;
     const int per = (n + 1023) / 1024;
     const int b = t * per, e = min(n, b + per);
     unsigned sum = 0;
-    for (int i = b; i < e; ++i) sum += hist[i];
+    for (int i = b; i < e; ++i) sum += H[i];
     sh[t] = sum;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -387,19 +395,24 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
         __syncthreads();
     }
     unsigned run = sh[t] - sum;
+    const unsigned total = sh[1023];
     for (int i = b; i < e; ++i) {
-        const unsigned c = hist[i];
-        hist[i] = run;
-        if ((i & (kBinCopies - 1)) == 0) tile_start[i / kBinCopies] = run;
+        const unsigned c = H[i];
+        H[i] = run;
         run += c;
     }
-    if (t == 1023) tile_start[n_tiles] = sh[1023];
     __syncthreads();
-    // segments: tile j -> ceil(count / kBinSeg) work items
+    if (LDS) for (int i = t; i < n; i += 1024) hist[i] = sh_hist[i];
+    // tile starts (+ sentinel) and the segment count per tile
     const int pt = (n_tiles + 1023) / 1024;
     const int tb = t * pt, te = min(n_tiles, tb + pt);
     unsigned ns = 0;
-    for (int j = tb; j < te; ++j) ns += (tile_start[j + 1] - tile_start[j] + kBinSeg - 1) / kBinSeg;
+    for (int j = tb; j < te; ++j) {
+        const unsigned s0 = H[j * kBinCopies], s1 = j + 1 < n_tiles ? H[(j + 1) * kBinCopies] : total;
+        tile_start[j] = s0;
+        ns += (s1 - s0 + kBinSeg - 1) / kBinSeg;
+    }
+    if (t == 0) tile_start[n_tiles] = total;
     __syncthreads();
     sh[t] = ns;
     __syncthreads();
@@ -411,13 +424,23 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
     }
     unsigned si = sh[t] - ns;
     for (int j = tb; j < te; ++j) {
-        const unsigned s0 = tile_start[j], s1 = tile_start[j + 1];
+        const unsigned s0 = H[j * kBinCopies], s1 = j + 1 < n_tiles ? H[(j + 1) * kBinCopies] : total;
         for (unsigned s = s0; s < s1; s += kBinSeg) {
             if (si < seg_cap) segs[si] = make_int4(j, (int)s, (int)min(s1, s + kBinSeg), 0);
             ++si;
         }
     }
     if (t == 1023) *nseg_out = min(sh[1023], seg_cap);
+}
+static void launch_bin_scan(unsigned* hist, int n_tiles, unsigned* tile_start, int4* segs, unsigned* nseg, unsigned seg_cap, hipStream_t s) {
+    const size_t lds = (size_t)n_tiles * kBinCopies * 4;
+    if (lds <= 150 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_bin_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        hipLaunchKernelGGL((k_bin_scan<true>), dim3(1), dim3(1024), lds, s, hist, n_tiles, tile_start, segs, nseg, seg_cap);
+    } else {
+        hipLaunchKernelGGL((k_bin_scan<false>), dim3(1), dim3(1024), 0, s, hist, n_tiles, tile_start, segs, nseg, seg_cap);
+    }
 }
 
 // (3) per ray (same ray -> wave -> copy map as the counting pass): write the records into their tiles' runs
@@ -630,15 +653,24 @@ __global__ __launch_bounds__(256) void k_bwd_l2(const float4* __restrict__ go, c
     const float w0 = w2[u], w1 = w2[128 + u], w2v = w2[256 + u];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
     const long long r0 = (long long)blockIdx.x * 64 + half * 32;
-    for (int k = 0; k < 32; ++k) {
-        const long long r = r0 + k;
-        if (r >= rows) break;
-        const float4 g = go[r];
-        const float h = h1[r * 128 + u];
-        a0 = fmaf(g.x, h, a0); a1 = fmaf(g.y, h, a1); a2 = fmaf(g.z, h, a2);
-        s0 += g.x; s1 += g.y; s2 += g.z;
-        const float v = fmaf(g.z, w2v, fmaf(g.y, w1, g.x * w0));
-        g1[r * 128 + u] = h > 0.f ? v : 0.f;
+    for (int k = 0; k < 32; k += 4) {           // four rows in flight per thread (the loop is load-latency bound)
+        float4 g[4]; float h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long r = r0 + k + q;
+            const bool ok = r < rows;
+            g[q] = ok ? go[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+            h[q] = ok ? h1[r * 128 + u] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long r = r0 + k + q;
+            if (r >= rows) break;
+            a0 = fmaf(g[q].x, h[q], a0); a1 = fmaf(g[q].y, h[q], a1); a2 = fmaf(g[q].z, h[q], a2);
+            s0 += g[q].x; s1 += g[q].y; s2 += g[q].z;
+            const float v = fmaf(g[q].z, w2v, fmaf(g[q].y, w1, g[q].x * w0));
+            g1[r * 128 + u] = h[q] > 0.f ? v : 0.f;
+        }
     }
     if (dw2) { atomicAdd(&dw2[u], a0); atomicAdd(&dw2[128 + u], a1); atomicAdd(&dw2[256 + u], a2); }
     if (db2 && u == 0) { atomicAdd(&db2[0], s0); atomicAdd(&db2[1], s1); atomicAdd(&db2[2], s2); }
@@ -1117,8 +1149,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             T2N_HIP(hipMemsetAsync(a.hist, 0, (size_t)geom.total * kBinCopies * 4, s));
             if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true, true>), dim3(nb), dim3(256), lds, s, a);
             else hipLaunchKernelGGL((k_bwd_march<false, true>), dim3(nb), dim3(256), lds, s, a);
-            hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, a.hist, geom.total, (unsigned*)(bw + b.tile_start),
-                               (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap);
+            launch_bin_scan(a.hist, geom.total, (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, s);
             BinArgs ba;
             ba.F = f->dev; ba.geom = geom; ba.rays = rays; ba.n_rays = n_rays; ba.ray_stride = ray_stride; ba.n_samples = n_samples;
             ba.jitter = jitter; ba.gfeat = a.gfeat; ba.ray_app = a.ray_app; ba.cursor = a.hist; ba.recs = (float4*)(bw + b.recs);
@@ -1169,8 +1200,8 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             T2N_HIP(hipMemsetAsync(ab.hist, 0, (size_t)ab.geom.total * kBinCopies * 4, s));
             const unsigned nbk = (unsigned)((rows + 255) / 256);
             hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, s, ab);
-            hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, ab.hist, ab.geom.total, (unsigned*)(bw + b.a_tile_start),
-                               (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg), b.a_seg_cap);
+            launch_bin_scan(ab.hist, ab.geom.total, (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),
+                            b.a_seg_cap, s);
             hipLaunchKernelGGL((k_app_bin<1>), dim3(nbk), dim3(256), 0, s, ab);
             TileAccumArgs ta;
             ta.S = f->dev.app; ta.G = sa.gapp; ta.geom = ab.geom; ta.segs = (const int4*)(bw + b.a_segs);
