@@ -61,7 +61,7 @@ def build_field(dev, scene="S1-soft", seed=0, grid=300):
     return m, params, aabb
 
 
-def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0):
+def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0, check=None):
     """The oracle's plain-C port (oracle/oracle_c.c, OpenMP over rays) timed on the host cores on the SAME workload: whole
     800x800 frames, repeated until ~budget_s of host work (at most 4 frames; fewer rays if one frame would take minutes)."""
     from oracle import oracle_torch as O
@@ -78,13 +78,22 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0):
     rays = synth.frame_rays_np(800, 800, stride=stride)
     done, frames, t0 = 0, 0, time.time()
     while frames < 4 and (frames == 0 or time.time() - t0 < budget_s):
-        co.render(rays, n_samples=n_samples, want_weights=False)
+        o_rgb, o_depth, _, _ = co.render(rays, n_samples=n_samples, want_weights=False)
         done += rays.shape[0]
         frames += 1
     dt = time.time() - t0
-    return {"value": done * n_samples / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
-            "sample": f"{frames} x {rays.shape[0]} rays (800x800 frame, pixel stride {stride}) x {n_samples} samples, "
-                      f"oracle_c (plain C, OpenMP {cores} threads), {dt:.1f} s"}
+    out = {"value": done * n_samples / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
+           "sample": f"{frames} x {rays.shape[0]} rays (800x800 frame, pixel stride {stride}) x {n_samples} samples, "
+                     f"oracle_c (plain C, OpenMP {cores} threads), {dt:.1f} s"}
+    if check is not None:   # the oracle as the checker: the HIP render of the SAME rays against it, whole frame (untimed)
+        h_rgb, h_depth = check(torch.from_numpy(rays))
+        e = np.abs(h_rgb - o_rgb)
+        out["parity_vs_oracle"] = {"rays": int(rays.shape[0]), "max_abs_rgb_err": float(e.max()),
+                                   "rays_over_1e-4": int((e.max(1) > 1e-4).sum()),
+                                   "max_abs_depth_err": float(np.abs(h_depth - o_depth).max()),
+                                   "evaluated_samples_equal": None}
+        out["parity_vs_oracle"]["oracle_evaluated"] = co.last_stats["evaluated"]
+    return out
 
 
 def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None):
@@ -338,7 +347,16 @@ def main():
             out["config"].update(train_bench(dev))
             out["config"].update(train_bench(dev, fused_optim=True))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(params, aabb, 300, N)
+            def hip_render(r):
+                with torch.no_grad():
+                    a, b, _, _ = field(r.to(dev), white_bg=True, is_train=False, N_samples=-1)
+                hip_render.evaluated = field.stats()["evaluated"]
+                return a.cpu().numpy(), b.cpu().numpy()
+            field.factor_storage = args.factor_storage
+            out["cpu_baseline"] = cpu_baseline(params, aabb, 300, N, check=hip_render)
+            pv = out["cpu_baseline"].get("parity_vs_oracle")
+            if pv:
+                pv["evaluated_samples_equal"] = bool(pv.pop("oracle_evaluated") == hip_render.evaluated)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
