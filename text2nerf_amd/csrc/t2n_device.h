@@ -202,7 +202,8 @@ __device__ __forceinline__ void issue_taps_ax(const FactorSet& S, int CQ, int q,
     const unsigned W = (unsigned)S.W[K];
     constexpr unsigned QB = HALF ? 8u : 16u;
     const unsigned tb = (unsigned)CQ * QB, qb = (unsigned)q * QB;
-    const unsigned r0 = (unsigned)ay.i0 * W, r1 = (unsigned)ay.i1 * W;
+    // 24-bit multiplies: full-rate VALU ops (v_mul_lo_u32 is quarter rate); tap indices and widths are < 2^24
+    const unsigned r0 = __umul24((unsigned)ay.i0, W), r1 = __umul24((unsigned)ay.i1, W);
     if constexpr (HALF) {
         const char* __restrict__ P = reinterpret_cast<const char*>(S.plane_h[K]);
         const char* __restrict__ Ln = reinterpret_cast<const char*>(S.line_h[K]);

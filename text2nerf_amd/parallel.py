@@ -92,10 +92,11 @@ def broadcast_parameters(params, src=0, group=None):
     params = list(params)
     if not params:
         return
-    flat = torch.cat([p.data.reshape(-1) for p in params])
-    dist.broadcast(flat, src=src, group=group)
-    off = 0
-    for p in params:
-        n = p.numel()
-        p.data.copy_(flat[off:off + n].view_as(p.data))
-        off += n
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))   # in-place on the parameter itself: bumps its version, so the native field
+            off += n                                 # re-uploads (a write through .data would leave a stale device copy)
