@@ -544,3 +544,56 @@ def test_g7a_alpha_mask_branch(tiny, tiny_params):
         r2 = f2(rays)
         r1 = f(rays)
     assert torch.equal(r1[0], r2[0]) and torch.equal(r1[3], r2[3])
+
+
+def test_c1_config_128_grid_200x200_n64_whole_frame_vs_oracles():
+    """BASELINE.json configs[0]: TensorVMSplit 128^3, 200x200 view, 64 samples/ray — the whole frame against the plain-C
+    oracle, a subset against the PyTorch oracle (weights / z_vals too)."""
+    from oracle import oracle_torch as O
+    from oracle.oracle_c import COracle
+    aabb = [[-8.0] * 3, [8.0] * 3]
+    params = synth.make_field_params(3, [128] * 3, scene="S2", aabb=aabb)
+    f = make_field(params, [128] * 3, aabb, [0.5, 8.0])
+    assert f.nSamples == 220                                      # golden G9: update_stepSize at 128^3
+    rays_np = synth.frame_rays_np(200, 200, c2w=synth.look_pose(0.2, -0.1, (0.3, 0.1, -0.5)))
+    rays = torch.from_numpy(rays_np)
+    with torch.no_grad():
+        rgb, depth, z, w = f(rays, N_samples=64)
+    cfg = O.FieldConfig(aabb=aabb, grid_size=[128] * 3)
+    co = COracle(cfg, params)
+    c_rgb, c_depth, c_z, c_w = co.render(rays_np, n_samples=64)
+    assert f.stats()["evaluated"] == co.last_stats["evaluated"]
+    close(rgb, c_rgb, atol=RGB_ATOL)
+    close(depth, c_depth, atol=DEPTH_ATOL)
+    close(z, c_z, atol=0)
+    close(w, c_w, atol=W_ATOL, rtol=W_RTOL)
+    sel = np.sort(np.random.Generator(np.random.PCG64(4)).choice(rays_np.shape[0], 3000, replace=False))
+    o_rgb, o_depth, o_z, o_w = O.forward(cfg, O.params_from_numpy(params), rays[sel], n_samples=64)
+    close(rgb[sel], o_rgb.numpy(), atol=RGB_ATOL)
+    close(w[sel], o_w.numpy(), atol=W_ATOL, rtol=W_RTOL)
+    assert f.stats()["appearance"] / rays_np.shape[0] > 2.0      # S2 (fog): a high appearance fraction
+
+
+def test_c4_shape_1600x1600_eight_ray_tiles_equal_whole_frame():
+    """BASELINE.json configs[3]: 1600x1600 render of the 300^3 scene split into 8 ray tiles (what 8 ranks render before the
+    all-gather): the concatenated tiles are bitwise the single-launch frame; ragged tile sizes included."""
+    from text2nerf_amd.parallel import shard_bounds
+    aabb = [[-8.0] * 3, [8.0] * 3]
+    f = make_field(synth.make_field_params(0, [300] * 3, scene="S1-soft", aabb=aabb), [300] * 3, aabb, [0.5, 8.0])
+    f.materialize_weights = False
+    from text2nerf_amd import generate_rays
+    rays = generate_rays(1600, 1600, [1600.0, 1600.0, 800, 800], np.eye(4, dtype=np.float32), device=dev())
+    R = rays.shape[0]
+    assert R == 2560000
+    with torch.no_grad():
+        rgb, depth, _, _ = f(rays)
+        whole_stats = f.stats()
+        parts, ev = [], 0
+        for r in range(8):
+            lo, hi = shard_bounds(R - 3, 8, r)                    # ragged: the last three rays form a ninth sliver
+            parts.append(f(rays[lo:hi]))
+            ev += f.stats()["evaluated"]
+        parts.append(f(rays[R - 3:]))
+        ev += f.stats()["evaluated"]
+    assert torch.equal(torch.cat([p[0] for p in parts]), rgb) and torch.equal(torch.cat([p[1] for p in parts]), depth)
+    assert ev == whole_stats["evaluated"]
