@@ -182,6 +182,13 @@ int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_
                        const float* jitter, float* rgb, float* depth, float* weights, float* z_vals, uint64_t* stats,
                        void* workspace, size_t workspace_bytes, t2n_stream stream);
 
+/* dda + ray_marcher (dataLoader/ray_utils.py:174-228): the AABB-clipped linspace sampler (no call sites in this driver; the
+ * live sampler is inside t2n_render_forward). bbox_host = {min xyz, max xyz} or NULL (then near/far = ray columns 6, 7);
+ * steps [n_samples] = torch.linspace(0, 1, n_samples) on the device; perturb [n, n_samples] = perturb * U[0,1) draws or NULL.
+ * Outputs (any may be NULL): xyz [n, n_samples, 3], z_vals [n, n_samples], near_far [n, 2] (dda's t_min, t_max). */
+int t2n_ray_marcher(const float* rays, int64_t n, int ray_stride, int n_samples, int lindisp, const float* bbox_host,
+                    const float* steps, const float* perturb, float* xyz, float* z_vals, float* near_far, t2n_stream stream);
+
 /* ---- f-2: frame post-processing of `evaluation` / `evaluation_path` (renderer.py:91-113,168-176; utils.py:241-257) on the
  * device: rgb8 [n,3] = uint8(255 * clamp(rgb,0,1)) (truncation); depth8 [n,3] = OpenCV COLORMAP_JET (B,G,R) of
  * uint8(255 * max((nan_to_num(d) - mi) / (ma - mi + 1e-8), 0)) with d = max((depth - depth_sub) + depth_add, 0) when

@@ -519,3 +519,25 @@ def postprocess_frame(rgb, depth, near_far, push_depth=None, gt_rgb=None):
         psnr = -10.0 * np.log(loss) / np.log(10.0)
     rgb8 = (rgb * 255).astype(np.uint8)
     return rgb8, depth8, psnr
+
+
+# ---- dda / ray_marcher (dataLoader/ray_utils.py:174-228): the AABB-clipped linspace sampler (no call sites in the driver) ----
+def dda(rays_o, rays_d, bbox):
+    """:174-181. bbox [2,3]. Returns (t_min [N,1], t_max [N,1])."""
+    inv = 1.0 / (rays_d + 1e-6)
+    t0, t1 = (bbox[0] - rays_o) * inv, (bbox[1] - rays_o) * inv
+    return (torch.minimum(t0, t1).max(-1, keepdim=True)[0], torch.maximum(t0, t1).min(-1, keepdim=True)[0])
+
+
+def ray_marcher(rays, n_samples=64, lindisp=False, perturb_draws=None, bbox=None):
+    """:184-228 with the perturbation draws handed in (already scaled by `perturb`). Returns (xyz [N,S,3], z_vals [N,S])."""
+    o, d = rays[:, 0:3], rays[:, 3:6]
+    near, far = (rays[:, 6:7], rays[:, 7:8]) if bbox is None else dda(o, d, bbox)
+    s = torch.linspace(0, 1, n_samples)
+    z = near * (1 - s) + far * s if not lindisp else 1 / (1 / near * (1 - s) + 1 / far * s)
+    z = z.expand(rays.shape[0], n_samples)
+    if perturb_draws is not None:
+        mid = 0.5 * (z[:, :-1] + z[:, 1:])
+        upper, lower = torch.cat([mid, z[:, -1:]], -1), torch.cat([z[:, :1], mid], -1)
+        z = lower + (upper - lower) * perturb_draws
+    return o[:, None, :] + d[:, None, :] * z[:, :, None], z

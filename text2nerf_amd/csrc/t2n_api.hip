@@ -241,6 +241,49 @@ __global__ __launch_bounds__(256) void k_frame_post(const float* __restrict__ rg
     }
 }
 
+// ---- dda + ray_marcher (dataLoader/ray_utils.py:174-228): the AABB-clipped linspace sampler — no call sites in this driver
+// (the live path is TensorBase.sample_ray), provided for the file's completeness. Thread per (ray, sample).
+// dda: inv = 1 / (d + 1e-6); t0 = (bbox_min - o) * inv, t1 = (bbox_max - o) * inv; near = max_xyz(min(t0,t1)), far = min_xyz(max(t0,t1)).
+// ray_marcher: z = near (1 - s) + far s  (or 1 / (1/near (1 - s) + 1/far s) with lindisp), s = torch.linspace(0,1,S) handed in;
+// optional perturbation draws u [n,S]: mid-point intervals (:211-218); xyz = o + d z.
+struct MarcherArgs {
+    const float* rays; long long n; int stride; int S; int lindisp; int use_bbox; float bmin[3], bmax[3];
+    const float* steps; const float* perturb; float* xyz; float* z_vals; float* near_far;
+};
+__device__ __forceinline__ void dda_ray(const MarcherArgs& a, const float* r, float& tn, float& tf) {
+    float lo = -3.402823466e38f, hi = 3.402823466e38f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float inv = 1.0f / (r[3 + k] + 1e-6f);
+        const float t0 = (a.bmin[k] - r[k]) * inv, t1 = (a.bmax[k] - r[k]) * inv;
+        lo = fmaxf(lo, fminf(t0, t1)); hi = fminf(hi, fmaxf(t0, t1));
+    }
+    tn = lo; tf = hi;
+}
+__device__ __forceinline__ float marcher_z(const MarcherArgs& a, float tn, float tf, int j) {
+    const float s = a.steps[j];
+    if (!a.lindisp) return tn * (1.f - s) + tf * s;
+    return 1.f / (1.f / tn * (1.f - s) + 1.f / tf * s);
+}
+__global__ __launch_bounds__(256) void k_ray_marcher(const MarcherArgs a) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n * a.S) return;
+    const long long i = t / a.S;
+    const int j = (int)(t - i * a.S);
+    const float* r = a.rays + i * a.stride;
+    float tn, tf;
+    if (a.use_bbox) dda_ray(a, r, tn, tf); else { tn = r[6]; tf = r[7]; }
+    if (a.near_far && j == 0) { a.near_far[i * 2] = tn; a.near_far[i * 2 + 1] = tf; }
+    float z = marcher_z(a, tn, tf, j);
+    if (a.perturb) {
+        const float zl = j > 0 ? marcher_z(a, tn, tf, j - 1) : z, zu = j < a.S - 1 ? marcher_z(a, tn, tf, j + 1) : z;
+        const float lower = j > 0 ? 0.5f * (zl + z) : z, upper = j < a.S - 1 ? 0.5f * (z + zu) : z;
+        z = lower + (upper - lower) * a.perturb[t];
+    }
+    if (a.z_vals) a.z_vals[t] = z;
+    if (a.xyz) { a.xyz[t * 3] = r[0] + r[3] * z; a.xyz[t * 3 + 1] = r[1] + r[4] * z; a.xyz[t * 3 + 2] = r[2] + r[5] * z; }
+}
+
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx) {
@@ -371,6 +414,20 @@ extern "C" int t2n_frame_postprocess(const float* rgb, const float* depth, int64
     const float den = (float)((double)ma - (double)mi + 1e-8);   // numpy: python-float scalar rounded to the array's fp32
     hipLaunchKernelGGL(k_frame_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rgb, depth, (long long)n,
                        depth_sub, depth_add, shift_clamp, mi, den, rgb8, depth8, gt_rgb, gt_rgb ? sq_err_sum : nullptr);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_ray_marcher(const float* rays, int64_t n, int ray_stride, int n_samples, int lindisp, const float* bbox_host,
+                               const float* steps, const float* perturb, float* xyz, float* z_vals, float* near_far, t2n_stream stream) {
+    if (!rays || n < 0 || n_samples < 1 || !steps || ray_stride < (bbox_host ? 6 : 8)) { set_error("t2n_ray_marcher: bad argument"); return T2N_ERR_INVALID; }
+    if (n == 0) return T2N_OK;
+    MarcherArgs a;
+    a.rays = rays; a.n = n; a.stride = ray_stride; a.S = n_samples; a.lindisp = lindisp ? 1 : 0; a.use_bbox = bbox_host ? 1 : 0;
+    for (int k = 0; k < 3; ++k) { a.bmin[k] = bbox_host ? bbox_host[k] : 0.f; a.bmax[k] = bbox_host ? bbox_host[3 + k] : 0.f; }
+    a.steps = steps; a.perturb = perturb; a.xyz = xyz; a.z_vals = z_vals; a.near_far = near_far;
+    const long long tot = (long long)n * n_samples;
+    hipLaunchKernelGGL(k_ray_marcher, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

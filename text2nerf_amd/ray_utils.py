@@ -48,3 +48,42 @@ def generate_rays(H, W, intrinsic, c2w, device="cuda"):
         _lib.check(lib.t2n_generate_rays(H, W, fx, fy, cx, cy, _c2w_host(c2w), _lib.ptr(out),
                                          _lib.current_stream_ptr(out.device)), "t2n_generate_rays")
     return out
+
+
+def _marcher(rays, N_samples, lindisp, perturb, bbox_3D, want_xyz=True):
+    lib = _lib.load()
+    # the reference draws the perturbation on the rays' own device generator (:217) — CPU rays consume the CPU stream
+    pr = perturb * torch.rand((rays.shape[0], N_samples), device=rays.device) if perturb > 0 else None
+    r = rays.contiguous().float()
+    if r.device.type != "cuda":
+        r = r.cuda()
+    dev = r.device
+    n = r.shape[0]
+    steps = torch.linspace(0, 1, N_samples, device=dev)
+    pr = pr.to(dev).float().contiguous() if pr is not None else None
+    bb = None
+    if bbox_3D is not None:
+        b = torch.as_tensor(bbox_3D, dtype=torch.float32).detach().cpu().reshape(2, 3)
+        bb = (C.c_float * 6)(*b.reshape(-1).tolist())
+    xyz = torch.empty(n, N_samples, 3, device=dev) if want_xyz else None
+    z = torch.empty(n, N_samples, device=dev)
+    nf = torch.empty(n, 2, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.t2n_ray_marcher(_lib.ptr(r), n, r.shape[1], int(N_samples), 1 if lindisp else 0, bb, _lib.ptr(steps),
+                                       _lib.ptr(pr), _lib.ptr(xyz), _lib.ptr(z), _lib.ptr(nf), _lib.current_stream_ptr(dev)),
+                   "t2n_ray_marcher")
+    return r, xyz, z, nf
+
+
+def dda(rays_o, rays_d, bbox_3D):
+    """dataLoader/ray_utils.py:174-181: slab intersection of rays with the box; returns (t_min [N,1], t_max [N,1])."""
+    rays = torch.cat([rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)], 1)
+    _, _, _, nf = _marcher(rays, 1, False, 0, bbox_3D, want_xyz=False)
+    return nf[:, 0:1], nf[:, 1:2]
+
+
+def ray_marcher(rays, N_samples=64, lindisp=False, perturb=0, bbox_3D=None):
+    """dataLoader/ray_utils.py:184-228: N_samples evenly spaced between the box entry and exit of every ray (or between the
+    ray's own near/far columns 6,7 without a box). Returns (xyz [N,S,3], rays_o, rays_d, z_vals [N,S])."""
+    r, xyz, z, _ = _marcher(rays, N_samples, lindisp, perturb, bbox_3D)
+    return xyz, r[:, 0:3], r[:, 3:6], z
