@@ -541,3 +541,17 @@ def ray_marcher(rays, n_samples=64, lindisp=False, perturb_draws=None, bbox=None
         upper, lower = torch.cat([mid, z[:, -1:]], -1), torch.cat([z[:, :1], mid], -1)
         z = lower + (upper - lower) * perturb_draws
     return o[:, None, :] + d[:, None, :] * z[:, :, None], z
+
+
+# ---- TensorVM (models/tensoRF.py:4-136): stacked coefficients -> the VM-split parameter dict this oracle works on ----------
+def vm_to_split(vm_params, density_n_comp, app_n_comp):
+    """plane_coef [3, A + D, res, res], line_coef [3, A + D, res, 1] (appearance first, density last, :29-36,57-58) ->
+    density_plane.k / density_line.k / app_plane.k / app_line.k; the other keys pass through."""
+    out = {k: v for k, v in vm_params.items() if k not in ("plane_coef", "line_coef")}
+    P, L = vm_params["plane_coef"], vm_params["line_coef"]
+    for k in range(3):
+        out[f"density_plane.{k}"] = P[k:k + 1, -density_n_comp:]
+        out[f"density_line.{k}"] = L[k:k + 1, -density_n_comp:]
+        out[f"app_plane.{k}"] = P[k:k + 1, :app_n_comp]
+        out[f"app_line.{k}"] = L[k:k + 1, :app_n_comp]
+    return out

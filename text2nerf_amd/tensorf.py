@@ -333,6 +333,14 @@ class TensorVMSplit(nn.Module):
                    self.renderModule.mlp[2].bias, self.renderModule.mlp[4].weight, self.renderModule.mlp[4].bias]
         return ps
 
+    # autograd hooks: the tensors autograd tracks (the module's leaf parameters) and, for a list of same-shaped buffers (the
+    # gradients), the 19 kernel-order views into them. Identity for the VM-split layout; TensorVM overrides both.
+    def _autograd_params(self):
+        return self._all_params()
+
+    def _kernel_views(self, tensors):
+        return list(tensors)
+
     def _param_struct(self, tensors, cls=_lib.FieldParams):
         s = cls()
         t = [x if x is None else x for x in tensors]
@@ -657,9 +665,9 @@ class TensorVMSplit(nn.Module):
         flags = (FLAG_TRAIN if is_train else 0) | (FLAG_ADD_BG if add_bg else 0)
         if not is_train and self.frame_width and R % int(self.frame_width) == 0:
             flags |= FLAG_COHERENT
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._all_params())
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._autograd_params())
         if needs_grad:
-            out = _RenderFn.apply(self, rays, N, flags, jitter, *self._all_params())
+            out = _RenderFn.apply(self, rays, N, flags, jitter, *self._autograd_params())
             return out
         rgb, depth, z, w = self._render_raw(rays, N, flags, jitter, self.materialize_weights)
         return rgb, depth, z, w
@@ -700,6 +708,83 @@ class TensorVMSplit(nn.Module):
         return {"evaluated": s[_lib.STAT_EVALUATED], "appearance": s[_lib.STAT_APPEARANCE]}
 
 
+class TensorVM(TensorVMSplit):
+    """models/tensoRF.py:4-136: the stacked-coefficient VM field — ``plane_coef [3, A + D, res, res]`` and
+    ``line_coef [3, A + D, res, 1]`` with the appearance components first (``[:, :A]``) and the density components last
+    (``[:, -D:]``) — on the SAME kernels as TensorVMSplit: each of the 12 factor tensors the C-ABI wants is a contiguous
+    slice of the two stacked tensors, so the native field reads the parameters in place and the backward writes straight
+    into slices of two dense gradient tensors. ``density_n_comp`` / ``appearance_n_comp`` are scalars as in upstream
+    TensoRF (the reference class cannot be built from this driver's list-valued options) and must be 16 / 48 here; the
+    grid is cubic (``res = gridSize[0]``, models/tensoRF.py:9-14)."""
+
+    def __init__(self, aabb, gridSize, device, density_n_comp=16, appearance_n_comp=48, **kargs):
+        d, a = int(density_n_comp), int(appearance_n_comp)
+        if len(set(int(g) for g in gridSize)) != 1:
+            raise T2NError("TensorVM stores res x res planes for all three pairs: the grid must be cubic")
+        super().__init__(aabb, gridSize, device, density_n_comp=[d] * 3, appearance_n_comp=[a] * 3, **kargs)
+        self._d, self._a = d, a
+
+    def init_svd_volume(self, res, device):
+        res = int(res)
+        c = self.app_n_comp[0] + self.density_n_comp[0]
+        self.plane_coef = nn.Parameter(0.1 * torch.randn((3, c, res, res), device=device))
+        self.line_coef = nn.Parameter(0.1 * torch.randn((3, c, res, 1), device=device))
+        self.basis_mat = nn.Linear(self.app_n_comp[0] * 3, self.app_dim, bias=False).to(device)
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        groups = [{"params": self.line_coef, "lr": lr_init_spatialxyz}, {"params": self.plane_coef, "lr": lr_init_spatialxyz},
+                  {"params": self.basis_mat.parameters(), "lr": lr_init_network}]
+        if isinstance(self.renderModule, nn.Module):
+            groups += [{"params": self.renderModule.parameters(), "lr": lr_init_network}]
+        return groups
+
+    def _mlp_params(self):
+        if self.renderModule is None:
+            return []
+        m = self.renderModule.mlp
+        return [m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias]
+
+    def _autograd_params(self):
+        return [self.plane_coef, self.line_coef, self.basis_mat.weight] + self._mlp_params()
+
+    def _kernel_views(self, tensors):
+        """[plane, line, basis, mlp...] (parameters or gradients) -> the 19 kernel-order tensors (contiguous slices)."""
+        plane, line = tensors[0], tensors[1]
+        a = self.app_n_comp[0]
+        den_p = [plane[k, a:].unsqueeze(0) for k in range(3)]
+        den_l = [line[k, a:].unsqueeze(0) for k in range(3)]
+        app_p = [plane[k, :a].unsqueeze(0) for k in range(3)]
+        app_l = [line[k, :a].unsqueeze(0) for k in range(3)]
+        return den_p + den_l + app_p + app_l + list(tensors[2:])
+
+    def _all_params(self):
+        return self._kernel_views([p.detach() if not torch.is_grad_enabled() else p for p in self._autograd_params()])
+
+    def get_kwargs(self):
+        kw = super().get_kwargs()
+        kw.update({"density_n_comp": self.density_n_comp[0], "appearance_n_comp": self.app_n_comp[0]})
+        return kw
+
+    def vector_comp_diffs(self):
+        a, d = self.app_n_comp[0], self.density_n_comp[0]
+        return self.vectorDiffs(self.line_coef[:, -d:]) + self.vectorDiffs(self.line_coef[:, :a])
+
+    def vectorDiffs(self, vector_comps):
+        total = 0
+        for idx in range(len(vector_comps)):
+            n_comp, n_size = vector_comps[idx].shape[:-1]
+            m = vector_comps[idx].view(n_comp, n_size)
+            dotp = torch.matmul(m, m.transpose(-1, -2))
+            total = total + torch.mean(torch.abs(dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]))
+        return total
+
+    def _unsupported(self, *a, **k):
+        raise T2NError("TensorVM: only the render path (forward / backward / checkpoints) is implemented; the reference's own "
+                       "TensorVM.upsample_volume_grid calls an undefined compute_stepSize (models/tensoRF.py:136)")
+
+    upsample_volume_grid = shrink = TV_loss_density = TV_loss_app = density_L1 = _unsupported
+
+
 class _RenderFn(torch.autograd.Function):
     """Autograd bridge: forward = t2n_render_forward (context kept in a private workspace), backward =
     t2n_render_backward. Gradients come back in the reference parameter layouts, so torch.optim / TVLoss see ordinary
@@ -722,9 +807,9 @@ class _RenderFn(torch.autograd.Function):
             raise T2NError("parameters changed between forward and backward")
         lib = _lib.load()
         dev = rays.device
-        params = field._all_params()
+        params = field._autograd_params()
         grads = [torch.zeros_like(p) for p in params]
-        gs = field._param_struct(grads, _lib.FieldGrads)
+        gs = field._param_struct(field._kernel_views(grads), _lib.FieldGrads)
         R = rays.shape[0]
         d_rgb = torch.zeros(R, 3, device=dev) if d_rgb is None else d_rgb.contiguous().float()
         d_depth = torch.zeros(R, device=dev) if d_depth is None else d_depth.contiguous().float()
