@@ -188,8 +188,20 @@ def linear_line(line, gv):
     return out
 
 
+def _cp_products(params, prefix, xyz_norm):
+    """TensorCP (models/tensoRF.py:334-366): product over the three axes of the linearly interpolated line factors, [C, n]."""
+    c = xyz_norm.detach()
+    out = None
+    for k in range(3):
+        l = linear_line(params[f"{prefix}_line.{k}"], c[:, VEC_MODE[k]])
+        out = l if out is None else out * l
+    return out
+
+
 def density_feature(params: Dict[str, torch.Tensor], xyz_norm):
-    """models/tensoRF.py:205-220."""
+    """models/tensoRF.py:205-220 (VM split); :334-349 for a CP parameter dict (no planes)."""
+    if "density_plane.0" not in params:
+        return _cp_products(params, "density", xyz_norm).sum(0)
     feat = torch.zeros(xyz_norm.shape[0], dtype=xyz_norm.dtype)
     c = xyz_norm.detach()
     for k in range(3):
@@ -209,7 +221,9 @@ def feature2density(cfg: FieldConfig, feat):
 
 
 def app_feature(params, xyz_norm):
-    """models/tensoRF.py:223-239: [A,144] products -> basis_mat (no bias) -> [A,app_dim]."""
+    """models/tensoRF.py:223-239: [A,144] products -> basis_mat (no bias) -> [A,app_dim]; :351-366 for a CP dict."""
+    if "app_plane.0" not in params:
+        return _cp_products(params, "app", xyz_norm).T @ params["basis_mat.weight"].T
     c = xyz_norm.detach()
     prods = []
     for k in range(3):

@@ -785,6 +785,104 @@ class TensorVM(TensorVMSplit):
     upsample_volume_grid = shrink = TV_loss_density = TV_loss_app = density_L1 = _unsupported
 
 
+class TensorCP(TensorVMSplit):
+    """models/tensoRF.py:306-434: the CP (line-only) field, sigma = sum_c Lz[c](z) Ly[c](y) Lx[c](x), rendered by the VM-split
+    kernels through an exact algebraic embedding: bilinear interpolation of the rank-one table Ly (x) Lx IS the product of
+    the two linear interpolations, so the field equals a VM field with plane_0 = Ly (x) Lx, line_0 = Lz and pairs 1, 2
+    zero (likewise for appearance; basis_mat [app_dim, A] becomes [basis | 0 | 0]). The virtual VM tensors are built with
+    differentiable torch ops, so autograd carries the kernels' plane / line gradients back to the six line parameters.
+    "Supported cheaply" (SURVEY.md 8a footnote): two thirds of the gathers read zeros; n_comp must be 16 / 48."""
+
+    def init_svd_volume(self, res, device):
+        if self.density_n_comp[0] != 16 or self.app_n_comp[0] != 48:
+            raise T2NError("TensorCP on the HIP kernels needs density_n_comp[0] == 16 and appearance_n_comp[0] == 48")
+        self.density_line = self.init_one_svd(self.density_n_comp[0], self.gridSize, 0.2, device)
+        self.app_line = self.init_one_svd(self.app_n_comp[0], self.gridSize, 0.2, device)
+        self.basis_mat = nn.Linear(self.app_n_comp[0], self.app_dim, bias=False).to(device)
+        self._virt, self._virt_key, self._virt_grad = None, None, False
+
+    def init_one_svd(self, n_component, gridSize, scale, device):
+        g = [int(x) for x in gridSize]
+        return nn.ParameterList([nn.Parameter(scale * torch.randn((1, n_component, g[VEC_MODE[i]], 1))) for i in range(3)]).to(device)
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        groups = [{"params": self.density_line, "lr": lr_init_spatialxyz}, {"params": self.app_line, "lr": lr_init_spatialxyz},
+                  {"params": self.basis_mat.parameters(), "lr": lr_init_network}]
+        if isinstance(self.renderModule, nn.Module):
+            groups += [{"params": self.renderModule.parameters(), "lr": lr_init_network}]
+        return groups
+
+    def _leaves(self):
+        ps = list(self.density_line) + list(self.app_line) + [self.basis_mat.weight]
+        if self.renderModule is not None:
+            m = self.renderModule.mlp
+            ps += [m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias]
+        return ps
+
+    def _embed(self, lines):
+        """lines[i] is along VEC_MODE[i] = (z, y, x): pair 0 = plane over (x, y) [1,C,gy,gx] x line over z."""
+        lz, ly, lx = lines[0], lines[1], lines[2]
+        plane0 = ly[0, :, :, 0][:, :, None] * lx[0, :, :, 0][:, None, :]          # [C, gy, gx]
+        return plane0.unsqueeze(0).contiguous(), lz
+
+    def _virtual(self):
+        leaves = self._leaves()
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in leaves)
+        key = tuple((p.data_ptr(), p._version) for p in leaves)
+        if self._virt is not None and key == self._virt_key and (self._virt_grad or not grad):
+            return self._virt     # (backward runs with grad mode off: it must see the forward's tensors, not rebuild them)
+        g = [int(x) for x in self.gridSize]
+        dev = self.basis_mat.weight.device
+
+        def zeros_pairs(C):
+            planes = [None] + [torch.zeros(1, C, g[MAT_MODE[k][1]], g[MAT_MODE[k][0]], device=dev) for k in (1, 2)]
+            lines = [None] + [torch.zeros(1, C, g[VEC_MODE[k]], 1, device=dev) for k in (1, 2)]
+            return planes, lines
+        with torch.set_grad_enabled(grad):
+            dp, dl = zeros_pairs(self.density_n_comp[0])
+            ap, al = zeros_pairs(self.app_n_comp[0])
+            dp[0], dl[0] = self._embed(self.density_line)
+            ap[0], al[0] = self._embed(self.app_line)
+            A = self.app_n_comp[0]
+            basis = torch.cat([self.basis_mat.weight, torch.zeros(self.app_dim, 2 * A, device=dev)], 1).contiguous()
+            virt = dp + dl + ap + al + [basis] + self._leaves()[7:]
+        self._virt, self._virt_key, self._virt_grad = virt, key, grad
+        return virt
+
+    def _all_params(self):
+        return self._virtual()
+
+    def _autograd_params(self):
+        return self._virtual()
+
+    def state_dict(self, *a, **k):
+        return super().state_dict(*a, **k)
+
+    def density_L1(self):
+        return sum(torch.mean(torch.abs(l)) for l in self.density_line)
+
+    def TV_loss_density(self, reg):
+        return sum(reg(l) * 1e-3 for l in self.density_line)
+
+    def TV_loss_app(self, reg):
+        return sum(reg(l) * 1e-3 for l in self.app_line)
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        """models/tensoRF.py:381-385 (lines only), through the same ATen-exact resize kernel as the VM variant."""
+        dummy_p = [torch.zeros(1, 1, 2, 2, device=self.basis_mat.weight.device) for _ in range(3)]
+        for name in ("density_line", "app_line"):
+            lines = getattr(self, name)
+            _, new = self.up_sampling_VM([p.clone() for p in dummy_p], lines, [max(int(r), 2) for r in res_target])
+            setattr(self, name, new)
+        self._virt = None
+        self._drop_handle()
+        self.update_stepSize(res_target)
+
+    def shrink(self, new_aabb):
+        raise T2NError("TensorCP.shrink is not implemented (the reference's version dereferences a missing alphaMask)")
+
+
 class _RenderFn(torch.autograd.Function):
     """Autograd bridge: forward = t2n_render_forward (context kept in a private workspace), backward =
     t2n_render_backward. Gradients come back in the reference parameter layouts, so torch.optim / TVLoss see ordinary
