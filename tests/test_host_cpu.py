@@ -47,9 +47,26 @@ def test_no_cpu_fallback():
                       appearance_n_comp=[48] * 3, shadingMode="MLP_Fea_noview", fea_pe=6, step_ratio=1.0)
     with pytest.raises(T2NError):
         m(torch.zeros(4, 6))
+    # the image-space entry points (f-2 / f-3) and the other field variants refuse to run on the host as well
+    import numpy as np
+    from text2nerf_amd import TensorCP, TensorVM, postprocess_frame
+    from text2nerf_amd.warp import bilinear_splat_warping_multiview, sparse_bilateral_filtering
+    with pytest.raises(T2NError):
+        postprocess_frame(torch.zeros(4, 4, 3), torch.zeros(4, 4), [0.5, 8.0])
+    with pytest.raises(T2NError):
+        sparse_bilateral_filtering(np.ones((8, 8), np.float32), np.zeros((8, 8, 3), np.float32))
+    with pytest.raises(T2NError):
+        bilinear_splat_warping_multiview([np.zeros((8, 8, 3), np.float32)], [np.ones((8, 8), np.float32)], np.eye(4)[None], np.eye(4),
+                                         8, 8, [8.0, 8.0, 4, 4])
+    for cls, kw in ((TensorVM, dict(density_n_comp=16, appearance_n_comp=48)),
+                    (TensorCP, dict(density_n_comp=[16] * 3, appearance_n_comp=[48] * 3))):
+        v = cls(torch.tensor([[-1.0] * 3, [1.0] * 3]), [8, 8, 8], "cpu", shadingMode="MLP_Fea_noview", fea_pe=6, step_ratio=1.0, **kw)
+        with pytest.raises(T2NError):
+            v(torch.zeros(4, 6))
     src = ""
-    for f in ("tensorf.py", "renderer.py", "ray_utils.py", "parallel.py", "_lib.py", "__init__.py"):
-        src += open(os.path.join(ROOT, "text2nerf_amd", f)).read()
+    for f in sorted(os.listdir(os.path.join(ROOT, "text2nerf_amd"))):
+        if f.endswith(".py"):
+            src += open(os.path.join(ROOT, "text2nerf_amd", f)).read()
     assert "oracle" not in src, "the shipped package must never import the oracle"
 
 
