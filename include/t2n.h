@@ -220,6 +220,12 @@ int t2n_warp_view(const float* rgb /*[H,W,3] in [0,1]*/, const float* depth /*[H
 int t2n_warp_finish(const uint8_t* filled, const uint8_t* image_u8, int H, int W, float* image_out /*[H,W,3]*/,
                     int64_t* mask_out /*[H,W] or NULL*/, t2n_stream stream);
 
+/* dibr_filter_mask2 (utils.py:393-409): raster-order in-place hole filling of the merged warp — unknown pixels whose 5x5
+ * neighbourhood is known to more than `threshold` (0.65) take the mean of their known 3x3 neighbours and count as known for
+ * the rest of the scan. Runs as skewed wavefronts (t = col + 3 row) in one workgroup. image [H,W,3] fp32, known [H,W]
+ * int32 (0 / non-zero), depth [H,W] fp64 or NULL; all updated in place. */
+int t2n_dibr_filter_mask2(float* image, int32_t* known, double* depth, int H, int W, float threshold, t2n_stream stream);
+
 /* ---- a-15: backward of the render call w.r.t. all field parameters (what autograd derives in the reference,
  * text2nerf_main.py:589; coordinates are detached there, models/tensoRF.py:208-210,226-228, so no ray gradients exist).
  * Protocol: (1) forward with T2N_FLAG_KEEP_CTX as ONE launch (workspace >= t2n_render_workspace_bytes_ctx), weights and

@@ -144,3 +144,31 @@ def bilinear_splat_warping_multiview(rgbs, depths, poses, pose_tar, H, W, intrin
         filled |= known
     image[~filled] = 255
     return filled.astype(np.int64), (image / 255).astype(np.float32), depth
+
+
+# ---- hole filling -------------------------------------------------------------------------------------------------------------
+FILL_W5 = np.array([[1, 1, 1.5, 1, 1], [1, 1.5, 3, 1.5, 1], [1.5, 3, 0, 3, 1.5], [1, 1.5, 3, 1.5, 1], [1, 1, 1.5, 1, 1]], np.float32)
+
+
+def dibr_filter_mask2(image, known, depth=None, thr=0.65):
+    """utils.py:393-409: one raster scan (rows 2..H-3, cols 2..W-3) over the unknown pixels; a pixel whose 5x5 neighbourhood
+    is known to more than `thr` (weights FILL_W5 / 36) takes the mean of its known 3x3 neighbours (colour and depth) and
+    becomes known IMMEDIATELY, so later pixels of the scan see it. In-place semantics restated on copies; fp64 means."""
+    image, known = image.copy(), known.copy()
+    depth = None if depth is None else depth.copy()
+    H, W, _ = image.shape
+    tot = float(FILL_W5.sum())
+    for i in range(2, H - 2):
+        for j in range(2, W - 2):
+            if known[i, j] != 0:
+                continue
+            if float((known[i - 2:i + 3, j - 2:j + 3] * FILL_W5).sum()) / tot <= thr:
+                continue
+            k3 = known[i - 1:i + 2, j - 1:j + 2].astype(np.float64)
+            n = k3.sum()
+            for c in range(3):
+                image[i, j, c] = (image[i - 1:i + 2, j - 1:j + 2, c].astype(np.float64) * k3).sum() / n
+            if depth is not None:
+                depth[i, j] = (depth[i - 1:i + 2, j - 1:j + 2] * k3).sum() / n
+            known[i, j] = 1
+    return (image, known) if depth is None else (image, known, depth)

@@ -53,6 +53,18 @@ def main():
     f2, m2, d2, flow = Warper().forward_warp((frames[1][0] * 255).astype(np.uint8), None, frames[1][1],
                                              np.linalg.inv(poses[1]), np.linalg.inv(poses[3]), K, None)
     out["fw_frame"], out["fw_mask"], out["fw_depth"], out["fw_flow"] = f2, m2, d2, flow
+    # hole filling (utils.py:393-409, the use_filter_filling branch of text2nerf_main.py:134-135) on the merged warp with
+    # extra random holes punched in (seeded), so that the raster-order dependence between fills is exercised
+    g = np.random.Generator(np.random.PCG64(41))
+    holes = g.uniform(0, 1, mask.shape) < 0.18
+    hm, hi, hd = mask.copy(), img.copy(), dep.copy()
+    hm[holes] = 0
+    hi[holes] = 1.0
+    hd[holes] = 0.0
+    out["fill_in_mask"] = hm.astype(np.uint8)
+    f_img, f_map, f_dep = ref_utils.dibr_filter_mask2(hi.copy(), hm.copy(), output_depth=hd.copy())
+    out["fill_image"], out["fill_mask"], out["fill_depth"] = f_img, f_map.astype(np.uint8), f_dep
+    print("holes", int((hm == 0).sum()), "filled", int((f_map != hm).sum()))
     np.savez_compressed(os.path.join(HERE, "warp.npz"), **out)
     print({k: (v.shape, str(v.dtype)) for k, v in out.items()})
     print("filled fraction:", float(mask.mean()), "filter changed px:",

@@ -85,3 +85,24 @@ def test_multiview_warp_vs_oracle_512_with_masks():
     r = OW.bilinear_splat_warping_multiview(*args, masks=masks)
     o = bilinear_splat_warping_multiview(*args, masks=masks)
     _check_warp(o[0], o[1], o[2], r[0], r[1], r[2])
+
+
+def test_hole_filling_vs_reference_golden_and_oracle(gw):
+    from text2nerf_amd.warp import dibr_filter_mask2
+    known = gw["fill_in_mask"].astype(np.int64)
+    img, dep = gw["warp_image"].copy(), gw["warp_depth"].copy()
+    holes = (known == 0) & (gw["warp_mask"] == 1)
+    img[holes] = 1.0
+    dep[holes] = 0.0
+    f_img, f_map, f_dep = dibr_filter_mask2(img.copy(), known.copy(), output_depth=dep.copy())
+    assert f_map.dtype == np.int64 and np.array_equal(f_map, gw["fill_mask"])
+    assert np.array_equal(f_img, gw["fill_image"])
+    np.testing.assert_allclose(f_dep, gw["fill_depth"], rtol=1e-13, atol=0)
+    # larger frame, many holes, no depth: against the oracle
+    rgb, d = synth.rgbd_frame(71, 150, 203, n_boxes=5)
+    g = np.random.Generator(np.random.PCG64(72))
+    k2 = (g.uniform(0, 1, d.shape) > 0.25).astype(np.int64)
+    rgb[k2 == 0] = 1.0
+    o_img, o_map = OW.dibr_filter_mask2(rgb, k2)
+    h_img, h_map = dibr_filter_mask2(rgb.copy(), k2.copy())
+    assert np.array_equal(h_map, o_map) and np.array_equal(h_img, o_img) and (o_map != k2).sum() > 3000

@@ -56,3 +56,16 @@ def test_multiview_warp_vs_reference(gw):
     assert np.array_equal(mask, gw["warp_mask"])
     assert np.abs(img - gw["warp_image"]).max() <= 1.0 / 255 + 1e-7 and (img != gw["warp_image"]).mean() < 1e-3
     np.testing.assert_allclose(dep, gw["warp_depth"], rtol=1e-9, atol=1e-12)
+
+
+def test_hole_filling_vs_reference(gw):
+    known = gw["fill_in_mask"].astype(np.int64)
+    img, dep = gw["warp_image"].copy(), gw["warp_depth"].copy()
+    holes = (known == 0) & (gw["warp_mask"] == 1)
+    img[holes] = 1.0
+    dep[holes] = 0.0
+    f_img, f_map, f_dep = OW.dibr_filter_mask2(img, known, dep)
+    assert np.array_equal(f_map, gw["fill_mask"])
+    assert np.array_equal(f_img, gw["fill_image"])
+    np.testing.assert_allclose(f_dep, gw["fill_depth"], rtol=1e-13, atol=0)
+    assert (f_map != known).sum() > 200

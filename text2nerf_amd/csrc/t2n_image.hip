@@ -185,6 +185,58 @@ __global__ __launch_bounds__(256) void k_warp_finish(const unsigned char* __rest
     if (out_mask) out_mask[t] = f ? 1 : 0;
 }
 
+// ---- hole filling: dibr_filter_mask2 (utils.py:393-409) -------------------------------------------------------------------------
+// The reference is ONE raster scan with in-place updates: a filled pixel counts as known for every later pixel. Pixel (i, j)
+// reads the known-map in rows i-2..i+2 x cols j-2..j+2 (earlier rows / earlier columns of its own row must already be
+// final, later ones still original) — so all pixels on a skewed front t = j + 3 i are mutually independent and the scan is
+// a sequence of (W - 5) + 3 (H - 5) + 1 fronts. One workgroup walks the fronts (barrier + agent-scope loads between them:
+// the values cross waves through L2); ~2000 fronts of <= H pixels for a 512^2 frame.
+__device__ __forceinline__ int ld_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_d(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// numpy's pairwise sum of 9 values: eight accumulators combined as a tree, then the ninth
+__device__ __forceinline__ double np_sum9(const double (&a)[9]) { return (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + a[8]; }
+__global__ __launch_bounds__(1024) void k_fill_fronts(float* image, int* known, double* depth, int H, int W, int twice_thr36) {
+    // 2 x (5x5 weights): 1 -> 2, 1.5 -> 3, 3 -> 6, centre 0
+    const int w5[25] = {2, 2, 3, 2, 2, 2, 3, 6, 3, 2, 3, 6, 0, 6, 3, 2, 3, 6, 3, 2, 2, 2, 3, 2, 2};
+    const int t0 = 2 + 3 * 2, t1 = (W - 3) + 3 * (H - 3);
+    for (int t = t0; t <= t1; ++t) {
+        // rows i with 2 <= j = t - 3 i <= W - 3
+        const int ilo = max(2, (t - (W - 3) + 2) / 3), ihi = min(H - 3, (t - 2) / 3);
+        for (int i = ilo + (int)threadIdx.x; i <= ihi; i += blockDim.x) {
+            const int j = t - 3 * i;
+            if (j < 2 || j > W - 3) continue;
+            if (ld_i(known + i * W + j) != 0) continue;
+            int s2 = 0;
+#pragma unroll
+            for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+                for (int dx = -2; dx <= 2; ++dx) s2 += w5[(dy + 2) * 5 + dx + 2] * (ld_i(known + (i + dy) * W + j + dx) != 0 ? 1 : 0);
+            if (s2 <= twice_thr36) continue;     // sum / 36 > thr  <=>  2 sum > 72 thr (sums are multiples of 0.5: exact)
+            double k3[9], v[9];
+            double n = 0.0;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                k3[q] = (double)ld_i(known + (i + q / 3 - 1) * W + j + q % 3 - 1);
+            }
+            n = np_sum9(k3);
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[q] = (double)ld_f(image + ((size_t)(i + q / 3 - 1) * W + j + q % 3 - 1) * 3 + c) * k3[q];
+                image[((size_t)i * W + j) * 3 + c] = (float)(np_sum9(v) / n);
+            }
+            if (depth) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[q] = ld_d(depth + (size_t)(i + q / 3 - 1) * W + j + q % 3 - 1) * k3[q];
+                depth[(size_t)i * W + j] = np_sum9(v) / n;
+            }
+            known[i * W + j] = 1;
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
 }  // namespace t2n
 
 using namespace t2n;
@@ -266,6 +318,15 @@ extern "C" int t2n_warp_finish(const uint8_t* filled, const uint8_t* image_u8, i
     const int n = H * W;
     hipLaunchKernelGGL(k_warp_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, filled, image_u8, n, image_out,
                        (long long*)mask_out);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_dibr_filter_mask2(float* image, int32_t* known, double* depth, int H, int W, float threshold, t2n_stream stream) {
+    if (!image || !known || H < 5 || W < 5) { set_error("t2n_dibr_filter_mask2: bad argument"); return T2N_ERR_INVALID; }
+    // numpy: float64(sum) / float32(36) > threshold (python float). 2 * sum is an integer: the pixel passes iff 2 sum > 72 thr
+    const int twice = (int)floor(72.0 * (double)threshold + 1e-9);
+    hipLaunchKernelGGL(k_fill_fronts, dim3(1), dim3(1024), 0, (hipStream_t)stream, image, known, depth, H, W, twice);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

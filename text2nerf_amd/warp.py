@@ -3,6 +3,7 @@
 
 * ``sparse_bilateral_filtering`` — dataLoader/bilateral_filtering.py:5-35 (an O(H W) Python loop in the reference)
 * ``bilinear_splat_warping_multiview`` — utils.py:83-119 over ``Warper.forward_warp`` (scripts/Warper.py:21-186, numpy add.at)
+* ``dibr_filter_mask2`` — utils.py:393-409, the raster-order hole filling (skewed wavefronts on the GPU)
 
 Inputs may be numpy arrays (as in the driver) or torch tensors; numpy in -> numpy out. No CPU fallback."""
 from __future__ import annotations
@@ -94,3 +95,25 @@ def bilinear_splat_warping_multiview(rgbs, depths, poses, pose_tar, H, W, intrin
     if as_numpy:
         return out_mask.cpu().numpy(), out_img.cpu().numpy(), dep.cpu().numpy()
     return out_mask, out_img, dep
+
+
+def dibr_filter_mask2(output_image, myMap, output_depth=None, device=None):
+    """Same signature / return as utils.py:393: ``(output_image, myMap[, output_depth])`` after the raster-order hole filling.
+    The reference mutates its numpy arguments in place; here the (new) results are returned — the driver rebinds all three
+    (text2nerf_main.py:135)."""
+    lib = _lib.load()
+    as_numpy = isinstance(output_image, np.ndarray)
+    dev = _dev(device if device is not None else (None if as_numpy else output_image.device))
+    img = _to(output_image, dev, torch.float32).clone()
+    known = _to(myMap, dev, torch.int32).clone()
+    H, W = known.shape
+    dep = None if output_depth is None else _to(output_depth, dev, torch.float64).clone()
+    with torch.cuda.device(dev):
+        _lib.check(lib.t2n_dibr_filter_mask2(_lib.ptr(img), _lib.ptr(known), _lib.ptr(dep), H, W, 0.65, _lib.current_stream_ptr(dev)),
+                   "t2n_dibr_filter_mask2")
+    if as_numpy:
+        m = known.cpu().numpy().astype(np.asarray(myMap).dtype)
+        out = (img.cpu().numpy(), m)
+        return out if dep is None else out + (dep.cpu().numpy(),)
+    out = (img, known.to(myMap.dtype))
+    return out if dep is None else out + (dep,)

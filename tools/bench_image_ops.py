@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from text2nerf_amd import synth
-from text2nerf_amd.warp import bilinear_splat_warping_multiview, sparse_bilateral_filtering
+from text2nerf_amd.warp import bilinear_splat_warping_multiview, dibr_filter_mask2, sparse_bilateral_filtering
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 from make_golden_warp_cases import pose44, warp_poses
@@ -37,7 +37,9 @@ def timed(fn, n=20):
 filt_ms = timed(lambda: sparse_bilateral_filtering(depth_t, rgb_t, filter_size=[7, 5, 5, 3, 3], depth_threshold=0.02, num_iter=5))
 warp_ms = timed(lambda: bilinear_splat_warping_multiview([f[0] for f in frames_t], [f[1] for f in frames_t], np.stack(poses[:3]),
                                                          poses[3], H, W, intr))
-out = {"frame": [H, W], "sparse_bilateral_filtering_ms": filt_ms, "warp_3_views_ms": warp_ms}
+wm, wi, wd = bilinear_splat_warping_multiview([f[0] for f in frames_t], [f[1] for f in frames_t], np.stack(poses[:3]), poses[3], H, W, intr)
+fill_ms = timed(lambda: dibr_filter_mask2(wi, wm, output_depth=wd))
+out = {"frame": [H, W], "sparse_bilateral_filtering_ms": filt_ms, "warp_3_views_ms": warp_ms, "dibr_filter_mask2_ms": fill_ms}
 if "--cpu" in sys.argv:
     from oracle import oracle_warp as OW
     t0 = time.perf_counter(); OW.sparse_bilateral_filtering(depth, rgb, [7, 5, 5, 3, 3], 0.02, 5); out["oracle_filter_s"] = time.perf_counter() - t0
