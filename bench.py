@@ -41,6 +41,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+L1_PEAK_GBS = 256 * 64 * 2.4   # 256 CUs x 64 B/clk vector-L1 data path x 2.4 GHz max clock = 39 321 GB/s
 BYTES_PER_EVAL = 1152   # 3 planes x 4 taps x 64 B + 3 lines x 2 taps x 64 B
 BYTES_PER_APP = 3456
 BYTES_PER_RAY = 40
@@ -311,7 +312,9 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg_bytes["march"] / launches, "avg_launch_ms": k_ms["march"],
                     "note": "field (69.6 MB) is cache-resident: achieved > HBM peak means the gather runs from L1/L2, "
-                            "traffic = PMC HBM bytes per launch from profiles/round1_traffic.json"}
+                            "traffic = PMC HBM bytes per launch from profiles/round1_traffic.json",
+                    # what actually bounds the gather: the vector L1 data path, 64 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md)
+                    "l1_path": {"peak": L1_PEAK_GBS, "unit": "GB/s", "frac": achieved / L1_PEAK_GBS}}
         else:
             # executed matrix-core work: 3 f16 products per fp32 product on the split path, 1 on the exact fp32 path
             exec_flop = FLOP_PER_APP * A * (3 if split else 1)
