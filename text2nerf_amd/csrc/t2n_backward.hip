@@ -524,14 +524,24 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
         if (b0 + 64 + lane < re) p = a.recs[b0 + 64 + lane];   // next batch in flight while this one is accumulated
         wave_lds_sync();
         const int nrec = min(64, re - b0);
-#pragma unroll 2
-        for (int q = 0; q * 4 < nrec; ++q) {
+        // appearance: the 16 per-channel gradients this lane needs for the batch, all in flight before the accumulate loop
+        // (a dependent global load per record inside the loop serialised ~1 us round trips)
+        float gpre[16];
+        if (a.gx) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float4 t0 = T[(q * 4 + sub) * 3];
+                gpre[q] = t0.w != 0.f ? a.gx[(size_t)__float_as_int(t0.z) * a.gx_ld + K * CT + coff + ch] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (q * 4 >= nrec) break;
             const int ri = q * 4 + sub;
             const float4 t0 = T[ri * 3], wp = T[ri * 3 + 1], wl = T[ri * 3 + 2];
             const int c00 = __float_as_int(t0.x) + ch, c01 = c00 + C, c10 = c00 + (kBinTile + 1) * C, c11 = c10 + C;
             const int r0 = __float_as_int(t0.y) + ch, r1 = r0 + C;
-            float g2 = t0.z;
-            if (a.gx) g2 = t0.w != 0.f ? a.gx[(size_t)__float_as_int(t0.z) * a.gx_ld + K * CT + coff + ch] : 0.f;
+            const float g2 = a.gx ? gpre[q] : t0.z;
             if (g2 != 0.f) {
                 float pv = Pv[c00] * wp.x;
                 pv = fmaf(Pv[c01], wp.y, pv); pv = fmaf(Pv[c10], wp.z, pv); pv = fmaf(Pv[c11], wp.w, pv);
