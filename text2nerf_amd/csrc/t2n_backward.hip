@@ -659,27 +659,31 @@ static size_t tile_accum_lds(int C, int Lmax) {
 // go [rows,4], h1 [rows,128] -> g1 [rows,128] = (go W2) * [h1>0]; dW2[3,128] += go^T h1; db2[3] += colsum(go)
 __global__ __launch_bounds__(256) void k_bwd_l2(const float4* __restrict__ go, const float* __restrict__ h1, long long rows,
                                                 const float* __restrict__ w2, float* g1, float* dw2, float* db2) {
+    // persistent workgroups (grid-stride over 64-row tiles): the 3 x 128 weight-gradient partial sums leave a workgroup once,
+    // so the same-address atomics on dw2 stay in the hundreds per address instead of one per 64 rows
     const int u = threadIdx.x & 127, half = threadIdx.x >> 7;
     const float w0 = w2[u], w1 = w2[128 + u], w2v = w2[256 + u];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    const long long r0 = (long long)blockIdx.x * 64 + half * 32;
-    for (int k = 0; k < 32; k += 4) {           // four rows in flight per thread (the loop is load-latency bound)
-        float4 g[4]; float h[4];
+    for (long long tile = blockIdx.x; tile * 64 < rows; tile += gridDim.x) {
+        const long long r0 = tile * 64 + half * 32;
+        for (int k = 0; k < 32; k += 4) {           // four rows in flight per thread
+            float4 g[4]; float h[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long long r = r0 + k + q;
-            const bool ok = r < rows;
-            g[q] = ok ? go[r] : make_float4(0.f, 0.f, 0.f, 0.f);
-            h[q] = ok ? h1[r * 128 + u] : 0.f;
-        }
+            for (int q = 0; q < 4; ++q) {
+                const long long r = r0 + k + q;
+                const bool ok = r < rows;
+                g[q] = ok ? go[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+                h[q] = ok ? h1[r * 128 + u] : 0.f;
+            }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const long long r = r0 + k + q;
-            if (r >= rows) break;
-            a0 = fmaf(g[q].x, h[q], a0); a1 = fmaf(g[q].y, h[q], a1); a2 = fmaf(g[q].z, h[q], a2);
-            s0 += g[q].x; s1 += g[q].y; s2 += g[q].z;
-            const float v = fmaf(g[q].z, w2v, fmaf(g[q].y, w1, g[q].x * w0));
-            g1[r * 128 + u] = h[q] > 0.f ? v : 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const long long r = r0 + k + q;
+                if (r >= rows) break;
+                a0 = fmaf(g[q].x, h[q], a0); a1 = fmaf(g[q].y, h[q], a1); a2 = fmaf(g[q].z, h[q], a2);
+                s0 += g[q].x; s1 += g[q].y; s2 += g[q].z;
+                const float v = fmaf(g[q].z, w2v, fmaf(g[q].y, w1, g[q].x * w0));
+                g1[r * 128 + u] = h[q] > 0.f ? v : 0.f;
+            }
         }
     }
     if (dw2) { atomicAdd(&dw2[u], a0); atomicAdd(&dw2[128 + u], a1); atomicAdd(&dw2[256 + u], a2); }
@@ -813,15 +817,21 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ IN, i
     }
 }
 
-// db[n] += sum_rows G[rows, ld]   (N <= 128; 256 threads: two row phases per block, `chunk` rows per block)
+// db[n] += sum_rows G[rows, ld]   (N <= 128; 256 threads: two row phases per block; grid-stride over `chunk`-row tiles so each
+// workgroup issues its N atomics once)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ G, int ld, long long rows, int N, float* db, int chunk) {
     __shared__ float part[256];
     const int n = threadIdx.x & 127, ph = threadIdx.x >> 7;
-    const long long r0 = (long long)blockIdx.x * chunk;
-    const long long r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
     float s = 0.f;
     if (n < N)
-        for (long long r = r0 + ph; r < r1; r += 2) s += G[r * ld + n];
+        for (long long r0 = (long long)blockIdx.x * chunk; r0 < rows; r0 += (long long)gridDim.x * chunk) {
+            const long long r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
+            float t0 = 0.f, t1 = 0.f;
+            long long r = r0 + ph;
+            for (; r + 2 < r1; r += 4) { t0 += G[r * ld + n]; t1 += G[(r + 2) * ld + n]; }
+            for (; r < r1; r += 2) t0 += G[r * ld + n];
+            s += t0 + t1;
+        }
     part[threadIdx.x] = s;
     __syncthreads();
     if (ph == 0 && n < N) atomicAdd(&db[n], part[n] + part[128 + n]);
@@ -1181,15 +1191,15 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         const t2n_field_params* P = &f->params_ref;
         timing_begin(f, T2N_K_BWD_MLP, s);
         // 3. layer 2
-        hipLaunchKernelGGL(k_bwd_l2, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, (const float4*)go, (const float*)h1,
+        hipLaunchKernelGGL(k_bwd_l2, dim3((unsigned)((rows + 63) / 64 < 1024 ? (rows + 63) / 64 : 1024)), dim3(256), 0, s, (const float4*)go, (const float*)h1,
                            (long long)rows, P->mlp_w2, g1, g->mlp_w2, g->mlp_b2);
         // 4. layers 1, 0, PE, basis
         if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s);
-        if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
+        if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
         launch_gemm_nn(g1, 128, P->mlp_w1, 128, rows, 128, 128, h0, 128, g0, 128, s);
         hipLaunchKernelGGL(k_pe_fwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)feat32, (long long)rows, xpe);
         if (g->mlp_w0) launch_gemm_tn<4>(g0, 128, xpe, 352, rows, 128, 351, g->mlp_w0, 351, part, s);
-        if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, s, (const float*)g0, 128, (long long)rows, 128, g->mlp_b0, 128);
+        if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g0, 128, (long long)rows, 128, g->mlp_b0, 128);
         launch_gemm_nn(g0, 128, P->mlp_w0, 351, rows, 128, 351, nullptr, 0, gx, 352, s);
         hipLaunchKernelGGL(k_pe_bwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)gx, (const float*)feat32, (long long)rows, gf);
         if (g->basis_weight) launch_gemm_tn<1>(gf, 32, x144, 144, rows, 27, 144, g->basis_weight, 144, part, s);
