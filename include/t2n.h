@@ -182,6 +182,9 @@ int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_
                        const float* jitter, float* rgb, float* depth, float* weights, float* z_vals, uint64_t* stats,
                        void* workspace, size_t workspace_bytes, t2n_stream stream);
 
+/* eval_sh_bases (models/sh.py:87-133): (deg+1)^2 real SH basis values per unit direction, deg 0..4. dirs [n,3] -> out [n,(deg+1)^2]. */
+int t2n_eval_sh_bases(int deg, const float* dirs, int64_t n, float* out, t2n_stream stream);
+
 /* dda + ray_marcher (dataLoader/ray_utils.py:174-228): the AABB-clipped linspace sampler (no call sites in this driver; the
  * live sampler is inside t2n_render_forward). bbox_host = {min xyz, max xyz} or NULL (then near/far = ray columns 6, 7);
  * steps [n_samples] = torch.linspace(0, 1, n_samples) on the device; perturb [n, n_samples] = perturb * U[0,1) draws or NULL.

@@ -569,3 +569,26 @@ def vm_to_split(vm_params, density_n_comp, app_n_comp):
         out[f"app_plane.{k}"] = P[k:k + 1, :app_n_comp]
         out[f"app_line.{k}"] = L[k:k + 1, :app_n_comp]
     return out
+
+
+def sh_bases(deg, d):
+    """models/sh.py:87-133 for any degree 0..4 (sh_bases_deg2 above is the fused head's degree): [..., (deg+1)^2]."""
+    x, y, z = d[..., 0], d[..., 1], d[..., 2]
+    xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+    one = torch.ones_like(x)
+    cols = [0.28209479177387814 * one]
+    if deg > 0:
+        cols += [-0.4886025119029199 * y, 0.4886025119029199 * z, -0.4886025119029199 * x]
+    if deg > 1:
+        cols += [1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.31539156525252005 * (2.0 * zz - xx - yy),
+                 -1.0925484305920792 * xz, 0.5462742152960396 * (xx - yy)]
+    if deg > 2:
+        cols += [-0.5900435899266435 * y * (3 * xx - yy), 2.890611442640554 * xy * z, -0.4570457994644658 * y * (4 * zz - xx - yy),
+                 0.3731763325901154 * z * (2 * zz - 3 * xx - 3 * yy), -0.4570457994644658 * x * (4 * zz - xx - yy),
+                 1.445305721320277 * z * (xx - yy), -0.5900435899266435 * x * (xx - 3 * yy)]
+    if deg > 3:
+        cols += [2.5033429417967046 * xy * (xx - yy), -1.7701307697799304 * yz * (3 * xx - yy), 0.9461746957575601 * xy * (7 * zz - 1),
+                 -0.6690465435572892 * yz * (7 * zz - 3), 0.10578554691520431 * (zz * (35 * zz - 30) + 3),
+                 -0.6690465435572892 * xz * (7 * zz - 3), 0.47308734787878004 * (xx - yy) * (7 * zz - 1),
+                 -1.7701307697799304 * xz * (xx - 3 * yy), 0.6258357354491761 * (xx * (xx - 3 * yy) - yy * (3 * xx - yy))]
+    return torch.stack(cols, -1)

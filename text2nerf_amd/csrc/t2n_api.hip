@@ -284,6 +284,46 @@ __global__ __launch_bounds__(256) void k_ray_marcher(const MarcherArgs a) {
     if (a.xyz) { a.xyz[t * 3] = r[0] + r[3] * z; a.xyz[t * 3 + 1] = r[1] + r[4] * z; a.xyz[t * 3 + 2] = r[2] + r[5] * z; }
 }
 
+// ---- eval_sh_bases (models/sh.py:87-133): real SH basis polynomials of degree 0..4 at unit directions, (deg+1)^2 values per
+// direction; products associated left to right like the reference's expressions (fp32, python-float constants rounded to
+// fp32 at their first use). SHRender (models/tensorBase.py:29-33) uses degree 2; the fused head lives in k_shade.
+__global__ __launch_bounds__(256) void k_sh_bases(int deg, const float* __restrict__ dirs, long long n, float* out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int nb = (deg + 1) * (deg + 1);
+    float* o = out + t * nb;
+    const float x = dirs[t * 3], y = dirs[t * 3 + 1], z = dirs[t * 3 + 2];
+    o[0] = 0.28209479177387814f;
+    if (deg < 1) return;
+    const float C1 = 0.4886025119029199f;
+    o[1] = -C1 * y; o[2] = C1 * z; o[3] = -C1 * x;
+    if (deg < 2) return;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.31539156525252005f * ((2.0f * zz - xx) - yy);
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.5462742152960396f * (xx - yy);
+    if (deg < 3) return;
+    o[9] = (-0.5900435899266435f * y) * (3.f * xx - yy);
+    o[10] = (2.890611442640554f * xy) * z;
+    o[11] = (-0.4570457994644658f * y) * ((4.f * zz - xx) - yy);
+    o[12] = (0.3731763325901154f * z) * ((2.f * zz - 3.f * xx) - 3.f * yy);
+    o[13] = (-0.4570457994644658f * x) * ((4.f * zz - xx) - yy);
+    o[14] = (1.445305721320277f * z) * (xx - yy);
+    o[15] = (-0.5900435899266435f * x) * (xx - 3.f * yy);
+    if (deg < 4) return;
+    o[16] = (2.5033429417967046f * xy) * (xx - yy);
+    o[17] = (-1.7701307697799304f * yz) * (3.f * xx - yy);
+    o[18] = (0.9461746957575601f * xy) * (7.f * zz - 1.f);
+    o[19] = (-0.6690465435572892f * yz) * (7.f * zz - 3.f);
+    o[20] = 0.10578554691520431f * (zz * (35.f * zz - 30.f) + 3.f);
+    o[21] = (-0.6690465435572892f * xz) * (7.f * zz - 3.f);
+    o[22] = (0.47308734787878004f * (xx - yy)) * (7.f * zz - 1.f);
+    o[23] = (-1.7701307697799304f * xz) * (xx - 3.f * yy);
+    o[24] = 0.6258357354491761f * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy));
+}
+
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx) {
@@ -428,6 +468,14 @@ extern "C" int t2n_ray_marcher(const float* rays, int64_t n, int ray_stride, int
     a.steps = steps; a.perturb = perturb; a.xyz = xyz; a.z_vals = z_vals; a.near_far = near_far;
     const long long tot = (long long)n * n_samples;
     hipLaunchKernelGGL(k_ray_marcher, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_eval_sh_bases(int deg, const float* dirs, int64_t n, float* out, t2n_stream stream) {
+    if (deg < 0 || deg > 4 || n < 0 || (n && (!dirs || !out))) { set_error("t2n_eval_sh_bases: deg must be 0..4"); return T2N_ERR_INVALID; }
+    if (n == 0) return T2N_OK;
+    hipLaunchKernelGGL(k_sh_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, deg, dirs, (long long)n, out);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }
