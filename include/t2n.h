@@ -48,6 +48,10 @@ enum {
     T2N_FLAG_TRAIN = 1u,      /* is_train: per-ray jitter, no z gate (models/tensorBase.py:314-316,459) */
     T2N_FLAG_ADD_BG = 2u,     /* rgb_map += 1-acc  (white_bg, or the train-time coin; models/tensorBase.py:497-498) */
     T2N_FLAG_KEEP_CTX = 4u,   /* keep the per-call context in the workspace for t2n_render_backward */
+    T2N_FLAG_NDC = 16u,       /* ndc_ray=True (models/tensorBase.py:293-302,441-446): the sample depths are a table shared by all
+                               * rays — pass it through the `jitter` argument: [n_samples] floats = torch.linspace(near, far, N)
+                               * (+ the shared train-time jitter, already added); dists are scaled by |d| and the SH head sees
+                               * normalised view directions. Not used by the Text2NeRF driver (ndc_ray=0). */
     T2N_FLAG_COHERENT = 8u    /* hint (eval): rays are a row-major image whose width was given by t2n_field_set_frame_width:
                                  march 8x8-pixel tiles with LDS-staged shared taps. Same samples, same arithmetic per sample;
                                  the transmittance is a sequential product instead of a wave scan (weights agree to ~1e-7) */
@@ -181,6 +185,10 @@ size_t t2n_render_workspace_bytes(int64_t rays_per_launch, int n_samples);
 int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
                        const float* jitter, float* rgb, float* depth, float* weights, float* z_vals, uint64_t* stats,
                        void* workspace, size_t workspace_bytes, t2n_stream stream);
+
+/* ndc_rays_blender (blender = 1) / ndc_rays (0) (dataLoader/ray_utils.py:88-124): [n,3] origins + directions -> NDC. */
+int t2n_ndc_rays(int H, int W, float focal, float near, int blender, const float* rays_o, const float* rays_d, int64_t n,
+                 float* o_out, float* d_out, t2n_stream stream);
 
 /* eval_sh_bases (models/sh.py:87-133): (deg+1)^2 real SH basis values per unit direction, deg 0..4. dirs [n,3] -> out [n,(deg+1)^2]. */
 int t2n_eval_sh_bases(int deg, const float* dirs, int64_t n, float* out, t2n_stream stream);

@@ -292,8 +292,21 @@ def raw2alpha(sigma, dist):
 # ------------------------------------------------------------------------------------------------
 # a-4  forward, a-3 chunked harness
 # ------------------------------------------------------------------------------------------------
+def sample_ray_ndc(cfg: FieldConfig, rays_o, rays_d, n_samples, jitter_row=None):
+    """models/tensorBase.py:293-302: ONE depth row for all rays, linspace(near, far, N) (+ jitter_row * (far - near) / N in
+    train mode, jitter_row [1,N] = the captured rand_like draw); points, z [1,N], in-box mask."""
+    near, far = cfg.near_far
+    z = torch.linspace(near, far, n_samples).unsqueeze(0).to(rays_o)
+    if jitter_row is not None:
+        z = z + jitter_row.to(rays_o) * ((far - near) / n_samples)
+    pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., None]
+    a = torch.tensor(cfg.aabb, dtype=pts.dtype)
+    out = ((a[0] > pts) | (pts > a[1])).any(dim=-1)
+    return pts, z, ~out
+
+
 def forward(cfg: FieldConfig, params, rays, white_bg=True, is_train=False, n_samples=-1, jitter=None,
-            bg_coin: Optional[bool] = None, return_aux=False):
+            bg_coin: Optional[bool] = None, return_aux=False, ndc=False):
     """models/tensorBase.py:436-507 (ndc_ray=False, alphaMask=None — the driver's configuration).
 
     ``jitter``: [R,1] uniform draw used when is_train. ``bg_coin``: outcome of the reference's
@@ -302,8 +315,15 @@ def forward(cfg: FieldConfig, params, rays, white_bg=True, is_train=False, n_sam
     if is_train and jitter is None:
         raise ValueError("train-mode oracle needs the captured jitter draw")
     ro, rd = rays[:, :3], rays[:, 3:6]
-    pts, z, valid = sample_ray(cfg, ro, rd, n, jitter if is_train else None)
-    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])], -1)
+    if ndc:     # models/tensorBase.py:441-446 (`jitter` is then the [1,N] shared row)
+        pts, z, valid = sample_ray_ndc(cfg, ro, rd, n, jitter if is_train else None)
+        dists = torch.cat([z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])], -1)
+        norm = torch.norm(rd, dim=-1, keepdim=True)
+        dists = dists * norm
+        rd = rd / norm
+    else:
+        pts, z, valid = sample_ray(cfg, ro, rd, n, jitter if is_train else None)
+        dists = torch.cat([z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])], -1)
     if cfg.alpha_volume is not None and valid.any():      # models/tensorBase.py:451-456
         keep = sample_alpha(cfg, pts[valid]) > 0
         valid = valid.clone()
@@ -592,3 +612,17 @@ def sh_bases(deg, d):
                  -0.6690465435572892 * xz * (7 * zz - 3), 0.47308734787878004 * (xx - yy) * (7 * zz - 1),
                  -1.7701307697799304 * xz * (xx - 3 * yy), 0.6258357354491761 * (xx * (xx - 3 * yy) - yy * (3 * xx - yy))]
     return torch.stack(cols, -1)
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d, blender=True):
+    """dataLoader/ray_utils.py:88-105 (ndc_rays_blender, blender=True) / :107-124 (ndc_rays)."""
+    s = -1.0 if blender else 1.0
+    t = (-(near + rays_o[..., 2]) if blender else (near - rays_o[..., 2])) / rays_d[..., 2]
+    o = rays_o + t[..., None] * rays_d
+    kx, ky = s * 1.0 / (W / (2.0 * focal)), s * 1.0 / (H / (2.0 * focal))
+    o0, o1 = kx * o[..., 0] / o[..., 2], ky * o[..., 1] / o[..., 2]
+    o2 = 1.0 - s * 2.0 * near / o[..., 2]
+    d0 = kx * (rays_d[..., 0] / rays_d[..., 2] - o[..., 0] / o[..., 2])
+    d1 = ky * (rays_d[..., 1] / rays_d[..., 2] - o[..., 1] / o[..., 2])
+    d2 = s * 2.0 * near / o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)

@@ -13,7 +13,7 @@ T2N_K_COUNT = 8
 KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_mlp", "bwd_scatter", "density")
 STAT_EVALUATED, STAT_APPEARANCE, STAT_RAYS, STAT_OVERFLOW = 0, 1, 2, 3
 
-FLAG_TRAIN, FLAG_ADD_BG, FLAG_KEEP_CTX, FLAG_COHERENT = 1, 2, 4, 8
+FLAG_TRAIN, FLAG_ADD_BG, FLAG_KEEP_CTX, FLAG_COHERENT, FLAG_NDC = 1, 2, 4, 8, 16
 SHADE_IDS = {"MLP_Fea_noview": 0, "SH": 1, "RGB": 2}
 ACT_IDS = {"softplus": 0, "relu": 1}
 
@@ -90,6 +90,8 @@ SIGNATURES = {
                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2n_dibr_filter_mask2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "t2n_eval_sh_bases": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "t2n_ndc_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                     C.c_void_p, C.c_void_p]),
     "t2n_render_ctx_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "t2n_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int64, C.c_int]),
     "t2n_render_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p,

@@ -324,6 +324,25 @@ __global__ __launch_bounds__(256) void k_sh_bases(int deg, const float* __restri
     o[24] = 0.6258357354491761f * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy));
 }
 
+// ---- ndc_rays_blender / ndc_rays (dataLoader/ray_utils.py:88-124): rays -> normalised device coordinates; sign = -1 for the
+// Blender (-z forward) form, +1 for the OpenCV form. Operation order of the reference's tensor expressions.
+__global__ __launch_bounds__(256) void k_ndc_rays(int H, int W, float focal, float near, float sign, const float* __restrict__ ro,
+                                                  const float* __restrict__ rd, long long n, float* o_out, float* d_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float ox = ro[i * 3], oy = ro[i * 3 + 1], oz = ro[i * 3 + 2];
+    const float dx = rd[i * 3], dy = rd[i * 3 + 1], dz = rd[i * 3 + 2];
+    const float t = sign < 0.f ? -(near + oz) / dz : (near - oz) / dz;
+    ox = ox + t * dx; oy = oy + t * dy; oz = oz + t * dz;
+    const float kx = sign * 1.f / ((float)W / (2.f * focal)), ky = sign * 1.f / ((float)H / (2.f * focal));
+    const float o0 = kx * ox / oz, o1 = ky * oy / oz;
+    const float o2 = sign < 0.f ? 1.f + 2.f * near / oz : 1.f - 2.f * near / oz;
+    const float d0 = kx * (dx / dz - ox / oz), d1 = ky * (dy / dz - oy / oz);
+    const float d2 = sign < 0.f ? -2.f * near / oz : 2.f * near / oz;
+    o_out[i * 3] = o0; o_out[i * 3 + 1] = o1; o_out[i * 3 + 2] = o2;
+    d_out[i * 3] = d0; d_out[i * 3 + 1] = d1; d_out[i * 3 + 2] = d2;
+}
+
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx) {
@@ -480,6 +499,16 @@ extern "C" int t2n_eval_sh_bases(int deg, const float* dirs, int64_t n, float* o
     return T2N_OK;
 }
 
+extern "C" int t2n_ndc_rays(int H, int W, float focal, float near, int blender, const float* rays_o, const float* rays_d, int64_t n,
+                            float* o_out, float* d_out, t2n_stream stream) {
+    if (n < 0 || (n && (!rays_o || !rays_d || !o_out || !d_out)) || H < 1 || W < 1) { set_error("t2n_ndc_rays: bad argument"); return T2N_ERR_INVALID; }
+    if (n == 0) return T2N_OK;
+    hipLaunchKernelGGL(k_ndc_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, H, W, focal, near,
+                       blender ? -1.f : 1.f, rays_o, rays_d, (long long)n, o_out, d_out);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
 extern "C" size_t t2n_render_workspace_bytes(int64_t rays_per_launch, int n_samples) {
     if (rays_per_launch <= 0 || n_samples <= 0) return 0;
     return carve(rays_per_launch, n_samples).total;
@@ -496,13 +525,17 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     if (!f || !rays || !rgb || !depth || !workspace || n_rays < 0 || ray_stride < 6) { set_error("t2n_render_forward: bad argument"); return T2N_ERR_INVALID; }
     if (!f->uploaded) { set_error("t2n_render_forward: field has no uploaded parameters"); return T2N_ERR_STATE; }
     if (n_samples <= 0 || n_samples > 2048) { set_error("t2n_render_forward: n_samples %d outside [1,2048]", n_samples); return T2N_ERR_UNSUPPORTED; }
-    if ((flags & T2N_FLAG_TRAIN) && !jitter) { set_error("t2n_render_forward: train mode needs the jitter draws"); return T2N_ERR_INVALID; }
+    if ((flags & (T2N_FLAG_TRAIN | T2N_FLAG_NDC)) && !jitter) { set_error("t2n_render_forward: train / NDC mode needs the jitter draws / depth table"); return T2N_ERR_INVALID; }
+    // NDC: the `jitter` argument carries the [n_samples] depth table; the kernels see it as FieldDev::ztab for this call
+    struct ZtabScope { t2n_field* f; ~ZtabScope() { f->dev.ztab = nullptr; } } ztab_scope{f};
+    f->dev.ztab = (flags & T2N_FLAG_NDC) ? jitter : nullptr;
+    const bool ndc = (flags & T2N_FLAG_NDC) != 0;
     hipStream_t s = (hipStream_t)stream;
     if (stats) T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s));
     if (n_rays == 0) return T2N_OK;
     const bool keep = (flags & T2N_FLAG_KEEP_CTX) != 0;
     // tile marcher: image-ordered eval rays with a known width (hint), whole rows per sub-launch
-    const bool tiles = (flags & T2N_FLAG_COHERENT) != 0 && !keep && !(flags & T2N_FLAG_TRAIN) && !f->dev.alpha && f->frame_w >= 8 &&
+    const bool tiles = (flags & T2N_FLAG_COHERENT) != 0 && !ndc && !keep && !(flags & T2N_FLAG_TRAIN) && !f->dev.alpha && f->frame_w >= 8 &&
                        n_rays % f->frame_w == 0 && n_rays / f->frame_w >= 8;
     if (keep) {
         if (carve_workspace(n_rays, n_samples, true).total > workspace_bytes || (uint64_t)list_capacity(n_rays, n_samples) * kLists > 0x7fffffffull) {
@@ -528,7 +561,7 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         const Carve c = carve_workspace(per, n_samples, true);
         RenderLaunch L;
         L.rays = rays + off * ray_stride; L.n_rays = cnt; L.ray_stride = ray_stride; L.n_samples = n_samples; L.flags = flags;
-        L.jitter = jitter ? jitter + off : nullptr;
+        L.jitter = (jitter && !ndc) ? jitter + off : jitter;     // NDC: one table for every sub-launch
         L.rgb = rgb + off * 3; L.depth = depth + off;
         L.weights = weights ? weights + off * n_samples : nullptr;
         L.z_vals = z_vals ? z_vals + off * n_samples : nullptr;

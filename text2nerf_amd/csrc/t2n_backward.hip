@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
     if (Lw <= 0) return;
     const int N = a.n_samples;
     const Ray ray = load_ray(F, a.rays + r * a.ray_stride, a.ray_stride);
-    const float u = TRAIN ? a.jitter[r] : 0.f;
+    const float u = (TRAIN && !F.ztab) ? a.jitter[r] : 0.f;   // NDC: `jitter` is the depth table
     // upstream gradients of this ray; clamp(0,1) passes gradient on the closed interval
     const float4 rr = a.rgb_raw[r];
     const float gr = (rr.x >= 0.f && rr.x <= 1.f) ? a.d_rgb[r * 3 + 0] : 0.f;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
             z = sample_z<TRAIN>(F, ray, i, u);
             if (i < N - 1) dist = sample_z<TRAIN>(F, ray, i + 1, u) - z;
         }
-        const float d = dist * F.dscale;
+        const float d = scaled_dist(F, ray, dist);
         const float alpha = 1.f - expf((-sg) * d);
         const float f = (1.f - alpha) + 1e-10f;
         const float incl = wave_scan_mul(f, lane);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
         if (j < Lw) {
             const float f = (1.f - al) + 1e-10f;
             const float dalpha = G * T - after / f;
-            const float dsigma = dalpha * (dist * F.dscale) * (1.f - al);
+            const float dsigma = dalpha * scaled_dist(F, ray, dist) * (1.f - al);
             const float dact = F.act == T2N_ACT_RELU ? (sg > 0.f ? 1.f : 0.f) : (1.f - expf(-sg));
             Gw[j] = dsigma * dact;
         }
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_bwd_bin(const BinArgs a) {
     if (Lw <= 0) return;
     const int N = a.n_samples;
     const Ray ray = load_ray(F, a.rays + r * a.ray_stride, a.ray_stride);
-    const float u = TRAIN ? a.jitter[r] : 0.f;
+    const float u = (TRAIN && !F.ztab) ? a.jitter[r] : 0.f;   // NDC: `jitter` is the depth table
     const unsigned copy = (unsigned)(r >> 2) & (kBinCopies - 1);
     for (int base = 0; base < Lw; base += 64) {
         const int j = base + lane, i = first + j;
@@ -1089,7 +1089,9 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     if (!f->uploaded) { set_error("t2n_render_backward: field has no uploaded parameters"); return T2N_ERR_STATE; }
     if (f->desc.shading != T2N_SHADE_MLP_FEA_NOVIEW) { set_error("t2n_render_backward: only the MLP_Fea_noview head is differentiable"); return T2N_ERR_UNSUPPORTED; }
     if (!(flags & T2N_FLAG_KEEP_CTX)) { set_error("t2n_render_backward: forward was not run with T2N_FLAG_KEEP_CTX"); return T2N_ERR_STATE; }
-    if ((flags & T2N_FLAG_TRAIN) && !jitter) { set_error("t2n_render_backward: train mode needs the jitter draws"); return T2N_ERR_INVALID; }
+    if ((flags & (T2N_FLAG_TRAIN | T2N_FLAG_NDC)) && !jitter) { set_error("t2n_render_backward: train / NDC mode needs the jitter draws / depth table"); return T2N_ERR_INVALID; }
+    struct ZtabScope { t2n_field* f; ~ZtabScope() { f->dev.ztab = nullptr; } } ztab_scope{f};
+    f->dev.ztab = (flags & T2N_FLAG_NDC) ? jitter : nullptr;
     if (n_samples > 1024) { set_error("t2n_render_backward: n_samples %d > 1024", n_samples); return T2N_ERR_UNSUPPORTED; }
     const Carve c = carve_workspace(n_rays, n_samples, true);
     if (c.total > fwd_workspace_bytes) { set_error("t2n_render_backward: forward workspace too small"); return T2N_ERR_WORKSPACE; }

@@ -41,7 +41,7 @@ __device__ __forceinline__ float wave_scan_mul(float v, int lane) {
 }
 
 struct Ray {
-    float ox, oy, oz, dx, dy, dz, tmin, last;
+    float ox, oy, oz, dx, dy, dz, tmin, last, norm;   // norm: |d| on the NDC path (dists are scaled by it, :443-444), else 1
 };
 
 // models/tensorBase.py:308-311
@@ -59,16 +59,22 @@ __device__ __forceinline__ Ray load_ray(const FieldDev& F, const float* __restri
     r.ox = rp[0]; r.oy = rp[1]; r.oz = rp[2]; r.dx = rp[3]; r.dy = rp[4]; r.dz = rp[5];
     r.last = rp[stride - 1];
     r.tmin = ray_tmin(F, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz);
+    r.norm = F.ztab ? sqrtf((r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz) : 1.f;
     return r;
 }
 
 // models/tensorBase.py:313-318: z_i = t_min + stepSize * (i [+ u])
 template <bool TRAIN>
 __device__ __forceinline__ float sample_z(const FieldDev& F, const Ray& r, int i, float u) {
+    if (F.ztab) return F.ztab[i];          // NDC: torch.linspace(near, far, N) [+ shared jitter], built by the host mirror
     float rng = (float)i;
     if (TRAIN) rng = rng + u;
     const float st = F.step * rng;
     return r.tmin + st;
+}
+// raw2alpha's distance argument (:475): dists * distance_scale, with dists first scaled by |d| on the NDC path (:444)
+__device__ __forceinline__ float scaled_dist(const FieldDev& F, const Ray& r, float dist) {
+    return F.ztab ? (dist * r.norm) * F.dscale : dist * F.dscale;
 }
 
 // Point, box mask (:320-321), eval z gate (:459-462), normalisation (:245-246). Returns validity.

@@ -45,6 +45,9 @@ struct FieldDev {
     const float* alpha; int aW, aH, aD; float a_min[3], a_inv[3];
     // split-f16 operands (t2n_shade.hip): uint4 = 8 halves per lane per (chunk, block, part)
     const uint4* basisH; const uint4* w0H; const uint4* w1H; const uint4* w2H; const float* biasH;
+    // NDC sampling (T2N_FLAG_NDC, models/tensorBase.py:293-302,441-446): per-call table of the n_samples depths shared by all
+    // rays; NULL on the regular path (z_i = t_min + step * (i [+ u]))
+    const float* ztab;
 };
 
 struct TimingSlot {

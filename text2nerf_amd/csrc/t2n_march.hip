@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
     if (r >= a.n_rays) return;
     const int N = a.n_samples;
     const Ray ray = load_ray(F, a.rays + r * a.ray_stride, a.ray_stride);
-    const float u = TRAIN ? a.jitter[r] : 0.f;
+    const float u = (TRAIN && !F.ztab) ? a.jitter[r] : 0.f;   // NDC: `jitter` is the depth table
 
     // ---- pass A: validity interval. The mask is an interval (every coordinate is monotone in the sample index), so its
     // ends are found by exact per-sample tests on the 32 candidates at either end of a conservative analytic range; the
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
         int lo, hi;
         ray_interval<TRAIN>(F, ray, N, lo, hi);
         bool done = hi < lo;
-        if (!done) {
+        if (F.ztab) { done = false; lo = 0; hi = -1; }   // NDC depths are a table: no analytic interval, exact scan below
+        if (!done && !F.ztab) {
             const bool narrow = hi - lo < 64;
             const int i = narrow ? lo + lane : (lane < 32 ? lo + lane : hi - (lane - 32));
             bool ok = false;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
                 z = sample_z<TRAIN>(F, ray, i, u);
                 if (i < N - 1) dist = sample_z<TRAIN>(F, ray, i + 1, u) - z;   // :448, last sample gets 0
             }
-            const float d = dist * F.dscale;
+            const float d = scaled_dist(F, ray, dist);
             const float nsd = (-sg) * d;
             const float alpha = 1.f - expf(nsd);
             const float f = (1.f - alpha) + 1e-10f;

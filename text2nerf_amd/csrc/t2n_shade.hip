@@ -488,7 +488,10 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
             if (h == 0 && live) {
                 float dx, dy, dz;
                 if (a.viewdirs) { dx = a.viewdirs[(size_t)idx * 3]; dy = a.viewdirs[(size_t)idx * 3 + 1]; dz = a.viewdirs[(size_t)idx * 3 + 2]; }
-                else { const float* rp = a.rays + (size_t)a.app_ray[idx] * a.ray_stride; dx = rp[3]; dy = rp[4]; dz = rp[5]; }
+                else {
+                    const float* rp = a.rays + (size_t)a.app_ray[idx] * a.ray_stride; dx = rp[3]; dy = rp[4]; dz = rp[5];
+                    if (F.ztab) { const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz); dx = dx / nrm; dy = dy / nrm; dz = dz / nrm; }   // :445
+                }
                 // models/sh.py:4-14,87-112 (degree 2)
                 const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
                 const float C20 = 1.0925484305920792f, C21 = -1.0925484305920792f, C22 = 0.31539156525252005f,

@@ -87,3 +87,26 @@ def ray_marcher(rays, N_samples=64, lindisp=False, perturb=0, bbox_3D=None):
     ray's own near/far columns 6,7 without a box). Returns (xyz [N,S,3], rays_o, rays_d, z_vals [N,S])."""
     r, xyz, z, _ = _marcher(rays, N_samples, lindisp, perturb, bbox_3D)
     return xyz, r[:, 0:3], r[:, 3:6], z
+
+
+def _ndc(H, W, focal, near, rays_o, rays_d, blender):
+    lib = _lib.load()
+    o = rays_o.reshape(-1, 3).contiguous().float()
+    d = rays_d.reshape(-1, 3).contiguous().float()
+    if o.device.type != "cuda":
+        o, d = o.cuda(), d.cuda()
+    oo, dd = torch.empty_like(o), torch.empty_like(d)
+    with torch.cuda.device(o.device):
+        _lib.check(lib.t2n_ndc_rays(int(H), int(W), float(focal), float(near), 1 if blender else 0, _lib.ptr(o), _lib.ptr(d), o.shape[0],
+                                    _lib.ptr(oo), _lib.ptr(dd), _lib.current_stream_ptr(o.device)), "t2n_ndc_rays")
+    return oo.reshape(rays_o.shape), dd.reshape(rays_d.shape)
+
+
+def ndc_rays_blender(H, W, focal, near, rays_o, rays_d):
+    """dataLoader/ray_utils.py:88-105 (the form `evaluation_path` applies when ndc_ray is set, renderer.py:162-163)."""
+    return _ndc(H, W, focal, near, rays_o, rays_d, True)
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """dataLoader/ray_utils.py:107-124."""
+    return _ndc(H, W, focal, near, rays_o, rays_d, False)

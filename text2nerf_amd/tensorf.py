@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import FLAG_ADD_BG, FLAG_COHERENT, FLAG_KEEP_CTX, FLAG_TRAIN, T2NError
+from ._lib import FLAG_ADD_BG, FLAG_COHERENT, FLAG_KEEP_CTX, FLAG_NDC, FLAG_TRAIN, T2NError
 
 MAT_MODE = [[0, 1], [0, 2], [1, 2]]
 VEC_MODE = [2, 1, 0]
@@ -644,8 +644,6 @@ class TensorVMSplit(nn.Module):
     # ---- the render call ----------------------------------------------------------------------------------------------------
     def forward(self, rays_chunk, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1):
         """models/tensorBase.py:436-507: returns (rgb_map [R,3], depth_map [R], z_vals [R,N], weight [R,N])."""
-        if ndc_ray:
-            raise T2NError("ndc_ray=True is not on the Text2NeRF path (ndc_ray=0 in every run) and is not implemented")
         dev = self.basis_mat.weight.device
         rays = to_device_async(rays_chunk, dev)
         if rays.dtype != torch.float32 or not rays.is_contiguous():
@@ -657,19 +655,30 @@ class TensorVMSplit(nn.Module):
             return torch.empty(0, 3, device=dev), torch.empty(0, device=dev), e, e
         jitter = None
         add_bg = bool(white_bg)
-        if is_train:
+        if ndc_ray:
+            # sample_ray_ndc (models/tensorBase.py:293-299): one depth table for all rays, linspace(near, far, N) on the rays'
+            # device (the reference's chunk is on the GPU by then), plus — in train mode — ONE shared jitter row drawn
+            # with rand_like on that device's generator. The table rides in the `jitter` slot of the C-ABI (T2N_FLAG_NDC).
+            near, far = self.near_far
+            interpx = torch.linspace(near, far, N).unsqueeze(0).to(rays)
+            if is_train:
+                interpx += torch.rand_like(interpx).to(rays) * ((far - near) / N)
+            jitter = interpx.reshape(-1).contiguous()
+        elif is_train:
             # the reference draws on the CPU default generator even for GPU runs (models/tensorBase.py:313-317)
             jitter = to_device_async(torch.rand(R, 1), dev).reshape(-1).contiguous()
-            if not white_bg:
-                add_bg = bool(torch.rand((1,)) < 0.5)   # models/tensorBase.py:497
-        flags = (FLAG_TRAIN if is_train else 0) | (FLAG_ADD_BG if add_bg else 0)
-        if not is_train and self.frame_width and R % int(self.frame_width) == 0:
+        if is_train and not white_bg:
+            add_bg = bool(torch.rand((1,)) < 0.5)   # models/tensorBase.py:497
+        flags = (FLAG_TRAIN if is_train else 0) | (FLAG_ADD_BG if add_bg else 0) | (FLAG_NDC if ndc_ray else 0)
+        if not is_train and not ndc_ray and self.frame_width and R % int(self.frame_width) == 0:
             flags |= FLAG_COHERENT
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._autograd_params())
         if needs_grad:
-            out = _RenderFn.apply(self, rays, N, flags, jitter, *self._autograd_params())
-            return out
-        rgb, depth, z, w = self._render_raw(rays, N, flags, jitter, self.materialize_weights)
+            rgb, depth, z, w = _RenderFn.apply(self, rays, N, flags, jitter, *self._autograd_params())
+        else:
+            rgb, depth, z, w = self._render_raw(rays, N, flags, jitter, self.materialize_weights)
+        if ndc_ray and z is not None:
+            z = z[:1]          # sample_ray_ndc returns ONE [1,N] depth row (models/tensorBase.py:296-302)
         return rgb, depth, z, w
 
     def _render_raw(self, rays, N, flags, jitter, want_wz, keep_ctx=False):
