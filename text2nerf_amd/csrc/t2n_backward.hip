@@ -777,9 +777,21 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ IN, i
     const int lane = threadIdx.x & 63, s = lane & 31, h = lane >> 5, w = threadIdx.x >> 6;
     const int ng = blockIdx.x;
     const int K4 = (K + 3) & ~3;
-    for (int idx = threadIdx.x; idx < K4 * 128; idx += 256) {
-        const int k = idx >> 7, n = ng * 128 + (idx & 127);
-        sW[idx] = (k < K && n < N) ? W[(size_t)k * ldw + n] : 0.f;
+    // stage the slab with eight independent loads in flight per thread (a one-load-per-iteration loop chained ~64 L2 round
+    // trips per workgroup and dominated the kernel)
+    for (int base = 0; base < K4 * 128; base += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            const int k = idx >> 7, n = ng * 128 + (idx & 127);
+            v[u] = (idx < K4 * 128 && k < K && n < N) ? W[(size_t)k * ldw + n] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            if (idx < K4 * 128) sW[idx] = v[u];
+        }
     }
     __syncthreads();
     const long long ntiles = (rows + 31) / 32;
@@ -788,17 +800,27 @@ __global__ __launch_bounds__(256) void k_gemm_nn(const float* __restrict__ IN, i
         const bool rok = r < rows;
         const float* __restrict__ inr = IN + (rok ? r : 0) * ldin;
         f32x16 acc[4] = {{0}, {0}, {0}, {0}};
-        float4 cur = *reinterpret_cast<const float4*>(inr);
-        for (int k0 = 0; k0 < K4; k0 += 4) {
-            const float4 nxt = k0 + 4 < K4 ? *reinterpret_cast<const float4*>(inr + k0 + 4) : cur;
-            const float b0 = h ? cur.y : cur.x, b1 = h ? cur.w : cur.z;
-            const float* w0 = sW + (k0 + h) * 128 + s;
-            const float* w1 = w0 + 256;
+        // the lane's row of IN, four float4 (16 K values = 2048 clk of MFMA work) ahead of its use: an L2 round trip is longer
+        // than one 8-MFMA step
+        constexpr int PF = 4;
+        float4 ring[PF];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = mfma(w0[m * 32], b0, acc[m]);
+        for (int p = 0; p < PF; ++p) ring[p] = 4 * p < K4 ? *reinterpret_cast<const float4*>(inr + 4 * p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k0 = 0; k0 < K4; k0 += 4 * PF) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = mfma(w1[m * 32], b1, acc[m]);
-            cur = nxt;
+            for (int p = 0; p < PF; ++p) {
+                const int kk = k0 + 4 * p;
+                if (kk >= K4) break;
+                const float4 cur = ring[p];
+                if (kk + 4 * PF < K4) ring[p] = *reinterpret_cast<const float4*>(inr + kk + 4 * PF);
+                const float b0 = h ? cur.y : cur.x, b1 = h ? cur.w : cur.z;
+                const float* w0 = sW + (kk + h) * 128 + s;
+                const float* w1 = w0 + 256;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = mfma(w0[m * 32], b0, acc[m]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = mfma(w1[m * 32], b1, acc[m]);
+            }
         }
         if (!rok) continue;
 #pragma unroll
@@ -1036,7 +1058,7 @@ static void launch_gemm_nn(const float* IN, int ldin, const float* W, int ldw, l
                            int ldact, float* OUT, int ldo, hipStream_t s) {
     const int ng = (N + 127) / 128;
     const long long tiles4 = ((rows + 31) / 32 + 3) / 4;
-    long long by = 768 / ng;                       // ~3 workgroups per CU in flight, each staging W once
+    long long by = 512 / ng;                       // ~2 workgroups per CU (the LDS slab allows two), each staging W once
     if (by > tiles4) by = tiles4;
     if (by < 1) by = 1;
     const size_t lds = (size_t)((K + 3) & ~3) * 128 * sizeof(float);
