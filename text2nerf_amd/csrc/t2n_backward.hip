@@ -170,7 +170,8 @@ __device__ __forceinline__ void scatter_win(const FactorSet& S, const GradSet& G
 // 17x17xC tile + the whole line) and flushes the non-zero texels once. Global atomics drop ~15x.
 constexpr int kBinTile = 16;      // texels per tile edge (footprints reach one texel further: 17 staged)
 constexpr int kBinCopies = 32;    // privatised histogram / cursor copies (every ray starts in the camera's tile)
-constexpr int kBinSeg = 8192;     // records per accumulate workgroup
+constexpr int kBinSeg = 8192;     // records per accumulate workgroup (density)
+constexpr int kBinSegApp = 2048;  // appearance: ~50x fewer records on ~165 tiles — smaller segments balance the workgroups
 
 struct BinGeom { int tw[3], before[3], total; };
 static BinGeom bin_geom(const FactorSet& S) {
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
 // per-thread serial runs do not chain ~70 dependent global round trips.
 template <bool LDS>
 __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, unsigned* tile_start, int4* segs, unsigned* nseg_out,
-                                                   unsigned seg_cap) {
+                                                   unsigned seg_cap, unsigned seg_size) {
     extern __shared__ unsigned sh_hist[];
     __shared__ unsigned sh[1024];
     const int t = threadIdx.x;
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
     for (int j = tb; j < te; ++j) {
         const unsigned s0 = H[j * kBinCopies], s1 = j + 1 < n_tiles ? H[(j + 1) * kBinCopies] : total;
         tile_start[j] = s0;
-        ns += (s1 - s0 + kBinSeg - 1) / kBinSeg;
+        ns += (s1 - s0 + seg_size - 1) / seg_size;
     }
     if (t == 0) tile_start[n_tiles] = total;
     __syncthreads();
@@ -425,21 +426,22 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
     unsigned si = sh[t] - ns;
     for (int j = tb; j < te; ++j) {
         const unsigned s0 = H[j * kBinCopies], s1 = j + 1 < n_tiles ? H[(j + 1) * kBinCopies] : total;
-        for (unsigned s = s0; s < s1; s += kBinSeg) {
-            if (si < seg_cap) segs[si] = make_int4(j, (int)s, (int)min(s1, s + kBinSeg), 0);
+        for (unsigned s = s0; s < s1; s += seg_size) {
+            if (si < seg_cap) segs[si] = make_int4(j, (int)s, (int)min(s1, s + seg_size), 0);
             ++si;
         }
     }
     if (t == 1023) *nseg_out = min(sh[1023], seg_cap);
 }
-static void launch_bin_scan(unsigned* hist, int n_tiles, unsigned* tile_start, int4* segs, unsigned* nseg, unsigned seg_cap, hipStream_t s) {
+static void launch_bin_scan(unsigned* hist, int n_tiles, unsigned* tile_start, int4* segs, unsigned* nseg, unsigned seg_cap, unsigned seg_size,
+                            hipStream_t s) {
     const size_t lds = (size_t)n_tiles * kBinCopies * 4;
     if (lds <= 150 * 1024) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_bin_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-        hipLaunchKernelGGL((k_bin_scan<true>), dim3(1), dim3(1024), lds, s, hist, n_tiles, tile_start, segs, nseg, seg_cap);
+        hipLaunchKernelGGL((k_bin_scan<true>), dim3(1), dim3(1024), lds, s, hist, n_tiles, tile_start, segs, nseg, seg_cap, seg_size);
     } else {
-        hipLaunchKernelGGL((k_bin_scan<false>), dim3(1), dim3(1024), 0, s, hist, n_tiles, tile_start, segs, nseg, seg_cap);
+        hipLaunchKernelGGL((k_bin_scan<false>), dim3(1), dim3(1024), 0, s, hist, n_tiles, tile_start, segs, nseg, seg_cap, seg_size);
     }
 }
 
@@ -530,14 +532,15 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
         if (a.gx) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const float4 t0 = T[(q * 4 + sub) * 3];
+                const float4 t0 = T[(sub * 16 + q) * 3];
                 gpre[q] = t0.w != 0.f ? a.gx[(size_t)__float_as_int(t0.z) * a.gx_ld + K * CT + coff + ch] : 0.f;
             }
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            if (q * 4 >= nrec) break;
-            const int ri = q * 4 + sub;
+            // the four records an instruction handles are 16 apart in the batch: neighbours in the list are neighbouring
+            // samples of ONE ray and would hit the same accumulator words (same-address LDS atomics serialise)
+            const int ri = sub * 16 + q;
             const float4 t0 = T[ri * 3], wp = T[ri * 3 + 1], wl = T[ri * 3 + 2];
             const int c00 = __float_as_int(t0.x) + ch, c01 = c00 + C, c10 = c00 + (kBinTile + 1) * C, c11 = c10 + C;
             const int r0 = __float_as_int(t0.y) + ch, r1 = r0 + C;
@@ -1023,7 +1026,7 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
     c.segs = o; o = al256(o + (size_t)c.seg_cap * 16);
     c.recs = o; o = al256(o + 3 * cap * 16);
     // the same for the appearance samples (one record per activation row and plane)
-    c.a_seg_cap = (unsigned)(3 * R / kBinSeg + (size_t)n_tiles + 1);
+    c.a_seg_cap = (unsigned)(3 * R / kBinSegApp + (size_t)n_tiles + 1);
     c.a_hist = o; o = al256(o + (size_t)n_tiles * kBinCopies * 4);
     c.a_tile_start = o; o = al256(o + ((size_t)n_tiles + 1) * 4);
     c.a_nseg = o; o = al256(o + 4);
@@ -1193,7 +1196,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             T2N_HIP(hipMemsetAsync(a.hist, 0, (size_t)geom.total * kBinCopies * 4, s));
             if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true, true>), dim3(nb), dim3(256), lds, s, a);
             else hipLaunchKernelGGL((k_bwd_march<false, true>), dim3(nb), dim3(256), lds, s, a);
-            launch_bin_scan(a.hist, geom.total, (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, s);
+            launch_bin_scan(a.hist, geom.total, (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, kBinSeg, s);
             BinArgs ba;
             ba.F = f->dev; ba.geom = geom; ba.rays = rays; ba.n_rays = n_rays; ba.ray_stride = ray_stride; ba.n_samples = n_samples;
             ba.jitter = jitter; ba.gfeat = a.gfeat; ba.ray_app = a.ray_app; ba.cursor = a.hist; ba.recs = (float4*)(bw + b.recs);
@@ -1245,7 +1248,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             const unsigned nbk = (unsigned)((rows + 255) / 256);
             hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, s, ab);
             launch_bin_scan(ab.hist, ab.geom.total, (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),
-                            b.a_seg_cap, s);
+                            b.a_seg_cap, kBinSegApp, s);
             hipLaunchKernelGGL((k_app_bin<1>), dim3(nbk), dim3(256), 0, s, ab);
             TileAccumArgs ta;
             ta.S = f->dev.app; ta.G = sa.gapp; ta.geom = ab.geom; ta.segs = (const int4*)(bw + b.a_segs);
@@ -1253,6 +1256,13 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             ta.dbg = 0; ta.gx = gxapp; ta.gx_ld = 144;
             T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin));
             hipLaunchKernelGGL((k_bwd_tile_accum<48>), dim3(b.a_seg_cap, 3), dim3(kAccThreads), lds_bin, s, ta);
+            if (getenv("T2N_DEBUG_NSEG")) {
+                unsigned nd = 0, na = 0;
+                (void)hipStreamSynchronize(s);
+                (void)hipMemcpy(&nd, bw + b.nseg, 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&na, bw + b.a_nseg, 4, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[t2n] segments: density %u (cap %u), appearance %u (cap %u), rows %lld\n", nd, b.seg_cap, na, b.a_seg_cap, (long long)rows);
+            }
         } else {
             unsigned blocks = (unsigned)((rows / 32 + 3) / 4);
             if (blocks > 2048) blocks = 2048;
