@@ -171,7 +171,9 @@ __device__ __forceinline__ void scatter_win(const FactorSet& S, const GradSet& G
 constexpr int kBinTile = 16;      // texels per tile edge (footprints reach one texel further: 17 staged)
 constexpr int kBinCopies = 32;    // privatised histogram / cursor copies (every ray starts in the camera's tile)
 constexpr int kBinSeg = 8192;     // records per accumulate workgroup (density)
-constexpr int kBinSegApp = 2048;  // appearance: ~50x fewer records on ~165 tiles — smaller segments balance the workgroups
+constexpr int kBinSegApp = 512;   // smallest segment (sizes the segment list); the scan picks the actual size per call
+constexpr unsigned kAccTargetSegs = 1024, kAccTargetSegsApp = 512;   // accumulate work items aimed at: whole rounds over 256 CUs
+constexpr unsigned kAccGrid = 2048;   // accumulate workgroups launched (grid-stride over the segment list)
 
 struct BinGeom { int tw[3], before[3], total; };
 static BinGeom bin_geom(const FactorSet& S) {
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
 // per-thread serial runs do not chain ~70 dependent global round trips.
 template <bool LDS>
 __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, unsigned* tile_start, int4* segs, unsigned* nseg_out,
-                                                   unsigned seg_cap, unsigned seg_size) {
+                                                   unsigned seg_cap, unsigned seg_size_in, unsigned target_segs) {
     extern __shared__ unsigned sh_hist[];
     __shared__ unsigned sh[1024];
     const int t = threadIdx.x;
@@ -404,17 +406,40 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
     }
     __syncthreads();
     if (LDS) for (int i = t; i < n; i += 1024) hist[i] = sh_hist[i];
-    // tile starts (+ sentinel) and the segment count per tile
+    // tile starts (+ sentinel); non-empty tiles; segment size such that the accumulate pass gets ~target_segs work items
+    // (a whole number of rounds over the CUs: with fixed 8192-record segments 1079 items ran as 4.2 rounds on 256 CUs)
     const int pt = (n_tiles + 1023) / 1024;
     const int tb = t * pt, te = min(n_tiles, tb + pt);
-    unsigned ns = 0;
+    unsigned ne = 0;
     for (int j = tb; j < te; ++j) {
         const unsigned s0 = H[j * kBinCopies], s1 = j + 1 < n_tiles ? H[(j + 1) * kBinCopies] : total;
         tile_start[j] = s0;
-        ns += (s1 - s0 + seg_size - 1) / seg_size;
+        ne += s1 > s0 ? 1u : 0u;
     }
     if (t == 0) tile_start[n_tiles] = total;
     __syncthreads();
+    sh[t] = ne;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = t >= o ? sh[t - o] : 0u;
+        __syncthreads();
+        sh[t] += v;
+        __syncthreads();
+    }
+    const unsigned nonempty = sh[1023];
+    __syncthreads();
+    unsigned seg_size = seg_size_in;
+    if (seg_size == 0) {
+        const unsigned room = target_segs > nonempty + 64 ? target_segs - nonempty / 2 : 64;   // every tile ends in a partial segment
+        seg_size = (total + room - 1) / room;
+        seg_size = (seg_size + 63) / 64 * 64;
+        seg_size = seg_size < 512 ? 512 : (seg_size > 16384 ? 16384 : seg_size);
+    }
+    unsigned ns = 0;
+    for (int j = tb; j < te; ++j) {
+        const unsigned s0 = H[j * kBinCopies], s1 = j + 1 < n_tiles ? H[(j + 1) * kBinCopies] : total;
+        ns += (s1 - s0 + seg_size - 1) / seg_size;
+    }
     sh[t] = ns;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -434,14 +459,14 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
     if (t == 1023) *nseg_out = min(sh[1023], seg_cap);
 }
 static void launch_bin_scan(unsigned* hist, int n_tiles, unsigned* tile_start, int4* segs, unsigned* nseg, unsigned seg_cap, unsigned seg_size,
-                            hipStream_t s) {
+                            unsigned target_segs, hipStream_t s) {
     const size_t lds = (size_t)n_tiles * kBinCopies * 4;
     if (lds <= 150 * 1024) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_bin_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-        hipLaunchKernelGGL((k_bin_scan<true>), dim3(1), dim3(1024), lds, s, hist, n_tiles, tile_start, segs, nseg, seg_cap, seg_size);
+        hipLaunchKernelGGL((k_bin_scan<true>), dim3(1), dim3(1024), lds, s, hist, n_tiles, tile_start, segs, nseg, seg_cap, seg_size, target_segs);
     } else {
-        hipLaunchKernelGGL((k_bin_scan<false>), dim3(1), dim3(1024), 0, s, hist, n_tiles, tile_start, segs, nseg, seg_cap, seg_size);
+        hipLaunchKernelGGL((k_bin_scan<false>), dim3(1), dim3(1024), 0, s, hist, n_tiles, tile_start, segs, nseg, seg_cap, seg_size, target_segs);
     }
 }
 
@@ -562,9 +587,11 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
 template <int CT>
 __global__ __launch_bounds__(kAccThreads) void k_bwd_tile_accum(const TileAccumArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (blockIdx.x >= *a.nseg) return;
-    const int4 sg = a.segs[blockIdx.x];
+    const unsigned nseg = *a.nseg;
     const int coff = blockIdx.y * 16;
+    for (unsigned seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    if (seg != blockIdx.x) __syncthreads();   // the previous segment's flush has finished reading the accumulators
+    const int4 sg = a.segs[seg];
     const int k = sg.x >= a.geom.before[2] ? 2 : (sg.x >= a.geom.before[1] ? 1 : 0);
     const int tile = sg.x - a.geom.before[k];
     int W, H, L, tw; const float* __restrict__ P; const float* __restrict__ Ln; float* gP; float* gL;
@@ -607,6 +634,7 @@ __global__ __launch_bounds__(kAccThreads) void k_bwd_tile_accum(const TileAccumA
         const float v = (float)La[C + idx];
         if (v != 0.f && !(a.dbg & 1)) atomicAdd(gL + (size_t)(idx / C) * CT + coff + (idx % C), v);
     }
+    }   // segments
 }
 
 // Appearance records: one per appearance-list entry and plane. PASS 0 counts, PASS 1 writes (same lane -> entry -> copy map).
@@ -1019,7 +1047,7 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
     c.part = o; o = al256(o + tn_part_bytes(rows));
     // tile-binned density scatter: worst case one record per sample and plane
     const size_t cap = (size_t)n_rays * (size_t)n_samples;
-    c.seg_cap = (unsigned)(3 * cap / kBinSeg + (size_t)n_tiles + 1);
+    c.seg_cap = (unsigned)(3 * cap / 512 + (size_t)n_tiles + 1);
     c.hist = o; o = al256(o + (size_t)n_tiles * kBinCopies * 4);
     c.tile_start = o; o = al256(o + ((size_t)n_tiles + 1) * 4);
     c.nseg = o; o = al256(o + 4);
@@ -1196,7 +1224,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             T2N_HIP(hipMemsetAsync(a.hist, 0, (size_t)geom.total * kBinCopies * 4, s));
             if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true, true>), dim3(nb), dim3(256), lds, s, a);
             else hipLaunchKernelGGL((k_bwd_march<false, true>), dim3(nb), dim3(256), lds, s, a);
-            launch_bin_scan(a.hist, geom.total, (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, kBinSeg, s);
+            launch_bin_scan(a.hist, geom.total, (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, 0u, kAccTargetSegs, s);
             BinArgs ba;
             ba.F = f->dev; ba.geom = geom; ba.rays = rays; ba.n_rays = n_rays; ba.ray_stride = ray_stride; ba.n_samples = n_samples;
             ba.jitter = jitter; ba.gfeat = a.gfeat; ba.ray_app = a.ray_app; ba.cursor = a.hist; ba.recs = (float4*)(bw + b.recs);
@@ -1208,7 +1236,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             ta.dbg = getenv("T2N_DEBUG_ACCUM") ? atoi(getenv("T2N_DEBUG_ACCUM")) : 0;
             ta.gx = nullptr; ta.gx_ld = 0;
             T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
-            hipLaunchKernelGGL((k_bwd_tile_accum<16>), dim3(b.seg_cap, 1), dim3(kAccThreads), lds_acc, s, ta);
+            hipLaunchKernelGGL((k_bwd_tile_accum<16>), dim3(b.seg_cap < kAccGrid ? b.seg_cap : kAccGrid, 1), dim3(kAccThreads), lds_acc, s, ta);
         }
         timing_end(f, T2N_K_BWD_MARCH, s);
         T2N_HIP(hipGetLastError());
@@ -1248,14 +1276,14 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             const unsigned nbk = (unsigned)((rows + 255) / 256);
             hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, s, ab);
             launch_bin_scan(ab.hist, ab.geom.total, (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),
-                            b.a_seg_cap, kBinSegApp, s);
+                            b.a_seg_cap, 0u, kAccTargetSegsApp, s);
             hipLaunchKernelGGL((k_app_bin<1>), dim3(nbk), dim3(256), 0, s, ab);
             TileAccumArgs ta;
             ta.S = f->dev.app; ta.G = sa.gapp; ta.geom = ab.geom; ta.segs = (const int4*)(bw + b.a_segs);
             ta.nseg = (const unsigned*)(bw + b.a_nseg); ta.recs = (const float4*)(bw + b.a_recs);
             ta.dbg = 0; ta.gx = gxapp; ta.gx_ld = 144;
             T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin));
-            hipLaunchKernelGGL((k_bwd_tile_accum<48>), dim3(b.a_seg_cap, 3), dim3(kAccThreads), lds_bin, s, ta);
+            hipLaunchKernelGGL((k_bwd_tile_accum<48>), dim3(b.a_seg_cap < kAccGrid ? b.a_seg_cap : kAccGrid, 3), dim3(kAccThreads), lds_bin, s, ta);
             if (getenv("T2N_DEBUG_NSEG")) {
                 unsigned nd = 0, na = 0;
                 (void)hipStreamSynchronize(s);
