@@ -1018,7 +1018,7 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
     const bool half = f->factor_bf16 && f->dev.app.plane_h[0];
     if (use_coop(f) && !ctx && half) hipLaunchKernelGGL(k_shade_coop<true>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), kCoopLds, s, a);
     else if (use_coop(f) && !ctx) hipLaunchKernelGGL(k_shade_coop<false>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), kCoopLds, s, a);
-    else if (f->mlp_split && !ctx) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
+    else if (f->mlp_split)   /* ctx (backward recompute) too: activations at ~1e-7 relative error */ hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
     timing_end(f, T2N_K_SHADE, s);
     T2N_HIP(hipGetLastError());
