@@ -39,7 +39,9 @@ enum {
 };
 
 /* shading heads: models/tensorBase.py:200-216 */
-enum { T2N_SHADE_MLP_FEA_NOVIEW = 0, T2N_SHADE_SH = 1, T2N_SHADE_RGB = 2 };
+enum { T2N_SHADE_MLP_FEA_NOVIEW = 0, T2N_SHADE_SH = 1, T2N_SHADE_RGB = 2,
+       /* view-dependent heads (models/tensorBase.py:62-86,111-159): general unfused path, csrc/t2n_heads.hip */
+       T2N_SHADE_MLP_FEA = 3, T2N_SHADE_MLP_PE = 4, T2N_SHADE_MLP = 5 };
 /* fea2denseAct: models/tensorBase.py:406-410 */
 enum { T2N_ACT_SOFTPLUS = 0, T2N_ACT_RELU = 1 };
 
@@ -75,6 +77,7 @@ typedef struct t2n_field_desc {
     float step_size;               /* stepSize */
     float near, far;               /* near_far */
     float z_gate;                  /* 2.0: the eval-only world-z gate (models/tensorBase.py:459-462) */
+    int32_t view_pe, pos_pe;       /* octaves of the view-direction / position encodings of the MLP_Fea, MLP_PE, MLP heads */
 } t2n_field_desc;
 
 /* Reference-layout parameter pointers (device, fp32), i.e. the tensors of TensorVMSplit.state_dict()

@@ -44,6 +44,8 @@ class FieldConfig:
     ray_march_weight_thres: float = 1e-4
     step_ratio: float = 1.0
     fea_pe: int = 6
+    view_pe: int = 6
+    pos_pe: int = 6
     shading_mode: str = "MLP_Fea_noview"
     fea2dense_act: str = "softplus"
     z_gate: float = 2.0   # models/tensorBase.py:460 (hard-coded 2.)
@@ -269,9 +271,27 @@ def sh_render(viewdirs, feat):
     return torch.relu((b * feat.view(-1, 3, b.shape[-1])).sum(-1) + 0.5)
 
 
-def shade(cfg: FieldConfig, params, viewdirs, feat):
+def mlp_view_head(cfg: FieldConfig, params, pts, viewdirs, feat):
+    """The view-dependent heads, models/tensorBase.py:62-86 (MLP_Fea), :111-135 (MLP_PE), :137-159 (MLP): the reference's
+    torch.cat column order, three Linear layers with ReLU, sigmoid."""
+    cols = [feat, viewdirs]
+    if cfg.shading_mode == "MLP_Fea" and cfg.fea_pe > 0:
+        cols.append(positional_encoding(feat, cfg.fea_pe))
+    if cfg.shading_mode == "MLP_PE" and cfg.pos_pe > 0:
+        cols.append(positional_encoding(pts, cfg.pos_pe))
+    if cfg.view_pe > 0:
+        cols.append(positional_encoding(viewdirs, cfg.view_pe))
+    x = torch.cat(cols, -1)
+    h = torch.relu(x @ params["renderModule.mlp.0.weight"].T + params["renderModule.mlp.0.bias"])
+    h = torch.relu(h @ params["renderModule.mlp.2.weight"].T + params["renderModule.mlp.2.bias"])
+    return torch.sigmoid(h @ params["renderModule.mlp.4.weight"].T + params["renderModule.mlp.4.bias"])
+
+
+def shade(cfg: FieldConfig, params, viewdirs, feat, pts=None):
     if cfg.shading_mode == "MLP_Fea_noview":
         return mlp_fea_noview(params, feat, cfg.fea_pe)
+    if cfg.shading_mode in ("MLP_Fea", "MLP_PE", "MLP"):
+        return mlp_view_head(cfg, params, pts, viewdirs, feat)
     if cfg.shading_mode == "SH":
         return sh_render(viewdirs, feat)
     if cfg.shading_mode == "RGB":
@@ -341,7 +361,7 @@ def forward(cfg: FieldConfig, params, rays, white_bg=True, is_train=False, n_sam
     if app_mask.any():
         vd = rd[:, None, :].expand(pts.shape)
         f = app_feature(params, xn[app_mask])
-        c = shade(cfg, params, vd[app_mask], f)
+        c = shade(cfg, params, vd[app_mask], f, pts=xn[app_mask])
         rgb = _scatter(rgb, app_mask, c)
     acc = weight.sum(-1)
     rgb_map = (weight[..., None] * rgb).sum(-2)

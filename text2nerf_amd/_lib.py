@@ -14,7 +14,7 @@ KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_mlp",
 STAT_EVALUATED, STAT_APPEARANCE, STAT_RAYS, STAT_OVERFLOW = 0, 1, 2, 3
 
 FLAG_TRAIN, FLAG_ADD_BG, FLAG_KEEP_CTX, FLAG_COHERENT, FLAG_NDC = 1, 2, 4, 8, 16
-SHADE_IDS = {"MLP_Fea_noview": 0, "SH": 1, "RGB": 2}
+SHADE_IDS = {"MLP_Fea_noview": 0, "SH": 1, "RGB": 2, "MLP_Fea": 3, "MLP_PE": 4, "MLP": 5}   # MLP_PE: rejected in tensorf.py (broken upstream)
 ACT_IDS = {"softplus": 0, "relu": 1}
 
 
@@ -28,7 +28,7 @@ class FieldDesc(C.Structure):
                 ("app_dim", C.c_int32), ("shading", C.c_int32), ("fea_pe", C.c_int32), ("feature_c", C.c_int32),
                 ("act", C.c_int32), ("density_shift", C.c_float), ("distance_scale", C.c_float),
                 ("weight_thres", C.c_float), ("step_size", C.c_float), ("near", C.c_float), ("far", C.c_float),
-                ("z_gate", C.c_float)]
+                ("z_gate", C.c_float), ("view_pe", C.c_int32), ("pos_pe", C.c_int32)]
 
 
 class FieldParams(C.Structure):

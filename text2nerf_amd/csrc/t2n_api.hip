@@ -121,6 +121,13 @@ static int apply_desc(t2n_field* f, const t2n_field_desc* d) {
         if (d->app_dim != 27) { set_error("SH head needs app_dim 27"); return T2N_ERR_UNSUPPORTED; }
     } else if (d->shading == T2N_SHADE_RGB) {
         if (d->app_dim != 3) { set_error("RGB head needs app_dim 3"); return T2N_ERR_UNSUPPORTED; }
+    } else if (head_is_generic(d->shading)) {
+        const HeadDims H = head_dims(*d);
+        if (d->app_dim < 1 || d->app_dim > 32 || d->feature_c != 128 || H.K0 > 512 || d->view_pe < 0 || d->pos_pe < 0 || d->fea_pe < 0) {
+            set_error("unsupported view-dependent head shape: app_dim %d featureC %d inputs %d (need app_dim <= 32, featureC 128, inputs <= 512)",
+                      d->app_dim, d->feature_c, H.K0);
+            return T2N_ERR_UNSUPPORTED;
+        }
     } else {
         set_error("unsupported shading head %d", d->shading);
         return T2N_ERR_UNSUPPORTED;
@@ -422,7 +429,7 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
 extern "C" int t2n_field_upload(t2n_field* f, const t2n_field_params* p, t2n_stream stream) {
     if (!f || !p) { set_error("t2n_field_upload: NULL argument"); return T2N_ERR_INVALID; }
     if (!p->basis_weight) { set_error("t2n_field_upload: NULL basis_weight"); return T2N_ERR_INVALID; }
-    if (f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW && (!p->mlp_w0 || !p->mlp_b0 || !p->mlp_w1 || !p->mlp_b1 || !p->mlp_w2 || !p->mlp_b2)) {
+    if ((f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW || head_is_generic(f->desc.shading)) && (!p->mlp_w0 || !p->mlp_b0 || !p->mlp_w1 || !p->mlp_b1 || !p->mlp_w2 || !p->mlp_b2)) {
         set_error("t2n_field_upload: MLP head needs all six renderModule tensors");
         return T2N_ERR_INVALID;
     }
@@ -578,7 +585,30 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
             float* wbuf = L.weights ? L.weights : (float*)(ws + c.sigma);
             if ((rc = launch_march_tiles(f, L, f->frame_w, (int)(cnt / f->frame_w), wbuf, L.weights != nullptr, s))) return rc;
         } else if ((rc = launch_march(f, L, s))) return rc;
-        if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, nullptr, s))) return rc;
+        if (head_is_generic(f->desc.shading)) {
+            // general head path: the appearance-row count is needed on the host to size the activation scratch (one stream
+            // sync per sub-launch; the fused MLP_Fea_noview head needs none)
+            unsigned raw[kLists * kCounterStride], tb[kLists + 1];
+            T2N_HIP(hipMemcpyAsync(raw, L.counters, sizeof(raw), hipMemcpyDeviceToHost, s));
+            T2N_HIP(hipStreamSynchronize(s));
+            unsigned t = 0;
+            for (int l = 0; l < kLists; ++l) { unsigned cnt = raw[l * kCounterStride]; if (cnt > L.list_cap) cnt = L.list_cap; tb[l] = t; t += (cnt + 31u) / 32u; }
+            tb[kLists] = t;
+            const long long rows = (long long)t * 32;
+            if (rows > 0) {
+                const HeadDims H = head_dims(f->desc);
+                float* scratch = nullptr;
+                const size_t per_row = (size_t)(32 + H.K0pad + 128 + 128) * sizeof(float);
+                T2N_HIP(hipMallocAsync((void**)&scratch, (size_t)rows * per_row, s));
+                float* feat32 = scratch; float* x0 = feat32 + rows * 32; float* h0 = x0 + rows * H.K0pad; float* h1 = h0 + rows * 128;
+                ShadeCtx ctx{nullptr, feat32, nullptr, nullptr};
+                rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, &ctx, s, true);
+                if (!rc) rc = launch_head_forward(f, tb, rows, feat32, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, x0, h0,
+                                                  h1, L.app_rgb, s);
+                (void)hipFreeAsync(scratch, s);
+                if (rc) return rc;
+            }
+        } else if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, nullptr, s))) return rc;
         if ((rc = launch_composite(f, L, s))) return rc;
     }
     return T2N_OK;

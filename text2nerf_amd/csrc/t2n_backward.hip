@@ -1023,9 +1023,9 @@ static TnPlan tn_plan(int64_t rows, int N) {
     if (p.chunks < 1) p.chunks = 1;
     return p;
 }
-static size_t tn_part_bytes(int64_t rows) {
+static size_t tn_part_bytes(int64_t rows, int k0) {
     size_t m = 0;
-    const int shapes[3][2] = {{128, 128}, {128, 351}, {32, 144}};
+    const int shapes[3][2] = {{128, 128}, {128, k0}, {32, 144}};
     for (auto& sh : shapes) {
         const TnPlan p = tn_plan(rows, sh[1]);
         const size_t b = (size_t)p.chunks * sh[0] * p.ldp * 4;
@@ -1034,7 +1034,7 @@ static size_t tn_part_bytes(int64_t rows) {
     return m;
 }
 static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
-static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_tiles) {
+static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_tiles, int k0 = 351) {   // k0: inputs of MLP layer 0
     BwdCarve c;
     size_t o = 0;
     const size_t R = (size_t)rows;
@@ -1043,8 +1043,8 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
     c.h0 = o; o = al256(o + R * 128 * 4);
     c.h1 = o; o = al256(o + R * 128 * 4);
     c.go = o; o = al256(o + R * 16);
-    c.xpe = o; o = al256(o + R * 352 * 4);
-    c.part = o; o = al256(o + tn_part_bytes(rows));
+    c.xpe = o; o = al256(o + R * (size_t)((k0 + 3) & ~3) * 4);
+    c.part = o; o = al256(o + tn_part_bytes(rows, k0));
     // tile-binned density scatter: worst case one record per sample and plane
     const size_t cap = (size_t)n_rays * (size_t)n_samples;
     c.seg_cap = (unsigned)(3 * cap / 512 + (size_t)n_tiles + 1);
@@ -1128,7 +1128,8 @@ extern "C" int t2n_render_ctx_rows(const void* fwd_workspace, int64_t n_rays, in
 
 extern "C" size_t t2n_backward_workspace_bytes(const t2n_field* f, int64_t rows, int64_t n_rays, int n_samples) {
     if (!f || n_rays <= 0 || n_samples <= 0) return 0;
-    return bwd_carve(rows < 32 ? 32 : rows, n_rays, n_samples, bin_geom(f->dev.den).total).total;
+    const int k0 = head_is_generic(f->desc.shading) ? head_dims(f->desc).K0 : 351;
+    return bwd_carve(rows < 32 ? 32 : rows, n_rays, n_samples, bin_geom(f->dev.den).total, k0).total;
 }
 
 extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
@@ -1140,7 +1141,9 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         return T2N_ERR_INVALID;
     }
     if (!f->uploaded) { set_error("t2n_render_backward: field has no uploaded parameters"); return T2N_ERR_STATE; }
-    if (f->desc.shading != T2N_SHADE_MLP_FEA_NOVIEW) { set_error("t2n_render_backward: only the MLP_Fea_noview head is differentiable"); return T2N_ERR_UNSUPPORTED; }
+    const bool generic = head_is_generic(f->desc.shading);
+    if (f->desc.shading != T2N_SHADE_MLP_FEA_NOVIEW && !generic) { set_error("t2n_render_backward: the SH / RGB heads have no parameters to differentiate here"); return T2N_ERR_UNSUPPORTED; }
+    const int K0 = generic ? head_dims(f->desc).K0 : 351, K0pad = (K0 + 3) & ~3;
     if (!(flags & T2N_FLAG_KEEP_CTX)) { set_error("t2n_render_backward: forward was not run with T2N_FLAG_KEEP_CTX"); return T2N_ERR_STATE; }
     if ((flags & (T2N_FLAG_TRAIN | T2N_FLAG_NDC)) && !jitter) { set_error("t2n_render_backward: train / NDC mode needs the jitter draws / depth table"); return T2N_ERR_INVALID; }
     struct ZtabScope { t2n_field* f; ~ZtabScope() { f->dev.ztab = nullptr; } } ztab_scope{f};
@@ -1156,7 +1159,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     if (rc) return rc;
     const int64_t rows_alloc = rows < 32 ? 32 : rows;
     const BinGeom geom = bin_geom(f->dev.den);
-    const BwdCarve b = bwd_carve(rows_alloc, n_rays, n_samples, geom.total);
+    const BwdCarve b = bwd_carve(rows_alloc, n_rays, n_samples, geom.total, K0);
     if (b.total > bwd_workspace_bytes) { set_error("t2n_render_backward: backward workspace %zu B < %zu B", bwd_workspace_bytes, b.total); return T2N_ERR_WORKSPACE; }
     if ((rc = ensure_grad_buffers(f))) return rc;
 
@@ -1187,9 +1190,13 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
 
     // 1. appearance forward recompute with activations kept
     timing_begin(f, T2N_K_BWD_MLP, s);
-    if (rows > 0) {
+    if (rows > 0 && !generic) {
         ShadeCtx ctx{x144, feat32, h0, h1};
         if ((rc = launch_shade_list(f, app_pos, app_ray, rays, ray_stride, counters, c.list_cap, app_rgb, &ctx, s))) return rc;
+    } else if (rows > 0) {   // general heads: features from the shade kernel's first two stages, then the unfused MLP (xpe holds X0)
+        ShadeCtx ctx{x144, feat32, nullptr, nullptr};
+        if ((rc = launch_shade_list(f, app_pos, app_ray, rays, ray_stride, counters, c.list_cap, app_rgb, &ctx, s, true))) return rc;
+        if ((rc = launch_head_forward(f, tp.t, rows, feat32, app_pos, app_ray, rays, ray_stride, counters, c.list_cap, xpe, h0, h1, app_rgb, s))) return rc;
     }
     timing_end(f, T2N_K_BWD_MLP, s);
 
@@ -1252,13 +1259,14 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s);
         if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
         launch_gemm_nn(g1, 128, P->mlp_w1, 128, rows, 128, 128, h0, 128, g0, 128, s);
-        hipLaunchKernelGGL(k_pe_fwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)feat32, (long long)rows, xpe);
-        if (g->mlp_w0) launch_gemm_tn<4>(g0, 128, xpe, 352, rows, 128, 351, g->mlp_w0, 351, part, s);
+        if (!generic) hipLaunchKernelGGL(k_pe_fwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)feat32, (long long)rows, xpe);
+        if (g->mlp_w0) launch_gemm_tn<4>(g0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, s);
         if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g0, 128, (long long)rows, 128, g->mlp_b0, 128);
-        launch_gemm_nn(g0, 128, P->mlp_w0, 351, rows, 128, 351, nullptr, 0, gx, 352, s);
-        hipLaunchKernelGGL(k_pe_bwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)gx, (const float*)feat32, (long long)rows, gf);
-        if (g->basis_weight) launch_gemm_tn<1>(gf, 32, x144, 144, rows, 27, 144, g->basis_weight, 144, part, s);
-        launch_gemm_nn(gf, 32, P->basis_weight, 144, rows, 27, 144, nullptr, 0, gxapp, 144, s);
+        launch_gemm_nn(g0, 128, P->mlp_w0, K0, rows, 128, K0, nullptr, 0, gx, K0pad, s);
+        if (!generic) hipLaunchKernelGGL(k_pe_bwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)gx, (const float*)feat32, (long long)rows, gf);
+        else if ((rc = launch_head_in_bwd(f, gx, feat32, rows, gf, s))) return rc;
+        if (g->basis_weight) launch_gemm_tn<1>(gf, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, s);
+        launch_gemm_nn(gf, 32, P->basis_weight, 144, rows, f->desc.app_dim, 144, nullptr, 0, gxapp, 144, s);
         timing_end(f, T2N_K_BWD_MLP, s);
         T2N_HIP(hipGetLastError());
         // 5. appearance scatter

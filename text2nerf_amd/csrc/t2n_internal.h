@@ -128,7 +128,17 @@ inline unsigned list_capacity(long long n_rays, int n_samples) {
 // Activation rows kept by the shade kernel in ctx mode (row = tile * 32 + lane sample; zero rows past a sub-list's end)
 struct ShadeCtx { float* x144; float* feat32; float* h0; float* h1; };
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
-                      const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s);
+                      const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s,
+                      bool features_only = false);   // features_only: gather + basis stages only (the general heads take over)
+
+// the general (unfused) view-dependent heads (t2n_heads.hip): MLP_Fea / MLP_PE / MLP input layout and launchers
+struct HeadDims { int shading, C, fea_pe, view_pe, pos_pe, o_feat, o_view, o_pe_a, n_pe_a, o_pe_v, n_pe_v, K0, K0pad; };
+HeadDims head_dims(const t2n_field_desc& d);
+inline bool head_is_generic(int shading) { return shading == T2N_SHADE_MLP_FEA || shading == T2N_SHADE_MLP_PE || shading == T2N_SHADE_MLP; }
+int launch_head_forward(t2n_field* f, const unsigned tiles_before[kLists + 1], long long rows, const float* feat32, const float4* app_pos,
+                        const int* app_ray, const float* rays, int ray_stride, const unsigned* counters, unsigned list_cap, float* x0,
+                        float* h0, float* h1, float4* app_rgb, hipStream_t s);
+int launch_head_in_bwd(t2n_field* f, const float* gx, const float* feat32, long long rows, float* gf, hipStream_t s);
 
 // forward-workspace carve shared by forward and backward (t2n_api.hip)
 struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, total; unsigned list_cap; };

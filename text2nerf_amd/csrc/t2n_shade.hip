@@ -998,11 +998,13 @@ static bool use_coop(const t2n_field* f) {
 }
 
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
-                      const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s) {
+                      const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s,
+                      bool features_only) {
     ShadeArgs a;
     memset(&a, 0, sizeof(a));
     if (ctx) a.ctx = *ctx;
     a.F = f->dev;
+    if (features_only) a.F.shading = T2N_SHADE_RGB;   // gather + basis only; the rgb slots get placeholder values the head overwrites
     a.app_pos = app_pos; a.app_ray = app_ray; a.rays = rays; a.ray_stride = ray_stride;
     a.counters = counters_dev; a.list_cap = list_cap; a.nlists = kLists; a.app_rgb = app_rgb;
     const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
@@ -1046,10 +1048,12 @@ extern "C" int t2n_shade_at(const t2n_field* fc, const float* xyz_norm, const fl
     if (!f || !xyz_norm || n < 0 || n > 0x7fffffff) { set_error("t2n_shade_at: bad argument"); return T2N_ERR_INVALID; }
     if (!f->uploaded) { set_error("t2n_shade_at: field has no uploaded parameters"); return T2N_ERR_STATE; }
     if (f->desc.shading == T2N_SHADE_SH && rgb && !viewdirs) { set_error("t2n_shade_at: SH head needs viewdirs"); return T2N_ERR_INVALID; }
+    if (head_is_generic(f->desc.shading) && rgb) { set_error("t2n_shade_at: the view-dependent MLP heads are evaluated by the render call only (features are available)"); return T2N_ERR_UNSUPPORTED; }
     if (n == 0) return T2N_OK;
     ShadeArgs a;
     memset(&a, 0, sizeof(a));
     a.F = f->dev;
+    if (head_is_generic(f->desc.shading)) a.F.shading = T2N_SHADE_RGB;   // features only
     a.xyz = xyz_norm; a.viewdirs = viewdirs; a.count_max = (unsigned)n; a.nlists = 1; a.feat_out = app_feat; a.rgb_out = rgb;
     const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
     T2N_HIP(hipFuncSetAttribute((const void*)k_shade<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

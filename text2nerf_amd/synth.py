@@ -49,7 +49,7 @@ def mlp_in_channels(shading_mode: str, app_dim: int, fea_pe: int, view_pe: int =
 
 def make_field_params(seed, grid_size, density_n_comp=(16, 16, 16), app_n_comp=(48, 48, 48), app_dim=27,
                       feature_c=128, fea_pe=6, shading_mode="MLP_Fea_noview", scene="random",
-                      density_scale=0.1, app_scale=0.1, aabb=((-8., -8., -8.), (8., 8., 8.))):
+                      density_scale=0.1, app_scale=0.1, aabb=((-8., -8., -8.), (8., 8., 8.)), view_pe=6, pos_pe=6):
     """Return ``{state_dict key: float32 ndarray}`` for a TensorVMSplit field."""
     rng = np.random.Generator(np.random.PCG64(seed))
     g = [int(x) for x in grid_size]
@@ -67,7 +67,7 @@ def make_field_params(seed, grid_size, density_n_comp=(16, 16, 16), app_n_comp=(
         sd[f"app_plane.{i}"] = _randn(rng, (1, app_n_comp[i], g[m1], g[m0]), app_scale)
         sd[f"app_line.{i}"] = _randn(rng, (1, app_n_comp[i], g[v], 1), app_scale)
     sd["basis_mat.weight"], _ = _linear(rng, app_dim, int(sum(app_n_comp)))
-    in_c = mlp_in_channels(shading_mode, app_dim, fea_pe)
+    in_c = mlp_in_channels(shading_mode, app_dim, fea_pe, view_pe, pos_pe)
     if in_c:
         sd["renderModule.mlp.0.weight"], sd["renderModule.mlp.0.bias"] = _linear(rng, feature_c, in_c)
         sd["renderModule.mlp.2.weight"], sd["renderModule.mlp.2.bias"] = _linear(rng, feature_c, feature_c)

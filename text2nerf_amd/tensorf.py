@@ -148,6 +148,47 @@ class MLPRender_Fea_noview(nn.Module):
                        "TensorVMSplit.shade(xyz_norm) / forward(rays) instead")
 
 
+class _ViewHead(nn.Module):
+    """Parameter containers of the view-dependent heads with the reference's key names; their arithmetic runs on the general
+    head path of the HIP library (csrc/t2n_heads.hip), reached through TensorVMSplit.forward."""
+
+    def _build(self, in_mlpC, featureC):
+        self.in_mlpC = in_mlpC
+        l0, l1, l2 = nn.Linear(in_mlpC, featureC), nn.Linear(featureC, featureC), nn.Linear(featureC, 3)
+        self.mlp = nn.Sequential(l0, nn.ReLU(inplace=True), l1, nn.ReLU(inplace=True), l2)
+        nn.init.constant_(self.mlp[-1].bias, 0)
+
+    def forward(self, pts, viewdirs, features):
+        raise T2NError(f"{type(self).__name__} runs inside TensorVMSplit's HIP render call; use TensorVMSplit.forward(rays)")
+
+
+class MLPRender_Fea(_ViewHead):
+    """models/tensorBase.py:62-86: [features, viewdirs, PE(features, feape), PE(viewdirs, viewpe)] -> 3-layer MLP -> sigmoid."""
+
+    def __init__(self, inChanel, viewpe=6, feape=6, featureC=128):
+        super().__init__()
+        self.viewpe, self.feape = viewpe, feape
+        self._build(2 * viewpe * 3 + 2 * feape * inChanel + 3 + inChanel, featureC)
+
+
+class MLPRender_PE(_ViewHead):
+    """models/tensorBase.py:111-135: [features, viewdirs, PE(pts, pospe), PE(viewdirs, viewpe)]."""
+
+    def __init__(self, inChanel, viewpe=6, pospe=6, featureC=128):
+        super().__init__()
+        self.viewpe, self.pospe = viewpe, pospe
+        self._build((3 + 2 * viewpe * 3) + (3 + 2 * pospe * 3) + inChanel, featureC)
+
+
+class MLPRender(_ViewHead):
+    """models/tensorBase.py:137-159: [features, viewdirs, PE(viewdirs, viewpe)]."""
+
+    def __init__(self, inChanel, viewpe=6, featureC=128):
+        super().__init__()
+        self.viewpe = viewpe
+        self._build((3 + 2 * viewpe * 3) + inChanel, featureC)
+
+
 class TensorVMSplit(nn.Module):
     def __init__(self, aabb, gridSize, device, density_n_comp=8, appearance_n_comp=24, app_dim=27,
                  shadingMode="MLP_PE", alphaMask=None, near_far=[2.0, 6.0], density_shift=-10, alphaMask_thres=0.001,
@@ -192,6 +233,14 @@ class TensorVMSplit(nn.Module):
         self.init_svd_volume(gridSize[0], device)
         if shadingMode == "MLP_Fea_noview":
             self.renderModule = MLPRender_Fea_noview(self.app_dim, fea_pe, featureC).to(device)
+        elif shadingMode == "MLP_PE":        # models/tensorBase.py:201-208
+            raise T2NError("shadingMode 'MLP_PE': the reference's MLPRender_PE sizes its first layer for 3 inputs it never "
+                           "concatenates (models/tensorBase.py:115 vs :126-131) and fails with a shape error for every "
+                           "pos_pe / view_pe; there is no behaviour to reproduce")
+        elif shadingMode == "MLP_Fea":
+            self.renderModule = MLPRender_Fea(self.app_dim, view_pe, fea_pe, featureC).to(device)
+        elif shadingMode == "MLP":
+            self.renderModule = MLPRender(self.app_dim, view_pe, featureC).to(device)
         else:
             self.renderModule = None
 
@@ -323,6 +372,7 @@ class TensorVMSplit(nn.Module):
         d.step_size = float(self.stepSize)
         d.near, d.far = float(self.near_far[0]), float(self.near_far[1])
         d.z_gate = float(self.z_gate)
+        d.view_pe, d.pos_pe = int(self.view_pe), int(self.pos_pe)
         return d
 
     def _all_params(self):
