@@ -1015,7 +1015,7 @@ static TnPlan tn_plan(int64_t rows, int N) {
     TnPlan p;
     p.ng = (N + 127) / 128;
     p.ldp = p.ng * 128;
-    int64_t c = (rows * p.ng + 767) / 768;
+    int64_t c = (rows * p.ng + 383) / 384;   // ~384 workgroups: the partial slabs (and their reduction) stay small
     c = (c + 31) / 32 * 32;
     if (c < 64) c = 64;
     p.chunk_rows = (int)c;
