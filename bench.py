@@ -198,6 +198,8 @@ def main():
     ap.add_argument("--weights", type=int, default=0, help="1: also materialise weights/z_vals [R,N] like the reference")
     ap.add_argument("--factor-storage", default="fp32", choices=["fp32", "bf16"],
                     help="bf16: BASELINE configs[4] storage mode (render == fp32 render of the bf16-rounded factor tensors)")
+    ap.add_argument("--per-ray-marcher", action="store_true",
+                    help="disable the 8x8-tile marcher (default for whole row-major frames: field.frame_width = W)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the C3-shaped train-step timing (iters/s)")
     args = ap.parse_args()
@@ -231,6 +233,9 @@ def main():
     field, params, aabb = build_field(dev, scene=args.scene, seed=0 if args.scene.startswith("S1") else 1)
     field.materialize_weights = bool(args.weights)
     field.factor_storage = args.factor_storage
+    # the rays of a step are one whole row-major frame: the width hint lets the renderer use the tile marcher (rays of an 8x8
+    # pixel tile share their LDS-staged taps); results stay within the parity tolerances of the per-ray marcher
+    field.frame_width = 0 if args.per_ray_marcher else W
     N = field.nSamples
     poses = synth.local_fixed_like_poses(max(world, 9))
     pose = poses[rank % len(poses)] if world > 1 else np.eye(4, dtype=np.float32)
@@ -308,7 +313,7 @@ def main():
         split = not field.mlp_exact_fp32
         if dom == "march":
             achieved = (alg_bytes["march"] / launches) / (k_ms["march"] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_march", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"bound": "hbm", "kernel": "k_march" if args.per_ray_marcher else "k_march_tiles (+ k_compact_list)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg_bytes["march"] / launches, "avg_launch_ms": k_ms["march"],
                     "note": "field (69.6 MB) is cache-resident: achieved > HBM peak means the gather runs from L1/L2, "
@@ -334,7 +339,8 @@ def main():
                      ("; factor tensors stored as bf16" if args.factor_storage == "bf16" else ""),
             "data": "synthetic",
             "config": {"workload": f"C2: TensorVMSplit 300^3, 800x800 view/GPU, {N} samples/ray, render_only, scene "
-                                   f"{args.scene} seed 0, white_bg, weights/z_vals materialised: {bool(args.weights)}",
+                                   f"{args.scene} seed 0, white_bg, weights/z_vals materialised: {bool(args.weights)}, "
+                                   f"marcher: {'per-ray' if args.per_ray_marcher else '8x8-pixel tiles'}",
                        "rays_per_gpu": R, "samples_per_ray": N, "evaluated_samples_per_frame": V,
                        "appearance_samples_per_frame": A, "rays_per_s": world * R * args.steps / dt,
                        "evaluated_samples_per_s": world * V * args.steps / dt,

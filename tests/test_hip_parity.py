@@ -655,3 +655,30 @@ def test_atomic_scatter_fallback_path_gradients():
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                        timeout=600)
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:]
+
+
+def test_tile_marcher_inline_compaction_overflow_rays():
+    """Lazy-output eval frames compact the appearance list inside the tile marcher (<= N/4 staged entries per ray); rays with
+    more appearance samples than that go through the overflow list (k_compact_list). A fog field with few samples per ray
+    forces both: results equal the per-ray marcher's within the usual tolerances, sample counts exactly."""
+    aabb = [[-8.0] * 3, [8.0] * 3]
+    f = make_field(synth.make_field_params(1, [64] * 3, scene="S2", aabb=aabb), [64] * 3, aabb, [0.5, 8.0])
+    f.materialize_weights = False
+    rays = torch.from_numpy(synth.frame_rays_np(72, 88, c2w=synth.look_pose(0.1, 0.05, (0.2, -0.1, 2.0)))).to(dev())   # behind the z > 2 gate
+    for n in (8, 40):                      # cap = 2 and 10 staged entries per ray
+        with torch.no_grad():
+            f.frame_width = 0
+            a = f(rays, N_samples=n)
+            sa = f.stats()
+            f.materialize_weights = True
+            w = f(rays, N_samples=n)[3]
+            f.materialize_weights = False
+            f.frame_width = 88
+            b = f(rays, N_samples=n)
+            sb = f.stats()
+        per_ray = (w > 1e-4).sum(-1)
+        if n == 8:
+            assert int((per_ray > n // 4).sum()) > 50, "the scene must push rays over the staging capacity"
+        assert sa["evaluated"] == sb["evaluated"] and abs(sa["appearance"] - sb["appearance"]) <= 3
+        close(b[0], a[0].cpu().numpy(), atol=3e-5)
+        close(b[1], a[1].cpu().numpy(), atol=1e-4)

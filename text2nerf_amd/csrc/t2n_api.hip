@@ -365,6 +365,9 @@ Carve carve_workspace(int64_t rays, int n_samples, bool ctx) {
     c.app_ray = o; o = align_up(o + cap * 4, 256);
     c.sigma = o; if (ctx) o = align_up(o + (size_t)rays * n_samples * 4, 256);
     c.rgb_raw = o; if (ctx) o = align_up(o + (size_t)rays * 16, 256);
+    // tile marcher: per-ray staging of up to n_samples / 4 appearance entries (+ one 256-B line: overflow counter) and an
+    // overflow ray list
+    c.scratch = o; if (ctx) o = align_up(o + (size_t)rays * (size_t)(n_samples / 4 > 0 ? n_samples / 4 : 1) * 16 + 256 + (size_t)rays * 4, 256);
     c.total = o;
     return c;
 }
@@ -583,7 +586,7 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         if (tiles) {
             // weights go straight to the caller's tensor when it was requested, else to the scratch region
             float* wbuf = L.weights ? L.weights : (float*)(ws + c.sigma);
-            if ((rc = launch_march_tiles(f, L, f->frame_w, (int)(cnt / f->frame_w), wbuf, L.weights != nullptr, s))) return rc;
+            if ((rc = launch_march_tiles(f, L, f->frame_w, (int)(cnt / f->frame_w), wbuf, L.weights != nullptr, (float4*)(ws + c.scratch), s))) return rc;
         } else if ((rc = launch_march(f, L, s))) return rc;
         if (head_is_generic(f->desc.shading)) {
             // general head path: the appearance-row count is needed on the host to size the activation scratch (one stream

@@ -117,13 +117,16 @@ struct RenderLaunch {
 };
 int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s);
 int launch_ray_stats(const RenderLaunch& L, hipStream_t s);
-int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h, float* wbuf, bool wbuf_is_output, hipStream_t s);
+int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h, float* wbuf, bool wbuf_is_output, float4* scratch,
+                       hipStream_t s);   // scratch: [n_rays][n_samples / 4] entries for the in-kernel compaction (lazy-output renders)
 constexpr int kLists = 8;   // appearance sub-lists per sub-launch
 constexpr int kCounterStride = 64;   // unsigned words between sub-list counters: one 256-B line each (same-line atomics serialise)
 // list_cap(n_rays, N): worst-case entries of one sub-list = rays of the largest XCD run x samples
 inline unsigned list_capacity(long long n_rays, int n_samples) {
     const unsigned nblocks = (unsigned)((n_rays + 3) / 4);
-    return ((nblocks >> 3) + ((nblocks & 7u) ? 1u : 0u)) * 4u * (unsigned)n_samples;
+    // + one ray's worth of slack per list: reservations that do not fit a list move on to the next one (compact_ray), and
+    // with n_samples spare entries per list a ray that fits nowhere would imply more entries than rays x samples
+    return ((nblocks >> 3) + ((nblocks & 7u) ? 1u : 0u)) * 4u * (unsigned)n_samples + (unsigned)n_samples;
 }
 // Activation rows kept by the shade kernel in ctx mode (row = tile * 32 + lane sample; zero rows past a sub-list's end)
 struct ShadeCtx { float* x144; float* feat32; float* h0; float* h1; };
@@ -141,7 +144,7 @@ int launch_head_forward(t2n_field* f, const unsigned tiles_before[kLists + 1], l
 int launch_head_in_bwd(t2n_field* f, const float* gx, const float* feat32, long long rows, float* gf, hipStream_t s);
 
 // forward-workspace carve shared by forward and backward (t2n_api.hip)
-struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, total; unsigned list_cap; };
+struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, total; unsigned list_cap; };
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx);   // ctx: also room for sigma [rays,N] and rgb_raw [rays]
 int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s);
 

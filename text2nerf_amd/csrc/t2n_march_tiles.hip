@@ -25,6 +25,12 @@ struct TileArgs {
     const float* rays; long long n_rays; int ray_stride; int n_samples; int img_w, img_h;
     float* wbuf;        // [n_rays, n_samples]
     float* acc; float* depth; int4* ray_app;
+    // in-kernel compaction (lazy-output eval renders): every lane stages its ray's appearance entries (<= cap) in `scratch`; at
+    // the end the wave reserves ONE contiguous region of the appearance list for its 64 rays and copies the entries there,
+    // ray by ray in sample order. Rays with more than cap entries go to `ovf_list` and are compacted from wbuf by
+    // k_compact_list. scratch == NULL: the separate k_compact pass builds the lists (weights / z_vals requested).
+    float4* scratch; int cap; unsigned* ovf_count; int* ovf_list;
+    float4* app_pos; int* app_ray; unsigned* counters; unsigned list_cap; unsigned long long* stats;
 };
 
 __device__ __forceinline__ void lds_fence_w() {
@@ -190,16 +196,54 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
             a.wbuf[r * N + i] = w;
             acc += w;
             dep = fmaf(w, z, dep);
-            napp += w > F.thres ? 1u : 0u;
+            if (w > F.thres) {
+                if (a.scratch && napp < (unsigned)a.cap) a.scratch[(size_t)r * a.cap + napp] = make_float4(xn, yn, zn, w);
+                ++napp;
+            }
             if (first < 0) first = i;
             last = i;
         }
     }
+    const int Lw = last >= first && first >= 0 ? last - first + 1 : 0;
     if (have) {
-        const int Lw = last >= first && first >= 0 ? last - first + 1 : 0;
-        a.ray_app[r] = make_int4(0, (int)napp, Lw, Lw > 0 ? (first | (Lw << 11)) : 0);
         a.acc[r] = acc;
         a.depth[r] = dep + (1.f - acc) * ray.last;                                         // :504-505
+    }
+    if (!a.scratch) {
+        if (have) a.ray_app[r] = make_int4(0, (int)napp, Lw, Lw > 0 ? (first | (Lw << 11)) : 0);
+        return;
+    }
+    // ---- in-kernel compaction: one list reservation per wave -------------------------------------------------------------
+    const bool over = have && napp > (unsigned)a.cap;
+    const unsigned n = (have && !over) ? napp : 0u;
+    unsigned incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const unsigned total = __shfl(incl, 63);
+    const unsigned list = blockIdx.x & 7u;   // the block's XCD: the reservation atomic stays in that XCD's L2
+    unsigned base = 0;
+    if (lane == 0 && total) base = atomicAdd(&a.counters[list * kCounterStride], total);
+    base = __shfl(base, 0);
+    // a region that does not fit its sub-list (small or ragged frames put many tiles on one list): the wave's rays take the
+    // per-ray route below, which tries every sub-list; the inflated counter is clamped to list_cap by its readers
+    const bool fits = base + total <= a.list_cap;
+    const unsigned slot0 = list * a.list_cap + base + (incl - n);
+    if (have) {
+        if (over || !fits) {
+            const unsigned k = atomicAdd(a.ovf_count, 1u);
+            a.ovf_list[k] = (int)r;
+            a.ray_app[r] = make_int4(0, (int)napp, Lw, Lw > 0 ? (first | (Lw << 11)) : 0);   // k_compact_list finishes this ray
+        } else {
+            a.ray_app[r] = make_int4((int)slot0, fits ? (int)n : 0, Lw, Lw > 0 ? (first | (Lw << 11)) : 0);
+            if (fits)
+                for (unsigned k = 0; k < n; ++k) {
+                    a.app_pos[slot0 + k] = a.scratch[(size_t)r * a.cap + k];
+                    a.app_ray[slot0 + k] = (int)r;
+                }
+        }
     }
 }
 
@@ -212,21 +256,21 @@ struct CompactArgs {
     int4* ray_app; float4* app_pos; int* app_ray; unsigned* counters; unsigned list_cap;
     unsigned long long* stats; unsigned nblocks;
 };
-__global__ __launch_bounds__(256) void k_compact(const CompactArgs a) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+__device__ __forceinline__ void compact_ray(const CompactArgs& a, long long r, unsigned list, int lane) {
     const FieldDev& F = a.F;
-    const unsigned list = blockIdx.x & 7u;
-    const long long r = (long long)xcd_tile(blockIdx.x, a.nblocks) * 4 + wid;
-    if (r >= a.n_rays) return;
     const int N = a.n_samples;
     int4 ra = a.ray_app[r];
     const int first = ra.w & 2047, Lw = ra.w >> 11;
     unsigned napp = (unsigned)ra.y;
     unsigned slot0 = 0;
     if (lane == 0) {
-        if (napp) slot0 = atomicAdd(&a.counters[list * kCounterStride], napp);
-        const bool fits = slot0 + napp <= a.list_cap;
-        slot0 += list * a.list_cap;
+        bool fits = napp == 0;
+        for (unsigned att = 0; att < (unsigned)kLists && !fits; ++att) {     // first sub-list with room (failed tries leave the
+            const unsigned l = (list + att) & (unsigned)(kLists - 1);          // counter above list_cap: readers clamp it)
+            if (a.counters[l * kCounterStride] + napp > a.list_cap) continue;
+            const unsigned s0 = atomicAdd(&a.counters[l * kCounterStride], napp);
+            if (s0 + napp <= a.list_cap) { slot0 = l * a.list_cap + s0; fits = true; }
+        }
         a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, ra.z, ra.w);
         if (!fits && a.stats) a.stats[T2N_STAT_OVERFLOW] = 1ull;
         if (!fits) napp = 0;
@@ -263,16 +307,37 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a) {
         }
     }
 }
+__global__ __launch_bounds__(256) void k_compact(const CompactArgs a) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned list = blockIdx.x & 7u;
+    const long long r = (long long)xcd_tile(blockIdx.x, a.nblocks) * 4 + wid;
+    if (r >= a.n_rays) return;
+    compact_ray(a, r, list, lane);
+}
+// the rays the tile marcher could not stage (more than cap appearance samples): a small persistent grid walks the list
+__global__ __launch_bounds__(256) void k_compact_list(const CompactArgs a, const unsigned* ovf_count, const int* ovf_list) {
+    const int lane = threadIdx.x & 63;
+    const unsigned n = *ovf_count;
+    for (unsigned k = blockIdx.x * 4u + (threadIdx.x >> 6); k < n; k += gridDim.x * 4u) compact_ray(a, ovf_list[k], blockIdx.x & 7u, lane);
+}
 
-int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h, float* wbuf, bool wbuf_is_output, hipStream_t s) {
+int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h, float* wbuf, bool wbuf_is_output, float4* scratch,
+                       hipStream_t s) {
+    // in-kernel compaction when nothing but rgb / depth is wanted (the eval default): no weights zero-fill, no z_vals
+    const bool inline_compact = scratch && !wbuf_is_output && !L.z_vals;
+    const int cap = L.n_samples / 4 > 0 ? L.n_samples / 4 : 1;
+    unsigned* ovf_count = (unsigned*)((char*)scratch + (size_t)L.n_rays * cap * 16);
+    int* ovf_list = (int*)((char*)ovf_count + 256);
     TileArgs a;
     a.F = f->dev;
     a.rays = L.rays; a.n_rays = L.n_rays; a.ray_stride = L.ray_stride; a.n_samples = L.n_samples; a.img_w = img_w; a.img_h = img_h;
     a.wbuf = wbuf; a.acc = L.acc; a.depth = L.depth; a.ray_app = L.ray_app;
+    a.scratch = inline_compact ? scratch : nullptr; a.cap = cap; a.ovf_count = ovf_count; a.ovf_list = ovf_list;
+    a.app_pos = L.app_pos; a.app_ray = L.app_ray; a.counters = L.counters; a.list_cap = L.list_cap; a.stats = (unsigned long long*)L.stats;
+    if (inline_compact) T2N_HIP(hipMemsetAsync(ovf_count, 0, 4, s));
     const long long tiles = (long long)((img_w + 7) / 8) * ((img_h + 7) / 8);
-    timing_begin(f, T2N_K_DENSITY, s);
+    timing_begin(f, T2N_K_MARCH, s);
     hipLaunchKernelGGL(k_march_tiles, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, a);
-    timing_end(f, T2N_K_DENSITY, s);
     T2N_HIP(hipGetLastError());
     CompactArgs c;
     c.F = f->dev;
@@ -280,8 +345,8 @@ int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h
     c.wbuf = wbuf; c.zero_fill = wbuf_is_output ? 1 : 0; c.z_vals = L.z_vals;
     c.ray_app = L.ray_app; c.app_pos = L.app_pos; c.app_ray = L.app_ray; c.counters = L.counters; c.list_cap = L.list_cap;
     c.stats = (unsigned long long*)L.stats; c.nblocks = (unsigned)((L.n_rays + 3) / 4);
-    timing_begin(f, T2N_K_MARCH, s);
-    hipLaunchKernelGGL(k_compact, dim3(c.nblocks), dim3(256), 0, s, c);
+    if (inline_compact) hipLaunchKernelGGL(k_compact_list, dim3(64), dim3(256), 0, s, c, (const unsigned*)ovf_count, (const int*)ovf_list);
+    else hipLaunchKernelGGL(k_compact, dim3(c.nblocks), dim3(256), 0, s, c);
     timing_end(f, T2N_K_MARCH, s);
     T2N_HIP(hipGetLastError());
     return launch_ray_stats(L, s);

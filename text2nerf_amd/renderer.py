@@ -50,8 +50,9 @@ def render_views(tensorf, poses, intrinsic, H, W, N_samples=-1, white_bg=True):
     ``depth [V,H,W]``. Nothing crosses PCIe per view. ``intrinsic`` = [fx, fy, cx, cy]."""
     from .ray_utils import generate_rays
     dev = tensorf.basis_mat.weight.device
-    keep = tensorf.materialize_weights
+    keep, keep_w = tensorf.materialize_weights, tensorf.frame_width
     tensorf.materialize_weights = False            # evaluation discards weights / z_vals (renderer.py:89)
+    tensorf.frame_width = W                        # whole row-major frames: the 8x8-tile marcher applies
     rgbs, depths = [], []
     try:
         for c2w in poses:
@@ -60,7 +61,7 @@ def render_views(tensorf, poses, intrinsic, H, W, N_samples=-1, white_bg=True):
             rgbs.append(rgb.clamp(0.0, 1.0).reshape(H, W, 3))
             depths.append(depth.reshape(H, W))
     finally:
-        tensorf.materialize_weights = keep
+        tensorf.materialize_weights, tensorf.frame_width = keep, keep_w
     return torch.stack(rgbs), torch.stack(depths)
 
 
