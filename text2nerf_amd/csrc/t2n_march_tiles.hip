@@ -33,6 +33,10 @@ struct TileArgs {
     float4* app_pos; int* app_ray; unsigned* counters; unsigned list_cap; unsigned long long* stats;
 };
 
+// 16 B per lane global -> LDS without passing through registers; `lds_base` must be wave-uniform (lane l lands at base + 16 l)
+__device__ __forceinline__ void glds16(const void* g, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
 __device__ __forceinline__ void lds_fence_w() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -154,18 +158,26 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
                           aw[0] <= kLineRows && aw[1] <= kLineRows && aw[2] <= kLineRows;
         float part = 0.f;
         if (fits) {
+            // LDS-DMA staging (global_load_lds_dwordx4: destination = wave-uniform LDS base + lane * 16 B, no VGPRs, no
+            // ds_write pass): all nine transfers of the step are in flight together — a load -> ds_write loop chained ~9 L2
+            // round trips per step, and register staging spilled (the compute phase needs the registers)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int m0 = mat0(k), m1 = mat1(k), vv = vecm(k);
                 const float4* __restrict__ P = reinterpret_cast<const float4*>(F.den.plane[k]);
                 const int rowq = aw[m0] * 4, total = rowq * aw[m1], W = F.den.W[k];
-                for (int it = lane; it < total; it += 64) {
-                    const int row = it / rowq, c = it - row * rowq;
-                    stP[k][it] = P[((size_t)(amn[m1] + row) * W + amn[m0]) * 4 + c];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int it = lane + 64 * u;
+                    if (it < total) {
+                        const int row = it / rowq, c = it - row * rowq;
+                        glds16(P + ((size_t)(amn[m1] + row) * W + amn[m0]) * 4 + c, stP[k] + 64 * u);
+                    }
                 }
                 const float4* __restrict__ Ln = reinterpret_cast<const float4*>(F.den.line[k]);
-                if (lane < aw[vv] * 4) stL[k][lane] = Ln[(size_t)amn[vv] * 4 + lane];
+                if (lane < aw[vv] * 4) glds16(Ln + (size_t)amn[vv] * 4 + lane, stL[k]);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_fence_w();
             if (ok) {
 #pragma unroll
