@@ -1,25 +1,38 @@
 // Tile marcher (eval frames in image order): 8x8-pixel tiles, ONE LANE PER RAY, all 64 rays of a tile advance through the
 // same sample index together. At a given depth the 64 rays lie within a few texels of each other (pixel pitch t/f is far
-// below the texel size), so per factor pair the union of their bilinear footprints is a small rectangle: the wave fetches
-// that rectangle ONCE (row-contiguous, coalesced), stages it in LDS and every lane reads its 4+2 taps x 16 channels with
-// ds_read_b128. Against k_march's pass B (16 samples x 4 lanes per step, 18 scattered 64-B gathers per sample; PMC: texture
-// addresser 71 % busy, VALU ~70 %) this removes ~15x of the addresser work and the 4x-redundant per-sample coordinate
-// math. The transmittance is a per-lane running product in sample order — exactly the reference's cumprod order
+// below the texel size), so per factor pair the union of their bilinear footprints is a small rectangle of R texels and a
+// short segment of S line rows. The density feature of a sample is
+//     sum_k sum_c (sum_t w_t P_k[t][c]) * (sum_l w_l L_k[l][c])  =  sum_k sum_t sum_l w_t w_l D_k[t][l],
+//     D_k[t][l] = sum_c P_k[t][c] * L_k[l][c]      (t over the rectangle, l over the segment, c over the 16 components)
+// so the wave computes the small table D_k = P_k L_k^T ONCE per step on the matrix cores (v_mfma_f32_16x16x4_f32, exact
+// f32: one 16-B load per lane supplies the A operand of four k-steps, lane l holding texel l&15, components 4(l>>4)..+3),
+// parks it in LDS (<= 64 x 16 floats per plane) and every lane reads just its 4 x 2 table entries per plane — 96 B per sample
+// instead of the 1152 B of factor data the per-lane interpolation reads. (The staged-factor variant of this kernel was LDS
+// bandwidth-bound: 72 ds_read_b128 per wave step = 576 clk of the CU's 128 B/clk LDS pipe x 12 resident waves.)
+// Against k_march's pass B (16 samples x 4 lanes per step, 18 scattered 64-B gathers per sample; PMC: texture addresser 71 %
+// busy, VALU ~70 %) this removes ~15x of the addresser work and the 4x-redundant per-sample coordinate math. The
+// transmittance is a per-lane running product in sample order — exactly the reference's cumprod order
 // (models/tensorBase.py:23) — so no wave scan is needed; acc/depth accumulate in registers.
 //
 // Outputs per ray: weights of the valid window into wbuf[ray][sample] (the caller's weights tensor or scratch), acc, depth,
 // (n_app, n_valid, first | Lw << 11). The appearance list is then built by k_compact (one wave per ray: reservation atomic,
 // ballot/prefix compaction), which keeps the per-ray contiguous, sample-ordered slices k_shade / k_composite rely on.
-// Steps whose rectangles do not fit the staging area (incoherent rays, huge field of view) fall back to direct gathers.
+// Steps whose rectangles do not fit the table (incoherent rays, huge field of view) fall back to direct gathers.
 // Replaces the same reference lines as k_march (see t2n_march.hip).
 #include "t2n_device.h"
 
 namespace t2n {
 
-constexpr int kRectTexels = 32;    // staging capacity per plane rectangle (texels of 16 channels = 64 B each)
-constexpr int kLineRows = 8;       // staging capacity per line segment
-constexpr int kStageF4 = 3 * kRectTexels * 4 + 3 * kLineRows * 4;   // float4 per wave
+// Table geometry: a plane rectangle of up to 2^LOG2W x 2^LOG2W texels lives in fixed slots (slot = row << LOG2W | col, so no
+// division by the rectangle width), the line segment in up to 2^LOG2W rows. LOG2W = 2 (16 slots = ONE 16x16x4 MFMA row
+// block per plane) covers nearly every step of a pinhole frame; LOG2W = 3 (64 slots, four row blocks) takes the rest.
+constexpr int kMaxLog2W = 2;
+constexpr int kDStrideMax = (1 << (2 * kMaxLog2W)) + 4;   // floats per line row of the transposed table D^T[line row][slot]
+constexpr int kStageFloats = 3 * 16 * kDStrideMax;       // per wave
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+__device__ unsigned long long g_tile_dbg[8];
+__device__ unsigned long long g_tile_hist[16];
 struct TileArgs {
     FieldDev F;
     const float* rays; long long n_rays; int ray_stride; int n_samples; int img_w, img_h;
@@ -33,10 +46,6 @@ struct TileArgs {
     float4* app_pos; int* app_ray; unsigned* counters; unsigned list_cap; unsigned long long* stats;
 };
 
-// 16 B per lane global -> LDS without passing through registers; `lds_base` must be wave-uniform (lane l lands at base + 16 l)
-__device__ __forceinline__ void glds16(const void* g, void* lds_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
-}
 __device__ __forceinline__ void lds_fence_w() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -71,20 +80,76 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return max(max(a, b), max(c, d));
 }
 
-// accumulate the 16-channel dot product of (bilinear plane value) x (linear line value) for one factor pair from LDS
-__device__ __forceinline__ float pair_dot_lds(const float4* __restrict__ P, const float4* __restrict__ L, int nw, int ne, int sw, int se,
-                                              int l0, int l1, float wnw, float wne, float wsw, float wse, float wl0, float wl1,
-                                              float part) {
+__device__ __forceinline__ unsigned wave_or_u(unsigned v) {
+    v |= (unsigned)dpp_shr<0x111>((int)v, 0);
+    v |= (unsigned)dpp_shr<0x112>((int)v, 0);
+    v |= (unsigned)dpp_shr<0x114>((int)v, 0);
+    v |= (unsigned)dpp_shr<0x118>((int)v, 0);
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 15), b = (unsigned)__builtin_amdgcn_readlane((int)v, 31);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 47), d = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    return (a | b) | (c | d);
+}
+
+// One marching step of the wave through the dot-product tables (see the file header). amn[a] = lowest tap index of axis a
+// over the wave; every axis spans at most 2^LOG2W taps. Returns the lane's density feature (0 for !ok lanes).
+template <int LOG2W>
+__device__ __forceinline__ float table_step(const FactorSet& S, const Axes3& A, const int (&amn)[3], bool ok, float* __restrict__ stD,
+                                            int l15, int lq) {
+    constexpr int WS = 1 << LOG2W, SL = WS * WS, NB = SL / 16, ST = SL + 4;
+    const int gs[3] = {S.W[0], S.H[0], S.H[1]};
+    // phase 1: every operand load of the step in flight together; slots beyond the rectangle read clamped (valid, unused) texels
+    float4 av[3][NB], bv[3];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float4 v = f4_mul(P[nw + q], wnw);
-        v = f4_fma(P[ne + q], wne, v);
-        v = f4_fma(P[sw + q], wsw, v);
-        v = f4_fma(P[se + q], wse, v);
-        float4 l = f4_mul(L[l0 + q], wl0);
-        l = f4_fma(L[l1 + q], wl1, l);
-        part = fmaf(v.x, l.x, part); part = fmaf(v.y, l.y, part); part = fmaf(v.z, l.z, part); part = fmaf(v.w, l.w, part);
+    for (int k = 0; k < 3; ++k) {
+        const int m0 = mat0(k), m1 = mat1(k), vv = vecm(k);
+        const float4* __restrict__ P = reinterpret_cast<const float4*>(S.plane[k]);
+        const float4* __restrict__ Ln = reinterpret_cast<const float4*>(S.line[k]);
+        const unsigned jr = (unsigned)min(amn[vv] + (l15 & (WS - 1)), gs[vv] - 1);
+        bv[k] = Ln[jr * 4u + (unsigned)lq];
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) {
+            const int t = mb * 16 + l15;
+            const unsigned yy = (unsigned)min(amn[m1] + (t >> LOG2W), gs[m1] - 1), xx = (unsigned)min(amn[m0] + (t & (WS - 1)), gs[m0] - 1);
+            av[k][mb] = P[(yy * (unsigned)gs[m0] + xx) * 4u + (unsigned)lq];
+        }
     }
+    // phase 2: D_k^T[line row][slot] = sum_c L_k[row][c] P_k[slot][c]; the lane holds slots 4 lq..+3 of line row l15
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float* __restrict__ Dk = stD + k * 16 * ST + l15 * ST + lq * 4;
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) {
+            f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k][mb].x, bv[k].x, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k][mb].y, bv[k].y, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k][mb].z, bv[k].z, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k][mb].w, bv[k].w, d, 0, 0, 0);
+            *reinterpret_cast<float4*>(Dk + mb * 16) = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    }
+    lds_fence_w();
+    float part = 0.f;
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int m0 = mat0(k), m1 = mat1(k), vv = vecm(k);
+            const Axis& ax = A.a[m0];
+            const Axis& ay = A.a[m1];
+            const Axis& al = A.a[vv];
+            const int rx0 = ax.i0 - amn[m0], rx1 = ax.i1 - amn[m0];
+            const int ry0 = (ay.i0 - amn[m1]) << LOG2W, ry1 = (ay.i1 - amn[m1]) << LOG2W;
+            const float* __restrict__ D0 = stD + k * 16 * ST + (al.i0 - amn[vv]) * ST;
+            const float* __restrict__ D1 = stD + k * 16 * ST + (al.i1 - amn[vv]) * ST;
+            const float wnw = ay.w0 * ax.w0, wne = ay.w0 * ax.w1, wsw = ay.w1 * ax.w0, wse = ay.w1 * ax.w1;
+            float v0 = D0[ry0 + rx0] * wnw, v1 = D1[ry0 + rx0] * wnw;
+            v0 = fmaf(D0[ry0 + rx1], wne, v0); v1 = fmaf(D1[ry0 + rx1], wne, v1);
+            v0 = fmaf(D0[ry1 + rx0], wsw, v0); v1 = fmaf(D1[ry1 + rx0], wsw, v1);
+            v0 = fmaf(D0[ry1 + rx1], wse, v0); v1 = fmaf(D1[ry1 + rx1], wse, v1);
+            part = fmaf(v0, al.w0, part);
+            part = fmaf(v1, al.w1, part);
+        }
+    }
+    lds_fence_w();
     return part;
 }
 
@@ -98,7 +163,7 @@ __device__ __forceinline__ float pair_dot_global(const FactorSet& S, const Axes3
     const unsigned W = (unsigned)S.W[K];
     const unsigned nw = ((unsigned)ay.i0 * W + ax.i0) * 4, ne = ((unsigned)ay.i0 * W + ax.i1) * 4;
     const unsigned sw = ((unsigned)ay.i1 * W + ax.i0) * 4, se = ((unsigned)ay.i1 * W + ax.i1) * 4;
-#pragma unroll
+#pragma unroll 1   // the rare direct-gather step: keep its register footprint below the table path's (occupancy)
     for (int q = 0; q < 4; ++q) {
         float4 v = f4_mul(P[nw + q], ay.w0 * ax.w0);
         v = f4_fma(P[ne + q], ay.w0 * ax.w1, v);
@@ -112,12 +177,10 @@ __device__ __forceinline__ float pair_dot_global(const FactorSet& S, const Axes3
 }
 
 __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
-    __shared__ __attribute__((aligned(16))) float4 smem[4 * kStageF4];
+    __shared__ __attribute__((aligned(16))) float smem[4 * kStageFloats];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float4* __restrict__ stage = smem + (size_t)wid * kStageF4;
-    float4* __restrict__ stP[3] = {stage, stage + kRectTexels * 4, stage + 2 * kRectTexels * 4};
-    float4* __restrict__ stL[3] = {stage + 3 * kRectTexels * 4, stage + 3 * kRectTexels * 4 + kLineRows * 4,
-                                   stage + 3 * kRectTexels * 4 + 2 * kLineRows * 4};
+    const int l15 = lane & 15, lq = lane >> 4;
+    float* __restrict__ stD = smem + (size_t)wid * kStageFloats;
     const FieldDev& F = a.F;
     const int tiles_x = (a.img_w + 7) >> 3;
     const long long tile = (long long)blockIdx.x * 4 + wid;
@@ -137,85 +200,87 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
     float T = 1.f, acc = 0.f, dep = 0.f;
     int first = -1, last = -1;
     unsigned napp = 0;
+    int ovf_from = 0;    // first sample whose weight went to wbuf instead of the (full) staging slice
 
+#ifdef T2N_TILE_DEBUG
+    unsigned long long dbgA = 0, dbgB = 0, dbgC = 0, dbgD = 0, dbgN = 0;
+    const unsigned long long t00 = __builtin_amdgcn_s_memtime();
+#endif
     for (int i = wlo; i <= whi; ++i) {
+#ifdef T2N_TILE_DEBUG
+        const unsigned long long tA = __builtin_amdgcn_s_memtime();
+#endif
         float xn = 0.f, yn = 0.f, zn = 0.f, z = 0.f;
         bool ok = false;
         if (have && i >= lo && i <= hi) {
             z = sample_z<false>(F, ray, i, 0.f);
             ok = sample_point<false>(F, ray, z, xn, yn, zn);
         }
-        if (!__any(ok)) continue;
+        const unsigned long long okm = __ballot(ok);
+        if (!okm) continue;
         const Axes3 A = sample_axes(F.den, xn, yn, zn);
-        // per-axis tap ranges over the wave (the three rectangles and line segments are products of these)
-        const int big = 1 << 20;
-        const int mn0 = wave_min_i(ok ? A.a[0].i0 : big), mx0 = wave_max_i(ok ? A.a[0].i1 : -1);
-        const int mn1 = wave_min_i(ok ? A.a[1].i0 : big), mx1 = wave_max_i(ok ? A.a[1].i1 : -1);
-        const int mn2 = wave_min_i(ok ? A.a[2].i0 : big), mx2 = wave_max_i(ok ? A.a[2].i1 : -1);
-        const int amn[3] = {mn0, mn1, mn2};
-        const int aw[3] = {mx0 - mn0 + 1, mx1 - mn1 + 1, mx2 - mn2 + 1};
-        const bool fits = aw[0] * aw[1] <= kRectTexels && aw[0] * aw[2] <= kRectTexels && aw[1] * aw[2] <= kRectTexels &&
-                          aw[0] <= kLineRows && aw[1] <= kLineRows && aw[2] <= kLineRows;
+        // the low-tap indices present in the wave, per axis, as ONE or-reduced bit set: 10 bits per axis around the first
+        // live lane's index (bit 5); an index outside [-5, +4] of it raises bit 30 (the step then gathers directly)
+        const int lead = (int)__builtin_ctzll(okm);
+        const int ref0 = __builtin_amdgcn_readlane(A.a[0].i0, lead), ref1 = __builtin_amdgcn_readlane(A.a[1].i0, lead),
+                  ref2 = __builtin_amdgcn_readlane(A.a[2].i0, lead);
+        unsigned bits = 0u;
+        if (ok) {
+            const unsigned d0 = (unsigned)(A.a[0].i0 - ref0 + 5), d1 = (unsigned)(A.a[1].i0 - ref1 + 5), d2 = (unsigned)(A.a[2].i0 - ref2 + 5);
+            bits = (d0 < 10u ? 1u << d0 : 0x40000000u) | (d1 < 10u ? 1u << (10u + d1) : 0x40000000u) |
+                   (d2 < 10u ? 1u << (20u + d2) : 0x40000000u);
+        }
+        bits = wave_or_u(bits);
+        const unsigned f0 = bits & 1023u, f1 = (bits >> 10) & 1023u, f2 = (bits >> 20) & 1023u;
+        const int amn[3] = {ref0 - 5 + __builtin_ctz(f0), ref1 - 5 + __builtin_ctz(f1), ref2 - 5 + __builtin_ctz(f2)};
+        // taps per axis: the high tap is at most one above the highest low tap (and inside the grid)
+        const int span = max(max(32 - __builtin_clz(f0) - __builtin_ctz(f0), 32 - __builtin_clz(f1) - __builtin_ctz(f1)),
+                             32 - __builtin_clz(f2) - __builtin_ctz(f2)) + 1;
+        const bool ranged = !(bits & 0x40000000u);
+#ifdef T2N_TILE_DEBUG
+        const unsigned long long tB = __builtin_amdgcn_s_memtime();
+        dbgA += tB - tA;
+        if (T2N_TILE_DEBUG > 1 && lane == 0) atomicAdd(&g_tile_hist[ranged ? min(span, 15) : 0], 1ull);   // serialises: stats only
+#endif
         float part = 0.f;
-        if (fits) {
-            // LDS-DMA staging (global_load_lds_dwordx4: destination = wave-uniform LDS base + lane * 16 B, no VGPRs, no
-            // ds_write pass): all nine transfers of the step are in flight together — a load -> ds_write loop chained ~9 L2
-            // round trips per step, and register staging spilled (the compute phase needs the registers)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int m0 = mat0(k), m1 = mat1(k), vv = vecm(k);
-                const float4* __restrict__ P = reinterpret_cast<const float4*>(F.den.plane[k]);
-                const int rowq = aw[m0] * 4, total = rowq * aw[m1], W = F.den.W[k];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int it = lane + 64 * u;
-                    if (it < total) {
-                        const int row = it / rowq, c = it - row * rowq;
-                        glds16(P + ((size_t)(amn[m1] + row) * W + amn[m0]) * 4 + c, stP[k] + 64 * u);
-                    }
-                }
-                const float4* __restrict__ Ln = reinterpret_cast<const float4*>(F.den.line[k]);
-                if (lane < aw[vv] * 4) glds16(Ln + (size_t)amn[vv] * 4 + lane, stL[k]);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_fence_w();
-            if (ok) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int m0 = mat0(k), m1 = mat1(k), vv = vecm(k);
-                    const Axis& ax = A.a[m0];
-                    const Axis& ay = A.a[m1];
-                    const Axis& al = A.a[vv];
-                    const int rx0 = ax.i0 - amn[m0], rx1 = ax.i1 - amn[m0];
-                    const int ry0 = (ay.i0 - amn[m1]) * aw[m0], ry1 = (ay.i1 - amn[m1]) * aw[m0];
-                    part = pair_dot_lds(stP[k], stL[k], (ry0 + rx0) * 4, (ry0 + rx1) * 4, (ry1 + rx0) * 4, (ry1 + rx1) * 4,
-                                        (al.i0 - amn[vv]) * 4, (al.i1 - amn[vv]) * 4, ay.w0 * ax.w0, ay.w0 * ax.w1, ay.w1 * ax.w0,
-                                        ay.w1 * ax.w1, al.w0, al.w1, part);
-                }
-            }
-            lds_fence_w();
-        } else if (ok) {
+        if (ranged && span <= 4) part = table_step<2>(F.den, A, amn, ok, stD, l15, lq);
+        else if (ok) {
             part = pair_dot_global<0>(F.den, A, part);
             part = pair_dot_global<1>(F.den, A, part);
             part = pair_dot_global<2>(F.den, A, part);
         }
+#ifdef T2N_TILE_DEBUG
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        dbgB += __builtin_amdgcn_s_memtime() - tB;
+#endif
         if (ok) {
             const float sg = feature2density(F, part);
             const float dist = i < N - 1 ? sample_z<false>(F, ray, i + 1, 0.f) - z : 0.f;     // :448
             const float alpha = 1.f - expf((-sg) * (dist * F.dscale));                      // raw2alpha :19-26
             const float w = alpha * T;
             T = T * ((1.f - alpha) + 1e-10f);
-            a.wbuf[r * N + i] = w;
             acc += w;
             dep = fmaf(w, z, dep);
+            // in-kernel compaction: the dense weights row is only the spill area of a ray whose staging slice is full (64
+            // lanes x 4 B to 64 different rows per step cost 3x their bytes in partial-line HBM writes: 2 GB per frame)
+            if (!a.scratch || napp >= (unsigned)a.cap) a.wbuf[r * N + i] = w;
             if (w > F.thres) {
                 if (a.scratch && napp < (unsigned)a.cap) a.scratch[(size_t)r * a.cap + napp] = make_float4(xn, yn, zn, w);
                 ++napp;
+                if (napp == (unsigned)a.cap) ovf_from = i + 1;
             }
             if (first < 0) first = i;
             last = i;
         }
+#ifdef T2N_TILE_DEBUG
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dbgC += __builtin_amdgcn_s_memtime() - tB;
+        dbgN += 1;
+#endif
     }
+#ifdef T2N_TILE_DEBUG
+    const unsigned long long t01 = __builtin_amdgcn_s_memtime();
+#endif
     const int Lw = last >= first && first >= 0 ? last - first + 1 : 0;
     if (have) {
         a.acc[r] = acc;
@@ -247,7 +312,7 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
         if (over || !fits) {
             const unsigned k = atomicAdd(a.ovf_count, 1u);
             a.ovf_list[k] = (int)r;
-            a.ray_app[r] = make_int4(0, (int)napp, Lw, Lw > 0 ? (first | (Lw << 11)) : 0);   // k_compact_list finishes this ray
+            a.ray_app[r] = make_int4(ovf_from, (int)napp, Lw, Lw > 0 ? (first | (Lw << 11)) : 0);   // k_compact_list finishes this ray
         } else {
             a.ray_app[r] = make_int4((int)slot0, fits ? (int)n : 0, Lw, Lw > 0 ? (first | (Lw << 11)) : 0);
             if (fits)
@@ -257,6 +322,20 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
                 }
         }
     }
+#ifdef T2N_TILE_DEBUG
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long t02 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+        atomicAdd(&g_tile_dbg[0], dbgN);
+        atomicAdd(&g_tile_dbg[1], dbgA);
+        atomicAdd(&g_tile_dbg[2], dbgB);
+        atomicAdd(&g_tile_dbg[3], dbgC);
+        atomicAdd(&g_tile_dbg[4], t01 - t00);
+        atomicAdd(&g_tile_dbg[5], t02 - t01);
+        atomicAdd(&g_tile_dbg[6], 1ull);
+        atomicMax(&g_tile_dbg[7], t02 - t00);
+    }
+#endif
 }
 
 // Build the appearance list from the weights written by k_march_tiles: one wave per ray.
@@ -267,14 +346,12 @@ struct CompactArgs {
     float* z_vals;                // optional [n_rays, n_samples]
     int4* ray_app; float4* app_pos; int* app_ray; unsigned* counters; unsigned list_cap;
     unsigned long long* stats; unsigned nblocks;
+    const float4* scratch; int cap;   // k_compact_list: the marcher's per-ray staging slices
 };
-__device__ __forceinline__ void compact_ray(const CompactArgs& a, long long r, unsigned list, int lane) {
-    const FieldDev& F = a.F;
-    const int N = a.n_samples;
-    int4 ra = a.ray_app[r];
-    const int first = ra.w & 2047, Lw = ra.w >> 11;
-    unsigned napp = (unsigned)ra.y;
-    unsigned slot0 = 0;
+// lane 0 reserves `napp` slots on the first sub-list with room; returns (slot0, napp or 0 when nothing fits) to all lanes
+__device__ __forceinline__ void reserve_slots(const CompactArgs& a, long long r, unsigned list, int lane, const int4 ra, unsigned& slot0,
+                                              unsigned& napp) {
+    slot0 = 0;
     if (lane == 0) {
         bool fits = napp == 0;
         for (unsigned att = 0; att < (unsigned)kLists && !fits; ++att) {     // first sub-list with room (failed tries leave the
@@ -289,6 +366,53 @@ __device__ __forceinline__ void compact_ray(const CompactArgs& a, long long r, u
     }
     slot0 = __shfl(slot0, 0);
     napp = __shfl(napp, 0);
+}
+// append the entries of wbuf[r][from, end) above the threshold at slot0 + run.. (sample order)
+__device__ __forceinline__ void compact_span(const CompactArgs& a, long long r, const Ray& ray, int from, int end, unsigned slot0, unsigned run,
+                                             int lane) {
+    const FieldDev& F = a.F;
+    const int N = a.n_samples;
+    for (int base = from; base < end; base += 64) {
+        const int i = base + lane;
+        const float w = i < end ? a.wbuf[r * N + i] : 0.f;
+        const bool m = (i < end) & (w > F.thres);
+        const unsigned long long bal = __ballot(m);
+        if (m) {
+            const unsigned pre = (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+            const float z = sample_z<false>(F, ray, i, 0.f);
+            float xn, yn, zn;
+            sample_point<false>(F, ray, z, xn, yn, zn);
+            const unsigned s = slot0 + run + pre;
+            a.app_pos[s] = make_float4(xn, yn, zn, w);
+            a.app_ray[s] = (int)r;
+        }
+        run += (unsigned)__popcll(bal);
+    }
+}
+// a ray the tile marcher handed over (staging slice full, or its wave's region did not fit the sub-list): the first
+// min(napp, cap) entries sit in the staging slice, the rest in wbuf[r][from..]
+__device__ __forceinline__ void compact_ray_staged(const CompactArgs& a, long long r, unsigned list, int lane) {
+    const int4 ra = a.ray_app[r];
+    const int first = ra.w & 2047, Lw = ra.w >> 11, from = ra.x;
+    unsigned napp = (unsigned)ra.y, slot0;
+    reserve_slots(a, r, list, lane, ra, slot0, napp);
+    const unsigned staged = napp < (unsigned)a.cap ? napp : (unsigned)a.cap;
+    for (unsigned k = (unsigned)lane; k < staged; k += 64u) {
+        a.app_pos[slot0 + k] = a.scratch[(size_t)r * a.cap + k];
+        a.app_ray[slot0 + k] = (int)r;
+    }
+    if (napp > staged) {
+        const Ray ray = load_ray(a.F, a.rays + r * a.ray_stride, a.ray_stride);
+        compact_span(a, r, ray, from, first + Lw, slot0, staged, lane);
+    }
+}
+__device__ __forceinline__ void compact_ray(const CompactArgs& a, long long r, unsigned list, int lane) {
+    const FieldDev& F = a.F;
+    const int N = a.n_samples;
+    const int4 ra = a.ray_app[r];
+    const int first = ra.w & 2047, Lw = ra.w >> 11;
+    unsigned napp = (unsigned)ra.y, slot0;
+    reserve_slots(a, r, list, lane, ra, slot0, napp);
     if (a.zero_fill) {
         for (int base = 0; base < N; base += 64) {
             const int i = base + lane;
@@ -300,23 +424,7 @@ __device__ __forceinline__ void compact_ray(const CompactArgs& a, long long r, u
         if (a.z_vals)
             for (int base = 0; base < N; base += 64)
                 if (base + lane < N) a.z_vals[r * N + base + lane] = sample_z<false>(F, ray, base + lane, 0.f);
-        unsigned run = 0;
-        for (int base = 0; base < Lw; base += 64) {
-            const int j = base + lane;
-            const float w = j < Lw ? a.wbuf[r * N + first + j] : 0.f;
-            const bool m = (j < Lw) & (w > F.thres);
-            const unsigned long long bal = __ballot(m);
-            if (m) {
-                const unsigned pre = (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-                const float z = sample_z<false>(F, ray, first + j, 0.f);
-                float xn, yn, zn;
-                sample_point<false>(F, ray, z, xn, yn, zn);
-                const unsigned s = slot0 + run + pre;
-                a.app_pos[s] = make_float4(xn, yn, zn, w);
-                a.app_ray[s] = (int)r;
-            }
-            run += (unsigned)__popcll(bal);
-        }
+        if (napp) compact_span(a, r, ray, first, first + Lw, slot0, 0u, lane);
     }
 }
 __global__ __launch_bounds__(256) void k_compact(const CompactArgs a) {
@@ -330,7 +438,7 @@ __global__ __launch_bounds__(256) void k_compact(const CompactArgs a) {
 __global__ __launch_bounds__(256) void k_compact_list(const CompactArgs a, const unsigned* ovf_count, const int* ovf_list) {
     const int lane = threadIdx.x & 63;
     const unsigned n = *ovf_count;
-    for (unsigned k = blockIdx.x * 4u + (threadIdx.x >> 6); k < n; k += gridDim.x * 4u) compact_ray(a, ovf_list[k], blockIdx.x & 7u, lane);
+    for (unsigned k = blockIdx.x * 4u + (threadIdx.x >> 6); k < n; k += gridDim.x * 4u) compact_ray_staged(a, ovf_list[k], blockIdx.x & 7u, lane);
 }
 
 int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h, float* wbuf, bool wbuf_is_output, float4* scratch,
@@ -357,6 +465,7 @@ int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h
     c.wbuf = wbuf; c.zero_fill = wbuf_is_output ? 1 : 0; c.z_vals = L.z_vals;
     c.ray_app = L.ray_app; c.app_pos = L.app_pos; c.app_ray = L.app_ray; c.counters = L.counters; c.list_cap = L.list_cap;
     c.stats = (unsigned long long*)L.stats; c.nblocks = (unsigned)((L.n_rays + 3) / 4);
+    c.scratch = scratch; c.cap = cap;
     if (inline_compact) hipLaunchKernelGGL(k_compact_list, dim3(64), dim3(256), 0, s, c, (const unsigned*)ovf_count, (const int*)ovf_list);
     else hipLaunchKernelGGL(k_compact, dim3(c.nblocks), dim3(256), 0, s, c);
     timing_end(f, T2N_K_MARCH, s);
@@ -365,3 +474,20 @@ int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h
 }
 
 }  // namespace t2n
+#ifdef T2N_TILE_DEBUG
+extern "C" int t2n_debug_tile_counters(unsigned long long* out, int reset) {
+    int rc = (int)hipDeviceSynchronize();
+    if (rc) return rc;
+    rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(t2n::g_tile_dbg), 64);
+    if (rc) return 1000 + rc;
+    rc = (int)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(t2n::g_tile_hist), 128);
+    if (rc) return 2000 + rc;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(t2n::g_tile_dbg), z, 64);
+        hipMemcpyToSymbol(HIP_SYMBOL(t2n::g_tile_hist), z, 128);
+    }
+    return 0;
+}
+#endif
+
