@@ -301,11 +301,19 @@ __device__ __forceinline__ void ray_interval(const FieldDev& F, const Ray& ray, 
     }
 }
 
+// log1p(t) for t >= 0 as log(u) + (t - (u - 1)) / u with u = fl(1 + t): the second term restores what the rounding of 1 + t
+// dropped (first order; the neglected term is below 2^-48 relative), so the result is within ~1 ulp of the accurate logf —
+// at ~35 instructions instead of the ~130 of the library's double-float log1pf (a quarter of the tile marcher's step).
+__device__ __forceinline__ float log1p_pos(float t) {
+    const float u = 1.f + t;
+    return fmaf(t - (u - 1.f), __builtin_amdgcn_rcpf(u), logf(u));
+}
+
 // feature2density (models/tensorBase.py:406-410): softplus(beta=1, threshold=20) of feat+shift, or relu(feat).
 __device__ __forceinline__ float feature2density(const FieldDev& F, float feat) {
     if (F.act == T2N_ACT_RELU) return fmaxf(feat, 0.f);
     const float x = feat + F.shift;
-    return x > 20.f ? x : log1pf(expf(x));
+    return x > 20.f ? x : log1p_pos(expf(x));
 }
 
 // XCD-aware block -> logical tile map: the dispatcher places block b on XCD b % 8; give every XCD a contiguous run of

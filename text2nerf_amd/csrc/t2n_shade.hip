@@ -554,8 +554,13 @@ struct CoopRing {
     }
     __device__ __forceinline__ void advance(int c, uint4 (&A)[8]) {
         const int b = c & 1;
+#ifndef T2N_EXP_NOA
 #pragma unroll
         for (int i = 0; i < 8; ++i) A[i] = *slot(b, i * 64 + lane);
+#else
+#pragma unroll
+        for (int i = 0; i < 8; ++i) A[i] = make_uint4(c, lane, c, lane);
+#endif
         *slot(b ^ 1, tid) = n0; *slot(b ^ 1, 256 + tid) = n1;
         n0 = nn0; n1 = nn1;
         gload(nn0, nn1, c + 3);
@@ -575,12 +580,16 @@ __device__ __forceinline__ void coop_step(CoopRing& R, int c, f32x16 (&acc)[4], 
     for (int m = 0; m < 4; ++m) acc[m] = mfma16(__builtin_bit_cast(h8, A[2 * m]), blo, acc[m]);
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = mfma16(__builtin_bit_cast(h8, A[2 * m + 1]), bhi, acc[m]);
+#ifndef T2N_EXP_NOPREP
     float x[8];
     prep(x);
     h8 nhi, nlo;
     split8(x, nhi, nlo);
     bhi = nhi; blo = nlo;
+#endif
+#ifndef T2N_EXP_NOBARRIER
     __syncthreads();
+#endif
 }
 
 // Layer-0 B operands in PeChunk's order, unrolled over the three-chunk period of (four pairs per chunk, six octaves per
