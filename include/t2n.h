@@ -55,8 +55,9 @@ enum {
                                * (+ the shared train-time jitter, already added); dists are scaled by |d| and the SH head sees
                                * normalised view directions. Not used by the Text2NeRF driver (ndc_ray=0). */
     T2N_FLAG_COHERENT = 8u    /* hint (eval): rays are a row-major image whose width was given by t2n_field_set_frame_width:
-                                 march 8x8-pixel tiles with LDS-staged shared taps. Same samples, same arithmetic per sample;
-                                 the transmittance is a sequential product instead of a wave scan (weights agree to ~1e-7) */
+                                 march 8x8-pixel tiles whose rays share one texel x line-row dot-product table per step
+                                 (f32 matrix cores). Same samples; the density feature is summed in table order and the
+                                 transmittance is a sequential product instead of a wave scan (weights agree to ~2e-6) */
 };
 
 /* Scalars of TensorBase.__init__/update_stepSize (models/tensorBase.py:163-231), computed by the host mirror. */
