@@ -584,9 +584,7 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         T2N_HIP(hipMemsetAsync(L.counters, 0, (size_t)kLists * kCounterStride * 4, s));
         int rc;
         if (tiles) {
-            // weights go straight to the caller's tensor when it was requested, else to the scratch region
-            float* wbuf = L.weights ? L.weights : (float*)(ws + c.sigma);
-            if ((rc = launch_march_tiles(f, L, f->frame_w, (int)(cnt / f->frame_w), wbuf, L.weights != nullptr, (float4*)(ws + c.scratch), s))) return rc;
+            if ((rc = launch_march_tiles(f, L, f->frame_w, (int)(cnt / f->frame_w), (float*)(ws + c.sigma), (float4*)(ws + c.scratch), s))) return rc;
         } else if ((rc = launch_march(f, L, s))) return rc;
         if (head_is_generic(f->desc.shading)) {
             // general head path: the appearance-row count is needed on the host to size the activation scratch (one stream

@@ -117,8 +117,8 @@ struct RenderLaunch {
 };
 int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s);
 int launch_ray_stats(const RenderLaunch& L, hipStream_t s);
-int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h, float* wbuf, bool wbuf_is_output, float4* scratch,
-                       hipStream_t s);   // scratch: [n_rays][n_samples / 4] entries for the in-kernel compaction (lazy-output renders)
+// spill: [n_rays][n_samples] scratch rows (used only when L.weights is NULL); scratch: [n_rays][n_samples / 4] staging entries
+int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h, float* spill, float4* scratch, hipStream_t s);
 constexpr int kLists = 8;   // appearance sub-lists per sub-launch
 constexpr int kCounterStride = 64;   // unsigned words between sub-list counters: one 256-B line each (same-line atomics serialise)
 // list_cap(n_rays, N): worst-case entries of one sub-list = rays of the largest XCD run x samples

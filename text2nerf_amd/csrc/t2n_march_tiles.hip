@@ -14,9 +14,8 @@
 // transmittance is a per-lane running product in sample order — exactly the reference's cumprod order
 // (models/tensorBase.py:23) — so no wave scan is needed; acc/depth accumulate in registers.
 //
-// Outputs per ray: weights of the valid window into wbuf[ray][sample] (the caller's weights tensor or scratch), acc, depth,
-// (n_app, n_valid, first | Lw << 11). The appearance list is then built by k_compact (one wave per ray: reservation atomic,
-// ballot/prefix compaction), which keeps the per-ray contiguous, sample-ordered slices k_shade / k_composite rely on.
+// Outputs per ray: acc, depth, (slot0, n_app, n_valid, first | Lw << 11) and the ray's contiguous, sample-ordered slice of
+// the appearance list (in-kernel compaction, see TileArgs); with weights / z_vals requested (DENSE) also their whole rows.
 // Steps whose rectangles do not fit the table (incoherent rays, huge field of view) fall back to direct gathers.
 // Replaces the same reference lines as k_march (see t2n_march.hip).
 #include "t2n_device.h"
@@ -36,14 +35,17 @@ __device__ unsigned long long g_tile_hist[16];
 struct TileArgs {
     FieldDev F;
     const float* rays; long long n_rays; int ray_stride; int n_samples; int img_w, img_h;
-    float* wbuf;        // [n_rays, n_samples]
     float* acc; float* depth; int4* ray_app;
-    // in-kernel compaction (lazy-output eval renders): every lane stages its ray's appearance entries (<= cap) in `scratch`; at
-    // the end the wave reserves ONE contiguous region of the appearance list for its 64 rays and copies the entries there,
-    // ray by ray in sample order. Rays with more than cap entries go to `ovf_list` and are compacted from wbuf by
-    // k_compact_list. scratch == NULL: the separate k_compact pass builds the lists (weights / z_vals requested).
+    // in-kernel compaction: every lane stages its ray's appearance entries (<= cap) in `scratch`; at the end the wave reserves
+    // ONE contiguous region of the appearance list for its 64 rays and copies the entries there, ray by ray in sample order.
+    // A ray whose slice is full writes its further weights to its row of `wbuf` (the caller's weights tensor when one was
+    // requested, else a scratch matrix) and goes to `ovf_list`; k_compact_list finishes those rays.
+    float* wbuf;        // [n_rays, n_samples] spill rows
     float4* scratch; int cap; unsigned* ovf_count; int* ovf_list;
     float4* app_pos; int* app_ray; unsigned* counters; unsigned list_cap; unsigned long long* stats;
+    // DENSE: the caller's [n_rays, n_samples] weights / z_vals tensors (either may be NULL), written as whole rows — zeros
+    // outside the sampled window — through a per-wave LDS transpose: 16 steps x 64 rays, then 64-B row segments per store
+    float* dense_w; float* dense_z;
 };
 
 __device__ __forceinline__ void lds_fence_w() {
@@ -176,11 +178,18 @@ __device__ __forceinline__ float pair_dot_global(const FactorSet& S, const Axes3
     return part;
 }
 
+constexpr int kDenseLd = 20;                          // floats per ray row of the transpose tile (16 steps + pad, 16-B aligned)
+constexpr int kDenseFloats = 2 * 64 * kDenseLd;       // per wave: weights tile + z tile
+typedef float4 __attribute__((aligned(4))) float4_u;  // row segments of an [n_rays, N] tensor are only 4-B aligned for odd N
+
+template <bool DENSE>
 __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * kStageFloats];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     float* __restrict__ stD = smem + (size_t)wid * kStageFloats;
+    float* __restrict__ wt = smem + 4 * kStageFloats + (size_t)wid * kDenseFloats;   // DENSE only
+    float* __restrict__ zt = wt + 64 * kDenseLd;
     const FieldDev& F = a.F;
     const int tiles_x = (a.img_w + 7) >> 3;
     const long long tile = (long long)blockIdx.x * 4 + wid;
@@ -206,18 +215,31 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
     unsigned long long dbgA = 0, dbgB = 0, dbgC = 0, dbgD = 0, dbgN = 0;
     const unsigned long long t00 = __builtin_amdgcn_s_memtime();
 #endif
-    for (int i = wlo; i <= whi; ++i) {
+    // row segments of the transpose flush: lane -> (ray rho = lane / 4 + 16 j, columns 4 (lane & 3) .. + 3), j = 0..3
+    long long frow[4];
+    if constexpr (DENSE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rho = (lane >> 2) + 16 * j;
+            const int fx = tx * 8 + (rho & 7), fy = ty * 8 + (rho >> 3);
+            frow[j] = (fx < a.img_w && fy < a.img_h) ? ((long long)fy * a.img_w + fx) * N : -1;
+        }
+    }
+    for (int i = DENSE ? 0 : wlo; i <= (DENSE ? N - 1 : whi); ++i) {
 #ifdef T2N_TILE_DEBUG
         const unsigned long long tA = __builtin_amdgcn_s_memtime();
 #endif
-        float xn = 0.f, yn = 0.f, zn = 0.f, z = 0.f;
+        float xn = 0.f, yn = 0.f, zn = 0.f, z = 0.f, w_out = 0.f;
         bool ok = false;
         if (have && i >= lo && i <= hi) {
             z = sample_z<false>(F, ray, i, 0.f);
             ok = sample_point<false>(F, ray, z, xn, yn, zn);
+        } else if (DENSE && a.dense_z) {
+            z = sample_z<false>(F, ray, i, 0.f);
         }
         const unsigned long long okm = __ballot(ok);
-        if (!okm) continue;
+        if (!DENSE && !okm) continue;
+        if (okm) {
         const Axes3 A = sample_axes(F.den, xn, yn, zn);
         // the low-tap indices present in the wave, per axis, as ONE or-reduced bit set: 10 bits per axis around the first
         // live lane's index (bit 5); an index outside [-5, +4] of it raises bit 30 (the step then gathers directly)
@@ -263,14 +285,45 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
             dep = fmaf(w, z, dep);
             // in-kernel compaction: the dense weights row is only the spill area of a ray whose staging slice is full (64
             // lanes x 4 B to 64 different rows per step cost 3x their bytes in partial-line HBM writes: 2 GB per frame)
-            if (!a.scratch || napp >= (unsigned)a.cap) a.wbuf[r * N + i] = w;
+            if (napp >= (unsigned)a.cap && !(DENSE && a.dense_w)) a.wbuf[r * N + i] = w;
             if (w > F.thres) {
-                if (a.scratch && napp < (unsigned)a.cap) a.scratch[(size_t)r * a.cap + napp] = make_float4(xn, yn, zn, w);
+                if (napp < (unsigned)a.cap) a.scratch[(size_t)r * a.cap + napp] = make_float4(xn, yn, zn, w);
                 ++napp;
                 if (napp == (unsigned)a.cap) ovf_from = i + 1;
             }
             if (first < 0) first = i;
             last = i;
+            w_out = w;
+        }
+        }   // okm
+        if constexpr (DENSE) {
+            const int c16 = i & 15;
+            wt[lane * kDenseLd + c16] = w_out;
+            zt[lane * kDenseLd + c16] = z;
+            if (c16 == 15 || i == N - 1) {
+                lds_fence_w();
+                const int col = (i & ~15) + 4 * (lane & 3);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (frow[j] < 0 || col >= N) continue;
+                    const int rho = (lane >> 2) + 16 * j;
+                    const float4 vw = *reinterpret_cast<const float4*>(wt + rho * kDenseLd + 4 * (lane & 3));
+                    const float4 vz = *reinterpret_cast<const float4*>(zt + rho * kDenseLd + 4 * (lane & 3));
+                    if (col + 3 < N) {
+                        if (a.dense_w) *reinterpret_cast<float4_u*>(a.dense_w + frow[j] + col) = vw;
+                        if (a.dense_z) *reinterpret_cast<float4_u*>(a.dense_z + frow[j] + col) = vz;
+                    } else {
+                        const float ew[4] = {vw.x, vw.y, vw.z, vw.w}, ez[4] = {vz.x, vz.y, vz.z, vz.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e < N) {
+                                if (a.dense_w) a.dense_w[frow[j] + col + e] = ew[e];
+                                if (a.dense_z) a.dense_z[frow[j] + col + e] = ez[e];
+                            }
+                    }
+                }
+                lds_fence_w();
+            }
         }
 #ifdef T2N_TILE_DEBUG
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -285,10 +338,6 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
     if (have) {
         a.acc[r] = acc;
         a.depth[r] = dep + (1.f - acc) * ray.last;                                         // :504-505
-    }
-    if (!a.scratch) {
-        if (have) a.ray_app[r] = make_int4(0, (int)napp, Lw, Lw > 0 ? (first | (Lw << 11)) : 0);
-        return;
     }
     // ---- in-kernel compaction: one list reservation per wave -------------------------------------------------------------
     const bool over = have && napp > (unsigned)a.cap;
@@ -338,15 +387,14 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
 #endif
 }
 
-// Build the appearance list from the weights written by k_march_tiles: one wave per ray.
+// The rays the tile marcher handed over: one wave per ray finishes their appearance slices.
 struct CompactArgs {
     FieldDev F;
     const float* rays; long long n_rays; int ray_stride; int n_samples;
-    float* wbuf; int zero_fill;   // zero_fill: wbuf is the caller's weights tensor: write 0 outside the valid window
-    float* z_vals;                // optional [n_rays, n_samples]
+    const float* wbuf;                // spill rows (see TileArgs)
     int4* ray_app; float4* app_pos; int* app_ray; unsigned* counters; unsigned list_cap;
-    unsigned long long* stats; unsigned nblocks;
-    const float4* scratch; int cap;   // k_compact_list: the marcher's per-ray staging slices
+    unsigned long long* stats;
+    const float4* scratch; int cap;   // the marcher's per-ray staging slices
 };
 // lane 0 reserves `napp` slots on the first sub-list with room; returns (slot0, napp or 0 when nothing fits) to all lanes
 __device__ __forceinline__ void reserve_slots(const CompactArgs& a, long long r, unsigned list, int lane, const int4 ra, unsigned& slot0,
@@ -406,34 +454,6 @@ __device__ __forceinline__ void compact_ray_staged(const CompactArgs& a, long lo
         compact_span(a, r, ray, from, first + Lw, slot0, staged, lane);
     }
 }
-__device__ __forceinline__ void compact_ray(const CompactArgs& a, long long r, unsigned list, int lane) {
-    const FieldDev& F = a.F;
-    const int N = a.n_samples;
-    const int4 ra = a.ray_app[r];
-    const int first = ra.w & 2047, Lw = ra.w >> 11;
-    unsigned napp = (unsigned)ra.y, slot0;
-    reserve_slots(a, r, list, lane, ra, slot0, napp);
-    if (a.zero_fill) {
-        for (int base = 0; base < N; base += 64) {
-            const int i = base + lane;
-            if (i < N && (i < first || i >= first + Lw)) a.wbuf[r * N + i] = 0.f;
-        }
-    }
-    if (napp || a.z_vals) {
-        const Ray ray = load_ray(F, a.rays + r * a.ray_stride, a.ray_stride);
-        if (a.z_vals)
-            for (int base = 0; base < N; base += 64)
-                if (base + lane < N) a.z_vals[r * N + base + lane] = sample_z<false>(F, ray, base + lane, 0.f);
-        if (napp) compact_span(a, r, ray, first, first + Lw, slot0, 0u, lane);
-    }
-}
-__global__ __launch_bounds__(256) void k_compact(const CompactArgs a) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const unsigned list = blockIdx.x & 7u;
-    const long long r = (long long)xcd_tile(blockIdx.x, a.nblocks) * 4 + wid;
-    if (r >= a.n_rays) return;
-    compact_ray(a, r, list, lane);
-}
 // the rays the tile marcher could not stage (more than cap appearance samples): a small persistent grid walks the list
 __global__ __launch_bounds__(256) void k_compact_list(const CompactArgs a, const unsigned* ovf_count, const int* ovf_list) {
     const int lane = threadIdx.x & 63;
@@ -441,33 +461,34 @@ __global__ __launch_bounds__(256) void k_compact_list(const CompactArgs a, const
     for (unsigned k = blockIdx.x * 4u + (threadIdx.x >> 6); k < n; k += gridDim.x * 4u) compact_ray_staged(a, ovf_list[k], blockIdx.x & 7u, lane);
 }
 
-int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h, float* wbuf, bool wbuf_is_output, float4* scratch,
-                       hipStream_t s) {
-    // in-kernel compaction when nothing but rgb / depth is wanted (the eval default): no weights zero-fill, no z_vals
-    const bool inline_compact = scratch && !wbuf_is_output && !L.z_vals;
+int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h, float* spill, float4* scratch, hipStream_t s) {
     const int cap = L.n_samples / 4 > 0 ? L.n_samples / 4 : 1;
     unsigned* ovf_count = (unsigned*)((char*)scratch + (size_t)L.n_rays * cap * 16);
     int* ovf_list = (int*)((char*)ovf_count + 256);
+    const bool dense = L.weights || L.z_vals;
     TileArgs a;
     a.F = f->dev;
     a.rays = L.rays; a.n_rays = L.n_rays; a.ray_stride = L.ray_stride; a.n_samples = L.n_samples; a.img_w = img_w; a.img_h = img_h;
-    a.wbuf = wbuf; a.acc = L.acc; a.depth = L.depth; a.ray_app = L.ray_app;
-    a.scratch = inline_compact ? scratch : nullptr; a.cap = cap; a.ovf_count = ovf_count; a.ovf_list = ovf_list;
+    a.acc = L.acc; a.depth = L.depth; a.ray_app = L.ray_app;
+    a.wbuf = L.weights ? L.weights : spill;
+    a.scratch = scratch; a.cap = cap; a.ovf_count = ovf_count; a.ovf_list = ovf_list;
     a.app_pos = L.app_pos; a.app_ray = L.app_ray; a.counters = L.counters; a.list_cap = L.list_cap; a.stats = (unsigned long long*)L.stats;
-    if (inline_compact) T2N_HIP(hipMemsetAsync(ovf_count, 0, 4, s));
+    a.dense_w = L.weights; a.dense_z = L.z_vals;
+    T2N_HIP(hipMemsetAsync(ovf_count, 0, 4, s));
     const long long tiles = (long long)((img_w + 7) / 8) * ((img_h + 7) / 8);
+    const dim3 grid((unsigned)((tiles + 3) / 4));
     timing_begin(f, T2N_K_MARCH, s);
-    hipLaunchKernelGGL(k_march_tiles, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, a);
+    if (dense) hipLaunchKernelGGL(k_march_tiles<true>, grid, dim3(256), (size_t)4 * (kStageFloats + kDenseFloats) * sizeof(float), s, a);
+    else hipLaunchKernelGGL(k_march_tiles<false>, grid, dim3(256), (size_t)4 * kStageFloats * sizeof(float), s, a);
     T2N_HIP(hipGetLastError());
     CompactArgs c;
     c.F = f->dev;
     c.rays = L.rays; c.n_rays = L.n_rays; c.ray_stride = L.ray_stride; c.n_samples = L.n_samples;
-    c.wbuf = wbuf; c.zero_fill = wbuf_is_output ? 1 : 0; c.z_vals = L.z_vals;
+    c.wbuf = a.wbuf;
     c.ray_app = L.ray_app; c.app_pos = L.app_pos; c.app_ray = L.app_ray; c.counters = L.counters; c.list_cap = L.list_cap;
-    c.stats = (unsigned long long*)L.stats; c.nblocks = (unsigned)((L.n_rays + 3) / 4);
+    c.stats = (unsigned long long*)L.stats;
     c.scratch = scratch; c.cap = cap;
-    if (inline_compact) hipLaunchKernelGGL(k_compact_list, dim3(64), dim3(256), 0, s, c, (const unsigned*)ovf_count, (const int*)ovf_list);
-    else hipLaunchKernelGGL(k_compact, dim3(c.nblocks), dim3(256), 0, s, c);
+    hipLaunchKernelGGL(k_compact_list, dim3(64), dim3(256), 0, s, c, (const unsigned*)ovf_count, (const int*)ovf_list);
     timing_end(f, T2N_K_MARCH, s);
     T2N_HIP(hipGetLastError());
     return launch_ray_stats(L, s);
