@@ -394,6 +394,35 @@ def test_tile_marcher_matches_per_ray_marcher(big300):
     close(depth[idx], big300["S1-soft_depth"], atol=DEPTH_ATOL)
 
 
+def test_tile_marcher_low_resolution_frames_gather_directly():
+    """Frames whose neighbouring rays are many texels apart (24x24 pixels over a 300^3 field): a tile's taps span more than the
+    4x4 table on most steps, which then gather directly; steps near the camera still take the table path. Odd sample counts
+    and ragged sizes through both output modes (whole weights / z_vals rows, and rgb / depth only)."""
+    aabb = [[-8.0] * 3, [8.0] * 3]
+    f = make_field(synth.make_field_params(0, [300] * 3, scene="S1-soft", aabb=aabb), [300] * 3, aabb, [0.5, 8.0])
+    for (H, W, n) in ((24, 24, 45), (40, 56, 131)):
+        rays = torch.from_numpy(synth.frame_rays_np(H, W, c2w=synth.look_pose(-0.15, 0.1, (0.2, -0.1, -0.4)))).to(dev())
+        with torch.no_grad():
+            f.frame_width = 0
+            f.materialize_weights = True
+            a = f(rays, N_samples=n)
+            sa = f.stats()
+            f.frame_width = W
+            b = f(rays, N_samples=n)
+            sb = f.stats()
+            f.materialize_weights = False
+            c = f(rays, N_samples=n)
+            sc = f.stats()
+        assert sa["evaluated"] == sb["evaluated"] == sc["evaluated"] and sa["evaluated"] > 0
+        assert abs(sa["appearance"] - sb["appearance"]) <= 2 and sb["appearance"] == sc["appearance"]
+        assert torch.equal(a[2], b[2])                                   # z_vals rows, bit-exact
+        close(b[3], a[3].cpu().numpy(), atol=2e-6, rtol=2e-5)            # weights rows
+        for out in (b, c):
+            close(out[0], a[0].cpu().numpy(), atol=2e-5)
+            close(out[1], a[1].cpu().numpy(), atol=5e-5)
+        assert torch.equal(b[0], c[0]) and torch.equal(b[1], c[1])       # the two output modes run the same arithmetic
+
+
 @pytest.mark.parametrize("seed", [7, 8, 9, 10])
 def test_g6_train_black_background_coin(tiny, field, seed):
     """RNG stream parity: jitter draw, then the background coin (models/tensorBase.py:313-317,497), both on the CPU generator."""
