@@ -166,11 +166,11 @@ __device__ __forceinline__ void scatter_win(const FactorSet& S, const GradSet& G
 // A training batch puts ~28 samples into every texel of every density plane, from unrelated rays: global fp32 atomics per
 // tap (even merged along a ray) run at the L2 atomic rate. Instead: (1) count the samples of every 16x16-texel plane tile,
 // (2) prefix-sum, (3) write a 16-B record (x, y, z, dL/dfeature) per sample and plane into its tile's run, (4) one
-// workgroup per <= kBinSeg records of one tile accumulates plane AND line gradients in LDS (ds_add_f32 on a staged
-// 17x17xC tile + the whole line) and flushes the non-zero texels once. Global atomics drop ~15x.
+// workgroup per segment of one tile's records (segment size picked on the device by k_bin_scan) accumulates plane AND line
+// gradients in LDS (ds_add_f64 on a staged 17x17xC tile + the whole line) and flushes the non-zero texels once. Global
+// atomics drop ~15x.
 constexpr int kBinTile = 16;      // texels per tile edge (footprints reach one texel further: 17 staged)
 constexpr int kBinCopies = 32;    // privatised histogram / cursor copies (every ray starts in the camera's tile)
-constexpr int kBinSeg = 8192;     // records per accumulate workgroup (density)
 constexpr int kBinSegApp = 512;   // smallest segment (sizes the segment list); the scan picks the actual size per call
 constexpr unsigned kAccTargetSegs = 1024, kAccTargetSegsApp = 512;   // accumulate work items aimed at: whole rounds over 256 CUs
 constexpr unsigned kAccGrid = 2048;   // accumulate workgroups launched (grid-stride over the segment list)
@@ -550,7 +550,6 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
         T[lane * 3 + 2] = make_float4(al.w0, al.w1, 0.f, 0.f);
         if (b0 + 64 + lane < re) p = a.recs[b0 + 64 + lane];   // next batch in flight while this one is accumulated
         wave_lds_sync();
-        const int nrec = min(64, re - b0);
         // appearance: the 16 per-channel gradients this lane needs for the batch, all in flight before the accumulate loop
         // (a dependent global load per record inside the loop serialised ~1 us round trips)
         float gpre[16];

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_img_disc(const float* __restrict__ vis,
     if (y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2) {
         const float c = 1.f / vis[t];
         const float u = 1.f / vis[t - W], b = 1.f / vis[t + W], l = 1.f / vis[t - 1], r = 1.f / vis[t + 1];
-        d = (fabsf(c - u) > thr) | (fabsf(c - b) > thr) | (fabsf(c - l) > thr) | (fabsf(c - r) > thr);
+        d = (fabsf(c - u) > thr) || (fabsf(c - b) > thr) || (fabsf(c - l) > thr) || (fabsf(c - r) > thr);
     }
     if (orig[t] == 0.f) d = true;
     disc[t] = d ? 1 : 0;

@@ -180,7 +180,7 @@ __device__ __forceinline__ float pair_dot_global(const FactorSet& S, const Axes3
 
 constexpr int kDenseLd = 20;                          // floats per ray row of the transpose tile (16 steps + pad, 16-B aligned)
 constexpr int kDenseFloats = 2 * 64 * kDenseLd;       // per wave: weights tile + z tile
-typedef float4 __attribute__((aligned(4))) float4_u;  // row segments of an [n_rays, N] tensor are only 4-B aligned for odd N
+struct __attribute__((aligned(4))) F4U { float x, y, z, w; };   // row segments of an [n_rays, N] tensor are only 4-B aligned for odd N
 
 template <bool DENSE>
 __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
                     const float4 vw = *reinterpret_cast<const float4*>(wt + rho * kDenseLd + 4 * (lane & 3));
                     const float4 vz = *reinterpret_cast<const float4*>(zt + rho * kDenseLd + 4 * (lane & 3));
                     if (col + 3 < N) {
-                        if (a.dense_w) *reinterpret_cast<float4_u*>(a.dense_w + frow[j] + col) = vw;
-                        if (a.dense_z) *reinterpret_cast<float4_u*>(a.dense_z + frow[j] + col) = vz;
+                        if (a.dense_w) *reinterpret_cast<F4U*>(a.dense_w + frow[j] + col) = F4U{vw.x, vw.y, vw.z, vw.w};
+                        if (a.dense_z) *reinterpret_cast<F4U*>(a.dense_z + frow[j] + col) = F4U{vz.x, vz.y, vz.z, vz.w};
                     } else {
                         const float ew[4] = {vw.x, vw.y, vw.z, vw.w}, ez[4] = {vz.x, vz.y, vz.z, vz.w};
 #pragma unroll
