@@ -394,6 +394,40 @@ def test_tile_marcher_matches_per_ray_marcher(big300):
     close(depth[idx], big300["S1-soft_depth"], atol=DEPTH_ATOL)
 
 
+def test_tile_marcher_with_alpha_mask_matches_per_ray_marcher():
+    """AlphaGridMask branch (models/tensorBase.py:451-456) on the tile marcher: a checkerboard-ish occupancy volume leaves gaps
+    inside every ray's sample window; same evaluated counts, outputs equal to the per-ray marcher in both output modes, also
+    with rays pushed over the staging capacity (their spill rows must stay gap-free)."""
+    from text2nerf_amd import AlphaGridMask
+    aabb = [[-8.0] * 3, [8.0] * 3]
+    f = make_field(synth.make_field_params(0, [128] * 3, scene="S1-soft", aabb=aabb, density_scale=1.0), [128] * 3, aabb, [0.5, 8.0])
+    g = np.random.Generator(np.random.PCG64(77))
+    vol = (g.uniform(size=(24, 20, 28)) < 0.55).astype(np.float32)
+    f.alphaMask = AlphaGridMask(dev(), torch.tensor(aabb), torch.from_numpy(vol))
+    for (H, W, n) in ((64, 72, 200), (33, 40, 40)):
+        rays = torch.from_numpy(synth.frame_rays_np(H, W, c2w=synth.look_pose(0.3, 0.05, (0.0, 0.0, 2.0)))).to(dev())
+        with torch.no_grad():
+            f.frame_width = 0
+            f.materialize_weights = True
+            a = f(rays, N_samples=n)
+            sa = f.stats()
+            f.frame_width = W
+            b = f(rays, N_samples=n)
+            sb = f.stats()
+            f.materialize_weights = False
+            c = f(rays, N_samples=n)
+            sc = f.stats()
+        assert sa["evaluated"] == sb["evaluated"] == sc["evaluated"] and 0 < sa["evaluated"]
+        assert abs(sa["appearance"] - sb["appearance"]) <= 2 and sb["appearance"] == sc["appearance"]
+        assert torch.equal(a[2], b[2])
+        close(b[3], a[3].cpu().numpy(), atol=2e-6, rtol=2e-5)
+        for out in (b, c):
+            close(out[0], a[0].cpu().numpy(), atol=2e-5)
+            close(out[1], a[1].cpu().numpy(), atol=5e-5)
+    f.frame_width = 0
+    f.materialize_weights = True
+
+
 def test_tile_marcher_low_resolution_frames_gather_directly():
     """Frames whose neighbouring rays are many texels apart (24x24 pixels over a 300^3 field): a tile's taps span more than the
     4x4 table on most steps, which then gather directly; steps near the camera still take the table path. Odd sample counts

@@ -545,7 +545,7 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     if (n_rays == 0) return T2N_OK;
     const bool keep = (flags & T2N_FLAG_KEEP_CTX) != 0;
     // tile marcher: image-ordered eval rays with a known width (hint), whole rows per sub-launch
-    const bool tiles = (flags & T2N_FLAG_COHERENT) != 0 && !ndc && !keep && !(flags & T2N_FLAG_TRAIN) && !f->dev.alpha && f->frame_w >= 8 &&
+    const bool tiles = (flags & T2N_FLAG_COHERENT) != 0 && !ndc && !keep && !(flags & T2N_FLAG_TRAIN) && f->frame_w >= 8 &&
                        n_rays % f->frame_w == 0 && n_rays / f->frame_w >= 8;
     if (keep) {
         if (carve_workspace(n_rays, n_samples, true).total > workspace_bytes || (uint64_t)list_capacity(n_rays, n_samples) * kLists > 0x7fffffffull) {

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
     float T = 1.f, acc = 0.f, dep = 0.f;
     int first = -1, last = -1;
     unsigned napp = 0;
+    int nev = 0;         // evaluated samples (the window [first, last] has gaps under an alpha mask)
     int ovf_from = 0;    // first sample whose weight went to wbuf instead of the (full) staging slice
 
 #ifdef T2N_TILE_DEBUG
@@ -234,11 +235,14 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
         if (have && i >= lo && i <= hi) {
             z = sample_z<false>(F, ray, i, 0.f);
             ok = sample_point<false>(F, ray, z, xn, yn, zn);
+            if (F.alpha && ok) ok = alpha_pass(F, ray, z);      // models/tensorBase.py:451-456
         } else if (DENSE && a.dense_z) {
             z = sample_z<false>(F, ray, i, 0.f);
         }
         const unsigned long long okm = __ballot(ok);
-        if (!DENSE && !okm) continue;
+        // (a lane whose staging slice is full keeps its spill row gap-free: masked-out samples inside its window get zeros)
+        const bool spill = have && napp >= (unsigned)a.cap && !(DENSE && a.dense_w);
+        if (!DENSE && !okm && !__any(spill)) continue;
         if (okm) {
         const Axes3 A = sample_axes(F.den, xn, yn, zn);
         // the low-tap indices present in the wave, per axis, as ONE or-reduced bit set: 10 bits per axis around the first
@@ -285,7 +289,6 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
             dep = fmaf(w, z, dep);
             // in-kernel compaction: the dense weights row is only the spill area of a ray whose staging slice is full (64
             // lanes x 4 B to 64 different rows per step cost 3x their bytes in partial-line HBM writes: 2 GB per frame)
-            if (napp >= (unsigned)a.cap && !(DENSE && a.dense_w)) a.wbuf[r * N + i] = w;
             if (w > F.thres) {
                 if (napp < (unsigned)a.cap) a.scratch[(size_t)r * a.cap + napp] = make_float4(xn, yn, zn, w);
                 ++napp;
@@ -293,9 +296,11 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
             }
             if (first < 0) first = i;
             last = i;
+            ++nev;
             w_out = w;
         }
         }   // okm
+        if (spill) a.wbuf[r * N + i] = w_out;
         if constexpr (DENSE) {
             const int c16 = i & 15;
             wt[lane * kDenseLd + c16] = w_out;
@@ -361,9 +366,9 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
         if (over || !fits) {
             const unsigned k = atomicAdd(a.ovf_count, 1u);
             a.ovf_list[k] = (int)r;
-            a.ray_app[r] = make_int4(ovf_from, (int)napp, Lw, Lw > 0 ? (first | (Lw << 11)) : 0);   // k_compact_list finishes this ray
+            a.ray_app[r] = make_int4(ovf_from, (int)napp, nev, Lw > 0 ? (first | (Lw << 11)) : 0);   // k_compact_list finishes this ray
         } else {
-            a.ray_app[r] = make_int4((int)slot0, fits ? (int)n : 0, Lw, Lw > 0 ? (first | (Lw << 11)) : 0);
+            a.ray_app[r] = make_int4((int)slot0, fits ? (int)n : 0, nev, Lw > 0 ? (first | (Lw << 11)) : 0);
             if (fits)
                 for (unsigned k = 0; k < n; ++k) {
                     a.app_pos[slot0 + k] = a.scratch[(size_t)r * a.cap + k];
