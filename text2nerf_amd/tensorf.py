@@ -90,8 +90,15 @@ def to_device_async(t: torch.Tensor, device) -> torch.Tensor:
         return ring.copy(t, device)
 
 
-def workspace_budget() -> int:
-    return int(float(os.environ.get("T2N_WORKSPACE_GIB", "8")) * (1 << 30))
+def workspace_budget(device=None) -> int:
+    """Largest scratch buffer a render call may take (a call needing more is split into sub-launches by the library).
+    Default: an eighth of the device's memory, at most 32 GiB — on a 288 GB MI355X a whole 800x800 x 518-sample frame
+    (13.6 GiB worst-case lists, almost all of it reserved and never touched) runs as ONE launch; T2N_WORKSPACE_GIB overrides."""
+    env = os.environ.get("T2N_WORKSPACE_GIB")
+    if env is not None:
+        return int(float(env) * (1 << 30))
+    total = torch.cuda.get_device_properties(device).total_memory if device is not None and torch.cuda.is_available() else 64 << 30
+    return int(min(32 << 30, total // 8))
 
 
 def raw2alpha(sigma: torch.Tensor, dist: torch.Tensor):
@@ -747,7 +754,7 @@ class TensorVMSplit(nn.Module):
             flags |= FLAG_KEEP_CTX
         else:
             need = int(lib.t2n_render_workspace_bytes(max(R, 1), N))
-            ws = workspace(dev, min(need, max(workspace_budget(), int(lib.t2n_render_workspace_bytes(1024, N)))))
+            ws = workspace(dev, min(need, max(workspace_budget(dev), int(lib.t2n_render_workspace_bytes(1024, N)))))
         with torch.cuda.device(dev):
             _lib.check(lib.t2n_render_forward(h, _lib.ptr(rays), R, rays.shape[1], N, flags, _lib.ptr(jitter),
                                               _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(w), _lib.ptr(z),
