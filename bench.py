@@ -123,7 +123,9 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None):
         g.normal(0, 0.05, (allrays.shape[0],)).astype(np.float32))
     if fused_optim:   # TV gradient + Adam as HIP streaming kernels (text2nerf_amd/optim.py)
         from text2nerf_amd.optim import TVAdam
-        opt = TVAdam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+        # single process: the plane / line tensors are stepped on the device's channel-last copies from device-side gradients
+        # (data-parallel runs all-reduce reference-layout gradients, so they keep the reference-layout kernels)
+        opt = TVAdam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=field if dist is None else None)
     else:
         opt = torch.optim.Adam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
     tv, tl = TVLoss(), TransMittanceLoss_mask(dev)

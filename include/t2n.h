@@ -270,6 +270,21 @@ int t2n_adam_step_multi(int count, float* const* params, const float* const* gra
                         const int64_t* sizes, const float* lrs, float beta1, float beta2, float eps, const int64_t* steps,
                         t2n_stream stream);
 
+/* The same step where the data already is: on the field's channel-last device copies, with the channel-last gradients the last
+ * t2n_render_backward left in the field (call that with NULL plane / line pointers in t2n_field_grads: the layout pass back
+ * to [1,C,H,W] and the caller's zero-filled gradient tensors are then skipped). For each of the 12 factor tensors (order:
+ * density_plane[0..2], density_line[0..2], app_plane[0..2], app_line[0..2]): TV gradient (planes; weights as for
+ * t2n_tv_grad_add, 0 = none), Adam update with lrs[i] / steps[i], new values written to the device copy AND to the
+ * reference-layout tensor params-> (so the caller's nn.Parameters stay current and no t2n_field_upload of the factors is
+ * needed — follow with t2n_field_upload_head when the head's tensors changed). exp_avg / exp_avg_sq: caller-owned
+ * CHANNEL-LAST state buffers [pos][C] of the tensors' sizes. Per-element arithmetic identical to t2n_tv_grad_add +
+ * t2n_adam_step. Not available with bf16 factor storage (T2N_ERR_UNSUPPORTED). */
+int t2n_field_tv_adam_step(t2n_field* f, const t2n_field_params* params, float* const* exp_avg, float* const* exp_avg_sq,
+                           const float* lrs, const int64_t* steps, float beta1, float beta2, float eps,
+                           float tv_weight_density, float tv_weight_app, t2n_stream stream);
+/* re-pack basis_mat / renderModule only (the factor copies of an uploaded field are left as they are) */
+int t2n_field_upload_head(t2n_field* f, const t2n_field_params* p, t2n_stream stream);
+
 /* ---- coarse-to-fine / occupancy-mask maintenance between training stages.
  * t2n_compute_alpha: models/tensorBase.py:412-434 — alpha = 1 - exp(-sigma * length) at world-space points [n,3]; sigma = 0
  *   where the field's AlphaGridMask (if one is set) samples <= 0.

@@ -514,7 +514,10 @@ def test_f1_fused_tv_adam_matches_torch(tiny, tiny_params):
     def run(fused):
         f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
         groups = f.get_optparam_groups(0.02, 1e-3)
-        opt = TVAdam(groups, betas=(0.9, 0.99)) if fused else torch.optim.Adam(groups, betas=(0.9, 0.99))
+        if fused == "device":     # factor tensors stepped on the device's channel-last copies from device-side gradients
+            opt = TVAdam(groups, betas=(0.9, 0.99), field=f)
+        else:
+            opt = TVAdam(groups, betas=(0.9, 0.99)) if fused else torch.optim.Adam(groups, betas=(0.9, 0.99))
         tv = TVLoss()
         torch.manual_seed(5)
         for it in range(4):
@@ -528,16 +531,26 @@ def test_f1_fused_tv_adam_matches_torch(tiny, tiny_params):
                 opt.step(tv=[(f.density_plane, 0.1), (f.app_plane, 0.01)])
             else:
                 opt.step()
+            if fused == "device":
+                assert all(p.grad is None for p in f._all_params()[:12]) and f.basis_mat.weight.grad is not None
+        if fused == "device":
+            # the device copies the optimiser wrote (only the head is re-uploaded) are exactly what the nn.Parameters hold
+            with torch.no_grad():
+                own = f(rays, is_train=False, N_samples=40)
+                fresh = make_field({k: v.detach().cpu().numpy() for k, v in f.state_dict().items()}, TINY["grid"], TINY["aabb"],
+                                   TINY["near_far"])(rays, is_train=False, N_samples=40)
+            assert torch.equal(own[0], fresh[0]) and torch.equal(own[1], fresh[1]) and torch.equal(own[3], fresh[3])
         return {k: v.detach().clone() for k, v in f.state_dict().items()}
 
-    a, b = run(False), run(True)
-    for k in a:
-        d = float((a[k] - b[k]).abs().max())
-        # Adam normalises the step: an fp32 ulp of difference in a tiny gradient can move a parameter by a fraction of lr
-        # in rare elements, so compare against the lr scale (0.02 spatial / 1e-3 network) rather than bitwise
-        lr = 0.02 if ("plane" in k or "line" in k) else 1e-3
-        frac = float(((a[k] - b[k]).abs() > 0.02 * lr).float().mean())
-        assert d <= 2.5 * lr * 4 and frac < 1e-3, (k, d, frac)
+    a = run(False)
+    for b in (run(True), run("device")):
+        for k in a:
+            d = float((a[k] - b[k]).abs().max())
+            # Adam normalises the step: an fp32 ulp of difference in a tiny gradient can move a parameter by a fraction of
+            # lr in rare elements, so compare against the lr scale (0.02 spatial / 1e-3 network) rather than bitwise
+            lr = 0.02 if ("plane" in k or "line" in k) else 1e-3
+            frac = float(((a[k] - b[k]).abs() > 0.02 * lr).float().mean())
+            assert d <= 2.5 * lr * 4 and frac < 1e-3, (k, d, frac)
 
 
 def test_render_views_and_wide_ray_rows(tiny, field):

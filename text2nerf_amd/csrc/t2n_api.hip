@@ -447,6 +447,25 @@ extern "C" int t2n_field_upload(t2n_field* f, const t2n_field_params* p, t2n_str
     return T2N_OK;
 }
 
+extern "C" int t2n_field_upload_head(t2n_field* f, const t2n_field_params* p, t2n_stream stream) {
+    if (!f || !p) { set_error("t2n_field_upload_head: NULL argument"); return T2N_ERR_INVALID; }
+    if (!f->uploaded) { set_error("t2n_field_upload_head: the field has no uploaded factors yet (t2n_field_upload first)"); return T2N_ERR_INVALID; }
+    if (!p->basis_weight) { set_error("t2n_field_upload_head: NULL basis_weight"); return T2N_ERR_INVALID; }
+    if ((f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW || head_is_generic(f->desc.shading)) && (!p->mlp_w0 || !p->mlp_b0 || !p->mlp_w1 || !p->mlp_b1 || !p->mlp_w2 || !p->mlp_b2)) {
+        set_error("t2n_field_upload_head: MLP head needs all six renderModule tensors");
+        return T2N_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    timing_begin(f, T2N_K_UPLOAD, s);
+    const int rc = launch_pack_mlp(f, p, s);
+    timing_end(f, T2N_K_UPLOAD, s);
+    if (rc) return rc;
+    f->params_ref.basis_weight = p->basis_weight;
+    f->params_ref.mlp_w0 = p->mlp_w0; f->params_ref.mlp_b0 = p->mlp_b0; f->params_ref.mlp_w1 = p->mlp_w1; f->params_ref.mlp_b1 = p->mlp_b1;
+    f->params_ref.mlp_w2 = p->mlp_w2; f->params_ref.mlp_b2 = p->mlp_b2;
+    return T2N_OK;
+}
+
 extern "C" int t2n_ray_directions(int H, int W, float fx, float fy, float cx, float cy, int normalize, float* dirs, t2n_stream stream) {
     if (H <= 0 || W <= 0 || !dirs) { set_error("t2n_ray_directions: bad argument"); return T2N_ERR_INVALID; }
     const long long n = (long long)H * W;

@@ -61,9 +61,120 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamMulti a) {
     p[i] = p[i] - a.lr_over_bc1[t] * (mi / denom);
 }
 
+// ---- the same step on the field's channel-last master copies -------------------------------------------------------------
+// The renderer's backward leaves the factor gradients in channel-last buffers [pos][C] and the forward reads channel-last
+// factor copies, so the reference-form step pays four layout passes per iteration around the two streaming kernels above
+// (gradients -> [1,C,H,W], zero-filled gradient tensors, parameters -> channel-last). t2n_field_tv_adam_step does the whole
+// thing where the data already is: TV stencil on the channel-last parameters (neighbours at +-C and +-W*C), then one pass
+// that reads g / m / v / p channel-last, writes p / m / v channel-last and the new values into the caller's reference-layout
+// tensor through an LDS tile transpose. Same arithmetic per element as k_tv_grad_add + k_adam (bit-identical results).
+__global__ __launch_bounds__(256) void k_tv_grad_cl(const float* __restrict__ x, float* __restrict__ g, int C4, int H, int W, float sh,
+                                                    float sw) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 of 4 channels
+    const long long n = (long long)H * W * C4;
+    if (t >= n) return;
+    const long long pos = t / C4;
+    const int w = (int)(pos % W), h = (int)(pos / W);
+    const float4* __restrict__ X = reinterpret_cast<const float4*>(x);
+    const float4 v = X[t];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (the reference-layout kernel's order: up, down, left, right)
+    if (h > 0) { const float4 u = X[t - (long long)W * C4]; acc.x += sh * (2.f * (v.x - u.x)); acc.y += sh * (2.f * (v.y - u.y)); acc.z += sh * (2.f * (v.z - u.z)); acc.w += sh * (2.f * (v.w - u.w)); }
+    if (h < H - 1) { const float4 d = X[t + (long long)W * C4]; acc.x -= sh * (2.f * (d.x - v.x)); acc.y -= sh * (2.f * (d.y - v.y)); acc.z -= sh * (2.f * (d.z - v.z)); acc.w -= sh * (2.f * (d.w - v.w)); }
+    if (w > 0) { const float4 l = X[t - C4]; acc.x += sw * (2.f * (v.x - l.x)); acc.y += sw * (2.f * (v.y - l.y)); acc.z += sw * (2.f * (v.z - l.z)); acc.w += sw * (2.f * (v.w - l.w)); }
+    if (w < W - 1) { const float4 r = X[t + C4]; acc.x -= sw * (2.f * (r.x - v.x)); acc.y -= sw * (2.f * (r.y - v.y)); acc.z -= sw * (2.f * (r.z - v.z)); acc.w -= sw * (2.f * (r.w - v.w)); }
+    float4* G = reinterpret_cast<float4*>(g);
+    float4 gv = G[t];
+    gv.x += acc.x; gv.y += acc.y; gv.z += acc.z; gv.w += acc.w;
+    G[t] = gv;
+}
+
+__device__ __forceinline__ float adam_one(float p, float gi, float& m, float& v, float lr_over_bc1, float beta1, float beta2, float eps,
+                                          float inv_bc2_sqrt) {
+    const float mi = m + (gi - m) * (1.f - beta1);
+    const float vi = v * beta2 + (1.f - beta2) * gi * gi;
+    m = mi; v = vi;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    return p - lr_over_bc1 * (mi / denom);
+}
+// one workgroup = 64 positions x C channels (a contiguous run of the channel-last arrays)
+template <int C>
+__global__ __launch_bounds__(256) void k_adam_cl(float* __restrict__ p_cl, const float* __restrict__ g_cl, float* __restrict__ m, float* __restrict__ v,
+                                                 float* __restrict__ p_ref, long long npos_total, float lr_over_bc1, float beta1, float beta2,
+                                                 float eps, float inv_bc2_sqrt) {
+    __shared__ float tile[C][65];
+    const long long pos0 = (long long)blockIdx.x * 64;
+    const int npos = (int)(npos_total - pos0 < 64 ? npos_total - pos0 : 64);
+    const long long base4 = pos0 * (C / 4);
+    const int n4 = npos * (C / 4);
+    float4* __restrict__ P = reinterpret_cast<float4*>(p_cl) + base4;
+    const float4* __restrict__ G = reinterpret_cast<const float4*>(g_cl) + base4;
+    float4* __restrict__ M = reinterpret_cast<float4*>(m) + base4;
+    float4* __restrict__ V = reinterpret_cast<float4*>(v) + base4;
+    for (int e = threadIdx.x; e < n4; e += 256) {
+        float4 pv = P[e], mv = M[e], vv = V[e];
+        const float4 gv = G[e];
+        pv.x = adam_one(pv.x, gv.x, mv.x, vv.x, lr_over_bc1, beta1, beta2, eps, inv_bc2_sqrt);
+        pv.y = adam_one(pv.y, gv.y, mv.y, vv.y, lr_over_bc1, beta1, beta2, eps, inv_bc2_sqrt);
+        pv.z = adam_one(pv.z, gv.z, mv.z, vv.z, lr_over_bc1, beta1, beta2, eps, inv_bc2_sqrt);
+        pv.w = adam_one(pv.w, gv.w, mv.w, vv.w, lr_over_bc1, beta1, beta2, eps, inv_bc2_sqrt);
+        P[e] = pv; M[e] = mv; V[e] = vv;
+        const int j = e / (C / 4), c = (e - j * (C / 4)) * 4;
+        tile[c][j] = pv.x; tile[c + 1][j] = pv.y; tile[c + 2][j] = pv.z; tile[c + 3][j] = pv.w;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * 64; e += 256) {
+        const int c = e >> 6, j = e & 63;
+        if (j < npos) p_ref[(long long)c * npos_total + pos0 + j] = tile[c][j];
+    }
+}
+
 }  // namespace t2n
 
 using namespace t2n;
+
+extern "C" int t2n_field_tv_adam_step(t2n_field* f, const t2n_field_params* params, float* const* exp_avg, float* const* exp_avg_sq,
+                                      const float* lrs, const int64_t* steps, float beta1, float beta2, float eps,
+                                      float tv_weight_density, float tv_weight_app, t2n_stream stream) {
+    if (!f || !params || !exp_avg || !exp_avg_sq || !lrs || !steps) { set_error("t2n_field_tv_adam_step: NULL argument"); return T2N_ERR_INVALID; }
+    if (!f->uploaded || !f->gbuf_den_plane[0]) {
+        set_error("t2n_field_tv_adam_step: needs an uploaded field and the gradients of a t2n_render_backward call");
+        return T2N_ERR_INVALID;
+    }
+    if (f->factor_bf16) { set_error("t2n_field_tv_adam_step: bf16 factor storage keeps no fp32 master copy on the device"); return T2N_ERR_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    const int* gr = f->desc.grid;
+    for (int k = 0; k < 3; ++k) {
+        const int H = gr[mat1(k)], W = gr[mat0(k)];
+        const long long HW = (long long)H * W, L = gr[vecm(k)];
+        // order of the 12 tensors: density planes, density lines, appearance planes, appearance lines
+        float* pcl[4] = {f->buf_den_plane[k], f->buf_den_line[k], f->buf_app_plane[k], f->buf_app_line[k]};
+        float* gcl[4] = {f->gbuf_den_plane[k], f->gbuf_den_line[k], f->gbuf_app_plane[k], f->gbuf_app_line[k]};
+        float* pref[4] = {(float*)params->density_plane[k], (float*)params->density_line[k], (float*)params->app_plane[k], (float*)params->app_line[k]};
+        const int Cs[4] = {16, 16, 48, 48};
+        const long long ns[4] = {HW, L, HW, L};
+        const float tvw[4] = {tv_weight_density, 0.f, tv_weight_app, 0.f};
+        for (int q = 0; q < 4; ++q) {
+            const int idx = q * 3 + k;
+            if (!pref[q] || !exp_avg[idx] || !exp_avg_sq[idx] || steps[idx] < 1) { set_error("t2n_field_tv_adam_step: bad tensor %d", idx); return T2N_ERR_INVALID; }
+            const int C = Cs[q];
+            if (tvw[q] != 0.f) {
+                if (H < 2 || W < 2) { set_error("t2n_field_tv_adam_step: TV needs planes of at least 2x2"); return T2N_ERR_INVALID; }
+                const float sh = tvw[q] * 2.f / ((float)C * (float)(H - 1) * (float)W);
+                const float sw = tvw[q] * 2.f / ((float)C * (float)H * (float)(W - 1));
+                const long long n4 = HW * (C / 4);
+                hipLaunchKernelGGL(k_tv_grad_cl, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)pcl[q], gcl[q], C / 4, H, W, sh, sw);
+            }
+            const double bc1 = 1.0 - pow((double)beta1, (double)steps[idx]), bc2 = 1.0 - pow((double)beta2, (double)steps[idx]);
+            const float lr_over_bc1 = (float)((double)lrs[idx] / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+            const dim3 grid((unsigned)((ns[q] + 63) / 64));
+            if (C == 16) hipLaunchKernelGGL(k_adam_cl<16>, grid, dim3(256), 0, s, pcl[q], (const float*)gcl[q], exp_avg[idx], exp_avg_sq[idx], pref[q], ns[q], lr_over_bc1, beta1, beta2, eps, inv_bc2_sqrt);
+            else hipLaunchKernelGGL(k_adam_cl<48>, grid, dim3(256), 0, s, pcl[q], (const float*)gcl[q], exp_avg[idx], exp_avg_sq[idx], pref[q], ns[q], lr_over_bc1, beta1, beta2, eps, inv_bc2_sqrt);
+        }
+    }
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
 
 extern "C" int t2n_adam_step_multi(int count, float* const* params, const float* const* grads, float* const* exp_avg,
                                    float* const* exp_avg_sq, const int64_t* sizes, const float* lrs, float beta1, float beta2, float eps,

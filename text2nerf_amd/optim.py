@@ -27,12 +27,73 @@ def _bump_version(t):
 
 
 class TVAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """``field=tensorf`` (a TensorVMSplit with fp32 factor storage, single process): the 12 plane / line tensors are stepped
+    where their data already is — the backward leaves their gradients in the library's channel-last buffers
+    (``tensorf.defer_factor_grads``: ``.grad`` of those parameters stays None, ONE backward per step), and
+    ``t2n_field_tv_adam_step`` applies TV + Adam on the device's channel-last copies, writing the new values into the
+    nn.Parameters as well. Same per-element arithmetic; the Adam moments of those tensors live channel-last in
+    ``state[p]["exp_avg_cl"]`` / ``["exp_avg_sq_cl"]``. Without ``field`` every tensor takes the reference-layout kernels."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, field=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.field = None
+        if field is not None:
+            if not field.supports_deferred_factor_grads():
+                raise _lib.T2NError("TVAdam(field=...): needs a TensorVMSplit with fp32 factor storage")
+            self.field = field
+            field.defer_factor_grads = True
+
+    def _step_factors_on_device(self, tv, betas, eps):
+        """TV + Adam of the field's 12 factor tensors from the device-side gradients; returns the ids of the tensors handled."""
+        import ctypes as C
+        f = self.field
+        ps = f._all_params()
+        fac = ps[:12]
+        if getattr(f, "_deferred_grad_key", None) is None or f._deferred_grad_key != f._uploaded_key:
+            raise _lib.T2NError("TVAdam(field=...): no device-side factor gradients for the current parameters "
+                                "(call backward once, with tensorf.defer_factor_grads still set, before every step)")
+        tv_d = tv_a = 0.0
+        for planes, weight in tv:
+            if planes is f.density_plane:
+                tv_d = float(weight) * 1e-2
+            elif planes is f.app_plane:
+                tv_a = float(weight) * 1e-2
+            else:
+                raise _lib.T2NError("TVAdam(field=...): tv entries must be tensorf.density_plane / tensorf.app_plane")
+        lr_of = {id(p): float(g["lr"]) for g in self.param_groups for p in g["params"]}
+        lrs, steps, ms, vs = [], [], [], []
+        for p in fac:
+            if id(p) not in lr_of:
+                raise _lib.T2NError("TVAdam(field=...): every plane / line tensor of the field must be in a parameter group")
+            st = self.state[p]
+            if "exp_avg_cl" not in st:
+                st["step"] = 0
+                st["exp_avg_cl"] = torch.zeros(p.numel(), device=p.device, dtype=torch.float32)
+                st["exp_avg_sq_cl"] = torch.zeros(p.numel(), device=p.device, dtype=torch.float32)
+            st["step"] += 1
+            lrs.append(lr_of[id(p)]); steps.append(int(st["step"])); ms.append(st["exp_avg_cl"]); vs.append(st["exp_avg_sq_cl"])
+        dev = fac[0].device
+        VP = C.c_void_p * 12
+        with torch.cuda.device(dev):
+            pst = f._param_struct([p.detach() for p in ps])
+            _lib.check(_lib.load().t2n_field_tv_adam_step(f._handle, C.byref(pst), VP(*[t.data_ptr() for t in ms]),
+                                                          VP(*[t.data_ptr() for t in vs]), (C.c_float * 12)(*lrs),
+                                                          (C.c_int64 * 12)(*steps), float(betas[0]), float(betas[1]), eps, tv_d, tv_a,
+                                                          _lib.current_stream_ptr(dev)), "t2n_field_tv_adam_step")
+        for p in fac:
+            _bump_version(p)
+        f._device_factor_key = tuple((p.data_ptr(), p._version) for p in fac)   # the device copies are these values
+        f._deferred_grad_key = None
+        return {id(p) for p in fac}
 
     @torch.no_grad()
     def step(self, tv=()):
         lib = _lib.load()
+        done = set()
+        if self.field is not None and self.field.defer_factor_grads:
+            g0 = self.param_groups[0]
+            done = self._step_factors_on_device(tv, tuple(g0["betas"]), float(g0["eps"]))
+            tv = ()
         # 1. TV gradient of the listed plane groups: TV_loss_* = sum_planes 1e-2 * TVLoss(plane) (models/tensoRF.py:193-203)
         for planes, weight in tv:
             if weight == 0:
@@ -54,7 +115,7 @@ class TVAdam(torch.optim.Optimizer):
             elif tuple(group["betas"]) != betas or float(group["eps"]) != eps:
                 raise _lib.T2NError("TVAdam: all parameter groups must share betas and eps")
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or id(p) in done:
                     continue
                 if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
                     raise _lib.T2NError("TVAdam needs contiguous float32 parameters and gradients on the GPU")

@@ -221,6 +221,7 @@ class TensorVMSplit(nn.Module):
         self.step_ratio = step_ratio
         self.matMode, self.vecMode, self.comp_w = MAT_MODE, VEC_MODE, [1, 1, 1]
         self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC = shadingMode, pos_pe, view_pe, fea_pe, featureC
+        self.defer_factor_grads = False   # set by optim.TVAdam(field=self): plane / line gradients stay on the device (channel-last)
         self.materialize_weights = True   # the reference always returns weights/z_vals; set False to skip 8*N B/ray
         self.z_gate = 2.0                 # models/tensorBase.py:460
         self.frame_width = 0              # set to the image width when eval rays are whole row-major frames: enables the
@@ -400,16 +401,23 @@ class TensorVMSplit(nn.Module):
 
     def _param_struct(self, tensors, cls=_lib.FieldParams):
         s = cls()
-        t = [x if x is None else x for x in tensors]
+        t = [None if x is None else x.data_ptr() for x in tensors]   # None -> NULL (e.g. deferred factor gradients)
         for k in range(3):
-            s.density_plane[k] = t[k].data_ptr()
-            s.density_line[k] = t[3 + k].data_ptr()
-            s.app_plane[k] = t[6 + k].data_ptr()
-            s.app_line[k] = t[9 + k].data_ptr()
-        s.basis_weight = t[12].data_ptr()
+            s.density_plane[k] = t[k]
+            s.density_line[k] = t[3 + k]
+            s.app_plane[k] = t[6 + k]
+            s.app_line[k] = t[9 + k]
+        s.basis_weight = t[12]
         if len(t) > 13:
-            s.mlp_w0, s.mlp_b0, s.mlp_w1, s.mlp_b1, s.mlp_w2, s.mlp_b2 = [x.data_ptr() for x in t[13:19]]
+            s.mlp_w0, s.mlp_b0, s.mlp_w1, s.mlp_b1, s.mlp_w2, s.mlp_b2 = t[13:19]
         return s
+
+    def supports_deferred_factor_grads(self):
+        """True when the 12 factor nn.Parameters ARE the kernel's tensors (TensorVMSplit; not the stacked TensorVM / the
+        embedded TensorCP) and the device keeps fp32 master copies: then ``defer_factor_grads`` lets the backward leave the
+        plane / line gradients in the library's channel-last buffers for ``optim.TVAdam(field=...)`` to consume in place."""
+        return type(self)._kernel_views is TensorVMSplit._kernel_views and type(self)._autograd_params is TensorVMSplit._autograd_params \
+            and self.factor_storage == "fp32"
 
     def sync_params(self, force=False):
         """Create the native field on first use and re-upload when any parameter changed (in-place optimiser steps
@@ -465,9 +473,15 @@ class TensorVMSplit(nn.Module):
         if force or key != self._uploaded_key:
             with torch.cuda.device(dev):
                 st = self._param_struct([p.detach() for p in ps])
-                _lib.check(lib.t2n_field_upload(self._handle, C.byref(st), _lib.current_stream_ptr(dev)),
-                           "t2n_field_upload")
+                if not force and self._uploaded_key is not None and key[:12] == getattr(self, "_device_factor_key", None):
+                    # the factor copies on the device are current (optim.TVAdam stepped them in place): head only
+                    _lib.check(lib.t2n_field_upload_head(self._handle, C.byref(st), _lib.current_stream_ptr(dev)),
+                               "t2n_field_upload_head")
+                else:
+                    _lib.check(lib.t2n_field_upload(self._handle, C.byref(st), _lib.current_stream_ptr(dev)),
+                               "t2n_field_upload")
             self._uploaded_key = key
+            self._device_factor_key = key[:12]
         return self._handle
 
     def __del__(self):
@@ -972,7 +986,10 @@ class _RenderFn(torch.autograd.Function):
         lib = _lib.load()
         dev = rays.device
         params = field._autograd_params()
-        grads = [torch.zeros_like(p) for p in params]
+        # deferred mode: the 12 plane / line gradients stay in the library's channel-last buffers (no layout pass, no
+        # zero-filled 69.6 MB of gradient tensors); optim.TVAdam(field=...) steps from there. ONE backward per step.
+        defer = bool(getattr(field, "defer_factor_grads", False)) and field.supports_deferred_factor_grads()
+        grads = [None if (defer and i < 12) else torch.zeros_like(p) for i, p in enumerate(params)]
         gs = field._param_struct(field._kernel_views(grads), _lib.FieldGrads)
         R = rays.shape[0]
         d_rgb = torch.zeros(R, 3, device=dev) if d_rgb is None else d_rgb.contiguous().float()
@@ -992,4 +1009,5 @@ class _RenderFn(torch.autograd.Function):
                                                C.byref(gs), _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.ptr(bws), bws.numel(),
                                                st), "t2n_render_backward")
         ctx.ws = None
+        field._deferred_grad_key = field._uploaded_key if defer else None   # which parameters the device-side gradients belong to
         return (None, None, None, None, None) + tuple(grads)
