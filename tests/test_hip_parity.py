@@ -553,6 +553,44 @@ def test_f1_fused_tv_adam_matches_torch(tiny, tiny_params):
             assert d <= 2.5 * lr * 4 and frac < 1e-3, (k, d, frac)
 
 
+def test_f1_device_side_step_survives_coarse_to_fine(tiny, tiny_params):
+    """TVAdam(field=...) across an upsample_volume_grid (text2nerf_main.py:596-601 re-creates the optimiser after it): the
+    native field, its gradient buffers and the device copies are rebuilt; the first step after the resize matches the
+    reference-layout TVAdam from the same state."""
+    from text2nerf_amd.optim import TVAdam
+    rays = torch.from_numpy(tiny["tiny_rays"])
+    tgt = torch.from_numpy(tiny["g6_train_rgb"]).to(dev()) * 0.5
+
+    def step(f, opt, seed):
+        torch.manual_seed(seed)
+        rgb, depth, z, w = f(rays, is_train=True, white_bg=True, N_samples=40)
+        loss = ((rgb - tgt) ** 2).mean() + 0.005 * (depth ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step(tv=[(f.density_plane, 0.1), (f.app_plane, 0.01)])
+        return float(loss.detach())
+
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    opt = TVAdam(f.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=f)
+    for it in range(2):
+        step(f, opt, 11 + it)
+    new_grid = [int(g * 1.5) for g in TINY["grid"]]
+    f.upsample_volume_grid(new_grid)
+    state = {k: v.detach().cpu().numpy().copy() for k, v in f.state_dict().items()}
+    opt = TVAdam(f.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=f)
+    la = step(f, opt, 21)
+    ref = make_field(state, new_grid, TINY["aabb"], TINY["near_far"])
+    ropt = TVAdam(ref.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    lb = step(ref, ropt, 21)
+    assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb))
+    a, b = f.state_dict(), ref.state_dict()
+    for k in a:
+        lr = 0.02 if ("plane" in k or "line" in k) else 1e-3
+        frac = float(((a[k] - b[k]).abs() > 0.02 * lr).float().mean())
+        assert frac < 1e-3, (k, frac)
+    step(f, opt, 22)   # and keeps going (head-only upload path)
+
+
 def test_render_views_and_wide_ray_rows(tiny, field):
     """render_views (device-side rays per pose) equals rendering host-built rays; rays with extra channels use their
     LAST channel for the depth background term (models/tensorBase.py:505)."""
