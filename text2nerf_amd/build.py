@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libt2n_hip.so")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-DNDEBUG"] + (["-DT2N_TILE_DEBUG=" + os.environ["T2N_TILE_DEBUG"]] if os.environ.get("T2N_TILE_DEBUG") else [])
+         "-fno-fast-math", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-DNDEBUG"]
 
 
 def sources():

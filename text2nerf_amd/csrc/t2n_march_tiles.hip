@@ -30,8 +30,6 @@ constexpr int kDStrideMax = (1 << (2 * kMaxLog2W)) + 4;   // floats per line row
 constexpr int kStageFloats = 3 * 16 * kDStrideMax;       // per wave
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-__device__ unsigned long long g_tile_dbg[8];
-__device__ unsigned long long g_tile_hist[16];
 struct TileArgs {
     FieldDev F;
     const float* rays; long long n_rays; int ray_stride; int n_samples; int img_w, img_h;
@@ -92,11 +90,11 @@ __device__ __forceinline__ unsigned wave_or_u(unsigned v) {
     return (a | b) | (c | d);
 }
 
-// One marching step of the wave through the dot-product tables (see the file header). amn[a] = lowest tap index of axis a
-// over the wave; every axis spans at most 2^LOG2W taps. Returns the lane's density feature (0 for !ok lanes).
+// The dot-product tables of one wave step (see the file header). amn[a] = lowest tap index of axis a over the wave; every axis
+// spans at most 2^LOG2W taps. table_build computes D_k^T[line row][slot] for the three pairs into the wave's LDS area;
+// table_read returns a lane's density feature from its 4 x 2 entries per pair. Several samples per lane may share one build.
 template <int LOG2W>
-__device__ __forceinline__ float table_step(const FactorSet& S, const Axes3& A, const int (&amn)[3], bool ok, float* __restrict__ stD,
-                                            int l15, int lq) {
+__device__ __forceinline__ void table_build(const FactorSet& S, const int (&amn)[3], float* __restrict__ stD, int l15, int lq) {
     constexpr int WS = 1 << LOG2W, SL = WS * WS, NB = SL / 16, ST = SL + 4;
     const int gs[3] = {S.W[0], S.H[0], S.H[1]};
     // phase 1: every operand load of the step in flight together; slots beyond the rectangle read clamped (valid, unused) texels
@@ -129,29 +127,29 @@ __device__ __forceinline__ float table_step(const FactorSet& S, const Axes3& A, 
             *reinterpret_cast<float4*>(Dk + mb * 16) = make_float4(d[0], d[1], d[2], d[3]);
         }
     }
-    lds_fence_w();
+}
+template <int LOG2W>
+__device__ __forceinline__ float table_read(const Axes3& A, const int (&amn)[3], const float* __restrict__ stD) {
+    constexpr int WS = 1 << LOG2W, SL = WS * WS, ST = SL + 4;
     float part = 0.f;
-    if (ok) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int m0 = mat0(k), m1 = mat1(k), vv = vecm(k);
-            const Axis& ax = A.a[m0];
-            const Axis& ay = A.a[m1];
-            const Axis& al = A.a[vv];
-            const int rx0 = ax.i0 - amn[m0], rx1 = ax.i1 - amn[m0];
-            const int ry0 = (ay.i0 - amn[m1]) << LOG2W, ry1 = (ay.i1 - amn[m1]) << LOG2W;
-            const float* __restrict__ D0 = stD + k * 16 * ST + (al.i0 - amn[vv]) * ST;
-            const float* __restrict__ D1 = stD + k * 16 * ST + (al.i1 - amn[vv]) * ST;
-            const float wnw = ay.w0 * ax.w0, wne = ay.w0 * ax.w1, wsw = ay.w1 * ax.w0, wse = ay.w1 * ax.w1;
-            float v0 = D0[ry0 + rx0] * wnw, v1 = D1[ry0 + rx0] * wnw;
-            v0 = fmaf(D0[ry0 + rx1], wne, v0); v1 = fmaf(D1[ry0 + rx1], wne, v1);
-            v0 = fmaf(D0[ry1 + rx0], wsw, v0); v1 = fmaf(D1[ry1 + rx0], wsw, v1);
-            v0 = fmaf(D0[ry1 + rx1], wse, v0); v1 = fmaf(D1[ry1 + rx1], wse, v1);
-            part = fmaf(v0, al.w0, part);
-            part = fmaf(v1, al.w1, part);
-        }
+    for (int k = 0; k < 3; ++k) {
+        const int m0 = mat0(k), m1 = mat1(k), vv = vecm(k);
+        const Axis& ax = A.a[m0];
+        const Axis& ay = A.a[m1];
+        const Axis& al = A.a[vv];
+        const int rx0 = ax.i0 - amn[m0], rx1 = ax.i1 - amn[m0];
+        const int ry0 = (ay.i0 - amn[m1]) << LOG2W, ry1 = (ay.i1 - amn[m1]) << LOG2W;
+        const float* __restrict__ D0 = stD + k * 16 * ST + (al.i0 - amn[vv]) * ST;
+        const float* __restrict__ D1 = stD + k * 16 * ST + (al.i1 - amn[vv]) * ST;
+        const float wnw = ay.w0 * ax.w0, wne = ay.w0 * ax.w1, wsw = ay.w1 * ax.w0, wse = ay.w1 * ax.w1;
+        float v0 = D0[ry0 + rx0] * wnw, v1 = D1[ry0 + rx0] * wnw;
+        v0 = fmaf(D0[ry0 + rx1], wne, v0); v1 = fmaf(D1[ry0 + rx1], wne, v1);
+        v0 = fmaf(D0[ry1 + rx0], wsw, v0); v1 = fmaf(D1[ry1 + rx0], wsw, v1);
+        v0 = fmaf(D0[ry1 + rx1], wse, v0); v1 = fmaf(D1[ry1 + rx1], wse, v1);
+        part = fmaf(v0, al.w0, part);
+        part = fmaf(v1, al.w1, part);
     }
-    lds_fence_w();
     return part;
 }
 
@@ -183,7 +181,7 @@ constexpr int kDenseFloats = 2 * 64 * kDenseLd;       // per wave: weights tile 
 struct __attribute__((aligned(4))) F4U { float x, y, z, w; };   // row segments of an [n_rays, N] tensor are only 4-B aligned for odd N
 
 template <bool DENSE>
-__global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_march_tiles(const TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -212,10 +210,6 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
     int nev = 0;         // evaluated samples (the window [first, last] has gaps under an alpha mask)
     int ovf_from = 0;    // first sample whose weight went to wbuf instead of the (full) staging slice
 
-#ifdef T2N_TILE_DEBUG
-    unsigned long long dbgA = 0, dbgB = 0, dbgC = 0, dbgD = 0, dbgN = 0;
-    const unsigned long long t00 = __builtin_amdgcn_s_memtime();
-#endif
     // row segments of the transpose flush: lane -> (ray rho = lane / 4 + 16 j, columns 4 (lane & 3) .. + 3), j = 0..3
     long long frow[4];
     if constexpr (DENSE) {
@@ -226,119 +220,138 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
             frow[j] = (fx < a.img_w && fy < a.img_h) ? ((long long)fy * a.img_w + fx) * N : -1;
         }
     }
-    for (int i = DENSE ? 0 : wlo; i <= (DENSE ? N - 1 : whi); ++i) {
-#ifdef T2N_TILE_DEBUG
-        const unsigned long long tA = __builtin_amdgcn_s_memtime();
-#endif
-        float xn = 0.f, yn = 0.f, zn = 0.f, z = 0.f, w_out = 0.f;
-        bool ok = false;
-        if (have && i >= lo && i <= hi) {
-            z = sample_z<false>(F, ray, i, 0.f);
-            ok = sample_point<false>(F, ray, z, xn, yn, zn);
-            if (F.alpha && ok) ok = alpha_pass(F, ray, z);      // models/tensorBase.py:451-456
-        } else if (DENSE && a.dense_z) {
-            z = sample_z<false>(F, ray, i, 0.f);
+    // kSteps consecutive samples per ray share ONE table build: the tap ranges of neighbouring steps overlap (the union of two
+    // steps spans 3-4 taps per axis on every pair of a pinhole frame), so the reduction, the six operand loads, the twelve
+    // MFMAs and the load -> MFMA -> LDS latency chain are paid once per pair.
+    constexpr int kSteps = 2;
+    const int i_begin = DENSE ? 0 : wlo, i_end = DENSE ? N - 1 : whi;
+    for (int i = i_begin; i <= i_end; i += kSteps) {
+        float xn[kSteps], yn[kSteps], zn[kSteps], z[kSteps], w_out[kSteps];
+        bool ok[kSteps];
+        Axes3 A[kSteps];
+        bool any_ok = false;
+#pragma unroll
+        for (int q = 0; q < kSteps; ++q) {
+            const int idx = i + q;
+            xn[q] = yn[q] = zn[q] = z[q] = w_out[q] = 0.f;
+            ok[q] = false;
+            if (have && idx >= lo && idx <= hi && idx <= i_end) {
+                z[q] = sample_z<false>(F, ray, idx, 0.f);
+                ok[q] = sample_point<false>(F, ray, z[q], xn[q], yn[q], zn[q]);
+                if (F.alpha && ok[q]) ok[q] = alpha_pass(F, ray, z[q]);      // models/tensorBase.py:451-456
+            } else if (DENSE && a.dense_z && idx < N) {
+                z[q] = sample_z<false>(F, ray, idx, 0.f);
+            }
+            any_ok |= ok[q];
         }
-        const unsigned long long okm = __ballot(ok);
+        const unsigned long long okm = __ballot(any_ok);
         // (a lane whose staging slice is full keeps its spill row gap-free: masked-out samples inside its window get zeros)
-        const bool spill = have && napp >= (unsigned)a.cap && !(DENSE && a.dense_w);
-        if (!DENSE && !okm && !__any(spill)) continue;
+        if (!DENSE && !okm && !__any(have && napp >= (unsigned)a.cap)) continue;
+        float part[kSteps];
+#pragma unroll
+        for (int q = 0; q < kSteps; ++q) part[q] = 0.f;
         if (okm) {
-        const Axes3 A = sample_axes(F.den, xn, yn, zn);
-        // the low-tap indices present in the wave, per axis, as ONE or-reduced bit set: 10 bits per axis around the first
-        // live lane's index (bit 5); an index outside [-5, +4] of it raises bit 30 (the step then gathers directly)
-        const int lead = (int)__builtin_ctzll(okm);
-        const int ref0 = __builtin_amdgcn_readlane(A.a[0].i0, lead), ref1 = __builtin_amdgcn_readlane(A.a[1].i0, lead),
-                  ref2 = __builtin_amdgcn_readlane(A.a[2].i0, lead);
-        unsigned bits = 0u;
-        if (ok) {
-            const unsigned d0 = (unsigned)(A.a[0].i0 - ref0 + 5), d1 = (unsigned)(A.a[1].i0 - ref1 + 5), d2 = (unsigned)(A.a[2].i0 - ref2 + 5);
-            bits = (d0 < 10u ? 1u << d0 : 0x40000000u) | (d1 < 10u ? 1u << (10u + d1) : 0x40000000u) |
-                   (d2 < 10u ? 1u << (20u + d2) : 0x40000000u);
-        }
-        bits = wave_or_u(bits);
-        const unsigned f0 = bits & 1023u, f1 = (bits >> 10) & 1023u, f2 = (bits >> 20) & 1023u;
-        const int amn[3] = {ref0 - 5 + __builtin_ctz(f0), ref1 - 5 + __builtin_ctz(f1), ref2 - 5 + __builtin_ctz(f2)};
-        // taps per axis: the high tap is at most one above the highest low tap (and inside the grid)
-        const int span = max(max(32 - __builtin_clz(f0) - __builtin_ctz(f0), 32 - __builtin_clz(f1) - __builtin_ctz(f1)),
-                             32 - __builtin_clz(f2) - __builtin_ctz(f2)) + 1;
-        const bool ranged = !(bits & 0x40000000u);
-#ifdef T2N_TILE_DEBUG
-        const unsigned long long tB = __builtin_amdgcn_s_memtime();
-        dbgA += tB - tA;
-        if (T2N_TILE_DEBUG > 1 && lane == 0) atomicAdd(&g_tile_hist[ranged ? min(span, 15) : 0], 1ull);   // serialises: stats only
-#endif
-        float part = 0.f;
-        if (ranged && span <= 4) part = table_step<2>(F.den, A, amn, ok, stD, l15, lq);
-        else if (ok) {
-            part = pair_dot_global<0>(F.den, A, part);
-            part = pair_dot_global<1>(F.den, A, part);
-            part = pair_dot_global<2>(F.den, A, part);
-        }
-#ifdef T2N_TILE_DEBUG
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        dbgB += __builtin_amdgcn_s_memtime() - tB;
-#endif
-        if (ok) {
-            const float sg = feature2density(F, part);
-            const float dist = i < N - 1 ? sample_z<false>(F, ray, i + 1, 0.f) - z : 0.f;     // :448
-            const float alpha = 1.f - expf((-sg) * (dist * F.dscale));                      // raw2alpha :19-26
-            const float w = alpha * T;
-            T = T * ((1.f - alpha) + 1e-10f);
-            acc += w;
-            dep = fmaf(w, z, dep);
-            // in-kernel compaction: the dense weights row is only the spill area of a ray whose staging slice is full (64
-            // lanes x 4 B to 64 different rows per step cost 3x their bytes in partial-line HBM writes: 2 GB per frame)
-            if (w > F.thres) {
-                if (napp < (unsigned)a.cap) a.scratch[(size_t)r * a.cap + napp] = make_float4(xn, yn, zn, w);
-                ++napp;
-                if (napp == (unsigned)a.cap) ovf_from = i + 1;
-            }
-            if (first < 0) first = i;
-            last = i;
-            ++nev;
-            w_out = w;
-        }
-        }   // okm
-        if (spill) a.wbuf[r * N + i] = w_out;
-        if constexpr (DENSE) {
-            const int c16 = i & 15;
-            wt[lane * kDenseLd + c16] = w_out;
-            zt[lane * kDenseLd + c16] = z;
-            if (c16 == 15 || i == N - 1) {
-                lds_fence_w();
-                const int col = (i & ~15) + 4 * (lane & 3);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (frow[j] < 0 || col >= N) continue;
-                    const int rho = (lane >> 2) + 16 * j;
-                    const float4 vw = *reinterpret_cast<const float4*>(wt + rho * kDenseLd + 4 * (lane & 3));
-                    const float4 vz = *reinterpret_cast<const float4*>(zt + rho * kDenseLd + 4 * (lane & 3));
-                    if (col + 3 < N) {
-                        if (a.dense_w) *reinterpret_cast<F4U*>(a.dense_w + frow[j] + col) = F4U{vw.x, vw.y, vw.z, vw.w};
-                        if (a.dense_z) *reinterpret_cast<F4U*>(a.dense_z + frow[j] + col) = F4U{vz.x, vz.y, vz.z, vz.w};
-                    } else {
-                        const float ew[4] = {vw.x, vw.y, vw.z, vw.w}, ez[4] = {vz.x, vz.y, vz.z, vz.w};
+            for (int q = 0; q < kSteps; ++q) A[q] = sample_axes(F.den, xn[q], yn[q], zn[q]);
+            // the low-tap indices present in the wave, per axis, as ONE or-reduced bit set: 10 bits per axis around the first
+            // live lane's index (bit 5); an index outside [-5, +4] of it raises bit 30 (the steps then gather directly)
+            int sel0 = 0, sel1 = 0, sel2 = 0;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (col + e < N) {
-                                if (a.dense_w) a.dense_w[frow[j] + col + e] = ew[e];
-                                if (a.dense_z) a.dense_z[frow[j] + col + e] = ez[e];
-                            }
-                    }
+            for (int q = kSteps - 1; q >= 0; --q)
+                if (ok[q]) { sel0 = A[q].a[0].i0; sel1 = A[q].a[1].i0; sel2 = A[q].a[2].i0; }
+            const int lead = (int)__builtin_ctzll(okm);
+            const int ref0 = __builtin_amdgcn_readlane(sel0, lead), ref1 = __builtin_amdgcn_readlane(sel1, lead),
+                      ref2 = __builtin_amdgcn_readlane(sel2, lead);
+            unsigned bits = 0u;
+#pragma unroll
+            for (int q = 0; q < kSteps; ++q)
+                if (ok[q]) {
+                    const unsigned d0 = (unsigned)(A[q].a[0].i0 - ref0 + 5), d1 = (unsigned)(A[q].a[1].i0 - ref1 + 5),
+                                   d2 = (unsigned)(A[q].a[2].i0 - ref2 + 5);
+                    bits |= (d0 < 10u ? 1u << d0 : 0x40000000u) | (d1 < 10u ? 1u << (10u + d1) : 0x40000000u) |
+                            (d2 < 10u ? 1u << (20u + d2) : 0x40000000u);
                 }
+            bits = wave_or_u(bits);
+            const unsigned f0 = bits & 1023u, f1 = (bits >> 10) & 1023u, f2 = (bits >> 20) & 1023u;
+            const int amn[3] = {ref0 - 5 + __builtin_ctz(f0), ref1 - 5 + __builtin_ctz(f1), ref2 - 5 + __builtin_ctz(f2)};
+            // taps per axis: the high tap is at most one above the highest low tap (and inside the grid)
+            const int span = max(max(32 - __builtin_clz(f0) - __builtin_ctz(f0), 32 - __builtin_clz(f1) - __builtin_ctz(f1)),
+                                 32 - __builtin_clz(f2) - __builtin_ctz(f2)) + 1;
+            const bool ranged = !(bits & 0x40000000u);
+            if (ranged && span <= 4) {
+                table_build<2>(F.den, amn, stD, l15, lq);
                 lds_fence_w();
+#pragma unroll
+                for (int q = 0; q < kSteps; ++q)
+                    if (ok[q]) part[q] = table_read<2>(A[q], amn, stD);
+                lds_fence_w();
+            } else {
+#pragma unroll   // (a rolled loop would index A[] dynamically and push the per-sample arrays to scratch)
+                for (int q = 0; q < kSteps; ++q)
+                    if (ok[q]) {
+                        float pq = pair_dot_global<0>(F.den, A[q], 0.f);
+                        pq = pair_dot_global<1>(F.den, A[q], pq);
+                        part[q] = pair_dot_global<2>(F.den, A[q], pq);
+                    }
             }
         }
-#ifdef T2N_TILE_DEBUG
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        dbgC += __builtin_amdgcn_s_memtime() - tB;
-        dbgN += 1;
-#endif
+#pragma unroll
+        for (int q = 0; q < kSteps; ++q) {
+            const int idx = i + q;
+            const bool spill = have && idx <= i_end && napp >= (unsigned)a.cap && !(DENSE && a.dense_w);
+            if (ok[q]) {
+                const float sg = feature2density(F, part[q]);
+                const float dist = idx < N - 1 ? sample_z<false>(F, ray, idx + 1, 0.f) - z[q] : 0.f;     // :448
+                const float alpha = 1.f - expf((-sg) * (dist * F.dscale));                            // raw2alpha :19-26
+                const float w = alpha * T;
+                T = T * ((1.f - alpha) + 1e-10f);
+                acc += w;
+                dep = fmaf(w, z[q], dep);
+                // in-kernel compaction: (x, y, z, w) of the samples above the threshold go to the ray's staging slice
+                if (w > F.thres) {
+                    if (napp < (unsigned)a.cap) a.scratch[(size_t)r * a.cap + napp] = make_float4(xn[q], yn[q], zn[q], w);
+                    ++napp;
+                    if (napp == (unsigned)a.cap) ovf_from = idx + 1;
+                }
+                if (first < 0) first = idx;
+                last = idx;
+                ++nev;
+                w_out[q] = w;
+            }
+            if (spill) a.wbuf[r * N + idx] = w_out[q];
+            if constexpr (DENSE) {
+                if (idx < N) {
+                    const int c16 = idx & 15;
+                    wt[lane * kDenseLd + c16] = w_out[q];
+                    zt[lane * kDenseLd + c16] = z[q];
+                }
+                if ((idx < N && (idx & 15) == 15) || idx == N - 1) {
+                    lds_fence_w();
+                    const int col = (idx & ~15) + 4 * (lane & 3);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (frow[j] < 0 || col >= N) continue;
+                        const int rho = (lane >> 2) + 16 * j;
+                        const float4 vw = *reinterpret_cast<const float4*>(wt + rho * kDenseLd + 4 * (lane & 3));
+                        const float4 vz = *reinterpret_cast<const float4*>(zt + rho * kDenseLd + 4 * (lane & 3));
+                        if (col + 3 < N) {
+                            if (a.dense_w) *reinterpret_cast<F4U*>(a.dense_w + frow[j] + col) = F4U{vw.x, vw.y, vw.z, vw.w};
+                            if (a.dense_z) *reinterpret_cast<F4U*>(a.dense_z + frow[j] + col) = F4U{vz.x, vz.y, vz.z, vz.w};
+                        } else {
+                            const float ew[4] = {vw.x, vw.y, vw.z, vw.w}, ez[4] = {vz.x, vz.y, vz.z, vz.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (col + e < N) {
+                                    if (a.dense_w) a.dense_w[frow[j] + col + e] = ew[e];
+                                    if (a.dense_z) a.dense_z[frow[j] + col + e] = ez[e];
+                                }
+                        }
+                    }
+                    lds_fence_w();
+                }
+            }
+        }
     }
-#ifdef T2N_TILE_DEBUG
-    const unsigned long long t01 = __builtin_amdgcn_s_memtime();
-#endif
     const int Lw = last >= first && first >= 0 ? last - first + 1 : 0;
     if (have) {
         a.acc[r] = acc;
@@ -376,20 +389,6 @@ __global__ __launch_bounds__(256) void k_march_tiles(const TileArgs a) {
                 }
         }
     }
-#ifdef T2N_TILE_DEBUG
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    const unsigned long long t02 = __builtin_amdgcn_s_memtime();
-    if (lane == 0) {
-        atomicAdd(&g_tile_dbg[0], dbgN);
-        atomicAdd(&g_tile_dbg[1], dbgA);
-        atomicAdd(&g_tile_dbg[2], dbgB);
-        atomicAdd(&g_tile_dbg[3], dbgC);
-        atomicAdd(&g_tile_dbg[4], t01 - t00);
-        atomicAdd(&g_tile_dbg[5], t02 - t01);
-        atomicAdd(&g_tile_dbg[6], 1ull);
-        atomicMax(&g_tile_dbg[7], t02 - t00);
-    }
-#endif
 }
 
 // The rays the tile marcher handed over: one wave per ray finishes their appearance slices.
@@ -500,20 +499,4 @@ int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h
 }
 
 }  // namespace t2n
-#ifdef T2N_TILE_DEBUG
-extern "C" int t2n_debug_tile_counters(unsigned long long* out, int reset) {
-    int rc = (int)hipDeviceSynchronize();
-    if (rc) return rc;
-    rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(t2n::g_tile_dbg), 64);
-    if (rc) return 1000 + rc;
-    rc = (int)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(t2n::g_tile_hist), 128);
-    if (rc) return 2000 + rc;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        hipMemcpyToSymbol(HIP_SYMBOL(t2n::g_tile_dbg), z, 64);
-        hipMemcpyToSymbol(HIP_SYMBOL(t2n::g_tile_hist), z, 128);
-    }
-    return 0;
-}
-#endif
 
