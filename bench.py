@@ -236,7 +236,7 @@ def main():
     field.materialize_weights = bool(args.weights)
     field.factor_storage = args.factor_storage
     # the rays of a step are one whole row-major frame: the width hint lets the renderer use the tile marcher (rays of an 8x8
-    # pixel tile share their LDS-staged taps); results stay within the parity tolerances of the per-ray marcher
+    # pixel tile share per-step dot-product tables); results stay within the parity tolerances of the per-ray marcher
     field.frame_width = 0 if args.per_ray_marcher else W
     N = field.nSamples
     poses = synth.local_fixed_like_poses(max(world, 9))

@@ -352,7 +352,7 @@ def test_train_batch_gradients_vs_oracle_300():
 
 
 def test_tile_marcher_matches_per_ray_marcher(big300):
-    """frame_width hint -> 8x8-pixel tile marcher (LDS-staged shared taps, sequential transmittance): same samples (exact
+    """frame_width hint -> 8x8-pixel tile marcher (shared per-step dot-product tables, sequential transmittance): same samples (exact
     counts, bit-exact z), weights/rgb/depth equal to the per-ray marcher within fp32 scan re-association, goldens hold,
     ragged image sizes (not multiples of 8) and multi-band sub-launches covered."""
     import os

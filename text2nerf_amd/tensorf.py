@@ -225,7 +225,7 @@ class TensorVMSplit(nn.Module):
         self.materialize_weights = True   # the reference always returns weights/z_vals; set False to skip 8*N B/ray
         self.z_gate = 2.0                 # models/tensorBase.py:460
         self.frame_width = 0              # set to the image width when eval rays are whole row-major frames: enables the
-                                          # 8x8-tile marcher (LDS-staged shared taps); 0 = unknown -> per-ray marcher
+                                          # 8x8-tile marcher (shared dot-product tables); 0 = unknown -> per-ray marcher
         self.mlp_exact_fp32 = os.environ.get("T2N_MLP_EXACT", "0") == "1"   # False: f16 two-way-split MFMA products
         # 'fp32' (default) or 'bf16' (BASELINE configs[4]): the forward gathers read bf16 copies of the 12 factor tensors;
         # the render equals the fp32 render of the bf16-rounded tensors bit for bit, the parameters stay fp32 masters
