@@ -161,11 +161,11 @@ __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
 
 // acc[m] += W_chunk,m (split) x B_chunk (split on the fly); A operands double-buffered one chunk ahead.
 template <int NMB, class BF>
-__device__ __forceinline__ void f16_stream(f32x16 (&acc)[NMB], const uint4* __restrict__ ap, int nchunks, BF& bf) {
+__device__ __forceinline__ void f16_stream(f32x16 (&acc)[NMB], const uint4* __restrict__ ap, int lane, int nchunks, BF& bf) {
     constexpr int NR = NMB * 2;
     uint4 A0[NR], A1[NR];
     auto fetch = [&](uint4 (&A)[NR], int c) {
-        const uint4* p = ap + (size_t)c * NR * 64;
+        const uint4* p = ap + lane + (size_t)c * NR * 64;
 #pragma unroll
         for (int i = 0; i < NR; ++i) A[i] = p[i * 64];
     };
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         f32x16 accb1[1] = {{0}};
         if constexpr (SPLIT) {
             LdsChunk bf{X + s, h, kBasisChunksReal};
-            f16_stream<1>(accb1, F.basisH + lane, kBasisChunks, bf);
+            f16_stream<1>(accb1, F.basisH, lane, kBasisChunks, bf);
             accb1[0] *= kWUnscale;
         } else {
             LdsBNoBias bf{X + (size_t)h * kXld + s, kBasisReal};
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc0[m] = bias_init(F.biasH, m, h);
                 PeChunk bf{Fe + s, h, 0.f, 1.f};
-                f16_stream<4>(acc0, F.w0H + lane, kL0Chunks, bf);
+                f16_stream<4>(acc0, F.w0H, lane, kL0Chunks, bf);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc0[m] *= kWUnscale;
             } else {
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc1[m] = bias_init(F.biasH + 128, m, h);
                 LdsChunk bf{Hs + s, h, kL1Chunks};
-                f16_stream<4>(acc1, F.w1H + lane, kL1Chunks, bf);
+                f16_stream<4>(acc1, F.w1H, lane, kL1Chunks, bf);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc1[m] *= kWUnscale;
             } else {
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
             if constexpr (SPLIT) {
                 acc2a[0] = bias_init(F.biasH + 256, 0, h);
                 LdsChunk bf{Hs + s, h, kL2Chunks};
-                f16_stream<1>(acc2a, F.w2H + lane, kL2Chunks, bf);
+                f16_stream<1>(acc2a, F.w2H, lane, kL2Chunks, bf);
                 acc2a[0] *= kWUnscale;
             } else {
                 LdsB bf{Hs + (size_t)h * kXld + s, 64, h};
@@ -539,10 +539,16 @@ struct CoopRing {
     __device__ __forceinline__ uint4* slot(int b, int i) const {
         return reinterpret_cast<uint4*>(smem + (size_t)(2 * b + (i >> 8)) * kWaveFloats + kRingOff) + (i & 255);
     }
+    // buffer loads: descriptor in SGPRs, the chunk as a SCALAR byte offset, the thread as one 32-bit VGPR offset — flat
+    // loads made the compiler keep a dozen 64-bit per-lane chunk pointers alive across the whole kernel (and spill them)
     __device__ __forceinline__ void gload(uint4& ga, uint4& gb, int c) const {
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
         c = c < last ? c : last;
-        const uint4* p = wp + (size_t)c * 512 + tid;
-        ga = p[0]; gb = p[256];
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wp), 0, 0x7fffffff, 0x00020000);
+        const int soff = c * 8192;
+        const u4v a = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, soff, 0);
+        const u4v b = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, soff + 4096, 0);
+        ga = make_uint4(a[0], a[1], a[2], a[3]); gb = make_uint4(b[0], b[1], b[2], b[3]);
     }
     __device__ __forceinline__ void start() {   // callers guarantee nobody still reads the ring
         gload(n0, n1, 0);
@@ -749,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
         f32x16 accb1[1] = {{0}};
         {
             LdsChunk bf{X + s, h, kBasisChunksReal};
-            f16_stream<1>(accb1, F.basisH + lane, kBasisChunks, bf);
+            f16_stream<1>(accb1, F.basisH, lane, kBasisChunks, bf);
             accb1[0] *= kWUnscale;
         }
         const f32x16 accb = accb1[0];
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
         acc2a[0] = bias_init(F.biasH + 256, 0, h);
         {
             LdsChunkT<kHld> bf{Hs + s, h, kL2Chunks};
-            f16_stream<1>(acc2a, F.w2H + lane, kL2Chunks, bf);
+            f16_stream<1>(acc2a, F.w2H, lane, kL2Chunks, bf);
         }
         const f32x16 acc2 = acc2a[0] * kWUnscale;
         if (h == 0 && live) {
