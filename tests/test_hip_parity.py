@@ -318,6 +318,42 @@ def test_g8_gradients_vs_reference_autograd(tiny, tiny_params):
     assert bool(torch.isfinite(rgb2).all())
 
 
+def test_g8_gradients_with_forward_kept_activation_rows(tiny, tiny_params):
+    """From the second iteration on the training forward keeps the MLP activation rows in spare KEEP_CTX workspace (sized from
+    the previous backward's row count) and the backward skips its appearance recompute: same gradients against the
+    reference's autograd (golden G8) — with an ample guess, with a guess that is too small (the backward falls back to
+    recomputing) and with the feature switched off."""
+    rays = torch.from_numpy(tiny["tiny_rays"])
+    ca, cb, cc = [torch.from_numpy(tiny[k]).to(dev()) for k in ("g8_ca", "g8_cb", "g8_cc")]
+    ref = {k[len("g8_grad."):]: v for k, v in tiny.items() if k.startswith("g8_grad.")}
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+
+    def run(expect_rgb=None):
+        for p in f.parameters():
+            p.grad = None
+        torch.manual_seed(123)
+        rgb, depth, z, w = f(rays, is_train=True, white_bg=True, N_samples=40)
+        loss = (rgb * ca).sum() + (depth * cb).sum() + (w * cc).sum()
+        close(loss, tiny["g8_loss"], atol=5e-4)
+        loss.backward()
+        return _grad_check(f, ref, rel=2e-4), rgb.detach().clone()
+
+    _, rgb0 = run()                               # first iteration: no guess yet -> recompute path
+    assert f._ctx_rows_hint >= 32
+    hint = f._ctx_rows_hint
+    w1, rgb1 = run()                              # kept rows
+    close(rgb1, rgb0.cpu().numpy(), atol=2e-6)    # exact-fp32 head instead of the f16-split one in the forward
+    f._ctx_rows_hint = 32                         # far too small: the forward keeps one tile, the backward recomputes
+    run()
+    f.keep_activation_rows = False
+    run()
+    assert f._ctx_rows_hint == 0
+    f.keep_activation_rows = True
+    run(); f._ctx_rows_hint = hint
+    w2, _ = run()
+    print("kept-rows max relative gradient errors:", {k: f"{v:.1e}" for k, v in w2.items()})
+
+
 def test_train_batch_gradients_vs_oracle_300():
     """C3-shaped: 300^3 field, random rays of a small-baseline pose set, N=259, is_train — gradients vs the oracle's
     autograd (fp32 CPU). Only rgb/depth/weights losses of the driver's form (MSE + transmittance-style weight term)."""

@@ -628,7 +628,15 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
                 (void)hipFreeAsync(scratch, s);
                 if (rc) return rc;
             }
-        } else if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, nullptr, s))) return rc;
+        } else {
+            // training forward with spare workspace: run the activation-keeping kernel now, so the backward need not re-run
+            // the appearance forward (rows past the capacity keep nothing; the backward then recomputes)
+            const KeptRows kr = keep && f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW ? kept_rows(c.total, workspace_bytes) : KeptRows{0, 0, 0, 0, 0};
+            if (kr.rows >= 32) {
+                ShadeCtx ctx{(float*)(ws + kr.x144), (float*)(ws + kr.feat32), (float*)(ws + kr.h0), (float*)(ws + kr.h1)};
+                if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, &ctx, s, false, kr.rows))) return rc;
+            } else if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, nullptr, s))) return rc;
+        }
         if ((rc = launch_composite(f, L, s))) return rc;
     }
     return T2N_OK;

@@ -1166,6 +1166,10 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     char* bw = (char*)bwd_workspace;
     float* x144 = (float*)(bw + b.x144); float* feat32 = (float*)(bw + b.feat32); float* h0 = (float*)(bw + b.h0);
     float* h1 = (float*)(bw + b.h1); float4* go = (float4*)(bw + b.go); float* xpe = (float*)(bw + b.xpe);
+    // the forward kept the activation rows (spare KEEP_CTX workspace, all rows fit): use them in place, skip the recompute
+    const KeptRows kr = generic ? KeptRows{0, 0, 0, 0, 0} : kept_rows(c.total, fwd_workspace_bytes);
+    const bool kept = kr.rows >= 32 && (int64_t)kr.rows >= rows_alloc;
+    if (kept) { x144 = (float*)(fw + kr.x144); feat32 = (float*)(fw + kr.feat32); h0 = (float*)(fw + kr.h0); h1 = (float*)(fw + kr.h1); }
     float* part = (float*)(bw + b.part);
     float* g1 = h1;      // k_bwd_l2 rewrites each element in place
     float* g0 = h0;      // gemm_nn reads the ReLU mask and writes the masked product at the same element
@@ -1189,10 +1193,10 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
 
     // 1. appearance forward recompute with activations kept
     timing_begin(f, T2N_K_BWD_MLP, s);
-    if (rows > 0 && !generic) {
+    if (rows > 0 && !generic && !kept) {
         ShadeCtx ctx{x144, feat32, h0, h1};
         if ((rc = launch_shade_list(f, app_pos, app_ray, rays, ray_stride, counters, c.list_cap, app_rgb, &ctx, s))) return rc;
-    } else if (rows > 0) {   // general heads: features from the shade kernel's first two stages, then the unfused MLP (xpe holds X0)
+    } else if (rows > 0 && generic) {   // general heads: features from the shade kernel's first two stages, then the unfused MLP (xpe holds X0)
         ShadeCtx ctx{x144, feat32, nullptr, nullptr};
         if ((rc = launch_shade_list(f, app_pos, app_ray, rays, ray_stride, counters, c.list_cap, app_rgb, &ctx, s, true))) return rc;
         if ((rc = launch_head_forward(f, tp.t, rows, feat32, app_pos, app_ray, rays, ray_stride, counters, c.list_cap, xpe, h0, h1, app_rgb, s))) return rc;

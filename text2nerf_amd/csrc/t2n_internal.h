@@ -132,7 +132,8 @@ inline unsigned list_capacity(long long n_rays, int n_samples) {
 struct ShadeCtx { float* x144; float* feat32; float* h0; float* h1; };
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
                       const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s,
-                      bool features_only = false);   // features_only: gather + basis stages only (the general heads take over)
+                      bool features_only = false, unsigned ctx_rows = 0xffffffffu);
+// features_only: gather + basis stages only (the general heads take over); ctx_rows: capacity of the ctx buffers in rows
 
 // the general (unfused) view-dependent heads (t2n_heads.hip): MLP_Fea / MLP_PE / MLP input layout and launchers
 struct HeadDims { int shading, C, fea_pe, view_pe, pos_pe, o_feat, o_view, o_pe_a, n_pe_a, o_pe_v, n_pe_v, K0, K0pad; };
@@ -147,5 +148,20 @@ int launch_head_in_bwd(t2n_field* f, const float* gx, const float* feat32, long 
 struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, total; unsigned list_cap; };
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx);   // ctx: also room for sigma [rays,N] and rgb_raw [rays]
 int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s);
+// Activation rows the forward keeps for the backward when the KEEP_CTX workspace is larger than the context itself (the
+// caller's guess of the appearance-row count; 1728 B per row): x144 [rows,144], feat32 [rows,32], h0 / h1 [rows,128] behind
+// the carved context. rows == 0: nothing kept (the backward re-runs the appearance forward).
+struct KeptRows { size_t x144, feat32, h0, h1; unsigned rows; };
+inline KeptRows kept_rows(size_t ctx_total, size_t workspace_bytes) {
+    KeptRows k{0, 0, 0, 0, 0};
+    const size_t base = (ctx_total + 255) / 256 * 256;
+    if (workspace_bytes <= base) return k;
+    size_t rows = (workspace_bytes - base) / ((144 + 32 + 128 + 128) * 4);
+    rows = rows / 32 * 32;
+    if (rows > 0x7fffffe0u) rows = 0x7fffffe0u;
+    k.rows = (unsigned)rows;
+    k.x144 = base; k.feat32 = k.x144 + rows * 144 * 4; k.h0 = k.feat32 + rows * 32 * 4; k.h1 = k.h0 + rows * 128 * 4;
+    return k;
+}
 
 }  // namespace t2n

@@ -282,6 +282,7 @@ struct ShadeArgs {
     const unsigned* counters; unsigned list_cap; int nlists; unsigned count_max;   // list mode: counters[nlists]; point mode: count_max
     float4* app_rgb; float* feat_out; float* rgb_out;   // rgb_out: packed [n,3] (explicit-point mode)
     ShadeCtx ctx;   // activation rows for the backward pass (all NULL in the normal forward)
+    unsigned ctx_rows;   // rows the ctx buffers hold: tiles past it keep nothing (forward-kept activations with a capacity guess)
 };
 
 // Gather: 384 (sample, channel-quad) items over 64 lanes, 6 per lane; an item computes its sample's three axis taps once
@@ -375,7 +376,9 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         const unsigned count = lbase + __shfl(cnt_l, li);      // one past the last live entry of this sub-list
         // ---- gather: plane x line products for 32 samples x 144 channels -> X ---------------------------------------
         const unsigned row0 = tile * 32u;   // activation row of lane sample 0 (ctx mode)
-        gather_all(F.app, X, lane, a.app_pos, a.xyz, base, count, a.ctx.x144, row0);
+        const bool keep_rows = row0 + 32u <= a.ctx_rows;
+        const ShadeCtx cx = keep_rows ? a.ctx : ShadeCtx{nullptr, nullptr, nullptr, nullptr};
+        gather_all(F.app, X, lane, a.app_pos, a.xyz, base, count, cx.x144, row0);
         wave_lds_sync();
 
         // ---- basis_mat: feat[i][s] = sum_k Wb[i][k] X[k][s] ----------------------------------------------------------
@@ -396,10 +399,10 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
 
         const unsigned idx = base + (unsigned)s;
         const bool live = idx < count;
-        if (a.ctx.feat32) {
+        if (cx.feat32) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(a.ctx.feat32 + (size_t)(row0 + s) * 32 + 8 * g + 4 * h) =
+                *reinterpret_cast<float4*>(cx.feat32 + (size_t)(row0 + s) * 32 + 8 * g + 4 * h) =
                     make_float4(accb[4 * g], accb[4 * g + 1], accb[4 * g + 2], accb[4 * g + 3]);
         }
         if (a.feat_out && live) {
@@ -433,12 +436,12 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) Hs[(ms * 32 + unit_of(v, h)) * kXld + s] = fmaxf(acc0[ms][v], 0.f);
             }
-            if (a.ctx.h0) {
+            if (cx.h0) {
 #pragma unroll
                 for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4*>(a.ctx.h0 + (size_t)(row0 + s) * 128 + ms * 32 + 8 * g + 4 * h) =
+                        *reinterpret_cast<float4*>(cx.h0 + (size_t)(row0 + s) * 128 + ms * 32 + 8 * g + 4 * h) =
                             make_float4(fmaxf(acc0[ms][4 * g], 0.f), fmaxf(acc0[ms][4 * g + 1], 0.f),
                                         fmaxf(acc0[ms][4 * g + 2], 0.f), fmaxf(acc0[ms][4 * g + 3], 0.f));
             }
@@ -462,12 +465,12 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) Hs[(ms * 32 + unit_of(v, h)) * kXld + s] = fmaxf(acc1[ms][v], 0.f);
             }
-            if (a.ctx.h1) {
+            if (cx.h1) {
 #pragma unroll
                 for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4*>(a.ctx.h1 + (size_t)(row0 + s) * 128 + ms * 32 + 8 * g + 4 * h) =
+                        *reinterpret_cast<float4*>(cx.h1 + (size_t)(row0 + s) * 128 + ms * 32 + 8 * g + 4 * h) =
                             make_float4(fmaxf(acc1[ms][4 * g], 0.f), fmaxf(acc1[ms][4 * g + 1], 0.f),
                                         fmaxf(acc1[ms][4 * g + 2], 0.f), fmaxf(acc1[ms][4 * g + 3], 0.f));
             }
@@ -1014,10 +1017,11 @@ static bool use_coop(const t2n_field* f) {
 
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
                       const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s,
-                      bool features_only) {
+                      bool features_only, unsigned ctx_rows) {
     ShadeArgs a;
     memset(&a, 0, sizeof(a));
     if (ctx) a.ctx = *ctx;
+    a.ctx_rows = ctx_rows;
     a.F = f->dev;
     if (features_only) a.F.shading = T2N_SHADE_RGB;   // gather + basis only; the rgb slots get placeholder values the head overwrites
     a.app_pos = app_pos; a.app_ray = app_ray; a.rays = rays; a.ray_stride = ray_stride;

@@ -221,6 +221,7 @@ class TensorVMSplit(nn.Module):
         self.step_ratio = step_ratio
         self.matMode, self.vecMode, self.comp_w = MAT_MODE, VEC_MODE, [1, 1, 1]
         self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC = shadingMode, pos_pe, view_pe, fea_pe, featureC
+        self.keep_activation_rows = True  # training: the forward keeps the MLP activations of the appearance samples for the backward
         self.defer_factor_grads = False   # set by optim.TVAdam(field=self): plane / line gradients stay on the device (channel-last)
         self.materialize_weights = True   # the reference always returns weights/z_vals; set False to skip 8*N B/ray
         self.z_gate = 2.0                 # models/tensorBase.py:460
@@ -764,7 +765,12 @@ class TensorVMSplit(nn.Module):
         stats = torch.empty(_lib.T2N_STAT_COUNT, device=dev, dtype=torch.int64)
         if keep_ctx:
             # the kept context must survive until backward: a private buffer, not the shared scratch
-            ws = torch.empty(int(lib.t2n_render_workspace_bytes_ctx(R, N)), dtype=torch.uint8, device=dev)
+            # plus room for the activation rows of the appearance samples (1728 B each), sized from the previous backward's
+            # row count: the forward then keeps them and the backward skips its appearance recompute (too small a guess
+            # only costs that recompute)
+            rows_hint = int(getattr(self, "_ctx_rows_hint", 0))
+            ws = torch.empty(int(lib.t2n_render_workspace_bytes_ctx(R, N)) + (256 + rows_hint * 1728 if rows_hint else 0),
+                             dtype=torch.uint8, device=dev)
             flags |= FLAG_KEEP_CTX
         else:
             need = int(lib.t2n_render_workspace_bytes(max(R, 1), N))
@@ -1001,6 +1007,7 @@ class _RenderFn(torch.autograd.Function):
             _lib.check(lib.t2n_render_ctx_rows(_lib.ptr(ctx.ws), R, ctx.N, st, C.byref(rows)), "t2n_render_ctx_rows")
             # shared grow-only scratch (geometric growth): the row count changes every iteration, and a fresh
             # multi-GB torch.empty per backward would hit hipMalloc each time
+            field._ctx_rows_hint = (int(rows.value * 1.25) + 95) // 32 * 32 if field.keep_activation_rows else 0
             need = int(lib.t2n_backward_workspace_bytes(field._handle, rows.value, R, ctx.N))
             bws = workspace(dev, need) if _WORKSPACE.get(str(dev)) is not None and _WORKSPACE[str(dev)].numel() >= need \
                 else workspace(dev, int(need * 1.5))
