@@ -412,11 +412,8 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
         if (f->hbuf_den_line[k]) (void)hipFree(f->hbuf_den_line[k]);
         if (f->hbuf_app_plane[k]) (void)hipFree(f->hbuf_app_plane[k]);
         if (f->hbuf_app_line[k]) (void)hipFree(f->hbuf_app_line[k]);
-        if (f->gbuf_den_plane[k]) (void)hipFree(f->gbuf_den_plane[k]);
-        if (f->gbuf_den_line[k]) (void)hipFree(f->gbuf_den_line[k]);
-        if (f->gbuf_app_plane[k]) (void)hipFree(f->gbuf_app_plane[k]);
-        if (f->gbuf_app_line[k]) (void)hipFree(f->gbuf_app_line[k]);
     }
+    if (f->gbuf_all) (void)hipFree(f->gbuf_all);
     if (f->buf_mlp) (void)hipFree(f->buf_mlp);
     if (f->buf_mlp_h) (void)hipFree(f->buf_mlp_h);
     if (f->buf_alpha) (void)hipFree(f->buf_alpha);

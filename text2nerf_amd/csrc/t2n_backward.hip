@@ -1064,13 +1064,20 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
 }
 
 static int ensure_grad_buffers(t2n_field* f) {
+    if (f->gbuf_all) return T2N_OK;
     const int* g = f->desc.grid;
+    size_t off[12], o = 0;
     for (int k = 0; k < 3; ++k) {
         const size_t HW = (size_t)g[mat1(k)] * g[mat0(k)], L = (size_t)g[vecm(k)];
-        if (!f->gbuf_den_plane[k]) T2N_HIP(hipMalloc((void**)&f->gbuf_den_plane[k], HW * 16 * 4));
-        if (!f->gbuf_den_line[k]) T2N_HIP(hipMalloc((void**)&f->gbuf_den_line[k], L * 16 * 4));
-        if (!f->gbuf_app_plane[k]) T2N_HIP(hipMalloc((void**)&f->gbuf_app_plane[k], HW * 48 * 4));
-        if (!f->gbuf_app_line[k]) T2N_HIP(hipMalloc((void**)&f->gbuf_app_line[k], L * 48 * 4));
+        const size_t sz[4] = {HW * 16 * 4, L * 16 * 4, HW * 48 * 4, L * 48 * 4};
+        for (int q = 0; q < 4; ++q) { off[q * 3 + k] = o; o += (sz[q] + 255) / 256 * 256; }
+    }
+    T2N_HIP(hipMalloc((void**)&f->gbuf_all, o));
+    f->gbuf_bytes = o;
+    char* b = (char*)f->gbuf_all;
+    for (int k = 0; k < 3; ++k) {
+        f->gbuf_den_plane[k] = (float*)(b + off[0 + k]); f->gbuf_den_line[k] = (float*)(b + off[3 + k]);
+        f->gbuf_app_plane[k] = (float*)(b + off[6 + k]); f->gbuf_app_line[k] = (float*)(b + off[9 + k]);
     }
     return T2N_OK;
 }
@@ -1182,13 +1189,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     const unsigned* counters = (const unsigned*)(fw + c.counters);
 
     const int* gr = f->desc.grid;
-    for (int k = 0; k < 3; ++k) {
-        const size_t HW = (size_t)gr[mat1(k)] * gr[mat0(k)], L = (size_t)gr[vecm(k)];
-        T2N_HIP(hipMemsetAsync(f->gbuf_den_plane[k], 0, HW * 16 * 4, s));
-        T2N_HIP(hipMemsetAsync(f->gbuf_den_line[k], 0, L * 16 * 4, s));
-        T2N_HIP(hipMemsetAsync(f->gbuf_app_plane[k], 0, HW * 48 * 4, s));
-        T2N_HIP(hipMemsetAsync(f->gbuf_app_line[k], 0, L * 48 * 4, s));
-    }
+    T2N_HIP(hipMemsetAsync(f->gbuf_all, 0, f->gbuf_bytes, s));
     T2N_HIP(hipMemsetAsync(go, 0, (size_t)rows_alloc * 16, s));
 
     // 1. appearance forward recompute with activations kept

@@ -82,6 +82,7 @@ struct t2n_field {
     float* gbuf_den_line[3] = {nullptr, nullptr, nullptr};
     float* gbuf_app_plane[3] = {nullptr, nullptr, nullptr};
     float* gbuf_app_line[3] = {nullptr, nullptr, nullptr};
+    float* gbuf_all = nullptr; size_t gbuf_bytes = 0;   // the 12 gradient buffers are slices of ONE allocation (one memset per backward)
     t2n_field_params params_ref;   // reference-layout parameter pointers of the last upload (backward reads W^T operands)
     bool uploaded = false;
     int timing = 0;

@@ -68,10 +68,9 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamMulti a) {
 // thing where the data already is: TV stencil on the channel-last parameters (neighbours at +-C and +-W*C), then one pass
 // that reads g / m / v / p channel-last, writes p / m / v channel-last and the new values into the caller's reference-layout
 // tensor through an LDS tile transpose. Same arithmetic per element as k_tv_grad_add + k_adam (bit-identical results).
-__global__ __launch_bounds__(256) void k_tv_grad_cl(const float* __restrict__ x, float* __restrict__ g, int C4, int H, int W, float sh,
-                                                    float sw) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 of 4 channels
-    const long long n = (long long)H * W * C4;
+__device__ __forceinline__ void tv_grad_cl_body(const float* __restrict__ x, float* __restrict__ g, long long t, int C4, int H, int W, float sh,
+                                                float sw) {
+    const long long n = (long long)H * W * C4;   // t: one float4 of 4 channels
     if (t >= n) return;
     const long long pos = t / C4;
     const int w = (int)(pos % W), h = (int)(pos / W);
@@ -97,13 +96,12 @@ __device__ __forceinline__ float adam_one(float p, float gi, float& m, float& v,
     const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
     return p - lr_over_bc1 * (mi / denom);
 }
-// one workgroup = 64 positions x C channels (a contiguous run of the channel-last arrays)
+// one workgroup = 64 positions x C channels (a contiguous run of the channel-last arrays); tile: [C][65] floats of LDS
 template <int C>
-__global__ __launch_bounds__(256) void k_adam_cl(float* __restrict__ p_cl, const float* __restrict__ g_cl, float* __restrict__ m, float* __restrict__ v,
-                                                 float* __restrict__ p_ref, long long npos_total, float lr_over_bc1, float beta1, float beta2,
-                                                 float eps, float inv_bc2_sqrt) {
-    __shared__ float tile[C][65];
-    const long long pos0 = (long long)blockIdx.x * 64;
+__device__ __forceinline__ void adam_cl_tile(float* __restrict__ tile, unsigned blk, float* __restrict__ p_cl, const float* __restrict__ g_cl,
+                                             float* __restrict__ m, float* __restrict__ v, float* __restrict__ p_ref, long long npos_total,
+                                             float lr_over_bc1, float beta1, float beta2, float eps, float inv_bc2_sqrt) {
+    const long long pos0 = (long long)blk * 64;
     const int npos = (int)(npos_total - pos0 < 64 ? npos_total - pos0 : 64);
     const long long base4 = pos0 * (C / 4);
     const int n4 = npos * (C / 4);
@@ -120,13 +118,40 @@ __global__ __launch_bounds__(256) void k_adam_cl(float* __restrict__ p_cl, const
         pv.w = adam_one(pv.w, gv.w, mv.w, vv.w, lr_over_bc1, beta1, beta2, eps, inv_bc2_sqrt);
         P[e] = pv; M[e] = mv; V[e] = vv;
         const int j = e / (C / 4), c = (e - j * (C / 4)) * 4;
-        tile[c][j] = pv.x; tile[c + 1][j] = pv.y; tile[c + 2][j] = pv.z; tile[c + 3][j] = pv.w;
+        tile[c * 65 + j] = pv.x; tile[(c + 1) * 65 + j] = pv.y; tile[(c + 2) * 65 + j] = pv.z; tile[(c + 3) * 65 + j] = pv.w;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < C * 64; e += 256) {
         const int c = e >> 6, j = e & 63;
-        if (j < npos) p_ref[(long long)c * npos_total + pos0 + j] = tile[c][j];
+        if (j < npos) p_ref[(long long)c * npos_total + pos0 + j] = tile[c * 65 + j];
     }
+}
+
+// the 12 factor tensors of a field in one launch each for the TV pass and the Adam pass (24 per-tensor launches otherwise:
+// the training step is within a few percent of being bound by the host's launch rate)
+struct FactorStep {
+    float* p[12]; float* g[12]; float* m[12]; float* v[12]; float* ref[12];
+    long long npos[12];
+    int C[12], H[12], W[12];
+    float sh[12], sw[12], lr_over_bc1[12], inv_bc2_sqrt[12];
+    unsigned ablock0[13], tblock0[13];   // first workgroup of tensor t in the Adam / TV launch (TV: zero-width for lines and weight 0)
+    float beta1, beta2, eps;
+};
+__global__ __launch_bounds__(256) void k_tv_grad_cl_multi(const FactorStep a) {
+    int t = 0;
+#pragma unroll 1
+    for (int q = 1; q < 12; ++q) t += (a.tblock0[q] <= blockIdx.x) ? 1 : 0;
+    const long long i = (long long)(blockIdx.x - a.tblock0[t]) * 256 + threadIdx.x;
+    tv_grad_cl_body(a.p[t], a.g[t], i, a.C[t] / 4, a.H[t], a.W[t], a.sh[t], a.sw[t]);
+}
+__global__ __launch_bounds__(256) void k_adam_cl_multi(const FactorStep a) {
+    __shared__ float tile[48 * 65];
+    int t = 0;
+#pragma unroll 1
+    for (int q = 1; q < 12; ++q) t += (a.ablock0[q] <= blockIdx.x) ? 1 : 0;
+    const unsigned blk = blockIdx.x - a.ablock0[t];
+    if (a.C[t] == 16) adam_cl_tile<16>(tile, blk, a.p[t], a.g[t], a.m[t], a.v[t], a.ref[t], a.npos[t], a.lr_over_bc1[t], a.beta1, a.beta2, a.eps, a.inv_bc2_sqrt[t]);
+    else adam_cl_tile<48>(tile, blk, a.p[t], a.g[t], a.m[t], a.v[t], a.ref[t], a.npos[t], a.lr_over_bc1[t], a.beta1, a.beta2, a.eps, a.inv_bc2_sqrt[t]);
 }
 
 }  // namespace t2n
@@ -144,34 +169,41 @@ extern "C" int t2n_field_tv_adam_step(t2n_field* f, const t2n_field_params* para
     if (f->factor_bf16) { set_error("t2n_field_tv_adam_step: bf16 factor storage keeps no fp32 master copy on the device"); return T2N_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
     const int* gr = f->desc.grid;
-    for (int k = 0; k < 3; ++k) {
-        const int H = gr[mat1(k)], W = gr[mat0(k)];
-        const long long HW = (long long)H * W, L = gr[vecm(k)];
-        // order of the 12 tensors: density planes, density lines, appearance planes, appearance lines
-        float* pcl[4] = {f->buf_den_plane[k], f->buf_den_line[k], f->buf_app_plane[k], f->buf_app_line[k]};
-        float* gcl[4] = {f->gbuf_den_plane[k], f->gbuf_den_line[k], f->gbuf_app_plane[k], f->gbuf_app_line[k]};
-        float* pref[4] = {(float*)params->density_plane[k], (float*)params->density_line[k], (float*)params->app_plane[k], (float*)params->app_line[k]};
-        const int Cs[4] = {16, 16, 48, 48};
-        const long long ns[4] = {HW, L, HW, L};
-        const float tvw[4] = {tv_weight_density, 0.f, tv_weight_app, 0.f};
-        for (int q = 0; q < 4; ++q) {
+    FactorStep A;
+    memset(&A, 0, sizeof(A));
+    A.beta1 = beta1; A.beta2 = beta2; A.eps = eps;
+    unsigned ab = 0, tb = 0;
+    // order of the 12 tensors: density planes, density lines, appearance planes, appearance lines
+    for (int q = 0; q < 4; ++q)
+        for (int k = 0; k < 3; ++k) {
             const int idx = q * 3 + k;
+            const int H = gr[mat1(k)], W = gr[mat0(k)];
+            const long long HW = (long long)H * W, L = gr[vecm(k)];
+            float* pcl[4] = {f->buf_den_plane[k], f->buf_den_line[k], f->buf_app_plane[k], f->buf_app_line[k]};
+            float* gcl[4] = {f->gbuf_den_plane[k], f->gbuf_den_line[k], f->gbuf_app_plane[k], f->gbuf_app_line[k]};
+            float* pref[4] = {(float*)params->density_plane[k], (float*)params->density_line[k], (float*)params->app_plane[k], (float*)params->app_line[k]};
+            const int C = q < 2 ? 16 : 48;
+            const bool plane = (q & 1) == 0;
+            const float tvw = q == 0 ? tv_weight_density : (q == 2 ? tv_weight_app : 0.f);
             if (!pref[q] || !exp_avg[idx] || !exp_avg_sq[idx] || steps[idx] < 1) { set_error("t2n_field_tv_adam_step: bad tensor %d", idx); return T2N_ERR_INVALID; }
-            const int C = Cs[q];
-            if (tvw[q] != 0.f) {
+            A.p[idx] = pcl[q]; A.g[idx] = gcl[q]; A.m[idx] = exp_avg[idx]; A.v[idx] = exp_avg_sq[idx]; A.ref[idx] = pref[q];
+            A.npos[idx] = plane ? HW : L; A.C[idx] = C; A.H[idx] = plane ? H : (int)L; A.W[idx] = plane ? W : 1;
+            A.tblock0[idx] = tb;
+            if (tvw != 0.f) {
                 if (H < 2 || W < 2) { set_error("t2n_field_tv_adam_step: TV needs planes of at least 2x2"); return T2N_ERR_INVALID; }
-                const float sh = tvw[q] * 2.f / ((float)C * (float)(H - 1) * (float)W);
-                const float sw = tvw[q] * 2.f / ((float)C * (float)H * (float)(W - 1));
-                const long long n4 = HW * (C / 4);
-                hipLaunchKernelGGL(k_tv_grad_cl, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (const float*)pcl[q], gcl[q], C / 4, H, W, sh, sw);
+                A.sh[idx] = tvw * 2.f / ((float)C * (float)(H - 1) * (float)W);
+                A.sw[idx] = tvw * 2.f / ((float)C * (float)H * (float)(W - 1));
+                tb += (unsigned)((HW * (C / 4) + 255) / 256);
             }
             const double bc1 = 1.0 - pow((double)beta1, (double)steps[idx]), bc2 = 1.0 - pow((double)beta2, (double)steps[idx]);
-            const float lr_over_bc1 = (float)((double)lrs[idx] / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-            const dim3 grid((unsigned)((ns[q] + 63) / 64));
-            if (C == 16) hipLaunchKernelGGL(k_adam_cl<16>, grid, dim3(256), 0, s, pcl[q], (const float*)gcl[q], exp_avg[idx], exp_avg_sq[idx], pref[q], ns[q], lr_over_bc1, beta1, beta2, eps, inv_bc2_sqrt);
-            else hipLaunchKernelGGL(k_adam_cl<48>, grid, dim3(256), 0, s, pcl[q], (const float*)gcl[q], exp_avg[idx], exp_avg_sq[idx], pref[q], ns[q], lr_over_bc1, beta1, beta2, eps, inv_bc2_sqrt);
+            A.lr_over_bc1[idx] = (float)((double)lrs[idx] / bc1);
+            A.inv_bc2_sqrt[idx] = (float)(1.0 / sqrt(bc2));
+            A.ablock0[idx] = ab;
+            ab += (unsigned)((A.npos[idx] + 63) / 64);
         }
-    }
+    A.tblock0[12] = tb; A.ablock0[12] = ab;
+    if (tb) hipLaunchKernelGGL(k_tv_grad_cl_multi, dim3(tb), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_adam_cl_multi, dim3(ab), dim3(256), 0, s, A);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }
