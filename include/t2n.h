@@ -247,7 +247,12 @@ int t2n_dibr_filter_mask2(float* image, int32_t* known, double* depth, int H, in
  * z_vals materialised; (2) t2n_render_ctx_rows reads the appearance-sample count back (SYNCHRONISES the stream) and
  * returns the padded activation row count; (3) t2n_render_backward with a second workspace of
  * t2n_backward_workspace_bytes(field, rows, n_rays, n_samples). Only the MLP_Fea_noview head is differentiable here (the driver's head).
- * d_weights may be NULL. Gradients are ACCUMULATED into `g` (reference layouts; NULL members are skipped). */
+ * d_weights may be NULL. Gradients are ACCUMULATED into `g` (reference layouts; NULL members are skipped: the channel-last
+ * plane / line gradients then stay in the field for t2n_field_tv_adam_step).
+ * Optional: a forward workspace LARGER than t2n_render_workspace_bytes_ctx by 256 + rows * 1728 bytes lets the forward keep
+ * the MLP activations of up to `rows` appearance samples (a guess, e.g. 1.25 x the previous call's row count); when the
+ * actual count fits — and the same byte count is passed to t2n_render_backward — the backward skips its re-run of the
+ * appearance forward. Too small a guess only costs that re-run. */
 size_t t2n_render_workspace_bytes_ctx(int64_t n_rays, int n_samples);
 int t2n_render_ctx_rows(const void* fwd_workspace, int64_t n_rays, int n_samples, t2n_stream stream, int64_t* rows);
 size_t t2n_backward_workspace_bytes(const t2n_field* f, int64_t rows, int64_t n_rays, int n_samples);
