@@ -11,6 +11,7 @@ Prints ONE JSON line (rank 0): metric/value/unit per BASELINE.json plus `rooflin
 `cpu_baseline` (the oracle — a PyTorch CPU restatement of the reference path — on a bounded sample of the workload).
 """
 import argparse
+import faulthandler
 import json
 import os
 import sys
@@ -31,6 +32,11 @@ def host_cores():
         pass
     return n
 
+
+if os.environ.get("T2N_BENCH_DEADLINE_S"):
+    # a rank that has not finished by then dumps every thread's Python stack to stderr and exits non-zero: a hang becomes a
+    # diagnosable failure of THIS process (never a re-exec of a process that has touched the GPU)
+    faulthandler.dump_traceback_later(float(os.environ["T2N_BENCH_DEADLINE_S"]), exit=True)
 
 HOST_CORES = host_cores()
 # host-side thread pools sized to the usable cores BEFORE torch / OpenMP start: oversubscribed pools stall the training
@@ -204,6 +210,14 @@ def main():
                     help="disable the 8x8-tile marcher (default for whole row-major frames: field.frame_width = W)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the C3-shaped train-step timing (iters/s)")
+    ap.add_argument("--mode", default="weak", choices=["weak", "c4"],
+                    help="weak: one 800x800 view per GPU (C2, the headline); c4: BASELINE configs[3] — ONE 1600x1600 frame split "
+                         "into contiguous ray tiles over the ranks, all-gather of the rgb+depth tiles inside every step "
+                         "(strong scaling)")
+    ap.add_argument("--check-c4", action="store_true",
+                    help="c4 mode: rank 0 also renders the whole frame alone and compares it bitwise with the gathered one")
+    ap.add_argument("--train-iters", type=int, default=20)
+    ap.add_argument("--train-warmup", type=int, default=3)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -212,26 +226,50 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.set_num_threads(max(1, min(HOST_CORES // max(world, 1), 16)))
-    if os.environ.get("T2N_BENCH_SAME_DEVICE"):   # functional test of the N>1 path on a 1-GPU box (with T2N_BENCH_BACKEND=gloo)
+    same_device = bool(os.environ.get("T2N_BENCH_SAME_DEVICE"))   # functional test of the N>1 path on a 1-GPU box (gloo)
+    if same_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    def note(msg):   # progress markers on stderr: the integration test tells a device bring-up stall from a hung collective
+        print(f"[bench] rank {rank}: {msg}", file=sys.stderr, flush=True)
+
+    def gpu_up():
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        torch.cuda.set_device(local_rank)
+        torch.zeros(1, device=dev).add_(1)
+        torch.cuda.synchronize()
+
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("T2N_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+        tmo = datetime.timedelta(seconds=float(os.environ.get("T2N_BENCH_COLLECTIVE_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            gpu_up()
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+            # several ranks on ONE device: bring the device up one process at a time
+            for r in range(world):
+                if r == rank or not same_device:
+                    gpu_up()
+                if same_device:
+                    dist.barrier()
+                else:
+                    break
+        note("gpu and process group ready")
+    else:
+        gpu_up()
 
     from text2nerf_amd import generate_rays, synth
     from text2nerf_amd.parallel import all_gather_tiles
 
-    H = W = 800
+    c4 = args.mode == "c4"
+    H = W = 1600 if c4 else 800
     field, params, aabb = build_field(dev, scene=args.scene, seed=0 if args.scene.startswith("S1") else 1)
     field.materialize_weights = bool(args.weights)
     field.factor_storage = args.factor_storage
@@ -240,9 +278,17 @@ def main():
     field.frame_width = 0 if args.per_ray_marcher else W
     N = field.nSamples
     poses = synth.local_fixed_like_poses(max(world, 9))
-    pose = poses[rank % len(poses)] if world > 1 else np.eye(4, dtype=np.float32)
+    pose = poses[rank % len(poses)] if world > 1 and not c4 else np.eye(4, dtype=np.float32)
     f = float(max(H, W))
     rays = generate_rays(H, W, [f, f, W // 2, H // 2], pose, device=dev)   # resident in HBM before the timed region
+    if c4:   # this rank's contiguous tile of the ONE frame (whole image rows: 1600 x 1600 / 8 ranks = 200 rows each)
+        from text2nerf_amd.parallel import shard_bounds, tile_capacity
+        frame_rays, R_frame = rays, rays.shape[0]
+        lo, hi = shard_bounds(R_frame, world, rank)
+        cap = tile_capacity(R_frame, world)
+        rays = frame_rays[lo:hi].contiguous()
+        if not args.check_c4:
+            del frame_rays
     R = rays.shape[0]
 
     # N > 1: the all-gather of frame k's [rays, 4] tile runs asynchronously (RCCL's own stream) while frame k+1 is rendered;
@@ -252,6 +298,12 @@ def main():
     def step():
         with torch.no_grad():
             rgb, depth, z, w = field(rays, white_bg=True, is_train=False, N_samples=-1)
+            if c4 and world > 1:   # strong scaling: the frame is complete only when every tile has arrived
+                tile = torch.zeros((cap, 4), dtype=rgb.dtype, device=rgb.device)
+                tile[:R, :3], tile[:R, 3] = rgb, depth
+                out = torch.empty((world * cap, 4), dtype=tile.dtype, device=tile.device)
+                dist.all_gather_into_tensor(out, tile)
+                return out
             if world > 1:
                 tile = torch.cat([rgb, depth[:, None]], 1)
                 out = torch.empty((world * tile.shape[0], 4), dtype=tile.dtype, device=tile.device)
@@ -290,16 +342,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    c4_equal = None
+    if c4 and args.check_c4:   # the gathered frame against the whole frame rendered by rank 0 alone (untimed; every rank gathers)
+        g = step()
+        if rank == 0:
+            with torch.no_grad():
+                s_rgb, s_depth, _, _ = field(frame_rays, white_bg=True, is_train=False, N_samples=-1)
+            if world > 1:
+                g = g.view(world, cap, 4)
+                g = torch.cat([g[r, : shard_bounds(R_frame, world, r)[1] - shard_bounds(R_frame, world, r)[0]]
+                               for r in range(world)], 0)
+                c4_equal = bool(torch.equal(g[:, :3], s_rgb) and torch.equal(g[:, 3], s_depth))
+            else:
+                c4_equal = bool(torch.equal(g, s_rgb))
+            del s_rgb, s_depth
     dp = {}
     if dist is not None and not args.no_train:   # every rank takes part in the data-parallel train step
         try:
-            dp = train_bench(dev, fused_optim=True, dist=dist)
-        except Exception as e:  # noqa: BLE001 - the render line must still be printed
-            dp = {"train_dp_error": repr(e)[:300]}
+            dp = train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True, dist=dist)
+        except BaseException:
+            # a rank that fails inside the data-parallel section must not leave its peers blocked in a collective it will
+            # never join: report and leave non-zero at once (the launcher tears the job down; the collectives carry a timeout)
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            os._exit(13)
     if rank == 0:
         V, A = st["evaluated"], st["appearance"]
         ms_step = dt / args.steps * 1e3
-        nominal = world * R * N * args.steps / dt
+        nominal = (R_frame if c4 else world * R) * N * args.steps / dt
         k_ms = {k: v[0] / max(v[1], 1) for k, v in timing.items()}        # avg ms per launch
         k_per_step = {k: v[1] / args.steps for k, v in timing.items()}     # launches per step
         frame_ms = {k: v[0] / args.steps for k, v in timing.items()}       # kernel ms per frame
@@ -336,18 +407,21 @@ def main():
         out = {
             "metric": "ray-samples/s (render) + iters/s (train), 300^3 VM-split, 800x800",
             "value": nominal, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if c4 else "weak", "vs_baseline": None,
             "dtype": "f32" + (" (basis/MLP products as f16x2-split MFMA, fp32 accumulate)" if split else "") +
                      ("; factor tensors stored as bf16" if args.factor_storage == "bf16" else ""),
             "data": "synthetic",
-            "config": {"workload": f"C2: TensorVMSplit 300^3, 800x800 view/GPU, {N} samples/ray, render_only, scene "
+            "config": {"workload": (f"C4: TensorVMSplit 300^3, ONE 1600x1600 frame in {world} contiguous ray tiles, "
+                                    if c4 else "C2: TensorVMSplit 300^3, 800x800 view/GPU, ") +
+                                   f"{N} samples/ray, render_only, scene "
                                    f"{args.scene} seed 0, white_bg, weights/z_vals materialised: {bool(args.weights)}, "
                                    f"marcher: {'per-ray' if args.per_ray_marcher else '8x8-pixel tiles'}",
                        "rays_per_gpu": R, "samples_per_ray": N, "evaluated_samples_per_frame": V,
-                       "appearance_samples_per_frame": A, "rays_per_s": world * R * args.steps / dt,
+                       "appearance_samples_per_frame": A, "rays_per_s": (R_frame if c4 else world * R) * args.steps / dt,
                        "evaluated_samples_per_s": world * V * args.steps / dt,
-                       "parallelism": f"ray-tile x{world}" + (" + RCCL all-gather of rgb+depth tiles (async, overlapped with the "
-                                                              "next frame's render)" if world > 1 else ""),
+                       "parallelism": f"ray-tile x{world}" + ((" + RCCL all-gather of rgb+depth tiles inside every step" if c4 else
+                                                               " + RCCL all-gather of rgb+depth tiles (async, overlapped with the "
+                                                               "next frame's render)") if world > 1 else ""),
                        "kernel_ms_per_frame": frame_ms,
                        "march_algorithmic_GBps": (alg_bytes["march"] / max(k_per_step.get("march", 1.0), 1.0)) /
                                                  (k_ms["march"] * 1e-3) / 1e9 if "march" in k_ms else None,
@@ -358,6 +432,8 @@ def main():
             "roofline": roof,
         }
         out["config"].update(dp)
+        if c4_equal is not None:
+            out["config"]["c4_gathered_equals_single_rank"] = c4_equal
         if world == 1 and args.factor_storage == "fp32":
             # the same frame with bf16 factor storage (configs[4] mode; not the headline value: it renders the ROUNDED field)
             field.factor_storage = "bf16"
@@ -371,9 +447,8 @@ def main():
             out["config"]["bf16_factor_storage_ms_per_step"] = (time.perf_counter() - t0) / args.steps * 1e3
             field.factor_storage = "fp32"
         if world == 1 and not args.no_train:
-            del rays
-            out["config"].update(train_bench(dev))
-            out["config"].update(train_bench(dev, fused_optim=True))
+            out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup))
+            out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True))
         if world == 1 and not args.no_cpu_baseline:
             def hip_render(r):
                 with torch.no_grad():

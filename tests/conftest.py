@@ -17,6 +17,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Stage-level parity first (tests/test_hip_parity.py), multi-process integration runs of bench.py last: with `-x` one
+    hung integration test must not keep a single parity test from running."""
+    def key(item):
+        name = os.path.basename(str(item.fspath))
+        return (0 if name == "test_hip_parity.py" else 2 if name.startswith("test_zz_") else 1)
+    items.sort(key=key)     # stable: the order inside each class stays as collected
+
+
 @pytest.fixture(scope="session")
 def tiny():
     return dict(np.load(os.path.join(GOLDEN, "tiny.npz"), allow_pickle=False))
