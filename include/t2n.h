@@ -315,7 +315,7 @@ int t2n_filter_rays_alpha(const t2n_field* f, const float* rays, int64_t n_rays,
  * the launch stream. t2n_timing_read synchronises those events and returns accumulated milliseconds and launch counts
  * per kernel since the last reset. Kernel ids: */
 enum { T2N_K_MARCH = 0, T2N_K_SHADE = 1, T2N_K_COMPOSITE = 2, T2N_K_UPLOAD = 3, T2N_K_BWD_MARCH = 4, T2N_K_BWD_MLP = 5,
-       T2N_K_BWD_SCATTER = 6, T2N_K_DENSITY = 7, T2N_K_COUNT = 8 };
+       T2N_K_BWD_SCATTER = 6, T2N_K_DENSITY = 7, T2N_K_APPFEAT = 8 /* appearance gather + basis_mat */, T2N_K_COUNT = 9 };
 int t2n_timing_enable(t2n_field* f, int on);
 int t2n_timing_read(t2n_field* f, double* ms /*[T2N_K_COUNT]*/, int64_t* launches /*[T2N_K_COUNT]*/, int reset);
 

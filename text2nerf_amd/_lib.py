@@ -6,11 +6,12 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libt2n_hip.so")
+# T2N_LIB selects another build of the library (experiment / instrumented variants) without touching the shipped artefact
+LIB_PATH = os.environ.get("T2N_LIB") or os.path.join(_HERE, "libt2n_hip.so")
 
 T2N_STAT_COUNT = 8
-T2N_K_COUNT = 8
-KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_mlp", "bwd_scatter", "density")
+T2N_K_COUNT = 9
+KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_mlp", "bwd_scatter", "density", "app_features")
 STAT_EVALUATED, STAT_APPEARANCE, STAT_RAYS, STAT_OVERFLOW = 0, 1, 2, 3
 
 FLAG_TRAIN, FLAG_ADD_BG, FLAG_KEEP_CTX, FLAG_COHERENT, FLAG_NDC = 1, 2, 4, 8, 16

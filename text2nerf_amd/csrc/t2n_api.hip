@@ -368,6 +368,11 @@ Carve carve_workspace(int64_t rays, int n_samples, bool ctx) {
     // tile marcher: per-ray staging of up to n_samples / 4 appearance entries (+ one 256-B line: overflow counter) and an
     // overflow ray list
     c.scratch = o; if (ctx) o = align_up(o + (size_t)rays * (size_t)(n_samples / 4 > 0 ? n_samples / 4 : 1) * 16 + 256 + (size_t)rays * 4, 256);
+    // appearance feature rows between the gather + basis kernel and the weight-stationary head: 32 rows per ray (the bench
+    // scene needs ~7), never more than the worst case; appearance tiles past the capacity take the one-kernel path
+    const size_t worst_rows = cap + (size_t)kLists * 32, want_rows = (size_t)rays * 32 + 1024;
+    c.feat_rows = (unsigned)(((worst_rows < want_rows ? worst_rows : want_rows) + 127) / 128 * 128);
+    c.feat = o; o = align_up(o + (size_t)c.feat_rows * 32 * sizeof(float), 256);
     c.total = o;
     return c;
 }
@@ -416,6 +421,7 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->gbuf_all) (void)hipFree(f->gbuf_all);
     if (f->buf_mlp) (void)hipFree(f->buf_mlp);
     if (f->buf_mlp_h) (void)hipFree(f->buf_mlp_h);
+    if (f->buf_ws) (void)hipFree(f->buf_ws);
     if (f->buf_alpha) (void)hipFree(f->buf_alpha);
     for (int k = 0; k < T2N_K_COUNT; ++k)
         for (int i = 0; i < 64; ++i) {
@@ -440,6 +446,7 @@ extern "C" int t2n_field_upload(t2n_field* f, const t2n_field_params* p, t2n_str
     timing_end(f, T2N_K_UPLOAD, s);
     if (rc) return rc;
     f->params_ref = *p;
+    f->ws_dirty = true;
     f->uploaded = true;
     return T2N_OK;
 }
@@ -460,6 +467,7 @@ extern "C" int t2n_field_upload_head(t2n_field* f, const t2n_field_params* p, t2
     f->params_ref.basis_weight = p->basis_weight;
     f->params_ref.mlp_w0 = p->mlp_w0; f->params_ref.mlp_b0 = p->mlp_b0; f->params_ref.mlp_w1 = p->mlp_w1; f->params_ref.mlp_b1 = p->mlp_b1;
     f->params_ref.mlp_w2 = p->mlp_w2; f->params_ref.mlp_b2 = p->mlp_b2;
+    f->ws_dirty = true;
     return T2N_OK;
 }
 
@@ -595,6 +603,7 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         L.counters = (unsigned*)(ws + c.counters); L.acc = (float*)(ws + c.acc); L.ray_app = (int4*)(ws + c.ray_app);
         L.app_pos = (float4*)(ws + c.app_pos); L.app_rgb = (float4*)(ws + c.app_rgb); L.app_ray = (int*)(ws + c.app_ray);
         L.list_cap = c.list_cap;
+        L.feat = (float*)(ws + c.feat); L.feat_rows = c.feat_rows;
         L.sigma_ctx = keep ? (float*)(ws + c.sigma) : nullptr;
         L.rgb_raw = keep ? (float4*)(ws + c.rgb_raw) : nullptr;
         T2N_HIP(hipMemsetAsync(L.counters, 0, (size_t)kLists * kCounterStride * 4, s));
@@ -632,7 +641,8 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
             if (kr.rows >= 32) {
                 ShadeCtx ctx{(float*)(ws + kr.x144), (float*)(ws + kr.feat32), (float*)(ws + kr.h0), (float*)(ws + kr.h1)};
                 if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, &ctx, s, false, kr.rows))) return rc;
-            } else if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, nullptr, s))) return rc;
+            } else if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, nullptr, s, false,
+                                               0xffffffffu, keep ? nullptr : L.feat, L.feat_rows))) return rc;
         }
         if ((rc = launch_composite(f, L, s))) return rc;
     }

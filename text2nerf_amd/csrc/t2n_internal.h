@@ -75,6 +75,8 @@ struct t2n_field {
     int factor_bf16 = 0;
     float* buf_mlp = nullptr;  // basisA | w0A | w1A | w2A
     void* buf_mlp_h = nullptr; // split-f16 operands + scaled biases
+    void* buf_ws = nullptr;    // weight-stationary head operands (t2n_mlp_ws.hip), packed lazily from params_ref
+    bool ws_dirty = true;
     float* buf_alpha = nullptr; // alpha-mask volume copy
     int mlp_split = 1;         // 1: f16 two-way split products (default), 0: exact fp32 MFMA
     // channel-last gradient accumulators (backward), allocated on first use
@@ -114,6 +116,7 @@ struct RenderLaunch {
     const float* jitter; float* rgb; float* depth; float* weights; float* z_vals; uint64_t* stats;
     // workspace carve (one sub-launch)
     float* acc; int4* ray_app; unsigned* counters; float4* app_pos; int* app_ray; float4* app_rgb; unsigned list_cap;
+    float* feat = nullptr; unsigned feat_rows = 0;   // appearance feature rows [feat_rows][32] between the gather + basis kernel and the head
     float* sigma_ctx; float4* rgb_raw;   // KEEP_CTX only, else NULL
 };
 int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s);
@@ -133,7 +136,12 @@ inline unsigned list_capacity(long long n_rays, int n_samples) {
 struct ShadeCtx { float* x144; float* feat32; float* h0; float* h1; };
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
                       const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s,
-                      bool features_only = false, unsigned ctx_rows = 0xffffffffu);
+                      bool features_only = false, unsigned ctx_rows = 0xffffffffu, float* feat = nullptr, unsigned feat_rows = 0);
+// feat / feat_rows: scratch rows for the two-kernel default path (features -> weight-stationary head, t2n_mlp_ws.hip); tiles
+// past the capacity take the one-kernel path. Word kRangeFlagWord of the counter block is the head's f16-range flag.
+constexpr int kRangeFlagWord = 32;
+int launch_mlp_ws(t2n_field* f, const float* feat, const unsigned* counters_dev, unsigned list_cap, unsigned tile_hi, float4* app_rgb,
+                  unsigned* range_flag, hipStream_t s);
 // features_only: gather + basis stages only (the general heads take over); ctx_rows: capacity of the ctx buffers in rows
 
 // the general (unfused) view-dependent heads (t2n_heads.hip): MLP_Fea / MLP_PE / MLP input layout and launchers
@@ -146,7 +154,7 @@ int launch_head_forward(t2n_field* f, const unsigned tiles_before[kLists + 1], l
 int launch_head_in_bwd(t2n_field* f, const float* gx, const float* feat32, long long rows, float* gf, hipStream_t s);
 
 // forward-workspace carve shared by forward and backward (t2n_api.hip)
-struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, total; unsigned list_cap; };
+struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, feat, total; unsigned list_cap, feat_rows; };
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx);   // ctx: also room for sigma [rays,N] and rgb_raw [rays]
 int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s);
 // Activation rows the forward keeps for the backward when the KEEP_CTX workspace is larger than the context itself (the

@@ -283,6 +283,8 @@ struct ShadeArgs {
     float4* app_rgb; float* feat_out; float* rgb_out;   // rgb_out: packed [n,3] (explicit-point mode)
     ShadeCtx ctx;   // activation rows for the backward pass (all NULL in the normal forward)
     unsigned ctx_rows;   // rows the ctx buffers hold: tiles past it keep nothing (forward-kept activations with a capacity guess)
+    unsigned tile_lo, tile_hi;        // this launch covers tiles [tile_lo, min(ntiles, tile_hi)) of the sub-lists
+    const unsigned* run_if_nonzero;   // when set: the launch is a no-op unless *run_if_nonzero != 0 (exact-path redo gate)
 };
 
 // Gather: 384 (sample, channel-quad) items over 64 lanes, 6 per lane; an item computes its sample's three axis taps once
@@ -365,10 +367,12 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         const unsigned t = __shfl_up(incl, o);
         if (lane >= o) incl += t;
     }
-    const unsigned ntiles = __shfl(incl, a.nlists - 1);
+    unsigned ntiles = __shfl(incl, a.nlists - 1);
+    if (ntiles > a.tile_hi) ntiles = a.tile_hi;
+    if (a.run_if_nonzero && *a.run_if_nonzero == 0u) return;
     const unsigned wave_stride = gridDim.x * 4u;
 
-    for (unsigned tile = blockIdx.x * 4u + wid; tile < ntiles; tile += wave_stride) {
+    for (unsigned tile = a.tile_lo + blockIdx.x * 4u + wid; tile < ntiles; tile += wave_stride) {
         const int li = (int)__popcll(__ballot((lane < a.nlists) & (incl <= tile)));
         const unsigned before = li ? __shfl(incl, li - 1) : 0u;
         const unsigned lbase = (unsigned)li * a.list_cap;
@@ -731,14 +735,15 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
         const unsigned t = __shfl_up(incl, o);
         if (lane >= o) incl += t;
     }
-    const unsigned ntiles = __shfl(incl, a.nlists - 1);
+    unsigned ntiles = __shfl(incl, a.nlists - 1);
+    if (ntiles > a.tile_hi) ntiles = a.tile_hi;
     const unsigned block_stride = gridDim.x * 4u;
 #ifdef T2N_PHASE_TIMING
     unsigned long long phacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     // the block's four waves take tiles tile0 .. tile0+3 together; a wave past the end runs an all-dead tile
-    for (unsigned tile0 = blockIdx.x * 4u; tile0 < ntiles; tile0 += block_stride) {
+    for (unsigned tile0 = a.tile_lo + blockIdx.x * 4u; tile0 < ntiles; tile0 += block_stride) {
         const unsigned tile = tile0 + wid;
         unsigned base = 0, count = 0;
         if (tile < ntiles) {
@@ -1015,13 +1020,19 @@ static bool use_coop(const t2n_field* f) {
     return !off && f->mlp_split && f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW;
 }
 
+static bool use_ws(const t2n_field* f) {
+    static const bool off = getenv("T2N_SHADE_NO_WS") != nullptr;   // A/B switch: the one-kernel cooperative path
+    return !off && use_coop(f);
+}
+
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
                       const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s,
-                      bool features_only, unsigned ctx_rows) {
+                      bool features_only, unsigned ctx_rows, float* feat, unsigned feat_rows) {
     ShadeArgs a;
     memset(&a, 0, sizeof(a));
     if (ctx) a.ctx = *ctx;
     a.ctx_rows = ctx_rows;
+    a.tile_lo = 0; a.tile_hi = 0xffffffffu;
     a.F = f->dev;
     if (features_only) a.F.shading = T2N_SHADE_RGB;   // gather + basis only; the rgb slots get placeholder values the head overwrites
     a.app_pos = app_pos; a.app_ray = app_ray; a.rays = rays; a.ray_stride = ray_stride;
@@ -1035,12 +1046,38 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
         attr_set = true;
     }
-    timing_begin(f, T2N_K_SHADE, s);
+    const dim3 grid(shade_grid((unsigned long long)list_cap * kLists));
     const bool half = f->factor_bf16 && f->dev.app.plane_h[0];
-    if (use_coop(f) && !ctx && half) hipLaunchKernelGGL(k_shade_coop<true>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), kCoopLds, s, a);
-    else if (use_coop(f) && !ctx) hipLaunchKernelGGL(k_shade_coop<false>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), kCoopLds, s, a);
-    else if (f->mlp_split)   /* ctx (backward recompute) too: activations at ~1e-7 relative error */ hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid((unsigned long long)list_cap * kLists)), dim3(256), lds, s, a);
+    const unsigned ws_tiles = feat ? feat_rows / 128u * 4u : 0u;
+    if (use_ws(f) && !ctx && !half && !features_only && ws_tiles >= 4u) {
+        // default render path: K2a gather + basis -> feature rows, K2b weight-stationary head; tiles past the row capacity take
+        // the one-kernel path; a head that met an activation outside the f16 range is redone on the exact fp32 path
+        ShadeArgs fa = a;
+        fa.F.shading = T2N_SHADE_RGB;
+        fa.app_rgb = nullptr;
+        fa.ctx = ShadeCtx{nullptr, feat, nullptr, nullptr};
+        fa.ctx_rows = ws_tiles * 32u; fa.tile_hi = ws_tiles;
+        timing_begin(f, T2N_K_APPFEAT, s);
+        hipLaunchKernelGGL(k_shade<true>, grid, dim3(256), lds, s, fa);
+        timing_end(f, T2N_K_APPFEAT, s);
+        timing_begin(f, T2N_K_SHADE, s);
+        const int rc = launch_mlp_ws(f, feat, counters_dev, list_cap, ws_tiles, app_rgb, const_cast<unsigned*>(counters_dev) + kRangeFlagWord, s);
+        if (rc) return rc;
+        ShadeArgs oa = a;
+        oa.tile_lo = ws_tiles;
+        hipLaunchKernelGGL(k_shade_coop<false>, grid, dim3(256), kCoopLds, s, oa);
+        ShadeArgs ra = a;
+        ra.tile_hi = ws_tiles; ra.run_if_nonzero = counters_dev + kRangeFlagWord;
+        hipLaunchKernelGGL(k_shade<false>, grid, dim3(256), lds, s, ra);
+        timing_end(f, T2N_K_SHADE, s);
+        T2N_HIP(hipGetLastError());
+        return T2N_OK;
+    }
+    timing_begin(f, T2N_K_SHADE, s);
+    if (use_coop(f) && !ctx && half) hipLaunchKernelGGL(k_shade_coop<true>, grid, dim3(256), kCoopLds, s, a);
+    else if (use_coop(f) && !ctx) hipLaunchKernelGGL(k_shade_coop<false>, grid, dim3(256), kCoopLds, s, a);
+    else if (f->mlp_split)   /* ctx (backward recompute) too: activations at ~1e-7 relative error */ hipLaunchKernelGGL(k_shade<true>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_shade<false>, grid, dim3(256), lds, s, a);
     timing_end(f, T2N_K_SHADE, s);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
@@ -1074,6 +1111,7 @@ extern "C" int t2n_shade_at(const t2n_field* fc, const float* xyz_norm, const fl
     a.F = f->dev;
     if (head_is_generic(f->desc.shading)) a.F.shading = T2N_SHADE_RGB;   // features only
     a.xyz = xyz_norm; a.viewdirs = viewdirs; a.count_max = (unsigned)n; a.nlists = 1; a.feat_out = app_feat; a.rgb_out = rgb;
+    a.tile_lo = 0; a.tile_hi = 0xffffffffu;
     const size_t lds = (size_t)4 * kTileFloats * sizeof(float);
     T2N_HIP(hipFuncSetAttribute((const void*)k_shade<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
