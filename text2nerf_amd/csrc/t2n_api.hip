@@ -368,9 +368,10 @@ Carve carve_workspace(int64_t rays, int n_samples, bool ctx) {
     // tile marcher: per-ray staging of up to n_samples / 4 appearance entries (+ one 256-B line: overflow counter) and an
     // overflow ray list
     c.scratch = o; if (ctx) o = align_up(o + (size_t)rays * (size_t)(n_samples / 4 > 0 ? n_samples / 4 : 1) * 16 + 256 + (size_t)rays * 4, 256);
-    // appearance feature rows between the gather + basis kernel and the weight-stationary head: 32 rows per ray (the bench
-    // scene needs ~7), never more than the worst case; appearance tiles past the capacity take the one-kernel path
-    const size_t worst_rows = cap + (size_t)kLists * 32, want_rows = (size_t)rays * 32 + 1024;
+    // appearance feature rows between the gather + basis kernel and the weight-stationary head: 64 rows per ray (the bench
+    // scene needs ~7, BASELINE configs[0] ~44), never more than the worst case; appearance tiles past the capacity take the
+    // one-kernel path
+    const size_t worst_rows = cap + (size_t)kLists * 32, want_rows = (size_t)rays * 64 + 1024;
     c.feat_rows = (unsigned)(((worst_rows < want_rows ? worst_rows : want_rows) + 127) / 128 * 128);
     c.feat = o; o = align_up(o + (size_t)c.feat_rows * 32 * sizeof(float), 256);
     c.total = o;

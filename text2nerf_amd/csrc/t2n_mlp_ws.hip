@@ -4,56 +4,77 @@
 //
 // Replaces (reference): models/tensorBase.py:11-17 (positional_encoding), :88-109 (MLPRender_Fea_noview.forward).
 //
-// Mapping (gfx950, wave64): ONE 256-thread workgroup per CU, persistent over groups of 128 samples (4 N-tiles of 32). Wave w
-// owns output units 32w .. 32w+31 of both hidden layers and keeps its slice of the layer-0 weights in registers for the whole
-// kernel (24 K-chunks x (hi, lo) x 16 B per lane = 192 VGPRs: the A operands of v_mfma_f32_32x32x16_f16 never move again;
-// the layer-1 / layer-2 slices sit in LDS). fp32 products are three f16 products of hi/lo splits (x = hi + lo, hi = RTZ_f16(x),
-// lo = RTZ_f16(x - hi); the lo*lo term is dropped: ~2^-21 relative), fp32 accumulate. Weights are pre-split and scaled by a
-// per-layer power of two chosen from max|W| at upload (k_ws_scales), activations are split where they are produced, and any
-// activation beyond the f16 range raises a flag that makes the caller's exact-fp32 kernel redo the launch.
+// Mapping (gfx950, wave64): ONE 512-thread workgroup per CU (two waves per SIMD), persistent over groups of 128 samples
+// (8 N-tiles of 16). Wave w owns output units 16w .. 16w+15 of both hidden layers and keeps its slice of the layer-0 weights in
+// registers for the whole kernel (12 K-chunks of 32 x (hi, lo) x 16 B per lane = 96 VGPRs: the A operands of
+// v_mfma_f32_16x16x32_f16 never move again; the layer-1 / layer-2 slices sit in LDS). fp32 products are three f16 products of
+// hi/lo splits (x = hi + lo, hi = RTZ_f16(x), lo = RTZ_f16(x - hi); the lo*lo term is dropped: ~2^-21 relative), fp32
+// accumulate. Weights are pre-split and scaled by a per-layer power of two chosen from max|W| at upload (k_ws_scales),
+// activations are split where they are produced, and any activation beyond the f16 range raises a flag that makes the caller's
+// exact-fp32 kernel redo the launch.
 //
-// The B operands (samples on N) go through LDS once per sample: the four waves share the encoding work — wave w' encodes
-// features 7w' .. 7w'+6 of every sample: sin / cos by v_sin_f32 / v_cos_f32 on the fraction of f * 2^q / (2 pi), 1 / (2 pi) as
-// a two-constant product (max abs error 4.2e-7 over |f| <= 3e4, measured: tools/experiments/hw_sincos.hip) — as six K-chunks
-// of 16 values, one chunk per pipeline step into a two-slot ring; a step's 48 MFMAs (4 chunks x 4 N-tiles x 3 products) run
-// on the chunks encoded during the previous step. Hidden activations return to LDS in the same B layout (relu, unscale,
-// split), so layers 1 and 2 are plain LDS -> MFMA streams. ~10 workgroup barriers per 128 samples.
+// (A first version ran four waves with 32 units each on 32x32x16 tiles — 192 weight registers, one wave per SIMD: with a single
+// in-order wave per SIMD the ~5 non-MFMA issues per MFMA of the encoding did not fit the MFMA's shadow even hand-interleaved:
+// 1.49 ms per frame, 48 cycles per MFMA in the encoding steps against 37 in a pure-MFMA step. Two waves per SIMD need <= 256
+// registers each, hence the 16-unit slices.)
 //
-// K order of layer 0 (what k_pack_ws mirrors): chunk c = 6 w' + j holds values v = 16 j .. 16 j + 15 of wave w's 96-value
-// sequence: v < 84: feature 7w' + v / 12, octave (v % 12) / 2, sin (even v) / cos (odd v); 84 <= v < 91: raw feature
-// 7w' + v - 84; the rest zero.
+// The B operands (samples on N) go through LDS once per sample: the waves share the encoding work — wave w' < 7 encodes features
+// 4w' .. 4w'+3 of every sample (sin / cos of octaves 0 and 3 by v_sin_f32 / v_cos_f32 on the fraction of f 2^q / (2 pi), 1 / (2 pi)
+// as a two-constant product: max abs error 4.2e-7 over |f| <= 3e4, tools/experiments/hw_sincos.hip; octaves 1, 2, 4, 5 by the
+// double-angle identities), wave 7 passes the raw features — as six K-octets of 8 values, one octet per pipeline step into a
+// two-slot ring; a step's 48 MFMAs per wave (2 chunks x 8 N-tiles x 3 products) run on the octets encoded during the previous
+// step. Hidden activations return to LDS in the same B layout (relu, unscale, split), so layers 1 and 2 are plain LDS -> MFMA
+// streams. 12 workgroup barriers per 128 samples.
+//
+// K order of layer 0 (what k_pack_ws mirrors): K-octet o = 8 j + w' (step j, producer w') = chunk 2j + w'/4, K-quarter w' % 4, holds
+// values v = 8j .. 8j+7 of producer w's 48-value sequence; w' < 7: feature 4w' + v / 12, octave (v % 12) / 2, sin (even v) / cos
+// (odd v); w' = 7: raw feature v (zero from 27 on).
+//
+// hipcc schedules a region MFMAs first, VALU after; two waves in lockstep would then fight for the matrix pipe and leave it idle
+// together. The instruction stream is therefore laid out by hand: a step is cut into SLOTS of one MFMA plus the VALU / LDS work
+// that should issue in its shadow, with a full scheduling fence after every slot.
 #include "t2n_device.h"
 
 namespace t2n {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef __fp16 hh2 __attribute__((ext_vector_type(2)));
 
-constexpr int kWsNT = 4;                        // N-tiles (32 samples) per group
-constexpr int kWsC0 = 24, kWsC1 = 8, kWsC2 = 8;   // K-chunks (16 values) of layers 0 / 1 / 2
-constexpr int kWsSlot = 4 * kWsNT * 2 * 64;     // uint4 per ring slot: [producer wave][N-tile][part][lane]
-constexpr int kWsH = kWsNT * kWsC1 * 2 * 64;    // uint4 of the hidden-activation tile: [N-tile][chunk][part][lane] (aliases the ring)
-constexpr int kWsW1 = 4 * kWsC1 * 2 * 64;       // [wave][chunk][part][lane]
+constexpr int kWsW = 8;                          // waves per workgroup = 16-unit slices of the hidden layers
+constexpr int kWsT = 8;                          // N-tiles (16 samples) per group
+constexpr int kWsC0 = 12, kWsC1 = 4, kWsC2 = 4;   // K-chunks (32 values) of layers 0 / 1 / 2
+constexpr int kWsSlot = 2 * kWsT * 2 * 64;       // uint4 per ring slot: [chunk of the step][N-tile][part][lane]
+constexpr int kWsH = kWsT * kWsC1 * 2 * 64;      // uint4 of the hidden-activation tile: [N-tile][chunk][part][lane] (aliases the ring)
+constexpr int kWsW1 = kWsW * kWsC1 * 2 * 64;     // [wave][chunk][part][lane]
 constexpr int kWsW2 = kWsC2 * 2 * 64;
-constexpr int kWsBias = 288;                    // floats: [layer][block][h][v] in accumulator order, scaled
-constexpr size_t kWsLds = (size_t)(kWsH + kWsW1 + kWsW2) * 16 + kWsBias * 4;
+constexpr int kWsBias = 288;                     // floats: layer 0 [128], layer 1 [128], layer 2 [32], scaled
+constexpr size_t kWsLds = (size_t)(kWsH + kWsW1 + kWsW2) * 16 + kWsBias * 4 + 16 * 4;   // + the sub-list table
 static_assert(2 * kWsSlot == kWsH, "ring and hidden tile share one region");
-constexpr float kWsRange = 60000.f;             // |activation| beyond this (f16 max 65504) -> exact-path redo
+constexpr float kWsRange = 60000.f;              // |activation| beyond this (f16 max 65504) -> exact-path redo
 
 struct WsArgs {
     const uint4* w0; const uint4* w1; const uint4* w2; const float* bias; const float* inv_scale;   // packed by k_pack_ws
-    const float* feat;            // [rows][32] fp32 feature rows (row = tile * 32 + sample)
+    const float* feat;            // [rows][32] fp32 feature rows (row = tile * 32 + sample), columns >= 27 zero
     const unsigned* counters; unsigned list_cap; int nlists;
-    unsigned tile_hi;             // tiles [0, min(ntiles, tile_hi)) are this kernel's; tile_hi is a multiple of 4
+    unsigned tile_hi;             // 32-sample tiles [0, min(ntiles, tile_hi)) are this kernel's; tile_hi is a multiple of 4
     float4* app_rgb;
     unsigned* range_flag;
     float neg1;                   // -1.0f at run time: x - hi stays an FMA with an f16 operand (v_fma_mix_f32, no convert)
 };
 
-__device__ __forceinline__ f32x16 ws_mfma(uint4 a, uint4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+#define WS_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+#ifdef T2N_PHASE_TIMING
+__device__ unsigned long long g_ws_phase[16];
+#define WS_PHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); phacc[i] += t_ - tph; tph = t_; } while (0)
+#else
+#define WS_PHASE(i) do {} while (0)
+#endif
+
+__device__ __forceinline__ f32x4 ws_mfma(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
 
 // (x0, x1) -> packed hi halves and packed lo halves
@@ -65,58 +86,49 @@ __device__ __forceinline__ void ws_split2(float x0, float x1, float neg1, unsign
     lo = __builtin_bit_cast(unsigned, (hh2)__builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 
-__device__ __forceinline__ f32x16 ws_bias(const float* lb, int m, int h) {
-    const float4* p = reinterpret_cast<const float4*>(lb + (m * 2 + h) * 16);
-    const float4 a = p[0], b = p[1], c = p[2], d = p[3];
-    f32x16 r = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-    return r;
-}
-
-// hipcc schedules a region MFMAs first, dependent-free VALU after (measured on the first version of this kernel: 48 MFMAs
-// back to back, then ~200 encoding instructions with the matrix pipe idle: 1.85 ms per frame). The instruction stream is
-// therefore laid out by hand: the work of a pipeline step is cut into SLOTS of one MFMA plus the VALU / LDS work that should
-// issue in its 32-cycle shadow, and a full scheduling fence after every slot keeps the order as written.
-#define WS_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-#ifdef T2N_PHASE_TIMING
-__device__ unsigned long long g_ws_phase[16];
-#define WS_PHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); phacc[i] += t_ - tph; tph = t_; } while (0)
-#else
-#define WS_PHASE(i) do {} while (0)
-#endif
-
-// 1 / (2 pi) as a two-constant product: t = th + tl carries f / (2 pi) to ~2^-48 relative
-__device__ __forceinline__ void ws_turns(float f, float& th, float& tl) {
-    const float C1 = 0.15915494309189535f;                                   // float(1 / (2 pi))
-    const float C2 = (float)(0.15915494309189533576888 - (double)C1);
-    th = f * C1;
-    tl = fmaf(f, C1, -th) + f * C2;
-}
-
-// Values V, V+1 of the lane's 96-value sequence (see the K order above) as packed hi / lo halves, in three phases of about
-// equal issue time (a transcendental costs ~4 plain issues), one phase per MFMA slot.
+// ---- encoding -------------------------------------------------------------------------------------------------------------------
+// Values V, V+1 of the lane's 48-value sequence as packed hi / lo halves, in three phases of about equal issue time, one phase
+// per slot. RAW (wave 7): the values are the step's eight raw features.
 struct WsUnit { float x0, x1; unsigned hi; };
-template <int V, int PH>
-__device__ __forceinline__ void ws_unit_phase(WsUnit& U, const float (&f)[7], const float (&th)[7], const float (&tl)[7], float neg1, unsigned& hi, unsigned& lo) {
-    constexpr int q = V < 84 ? (V % 12) / 2 : 0;
-    constexpr bool fresh = V < 84 && (q == 0 || q == 3);   // octaves 1, 2, 4, 5 by the double-angle identities from the one before
+struct WsEnc {
+    float f[2][4];           // PE waves: features 4w' .. 4w'+3 of the lane's two samples (passes 0 / 1)
+    float4 r[2][2];          // raw wave: the current octet's eight feature values per pass
+    WsUnit U[2];             // per pass: the unit in flight; between units (sin, cos) of the pass's previous octave
+    unsigned ph[4], pl[4];   // packed halves of the octet being encoded
+    float amax;              // raw wave: running max |feature| (f16 range check)
+};
+
+template <int V, int PH, bool RAW>
+__device__ __forceinline__ void ws_unit_phase(WsUnit& U, const float (&f)[4], const float4 (&r)[2], float neg1, unsigned& hi, unsigned& lo, float& amax) {
+    constexpr int q = (V % 12) / 2;
+    constexpr bool fresh = q == 0 || q == 3;   // octaves 1, 2, 4, 5 from the one before
     if constexpr (PH == 0) {
-        if constexpr (fresh) {
-            constexpr int fi = V / 12;
+        if constexpr (RAW) {
+            constexpr int e = V % 8;
+            const float4 s = r[e / 4];
+            U.x0 = (e % 4) == 0 ? s.x : s.z;
+            U.x1 = (e % 4) == 0 ? s.y : s.w;
+            amax = fmaxf(amax, fmaxf(fabsf(U.x0), fabsf(U.x1)));
+        } else if constexpr (fresh) {
+            // f / (2 pi) as th + tl (two-constant product, ~2^-48 relative), then the fraction of its 2^q multiple: sin / cos take
+            // revolutions and have period 1
+            const float C1 = 0.15915494309189535f;                                   // float(1 / (2 pi))
+            const float C2 = (float)(0.15915494309189533576888 - (double)C1);
             constexpr float sc = (float)(1 << q);
-            U.x1 = fmaf(tl[fi], sc, __builtin_amdgcn_fractf(th[fi] * sc));   // revolutions: sin / cos have period 1
-            U.x0 = __builtin_amdgcn_sinf(U.x1);
-        } else if constexpr (V < 84) {
-            // U still holds (sin, cos) of the previous octave of this sample (units of a pass run in sequence order)
-            const float sn = U.x0, cs = U.x1;
+            const float x = f[V / 12];
+            const float th = x * C1;
+            const float tl = fmaf(x, C1, -th) + x * C2;
+            U.x1 = fmaf(tl, sc, __builtin_amdgcn_fractf(th * sc));
+        } else {
+            const float sn = U.x0, cs = U.x1;   // (sin, cos) of the previous octave of this sample
             U.x0 = 2.f * (sn * cs);
             U.x1 = (cs - sn) * (cs + sn);
-        } else {
-            U.x0 = V < 91 ? f[V < 91 ? V - 84 : 0] : 0.f;
-            U.x1 = V + 1 < 91 ? f[V + 1 < 91 ? V + 1 - 84 : 0] : 0.f;
         }
     } else if constexpr (PH == 1) {
-        if constexpr (fresh) U.x1 = __builtin_amdgcn_cosf(U.x1);
+        if constexpr (!RAW && fresh) {
+            U.x0 = __builtin_amdgcn_sinf(U.x1);
+            U.x1 = __builtin_amdgcn_cosf(U.x1);
+        }
         U.hi = __builtin_bit_cast(unsigned, (hh2)__builtin_amdgcn_cvt_pkrtz(U.x0, U.x1));
     } else {
         const h2v ph = __builtin_bit_cast(h2v, U.hi);
@@ -126,151 +138,128 @@ __device__ __forceinline__ void ws_unit_phase(WsUnit& U, const float (&f)[7], co
     }
 }
 
-struct WsEnc {   // per-lane encoder state of one group: features of the lane's two samples (passes 0 / 1) and their turns
-    float f[2][7], th[2][7], tl[2][7];
-    unsigned ph[8], pl[8];   // packed halves of the chunk being encoded
-    WsUnit U[2];             // per pass: the unit in flight; between units (sin, cos) of the pass's previous octave
-};
-
-// unit I (0..15) of chunk J: pass I / 8, pair I % 8
-template <int J, int I, int PH>
+// unit I (0..7) of octet J: pass I / 4, pair I % 4
+template <int J, int I, int PH, bool RAW>
 __device__ __forceinline__ void ws_enc_phase(WsEnc& E, float neg1) {
-    constexpr int p = I / 8, u = I % 8;
-    ws_unit_phase<16 * J + 2 * u, PH>(E.U[p], E.f[p], E.th[p], E.tl[p], neg1, E.ph[u], E.pl[u]);
+    constexpr int p = I / 4, u = I % 4;
+    ws_unit_phase<8 * J + 2 * u, PH, RAW>(E.U[p], E.f[p], E.r[p], neg1, E.ph[u], E.pl[u], E.amax);
 }
-template <int J, int I>
-__device__ __forceinline__ void ws_enc_unit(WsEnc& E, float neg1) {
-    ws_enc_phase<J, I, 0>(E, neg1); ws_enc_phase<J, I, 1>(E, neg1); ws_enc_phase<J, I, 2>(E, neg1);
-}
-// the four 16-B stores of one pass: [producer wave][N-tile 2p + (lane >> 5)][part][column (lane & 31) + 32 * K-half]
+// the two 16-B stores of one pass: ring [chunk w' / 4][N-tile 4P + (lane >> 4)][part][column (lane & 15) + 16 (w' % 4)]
 template <int P>
-__device__ __forceinline__ void ws_enc_store(const WsEnc& E, uint4* __restrict__ dst /* slot + ((w*NT + lane>>5) * 2) * 64 + (lane & 31) */) {
-    uint4* d = dst + P * 2 * 128;
+__device__ __forceinline__ void ws_enc_store(const WsEnc& E, uint4* __restrict__ dst /* slot + (((w/4)*T + lane>>4) * 2) * 64 + (lane & 15) + 16 (w%4) */) {
+    uint4* d = dst + P * 4 * 128;
     d[0] = make_uint4(E.ph[0], E.ph[1], E.ph[2], E.ph[3]);
-    d[32] = make_uint4(E.ph[4], E.ph[5], E.ph[6], E.ph[7]);
     d[64] = make_uint4(E.pl[0], E.pl[1], E.pl[2], E.pl[3]);
-    d[96] = make_uint4(E.pl[4], E.pl[5], E.pl[6], E.pl[7]);
 }
-
-template <int J, int I0, int I1>
-__device__ __forceinline__ void ws_enc_range(WsEnc& E, float neg1) {
-    if constexpr (I0 < I1) { ws_enc_unit<J, I0>(E, neg1); ws_enc_range<J, I0 + 1, I1>(E, neg1); }
+template <int J, bool RAW>
+__device__ __forceinline__ void ws_enc_octet(WsEnc& E, uint4* __restrict__ dst, float neg1) {   // unscheduled form (prologue)
+#define WS_U(I) ws_enc_phase<J, I, 0, RAW>(E, neg1); ws_enc_phase<J, I, 1, RAW>(E, neg1); ws_enc_phase<J, I, 2, RAW>(E, neg1)
+    WS_U(0); WS_U(1); WS_U(2); WS_U(3); ws_enc_store<0>(E, dst);
+    WS_U(4); WS_U(5); WS_U(6); WS_U(7); ws_enc_store<1>(E, dst);
+#undef WS_U
 }
-
-struct WsB { uint4 h[2][kWsNT], l[2][kWsNT]; };   // B operands of two chunks in flight
-
-// slot M (0..47) of layer-0 step J: MFMA M (chunk M / 12 of the step = producer wave w', product (M % 12) / 4, N-tile M % 4), one
-// B-operand read of the next chunk, and — every third slot — one encoding unit of chunk J + 1
-template <int J, int M>
-__device__ __forceinline__ void ws_l0_slots(f32x16 (&acc)[kWsNT], const uint4 (&A0)[kWsC0][2], WsB& B, const uint4* __restrict__ cur,
-                                            uint4* __restrict__ dst, WsEnc& E, float neg1) {
-    if constexpr (M < 48) {
-        constexpr int k = M / 12, m = M % 12, t = m & 3, prod = m >> 2;
-        acc[t] = ws_mfma(A0[6 * k + J][prod == 2 ? 1 : 0], prod == 1 ? B.l[k & 1][t] : B.h[k & 1][t], acc[t]);
-        if constexpr (k < 3 && m < 8) {
-            if constexpr (m < 4) B.h[(k + 1) & 1][m] = cur[(k + 1) * kWsNT * 128 + m * 128];
-            else B.l[(k + 1) & 1][m - 4] = cur[(k + 1) * kWsNT * 128 + (m - 4) * 128 + 64];
-        }
-        if constexpr (J < 5) {
-            // unit 0 ran before slot 0; unit i = 1..15 takes slots 3(i-1) .. 3(i-1)+2, one phase each; a pass is stored right after
-            // its last unit (pass 0: units 0..7 -> slot 21, pass 1: slot 45)
-            if constexpr (M / 3 + 1 < 16) ws_enc_phase<J + 1, M / 3 + 1, M % 3>(E, neg1);
-            if constexpr (M == 21) ws_enc_store<0>(E, dst);
-            if constexpr (M == 45) ws_enc_store<1>(E, dst);
-        }
-        WS_FENCE();
-        ws_l0_slots<J, M + 1>(acc, A0, B, cur, dst, E, neg1);
+// raw wave: the eight raw features of octet J for both passes (columns 8J .. 8J+7 of the feature rows; zero from column 27 on)
+template <int J>
+__device__ __forceinline__ void ws_raw_load(float4 (&d)[2][2], const float* __restrict__ row0, const float* __restrict__ row1) {
+    if constexpr (J < 4) {
+        const float4* p0 = reinterpret_cast<const float4*>(row0 + 8 * J);
+        const float4* p1 = reinterpret_cast<const float4*>(row1 + 8 * J);
+        d[0][0] = p0[0]; d[0][1] = p0[1]; d[1][0] = p1[0]; d[1][1] = p1[1];
+    } else {
+        d[0][0] = d[0][1] = d[1][0] = d[1][1] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
-template <int J>
-__device__ __forceinline__ void ws_l0_step(f32x16 (&acc)[kWsNT], const uint4 (&A0)[kWsC0][2], uint4* __restrict__ ring, int w, int lane,
-                                           WsEnc& E, float neg1) {
-    const uint4* __restrict__ cur = ring + (J & 1) * kWsSlot + lane;
-    uint4* __restrict__ dst = ring + ((J + 1) & 1) * kWsSlot + ((w * kWsNT + (lane >> 5)) * 2) * 64 + (lane & 31);
-    WsB B;
+// ---- MFMA streams ---------------------------------------------------------------------------------------------------------------
+struct WsB { uint4 h[2][4], l[4]; };   // B operands: hi parts of two half-chunks (4 N-tiles each) in flight, lo parts of one
+
+// Slot M (0..47) of a two-chunk step: chunk M / 24, N-tile half (M % 24) / 12, product (M % 12) / 4 (hi*hi, lo*hi, hi*lo), tile
+// 4 half + M % 4. B operands come from LDS at b + chunk * SC + tile * ST (+ 64: lo part): the hi parts one half-chunk ahead, the
+// lo parts during the half's first slots (their product comes last) — 48 operand registers, not 64: a spill anywhere between
+// the issue of the next group's global loads and their use makes the wave wait for those loads (vmcnt retires in order). A
+// operands from the register file (layer 0) or from LDS one chunk ahead (layer 1). ENC: every second slot carries one encoding
+// phase of octet JN.
+template <int M, int SC, int ST, bool A_LDS, bool ENC, int JN, bool RAW, class AOps>
+__device__ __forceinline__ void ws_slots(f32x4 (&acc)[kWsT], AOps& A, WsB& B, const uint4* __restrict__ b, WsEnc& E, uint4* __restrict__ dst, float neg1) {
+    if constexpr (M < 48) {
+        constexpr int c = M / 24, hf = (M % 24) / 12, prod = (M % 12) / 4, t = M % 4, hb = (M / 12) & 1, m = M % 12;
+        acc[4 * hf + t] = ws_mfma(prod == 1 ? A.lo(c) : A.hi(c), prod == 2 ? B.l[t] : B.h[hb][t], acc[4 * hf + t]);
+        if constexpr (m < 4) {
+            B.l[m] = b[c * SC + (4 * hf + m) * ST + 64];   // this half's lo part (the previous half's last product issued before slot 0)
+            if constexpr (M < 36) {
+                constexpr int nh = M / 12 + 1, nc = nh / 2, nhf = nh % 2;
+                B.h[nh & 1][m] = b[nc * SC + (4 * nhf + m) * ST];
+            }
+        }
+        if constexpr (A_LDS && M == 8) A.fetch(1);
+        if constexpr (ENC) {
+            if constexpr (M % 2 == 0) ws_enc_phase<JN, (M / 2) / 3, (M / 2) % 3, RAW>(E, neg1);
+            if constexpr (M == 23) ws_enc_store<0>(E, dst);
+            if constexpr (M == 47) ws_enc_store<1>(E, dst);
+        }
+        WS_FENCE();
+        ws_slots<M + 1, SC, ST, A_LDS, ENC, JN, RAW>(acc, A, B, b, E, dst, neg1);
+    }
+}
+template <int SC, int ST>
+__device__ __forceinline__ void ws_first_half(WsB& B, const uint4* __restrict__ b) {
 #pragma unroll
-    for (int t = 0; t < kWsNT; ++t) { B.h[0][t] = cur[t * 128]; B.l[0][t] = cur[t * 128 + 64]; }
+    for (int t = 0; t < 4; ++t) B.h[0][t] = b[t * ST];
+}
+
+template <int J2>
+struct WsA0 {   // layer-0 A operands of one step: chunks J2, J2+1 of the wave's register-resident slice
+    const uint4 (&a)[kWsC0][2];
+    __device__ __forceinline__ uint4 hi(int c) const { return a[J2 + c][0]; }
+    __device__ __forceinline__ uint4 lo(int c) const { return a[J2 + c][1]; }
+    __device__ __forceinline__ void fetch(int) {}
+};
+struct WsA1 {   // layer-1 / layer-2 A operands from LDS: two chunks per step
+    const uint4* __restrict__ p;   // slice + first chunk of the step + lane; chunk stride 128
+    uint4 h_[2], l_[2];
+    __device__ __forceinline__ uint4 hi(int c) const { return h_[c]; }
+    __device__ __forceinline__ uint4 lo(int c) const { return l_[c]; }
+    __device__ __forceinline__ void fetch(int c) { h_[c] = p[c * 128]; l_[c] = p[c * 128 + 64]; }
+};
+
+template <int J, bool RAW>
+__device__ __forceinline__ void ws_l0_step(f32x4 (&acc)[kWsT], const uint4 (&A0)[kWsC0][2], uint4* __restrict__ ring, int w, int lane, WsEnc& E,
+                                           const float* __restrict__ row0, const float* __restrict__ row1, float neg1) {
+    const uint4* __restrict__ cur = ring + (J & 1) * kWsSlot + lane;
+    uint4* __restrict__ dst = ring + ((J + 1) & 1) * kWsSlot + (((w >> 2) * kWsT + (lane >> 4)) * 2) * 64 + (lane & 15) + 16 * (w & 3);
+    WsB B;
+    ws_first_half<kWsT * 128, 128>(B, cur);
+    if constexpr (RAW && J < 5) ws_raw_load<J + 1>(E.r, row0, row1);   // same cache lines as octet 0: vector-L1 hits
     WS_FENCE();
-    if constexpr (J < 5) { ws_enc_unit<J + 1, 0>(E, neg1); WS_FENCE(); }   // covers the first reads' LDS latency
-    ws_l0_slots<J, 0>(acc, A0, B, cur, dst, E, neg1);
+    WsA0<2 * J> A{A0};
+    ws_slots<0, kWsT * 128, 128, false, (J < 5), J + 1, RAW>(acc, A, B, cur, E, dst, neg1);
     __syncthreads();
 }
 
-// relu(acc * inv) of units 32w + 8g + 4h .. +3 of one N-tile -> H in B layout (chunk 2w + (g >> 1), K-half g & 1, elements
-// 4h .. 4h+3): one 8-B store per part. Three phases (pair 0-1, pair 2-3, range check + stores) so that a stage can spread it.
-struct WsQuad { float m0, m1; uint2 hi, lo; };
-template <int G, int PH>
-__device__ __forceinline__ void ws_quad_phase(WsQuad& Q, const f32x16& acc, float inv, uint2* __restrict__ H2t /* tile base + lane part */, int w, float neg1, float& amax) {
-    if constexpr (PH < 2) {
-        const float v0 = fmaxf(acc[4 * G + 2 * PH] * inv, 0.f), v1 = fmaxf(acc[4 * G + 2 * PH + 1] * inv, 0.f);
-        if constexpr (PH == 0) { Q.m0 = fmaxf(v0, v1); ws_split2(v0, v1, neg1, Q.hi.x, Q.lo.x); }
-        else { Q.m1 = fmaxf(v0, v1); ws_split2(v0, v1, neg1, Q.hi.y, Q.lo.y); }
-    } else {
-        amax = fmaxf(amax, fmaxf(Q.m0, Q.m1));
-        const int u4 = ((2 * w + (G >> 1)) * 2) * 64 + 32 * (G & 1);
-        H2t[(size_t)u4 * 2] = Q.hi;
-        H2t[(size_t)(u4 + 64) * 2] = Q.lo;
-    }
-}
-template <int G>
-__device__ __forceinline__ float ws_store_quad(const f32x16& acc, float inv, uint2* __restrict__ H2t, int w, float neg1, float amax) {
-    WsQuad Q;
-    ws_quad_phase<G, 0>(Q, acc, inv, H2t, w, neg1, amax);
-    ws_quad_phase<G, 1>(Q, acc, inv, H2t, w, neg1, amax);
-    ws_quad_phase<G, 2>(Q, acc, inv, H2t, w, neg1, amax);
+// relu(acc * inv) of the lane's four units 16w + 4 (lane >> 4) .. +3 of one N-tile -> H in B layout: chunk w / 2, K-quarter
+// 2 (w & 1) + (lane >> 5), elements 4 ((lane >> 4) & 1) .. +3: one 8-B store per part
+__device__ __forceinline__ float ws_store_quad(const f32x4& acc, float inv, uint2* __restrict__ H2t /* H as uint2, tile + lane part */, float neg1, float amax) {
+    const float v0 = fmaxf(acc[0] * inv, 0.f), v1 = fmaxf(acc[1] * inv, 0.f), v2 = fmaxf(acc[2] * inv, 0.f), v3 = fmaxf(acc[3] * inv, 0.f);
+    amax = fmaxf(fmaxf(v0, v1), fmaxf(amax, fmaxf(v2, v3)));
+    uint2 hi, lo;
+    ws_split2(v0, v1, neg1, hi.x, lo.x);
+    ws_split2(v2, v3, neg1, hi.y, lo.y);
+    H2t[0] = hi;
+    H2t[128] = lo;   // part 1: + 64 uint4
     return amax;
 }
 
-struct WsL1 { uint4 ah[2], al[2], bh[2], bl[2]; };
-
-// slot M (0..23) of the layer-1 stage of N-tile T: MFMA (chunk M / 3, product M % 3) on acc[T], operand reads of the next chunk,
-// and in its shadow the hidden-activation stores of the neighbouring tiles: h0 of tile T + 1 (still in acc[T + 1]) and h1 of
-// tile T - 1 (now in acc[T - 1])
-template <int T, int M>
-__device__ __forceinline__ void ws_l1_slots(f32x16 (&acc)[kWsNT], WsL1& O, WsQuad& Q, const uint4* __restrict__ w1 /* W1 + w slice + lane */,
-                                            const uint4* __restrict__ hb /* H tile T + lane */, uint2* __restrict__ H2 /* H as uint2 + lane part */,
-                                            int w, float inv0, float inv1, float neg1, float& amax) {
-    if constexpr (M < 24) {
-        constexpr int c = M / 3, prod = M % 3;
-        acc[T] = ws_mfma(prod == 2 ? O.al[c & 1] : O.ah[c & 1], prod == 1 ? O.bl[c & 1] : O.bh[c & 1], acc[T]);
-        if constexpr (c < 7) {
-            if constexpr (prod == 0) { O.ah[(c + 1) & 1] = w1[(c + 1) * 128]; O.bh[(c + 1) & 1] = hb[(c + 1) * 128]; }
-            if constexpr (prod == 1) { O.al[(c + 1) & 1] = w1[(c + 1) * 128 + 64]; O.bl[(c + 1) & 1] = hb[(c + 1) * 128 + 64]; }
-        }
-        // quad g of the h0 store in slots 6g .. 6g+2, of the h1 store in slots 6g+3 .. 6g+5
-        if constexpr (T + 1 < kWsNT && M % 6 < 3) ws_quad_phase<M / 6, M % 6>(Q, acc[T + 1 < kWsNT ? T + 1 : T], inv0, H2 + (size_t)(T + 1) * kWsC1 * 256, w, neg1, amax);
-        if constexpr (T >= 1 && M % 6 >= 3) ws_quad_phase<M / 6, M % 6 - 3>(Q, acc[T >= 1 ? T - 1 : T], inv1, H2 + (size_t)(T - 1) * kWsC1 * 256, w, neg1, amax);
-        WS_FENCE();
-        ws_l1_slots<T, M + 1>(acc, O, Q, w1, hb, H2, w, inv0, inv1, neg1, amax);
-    }
-}
-
-template <int T>
-__device__ __forceinline__ void ws_l1_stage(f32x16 (&acc)[kWsNT], const uint4* __restrict__ W1, uint4* __restrict__ H, const float* __restrict__ LB,
-                                            int w, int lane, float inv0, float inv1, float neg1, float& amax) {
-    const uint4* __restrict__ w1 = W1 + (w * kWsC1 * 2) * 64 + lane;
-    const uint4* __restrict__ hb = H + (T * kWsC1 * 2) * 64 + lane;
-    uint2* __restrict__ H2 = reinterpret_cast<uint2*>(H) + (size_t)(lane & 31) * 2 + (lane >> 5);
-    WsL1 O;
-    WsQuad Q;
-    O.ah[0] = w1[0]; O.al[0] = w1[64]; O.bh[0] = hb[0]; O.bl[0] = hb[64];
-    acc[T] = ws_bias(LB + 128, w, lane >> 5);   // acc[T] held layer 0 until its h0 store one stage ago
-    WS_FENCE();
-    ws_l1_slots<T, 0>(acc, O, Q, w1, hb, H2, w, inv0, inv1, neg1, amax);
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256, 1) void k_mlp_ws(const WsArgs a) {
+__global__ __launch_bounds__(512) void k_mlp_ws(const WsArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     uint4* __restrict__ RH = lds;                       // ring slots 0 / 1 during layer 0, hidden tile afterwards
     uint4* __restrict__ W1 = lds + kWsH;
     uint4* __restrict__ W2 = W1 + kWsW1;
     float* __restrict__ LB = reinterpret_cast<float*>(W2 + kWsW2);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int n = lane & 31, h = lane >> 5;
+    unsigned* __restrict__ LT = reinterpret_cast<unsigned*>(LB + kWsBias);   // [0..7] inclusive tile prefix of the sub-lists, [8..15] their counts
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, rq = lane >> 4;
 
-    // tile enumeration over the appearance sub-lists (as k_shade): tile -> (list, offset)
+    // tile enumeration over the appearance sub-lists (as k_shade): 32-sample tile -> (list, offset)
     unsigned cnt_l = 0;
     if (lane < a.nlists) {
         cnt_l = a.counters[lane * kCounterStride];
@@ -284,8 +273,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_ws(const WsArgs a) {
     }
     unsigned ntiles = __shfl(incl, a.nlists - 1);
     if (ntiles > a.tile_hi) ntiles = a.tile_hi;
-    const unsigned ngroups = (ntiles + kWsNT - 1) / kWsNT;
+    const unsigned ngroups = (ntiles + 3u) / 4u;
     if (blockIdx.x >= ngroups) return;
+    if (tid < 8) { LT[tid] = tid < a.nlists ? incl : 0xffffffffu; LT[8 + tid] = cnt_l; }   // kept in LDS: no live registers across the loop
 
     // stationary operands: layer 0 in registers, layers 1 / 2 and the biases in LDS
     uint4 A0[kWsC0][2];
@@ -294,116 +284,141 @@ __global__ __launch_bounds__(256, 1) void k_mlp_ws(const WsArgs a) {
         A0[c][0] = a.w0[((size_t)(w * kWsC0 + c) * 2) * 64 + lane];
         A0[c][1] = a.w0[((size_t)(w * kWsC0 + c) * 2 + 1) * 64 + lane];
     }
-    for (int i = tid; i < kWsW1; i += 256) W1[i] = a.w1[i];
-    for (int i = tid; i < kWsW2; i += 256) W2[i] = a.w2[i];
-    for (int i = tid; i < kWsBias; i += 256) LB[i] = a.bias[i];
+    for (int i = tid; i < kWsW1; i += 512) W1[i] = a.w1[i];
+    for (int i = tid; i < kWsW2; i += 512) W2[i] = a.w2[i];
+    for (int i = tid; i < kWsBias; i += 512) LB[i] = a.bias[i];
     const float inv0 = a.inv_scale[0], inv1 = a.inv_scale[1], inv2 = a.inv_scale[2];
     const float neg1 = a.neg1;
+    const bool raw = w == 7;
     float amax = 0.f;
 
-    auto load_feat = [&](unsigned g, float (&f0)[7], float (&f1)[7]) {
-        // row = tile * 32 + sample = 128 g + 64 p + lane; tiles past the end re-read the last tile's rows (their results are
-        // never stored): no predication, 14 plain loads
-        const unsigned last = ntiles * 32u - 1u;
-        unsigned r0 = g * 128u + (unsigned)lane, r1 = r0 + 64u;
-        r0 = r0 < last ? r0 : last; r1 = r1 < last ? r1 : last;
-        const float* p0 = a.feat + (size_t)r0 * 32 + 7 * w;
-        const float* p1 = a.feat + (size_t)r1 * 32 + 7 * w;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) { f0[i] = p0[i]; f1[i] = p1[i]; }
+    // feature rows of the lane's two samples of group g (row = 128 g + 64 p + lane; tiles past the end re-read the last tile's rows:
+    // their results are never stored)
+    const unsigned last = ntiles * 32u - 1u;
+    auto rows_of = [&](unsigned g, const float*& r0, const float*& r1) {
+        unsigned i0 = g * 128u + (unsigned)lane, i1 = i0 + 64u;
+        i0 = i0 < last ? i0 : last; i1 = i1 < last ? i1 : last;
+        r0 = a.feat + (size_t)i0 * 32; r1 = a.feat + (size_t)i1 * 32;
     };
-    float nf0[7], nf1[7];   // the next group's feature rows, loaded one group ahead
-    load_feat(blockIdx.x, nf0, nf1);
+    // the next group's inputs, loaded one group ahead: PE waves: four features per pass (nx[0], nx[1]); raw wave: octet 0
+    float4 nx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // two parts (the register allocator spills a four-register-tuple prefetch that lives across layer 1 or the h1 store, and a
+    // spill waits for the load): part 0 = PE features / raw pass 0, part 1 = raw pass 1
+    auto prefetch = [&](unsigned g, int part) {
+        const float *r0, *r1;
+        rows_of(g, r0, r1);
+        if (!raw) { if (part == 0) { nx[0] = *reinterpret_cast<const float4*>(r0 + 4 * w); nx[1] = *reinterpret_cast<const float4*>(r1 + 4 * w); } }
+        else if (part == 0) { const float4* p0 = reinterpret_cast<const float4*>(r0); nx[0] = p0[0]; nx[2] = p0[1]; }
+        else { const float4* p1 = reinterpret_cast<const float4*>(r1); nx[1] = p1[0]; nx[3] = p1[1]; }
+    };
+    prefetch(blockIdx.x, 0);
+    prefetch(blockIdx.x, 1);
     __syncthreads();   // W1 / W2 / bias visible
-    uint2* __restrict__ H2l = reinterpret_cast<uint2*>(RH) + (size_t)n * 2 + h;
-
+    uint2* __restrict__ H2l = reinterpret_cast<uint2*>(RH) + (size_t)((((w >> 1) * 2) * 64 + n + 16 * (2 * (w & 1) + (rq >> 1))) * 2 + (rq & 1));
 #ifdef T2N_PHASE_TIMING
     unsigned long long phacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tph = __builtin_amdgcn_s_memtime();
 #endif
+
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x) {
         WS_PHASE(15);
         WsEnc E;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            E.f[0][i] = nf0[i]; E.f[1][i] = nf1[i];
-            amax = fmaxf(amax, fmaxf(fabsf(nf0[i]), fabsf(nf1[i])));
-            ws_turns(nf0[i], E.th[0][i], E.tl[0][i]);
-            ws_turns(nf1[i], E.th[1][i], E.tl[1][i]);
-        }
-        // ---- layer 0: chunk 0 encoded up front, then 6 steps (step j multiplies chunks {6w' + j}, encodes chunk j + 1) ---------
+        E.amax = amax;
+        E.f[0][0] = nx[0].x; E.f[0][1] = nx[0].y; E.f[0][2] = nx[0].z; E.f[0][3] = nx[0].w;
+        E.f[1][0] = nx[1].x; E.f[1][1] = nx[1].y; E.f[1][2] = nx[1].z; E.f[1][3] = nx[1].w;
+        E.r[0][0] = nx[0]; E.r[0][1] = nx[2]; E.r[1][0] = nx[1]; E.r[1][1] = nx[3];
+        const float *row0, *row1;
+        rows_of(g, row0, row1);
+        // ---- layer 0: octet 0 encoded up front, then 6 steps (step j multiplies chunks 2j, 2j+1 and encodes octet j + 1) -----------
+        f32x4 acc[kWsT];
         {
-            uint4* __restrict__ dst = RH + ((w * kWsNT + h) * 2) * 64 + n;
-            ws_enc_range<0, 0, 8>(E, neg1); ws_enc_store<0>(E, dst);
-            ws_enc_range<0, 8, 16>(E, neg1); ws_enc_store<1>(E, dst);
-        }
-        f32x16 acc[kWsNT];
+            const float4 b = *reinterpret_cast<const float4*>(LB + 16 * w + 4 * rq);
 #pragma unroll
-        for (int t = 0; t < kWsNT; ++t) acc[t] = ws_bias(LB, w, h);
+            for (int t = 0; t < kWsT; ++t) { acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w; }
+        }
+        uint4* __restrict__ dst0 = RH + (((w >> 2) * kWsT + rq) * 2) * 64 + n + 16 * (w & 3);
+        if (raw) ws_enc_octet<0, true>(E, dst0, neg1);
+        else ws_enc_octet<0, false>(E, dst0, neg1);
         __syncthreads();
         WS_PHASE(0);
-        ws_l0_step<0>(acc, A0, RH, w, lane, E, neg1);
-        WS_PHASE(1);
-        ws_l0_step<1>(acc, A0, RH, w, lane, E, neg1);
-        ws_l0_step<2>(acc, A0, RH, w, lane, E, neg1);
-        ws_l0_step<3>(acc, A0, RH, w, lane, E, neg1);
-        ws_l0_step<4>(acc, A0, RH, w, lane, E, neg1);
-        WS_PHASE(2);
-        ws_l0_step<5>(acc, A0, RH, w, lane, E, neg1);
-        WS_PHASE(3);
-        // the next group's feature rows: in flight under layers 1 and 2
-        const unsigned gn = g + gridDim.x;
-        load_feat(gn < ngroups ? gn : g, nf0, nf1);
-        // ---- layers 1 and the hidden-activation stores, one N-tile per stage ------------------------------------------------------
-        // (every wave passed the last ring read at the barrier that ended step 5; h1 of tile t overwrites h0 of tile t one stage
-        // after every wave finished reading it)
-        amax = ws_store_quad<0>(acc[0], inv0, H2l, w, neg1, amax);
-        amax = ws_store_quad<1>(acc[0], inv0, H2l, w, neg1, amax);
-        amax = ws_store_quad<2>(acc[0], inv0, H2l, w, neg1, amax);
-        amax = ws_store_quad<3>(acc[0], inv0, H2l, w, neg1, amax);
-        __syncthreads();
-        WS_PHASE(4);
-        ws_l1_stage<0>(acc, W1, RH, LB, w, lane, inv0, inv1, neg1, amax);
-        WS_PHASE(5);
-        ws_l1_stage<1>(acc, W1, RH, LB, w, lane, inv0, inv1, neg1, amax);
-        ws_l1_stage<2>(acc, W1, RH, LB, w, lane, inv0, inv1, neg1, amax);
-        WS_PHASE(6);
-        ws_l1_stage<3>(acc, W1, RH, LB, w, lane, inv0, inv1, neg1, amax);
-        WS_PHASE(7);
-        {
-            uint2* __restrict__ H2t = H2l + (size_t)3 * kWsC1 * 256;
-            amax = ws_store_quad<0>(acc[3], inv1, H2t, w, neg1, amax);
-            amax = ws_store_quad<1>(acc[3], inv1, H2t, w, neg1, amax);
-            amax = ws_store_quad<2>(acc[3], inv1, H2t, w, neg1, amax);
-            amax = ws_store_quad<3>(acc[3], inv1, H2t, w, neg1, amax);
+        if (raw) {
+            ws_l0_step<0, true>(acc, A0, RH, w, lane, E, row0, row1, neg1);
+            ws_l0_step<1, true>(acc, A0, RH, w, lane, E, row0, row1, neg1);
+            ws_l0_step<2, true>(acc, A0, RH, w, lane, E, row0, row1, neg1);
+            ws_l0_step<3, true>(acc, A0, RH, w, lane, E, row0, row1, neg1);
+            ws_l0_step<4, true>(acc, A0, RH, w, lane, E, row0, row1, neg1);
+        } else {
+            ws_l0_step<0, false>(acc, A0, RH, w, lane, E, row0, row1, neg1);
+            ws_l0_step<1, false>(acc, A0, RH, w, lane, E, row0, row1, neg1);
+            ws_l0_step<2, false>(acc, A0, RH, w, lane, E, row0, row1, neg1);
+            ws_l0_step<3, false>(acc, A0, RH, w, lane, E, row0, row1, neg1);
+            ws_l0_step<4, false>(acc, A0, RH, w, lane, E, row0, row1, neg1);
         }
+        WS_PHASE(1);
+        ws_l0_step<5, false>(acc, A0, RH, w, lane, E, row0, row1, neg1);
+        WS_PHASE(2);
+        amax = E.amax;
+        // ---- h0 -> LDS (every wave passed the last ring read at the barrier that ended step 5) ------------------------------------------
+#pragma unroll
+        for (int t = 0; t < kWsT; ++t) amax = ws_store_quad(acc[t], inv0, H2l + (size_t)t * kWsC1 * 256, neg1, amax);
         __syncthreads();
-        WS_PHASE(8);
-        // ---- layer 2: wave w finishes N-tile w (three independent product chains) -----------------------------------------
+        WS_PHASE(3);
+        // ---- layer 1: two steps of two chunks, A operands from the wave's LDS slice ------------------------------------------------------
         {
-            f32x16 c0 = ws_bias(LB + 256, 0, h), c1 = {0}, c2 = {0};
+            const float4 b = *reinterpret_cast<const float4*>(LB + 128 + 16 * w + 4 * rq);
+#pragma unroll
+            for (int t = 0; t < kWsT; ++t) { acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w; }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const uint4* __restrict__ hb = RH + (2 * st * 2) * 64 + lane;
+            WsA1 A{W1 + ((w * kWsC1 + 2 * st) * 2) * 64 + lane};
+            WsB B;
+            ws_first_half<128, kWsC1 * 128>(B, hb);
+            A.fetch(0);
+            WS_FENCE();
+            ws_slots<0, 128, kWsC1 * 128, true, false, 0, false>(acc, A, B, hb, E, dst0, neg1);
+        }
+        __syncthreads();   // h0 reads done
+        WS_PHASE(4);
+        // the next group's inputs: in flight under the h1 store and layer 2 (issued here, not before layer 1: the layer-1 stream
+        // leaves no registers for them, and a spill would wait for the loads)
+        const unsigned gn = g + gridDim.x < ngroups ? g + gridDim.x : g;
+        prefetch(gn, 0);
+#pragma unroll
+        for (int t = 0; t < kWsT; ++t) amax = ws_store_quad(acc[t], inv1, H2l + (size_t)t * kWsC1 * 256, neg1, amax);
+        __syncthreads();
+        WS_PHASE(5);
+        prefetch(gn, 1);
+        // ---- layer 2: wave w finishes N-tile w (three independent product chains) -----------------------------------------------------------
+        {
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
+            if (rq == 0) { const float4 b = *reinterpret_cast<const float4*>(LB + 256); c0[0] = b.x; c0[1] = b.y; c0[2] = b.z; c0[3] = b.w; }
             const uint4* __restrict__ w2 = W2 + lane;
             const uint4* __restrict__ hb = RH + (w * kWsC1 * 2) * 64 + lane;
-            uint4 ah[3], al[3], bh[3], bl[3];   // operands of three chunks in flight
+            uint4 ah[kWsC2], al[kWsC2], bh[kWsC2], bl[kWsC2];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) { ah[c] = w2[c * 128]; al[c] = w2[c * 128 + 64]; bh[c] = hb[c * 128]; bl[c] = hb[c * 128 + 64]; }
-            WS_FENCE();
+            for (int c = 0; c < kWsC2; ++c) { ah[c] = w2[c * 128]; al[c] = w2[c * 128 + 64]; bh[c] = hb[c * 128]; bl[c] = hb[c * 128 + 64]; }
 #pragma unroll
             for (int c = 0; c < kWsC2; ++c) {
-                if (c + 2 < kWsC2) { ah[(c + 2) % 3] = w2[(c + 2) * 128]; al[(c + 2) % 3] = w2[(c + 2) * 128 + 64]; bh[(c + 2) % 3] = hb[(c + 2) * 128]; bl[(c + 2) % 3] = hb[(c + 2) * 128 + 64]; }
-                c0 = ws_mfma(ah[c % 3], bh[c % 3], c0);
-                c1 = ws_mfma(ah[c % 3], bl[c % 3], c1);
-                c2 = ws_mfma(al[c % 3], bh[c % 3], c2);
-                WS_FENCE();
+                c0 = ws_mfma(ah[c], bh[c], c0);
+                c1 = ws_mfma(ah[c], bl[c], c1);
+                c2 = ws_mfma(al[c], bh[c], c2);
             }
-            const unsigned tile = g * kWsNT + (unsigned)w;
+            const unsigned tile = g * 4u + (unsigned)(w >> 1);
             if (tile < ntiles) {
-                const int li = (int)__popcll(__ballot((lane < a.nlists) & (incl <= tile)));
-                const unsigned before = li ? __shfl(incl, li - 1) : 0u;
+                const uint4 i0 = *reinterpret_cast<const uint4*>(LT), i1 = *reinterpret_cast<const uint4*>(LT + 4);
+                const unsigned pre[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+                int li = 0;
+                unsigned before = 0u;
+#pragma unroll
+                for (int l = 0; l < 8; ++l) if (pre[l] <= tile) { li = l + 1; before = pre[l]; }
                 const unsigned lbase = (unsigned)li * a.list_cap;
-                const unsigned idx = lbase + (tile - before) * 32u + (unsigned)n;
-                const unsigned count = lbase + __shfl(cnt_l, li);
-                if (h == 0 && idx < count) {
+                const unsigned idx = lbase + (tile - before) * 32u + 16u * (unsigned)(w & 1) + (unsigned)n;
+                const unsigned count = lbase + LT[8 + li];
+                if (rq == 0 && idx < count) {   // output rows 0..2 live in registers 0..2 of lanes 0..15
                     const float r = ((c0[0] + c1[0]) + c2[0]) * inv2, gg = ((c0[1] + c1[1]) + c2[1]) * inv2, b = ((c0[2] + c1[2]) + c2[2]) * inv2;
                     // sigmoid by v_exp_f32 / v_rcp_f32 (1 ulp each: ~2e-7 absolute on a value in (0, 1))
                     a.app_rgb[idx] = make_float4(__builtin_amdgcn_rcpf(1.f + __expf(-r)), __builtin_amdgcn_rcpf(1.f + __expf(-gg)),
@@ -411,9 +426,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_ws(const WsArgs a) {
                 }
             }
         }
-        WS_PHASE(9);
+        WS_PHASE(6);
         __syncthreads();   // hidden-tile reads done before the next group's ring writes
-        WS_PHASE(10);
+        WS_PHASE(7);
     }
 #ifdef T2N_PHASE_TIMING
     if (tid == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_ws_phase[i], phacc[i]);
@@ -464,69 +479,63 @@ __device__ __forceinline__ unsigned ws_pack2(float x0, float x1, int part) {
     return __builtin_bit_cast(unsigned, r);
 }
 
-// reference column of layer-0 K index (chunk c, half hh, element e); -1: zero padding
-__host__ __device__ inline int ws_l0_col(int c, int hh, int e) {
-    const int wp = c / 6, j = c % 6, v = 16 * j + 8 * hh + e;
-    if (v < 84) {
-        const int F = 7 * wp + v / 12, r = v % 12, q = r >> 1, sc = r & 1;
-        return F < 27 ? (sc ? 189 : 27) + F * 6 + q : -1;
-    }
-    if (v < 91) { const int F = 7 * wp + v - 84; return F < 27 ? F : -1; }
-    return -1;
+// reference column (models/tensorBase.py:11-17,101-104: [features | sin block | cos block], feature-major, octave-minor) of
+// layer-0 K index (chunk cc, K-quarter kq, element e); -1: zero padding
+__host__ __device__ inline int ws_l0_col(int cc, int kq, int e) {
+    const int o = 4 * cc + kq, j = o / 8, wp = o % 8, v = 8 * j + e;
+    if (wp == 7) return v < 27 ? v : -1;
+    const int F = 4 * wp + v / 12, r = v % 12, q = r >> 1, sc = r & 1;
+    return F < 27 ? (sc ? 189 : 27) + F * 6 + q : -1;
 }
 
 __global__ __launch_bounds__(256) void k_pack_ws(const WsPackArgs a) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n0 = 4 * kWsC0 * 2 * 64, n1 = kWsW1, n2 = kWsW2;
+    const int n0 = kWsW * kWsC0 * 2 * 64, n1 = kWsW1, n2 = kWsW2;
     const float s0 = a.scales[0], s1 = a.scales[1], s2 = a.scales[2];
     int g = gid;
-    if (g < n0) {
+    if (g < n0) {   // [wave][chunk][part][lane]: unit 16 wave + (lane & 15), K-quarter lane >> 4
         const int lane = g & 63, part = (g >> 6) & 1, c = (g >> 7) % kWsC0, w = (g >> 7) / kWsC0;
-        const int unit = 32 * w + (lane & 31), hh = lane >> 5;
+        const int unit = 16 * w + (lane & 15), kq = lane >> 4;
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const int col = ws_l0_col(c, hh, e); x[e] = col >= 0 ? a.w0[unit * 351 + col] * s0 : 0.f; }
+        for (int e = 0; e < 8; ++e) { const int col = ws_l0_col(c, kq, e); x[e] = col >= 0 ? a.w0[unit * 351 + col] * s0 : 0.f; }
         a.w0p[g] = make_uint4(ws_pack2(x[0], x[1], part), ws_pack2(x[2], x[3], part), ws_pack2(x[4], x[5], part), ws_pack2(x[6], x[7], part));
         return;
     }
     g -= n0;
     if (g < n1) {
         const int lane = g & 63, part = (g >> 6) & 1, c = (g >> 7) % kWsC1, w = (g >> 7) / kWsC1;
-        const int unit = 32 * w + (lane & 31), hh = lane >> 5;
+        const int unit = 16 * w + (lane & 15), kq = lane >> 4;
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = a.w1[unit * 128 + 16 * c + 8 * hh + e] * s1;
+        for (int e = 0; e < 8; ++e) x[e] = a.w1[unit * 128 + 32 * c + 8 * kq + e] * s1;
         a.w1p[g] = make_uint4(ws_pack2(x[0], x[1], part), ws_pack2(x[2], x[3], part), ws_pack2(x[4], x[5], part), ws_pack2(x[6], x[7], part));
         return;
     }
     g -= n1;
     if (g < n2) {
         const int lane = g & 63, part = (g >> 6) & 1, c = g >> 7;
-        const int row = lane & 31, hh = lane >> 5;
+        const int row = lane & 15, kq = lane >> 4;
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = row < 3 ? a.w2[row * 128 + 16 * c + 8 * hh + e] * s2 : 0.f;
+        for (int e = 0; e < 8; ++e) x[e] = row < 3 ? a.w2[row * 128 + 32 * c + 8 * kq + e] * s2 : 0.f;
         a.w2p[g] = make_uint4(ws_pack2(x[0], x[1], part), ws_pack2(x[2], x[3], part), ws_pack2(x[4], x[5], part), ws_pack2(x[6], x[7], part));
         return;
     }
     g -= n2;
-    if (g < kWsBias) {   // [layer][block][h][v]: unit = block*32 + (v&3) + 8*(v>>2) + 4*h
-        const int layer = g < 128 ? 0 : (g < 256 ? 1 : 2);
-        const int r = g - (layer == 0 ? 0 : (layer == 1 ? 128 : 256));
-        const int mm = r / 32, hh = (r / 16) & 1, v = r & 15;
-        const int u = mm * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
+    if (g < kWsBias) {   // natural unit order (the 16x16 accumulator holds units 4 (lane >> 4) .. +3 of the wave's slice), scaled
         float b = 0.f;
-        if (layer == 0) b = a.b0[u] * s0;
-        else if (layer == 1) b = a.b1[u] * s1;
-        else if (u < 3) b = a.b2[u] * s2;
+        if (g < 128) b = a.b0[g] * s0;
+        else if (g < 256) b = a.b1[g - 128] * s1;
+        else if (g - 256 < 3) b = a.b2[g - 256] * s2;
         a.biasp[g] = b;
     }
 }
 
 int ws_pack(t2n_field* f, hipStream_t s) {
-    const size_t n0 = (size_t)4 * kWsC0 * 2 * 64, n1 = kWsW1, n2 = kWsW2;
+    const size_t n0 = (size_t)kWsW * kWsC0 * 2 * 64, n1 = kWsW1, n2 = kWsW2;
     if (!f->buf_ws) {
-        T2N_HIP(hipMalloc((void**)&f->buf_ws, (n0 + n1 + n2) * 16 + (kWsBias + 8 + 2) * 4));
+        T2N_HIP(hipMalloc((void**)&f->buf_ws, (n0 + n1 + n2) * 16 + (kWsBias + 8) * 4));
     }
     uint4* base = (uint4*)f->buf_ws;
     WsPackArgs a;
@@ -552,14 +561,14 @@ int launch_mlp_ws(t2n_field* f, const float* feat, const unsigned* counters_dev,
         T2N_HIP(hipFuncSetAttribute((const void*)k_mlp_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWsLds));
         attr_set = true;
     }
-    const size_t n0 = (size_t)4 * kWsC0 * 2 * 64, n1 = kWsW1, n2 = kWsW2;
+    const size_t n0 = (size_t)kWsW * kWsC0 * 2 * 64, n1 = kWsW1, n2 = kWsW2;
     uint4* base = (uint4*)f->buf_ws;
     WsArgs a;
     a.w0 = base; a.w1 = base + n0; a.w2 = base + n0 + n1;
     a.bias = (const float*)(base + n0 + n1 + n2); a.inv_scale = a.bias + kWsBias + 4;
     a.feat = feat; a.counters = counters_dev; a.list_cap = list_cap; a.nlists = kLists; a.tile_hi = tile_hi; a.app_rgb = app_rgb;
     a.range_flag = range_flag; a.neg1 = -1.f;
-    hipLaunchKernelGGL(k_mlp_ws, dim3(256), dim3(256), kWsLds, s, a);
+    hipLaunchKernelGGL(k_mlp_ws, dim3(256), dim3(512), kWsLds, s, a);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

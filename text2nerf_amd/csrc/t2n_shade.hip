@@ -347,7 +347,7 @@ __device__ __forceinline__ void gather_all(const FactorSet& S, float* __restrict
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <bool SPLIT>
+template <bool SPLIT, bool HALF = false>
 __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         const unsigned row0 = tile * 32u;   // activation row of lane sample 0 (ctx mode)
         const bool keep_rows = row0 + 32u <= a.ctx_rows;
         const ShadeCtx cx = keep_rows ? a.ctx : ShadeCtx{nullptr, nullptr, nullptr, nullptr};
-        gather_all(F.app, X, lane, a.app_pos, a.xyz, base, count, cx.x144, row0);
+        gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, cx.x144, row0);
         wave_lds_sync();
 
         // ---- basis_mat: feat[i][s] = sum_k Wb[i][k] X[k][s] ----------------------------------------------------------
@@ -1042,6 +1042,7 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
     if (!attr_set) {
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
         attr_set = true;
@@ -1049,23 +1050,27 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
     const dim3 grid(shade_grid((unsigned long long)list_cap * kLists));
     const bool half = f->factor_bf16 && f->dev.app.plane_h[0];
     const unsigned ws_tiles = feat ? feat_rows / 128u * 4u : 0u;
-    if (use_ws(f) && !ctx && !half && !features_only && ws_tiles >= 4u) {
-        // default render path: K2a gather + basis -> feature rows, K2b weight-stationary head; tiles past the row capacity take
-        // the one-kernel path; a head that met an activation outside the f16 range is redone on the exact fp32 path
+    if (use_ws(f) && !ctx && !features_only && ws_tiles >= 4u) {
+        // default render path: K2a gather + basis -> feature rows (t2n_appfeat.hip), K2b weight-stationary head (t2n_mlp_ws.hip);
+        // tiles past the row capacity take the one-kernel path; a launch that met a value outside the f16 range is redone on the
+        // exact fp32 path
+        unsigned* flag = const_cast<unsigned*>(counters_dev) + kRangeFlagWord;
         ShadeArgs fa = a;
         fa.F.shading = T2N_SHADE_RGB;
         fa.app_rgb = nullptr;
         fa.ctx = ShadeCtx{nullptr, feat, nullptr, nullptr};
         fa.ctx_rows = ws_tiles * 32u; fa.tile_hi = ws_tiles;
         timing_begin(f, T2N_K_APPFEAT, s);
-        hipLaunchKernelGGL(k_shade<true>, grid, dim3(256), lds, s, fa);
+        if (half) hipLaunchKernelGGL((k_shade<true, true>), grid, dim3(256), lds, s, fa);
+        else hipLaunchKernelGGL((k_shade<true, false>), grid, dim3(256), lds, s, fa);
         timing_end(f, T2N_K_APPFEAT, s);
         timing_begin(f, T2N_K_SHADE, s);
-        const int rc = launch_mlp_ws(f, feat, counters_dev, list_cap, ws_tiles, app_rgb, const_cast<unsigned*>(counters_dev) + kRangeFlagWord, s);
+        const int rc = launch_mlp_ws(f, feat, counters_dev, list_cap, ws_tiles, app_rgb, flag, s);
         if (rc) return rc;
         ShadeArgs oa = a;
         oa.tile_lo = ws_tiles;
-        hipLaunchKernelGGL(k_shade_coop<false>, grid, dim3(256), kCoopLds, s, oa);
+        if (half) hipLaunchKernelGGL(k_shade_coop<true>, grid, dim3(256), kCoopLds, s, oa);
+        else hipLaunchKernelGGL(k_shade_coop<false>, grid, dim3(256), kCoopLds, s, oa);
         ShadeArgs ra = a;
         ra.tile_hi = ws_tiles; ra.run_if_nonzero = counters_dev + kRangeFlagWord;
         hipLaunchKernelGGL(k_shade<false>, grid, dim3(256), lds, s, ra);

@@ -19,8 +19,8 @@ with torch.no_grad():
     torch.cuda.synchronize()
     L.t2n_debug_ws_phase_read(buf, 0)
 v = np.array(list(buf), dtype=np.float64)
-names = ["prologue (turns, chunk 0, barrier)", "L0 step 0", "L0 steps 1-4", "L0 step 5", "h0 store tile 0 + barrier", "L1 stage 0", "L1 stages 1-2", "L1 stage 3",
-         "h1 store tile 3 + barrier", "L2 + output", "end barrier", "-", "-", "-", "-", "loop top"]
+names = ["octet 0 + barrier", "L0 steps 0-4", "L0 step 5", "h0 store + barrier", "L1 + barrier", "h1 store + barrier", "L2 + output", "end barrier",
+         "-", "-", "-", "-", "-", "-", "-", "loop top"]
 tot = v.sum()
 groups = field.stats()["appearance"] / 128.0
 for n, x in zip(names, v):
