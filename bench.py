@@ -52,6 +52,8 @@ BYTES_PER_EVAL = 1152   # 3 planes x 4 taps x 64 B + 3 lines x
 BYTES_PER_APP = 3456
 BYTES_PER_RAY = 40
 FLOP_PER_APP = 131168    # 2*(144*27 + 351*128 + 128*128 + 128*3)
+FLOP_HEAD = 123392       # 2*(351*128 + 128*128 + 128*3): the MLP head without basis_mat
+PMC_FILE = "round2_pmc.json"
 MFMA_F32_PEAK_TF = 157.3
 MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 
@@ -92,6 +94,24 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0, check=None):
     out = {"value": done * n_samples / dt, "unit": "ray-samples/s", "cores": cores, "kind": "port",
            "sample": f"{frames} x {rays.shape[0]} rays (800x800 frame, pixel stride {stride}) x {n_samples} samples, "
                      f"oracle_c (plain C, OpenMP {cores} threads), {dt:.1f} s"}
+    # the PyTorch restatement (oracle_torch, the form BASELINE.md's reference-on-CPU figures were taken in) on a bounded sample
+    try:
+        P = O.params_from_numpy(params)
+        sub = torch.from_numpy(synth.frame_rays_np(800, 800, stride=8))      # 10 000 rays
+        t0 = time.time()
+        with torch.no_grad():
+            O.forward(cfg, P, sub[:2000], n_samples=n_samples)
+        per = (time.time() - t0) / 2000
+        n_t = int(min(10000, max(2000, 8.0 / max(per, 1e-6))))
+        t0 = time.time()
+        with torch.no_grad():
+            for i in range(0, n_t, 2000):
+                O.forward(cfg, P, sub[i:i + 2000], n_samples=n_samples)
+        dt_t = time.time() - t0
+        out["oracle_torch"] = {"value": n_t * n_samples / dt_t, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
+                               "sample": f"{n_t} rays (800x800 frame, pixel stride 8) x {n_samples} samples in chunks of 2000, {dt_t:.1f} s"}
+    except Exception as e:  # noqa: BLE001
+        out["oracle_torch"] = {"error": repr(e)[:200]}
     if check is not None:   # the oracle as the checker: the HIP render of the SAME rays against it, whole frame (untimed)
         h_rgb, h_depth = check(torch.from_numpy(rays))
         e = np.abs(h_rgb - o_rgb)
@@ -209,6 +229,7 @@ def main():
     ap.add_argument("--per-ray-marcher", action="store_true",
                     help="disable the 8x8-tile marcher (default for whole row-major frames: field.frame_width = W)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="skip the secondary measurements (sustained, bf16, materialised, exact fp32)")
     ap.add_argument("--no-train", action="store_true", help="skip the C3-shaped train-step timing (iters/s)")
     ap.add_argument("--mode", default="weak", choices=["weak", "c4"],
                     help="weak: one 800x800 view per GPU (C2, the headline); c4: BASELINE configs[3] — ONE 1600x1600 frame split "
@@ -374,36 +395,61 @@ def main():
         k_ms = {k: v[0] / max(v[1], 1) for k, v in timing.items()}        # avg ms per launch
         k_per_step = {k: v[1] / args.steps for k, v in timing.items()}     # launches per step
         frame_ms = {k: v[0] / args.steps for k, v in timing.items()}       # kernel ms per frame
-        dom = max(("march", "shade"), key=lambda k: frame_ms.get(k, 0.0))
-        launches = max(k_per_step.get(dom, 1.0), 1.0)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "round1_traffic.json")) as fh:
-                traffic = json.load(fh).get(f"k_{dom}", {}).get("hbm_bytes_per_launch")
+        pmc = {}
+        try:   # per-launch PMC figures of the same command (tools/pmc_traffic.sh, tools/pmc_shade.sh), committed under profiles/
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as fh:
+                pmc = json.load(fh)
         except Exception:
             pass
-        alg_bytes = {"march": BYTES_PER_EVAL * V + BYTES_PER_RAY * R, "shade": BYTES_PER_APP * A}
         split = not field.mlp_exact_fp32
-        if dom == "march":
-            achieved = (alg_bytes["march"] / launches) / (k_ms["march"] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_march" if args.per_ray_marcher else "k_march_tiles (+ k_compact_list)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg_bytes["march"] / launches, "avg_launch_ms": k_ms["march"],
-                    "note": "field (69.6 MB) is cache-resident: achieved > HBM peak means the gather runs from L1/L2, "
-                            "traffic = PMC HBM bytes per launch from profiles/round1_traffic.json",
-                    # what actually bounds the gather: the vector L1 data path, 64 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md)
-                    "l1_path": {"peak": L1_PEAK_GBS, "unit": "GB/s", "frac": achieved / L1_PEAK_GBS}}
-        else:
-            # executed matrix-core work: 3 f16 products per fp32 product on the split path, 1 on the exact fp32 path
-            exec_flop = FLOP_PER_APP * A * (3 if split else 1)
+        two_kernel = "app_features" in frame_ms    # default path: gather + basis kernel, then the weight-stationary head
+        roofs = {}
+        if "shade" in k_ms:
+            # algorithmic work of the head kernel: the reference's fp32 MACs, 2 flop each; basis_mat's 7 776 flop per sample belong
+            # to the gather + basis kernel on the two-kernel path
+            flop_per = FLOP_HEAD if two_kernel else FLOP_PER_APP
+            launches = max(k_per_step["shade"], 1.0)
+            alg = flop_per * A / launches
+            t = k_ms["shade"] * 1e-3
             peak = MFMA_F16_PEAK_TF if split else MFMA_F32_PEAK_TF
-            achieved = (exec_flop / launches) / (k_ms["shade"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "k_shade", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                    "frac": achieved / peak, "traffic": traffic,
-                    "algorithmic_flop_per_launch": FLOP_PER_APP * A / launches, "avg_launch_ms": k_ms["shade"],
-                    "note": ("fp32 products executed as 3 f16 MFMA products of hi/lo splits (fp32 accumulate); "
-                             "fp32-equivalent rate = achieved / 3" if split else "exact fp32 MFMA")}
-        other = "shade" if dom == "march" else "march"
+            kname = "k_mlp_ws" if two_kernel else ("k_shade_coop" if split else "k_shade<exact>")
+            roofs["shade"] = {
+                "bound": "mfma", "kernel": kname, "achieved": alg / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": alg / t / 1e12 / peak, "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"),
+                "algorithmic_flop_per_launch": alg, "avg_launch_ms": k_ms["shade"],
+                # every fp32 product runs as three f16 MFMA products of hi/lo splits: what the matrix pipe actually executes
+                "executed_frac": (3.0 if split else 1.0) * alg / t / 1e12 / peak,
+                "mfma_busy_frac_pmc": pmc.get(kname, {}).get("mfma_busy_frac"),
+                "note": ("frac = algorithmic fp32-equivalent flop (123 392 per appearance sample: 351x128 + 128x128 + 128x3 MACs) / time / "
+                         "dense f16 MFMA peak; executed_frac counts the 3 f16 products per fp32 product" if split else "exact fp32 MFMA")}
+        if "march" in k_ms:
+            # the tile marcher replaces the per-sample 1152-B gather by dot-product tables on the matrix cores: it is bound by VALU
+            # issue, not by bytes. achieved = VALU instructions per launch (PMC SQ_INSTS_VALU of this command) / measured time;
+            # peak = 1024 SIMDs x one wave64 VALU instruction per 2 cycles x 2.4 GHz
+            kname = "k_march" if args.per_ray_marcher else "k_march_tiles"
+            insts = pmc.get(kname, {}).get("valu_insts_per_launch")
+            t = k_ms["march"] * 1e-3
+            peak = 1024 * 0.5 * 2.4
+            roofs["march"] = {"bound": "valu-issue", "kernel": kname, "unit": "Ginst/s", "peak": peak,
+                              "achieved": (insts / t / 1e9) if insts else None, "frac": (insts / t / 1e9 / peak) if insts else None,
+                              "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"), "avg_launch_ms": k_ms["march"],
+                              "gather_work_rate_GBps": (BYTES_PER_EVAL * V + BYTES_PER_RAY * R) / max(k_per_step["march"], 1.0) / t / 1e9,
+                              "note": "gather_work_rate = 1152 B per evaluated sample / time: a work rate for comparison across versions "
+                                      "(the field is cache-resident and the tile marcher does not move those bytes), not a bandwidth"}
+        if "app_features" in k_ms:
+            # 216 16-B lane loads per appearance sample (18 taps x 12 channel quads) through the texture addresser, which retires
+            # ~4 lane addresses per clock and CU (measured): peak = 256 x 4 x 2.4 GHz
+            t = k_ms["app_features"] * 1e-3
+            lane_loads = 216.0 * A / max(k_per_step["app_features"], 1.0)
+            peak = 256 * 4 * 2.4
+            roofs["app_features"] = {"bound": "texture-addresser", "kernel": "k_shade<split> (features mode)", "unit": "G lane-loads/s",
+                                     "achieved": lane_loads / t / 1e9, "peak": peak, "frac": lane_loads / t / 1e9 / peak,
+                                     "traffic": pmc.get("k_shade", {}).get("hbm_bytes_per_launch"), "avg_launch_ms": k_ms["app_features"],
+                                     "algorithmic_GBps": BYTES_PER_APP * A / max(k_per_step["app_features"], 1.0) / t / 1e9}
+        dom = max(roofs, key=lambda k: frame_ms.get(k, 0.0)) if roofs else None
+        roof = dict(roofs[dom]) if dom else {}
+        if dom and roof.get("bound") not in ("hbm", "mfma"):
+            roof["bound_contract"] = "hbm"     # the contract's two classes: everything that is not matrix work
         out = {
             "metric": "ray-samples/s (render) + iters/s (train), 300^3 VM-split, 800x800",
             "value": nominal, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -423,29 +469,58 @@ def main():
                                                                " + RCCL all-gather of rgb+depth tiles (async, overlapped with the "
                                                                "next frame's render)") if world > 1 else ""),
                        "kernel_ms_per_frame": frame_ms,
-                       "march_algorithmic_GBps": (alg_bytes["march"] / max(k_per_step.get("march", 1.0), 1.0)) /
-                                                 (k_ms["march"] * 1e-3) / 1e9 if "march" in k_ms else None,
-                       "shade_fp32_equiv_TFLOPs": (FLOP_PER_APP * A / max(k_per_step.get("shade", 1.0), 1.0)) /
-                                                  (k_ms["shade"] * 1e-3) / 1e12 if "shade" in k_ms else None,
-                       "path_roofline_frac": ((BYTES_PER_EVAL * V + BYTES_PER_APP * A + BYTES_PER_RAY * R) /
-                                              (ms_step * 1e-3) / 1e9) / HBM_PEAK_GBS},
+                       "kernel_rooflines": roofs,
+                       "scaling_measured": "no multi-GPU scaling curve has been measured by the builder (1-GPU boxes only)"},
             "roofline": roof,
         }
         out["config"].update(dp)
         if c4_equal is not None:
             out["config"]["c4_gathered_equals_single_rank"] = c4_equal
-        if world == 1 and args.factor_storage == "fp32":
-            # the same frame with bf16 factor storage (configs[4] mode; not the headline value: it renders the ROUNDED field)
-            field.factor_storage = "bf16"
+
+        def timed_frames(n):
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(n):
                 step()
             torch.cuda.synchronize()
-            out["config"]["bf16_factor_storage_ms_per_step"] = (time.perf_counter() - t0) / args.steps * 1e3
-            field.factor_storage = "fp32"
+            return (time.perf_counter() - t0) / n * 1e3
+
+        if world == 1 and not c4 and not args.quick:
+            # sustained clocks: the same frame for >= 2 s
+            n_sus = max(int(2200.0 / max(ms_step, 0.1)), args.steps)
+            out["config"]["sustained_ms_per_step"] = timed_frames(n_sus)
+            out["config"]["sustained_frames"] = n_sus
+            if args.factor_storage == "fp32":
+                # bf16 factor storage (configs[4] mode): halves the field's footprint; NOT faster (the gathers are addresser / VALU
+                # bound) and not the headline value: it renders the ROUNDED field
+                field.factor_storage = "bf16"
+                out["config"]["bf16_factor_storage_ms_per_step"] = timed_frames(args.steps)
+                out["config"]["bf16_factor_storage_note"] = "footprint only (34.8 MB instead of 69.6 MB); same kernels, 8-B gathers"
+                field.factor_storage = "fp32"
+            if not args.weights:
+                # the reference's actual return: weights and z_vals [R, N] materialised (renderer.py:39-42), 2.65 GB per frame
+                field.materialize_weights = True
+                out["config"]["weights_materialised_ms_per_step"] = timed_frames(max(args.steps // 2, 3))
+                field.materialize_weights = False
+            if split:
+                # the reference's own arithmetic: exact fp32 products (nn.Linear, models/tensorBase.py:94-106) on the f32 matrix cores
+                field.mlp_exact_fp32 = True
+                field.timing(True)
+                field.read_timing(reset=True)
+                ms_exact = timed_frames(max(args.steps // 2, 3))
+                tx = field.read_timing(reset=True)
+                field.timing(False)
+                field.mlp_exact_fp32 = False
+                sh = tx.get("shade")
+                ex = {"ms_per_step": ms_exact}
+                if sh and sh[1]:
+                    t = sh[0] / sh[1] * 1e-3
+                    ex.update({"kernel": "k_shade<exact> (gather + basis + MLP, one kernel)", "shade_avg_launch_ms": sh[0] / sh[1],
+                               "achieved_TFLOPs": FLOP_PER_APP * A / t / 1e12, "peak_TFLOPs": MFMA_F32_PEAK_TF,
+                               "frac": FLOP_PER_APP * A / t / 1e12 / MFMA_F32_PEAK_TF})
+                out["exact_fp32"] = ex
         if world == 1 and not args.no_train:
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True))

@@ -112,6 +112,8 @@ enum { T2N_STAT_EVALUATED = 0,   /* V: in-box (and z-gated) samples that read th
        T2N_STAT_APPEARANCE = 1,  /* A: samples with weight > weight_thres that read the appearance factors */
        T2N_STAT_RAYS = 2,
        T2N_STAT_OVERFLOW = 3,    /* must stay 0 */
+       T2N_STAT_F16_REDO = 4,    /* sub-launches whose split-f16 appearance stage met a value outside the f16 range and were
+                                    redone on the exact fp32 path (results are the exact path's) */
        T2N_STAT_COUNT = 8 };
 
 const char* t2n_last_error(void);

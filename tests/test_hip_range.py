@@ -1,0 +1,128 @@
+"""Range stress of the split-f16 appearance stage (default render path): every fp32 product of basis_mat and the MLP runs as three
+f16 MFMA products of hi/lo halves, so magnitudes matter — f16 has 5 exponent bits. The reference's arithmetic is fp32 nn.Linear
+(models/tensorBase.py:94-106, models/tensoRF.py:147,239). Each case renders a frame of the tiny field with rescaled appearance
+factors / head weights and compares with the oracle at the north-star tolerance (1e-4 RGB); cases built to leave the f16 range
+must be caught by the kernels' range flag and come out of the exact-fp32 redo (stats()["f16_redo"] > 0) — still within 1e-4.
+
+Scales are applied where they change magnitudes seen by the split path: appearance planes / lines (-> plane x line products),
+basis_mat, the three MLP layers. Density factors stay put so the sample set is the same."""
+import numpy as np
+import pytest
+import torch
+
+from text2nerf_amd import synth
+from tests.conftest import TINY
+from tests.test_hip_parity import RGB_ATOL, dev, make_field
+
+pytestmark = pytest.mark.gpu
+
+
+def rays():
+    return torch.from_numpy(synth.frame_rays_np(20, 24, c2w=synth.look_pose(0.3, -0.1, (0.2, 0.1, -1.0))))
+
+
+def render_both(params):
+    from oracle import oracle_torch as O
+    f = make_field(params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    r = rays()
+    with torch.no_grad():
+        rgb, depth, _, _ = f(r.to(dev()), white_bg=True, is_train=False, N_samples=-1)
+    cfg = O.FieldConfig(aabb=TINY["aabb"], grid_size=TINY["grid"], near_far=TINY["near_far"])
+    o_rgb, o_depth, _, _ = O.forward(cfg, O.params_from_numpy(params), r)
+    st = f.stats()
+    assert st["appearance"] > 500, st          # the case must actually exercise the appearance stage
+    return rgb.cpu().numpy(), o_rgb.numpy(), st
+
+
+def scaled(base, **scale):
+    """copy of the parameter dict with every tensor whose name starts with a key of `scale` multiplied by that factor"""
+    out = {}
+    for k, v in base.items():
+        s = 1.0
+        for pre, fac in scale.items():
+            if k.startswith(pre):
+                s *= fac
+        out[k] = (v * np.float32(s)).astype(np.float32)
+    return out
+
+
+CASES = {
+    # name: (scales, expect_redo)  expect_redo None = either
+    "baseline": ({}, False),
+    "app factors x8 each (products x64)": ({"app_plane": 8.0, "app_line": 8.0}, None),
+    "app factors x1/32 each (products x1/1024)": ({"app_plane": 1 / 32.0, "app_line": 1 / 32.0}, False),
+    "basis_mat x64": ({"basis_mat": 64.0}, None),
+    "basis_mat x1/1024": ({"basis_mat": 1 / 1024.0}, False),
+    "layer 0 x64": ({"renderModule.mlp.0": 64.0}, None),
+    "layer 1 x64": ({"renderModule.mlp.2": 64.0}, None),
+    "all MLP layers x1/1024": ({"renderModule.mlp": 1 / 1024.0}, False),
+    "all MLP layers x8": ({"renderModule.mlp": 8.0}, None),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_scaled_fields_match_oracle(tiny_params, name):
+    scales, expect_redo = CASES[name]
+    got, ref, st = render_both(scaled(tiny_params, **scales))
+    err = float(np.abs(got - ref).max())
+    assert err <= RGB_ATOL, (name, err, st)
+    if expect_redo is not None:
+        assert (st["f16_redo"] > 0) == expect_redo, (name, st)
+
+
+def test_weight_beyond_256_and_large_activations(tiny_params):
+    """|w| > 256 (the round-1 path pre-scaled by a fixed 2^8 and overflowed there) and hidden activations beyond 2^15 / 2^8"""
+    p = {k: v.copy() for k, v in tiny_params.items()}
+    w1 = p["renderModule.mlp.2.weight"]
+    w1[3, 5] = 300.0
+    w1[17, 9] = -411.0
+    got, ref, st = render_both(p)
+    assert float(np.abs(got - ref).max()) <= RGB_ATOL, st
+    p = scaled(tiny_params, **{"renderModule.mlp.0.bias": 1.0})
+    p["renderModule.mlp.0.bias"] = p["renderModule.mlp.0.bias"] + np.float32(400.0)       # h0 ~ 400 on every unit
+    got, ref, st = render_both(p)
+    assert float(np.abs(got - ref).max()) <= RGB_ATOL, st
+
+
+def test_values_outside_f16_range_take_the_exact_redo(tiny_params):
+    """hidden activations of ~1e5 cannot be split into f16 halves: the range flag must fire and the frame must come from the exact
+    fp32 kernels (same tolerance)"""
+    p = {k: v.copy() for k, v in tiny_params.items()}
+    p["renderModule.mlp.0.bias"] = p["renderModule.mlp.0.bias"] + np.float32(1.0e5)
+    p["renderModule.mlp.2.weight"] = p["renderModule.mlp.2.weight"] * np.float32(1e-3)   # keeps layer 1 in a sane range
+    got, ref, st = render_both(p)
+    assert st["f16_redo"] > 0, st
+    assert float(np.abs(got - ref).max()) <= RGB_ATOL, st
+    # features beyond the range (basis_mat x 1e7): caught on the raw-feature check
+    got, ref, st = render_both(scaled(tiny_params, **{"basis_mat": 1.0e7, "renderModule.mlp.0": 1.0e-7}))
+    assert st["f16_redo"] > 0, st
+    assert float(np.abs(got - ref).max()) <= RGB_ATOL, st
+
+
+def test_field_after_optimisation_steps_matches_oracle(tiny_params):
+    """a trained checkpoint is where magnitudes drift: 200 fused TV + Adam steps on random targets, then a frame vs the oracle on the
+    trained parameters"""
+    from oracle import oracle_torch as O
+    from text2nerf_amd import OctreeRender_trilinear_fast
+    from text2nerf_amd.optim import TVAdam
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    opt = TVAdam(f.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=f)
+    r = rays()
+    g = torch.Generator().manual_seed(7)
+    tgt = torch.rand(r.shape[0], 3, generator=g).to(dev())
+    torch.manual_seed(11)
+    for _ in range(200):
+        rgb, _, depth, w, z = OctreeRender_trilinear_fast(r, f, chunk=r.shape[0], N_samples=-1, white_bg=True, is_train=True, device=dev())
+        loss = torch.mean((rgb - tgt) ** 2)
+        opt.zero_grad()
+        loss.backward()
+        opt.step(tv=[(f.density_plane, 0.1), (f.app_plane, 0.01)])
+    params = {k: v.detach().cpu().numpy() for k, v in f.state_dict().items()}
+    with torch.no_grad():
+        rgb, depth, _, _ = f(r.to(dev()), white_bg=True, is_train=False, N_samples=-1)
+    cfg = O.FieldConfig(aabb=TINY["aabb"], grid_size=TINY["grid"], near_far=TINY["near_far"])
+    o_rgb, _, _, _ = O.forward(cfg, O.params_from_numpy(params), r)
+    st = f.stats()
+    assert st["appearance"] > 100, st
+    assert float((rgb.cpu() - o_rgb).abs().max()) <= RGB_ATOL, st
+    assert float(loss.detach()) < 0.2            # the steps did optimise something

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("T2N_LIB") or os.path.join(_HERE, "libt2n_hip.so")
 T2N_STAT_COUNT = 8
 T2N_K_COUNT = 9
 KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_mlp", "bwd_scatter", "density", "app_features")
-STAT_EVALUATED, STAT_APPEARANCE, STAT_RAYS, STAT_OVERFLOW = 0, 1, 2, 3
+STAT_EVALUATED, STAT_APPEARANCE, STAT_RAYS, STAT_OVERFLOW, STAT_F16_REDO = 0, 1, 2, 3, 4
 
 FLAG_TRAIN, FLAG_ADD_BG, FLAG_KEEP_CTX, FLAG_COHERENT, FLAG_NDC = 1, 2, 4, 8, 16
 SHADE_IDS = {"MLP_Fea_noview": 0, "SH": 1, "RGB": 2, "MLP_Fea": 3, "MLP_PE": 4, "MLP": 5}   # MLP_PE: rejected in tensorf.py (broken upstream)

@@ -643,7 +643,7 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
                 ShadeCtx ctx{(float*)(ws + kr.x144), (float*)(ws + kr.feat32), (float*)(ws + kr.h0), (float*)(ws + kr.h1)};
                 if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, &ctx, s, false, kr.rows))) return rc;
             } else if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, nullptr, s, false,
-                                               0xffffffffu, keep ? nullptr : L.feat, L.feat_rows))) return rc;
+                                               0xffffffffu, keep ? nullptr : L.feat, L.feat_rows, stats))) return rc;
         }
         if ((rc = launch_composite(f, L, s))) return rc;
     }

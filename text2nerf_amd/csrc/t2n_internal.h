@@ -136,7 +136,8 @@ inline unsigned list_capacity(long long n_rays, int n_samples) {
 struct ShadeCtx { float* x144; float* feat32; float* h0; float* h1; };
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
                       const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s,
-                      bool features_only = false, unsigned ctx_rows = 0xffffffffu, float* feat = nullptr, unsigned feat_rows = 0);
+                      bool features_only = false, unsigned ctx_rows = 0xffffffffu, float* feat = nullptr, unsigned feat_rows = 0,
+                      uint64_t* stats = nullptr);
 // feat / feat_rows: scratch rows for the two-kernel default path (features -> weight-stationary head, t2n_mlp_ws.hip); tiles
 // past the capacity take the one-kernel path. Word kRangeFlagWord of the counter block is the head's f16-range flag.
 constexpr int kRangeFlagWord = 32;

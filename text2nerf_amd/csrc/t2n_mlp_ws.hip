@@ -95,11 +95,11 @@ struct WsEnc {
     float4 r[2][2];          // raw wave: the current octet's eight feature values per pass
     WsUnit U[2];             // per pass: the unit in flight; between units (sin, cos) of the pass's previous octave
     unsigned ph[4], pl[4];   // packed halves of the octet being encoded
-    float amax;              // raw wave: running max |feature| (f16 range check)
+    unsigned amax_u;         // raw wave: running max of the features' |bit patterns| (orders like |x| and ranks inf / NaN on top)
 };
 
 template <int V, int PH, bool RAW>
-__device__ __forceinline__ void ws_unit_phase(WsUnit& U, const float (&f)[4], const float4 (&r)[2], float neg1, unsigned& hi, unsigned& lo, float& amax) {
+__device__ __forceinline__ void ws_unit_phase(WsUnit& U, const float (&f)[4], const float4 (&r)[2], float neg1, unsigned& hi, unsigned& lo, unsigned& amax_u) {
     constexpr int q = (V % 12) / 2;
     constexpr bool fresh = q == 0 || q == 3;   // octaves 1, 2, 4, 5 from the one before
     if constexpr (PH == 0) {
@@ -108,7 +108,7 @@ __device__ __forceinline__ void ws_unit_phase(WsUnit& U, const float (&f)[4], co
             const float4 s = r[e / 4];
             U.x0 = (e % 4) == 0 ? s.x : s.z;
             U.x1 = (e % 4) == 0 ? s.y : s.w;
-            amax = fmaxf(amax, fmaxf(fabsf(U.x0), fabsf(U.x1)));
+            amax_u = max(amax_u, max(__float_as_uint(U.x0) & 0x7fffffffu, __float_as_uint(U.x1) & 0x7fffffffu));
         } else if constexpr (fresh) {
             // f / (2 pi) as th + tl (two-constant product, ~2^-48 relative), then the fraction of its 2^q multiple: sin / cos take
             // revolutions and have period 1
@@ -142,7 +142,7 @@ __device__ __forceinline__ void ws_unit_phase(WsUnit& U, const float (&f)[4], co
 template <int J, int I, int PH, bool RAW>
 __device__ __forceinline__ void ws_enc_phase(WsEnc& E, float neg1) {
     constexpr int p = I / 4, u = I % 4;
-    ws_unit_phase<8 * J + 2 * u, PH, RAW>(E.U[p], E.f[p], E.r[p], neg1, E.ph[u], E.pl[u], E.amax);
+    ws_unit_phase<8 * J + 2 * u, PH, RAW>(E.U[p], E.f[p], E.r[p], neg1, E.ph[u], E.pl[u], E.amax_u);
 }
 // the two 16-B stores of one pass: ring [chunk w' / 4][N-tile 4P + (lane >> 4)][part][column (lane & 15) + 16 (w' % 4)]
 template <int P>
@@ -290,7 +290,8 @@ __global__ __launch_bounds__(512) void k_mlp_ws(const WsArgs a) {
     const float inv0 = a.inv_scale[0], inv1 = a.inv_scale[1], inv2 = a.inv_scale[2];
     const float neg1 = a.neg1;
     const bool raw = w == 7;
-    float amax = 0.f;
+    float amax = 0.f;          // hidden activations (non-negative, finite inputs)
+    unsigned amax_u = 0u;      // raw features
 
     // feature rows of the lane's two samples of group g (row = 128 g + 64 p + lane; tiles past the end re-read the last tile's rows:
     // their results are never stored)
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(512) void k_mlp_ws(const WsArgs a) {
     for (unsigned g = blockIdx.x; g < ngroups; g += gridDim.x) {
         WS_PHASE(15);
         WsEnc E;
-        E.amax = amax;
+        E.amax_u = amax_u;
         E.f[0][0] = nx[0].x; E.f[0][1] = nx[0].y; E.f[0][2] = nx[0].z; E.f[0][3] = nx[0].w;
         E.f[1][0] = nx[1].x; E.f[1][1] = nx[1].y; E.f[1][2] = nx[1].z; E.f[1][3] = nx[1].w;
         E.r[0][0] = nx[0]; E.r[0][1] = nx[2]; E.r[1][0] = nx[1]; E.r[1][1] = nx[3];
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(512) void k_mlp_ws(const WsArgs a) {
         WS_PHASE(1);
         ws_l0_step<5, false>(acc, A0, RH, w, lane, E, row0, row1, neg1);
         WS_PHASE(2);
-        amax = E.amax;
+        amax_u = E.amax_u;
         // ---- h0 -> LDS (every wave passed the last ring read at the barrier that ended step 5) ------------------------------------------
 #pragma unroll
         for (int t = 0; t < kWsT; ++t) amax = ws_store_quad(acc[t], inv0, H2l + (size_t)t * kWsC1 * 256, neg1, amax);
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(512) void k_mlp_ws(const WsArgs a) {
 #ifdef T2N_PHASE_TIMING
     if (tid == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_ws_phase[i], phacc[i]);
 #endif
-    if (__any(!(amax <= kWsRange)) && lane == 0) atomicOr(a.range_flag, 1u);
+    if (__any(!(amax <= kWsRange) || amax_u > __float_as_uint(kWsRange)) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
 // ---- operand packing -----------------------------------------------------------------------------------------------------

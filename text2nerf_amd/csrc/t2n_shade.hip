@@ -138,22 +138,28 @@ constexpr int kBasisChunksReal = 9, kL0ChunksReal = 23;
 
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+// -1.0f the optimiser cannot see through: x - hi then stays an FMA whose f16 operand is read in place (v_fma_mix_f32), no
+// convert instruction
+__device__ __forceinline__ float opaque_neg1() {
+    float x;
+    asm("s_mov_b32 %0, 0xbf800000" : "=s"(x));
+    return x;
+}
 __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
-    // hi = x truncated to an 11-bit significand (mask), exactly representable in f16, so the packed round-toward-zero
-    // conversion is exact and no convert-back is needed for the residual; lo = f16(x - hi) carries the next 11 bits.
+    // hi = RTZ_f16(x) (packed convert), lo = RTZ_f16(x - hi): the residual is exact in fp32 (hi is a truncation of x) and is
+    // formed by v_fma_mix_f32 straight from the packed halves: two instructions per value
     typedef __fp16 hh2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    float t[8], r[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        t[e] = __uint_as_float(__float_as_uint(x[e]) & 0xffffe000u);
-        r[e] = x[e] - t[e];
-    }
+    const float n1 = opaque_neg1();
     u4 uh, ul;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        uh[e] = __builtin_bit_cast(unsigned, (hh2)__builtin_amdgcn_cvt_pkrtz(t[2 * e], t[2 * e + 1]));
-        ul[e] = __builtin_bit_cast(unsigned, (hh2)__builtin_amdgcn_cvt_pkrtz(r[2 * e], r[2 * e + 1]));
+        const hh2 p = __builtin_amdgcn_cvt_pkrtz(x[2 * e], x[2 * e + 1]);
+        const h2 ph = __builtin_bit_cast(h2, p);
+        const float r0 = fmaf((float)ph[0], n1, x[2 * e]), r1 = fmaf((float)ph[1], n1, x[2 * e + 1]);
+        uh[e] = __builtin_bit_cast(unsigned, p);
+        ul[e] = __builtin_bit_cast(unsigned, (hh2)__builtin_amdgcn_cvt_pkrtz(r0, r1));
     }
     hi = __builtin_bit_cast(h8, uh);
     lo = __builtin_bit_cast(h8, ul);
@@ -285,6 +291,8 @@ struct ShadeArgs {
     unsigned ctx_rows;   // rows the ctx buffers hold: tiles past it keep nothing (forward-kept activations with a capacity guess)
     unsigned tile_lo, tile_hi;        // this launch covers tiles [tile_lo, min(ntiles, tile_hi)) of the sub-lists
     const unsigned* run_if_nonzero;   // when set: the launch is a no-op unless *run_if_nonzero != 0 (exact-path redo gate)
+    unsigned* range_flag;             // when set: raised by the split path when a value left the f16 range
+    unsigned long long* stats;        // redo launches count themselves in stats[T2N_STAT_F16_REDO]
 };
 
 // Gather: 384 (sample, channel-quad) items over 64 lanes, 6 per lane; an item computes its sample's three axis taps once
@@ -315,34 +323,36 @@ __device__ __forceinline__ void gather_issue(const FactorSet& S, int it, int lan
     issue_taps_ax<1, HALF>(S, CQ, g.q, A, g.t[1]);
     issue_taps_ax<2, HALF>(S, CQ, g.q, A, g.t[2]);
 }
-__device__ __forceinline__ void gather_consume(const GatherItem& g, float* __restrict__ X, float* ctx_x, unsigned row0) {
+template <bool TRACK = false>
+__device__ __forceinline__ void gather_consume(const GatherItem& g, float* __restrict__ X, float* ctx_x, unsigned row0, float& amax) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float4 p = taps_plane(g.t[k]), l = taps_line(g.t[k]);
         float4 v = make_float4(p.x * l.x, p.y * l.y, p.z * l.z, p.w * l.w);
         if (!g.live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (TRACK) amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(amax, fmaxf(fabsf(v.z), fabsf(v.w))));   // f16 range of the split path
         float* dst = X + (size_t)(k * 48 + g.q * 4) * kXld + g.s;
         dst[0] = v.x; dst[kXld] = v.y; dst[2 * kXld] = v.z; dst[3 * kXld] = v.w;
         if (ctx_x) *reinterpret_cast<float4*>(ctx_x + (size_t)(row0 + g.s) * kAppK + k * 48 + g.q * 4) = v;
     }
 }
 
-template <bool HALF = false>
+template <bool HALF = false, bool TRACK = false>
 __device__ __forceinline__ void gather_all(const FactorSet& S, float* __restrict__ X, int lane, const float4* pos_l,
-                                           const float* xyz, unsigned base, unsigned count, float* ctx_x, unsigned row0) {
+                                           const float* xyz, unsigned base, unsigned count, float* ctx_x, unsigned row0, float& amax) {
     GatherItem g0, g1;
     gather_issue<HALF>(S, 0, lane, pos_l, xyz, base, count, g0);
     gather_issue<HALF>(S, 1, lane, pos_l, xyz, base, count, g1);
-    gather_consume(g0, X, ctx_x, row0);
+    gather_consume<TRACK>(g0, X, ctx_x, row0, amax);
     gather_issue<HALF>(S, 2, lane, pos_l, xyz, base, count, g0);
-    gather_consume(g1, X, ctx_x, row0);
+    gather_consume<TRACK>(g1, X, ctx_x, row0, amax);
     gather_issue<HALF>(S, 3, lane, pos_l, xyz, base, count, g1);
-    gather_consume(g0, X, ctx_x, row0);
+    gather_consume<TRACK>(g0, X, ctx_x, row0, amax);
     gather_issue<HALF>(S, 4, lane, pos_l, xyz, base, count, g0);
-    gather_consume(g1, X, ctx_x, row0);
+    gather_consume<TRACK>(g1, X, ctx_x, row0, amax);
     gather_issue<HALF>(S, 5, lane, pos_l, xyz, base, count, g1);
-    gather_consume(g0, X, ctx_x, row0);
-    gather_consume(g1, X, ctx_x, row0);
+    gather_consume<TRACK>(g0, X, ctx_x, row0, amax);
+    gather_consume<TRACK>(g1, X, ctx_x, row0, amax);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -369,8 +379,12 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
     }
     unsigned ntiles = __shfl(incl, a.nlists - 1);
     if (ntiles > a.tile_hi) ntiles = a.tile_hi;
-    if (a.run_if_nonzero && *a.run_if_nonzero == 0u) return;
+    if (a.run_if_nonzero) {
+        if (*a.run_if_nonzero == 0u) return;
+        if (a.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.stats[T2N_STAT_F16_REDO], 1ull);
+    }
     const unsigned wave_stride = gridDim.x * 4u;
+    float amax = 0.f;   // (range tracking lives in k_app_features / k_mlp_ws)
 
     for (unsigned tile = a.tile_lo + blockIdx.x * 4u + wid; tile < ntiles; tile += wave_stride) {
         const int li = (int)__popcll(__ballot((lane < a.nlists) & (incl <= tile)));
@@ -382,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         const unsigned row0 = tile * 32u;   // activation row of lane sample 0 (ctx mode)
         const bool keep_rows = row0 + 32u <= a.ctx_rows;
         const ShadeCtx cx = keep_rows ? a.ctx : ShadeCtx{nullptr, nullptr, nullptr, nullptr};
-        gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, cx.x144, row0);
+        gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, cx.x144, row0, amax);
         wave_lds_sync();
 
         // ---- basis_mat: feat[i][s] = sum_k Wb[i][k] X[k][s] ----------------------------------------------------------
@@ -528,6 +542,54 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
     }
 }
 
+// ---- features only (K2a of the default render path): gather + basis_mat -> fp32 feature rows [tile * 32 + sample][32] for the
+// weight-stationary head (t2n_mlp_ws.hip). The gather and basis stages of k_shade<true> without the head's code and registers:
+// one wave per 32-sample tile, X[144][33] through the wave's LDS tile, basis_mat as split-f16 MFMA products (weights x 2^8).
+// Raises *range_flag when a plane x line product left the f16 range (inf / NaN features are caught by the head's own check).
+template <bool HALF>
+__global__ __launch_bounds__(256, 2) void k_app_features(const ShadeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int s = lane & 31, h = lane >> 5;
+    float* __restrict__ X = smem + (size_t)wid * kTileFloats;
+    const FieldDev& F = a.F;
+    unsigned cnt_l = 0;
+    if (lane < a.nlists) {
+        cnt_l = a.counters[lane * kCounterStride];
+        if (cnt_l > a.list_cap) cnt_l = a.list_cap;
+    }
+    unsigned incl = (cnt_l + 31u) / 32u;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    unsigned ntiles = __shfl(incl, a.nlists - 1);
+    if (ntiles > a.tile_hi) ntiles = a.tile_hi;
+    const unsigned wave_stride = gridDim.x * 4u;
+    float amax = 0.f;
+    for (unsigned tile = blockIdx.x * 4u + wid; tile < ntiles; tile += wave_stride) {
+        const int li = (int)__popcll(__ballot((lane < a.nlists) & (incl <= tile)));
+        const unsigned before = li ? __shfl(incl, li - 1) : 0u;
+        const unsigned lbase = (unsigned)li * a.list_cap;
+        const unsigned base = lbase + (tile - before) * 32u;
+        const unsigned count = lbase + __shfl(cnt_l, li);
+        gather_all<HALF, true>(F.app, X, lane, a.app_pos, nullptr, base, count, nullptr, 0, amax);
+        wave_lds_sync();
+        f32x16 accb1[1] = {{0}};
+        LdsChunk bf{X + s, h, kBasisChunksReal};
+        f16_stream<1>(accb1, F.basisH, lane, kBasisChunks, bf);
+        const f32x16 accb = accb1[0] * kWUnscale;
+        // lane (s, h) register v holds feature (v & 3) + 8 (v >> 2) + 4 h: four float4 stores per lane
+        float* __restrict__ row = a.ctx.feat32 + ((size_t)tile * 32 + s) * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(row + 8 * g) = make_float4(accb[4 * g], accb[4 * g + 1], accb[4 * g + 2], accb[4 * g + 3]);
+        wave_lds_sync();   // X reads done before the next tile's gather
+    }
+    if (a.range_flag && __any(!(amax <= 60000.f)) && lane == 0) atomicOr(a.range_flag, 1u);
+}
+
 // ---- block-cooperative variant (default render path, split-f16 MLP head) ---------------------------------------------
 // k_shade streams every weight chunk from L2 once per wave: 292 KB per 32-sample tile, ~39 GB per 800x800 frame, which is
 // the cache fabric's whole budget for the kernel. Here the four waves of a block walk their four tiles in lockstep and
@@ -610,7 +672,16 @@ __device__ __forceinline__ void coop_step(CoopRing& R, int c, f32x16 (&acc)[4], 
 struct PePipe {
     const float* feh;   // Fe + s + 14 h kXld
     float sn, cs, v;
-    __device__ __forceinline__ void fresh(float arg) { fast_sincosf(arg, &sn, &cs); }
+    // sin / cos by v_sin_f32 / v_cos_f32 (revolutions) on the fraction of arg / (2 pi), 1 / (2 pi) as a two-constant product: max
+    // abs error 4.2e-7 (tools/experiments/hw_sincos.hip), ~9 instructions against ~30 for the polynomial
+    __device__ __forceinline__ void fresh(float arg) {
+        const float C1 = 0.15915494309189535f, C2 = (float)(0.15915494309189533576888 - (double)C1);
+        const float th = arg * C1;
+        const float tl = fmaf(arg, C1, -th) + arg * C2;
+        const float t = __builtin_amdgcn_fractf(th) + tl;
+        sn = __builtin_amdgcn_sinf(t);
+        cs = __builtin_amdgcn_cosf(t);
+    }
     __device__ __forceinline__ void put(float (&x)[8], int p) { x[2 * p] = sn; x[2 * p + 1] = cs; }
     __device__ __forceinline__ void type_a(int fa, float (&x)[8]) {
         v = feh[(size_t)fa * kXld];
@@ -756,7 +827,8 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
 #ifdef T2N_PHASE_TIMING
         unsigned long long tph = __builtin_amdgcn_s_memtime();
 #endif
-        gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, nullptr, 0);
+        float amax_unused = 0.f;
+        gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, nullptr, 0, amax_unused);
         wave_lds_sync();
         T2N_PHASE(0);
 
@@ -1027,7 +1099,7 @@ static bool use_ws(const t2n_field* f) {
 
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
                       const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s,
-                      bool features_only, unsigned ctx_rows, float* feat, unsigned feat_rows) {
+                      bool features_only, unsigned ctx_rows, float* feat, unsigned feat_rows, uint64_t* stats) {
     ShadeArgs a;
     memset(&a, 0, sizeof(a));
     if (ctx) a.ctx = *ctx;
@@ -1042,7 +1114,8 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
     if (!attr_set) {
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        T2N_HIP(hipFuncSetAttribute((const void*)k_app_features<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        T2N_HIP(hipFuncSetAttribute((const void*)k_app_features<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
         attr_set = true;
@@ -1060,9 +1133,10 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
         fa.app_rgb = nullptr;
         fa.ctx = ShadeCtx{nullptr, feat, nullptr, nullptr};
         fa.ctx_rows = ws_tiles * 32u; fa.tile_hi = ws_tiles;
+        fa.range_flag = flag;
         timing_begin(f, T2N_K_APPFEAT, s);
-        if (half) hipLaunchKernelGGL((k_shade<true, true>), grid, dim3(256), lds, s, fa);
-        else hipLaunchKernelGGL((k_shade<true, false>), grid, dim3(256), lds, s, fa);
+        if (half) hipLaunchKernelGGL(k_app_features<true>, grid, dim3(256), lds, s, fa);
+        else hipLaunchKernelGGL(k_app_features<false>, grid, dim3(256), lds, s, fa);
         timing_end(f, T2N_K_APPFEAT, s);
         timing_begin(f, T2N_K_SHADE, s);
         const int rc = launch_mlp_ws(f, feat, counters_dev, list_cap, ws_tiles, app_rgb, flag, s);
@@ -1071,8 +1145,8 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
         oa.tile_lo = ws_tiles;
         if (half) hipLaunchKernelGGL(k_shade_coop<true>, grid, dim3(256), kCoopLds, s, oa);
         else hipLaunchKernelGGL(k_shade_coop<false>, grid, dim3(256), kCoopLds, s, oa);
-        ShadeArgs ra = a;
-        ra.tile_hi = ws_tiles; ra.run_if_nonzero = counters_dev + kRangeFlagWord;
+        ShadeArgs ra = a;   // every tile of the launch, the one-kernel path's included
+        ra.run_if_nonzero = counters_dev + kRangeFlagWord; ra.stats = (unsigned long long*)stats;
         hipLaunchKernelGGL(k_shade<false>, grid, dim3(256), lds, s, ra);
         timing_end(f, T2N_K_SHADE, s);
         T2N_HIP(hipGetLastError());

@@ -791,7 +791,7 @@ class TensorVMSplit(nn.Module):
         s = self.last_stats.cpu().tolist()
         if s[_lib.STAT_OVERFLOW]:
             raise T2NError("appearance list overflow — workspace sizing bug")
-        return {"evaluated": s[_lib.STAT_EVALUATED], "appearance": s[_lib.STAT_APPEARANCE]}
+        return {"evaluated": s[_lib.STAT_EVALUATED], "appearance": s[_lib.STAT_APPEARANCE], "f16_redo": s[_lib.STAT_F16_REDO]}
 
 
 class TensorVM(TensorVMSplit):

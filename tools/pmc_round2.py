@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc CSVs of tools/pmc_round2.sh -> per-kernel JSON read by bench.py (profiles/round2_pmc.json).
+Per launch (mean over the dispatches of the run): HBM bytes (FETCH_SIZE x 2 per MI355X_MICROARCH.md for gfx950's wide reads, + WRITE_SIZE; both
+reported in KB), L2 hit rate, VALU / MFMA instruction counts, the MFMA pipe's busy fraction (SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs x
+the launch's cycles = GRBM_GUI_ACTIVE / 8 XCDs)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("t2n::", "").split("<")[0]
+            acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {"_comment": "per-launch PMC means of `bench.py --steps 3` (one launch = one 640000-ray 800x800 C2 frame), tools/pmc_round2.sh; "
+                   "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB -> B), the doubling per MI355X_MICROARCH.md"}
+for k, c in sorted(acc.items()):
+    if not k.startswith("k_"):
+        continue
+    m = {n: sum(v) / len(v) for n, v in c.items()}
+    e = {"dispatches": int(max(len(v) for v in c.values()))}
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        e.update(fetch_size_kb=m["FETCH_SIZE"], write_size_kb=m["WRITE_SIZE"], hbm_bytes_per_launch=int((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024))
+    if "TCC_HIT_sum" in m and m["TCC_HIT_sum"] + m.get("TCC_MISS_sum", 0) > 0:
+        e["l2_hit_rate"] = round(m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]), 4)
+    if "SQ_INSTS_VALU" in m:
+        e["valu_insts_per_launch"] = m["SQ_INSTS_VALU"] - m.get("SQ_INSTS_MFMA", 0.0)
+        e["mfma_insts_per_launch"] = m.get("SQ_INSTS_MFMA", 0.0)
+        e["lds_insts_per_launch"] = m.get("SQ_INSTS_LDS", 0.0)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("GRBM_GUI_ACTIVE"):
+        e["mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0), 4)
+    out[k] = e
+print(json.dumps(out, indent=1))

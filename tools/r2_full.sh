@@ -3,13 +3,7 @@
 out=gpurun_out/${1:-r2k}
 mkdir -p $out
 ( time python -m pytest tests -q -m gpu ) > $out/gpu_tests.log 2>&1
-tail -25 $out/gpu_tests.log
-python bench.py --no-train --steps 30 > $out/bench_ws.json 2> $out/bench_ws.err
-python - <<PY
-import json
-try:
-    d = json.loads([l for l in open("$out/bench_ws.json") if l.startswith("{")][0])
-    print("ms/step", round(d["ms_per_step"], 3), d["config"]["kernel_ms_per_frame"], d.get("cpu_baseline", {}).get("parity_vs_oracle"))
-except Exception as e:
-    print("failed", e); print(open("$out/bench_ws.err").read()[-2000:])
-PY
+tail -40 $out/gpu_tests.log
+python bench.py ${BENCH_ARGS:---no-train} --steps 30 > $out/bench.json 2> $out/bench.err
+tail -c 6000 $out/bench.json
+tail -5 $out/bench.err
