@@ -123,7 +123,7 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0, check=None):
     return out
 
 
-def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None):
+def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_step=False):
     """C3-shaped optimisation step (text2nerf_main.py:547-601): 16 384 random rays of 9 small-baseline 512x512 views,
     N=259, is_train, MSE(rgb)+0.005 MSE(depth)+1e3 transmittance+TV(density 0.1, app 0.01), Adam(0.02/1e-3).
     With `dist` (world > 1): data-parallel — the SAME 16 384-ray batch is split into equal shards (strong scaling), local
@@ -147,11 +147,11 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None):
               torch.from_numpy(g.normal(0, 0.05, (allrays.shape[0], 3)).astype(np.float32))).clamp(0, 1)
     alldepth = dep_s.cpu().repeat_interleave(4, 0)[: allrays.shape[0]] + torch.from_numpy(
         g.normal(0, 0.05, (allrays.shape[0],)).astype(np.float32))
-    if fused_optim:   # TV gradient + Adam as HIP streaming kernels (text2nerf_amd/optim.py)
+    if fused_optim or fused_step:   # TV gradient + Adam as HIP streaming kernels (text2nerf_amd/optim.py)
         from text2nerf_amd.optim import TVAdam
-        # single process: the plane / line tensors are stepped on the device's channel-last copies from device-side gradients
-        # (data-parallel runs all-reduce reference-layout gradients, so they keep the reference-layout kernels)
-        opt = TVAdam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=field if dist is None else None)
+        # the plane / line tensors are stepped on the device's channel-last copies from device-side gradients; data-parallel runs
+        # all-reduce that contiguous gradient buffer in place
+        opt = TVAdam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=field)
     else:
         opt = torch.optim.Adam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
     tv, tl = TVLoss(), TransMittanceLoss_mask(dev)
@@ -166,10 +166,16 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None):
         all_params = [p for p in field.parameters() if p.requires_grad]
         lo, hi = shard_batch(batch, world, rank)
 
+    tv_terms = [(field.density_plane, 0.1), (field.app_plane, 0.01)]
+
     def it(k):
         idx = perm[(k * batch) % (perm.numel() - batch):][:batch]
         if dist is not None:
             idx = idx[lo:hi]
+        if fused_step:   # autograd-free: render -> loss kernel (emits d_rgb / d_depth / d_weights) -> backward -> TV + Adam
+            ar = (lambda: allreduce_gradients(all_params, average=True, field=field)) if dist is not None else None
+            return field.train_step(allrays[idx], allrgb[idx], alldepth[idx], opt, N_samples=n_samples, white_bg=True, tv=tv_terms,
+                                    all_reduce=ar)[3]
         # targets go host -> device like text2nerf_main.py:550-553, through the pinned staging ring (a pageable .to(device)
         # drains the stream first and idles the GPU for the rest of the host-side batch preparation)
         rays, rgb_t, dep_t = allrays[idx], to_device_async(allrgb[idx], dev), to_device_async(alldepth[idx], dev)
@@ -182,9 +188,9 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None):
         opt.zero_grad()
         loss.backward()
         if dist is not None:
-            allreduce_gradients(all_params, average=True)
+            allreduce_gradients(all_params, average=True, field=field if fused_optim else None)
         if fused_optim:
-            opt.step(tv=[(field.density_plane, 0.1), (field.app_plane, 0.01)])
+            opt.step(tv=tv_terms)
         else:
             opt.step()
         return loss
@@ -206,9 +212,13 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         return {"train_dp_iters_per_s": iters / dt, "train_dp_ms_per_iter": dt / iters * 1e3,
-                "train_dp_step": f"data-parallel x{world}: {batch} rays split into {hi - lo}/GPU (strong scaling), one flat "
-                                 f"{sum(p.numel() for p in all_params) * 4 / 1e6:.1f} MB gradient all-reduce, "
-                                 f"{'fused TV+Adam' if fused_optim else 'torch TV+Adam'}, loss {float(loss.detach()):.4f}"}
+                "train_dp_step": f"data-parallel x{world}: {batch} rays split into {hi - lo}/GPU (strong scaling), in-place all-reduce of the "
+                                 f"{field.factor_grad_buffer().numel() * 4 / 1e6:.1f} MB channel-last factor-gradient buffer + one small flat "
+                                 f"message for the head, fused loss + TV + Adam on the device copies, loss {float(loss.detach()):.4f}"}
+    if fused_step:
+        return {"train_iters_per_s_fused_step": iters / dt, "train_ms_per_iter_fused_step": dt / iters * 1e3,
+                "train_step_fused": "TensorVMSplit.train_step: no autograd graph, loss + its gradients in one kernel, event-based row "
+                                    f"count, TV + Adam on the device copies; loss {float(loss.detach()):.4f}"}
     if fused_optim:
         return {"train_iters_per_s_fused_optim": iters / dt, "train_ms_per_iter_fused_optim": dt / iters * 1e3}
     return {"train_iters_per_s": iters / dt, "train_ms_per_iter": dt / iters * 1e3, "train_iters": iters,
@@ -380,7 +390,7 @@ def main():
     dp = {}
     if dist is not None and not args.no_train:   # every rank takes part in the data-parallel train step
         try:
-            dp = train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True, dist=dist)
+            dp = train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True, dist=dist)
         except BaseException:
             # a rank that fails inside the data-parallel section must not leave its peers blocked in a collective it will
             # never join: report and leave non-zero at once (the launcher tears the job down; the collectives carry a timeout)
@@ -524,6 +534,7 @@ def main():
         if world == 1 and not args.no_train:
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True))
+            out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True))
         if world == 1 and not args.no_cpu_baseline:
             def hip_render(r):
                 with torch.no_grad():

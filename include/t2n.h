@@ -263,6 +263,26 @@ int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray
                         const t2n_field_grads* g, void* fwd_workspace, size_t fwd_workspace_bytes, void* bwd_workspace,
                         size_t bwd_workspace_bytes, t2n_stream stream);
 
+/* The channel-last gradients of the 12 factor tensors live in ONE buffer of t2n_field_grad_buffer_bytes (order: density planes,
+ * density lines, appearance planes, appearance lines; 256-B aligned slices). By default the library owns it and every
+ * t2n_render_backward zeroes it first (it then holds the gradients of that call). A caller that hands in its own device buffer
+ * (t2n_field_set_grad_buffer; NULL returns to the library-owned one) owns the zeroing: backward calls ACCUMULATE into it (a batch
+ * split into chunks, gradient accumulation), a data-parallel all-reduce can run on it in place, and t2n_field_tv_adam_step reads
+ * it. Replaces the autograd accumulation of text2nerf_main.py:588-590 for those tensors. */
+size_t t2n_field_grad_buffer_bytes(const t2n_field* f);
+int t2n_field_set_grad_buffer(t2n_field* f, void* buf, size_t bytes);
+
+/* The driver's loss of one training batch (text2nerf_main.py:559-575; TransMittanceLoss_mask, utils.py:67-80) in one pass over the
+ * render outputs: loss = mean((rgb - rgb_t)^2) + w_depth * mean((depth - depth_t)^2) + w_trans * mean_r(m_r^2) with
+ * m_r = mean_n(weights[r,n] * [z_vals[r,n] - depth_t[r] + delta < 0]); NaN depths count as 0 and get no gradient (:559-560).
+ * Writes the upstream gradients t2n_render_backward takes (d_rgb [R,3], d_depth [R], d_weights [R,N]) and
+ * losses[4] = {mse, depth loss, transmittance loss, total} (device floats, deterministic sums). The driver's values:
+ * w_depth 0.005, w_trans 1e3, delta 0.1. workspace: t2n_train_loss_workspace_bytes(n_rays). */
+size_t t2n_train_loss_workspace_bytes(int64_t n_rays);
+int t2n_train_loss(const float* rgb, const float* depth, const float* weights, const float* z_vals, const float* rgb_t,
+                   const float* depth_t, int64_t n_rays, int n_samples, float w_depth, float w_trans, float delta, float* d_rgb,
+                   float* d_depth, float* d_weights, float* losses, void* workspace, size_t workspace_bytes, t2n_stream stream);
+
 /* ---- SURVEY.md 8(f-1), optional: the dense tail of the training step as streaming kernels.
  * t2n_tv_grad_add: grad += d/dparam [ weight * TVLoss(param) ] for one reference-layout plane [1,C,H,W]
  *   (utils.py:488-504; the driver's term is TV_loss_*(tvreg) * TV_weight with TV_loss_* = sum_planes 1e-2 * TVLoss,

@@ -1,0 +1,111 @@
+"""The autograd-free training step (TensorVMSplit.train_step: render -> t2n_train_loss -> t2n_render_backward -> TVAdam) against the
+autograd form of the same step (text2nerf_main.py:547-590 restated with torch ops: MSE(rgb) + 0.005 MSE(depth) + 1e3 masked
+transmittance, TV terms in TVAdam), the fused loss kernel against torch's loss and autograd gradients, and deferred factor gradients
+that add up over several backward calls of one step (a batch rendered in chunks)."""
+import numpy as np
+import pytest
+import torch
+
+from text2nerf_amd import synth
+from tests.conftest import TINY
+from tests.test_hip_parity import dev, make_field
+
+pytestmark = pytest.mark.gpu
+
+
+def batch(seed=3, n=384):
+    g = np.random.Generator(np.random.PCG64(seed))
+    rays = torch.from_numpy(synth.frame_rays_np(16, 24, c2w=synth.look_pose(0.3, -0.1, (0.2, 0.1, -1.0))))[:n]
+    rgb_t = torch.from_numpy(g.uniform(0, 1, (rays.shape[0], 3)).astype(np.float32))
+    dep_t = torch.from_numpy(g.uniform(2, 7, (rays.shape[0],)).astype(np.float32))
+    return rays, rgb_t, dep_t
+
+
+def torch_loss(rgb, depth, w, z, rgb_t, dep_t):
+    from text2nerf_amd.losses import TransMittanceLoss_mask
+    depth = torch.where(torch.isnan(depth), torch.zeros_like(depth), depth)
+    mse = torch.mean((rgb - rgb_t) ** 2)
+    dl = torch.mean((depth - dep_t) ** 2)
+    tl = TransMittanceLoss_mask()(w, (z - dep_t[:, None] + 0.1) < 0)
+    return mse, dl, tl, mse + 0.005 * dl + 1e3 * tl
+
+
+def test_fused_loss_kernel_matches_torch_loss_and_autograd():
+    import ctypes as C
+    from text2nerf_amd import _lib
+    lib = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    R, N = 301, 37
+    rgb = torch.rand(R, 3, generator=g).to(d).requires_grad_(True)
+    depth = (torch.rand(R, generator=g) * 6 + 1).to(d)
+    depth[7] = float("nan")
+    depth.requires_grad_(True)
+    w = (torch.rand(R, N, generator=g) * 0.05).to(d).requires_grad_(True)
+    z = (torch.rand(R, N, generator=g).sort(1)[0] * 8).to(d)
+    rgb_t, dep_t = torch.rand(R, 3, generator=g).to(d), (torch.rand(R, generator=g) * 5 + 2).to(d)
+    mse, dl, tl, tot = torch_loss(rgb, depth, w, z, rgb_t, dep_t)
+    tot.backward()
+    d_rgb, d_depth, d_w, losses = torch.empty(R, 3, device=d), torch.empty(R, device=d), torch.empty(R, N, device=d), torch.empty(4, device=d)
+    ws = torch.empty(int(lib.t2n_train_loss_workspace_bytes(R)), dtype=torch.uint8, device=d)
+    with torch.cuda.device(d):
+        _lib.check(lib.t2n_train_loss(_lib.ptr(rgb.detach()), _lib.ptr(depth.detach()), _lib.ptr(w.detach()), _lib.ptr(z), _lib.ptr(rgb_t), _lib.ptr(dep_t),
+                                      R, N, 0.005, 1e3, 0.1, _lib.ptr(d_rgb), _lib.ptr(d_depth), _lib.ptr(d_w), _lib.ptr(losses), _lib.ptr(ws),
+                                      ws.numel(), _lib.current_stream_ptr(d)), "t2n_train_loss")
+    ref = torch.stack([mse, dl, tl, tot]).detach()
+    assert torch.allclose(losses, ref, rtol=2e-6, atol=1e-9), (losses, ref)
+    for got, want in ((d_rgb, rgb.grad), (d_depth, depth.grad), (d_w, w.grad)):
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-12
+    assert float(d_depth[7]) == 0.0        # the NaN depth got no gradient
+
+
+def step_autograd(f, opt, rays, rgb_t, dep_t, chunk=None):
+    from text2nerf_amd import OctreeRender_trilinear_fast
+    d = dev()
+    rgb, _, depth, w, z = OctreeRender_trilinear_fast(rays, f, chunk=chunk or rays.shape[0], N_samples=-1, white_bg=True, is_train=True, device=d)
+    mse, dl, tl, tot = torch_loss(rgb, depth, w, z, rgb_t.to(d), dep_t.to(d))
+    opt.zero_grad()
+    tot.backward()
+    return torch.stack([mse, dl, tl, tot]).detach()
+
+
+def test_train_step_equals_the_autograd_step(tiny_params):
+    from text2nerf_amd.optim import TVAdam
+    rays, rgb_t, dep_t = batch()
+    fa = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    fb = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    oa = TVAdam(fa.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fa)
+    ob = TVAdam(fb.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fb)
+    for it in range(3):
+        tv = [(fa.density_plane, 0.1), (fa.app_plane, 0.01)]
+        torch.manual_seed(100 + it)            # the jitter comes from the CPU default generator in both forms
+        la = step_autograd(fa, oa, rays, rgb_t, dep_t)
+        oa.step(tv=tv)
+        torch.manual_seed(100 + it)
+        lb = fb.train_step(rays, rgb_t, dep_t, ob, N_samples=-1, white_bg=True, tv=[(fb.density_plane, 0.1), (fb.app_plane, 0.01)])
+        assert torch.allclose(la, lb, rtol=1e-5, atol=1e-9), (it, la, lb)
+    for (k, a), (_, b) in zip(fa.state_dict().items(), fb.state_dict().items()):
+        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-7, k
+
+
+def test_deferred_factor_gradients_add_up_over_chunks(tiny_params):
+    """with TVAdam(field=...) a batch larger than `chunk` makes several backward nodes; every one of them must land in
+    the factor gradients (round 1 zeroed the buffer per backward call and kept only the last chunk's). Reference: the same chunked
+    step with reference-layout gradients (TVAdam without field: autograd accumulates .grad across the nodes)."""
+    from text2nerf_amd.optim import TVAdam
+    rays, rgb_t, dep_t = batch(n=320)
+    f1 = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    f2 = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    o1 = TVAdam(f1.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))                 # reference-layout gradients
+    o2 = TVAdam(f2.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=f2)       # deferred, channel-last
+    for it in range(2):
+        torch.manual_seed(9 + it)
+        step_autograd(f1, o1, rays, rgb_t, dep_t, chunk=96)           # 4 chunks -> 4 backward nodes
+        o1.step(tv=[(f1.density_plane, 0.1), (f1.app_plane, 0.01)])
+        torch.manual_seed(9 + it)
+        step_autograd(f2, o2, rays, rgb_t, dep_t, chunk=96)
+        assert float(f2.factor_grad_buffer().abs().max()) > 0
+        o2.step(tv=[(f2.density_plane, 0.1), (f2.app_plane, 0.01)])
+        assert float(f2.factor_grad_buffer().abs().max()) == 0.0      # consumed and zeroed by the step
+    for (k, a), (_, b) in zip(f1.state_dict().items(), f2.state_dict().items()):
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-7, k

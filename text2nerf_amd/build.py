@@ -11,7 +11,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libt2n_hip.so")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fno-fast-math", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-DNDEBUG"]
+         "-fno-fast-math", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-DNDEBUG",
+         "-Wl,--no-undefined"]   # an unresolved internal symbol must fail the build, not the first dlopen on the GPU box
 
 
 def sources():

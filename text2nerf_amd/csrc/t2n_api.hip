@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_ndc_rays(int H, int W, float focal, flo
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-Carve carve_workspace(int64_t rays, int n_samples, bool ctx) {
+Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat) {
     Carve c;
     c.list_cap = list_capacity(rays, n_samples);
     const size_t cap = (size_t)c.list_cap * kLists;
@@ -373,6 +373,7 @@ Carve carve_workspace(int64_t rays, int n_samples, bool ctx) {
     // one-kernel path
     const size_t worst_rows = cap + (size_t)kLists * 32, want_rows = (size_t)rays * 64 + 1024;
     c.feat_rows = (unsigned)(((worst_rows < want_rows ? worst_rows : want_rows) + 127) / 128 * 128);
+    if (!feat) c.feat_rows = 0;
     c.feat = o; o = align_up(o + (size_t)c.feat_rows * 32 * sizeof(float), 256);
     c.total = o;
     return c;
@@ -419,7 +420,7 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
         if (f->hbuf_app_plane[k]) (void)hipFree(f->hbuf_app_plane[k]);
         if (f->hbuf_app_line[k]) (void)hipFree(f->hbuf_app_line[k]);
     }
-    if (f->gbuf_all) (void)hipFree(f->gbuf_all);
+    if (f->gbuf_all && !f->gbuf_external) (void)hipFree(f->gbuf_all);
     if (f->buf_mlp) (void)hipFree(f->buf_mlp);
     if (f->buf_mlp_h) (void)hipFree(f->buf_mlp_h);
     if (f->buf_ws) (void)hipFree(f->buf_ws);
@@ -551,7 +552,7 @@ extern "C" size_t t2n_render_workspace_bytes(int64_t rays_per_launch, int n_samp
 
 extern "C" size_t t2n_render_workspace_bytes_ctx(int64_t n_rays, int n_samples) {
     if (n_rays <= 0 || n_samples <= 0) return 0;
-    return carve_workspace(n_rays, n_samples, true).total;
+    return carve_workspace(n_rays, n_samples, true, false).total;
 }
 
 extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
@@ -573,17 +574,17 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     const bool tiles = (flags & T2N_FLAG_COHERENT) != 0 && !ndc && !keep && !(flags & T2N_FLAG_TRAIN) && f->frame_w >= 8 &&
                        n_rays % f->frame_w == 0 && n_rays / f->frame_w >= 8;
     if (keep) {
-        if (carve_workspace(n_rays, n_samples, true).total > workspace_bytes || (uint64_t)list_capacity(n_rays, n_samples) * kLists > 0x7fffffffull) {
+        if (carve_workspace(n_rays, n_samples, true, false).total > workspace_bytes || (uint64_t)list_capacity(n_rays, n_samples) * kLists > 0x7fffffffull) {
             set_error("t2n_render_forward: KEEP_CTX needs the whole call in one launch (workspace %zu B < %zu B)", workspace_bytes,
-                      carve_workspace(n_rays, n_samples, true).total);
+                      carve_workspace(n_rays, n_samples, true, false).total);
             return T2N_ERR_WORKSPACE;
         }
         if (!weights || !z_vals) { set_error("t2n_render_forward: KEEP_CTX needs weights and z_vals materialised"); return T2N_ERR_INVALID; }
     }
     // largest sub-launch whose worst case (every sample an appearance sample) fits the workspace
     int64_t per = n_rays;
-    while (per > 1 && carve(per, n_samples).total > workspace_bytes) per = (per + 1) / 2;
-    if (carve(per, n_samples).total > workspace_bytes) { set_error("t2n_render_forward: workspace %zu B too small", workspace_bytes); return T2N_ERR_WORKSPACE; }
+    while (!keep && per > 1 && carve(per, n_samples).total > workspace_bytes) per = (per + 1) / 2;
+    if (!keep && carve(per, n_samples).total > workspace_bytes) { set_error("t2n_render_forward: workspace %zu B too small", workspace_bytes); return T2N_ERR_WORKSPACE; }
     while ((uint64_t)list_capacity(per, n_samples) * kLists > 0x7fffffffull) per = (per + 1) / 2;   // int slots
     if (tiles && per < n_rays) {   // sub-launches must cover whole 8-row bands of the image
         const int64_t band = (int64_t)8 * f->frame_w;
@@ -593,7 +594,7 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     char* ws = (char*)workspace;
     for (int64_t off = 0; off < n_rays; off += per) {
         const int64_t cnt = (n_rays - off) < per ? (n_rays - off) : per;
-        const Carve c = carve_workspace(per, n_samples, true);
+        const Carve c = carve_workspace(per, n_samples, true, !keep);
         RenderLaunch L;
         L.rays = rays + off * ray_stride; L.n_rays = cnt; L.ray_stride = ray_stride; L.n_samples = n_samples; L.flags = flags;
         L.jitter = (jitter && !ndc) ? jitter + off : jitter;     // NDC: one table for every sub-launch
@@ -612,6 +613,7 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         if (tiles) {
             if ((rc = launch_march_tiles(f, L, f->frame_w, (int)(cnt / f->frame_w), (float*)(ws + c.sigma), (float4*)(ws + c.scratch), s))) return rc;
         } else if ((rc = launch_march(f, L, s))) return rc;
+        if (keep && (rc = ctx_counts_post(workspace, L.counters, s))) return rc;   // the backward sizes itself from these without draining the stream
         if (head_is_generic(f->desc.shading)) {
             // general head path: the appearance-row count is needed on the host to size the activation scratch (one stream
             // sync per sub-launch; the fused MLP_Fea_noview head needs none)

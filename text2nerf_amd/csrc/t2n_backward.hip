@@ -1063,22 +1063,33 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
     return c;
 }
 
-static int ensure_grad_buffers(t2n_field* f) {
-    if (f->gbuf_all) return T2N_OK;
+// the 12 channel-last gradient buffers are slices of ONE allocation (density planes, density lines, appearance planes, appearance
+// lines; 256-B aligned slices): one memset, one in-place all-reduce
+static size_t grad_layout(const t2n_field* f, size_t (&off)[12]) {
     const int* g = f->desc.grid;
-    size_t off[12], o = 0;
+    size_t o = 0;
     for (int k = 0; k < 3; ++k) {
         const size_t HW = (size_t)g[mat1(k)] * g[mat0(k)], L = (size_t)g[vecm(k)];
         const size_t sz[4] = {HW * 16 * 4, L * 16 * 4, HW * 48 * 4, L * 48 * 4};
         for (int q = 0; q < 4; ++q) { off[q * 3 + k] = o; o += (sz[q] + 255) / 256 * 256; }
     }
-    T2N_HIP(hipMalloc((void**)&f->gbuf_all, o));
-    f->gbuf_bytes = o;
+    return o;
+}
+static void grad_slices(t2n_field* f, const size_t (&off)[12]) {
     char* b = (char*)f->gbuf_all;
     for (int k = 0; k < 3; ++k) {
         f->gbuf_den_plane[k] = (float*)(b + off[0 + k]); f->gbuf_den_line[k] = (float*)(b + off[3 + k]);
         f->gbuf_app_plane[k] = (float*)(b + off[6 + k]); f->gbuf_app_line[k] = (float*)(b + off[9 + k]);
     }
+}
+static int ensure_grad_buffers(t2n_field* f) {
+    if (f->gbuf_all) return T2N_OK;
+    size_t off[12];
+    const size_t o = grad_layout(f, off);
+    T2N_HIP(hipMalloc((void**)&f->gbuf_all, o));
+    f->gbuf_bytes = o;
+    f->gbuf_external = false;
+    grad_slices(f, off);
     return T2N_OK;
 }
 
@@ -1108,12 +1119,40 @@ static void launch_gemm_nn(const float* IN, int ldin, const float* W, int ldw, l
 
 using namespace t2n;
 
+// The appearance counts of a KEEP_CTX forward travel to pinned host memory right behind the march kernel (ctx_counts_post, called by
+// t2n_render_forward) with an event behind the copy: the backward waits for THAT event, not for the stream — the loss ops queued
+// between forward and backward keep the GPU busy while the host sizes and launches the backward. Slots are matched by workspace
+// pointer; a forward from another library build / an evicted slot falls back to the stream-draining read.
+struct CtxSlot { const void* ws; hipEvent_t ev; unsigned* host; bool valid; };
+static CtxSlot g_ctx[8];
+static unsigned g_ctx_next = 0;
+int t2n::ctx_counts_post(const void* ws, const unsigned* counters_dev, hipStream_t s) {
+    for (auto& q : g_ctx) if (q.valid && q.ws == ws) q.valid = false;
+    CtxSlot& c = g_ctx[g_ctx_next++ % 8];
+    if (!c.host) {
+        T2N_HIP(hipHostMalloc((void**)&c.host, sizeof(unsigned) * kLists * kCounterStride, hipHostMallocDefault));
+        T2N_HIP(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+    }
+    c.ws = ws;
+    T2N_HIP(hipMemcpyAsync(c.host, counters_dev, sizeof(unsigned) * kLists * kCounterStride, hipMemcpyDeviceToHost, s));
+    T2N_HIP(hipEventRecord(c.ev, s));
+    c.valid = true;
+    return T2N_OK;
+}
+
 static int read_counts(const void* fwd_ws, int64_t n_rays, int n_samples, hipStream_t s, unsigned counts[kLists], TilePrefix* tp,
                        int64_t* rows) {
-    const Carve c = carve_workspace(n_rays, n_samples, true);
+    const Carve c = carve_workspace(n_rays, n_samples, true, false);
     unsigned raw[kLists * kCounterStride];
-    T2N_HIP(hipMemcpyAsync(raw, (const char*)fwd_ws + c.counters, sizeof(raw), hipMemcpyDeviceToHost, s));
-    T2N_HIP(hipStreamSynchronize(s));
+    const CtxSlot* slot = nullptr;
+    for (const auto& q : g_ctx) if (q.valid && q.ws == fwd_ws) slot = &q;
+    if (slot) {
+        T2N_HIP(hipEventSynchronize(slot->ev));
+        memcpy(raw, slot->host, sizeof(raw));
+    } else {
+        T2N_HIP(hipMemcpyAsync(raw, (const char*)fwd_ws + c.counters, sizeof(raw), hipMemcpyDeviceToHost, s));
+        T2N_HIP(hipStreamSynchronize(s));
+    }
     for (int l = 0; l < kLists; ++l) counts[l] = raw[l * kCounterStride];
     unsigned t = 0;
     for (int l = 0; l < kLists; ++l) {
@@ -1155,7 +1194,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     struct ZtabScope { t2n_field* f; ~ZtabScope() { f->dev.ztab = nullptr; } } ztab_scope{f};
     f->dev.ztab = (flags & T2N_FLAG_NDC) ? jitter : nullptr;
     if (n_samples > 1024) { set_error("t2n_render_backward: n_samples %d > 1024", n_samples); return T2N_ERR_UNSUPPORTED; }
-    const Carve c = carve_workspace(n_rays, n_samples, true);
+    const Carve c = carve_workspace(n_rays, n_samples, true, false);
     if (c.total > fwd_workspace_bytes) { set_error("t2n_render_backward: forward workspace too small"); return T2N_ERR_WORKSPACE; }
     hipStream_t s = (hipStream_t)stream;
     unsigned counts[kLists];
@@ -1189,7 +1228,9 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     const unsigned* counters = (const unsigned*)(fw + c.counters);
 
     const int* gr = f->desc.grid;
-    T2N_HIP(hipMemsetAsync(f->gbuf_all, 0, f->gbuf_bytes, s));
+    // a library-owned gradient buffer holds the gradients of THIS call; a caller-owned one (t2n_field_set_grad_buffer) accumulates
+    // and is zeroed by its owner
+    if (!f->gbuf_external) T2N_HIP(hipMemsetAsync(f->gbuf_all, 0, f->gbuf_bytes, s));
     T2N_HIP(hipMemsetAsync(go, 0, (size_t)rows_alloc * 16, s));
 
     // 1. appearance forward recompute with activations kept
@@ -1321,6 +1362,108 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         if (g->app_plane[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((HW + 63) / 64)), dim3(256), 0, s, (const float*)f->gbuf_app_plane[k], g->app_plane[k], 48, HW);
         if (g->app_line[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((L + 63) / 64)), dim3(256), 0, s, (const float*)f->gbuf_app_line[k], g->app_line[k], 48, L);
     }
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" size_t t2n_field_grad_buffer_bytes(const t2n_field* f) {
+    if (!f) return 0;
+    size_t off[12];
+    return grad_layout(f, off);
+}
+
+extern "C" int t2n_field_set_grad_buffer(t2n_field* f, void* buf, size_t bytes) {
+    if (!f) { set_error("t2n_field_set_grad_buffer: NULL field"); return T2N_ERR_INVALID; }
+    size_t off[12];
+    const size_t need = grad_layout(f, off);
+    if (!buf) {   // back to a library-owned buffer (allocated on the next backward)
+        if (f->gbuf_external) { f->gbuf_all = nullptr; f->gbuf_bytes = 0; f->gbuf_external = false; }
+        return T2N_OK;
+    }
+    if (bytes < need || ((uintptr_t)buf & 255u)) { set_error("t2n_field_set_grad_buffer: needs %zu bytes, 256-B aligned", need); return T2N_ERR_INVALID; }
+    if (f->gbuf_all && !f->gbuf_external) (void)hipFree(f->gbuf_all);
+    f->gbuf_all = (float*)buf; f->gbuf_bytes = need; f->gbuf_external = true;
+    grad_slices(f, off);
+    return T2N_OK;
+}
+
+// ---- the driver's loss (text2nerf_main.py:559-575) as one pass over the render outputs --------------------------------------------
+// loss = mean((rgb - rgb_t)^2) + w_depth mean((depth - depth_t)^2) + w_trans mean_r(m_r^2), m_r = mean_n(w[r,n] [z[r,n] - depth_t[r] + delta < 0])
+// (TransMittanceLoss_mask, utils.py:67-80, target 0), NaN depths count as 0 with no gradient (:559-560). One wave per ray: the
+// upstream gradients d_rgb, d_depth, d_weights of t2n_render_backward leave in the same pass; per-workgroup partial sums, then one
+// workgroup adds them in a fixed order (deterministic).
+namespace t2n {
+struct LossArgs {
+    const float* rgb; const float* depth; const float* w; const float* z; const float* rgb_t; const float* depth_t;
+    long long R; int N; float w_depth, w_trans, delta;
+    float* d_rgb; float* d_depth; float* d_w; float* part; float* losses; unsigned nblocks;
+};
+__global__ __launch_bounds__(256) void k_train_loss(const LossArgs a) {
+    __shared__ float red[4][3];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const long long r = (long long)blockIdx.x * 4 + wid;
+    float e_rgb = 0.f, e_dep = 0.f, e_tr = 0.f;
+    if (r < a.R) {
+        const float dt = a.depth_t[r];
+        const float* wr = a.w + r * a.N;
+        const float* zr = a.z + r * a.N;
+        float m = 0.f;
+        for (int n = lane; n < a.N; n += 64) m += ((zr[n] - dt) + a.delta < 0.f) ? wr[n] : 0.f;
+        m = wave_sum(m) / (float)a.N;
+        const float gw = (2.f * a.w_trans * m / (float)a.R) / (float)a.N;
+        float* dwr = a.d_w + r * a.N;
+        for (int n = lane; n < a.N; n += 64) dwr[n] = ((zr[n] - dt) + a.delta < 0.f) ? gw : 0.f;
+        if (lane < 3) {
+            const float d = a.rgb[r * 3 + lane] - a.rgb_t[r * 3 + lane];
+            a.d_rgb[r * 3 + lane] = 2.f * d / (3.f * (float)a.R);
+            e_rgb = d * d;
+        }
+        e_rgb = wave_sum(e_rgb);
+        float dep = a.depth[r];
+        const bool bad = dep != dep;
+        if (bad) dep = 0.f;
+        const float dd = dep - dt;
+        if (lane == 0) a.d_depth[r] = bad ? 0.f : 2.f * a.w_depth * dd / (float)a.R;
+        e_dep = dd * dd;
+        e_tr = m * m;
+    }
+    if (lane == 0) { red[wid][0] = e_rgb; red[wid][1] = e_dep; red[wid][2] = e_tr; }
+    __syncthreads();
+    if (threadIdx.x < 3) a.part[(size_t)blockIdx.x * 3 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_train_loss_reduce(const LossArgs a) {
+    __shared__ float red[256][3];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (unsigned b = threadIdx.x; b < a.nblocks; b += 256) { s0 += a.part[(size_t)b * 3]; s1 += a.part[(size_t)b * 3 + 1]; s2 += a.part[(size_t)b * 3 + 2]; }
+    red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1; red[threadIdx.x][2] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[threadIdx.x][0] += red[threadIdx.x + o][0]; red[threadIdx.x][1] += red[threadIdx.x + o][1]; red[threadIdx.x][2] += red[threadIdx.x + o][2]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mse = red[0][0] / (3.f * (float)a.R), dl = red[0][1] / (float)a.R, tl = red[0][2] / (float)a.R;
+        a.losses[0] = mse; a.losses[1] = dl; a.losses[2] = tl; a.losses[3] = mse + a.w_depth * dl + a.w_trans * tl;
+    }
+}
+}  // namespace t2n
+
+extern "C" size_t t2n_train_loss_workspace_bytes(int64_t n_rays) { return n_rays > 0 ? (size_t)((n_rays + 3) / 4) * 3 * sizeof(float) : 0; }
+
+extern "C" int t2n_train_loss(const float* rgb, const float* depth, const float* weights, const float* z_vals, const float* rgb_t,
+                              const float* depth_t, int64_t n_rays, int n_samples, float w_depth, float w_trans, float delta, float* d_rgb,
+                              float* d_depth, float* d_weights, float* losses, void* workspace, size_t workspace_bytes, t2n_stream stream) {
+    if (!rgb || !depth || !weights || !z_vals || !rgb_t || !depth_t || !d_rgb || !d_depth || !d_weights || !losses || !workspace || n_rays <= 0 || n_samples <= 0) {
+        set_error("t2n_train_loss: bad argument");
+        return T2N_ERR_INVALID;
+    }
+    if (workspace_bytes < t2n_train_loss_workspace_bytes(n_rays)) { set_error("t2n_train_loss: workspace too small"); return T2N_ERR_WORKSPACE; }
+    LossArgs a;
+    a.rgb = rgb; a.depth = depth; a.w = weights; a.z = z_vals; a.rgb_t = rgb_t; a.depth_t = depth_t; a.R = n_rays; a.N = n_samples;
+    a.w_depth = w_depth; a.w_trans = w_trans; a.delta = delta; a.d_rgb = d_rgb; a.d_depth = d_depth; a.d_w = d_weights;
+    a.part = (float*)workspace; a.losses = losses; a.nblocks = (unsigned)((n_rays + 3) / 4);
+    hipLaunchKernelGGL(k_train_loss, dim3(a.nblocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_train_loss_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

@@ -84,6 +84,7 @@ struct t2n_field {
     float* gbuf_den_line[3] = {nullptr, nullptr, nullptr};
     float* gbuf_app_plane[3] = {nullptr, nullptr, nullptr};
     float* gbuf_app_line[3] = {nullptr, nullptr, nullptr};
+    bool gbuf_external = false;   // caller-owned (t2n_field_set_grad_buffer): never freed, never zeroed by the backward
     float* gbuf_all = nullptr; size_t gbuf_bytes = 0;   // the 12 gradient buffers are slices of ONE allocation (one memset per backward)
     t2n_field_params params_ref;   // reference-layout parameter pointers of the last upload (backward reads W^T operands)
     bool uploaded = false;
@@ -156,8 +157,9 @@ int launch_head_in_bwd(t2n_field* f, const float* gx, const float* feat32, long 
 
 // forward-workspace carve shared by forward and backward (t2n_api.hip)
 struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, feat, total; unsigned list_cap, feat_rows; };
-Carve carve_workspace(int64_t rays, int n_samples, bool ctx);   // ctx: also room for sigma [rays,N] and rgb_raw [rays]
+Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat = true);   // ctx: also room for sigma [rays,N] and rgb_raw [rays]; feat: feature rows (last region: the other offsets do not depend on it; KEEP_CTX calls carve without)
 int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s);
+int ctx_counts_post(const void* ws, const unsigned* counters_dev, hipStream_t s);   // KEEP_CTX forward: counts -> pinned host copy + event (t2n_backward.hip)
 // Activation rows the forward keeps for the backward when the KEEP_CTX workspace is larger than the context itself (the
 // caller's guess of the appearance-row count; 1728 B per row): x144 [rows,144], feat32 [rows,32], h0 / h1 [rows,128] behind
 // the carved context. rows == 0: nothing kept (the backward re-runs the appearance forward).

@@ -1,6 +1,7 @@
 """The two small loss terms the training step of text2nerf_main.py:563-586 applies to the renderer's outputs and
 parameters (utils.py:67-80, 488-504), restated so the C3-shaped benchmark step and users of the drop-in have them next to
-the renderer. Plain torch ops (SURVEY.md §8 f-1 lists a fused TV+Adam kernel as the next row)."""
+the renderer. Plain torch ops; the fused forms are optim.TVAdam (TV + Adam) and TensorVMSplit.train_step / t2n_train_loss
+(the render loss and its gradients in one kernel)."""
 import torch
 import torch.nn as nn
 

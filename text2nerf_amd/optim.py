@@ -29,7 +29,8 @@ def _bump_version(t):
 class TVAdam(torch.optim.Optimizer):
     """``field=tensorf`` (a TensorVMSplit with fp32 factor storage, single process): the 12 plane / line tensors are stepped
     where their data already is — the backward leaves their gradients in the library's channel-last buffers
-    (``tensorf.defer_factor_grads``: ``.grad`` of those parameters stays None, ONE backward per step), and
+    (``tensorf.defer_factor_grads``: ``.grad`` of those parameters stays None; several backward calls before a step — a batch
+    rendered in chunks, gradient accumulation — add up in ``tensorf.factor_grad_buffer()``, which ``step`` / ``zero_grad`` zero), and
     ``t2n_field_tv_adam_step`` applies TV + Adam on the device's channel-last copies, writing the new values into the
     nn.Parameters as well. Same per-element arithmetic; the Adam moments of those tensors live channel-last in
     ``state[p]["exp_avg_cl"]`` / ``["exp_avg_sq_cl"]``. Without ``field`` every tensor takes the reference-layout kernels."""
@@ -51,7 +52,13 @@ class TVAdam(torch.optim.Optimizer):
         fac = ps[:12]
         if getattr(f, "_deferred_grad_key", None) is None or f._deferred_grad_key != f._uploaded_key:
             raise _lib.T2NError("TVAdam(field=...): no device-side factor gradients for the current parameters "
-                                "(call backward once, with tensorf.defer_factor_grads still set, before every step)")
+                                "(call backward, with tensorf.defer_factor_grads still set, before every step)")
+        f.factor_grad_buffer()
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not getattr(f, "_gbuf_reduced", False):
+            raise _lib.T2NError("TVAdam(field=...): more than one rank — all-reduce the device-side factor gradients first "
+                                "(parallel.allreduce_gradients(params, field=tensorf)); stepping from local gradients would let the "
+                                "ranks drift apart")
         tv_d = tv_a = 0.0
         for planes, weight in tv:
             if planes is f.density_plane:
@@ -83,8 +90,13 @@ class TVAdam(torch.optim.Optimizer):
         for p in fac:
             _bump_version(p)
         f._device_factor_key = tuple((p.data_ptr(), p._version) for p in fac)   # the device copies are these values
-        f._deferred_grad_key = None
+        f.zero_factor_grads()      # consumed: the next step's backward calls accumulate from zero
         return {id(p) for p in fac}
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=set_to_none)
+        if self.field is not None:
+            self.field.zero_factor_grads()
 
     @torch.no_grad()
     def step(self, tv=()):

@@ -233,6 +233,8 @@ class TensorVMSplit(nn.Module):
         self.factor_storage = os.environ.get("T2N_FACTOR_STORAGE", "fp32")
         self._handle = None
         self._uploaded_key = None
+        self._gbuf = None
+        self._gbuf_dirty = False
         self.last_stats = None
 
         if shadingMode not in _lib.SHADE_IDS:
@@ -420,6 +422,28 @@ class TensorVMSplit(nn.Module):
         return type(self)._kernel_views is TensorVMSplit._kernel_views and type(self)._autograd_params is TensorVMSplit._autograd_params \
             and self.factor_storage == "fp32"
 
+    def factor_grad_buffer(self):
+        """The channel-last gradients of the 12 plane / line tensors as ONE flat fp32 tensor owned here and handed to the native
+        field (t2n_field_set_grad_buffer): deferred backward calls ACCUMULATE into it — a batch split into chunks, gradient
+        accumulation, a data-parallel all-reduce in place (parallel.allreduce_gradients(field=...)) — and TVAdam(field=...) consumes
+        and zeroes it."""
+        h = self.sync_params()
+        if getattr(self, "_gbuf", None) is None:
+            lib = _lib.load()
+            dev = self.basis_mat.weight.device
+            n = int(lib.t2n_field_grad_buffer_bytes(h))
+            self._gbuf = torch.zeros(n // 4, device=dev, dtype=torch.float32)
+            _lib.check(lib.t2n_field_set_grad_buffer(h, _lib.ptr(self._gbuf), n), "t2n_field_set_grad_buffer")
+            self._gbuf_dirty = False
+        return self._gbuf
+
+    def zero_factor_grads(self):
+        if getattr(self, "_gbuf", None) is not None and self._gbuf_dirty:
+            self._gbuf.zero_()
+        self._gbuf_dirty = False
+        self._gbuf_reduced = False
+        self._deferred_grad_key = None
+
     def sync_params(self, force=False):
         """Create the native field on first use and re-upload when any parameter changed (in-place optimiser steps
         and load_state_dict bump tensor versions)."""
@@ -597,6 +621,8 @@ class TensorVMSplit(nn.Module):
             _lib.load().t2n_field_destroy(self._handle)
             self._handle = None
         self._uploaded_key = None
+        self._gbuf = None            # channel-last factor gradients: sized by the grid
+        self._gbuf_dirty = False
 
     @torch.no_grad()
     def compute_alpha(self, xyz_locs, length=1):
@@ -785,6 +811,92 @@ class TensorVMSplit(nn.Module):
         if keep_ctx:
             return rgb, depth, z, w, ws
         return rgb, depth, z, w
+
+    def _backward_raw(self, rays, jitter, N, flags, ws, d_rgb, d_depth, d_w, head_grads=None):
+        """t2n_render_backward for a KEEP_CTX forward (workspace `ws`): returns the 19 gradient tensors in autograd order (None for the
+        12 factor tensors in deferred mode: those accumulate in factor_grad_buffer()). `head_grads`: optional preallocated, zeroed
+        gradient tensors of the 7 head tensors (train_step reuses one flat buffer)."""
+        lib = _lib.load()
+        dev = rays.device
+        params = self._autograd_params()
+        # deferred mode: the 12 plane / line gradients stay channel-last in the field's gradient buffer (no layout pass, no
+        # zero-filled 69.6 MB of gradient tensors); optim.TVAdam(field=...) steps from there
+        defer = bool(getattr(self, "defer_factor_grads", False)) and self.supports_deferred_factor_grads()
+        if defer:
+            self.factor_grad_buffer()     # caller-owned: this backward accumulates into it (chunked batches add up)
+            self._gbuf_dirty = True
+        if head_grads is not None and defer:
+            grads = [None] * 12 + list(head_grads)
+        else:
+            grads = [None if (defer and i < 12) else torch.zeros_like(p) for i, p in enumerate(params)]
+        gs = self._param_struct(self._kernel_views(grads), _lib.FieldGrads)
+        R = rays.shape[0]
+        d_rgb = torch.zeros(R, 3, device=dev) if d_rgb is None else d_rgb.contiguous().float()
+        d_depth = torch.zeros(R, device=dev) if d_depth is None else d_depth.contiguous().float()
+        d_w = None if d_w is None else d_w.contiguous().float()
+        st = _lib.current_stream_ptr(dev)
+        with torch.cuda.device(dev):
+            rows = C.c_int64(0)
+            # the counts reached pinned host memory behind the forward's march kernel: this waits for that copy's event, not
+            # for the stream (the loss kernels queued since keep running)
+            _lib.check(lib.t2n_render_ctx_rows(_lib.ptr(ws), R, N, st, C.byref(rows)), "t2n_render_ctx_rows")
+            # shared grow-only scratch (geometric growth): the row count changes every iteration, and a fresh
+            # multi-GB torch.empty per backward would hit hipMalloc each time
+            self._ctx_rows_hint = (int(rows.value * 1.25) + 95) // 32 * 32 if self.keep_activation_rows else 0
+            need = int(lib.t2n_backward_workspace_bytes(self._handle, rows.value, R, N))
+            bws = workspace(dev, need) if _WORKSPACE.get(str(dev)) is not None and _WORKSPACE[str(dev)].numel() >= need \
+                else workspace(dev, int(need * 1.5))
+            _lib.check(lib.t2n_render_backward(self._handle, _lib.ptr(rays), R, rays.shape[1], N, flags | FLAG_KEEP_CTX,
+                                               _lib.ptr(jitter), _lib.ptr(d_rgb), _lib.ptr(d_depth), _lib.ptr(d_w),
+                                               C.byref(gs), _lib.ptr(ws), ws.numel(), _lib.ptr(bws), bws.numel(),
+                                               st), "t2n_render_backward")
+        self._deferred_grad_key = self._uploaded_key if defer else None   # which parameters the device-side gradients belong to
+        return grads
+
+    def train_step(self, rays, rgb_target, depth_target, optimizer, N_samples=-1, white_bg=True, w_depth=0.005, w_trans=1e3, delta=0.1,
+                   tv=(), all_reduce=None):
+        """One optimisation step of text2nerf_main.py:547-590 without the autograd graph: render (train mode, CPU-generator jitter
+        like models/tensorBase.py:313-317) -> the driver's loss as ONE kernel that emits d_rgb / d_depth / d_weights
+        (t2n_train_loss) -> t2n_render_backward -> optimizer.step(). `optimizer`: optim.TVAdam(field=self) (TV terms via `tv`, as
+        in TVAdam.step); `all_reduce`: optional callable run between backward and step (data-parallel:
+        lambda: parallel.allreduce_gradients(params, field=self)). Returns the device tensor [mse, depth loss, transmittance loss,
+        total] of this batch (no host synchronisation). Same arithmetic as the autograd path: tests/test_train_step.py."""
+        lib = _lib.load()
+        dev = self.basis_mat.weight.device
+        rays = to_device_async(rays, dev)
+        if rays.dtype != torch.float32 or not rays.is_contiguous():
+            rays = rays.contiguous().float()
+        R = rays.shape[0]
+        N = int(N_samples) if N_samples > 0 else self.nSamples
+        jitter = to_device_async(torch.rand(R, 1), dev).reshape(-1).contiguous()
+        flags = FLAG_TRAIN | (FLAG_ADD_BG if (white_bg or bool(torch.rand((1,)) < 0.5)) else 0)
+        rgb_t = to_device_async(rgb_target, dev).contiguous().float()
+        dep_t = to_device_async(depth_target, dev).contiguous().float()
+        head = self._autograd_params()[12:]
+        if getattr(self, "_head_flat", None) is None or self._head_flat.numel() != sum(p.numel() for p in head):
+            self._head_flat = torch.zeros(sum(p.numel() for p in head), device=dev)
+        with torch.no_grad():
+            rgb, depth, z, w, ws = self._render_raw(rays, N, flags, jitter, True, keep_ctx=True)
+            d_rgb, d_depth, d_w = torch.empty_like(rgb), torch.empty_like(depth), torch.empty_like(w)
+            losses = torch.empty(4, device=dev)
+            lws = torch.empty(int(lib.t2n_train_loss_workspace_bytes(R)), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.t2n_train_loss(_lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(w), _lib.ptr(z), _lib.ptr(rgb_t), _lib.ptr(dep_t), R, N,
+                                              float(w_depth), float(w_trans), float(delta), _lib.ptr(d_rgb), _lib.ptr(d_depth), _lib.ptr(d_w),
+                                              _lib.ptr(losses), _lib.ptr(lws), lws.numel(), _lib.current_stream_ptr(dev)), "t2n_train_loss")
+            # head gradients: views of one flat buffer (one memset), installed as .grad of the 7 head tensors
+            self._head_flat.zero_()
+            views, off = [], 0
+            for p in head:
+                views.append(self._head_flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            grads = self._backward_raw(rays, jitter, N, flags, ws, d_rgb, d_depth, d_w, head_grads=views)
+            for p, g in zip(self._autograd_params(), grads):
+                p.grad = g
+            if all_reduce is not None:
+                all_reduce()
+            optimizer.step(tv=tv) if tv else optimizer.step()
+        return losses
 
     def stats(self):
         """Counters of the last render call (one device->host copy): evaluated / appearance samples, overflow."""
@@ -989,32 +1101,6 @@ class _RenderFn(torch.autograd.Function):
         rays, jitter = ctx.saved_tensors
         if field._uploaded_key != ctx.key:
             raise T2NError("parameters changed between forward and backward")
-        lib = _lib.load()
-        dev = rays.device
-        params = field._autograd_params()
-        # deferred mode: the 12 plane / line gradients stay in the library's channel-last buffers (no layout pass, no
-        # zero-filled 69.6 MB of gradient tensors); optim.TVAdam(field=...) steps from there. ONE backward per step.
-        defer = bool(getattr(field, "defer_factor_grads", False)) and field.supports_deferred_factor_grads()
-        grads = [None if (defer and i < 12) else torch.zeros_like(p) for i, p in enumerate(params)]
-        gs = field._param_struct(field._kernel_views(grads), _lib.FieldGrads)
-        R = rays.shape[0]
-        d_rgb = torch.zeros(R, 3, device=dev) if d_rgb is None else d_rgb.contiguous().float()
-        d_depth = torch.zeros(R, device=dev) if d_depth is None else d_depth.contiguous().float()
-        d_w = None if d_w is None else d_w.contiguous().float()
-        st = _lib.current_stream_ptr(dev)
-        with torch.cuda.device(dev):
-            rows = C.c_int64(0)
-            _lib.check(lib.t2n_render_ctx_rows(_lib.ptr(ctx.ws), R, ctx.N, st, C.byref(rows)), "t2n_render_ctx_rows")
-            # shared grow-only scratch (geometric growth): the row count changes every iteration, and a fresh
-            # multi-GB torch.empty per backward would hit hipMalloc each time
-            field._ctx_rows_hint = (int(rows.value * 1.25) + 95) // 32 * 32 if field.keep_activation_rows else 0
-            need = int(lib.t2n_backward_workspace_bytes(field._handle, rows.value, R, ctx.N))
-            bws = workspace(dev, need) if _WORKSPACE.get(str(dev)) is not None and _WORKSPACE[str(dev)].numel() >= need \
-                else workspace(dev, int(need * 1.5))
-            _lib.check(lib.t2n_render_backward(field._handle, _lib.ptr(rays), R, rays.shape[1], ctx.N, ctx.flags,
-                                               _lib.ptr(jitter), _lib.ptr(d_rgb), _lib.ptr(d_depth), _lib.ptr(d_w),
-                                               C.byref(gs), _lib.ptr(ctx.ws), ctx.ws.numel(), _lib.ptr(bws), bws.numel(),
-                                               st), "t2n_render_backward")
+        grads = field._backward_raw(rays, jitter, ctx.N, ctx.flags, ctx.ws, d_rgb, d_depth, d_w)
         ctx.ws = None
-        field._deferred_grad_key = field._uploaded_key if defer else None   # which parameters the device-side gradients belong to
         return (None, None, None, None, None) + tuple(grads)
