@@ -58,6 +58,16 @@ MFMA_F32_PEAK_TF = 157.3
 MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
+def reference_poses(name, n=None):
+    """Camera poses captured from the reference's own generators (tests/golden/poses.npz <- tests/golden/make_golden_poses.py:
+    `local_fixed` = get_local_fixed_poses2, `circle_train_96` = cam_traj_gen circle, dataLoader/scene_util.py); repeated cyclically
+    when more than the fixture holds are asked for."""
+    P = np.load(os.path.join(ROOT, "tests", "golden", "poses.npz"))[name].astype(np.float32)
+    if n is None or n <= P.shape[0]:
+        return P if n is None else P[:n]
+    return P[np.arange(n) % P.shape[0]]
+
+
 def build_field(dev, scene="S1-soft", seed=0, grid=300):
     from text2nerf_amd import TensorVMSplit, synth
     aabb = [[-8.0] * 3, [8.0] * 3]
@@ -134,7 +144,7 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_ste
     from text2nerf_amd.losses import TVLoss, TransMittanceLoss_mask
     field, params, aabb = build_field(dev)
     n_samples = min(int(1e6), int(synth.cal_n_samples([300] * 3, 1.0) / 2))          # text2nerf_main.py:439 -> 259
-    poses = synth.local_fixed_like_poses(9)
+    poses = reference_poses("local_fixed")      # the 9 training poses of the driver's default trajectory (scene_gen.py:242)
     allrays = torch.from_numpy(np.concatenate([synth.frame_rays_np(512, 512, c2w=p) for p in poses]))   # CPU, like the driver
     # targets: the scene's own colours/depths (eval render of every 4th ray, nearest-assigned) + noise, so that the step
     # has realistic gradients but the field stays a scene; i.i.d. uniform targets turn the field into fog within ~10
@@ -308,7 +318,7 @@ def main():
     # pixel tile share per-step dot-product tables); results stay within the parity tolerances of the per-ray marcher
     field.frame_width = 0 if args.per_ray_marcher else W
     N = field.nSamples
-    poses = synth.local_fixed_like_poses(max(world, 9))
+    poses = reference_poses("local_fixed", max(world, 9))
     pose = poses[rank % len(poses)] if world > 1 and not c4 else np.eye(4, dtype=np.float32)
     f = float(max(H, W))
     rays = generate_rays(H, W, [f, f, W // 2, H // 2], pose, device=dev)   # resident in HBM before the timed region
@@ -509,6 +519,22 @@ def main():
                 out["config"]["bf16_factor_storage_ms_per_step"] = timed_frames(args.steps)
                 out["config"]["bf16_factor_storage_note"] = "footprint only (34.8 MB instead of 69.6 MB); same kernels, 8-B gathers"
                 field.factor_storage = "fp32"
+            # BASELINE configs[4] on one GPU: the 48 training views of the reference's circle trajectory (cam_traj_gen, fixture), bf16
+            # factor storage, rays generated on the device, one frame per view
+            try:
+                from text2nerf_amd import render_views
+                c5 = reference_poses("circle_train_96")
+                field.factor_storage = "bf16"
+                render_views(field, c5[:2], [f, f, W // 2, H // 2], H, W)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                render_views(field, c5, [f, f, W // 2, H // 2], H, W)
+                torch.cuda.synchronize()
+                out["config"]["c5_circle_48_views_bf16_ms_per_view"] = (time.perf_counter() - t0) / c5.shape[0] * 1e3
+            except Exception as e:  # noqa: BLE001
+                out["config"]["c5_circle_error"] = repr(e)[:200]
+            field.factor_storage = "fp32"
+            field.frame_width = 0 if args.per_ray_marcher else W
             if not args.weights:
                 # the reference's actual return: weights and z_vals [R, N] materialised (renderer.py:39-42), 2.65 GB per frame
                 field.materialize_weights = True

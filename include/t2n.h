@@ -333,6 +333,15 @@ int t2n_upsample_bilinear(const float* src, int C, int Hin, int Win, float* dst,
 int t2n_filter_rays_alpha(const t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint8_t* mask,
                           t2n_stream stream);
 
+/* Global depth alignment of the inpainting loop, text2nerf_main.py:241-270: scale of the monocular estimate from the ratios of depth
+ * differences between consecutive pixels of the caller's sample list ([n_samples][2] int32 (row, col): random.sample of the filled
+ * pixels, :234-240), kept when finite, >= 0 and within 5 |thresh - 1| of 1, thresh = (max rendered - push_depth) / (max estimate -
+ * push_depth), fallback thresh; then the mean shift against the rendered depth over the samples within 2 |max scaled - max rendered|,
+ * fallback that difference. depth_shift [H,W] = scale * depth_est - shift; scale_shift: device double[4] = {scale, shift, pairs kept,
+ * samples kept}. Double precision, deterministic. */
+int t2n_depth_align_global(const float* depth_rendered, const float* depth_est, int H, int W, const int32_t* pixel_sample_yx,
+                           int n_samples, double push_depth, float* depth_shift, double* scale_shift, t2n_stream stream);
+
 /* ---- measurement hooks (bench.py): when enabled, each kernel launch of the render call is bracketed by HIP events on
  * the launch stream. t2n_timing_read synchronises those events and returns accumulated milliseconds and launch counts
  * per kernel since the last reset. Kernel ids: */

@@ -172,3 +172,41 @@ def dibr_filter_mask2(image, known, depth=None, thr=0.65):
                 depth[i, j] = (depth[i - 1:i + 2, j - 1:j + 2] * k3).sum() / n
             known[i, j] = 1
     return (image, known) if depth is None else (image, known, depth)
+
+
+def align_depth_global(depth_rendered, depth_est, pixel_sample, push_depth):
+    """text2nerf_main.py:241-270 (the part after the pixel list has been drawn with random.sample, :234-240): global scale from the
+    ratios of depth differences between CONSECUTIVE sampled pixels — kept when finite, non-negative and within 5 |thresh - 1| of 1,
+    thresh = (max rendered - push) / (max estimate - push); fallback thresh — then the mean shift of the scaled estimate against the
+    rendered depth over the samples within 2 |max scaled - max rendered|; fallback that difference. numpy dtypes as the driver has
+    them: depth_rendered float32, depth_est float64. Returns (scale, shift, depth_shift)."""
+    dr, de = np.asarray(depth_rendered), np.asarray(depth_est)
+    ps = np.asarray(pixel_sample)
+    thresh = (dr.max() - push_depth) / (de.max() - push_depth)
+    scales = []
+    for ii in range(len(ps) - 1):
+        y1, x1 = ps[ii]
+        y2, x2 = ps[ii + 1]
+        dd1 = dr[y1, x1] - dr[y2, x2]
+        dd2 = de[y1, x1] - de[y2, x2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ss = dd1 / (dd2 + 1e-8)
+        if not np.isfinite(ss) or abs(ss - 1) > 5 * abs(thresh - 1) or ss < 0:
+            continue
+        scales.append(ss)
+    if len(scales) == 0:
+        scales.append(thresh)
+    scale = np.average(np.stack(scales))
+    ds = de * scale
+    thresh2 = ds.max() - dr.max()
+    shifts = []
+    for ii in range(len(ps)):
+        y1, x1 = ps[ii]
+        ss = ds[y1, x1] - dr[y1, x1]
+        if abs(ss) > 2 * abs(thresh2):
+            continue
+        shifts.append(ss)
+    if len(shifts) == 0:
+        shifts.append(thresh2)
+    shift = np.average(np.stack(shifts))
+    return float(scale), float(shift), ds - shift

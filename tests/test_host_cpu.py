@@ -212,3 +212,17 @@ def test_data_parallel_gradient_allreduce_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"OK {r}" in o, o
+
+
+def test_reference_pose_fixture():
+    """tests/golden/poses.npz (tests/golden/make_golden_poses.py: the reference's own trajectory generators): shapes, rotations, the
+    first local_fixed pose is the reference pose, the circle keeps its radius."""
+    import numpy as np
+    P = dict(np.load(os.path.join(ROOT, "tests", "golden", "poses.npz")))
+    assert P["local_fixed"].shape == (9, 4, 4) and P["circle_train_96"].shape == (48, 4, 4)
+    assert P["eval_spiral_120"].shape == (120, 4, 4) and P["circle_eval_360"].shape == (360, 4, 4)
+    for k in ("local_fixed", "circle_train_96", "eval_spiral_120"):
+        R = P[k][:, :3, :3]
+        assert np.allclose(np.einsum("vij,vkj->vik", R, R), np.eye(3)[None], atol=1e-5), k
+    assert np.allclose(P["local_fixed"][0], np.eye(4))
+    assert np.abs(P["local_fixed"][1:, :3, 3]).max() <= 0.2 + 1e-6          # range_center = 0.2

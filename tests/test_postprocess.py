@@ -27,6 +27,34 @@ def test_jet_table_shape_and_landmarks():
     assert np.all(np.diff(t[96:160, 0].astype(int)) <= 0) and np.all(np.diff(t[96:160, 2].astype(int)) >= 0)
 
 
+def _jet_fixture():
+    import os
+    from tests.conftest import GOLDEN
+    rows = [l.split() for l in open(os.path.join(GOLDEN, "jet_bgr_table.txt")) if l.strip() and not l.startswith("#")]
+    return np.array(rows, dtype=np.uint8)
+
+
+def test_jet_table_equals_committed_table():
+    """tests/golden/jet_bgr_table.txt: the 256-entry COLORMAP_JET table (B, G, R), pinned to OpenCV's published definition
+    (modules/imgproc/src/colormap.cpp, class Jet) — not to a cv2 run: see the file's header."""
+    t = _jet_fixture()
+    assert t.shape == (256, 3)
+    assert np.array_equal(O.jet_table_bgr(), t)
+    assert tuple(t[0]) == (128, 0, 0) and tuple(t[128]) == (126, 255, 130) and tuple(t[255]) == (0, 0, 128)
+
+
+@pytest.mark.gpu
+def test_hip_kernel_reproduces_the_jet_table_byte_exact():
+    """every one of the 256 indices through the HIP post-processing kernel: depth values that map to index i exactly"""
+    from text2nerf_amd import postprocess_frame
+    dev = torch.device("cuda:0")
+    mi, ma = 0.0, 255.0
+    depth = torch.arange(256, dtype=torch.float32) + 0.25          # (d - mi) / (ma - mi + 1e-8) * 255 -> i + 0.25 -> index i
+    rgb = torch.zeros(256, 3)
+    _, d8, _ = postprocess_frame(rgb.to(dev).reshape(16, 16, 3), depth.to(dev).reshape(16, 16), [mi, ma], push_depth=None)
+    assert np.array_equal(d8.cpu().numpy().reshape(256, 3), _jet_fixture())
+
+
 def test_oracle_postprocess_semantics():
     rgb, depth, gt = _frame()
     r8, d8, psnr = O.postprocess_frame(rgb, depth, [0.5, 8.0], push_depth=2.0, gt_rgb=gt)

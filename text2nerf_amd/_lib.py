@@ -75,6 +75,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
     "t2n_render_workspace_bytes_ctx": (C.c_size_t, [C.c_int64, C.c_int]),
+    "t2n_depth_align_global": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
     "t2n_field_grad_buffer_bytes": (C.c_size_t, [C.c_void_p]),
     "t2n_field_set_grad_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "t2n_train_loss_workspace_bytes": (C.c_size_t, [C.c_int64]),

@@ -330,3 +330,81 @@ extern "C" int t2n_dibr_filter_mask2(float* image, int32_t* known, double* depth
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }
+
+// ---- global depth alignment (text2nerf_main.py:241-270) --------------------------------------------------------------------------
+// scale = mean over consecutive sampled pixel pairs of (rendered difference) / (estimated difference + 1e-8), pairs kept when the ratio
+// is finite, >= 0 and within 5 |thresh - 1| of 1 (thresh = (max rendered - push) / (max estimate - push)); fallback thresh. shift = mean
+// over the samples of scale * estimate - rendered within 2 |max(scale * estimate) - max rendered|; fallback that difference. Output:
+// scale * estimate - shift. The pixel list is the caller's (random.sample of the filled pixels, :234-240). Everything is a reduction
+// over <= 10 000 samples plus two passes over the image: one workgroup in double precision with fixed-order tree sums
+// (deterministic), then an elementwise pass.
+namespace t2n {
+struct AlignArgs {
+    const float* dr; const float* de; int H, W; const int* ps; int K; double push;
+    float* out; double* ss;   // ss: [0] scale, [1] shift, [2] pairs kept, [3] samples kept
+};
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    sm[t] = v;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (t < o) sm[t] += sm[t + o]; __syncthreads(); }
+    return sm[0];
+}
+__device__ __forceinline__ double block_max(double v, double* sm) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    sm[t] = v;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (t < o) sm[t] = fmax(sm[t], sm[t + o]); __syncthreads(); }
+    return sm[0];
+}
+__global__ __launch_bounds__(1024) void k_align_stats(const AlignArgs a) {
+    __shared__ double sm[1024];
+    const int t = threadIdx.x;
+    const long long n = (long long)a.H * a.W;
+    double mr = -1e300, me = -1e300, mn = 1e300;
+    for (long long i = t; i < n; i += 1024) { mr = fmax(mr, (double)a.dr[i]); me = fmax(me, (double)a.de[i]); mn = fmin(mn, (double)a.de[i]); }
+    const double max_r = block_max(mr, sm), max_e = block_max(me, sm), min_e = -block_max(-mn, sm);
+    const double thresh = (max_r - a.push) / (max_e - a.push);
+    double s = 0.0, c = 0.0;
+    for (int i = t; i < a.K - 1; i += 1024) {
+        const size_t p1 = (size_t)a.ps[2 * i] * a.W + a.ps[2 * i + 1], p2 = (size_t)a.ps[2 * i + 2] * a.W + a.ps[2 * i + 3];
+        const double dd1 = (double)(a.dr[p1] - a.dr[p2]);           // float32 difference, as numpy forms it
+        const double dd2 = (double)a.de[p1] - (double)a.de[p2];
+        const double r = dd1 / (dd2 + 1e-8);
+        const bool keep = isfinite(r) && !(fabs(r - 1.0) > 5.0 * fabs(thresh - 1.0)) && !(r < 0.0);
+        if (keep) { s += r; c += 1.0; }
+    }
+    const double ssum = block_sum(s, sm), scnt = block_sum(c, sm);
+    const double scale = scnt > 0.0 ? ssum / scnt : thresh;
+    const double thresh2 = (scale >= 0.0 ? max_e * scale : min_e * scale) - max_r;
+    s = 0.0; c = 0.0;
+    for (int i = t; i < a.K; i += 1024) {
+        const size_t p1 = (size_t)a.ps[2 * i] * a.W + a.ps[2 * i + 1];
+        const double d = (double)a.de[p1] * scale - (double)a.dr[p1];
+        if (!(fabs(d) > 2.0 * fabs(thresh2))) { s += d; c += 1.0; }
+    }
+    const double hsum = block_sum(s, sm), hcnt = block_sum(c, sm);
+    if (t == 0) { a.ss[0] = scale; a.ss[1] = hcnt > 0.0 ? hsum / hcnt : thresh2; a.ss[2] = scnt; a.ss[3] = hcnt; }
+}
+__global__ __launch_bounds__(256) void k_align_apply(const AlignArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long long)a.H * a.W) a.out[i] = (float)((double)a.de[i] * a.ss[0] - a.ss[1]);
+}
+}  // namespace t2n
+
+extern "C" int t2n_depth_align_global(const float* depth_rendered, const float* depth_est, int H, int W, const int32_t* pixel_sample_yx,
+                                      int n_samples, double push_depth, float* depth_shift, double* scale_shift, t2n_stream stream) {
+    if (!depth_rendered || !depth_est || !pixel_sample_yx || !depth_shift || !scale_shift || H < 1 || W < 1 || n_samples < 1) {
+        set_error("t2n_depth_align_global: bad argument");
+        return T2N_ERR_INVALID;
+    }
+    AlignArgs a;
+    a.dr = depth_rendered; a.de = depth_est; a.H = H; a.W = W; a.ps = pixel_sample_yx; a.K = n_samples; a.push = push_depth;
+    a.out = depth_shift; a.ss = scale_shift;
+    hipLaunchKernelGGL(k_align_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_align_apply, dim3((unsigned)(((long long)H * W + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}

@@ -195,3 +195,18 @@ def rgbd_frame(seed, H, W, n_boxes=3, holes=0):
     for _ in range(holes):
         depth[int(g.integers(0, H)), int(g.integers(0, W))] = 0.0
     return rgb, depth
+
+
+def align_inputs(seed, H):
+    """Synthetic inputs of the global depth alignment (text2nerf_main.py:233-270; tests/golden/make_golden_align.py): a rendered depth
+    map (float32, as the renderer returns it), a monocular estimate that is an affine function of (depth - push_depth) plus noise
+    (float64, as `depth_est / 12000 + push_depth` is), and the validity map of the warped view with an unseen band."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    yy, xx = np.mgrid[0:H, 0:H].astype(np.float64) / H
+    true = 3.0 + 1.5 * np.sin(3 * xx) * np.cos(2 * yy) + 0.8 * xx
+    depth_rendered = (true + g.normal(0, 0.01, true.shape)).astype(np.float32)
+    s, t = (0.8, 0.35) if seed % 2 == 0 else (1.3, -0.4)
+    depth_est = (true - 2.0) / s + t + 2.0 + g.normal(0, 0.01, true.shape)
+    my_map = (g.uniform(0, 1, true.shape) < 0.6).astype(np.float64)
+    my_map[:, : H // 4] = 0.0
+    return depth_rendered, depth_est, my_map

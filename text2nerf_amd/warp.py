@@ -117,3 +117,23 @@ def dibr_filter_mask2(output_image, myMap, output_depth=None, device=None):
         return out if dep is None else out + (dep.cpu().numpy(),)
     out = (img, known.to(myMap.dtype))
     return out if dep is None else out + (dep,)
+
+
+def align_depth_global(depth_rendered, depth_est, pixel_sample, push_depth=2.0, device=None):
+    """The global stage of the depth alignment in ``render_warping_inapinting`` (text2nerf_main.py:241-270) on the device: scale and
+    shift of the monocular estimate against the rendered depth over the caller's sampled pixel list (``random.sample`` of the filled
+    pixels, :234-240 — host-side and the caller's, like the reference's). Returns ``(scale, shift, depth_shift)`` with ``depth_shift``
+    a float32 [H,W] device tensor (= depth_est * scale - shift) and scale / shift Python floats (one 32-byte read-back)."""
+    lib = _lib.load()
+    dev = _dev(device)
+    dr = _to(depth_rendered, dev, torch.float32)
+    de = _to(depth_est, dev, torch.float32)
+    ps = torch.as_tensor(np.asarray(pixel_sample, dtype=np.int32).reshape(-1, 2)).to(dev).contiguous()
+    H, W = dr.shape
+    out = torch.empty(H, W, device=dev, dtype=torch.float32)
+    ss = torch.empty(4, device=dev, dtype=torch.float64)
+    with torch.cuda.device(dev):
+        _lib.check(lib.t2n_depth_align_global(_lib.ptr(dr), _lib.ptr(de), H, W, _lib.ptr(ps), int(ps.shape[0]), float(push_depth),
+                                              _lib.ptr(out), _lib.ptr(ss), _lib.current_stream_ptr(dev)), "t2n_depth_align_global")
+    s = ss.cpu().tolist()
+    return s[0], s[1], out

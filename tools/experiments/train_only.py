@@ -1,9 +1,10 @@
-"""Run only the C3-shaped train loop of bench.py (for rocprofv3 --kernel-trace --stats). argv[1]: 0 = torch TV+Adam, 1 = fused."""
+"""Run only the C3-shaped train loop of bench.py (for rocprofv3 --kernel-trace --stats). argv[1]: 0 = torch TV+Adam, 1 = fused TV+Adam,
+2 = autograd-free train_step."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 torch.set_num_threads(max(1, min(bench.HOST_CORES, 16)))
-fused = len(sys.argv) > 1 and sys.argv[1] == "1"
+mode = sys.argv[1] if len(sys.argv) > 1 else "0"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-print(json.dumps(bench.train_bench(torch.device("cuda:0"), iters=iters, warmup=3, fused_optim=fused)))
+print(json.dumps(bench.train_bench(torch.device("cuda:0"), iters=iters, warmup=3, fused_optim=mode == "1", fused_step=mode == "2")))
