@@ -610,6 +610,12 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         L.rgb_raw = keep ? (float4*)(ws + c.rgb_raw) : nullptr;
         T2N_HIP(hipMemsetAsync(L.counters, 0, (size_t)kLists * kCounterStride * 4, s));
         int rc;
+        const KeptRows kr = keep && f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW ? kept_rows(c.total, workspace_bytes) : KeptRows{0, 0, 0, 0, 0};
+        if (kr.rows >= 32) {   // recorded in the workspace itself (and in the counts' host copy): the backward checks it
+            // device-side fills (a copy from pageable host memory would drain the stream)
+            T2N_HIP(hipMemsetD32Async((hipDeviceptr_t)(L.counters + kKeptMagicWord), (int)kKeptMagic, 1, s));
+            T2N_HIP(hipMemsetD32Async((hipDeviceptr_t)(L.counters + kKeptRowsWord), (int)kr.rows, 1, s));
+        }
         if (tiles) {
             if ((rc = launch_march_tiles(f, L, f->frame_w, (int)(cnt / f->frame_w), (float*)(ws + c.sigma), (float4*)(ws + c.scratch), s))) return rc;
         } else if ((rc = launch_march(f, L, s))) return rc;
@@ -640,7 +646,6 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         } else {
             // training forward with spare workspace: run the activation-keeping kernel now, so the backward need not re-run
             // the appearance forward (rows past the capacity keep nothing; the backward then recomputes)
-            const KeptRows kr = keep && f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW ? kept_rows(c.total, workspace_bytes) : KeptRows{0, 0, 0, 0, 0};
             if (kr.rows >= 32) {
                 ShadeCtx ctx{(float*)(ws + kr.x144), (float*)(ws + kr.feat32), (float*)(ws + kr.h0), (float*)(ws + kr.h1)};
                 if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, &ctx, s, false, kr.rows))) return rc;

@@ -1141,11 +1141,11 @@ int t2n::ctx_counts_post(const void* ws, const unsigned* counters_dev, hipStream
 }
 
 static int read_counts(const void* fwd_ws, int64_t n_rays, int n_samples, hipStream_t s, unsigned counts[kLists], TilePrefix* tp,
-                       int64_t* rows) {
+                       int64_t* rows, unsigned* kept_rows_stated = nullptr, bool consume = false) {
     const Carve c = carve_workspace(n_rays, n_samples, true, false);
     unsigned raw[kLists * kCounterStride];
-    const CtxSlot* slot = nullptr;
-    for (const auto& q : g_ctx) if (q.valid && q.ws == fwd_ws) slot = &q;
+    CtxSlot* slot = nullptr;
+    for (auto& q : g_ctx) if (q.valid && q.ws == fwd_ws) slot = &q;
     if (slot) {
         T2N_HIP(hipEventSynchronize(slot->ev));
         memcpy(raw, slot->host, sizeof(raw));
@@ -1154,6 +1154,11 @@ static int read_counts(const void* fwd_ws, int64_t n_rays, int n_samples, hipStr
         T2N_HIP(hipStreamSynchronize(s));
     }
     for (int l = 0; l < kLists; ++l) counts[l] = raw[l * kCounterStride];
+    if (kept_rows_stated) *kept_rows_stated = raw[kKeptMagicWord] == kKeptMagic ? raw[kKeptRowsWord] : 0u;
+    if (consume) {   // the backward overwrites the kept rows in place: a second backward on this workspace must recompute
+        if (slot) slot->host[kKeptMagicWord] = 0u;
+        T2N_HIP(hipMemsetAsync((char*)const_cast<void*>(fwd_ws) + c.counters + kKeptMagicWord * 4, 0, 4, s));
+    }
     unsigned t = 0;
     for (int l = 0; l < kLists; ++l) {
         if (counts[l] > c.list_cap) counts[l] = c.list_cap;
@@ -1200,7 +1205,8 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     unsigned counts[kLists];
     TilePrefix tp;
     int64_t rows = 0;
-    int rc = read_counts(fwd_workspace, n_rays, n_samples, s, counts, &tp, &rows);
+    unsigned kept_stated = 0;
+    int rc = read_counts(fwd_workspace, n_rays, n_samples, s, counts, &tp, &rows, &kept_stated, true);
     if (rc) return rc;
     const int64_t rows_alloc = rows < 32 ? 32 : rows;
     const BinGeom geom = bin_geom(f->dev.den);
@@ -1214,7 +1220,9 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     float* h1 = (float*)(bw + b.h1); float4* go = (float4*)(bw + b.go); float* xpe = (float*)(bw + b.xpe);
     // the forward kept the activation rows (spare KEEP_CTX workspace, all rows fit): use them in place, skip the recompute
     const KeptRows kr = generic ? KeptRows{0, 0, 0, 0, 0} : kept_rows(c.total, fwd_workspace_bytes);
-    const bool kept = kr.rows >= 32 && (int64_t)kr.rows >= rows_alloc;
+    // ... and only when the forward SAID it kept them with this very capacity: a caller that hands the backward a larger (pooled) buffer
+    // than the forward saw would otherwise read uninitialised activations
+    const bool kept = kr.rows >= 32 && (int64_t)kr.rows >= rows_alloc && kept_stated == kr.rows;
     if (kept) { x144 = (float*)(fw + kr.x144); feat32 = (float*)(fw + kr.feat32); h0 = (float*)(fw + kr.h0); h1 = (float*)(fw + kr.h1); }
     float* part = (float*)(bw + b.part);
     float* g1 = h1;      // k_bwd_l2 rewrites each element in place

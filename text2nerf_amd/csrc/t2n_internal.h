@@ -142,6 +142,11 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
 // feat / feat_rows: scratch rows for the two-kernel default path (features -> weight-stationary head, t2n_mlp_ws.hip); tiles
 // past the capacity take the one-kernel path. Word kRangeFlagWord of the counter block is the head's f16-range flag.
 constexpr int kRangeFlagWord = 32;
+// Words 33 / 34 of the counter block of a KEEP_CTX forward: the forward states that it keeps the MLP activation rows (magic) and
+// with which capacity; the backward takes the kept path only when both match what it derives from ITS workspace size, and clears
+// the statement once it has consumed the rows (h0 / h1 are overwritten in place).
+constexpr int kKeptMagicWord = 33, kKeptRowsWord = 34;
+constexpr unsigned kKeptMagic = 0x4b455054u;   // "KEPT"
 int launch_mlp_ws(t2n_field* f, const float* feat, const unsigned* counters_dev, unsigned list_cap, unsigned tile_hi, float4* app_rgb,
                   unsigned* range_flag, hipStream_t s);
 // features_only: gather + basis stages only (the general heads take over); ctx_rows: capacity of the ctx buffers in rows

@@ -1,8 +1,6 @@
 #!/bin/bash
-# Per-phase wave cycles of k_shade_coop: swaps a -DT2N_PHASE_TIMING build in as libt2n_hip.so for one run (on the GPU box).
-set -e
+# Per-phase wave cycles of the appearance kernels: a -DT2N_PHASE_TIMING build (text2nerf_amd/libt2n_hip_phase.so) selected through
+# T2N_LIB; the shipped library stays untouched (on the GPU box).
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
-cp text2nerf_amd/libt2n_hip.so /tmp/libt2n_hip.so.orig
-cp text2nerf_amd/libt2n_hip_phase.so text2nerf_amd/libt2n_hip.so
-python tools/experiments/phase_timing.py || true
-cp /tmp/libt2n_hip.so.orig text2nerf_amd/libt2n_hip.so
+T2N_LIB=$PWD/text2nerf_amd/libt2n_hip_phase.so python tools/experiments/ws_phase.py
+T2N_LIB=$PWD/text2nerf_amd/libt2n_hip_phase.so T2N_SHADE_NO_WS=1 python tools/experiments/phase_timing.py

@@ -1,10 +1,8 @@
 #!/bin/bash
-# Run the train loop with each libt2n_var_*.so swapped in as libt2n_hip.so (on the GPU box).
+# Run the train loop with each libt2n_var_*.so selected through T2N_LIB (text2nerf_amd/_lib.py) — the shipped libt2n_hip.so is never
+# overwritten, so an interrupted sweep cannot leave a variant installed (on the GPU box).
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
-cp text2nerf_amd/libt2n_hip.so /tmp/libt2n_hip.so.orig
 for v in text2nerf_amd/libt2n_var_*.so; do
-  cp $v text2nerf_amd/libt2n_hip.so
-  echo "== $v"; python tools/experiments/train_only.py 1 40 2>&1 | tail -1
+  echo "== $v"; T2N_LIB=$PWD/$v python tools/experiments/train_only.py 1 40 2>&1 | tail -1
 done
-cp /tmp/libt2n_hip.so.orig text2nerf_amd/libt2n_hip.so
 echo "== baseline"; python tools/experiments/train_only.py 1 40 2>&1 | tail -1
