@@ -59,6 +59,20 @@ def test_fused_loss_kernel_matches_torch_loss_and_autograd():
     assert float(d_depth[7]) == 0.0        # the NaN depth got no gradient
 
 
+def assert_same_trajectory(fa, fb, steps, lr_spatial=0.02, lr_network=1e-3, frac=2e-3):
+    """Parameters of two fields after `steps` Adam steps from the same start. The factor gradients are sums of floating-point
+    atomics (order differs run to run) and Adam divides by sqrt(v): an element whose gradient is a near-cancelling sum can move a
+    visibly different fraction of a step, so the bound is stated in Adam's own unit — `frac` of one learning-rate step per
+    iteration — instead of in ulps of the parameter. A wrong loss weight, a dropped TV term or a lost chunk moves elements by
+    whole steps (lr), 500x this bound."""
+    for (k, a), (_, b) in zip(fa.state_dict().items(), fb.state_dict().items()):
+        lr = lr_spatial if ("plane" in k or "line" in k) else lr_network
+        diff = float((a - b).abs().max())
+        assert diff <= frac * lr * steps, (k, diff, frac * lr * steps)
+        # and the bulk of the elements agrees far more tightly than the worst one
+        assert float((a - b).abs().mean()) <= 2e-5 * lr * steps + 1e-9, k
+
+
 def step_autograd(f, opt, rays, rgb_t, dep_t, chunk=None):
     from text2nerf_amd import OctreeRender_trilinear_fast
     d = dev()
@@ -84,8 +98,7 @@ def test_train_step_equals_the_autograd_step(tiny_params):
         torch.manual_seed(100 + it)
         lb = fb.train_step(rays, rgb_t, dep_t, ob, N_samples=-1, white_bg=True, tv=[(fb.density_plane, 0.1), (fb.app_plane, 0.01)])
         assert torch.allclose(la, lb, rtol=1e-5, atol=1e-9), (it, la, lb)
-    for (k, a), (_, b) in zip(fa.state_dict().items(), fb.state_dict().items()):
-        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-7, k
+    assert_same_trajectory(fa, fb, steps=3)
 
 
 def test_deferred_factor_gradients_add_up_over_chunks(tiny_params):
@@ -107,5 +120,4 @@ def test_deferred_factor_gradients_add_up_over_chunks(tiny_params):
         assert float(f2.factor_grad_buffer().abs().max()) > 0
         o2.step(tv=[(f2.density_plane, 0.1), (f2.app_plane, 0.01)])
         assert float(f2.factor_grad_buffer().abs().max()) == 0.0      # consumed and zeroed by the step
-    for (k, a), (_, b) in zip(f1.state_dict().items(), f2.state_dict().items()):
-        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-7, k
+    assert_same_trajectory(f1, f2, steps=2)
