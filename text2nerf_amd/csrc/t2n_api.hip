@@ -424,6 +424,7 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->buf_mlp) (void)hipFree(f->buf_mlp);
     if (f->buf_mlp_h) (void)hipFree(f->buf_mlp_h);
     if (f->buf_ws) (void)hipFree(f->buf_ws);
+    if (f->buf_ss) (void)hipFree(f->buf_ss);
     if (f->buf_alpha) (void)hipFree(f->buf_alpha);
     for (int k = 0; k < T2N_K_COUNT; ++k)
         for (int i = 0; i < 64; ++i) {
@@ -449,6 +450,7 @@ extern "C" int t2n_field_upload(t2n_field* f, const t2n_field_params* p, t2n_str
     if (rc) return rc;
     f->params_ref = *p;
     f->ws_dirty = true;
+    f->ss_dirty = true;
     f->uploaded = true;
     return T2N_OK;
 }
@@ -470,6 +472,7 @@ extern "C" int t2n_field_upload_head(t2n_field* f, const t2n_field_params* p, t2
     f->params_ref.mlp_w0 = p->mlp_w0; f->params_ref.mlp_b0 = p->mlp_b0; f->params_ref.mlp_w1 = p->mlp_w1; f->params_ref.mlp_b1 = p->mlp_b1;
     f->params_ref.mlp_w2 = p->mlp_w2; f->params_ref.mlp_b2 = p->mlp_b2;
     f->ws_dirty = true;
+    f->ss_dirty = true;
     return T2N_OK;
 }
 

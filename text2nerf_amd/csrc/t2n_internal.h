@@ -77,6 +77,8 @@ struct t2n_field {
     void* buf_mlp_h = nullptr; // split-f16 operands + scaled biases
     void* buf_ws = nullptr;    // weight-stationary head operands (t2n_mlp_ws.hip), packed lazily from params_ref
     bool ws_dirty = true;
+    void* buf_ss = nullptr;    // sample-stationary head operands (t2n_mlp_ss.hip), packed lazily from params_ref
+    bool ss_dirty = true;
     float* buf_alpha = nullptr; // alpha-mask volume copy
     int mlp_split = 1;         // 1: f16 two-way split products (default), 0: exact fp32 MFMA
     // channel-last gradient accumulators (backward), allocated on first use
@@ -148,6 +150,8 @@ constexpr int kRangeFlagWord = 32;
 constexpr int kKeptMagicWord = 33, kKeptRowsWord = 34;
 constexpr unsigned kKeptMagic = 0x4b455054u;   // "KEPT"
 int launch_mlp_ws(t2n_field* f, const float* feat, const unsigned* counters_dev, unsigned list_cap, unsigned tile_hi, float4* app_rgb,
+                  unsigned* range_flag, hipStream_t s);
+int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev, unsigned list_cap, unsigned tile_hi, float4* app_rgb,
                   unsigned* range_flag, hipStream_t s);
 // features_only: gather + basis stages only (the general heads take over); ctx_rows: capacity of the ctx buffers in rows
 

@@ -1139,7 +1139,9 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
         else hipLaunchKernelGGL(k_app_features<false>, grid, dim3(256), lds, s, fa);
         timing_end(f, T2N_K_APPFEAT, s);
         timing_begin(f, T2N_K_SHADE, s);
-        const int rc = launch_mlp_ws(f, feat, counters_dev, list_cap, ws_tiles, app_rgb, flag, s);
+        static const bool head_ws = getenv("T2N_HEAD_WS") != nullptr;   // A/B switch: the weight-stationary form of the head
+        const int rc = head_ws ? launch_mlp_ws(f, feat, counters_dev, list_cap, ws_tiles, app_rgb, flag, s)
+                               : launch_mlp_ss(f, feat, counters_dev, list_cap, ws_tiles, app_rgb, flag, s);
         if (rc) return rc;
         ShadeArgs oa = a;
         oa.tile_lo = ws_tiles;
