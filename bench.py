@@ -422,7 +422,7 @@ def main():
         except Exception:
             pass
         split = not field.mlp_exact_fp32
-        two_kernel = "app_features" in frame_ms    # default path: gather + basis kernel, then the weight-stationary head
+        two_kernel = "app_features" in frame_ms    # default path: gather + basis kernel, then the sample-stationary head
         roofs = {}
         if "shade" in k_ms:
             # algorithmic work of the head kernel: the reference's fp32 MACs, 2 flop each; basis_mat's 7 776 flop per sample belong
@@ -432,7 +432,7 @@ def main():
             alg = flop_per * A / launches
             t = k_ms["shade"] * 1e-3
             peak = MFMA_F16_PEAK_TF if split else MFMA_F32_PEAK_TF
-            kname = "k_mlp_ws" if two_kernel else ("k_shade_coop" if split else "k_shade<exact>")
+            kname = ("k_mlp_ws" if os.environ.get("T2N_HEAD_WS") else "k_mlp_ss") if two_kernel else ("k_shade_coop" if split else "k_shade<exact>")
             roofs["shade"] = {
                 "bound": "mfma", "kernel": kname, "achieved": alg / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": alg / t / 1e12 / peak, "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"),
@@ -440,6 +440,10 @@ def main():
                 # every fp32 product runs as three f16 MFMA products of hi/lo splits: what the matrix pipe actually executes
                 "executed_frac": (3.0 if split else 1.0) * alg / t / 1e12 / peak,
                 "mfma_busy_frac_pmc": pmc.get(kname, {}).get("mfma_busy_frac"),
+                # what a bare stream of v_mfma_f32_32x32x16_f16 sustains on this part (two waves per SIMD, no other instructions,
+                # tools/experiments/mfma_fillers.hip: 16.2 ns per MFMA and SIMD = 2.07 PFLOP/s at the clock the chip holds under
+                # that load) - the kernel's practical ceiling; with 4-6 other instructions per MFMA the same loop runs 18.7-19.4 ns
+                "executed_frac_of_sustained_mfma_rate": ((3.0 * alg / t / 1e12 / 2070.0) if split else None),
                 "note": ("frac = algorithmic fp32-equivalent flop (123 392 per appearance sample: 351x128 + 128x128 + 128x3 MACs) / time / "
                          "dense f16 MFMA peak; executed_frac counts the 3 f16 products per fp32 product" if split else "exact fp32 MFMA")}
         if "march" in k_ms:

@@ -14,8 +14,8 @@
 //   layers 1, 2: K index (step s, half h, element e) = hidden unit 32 (s / 2) + 8 (2 (s % 2) + e / 4) + 4h + e % 4 — what the lane
 //            holds of unit tile s / 2 of the previous layer's accumulators.
 // The weights are the A operands. Layer-0 weights (196 KB as hi / lo f16 halves) stream through a three-slot LDS ring of 16-KB
-// chunks (two K-steps) that the eight waves share (each thread carries 32 B of the chunk after next in registers; one barrier
-// per chunk); layers 1 and 2 (80 KB) stay resident in LDS.
+// chunks (two K-steps) that the eight waves share (filled by LDS-DMA two chunks ahead; one barrier per chunk); layers 1 and 2
+// (80 KB) stay resident in LDS.
 //
 // fp32 products are three f16 products of hi / lo splits (x = hi + lo, hi = RTZ_f16(x), lo = RTZ_f16(x - hi); the lo*lo term is
 // dropped: ~2^-21 relative), fp32 accumulate. Weights are pre-split and scaled by a per-layer power of two chosen from max|W| at
@@ -135,8 +135,9 @@ __device__ __forceinline__ void enc_unit(Unit& U, const float (&f)[14], float ne
             U.x1 = fmaf(tl, sc, __builtin_amdgcn_fractf(th * sc));
         } else {
             const float sn = U.x0, cs = U.x1;   // (sin, cos) of the previous octave of this sample
-            U.x0 = 2.f * (sn * cs);
-            U.x1 = (cs - sn) * (cs + sn);
+            const float t = sn + sn;
+            U.x0 = t * cs;
+            U.x1 = fmaf(-t, sn, 1.f);           // cos 2a = 1 - 2 sin^2 a: absolute error ~6e-8 (what matters: the value multiplies a weight)
         }
     } else if constexpr (PH == 1) {
         if constexpr (fresh) {
@@ -209,9 +210,10 @@ struct AOp { uint4 h, l; };
 // Slot M (0..11) of one K-step of a 128-unit layer: unit-tile pair M / 6, product (M % 6) / 2 (hi*hi, lo*hi, hi*lo), tile of the pair
 // M % 2 — an accumulator is touched every second slot. The A operands of the next pair (cur + tile * 128 [+ 64: lo part]; the second
 // pair fetches the first pair of the next step, nxt) are fetched in a pair's first slot. One filler phase per slot.
-template <int M, class Fill>
+struct NoRing { template <int M> __device__ __forceinline__ void run() {} };
+template <int M, class Fill, class Ring = NoRing>
 __device__ __forceinline__ void slots(f32x16 (&acc)[4], AOp (&A)[2][2], const uint4& Bh, const uint4& Bl,
-                                      const uint4* __restrict__ cur, const uint4* __restrict__ nxt, Fill& F) {
+                                      const uint4* __restrict__ cur, const uint4* __restrict__ nxt, Fill& F, Ring R = Ring()) {
     if constexpr (M < 12) {
         constexpr int g = M / 6, k = M % 6, p = k / 2, i = k % 2, u = 2 * g + i;
         acc[u] = mfma(p == 1 ? A[g][i].l : A[g][i].h, p == 2 ? Bl : Bh, acc[u]);
@@ -224,8 +226,9 @@ __device__ __forceinline__ void slots(f32x16 (&acc)[4], AOp (&A)[2][2], const ui
         }
         F.template run<M>();
         if constexpr (M == 11) F.done();
-        SS_FENCE();
-        slots<M + 1>(acc, A, Bh, Bl, cur, nxt, F);
+        R.template run<M>();
+        SS_FENCE();   // (MFMAs of a tile pair or of a whole K-step issued back to back, fillers behind them: 2-3 % slower)
+        slots<M + 1>(acc, A, Bh, Bl, cur, nxt, F, R);
     }
 }
 
@@ -247,19 +250,26 @@ __device__ __forceinline__ void step2(f32x16 (&ch)[3], AOp (&A)[2][2], const uin
     SS_FENCE();
 }
 
-// the layer-0 weight stream: thread tid carries uint4 [tid] and [512 + tid] of a chunk. Buffer loads (descriptor in SGPRs, the
-// chunk as a scalar byte offset, the thread as one 32-bit VGPR offset): no 64-bit per-lane pointers kept alive.
+// the layer-0 weight stream: LDS-DMA (buffer_load ... lds: descriptor in SGPRs, the chunk as a scalar byte offset, the thread as one
+// 32-bit VGPR offset; the data never touches a VGPR). Wave w moves KB w and 8 + w of a 16-KB chunk, one
+// 1-KB piece per instruction (the LDS side of the instruction is wave-linear: M0 base + lane * 16).
 struct Stream {
     const uint4* wp; int tid;
-    uint4 s0, s1;
-    __device__ __forceinline__ void load(int c) {
-        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    template <int HALF> __device__ __forceinline__ void dma(uint4* __restrict__ slot, int c) const {
+        typedef __attribute__((address_space(3))) void* lp;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wp), 0, 0x7fffffff, 0x00020000);
-        const u4v a = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, c * (kChunk * 16), 0);
-        const u4v b = __builtin_amdgcn_raw_buffer_load_b128(rs, tid * 16, c * (kChunk * 16) + 8192, 0);
-        s0 = make_uint4(a[0], a[1], a[2], a[3]); s1 = make_uint4(b[0], b[1], b[2], b[3]);
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lp)(slot + HALF * 512 + w * 64), 16, tid * 16, c * (kChunk * 16) + HALF * 8192, 0, 0);
     }
-    __device__ __forceinline__ void store(uint4* __restrict__ slot) const { slot[tid] = s0; slot[512 + tid] = s1; }
+};
+// the ring traffic of one chunk iteration rides in the MFMA slots of its first K-step (the piece lands one iteration later:
+// hipcc waits vmcnt(0) in front of the next barrier, by which time it has long arrived)
+struct RingOps {
+    const Stream& S; uint4* __restrict__ slot; int chunk;
+    template <int M> __device__ __forceinline__ void run() {
+        if constexpr (M == 1) S.template dma<0>(slot, chunk);
+        if constexpr (M == 5) S.template dma<1>(slot, chunk);
+    }
 };
 
 __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
@@ -302,14 +312,13 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
     if (blockIdx.x >= nrounds) return;
     if (tid < 8) { LT[tid] = tid < a.nlists ? incl : 0xffffffffu; LT[8 + tid] = cnt_l; }   // kept in LDS: no live registers across the loop
 
-    // resident operands: layers 1 / 2 and the biases; ring slots 0 / 1 <- chunks 0 / 1, chunk 2 in flight in registers
+    // resident operands: layers 1 / 2 and the biases; ring slots 0 / 1 <- chunks 0 / 1
     for (int i = tid; i < kW1; i += 512) W1[i] = a.w1[i];
     for (int i = tid; i < kW2; i += 512) W2[i] = a.w2[i];
     for (int i = tid; i < kBias; i += 512) LB[i] = a.bias[i];
-    Stream S{a.w0, tid};
-    S.load(0); S.store(RING);
-    S.load(1); S.store(RING + kChunk);
-    S.load(2);
+    const Stream S{a.w0, tid};
+    S.dma<0>(RING, 0); S.dma<1>(RING, 0);
+    S.dma<0>(RING + kChunk, 1); S.dma<1>(RING + kChunk, 1);
     const float inv0 = a.inv_scale[0], inv1 = a.inv_scale[1], inv2 = a.inv_scale[2];
     const float neg1 = a.neg1;
     h2v amax = {(_Float16)0.f, (_Float16)0.f};   // hidden activations (non-negative, finite inputs), as packed RTZ f16 halves
@@ -363,20 +372,23 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
             SS_PHASE(0);                                                                                                          \
             if constexpr (!kExpNoBar) __syncthreads();   /* chunk C + 1 written by every wave; chunk C - 1 read by every wave */  \
             SS_PHASE(5);                                                                                                          \
-            if constexpr (!kExpNoRing) { S.store(RING + ((C + 2) % 3) * kChunk); if constexpr (C < 11) S.load((C + 3) % kC0); }    \
+            RingOps ring{S, RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0};   /* lands before the next barrier */                  \
             SS_PHASE(6);                                                                                                          \
             const uint4* __restrict__ cur = LA0 + kW2 + (C % 3) * kChunk;                                                         \
             const uint4* __restrict__ nxt = C < 11 ? LA0 + kW2 + ((C + 1) % 3) * kChunk : LA1;                                    \
             /* K-step 23 (the second step of chunk 11) is all padding: 23 steps, the last one hands over to layer 1 */            \
             if constexpr (!kExpNoFill && C < 11) {                                                                                \
                 EncFill<2 * C + 1> f0{E, Bh[1], Bl[1], neg1};                                                                     \
-                slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0);                                                            \
+                if constexpr (kExpNoRing) slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0);                                  \
+                else slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0, ring);                                                 \
             } else if constexpr (C == 11) {                                                                                       \
                 NoFill f0;                                                                                                        \
-                slots<0>(acc0, A, Bh[0], Bl[0], cur, nxt, f0);                                                                    \
+                if constexpr (kExpNoRing) slots<0>(acc0, A, Bh[0], Bl[0], cur, nxt, f0);                                          \
+                else slots<0>(acc0, A, Bh[0], Bl[0], cur, nxt, f0, ring);                                                         \
             } else {                                                                                                              \
                 NoFill f0;                                                                                                        \
-                slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0);                                                            \
+                if constexpr (kExpNoRing) slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0);                                  \
+                else slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0, ring);                                                 \
             }                                                                                                                     \
             if constexpr (C < 11 && !kExpNoFill) {                                                                                \
                 EncFill<(C < 11 ? 2 * C + 2 : 0)> f1{E, Bh[0], Bl[0], neg1};                                                      \
@@ -421,7 +433,6 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
         SS_PHASE(2);
         // ---- h1 -> layer-2 B operands, layer 2 (three product chains), sigmoid, store ---------------------------------------------------
         // (layer 1's last pair fetched W2 steps 0 / 1 as if they were a tile pair: A[0][0] = step 0, A[0][1] = step 1)
-        if constexpr (!kExpNoRing) S.load(2);   // the next round's chunk 2: lands under layer 2, enters the ring at chunk 0's barrier
         load_feat(rn, E.f);                     // the next round's features: in flight under layer 2, encoded in its last step
         uint4 H1h[8], H1l[8];
         {

@@ -15,4 +15,4 @@ for set in \
   timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -o p -- python3 tools/experiments/one_frame.py > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
 done
 python3 tools/pmc_summary.py $OUT > $OUT/summary.txt
-grep -A40 "${PMC_KERNEL:-k_mlp_ws}" $OUT/summary.txt | head -60
+grep -A40 "${PMC_KERNEL:-k_mlp_ss}" $OUT/summary.txt | head -60
