@@ -432,7 +432,7 @@ def main():
             alg = flop_per * A / launches
             t = k_ms["shade"] * 1e-3
             peak = MFMA_F16_PEAK_TF if split else MFMA_F32_PEAK_TF
-            kname = ("k_mlp_ws" if os.environ.get("T2N_HEAD_WS") else "k_mlp_ss") if two_kernel else ("k_shade_coop" if split else "k_shade<exact>")
+            kname = "k_mlp_ss" if two_kernel else ("k_shade_coop" if split else "k_shade<exact>")
             roofs["shade"] = {
                 "bound": "mfma", "kernel": kname, "achieved": alg / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": alg / t / 1e12 / peak, "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"),

@@ -368,10 +368,10 @@ Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat) {
     // tile marcher: per-ray staging of up to n_samples / 4 appearance entries (+ one 256-B line: overflow counter) and an
     // overflow ray list
     c.scratch = o; if (ctx) o = align_up(o + (size_t)rays * (size_t)(n_samples / 4 > 0 ? n_samples / 4 : 1) * 16 + 256 + (size_t)rays * 4, 256);
-    // appearance feature rows between the gather + basis kernel and the weight-stationary head: 64 rows per ray (the bench
+    // appearance feature rows between the gather + basis kernel and the sample-stationary head: 32 rows per ray (the bench
     // scene needs ~7, BASELINE configs[0] ~44), never more than the worst case; appearance tiles past the capacity take the
     // one-kernel path
-    const size_t worst_rows = cap + (size_t)kLists * 32, want_rows = (size_t)rays * 64 + 1024;
+    const size_t worst_rows = cap + (size_t)kLists * 32, want_rows = (size_t)rays * 32 + 1024;
     c.feat_rows = (unsigned)(((worst_rows < want_rows ? worst_rows : want_rows) + 127) / 128 * 128);
     if (!feat) c.feat_rows = 0;
     c.feat = o; o = align_up(o + (size_t)c.feat_rows * 32 * sizeof(float), 256);
@@ -423,7 +423,6 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->gbuf_all && !f->gbuf_external) (void)hipFree(f->gbuf_all);
     if (f->buf_mlp) (void)hipFree(f->buf_mlp);
     if (f->buf_mlp_h) (void)hipFree(f->buf_mlp_h);
-    if (f->buf_ws) (void)hipFree(f->buf_ws);
     if (f->buf_ss) (void)hipFree(f->buf_ss);
     if (f->buf_alpha) (void)hipFree(f->buf_alpha);
     for (int k = 0; k < T2N_K_COUNT; ++k)
@@ -449,7 +448,6 @@ extern "C" int t2n_field_upload(t2n_field* f, const t2n_field_params* p, t2n_str
     timing_end(f, T2N_K_UPLOAD, s);
     if (rc) return rc;
     f->params_ref = *p;
-    f->ws_dirty = true;
     f->ss_dirty = true;
     f->uploaded = true;
     return T2N_OK;
@@ -471,7 +469,6 @@ extern "C" int t2n_field_upload_head(t2n_field* f, const t2n_field_params* p, t2
     f->params_ref.basis_weight = p->basis_weight;
     f->params_ref.mlp_w0 = p->mlp_w0; f->params_ref.mlp_b0 = p->mlp_b0; f->params_ref.mlp_w1 = p->mlp_w1; f->params_ref.mlp_b1 = p->mlp_b1;
     f->params_ref.mlp_w2 = p->mlp_w2; f->params_ref.mlp_b2 = p->mlp_b2;
-    f->ws_dirty = true;
     f->ss_dirty = true;
     return T2N_OK;
 }

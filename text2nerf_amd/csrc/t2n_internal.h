@@ -75,8 +75,6 @@ struct t2n_field {
     int factor_bf16 = 0;
     float* buf_mlp = nullptr;  // basisA | w0A | w1A | w2A
     void* buf_mlp_h = nullptr; // split-f16 operands + scaled biases
-    void* buf_ws = nullptr;    // weight-stationary head operands (t2n_mlp_ws.hip), packed lazily from params_ref
-    bool ws_dirty = true;
     void* buf_ss = nullptr;    // sample-stationary head operands (t2n_mlp_ss.hip), packed lazily from params_ref
     bool ss_dirty = true;
     float* buf_alpha = nullptr; // alpha-mask volume copy
@@ -141,7 +139,7 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
                       const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s,
                       bool features_only = false, unsigned ctx_rows = 0xffffffffu, float* feat = nullptr, unsigned feat_rows = 0,
                       uint64_t* stats = nullptr);
-// feat / feat_rows: scratch rows for the two-kernel default path (features -> weight-stationary head, t2n_mlp_ws.hip); tiles
+// feat / feat_rows: scratch rows for the two-kernel default path (features -> sample-stationary head, t2n_mlp_ss.hip); tiles
 // past the capacity take the one-kernel path. Word kRangeFlagWord of the counter block is the head's f16-range flag.
 constexpr int kRangeFlagWord = 32;
 // Words 33 / 34 of the counter block of a KEEP_CTX forward: the forward states that it keeps the MLP activation rows (magic) and
@@ -149,8 +147,6 @@ constexpr int kRangeFlagWord = 32;
 // the statement once it has consumed the rows (h0 / h1 are overwritten in place).
 constexpr int kKeptMagicWord = 33, kKeptRowsWord = 34;
 constexpr unsigned kKeptMagic = 0x4b455054u;   // "KEPT"
-int launch_mlp_ws(t2n_field* f, const float* feat, const unsigned* counters_dev, unsigned list_cap, unsigned tile_hi, float4* app_rgb,
-                  unsigned* range_flag, hipStream_t s);
 int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev, unsigned list_cap, unsigned tile_hi, float4* app_rgb,
                   unsigned* range_flag, hipStream_t s);
 // features_only: gather + basis stages only (the general heads take over); ctx_rows: capacity of the ctx buffers in rows

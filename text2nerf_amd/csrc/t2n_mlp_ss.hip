@@ -22,7 +22,7 @@
 // upload (k_ss_scales); activations are split where they are produced; any activation beyond the f16 range raises a flag that
 // makes the caller's exact-fp32 kernel redo the launch.
 //
-// Why not weight-stationary (the round-2 first form, t2n_mlp_ws.hip): there the samples went through LDS between the layers, so
+// Why not weight-stationary (the round-2 first form, 1.51 ms per C2 frame against 1.24 ms: profiles/round2_v16_* / round2_v17_*): there the samples went through LDS between the layers, so
 // every layer boundary was a workgroup barrier around a VALU-only phase (split + store) with the matrix pipe idle: a quarter of
 // the kernel. Here the conversion work rides in the MFMA slots of the wave's own stream, and the waves only meet at the ring.
 // Why 32x32x16 tiles: measured on the 16x16x32 form of this kernel, every non-MFMA instruction of a wave costs its ~4 issue

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         if (a.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.stats[T2N_STAT_F16_REDO], 1ull);
     }
     const unsigned wave_stride = gridDim.x * 4u;
-    float amax = 0.f;   // (range tracking lives in k_app_features / k_mlp_ws)
+    float amax = 0.f;   // (range tracking lives in k_app_features / k_mlp_ss)
 
     for (unsigned tile = a.tile_lo + blockIdx.x * 4u + wid; tile < ntiles; tile += wave_stride) {
         const int li = (int)__popcll(__ballot((lane < a.nlists) & (incl <= tile)));
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
 }
 
 // ---- features only (K2a of the default render path): gather + basis_mat -> fp32 feature rows [tile * 32 + sample][32] for the
-// weight-stationary head (t2n_mlp_ws.hip). The gather and basis stages of k_shade<true> without the head's code and registers:
+// sample-stationary head (t2n_mlp_ss.hip). The gather and basis stages of k_shade<true> without the head's code and registers:
 // one wave per 32-sample tile, X[144][33] through the wave's LDS tile, basis_mat as split-f16 MFMA products (weights x 2^8).
 // Raises *range_flag when a plane x line product left the f16 range (inf / NaN features are caught by the head's own check).
 template <bool HALF>
@@ -1093,7 +1093,7 @@ static bool use_coop(const t2n_field* f) {
 }
 
 static bool use_ws(const t2n_field* f) {
-    static const bool off = getenv("T2N_SHADE_NO_WS") != nullptr;   // A/B switch: the one-kernel cooperative path
+    static const bool off = getenv("T2N_SHADE_NO_WS") != nullptr;   // A/B switch: the one-kernel cooperative path instead of features + head
     return !off && use_coop(f);
 }
 
@@ -1124,7 +1124,7 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
     const bool half = f->factor_bf16 && f->dev.app.plane_h[0];
     const unsigned ws_tiles = feat ? feat_rows / 128u * 4u : 0u;
     if (use_ws(f) && !ctx && !features_only && ws_tiles >= 4u) {
-        // default render path: K2a gather + basis -> feature rows (t2n_appfeat.hip), K2b weight-stationary head (t2n_mlp_ws.hip);
+        // default render path: K2a gather + basis -> feature rows (t2n_appfeat.hip), K2b sample-stationary head (t2n_mlp_ss.hip);
         // tiles past the row capacity take the one-kernel path; a launch that met a value outside the f16 range is redone on the
         // exact fp32 path
         unsigned* flag = const_cast<unsigned*>(counters_dev) + kRangeFlagWord;
@@ -1139,9 +1139,7 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
         else hipLaunchKernelGGL(k_app_features<false>, grid, dim3(256), lds, s, fa);
         timing_end(f, T2N_K_APPFEAT, s);
         timing_begin(f, T2N_K_SHADE, s);
-        static const bool head_ws = getenv("T2N_HEAD_WS") != nullptr;   // A/B switch: the weight-stationary form of the head
-        const int rc = head_ws ? launch_mlp_ws(f, feat, counters_dev, list_cap, ws_tiles, app_rgb, flag, s)
-                               : launch_mlp_ss(f, feat, counters_dev, list_cap, ws_tiles, app_rgb, flag, s);
+        const int rc = launch_mlp_ss(f, feat, counters_dev, list_cap, ws_tiles, app_rgb, flag, s);
         if (rc) return rc;
         ShadeArgs oa = a;
         oa.tile_lo = ws_tiles;

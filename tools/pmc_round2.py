@@ -14,7 +14,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("t2n::", "").split("<")[0]
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("t2n::", "").replace("ss::", "").split("<")[0]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {"_comment": "per-launch PMC means of `bench.py --steps 3` (one launch = one 640000-ray 800x800 C2 frame), tools/pmc_round2.sh; "
                    "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB -> B), the doubling per MI355X_MICROARCH.md"}

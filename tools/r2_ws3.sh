@@ -12,4 +12,4 @@ try:
 except Exception as e:
     print("failed", e); print(open("$out/bench_ws.err").read()[-2000:])
 PY
-T2N_LIB=$PWD/text2nerf_amd/libt2n_hip_phase.so python tools/experiments/ws_phase.py 2>&1 | tee $out/ws_phase.txt
+T2N_LIB=$PWD/text2nerf_amd/libt2n_hip_phase.so python tools/experiments/ss_phase.py 2>&1 | tee $out/ws_phase.txt
