@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void k_dense(const float* __restrict__ IN, int
 // layer 2 (3 outputs) + sigmoid -> app_rgb of the row's list entry; 4 lanes per row
 struct Dense3Args {
     const float* h1; const float* w2; const float* b2; const unsigned* counters; unsigned list_cap; TilePrefixH tp; long long rows; float4* app_rgb;
+    const float4* app_pos;   // the entry's compositing weight (.w) rides along in app_rgb.w: k_composite reads one array
 };
 __global__ __launch_bounds__(256) void k_dense3_sigmoid(const Dense3Args a) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void k_dense3_sigmoid(const Dense3Args a) {
         unsigned idx;
         if (row_entry(row, a.tp, a.counters, a.list_cap, idx)) {
             const float r = 1.f / (1.f + expf(-(s0 + a.b2[0]))), g = 1.f / (1.f + expf(-(s1 + a.b2[1]))), b = 1.f / (1.f + expf(-(s2 + a.b2[2])));
-            a.app_rgb[idx] = make_float4(r, g, b, 0.f);
+            a.app_rgb[idx] = make_float4(r, g, b, a.app_pos[idx].w);
         }
     }
 }
@@ -238,7 +239,7 @@ int launch_head_forward(t2n_field* f, const unsigned tiles_before[kLists + 1], l
     if ((rc = launch_dense(x0, H.K0pad, P->mlp_w0, H.K0, 128, P->mlp_b0, 1, rows, h0, 128, s))) return rc;
     if ((rc = launch_dense(h0, 128, P->mlp_w1, 128, 128, P->mlp_b1, 1, rows, h1, 128, s))) return rc;
     Dense3Args d;
-    d.h1 = h1; d.w2 = P->mlp_w2; d.b2 = P->mlp_b2; d.counters = counters; d.list_cap = list_cap; d.tp = a.tp; d.rows = rows; d.app_rgb = app_rgb;
+    d.h1 = h1; d.w2 = P->mlp_w2; d.b2 = P->mlp_b2; d.counters = counters; d.list_cap = list_cap; d.tp = a.tp; d.rows = rows; d.app_rgb = app_rgb; d.app_pos = app_pos;
     hipLaunchKernelGGL(k_dense3_sigmoid, dim3((unsigned)((rows * 4 + 255) / 256)), dim3(256), 0, s, d);
     T2N_HIP(hipGetLastError());
     return T2N_OK;

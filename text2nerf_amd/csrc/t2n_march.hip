@@ -253,9 +253,8 @@ __global__ __launch_bounds__(256) void k_composite(const CompositeArgs a) {
     const int4 ra = a.ray_app[r];
     float cr = 0.f, cg = 0.f, cb = 0.f;
     for (int k = 0; k < ra.y; ++k) {
-        const float w = a.app_pos[ra.x + k].w;
-        const float4 c = a.app_rgb[ra.x + k];
-        cr = fmaf(w, c.x, cr); cg = fmaf(w, c.y, cg); cb = fmaf(w, c.z, cb);
+        const float4 c = a.app_rgb[ra.x + k];   // (r, g, b, w): the shading kernels copy the entry's weight next to its colour
+        cr = fmaf(c.w, c.x, cr); cg = fmaf(c.w, c.y, cg); cb = fmaf(c.w, c.z, cb);
     }
     if (a.add_bg) {
         const float bg = 1.f - a.acc[r];

@@ -56,7 +56,7 @@ constexpr float kRange = 59968.f;             // |activation| from here on (an f
 
 struct Args {
     const uint4* w0; const uint4* w1; const uint4* w2; const float* bias; const float* inv_scale;   // packed by k_pack_ss
-    const float* feat;            // [rows][32] fp32 feature rows (row = tile * 32 + sample), columns >= 27 zero
+    const float* feat;            // [rows][32] fp32 feature rows (row = tile * 32 + sample): 27 features, the entry's compositing weight, zeros
     const unsigned* counters; unsigned list_cap; int nlists;
     unsigned tile_hi;             // 32-sample tiles [0, min(ntiles, tile_hi)) are this kernel's
     float4* app_rgb;
@@ -367,6 +367,9 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
 #pragma unroll
         for (int e = 0; e < 14; ++e) amax_u = max(amax_u, __float_as_uint(E.f[e]) & 0x7fffffffu);
         const unsigned rn = r + gridDim.x < nrounds ? r + gridDim.x : r;
+        // column 27 of the feature row (feature "27" of half 1: zero weights) carries the entry's compositing weight: lane (j, 0)
+        // stores it next to the colour, k_composite then reads one array
+        const float wgt = __shfl(E.f[13], j + 32);
 #define SS_L0(C)                                                                                                                  \
         {                                                                                                                         \
             SS_PHASE(0);                                                                                                          \
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
                             bb = ((ch[0][2] + ch[2][2]) + ch[1][2]) * inv2;
                 // sigmoid by v_exp_f32 / v_rcp_f32 (1 ulp each: ~2e-7 absolute on a value in (0, 1))
                 a.app_rgb[idx] = make_float4(__builtin_amdgcn_rcpf(1.f + __expf(-rr)), __builtin_amdgcn_rcpf(1.f + __expf(-gg)),
-                                             __builtin_amdgcn_rcpf(1.f + __expf(-bb)), 0.f);
+                                             __builtin_amdgcn_rcpf(1.f + __expf(-bb)), wgt);
             }
         }
         SS_PHASE(4);

@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
             if (h == 0) { cr = Fe[0 * kXld + s]; cg = Fe[1 * kXld + s]; cb = Fe[2 * kXld + s]; }
         }
         if (h == 0 && live) {
-            if (a.app_rgb) a.app_rgb[idx] = make_float4(cr, cg, cb, 0.f);
+            if (a.app_rgb) a.app_rgb[idx] = make_float4(cr, cg, cb, a.app_pos[idx].w);   // .w: the compositing weight rides along (k_composite reads one array)
             if (a.rgb_out) { a.rgb_out[(size_t)idx * 3] = cr; a.rgb_out[(size_t)idx * 3 + 1] = cg; a.rgb_out[(size_t)idx * 3 + 2] = cb; }
         }
         wave_lds_sync();   // Fe reads done before the next tile's gather overwrites X
@@ -580,11 +580,14 @@ __global__ __launch_bounds__(256, 2) void k_app_features(const ShadeArgs a) {
         LdsChunk bf{X + s, h, kBasisChunksReal};
         f16_stream<1>(accb1, F.basisH, lane, kBasisChunks, bf);
         const f32x16 accb = accb1[0] * kWUnscale;
-        // lane (s, h) register v holds feature (v & 3) + 8 (v >> 2) + 4 h: four float4 stores per lane
+        // lane (s, h) register v holds feature (v & 3) + 8 (v >> 2) + 4 h: four float4 stores per lane. Column 27 (a zero of the
+        // padded basis) carries the entry's compositing weight to the head, which hands it on in app_rgb.w
         float* __restrict__ row = a.ctx.feat32 + ((size_t)tile * 32 + s) * 32 + 4 * h;
+        const unsigned eidx = base + (unsigned)s;
+        const float wgt = (h == 0 && eidx < count) ? a.app_pos[eidx].w : 0.f;   // lane (s, 0) holds columns 24..27 in registers 12..15
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(row + 8 * g) = make_float4(accb[4 * g], accb[4 * g + 1], accb[4 * g + 2], accb[4 * g + 3]);
+            *reinterpret_cast<float4*>(row + 8 * g) = make_float4(accb[4 * g], accb[4 * g + 1], accb[4 * g + 2], (g == 3 && h == 0) ? wgt : accb[4 * g + 3]);
         wave_lds_sync();   // X reads done before the next tile's gather
     }
     if (a.range_flag && __any(!(amax <= 60000.f)) && lane == 0) atomicOr(a.range_flag, 1u);
@@ -899,7 +902,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
         const f32x16 acc2 = acc2a[0] * kWUnscale;
         if (h == 0 && live) {
             const float cr = sigmoidf_(acc2[0]), cg = sigmoidf_(acc2[1]), cb = sigmoidf_(acc2[2]);
-            if (a.app_rgb) a.app_rgb[idx] = make_float4(cr, cg, cb, 0.f);
+            if (a.app_rgb) a.app_rgb[idx] = make_float4(cr, cg, cb, a.app_pos[idx].w);
             if (a.rgb_out) { a.rgb_out[(size_t)idx * 3] = cr; a.rgb_out[(size_t)idx * 3 + 1] = cg; a.rgb_out[(size_t)idx * 3 + 2] = cb; }
         }
         wave_lds_sync();   // H reads done before the next tile's gather overwrites the tile
