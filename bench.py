@@ -498,6 +498,19 @@ def main():
             "roofline": roof,
         }
         out["config"].update(dp)
+        try:   # render scratch actually reserved (appearance lists budgeted from the previous frame) next to the worst-case figure
+            from text2nerf_amd import _lib as _L, tensorf as _tf
+            _l = _L.load()
+            _ws = _tf._WORKSPACE.get(str(dev))
+            out["config"]["workspace"] = {
+                "reserved_GiB": round((_ws.numel() if _ws is not None else 0) / 2 ** 30, 2),
+                "worst_case_GiB": round(int(_l.t2n_render_workspace_bytes(R, N)) / 2 ** 30, 2),
+                "steady_state_hint_GiB": round(int(_l.t2n_render_workspace_bytes_hint(field.sync_params(), R, N)) / 2 ** 30, 2),
+                "list_retries": int(_l.t2n_field_list_retries(field.sync_params())),
+                "note": "image-ordered frames run as one launch with appearance lists sized from the previous frame's counters; "
+                        "an overflowing frame is rendered again with worst-case lists (counted in list_retries)"}
+        except Exception as e:   # reporting only
+            out["config"]["workspace"] = {"error": repr(e)}
         if c4_equal is not None:
             out["config"]["c4_gathered_equals_single_rank"] = c4_equal
 

@@ -1,0 +1,93 @@
+"""Budgeted appearance lists: an image-ordered frame given less than the worst-case workspace runs as ONE launch with
+lists sized for a per-ray entry budget; the library reads the march kernels' counters back (pinned copy + event) and renders a
+frame whose lists overflowed again with worst-case lists. Checked here: the budgeted frame is bitwise the worst-case frame, the hint
+shrinks once a frame has been seen, and a forced overflow is detected, counted and repaired (same pixels)."""
+import os
+
+import pytest
+import torch
+
+from text2nerf_amd import _lib, synth
+from tests.conftest import TINY
+from tests.test_hip_parity import dev, make_field
+
+pytestmark = pytest.mark.gpu
+
+
+def render(f, rays):
+    with torch.no_grad():
+        rgb, depth, _, _ = f(rays)
+    return rgb, depth, f.stats()
+
+
+def worst_case(f, rays):
+    os.environ["T2N_NO_BUDGET"] = "1"
+    try:
+        f.workspace_bytes_override = None
+        from text2nerf_amd import tensorf as tf
+        tf._WORKSPACE.clear()
+        return render(f, rays)
+    finally:
+        os.environ.pop("T2N_NO_BUDGET")
+
+
+def test_budgeted_frame_equals_worst_case_frame_c2():
+    lib = _lib.load()
+    aabb = [[-8.0] * 3, [8.0] * 3]
+    f = make_field(synth.make_field_params(0, [300] * 3, scene="S1-soft", aabb=aabb), [300] * 3, aabb, [0.5, 8.0])
+    f.materialize_weights = False
+    f.frame_width = 800
+    rays = torch.from_numpy(synth.frame_rays_np(800, 800)).to(dev())
+    R, N = rays.shape[0], f.nSamples
+    from text2nerf_amd import tensorf as tf
+    tf._WORKSPACE.clear()
+    h = f.sync_params()
+    worst = int(lib.t2n_render_workspace_bytes(R, N))
+    first = int(lib.t2n_render_workspace_bytes_hint(h, R, N))
+    assert first < worst / 2                                   # nothing known yet: a quarter of the samples per ray
+    rgb, depth, st = render(f, rays)
+    assert st["list_retry"] == 0 and tf._WORKSPACE[str(dev())].numel() == first
+    second = int(lib.t2n_render_workspace_bytes_hint(h, R, N))
+    assert second < first and second < worst / 3               # ~7 entries per ray seen: 30 reserved
+    rgb2, depth2, st2 = render(f, rays)
+    assert st2["list_retry"] == 0 and st2["appearance"] == st["appearance"]
+    ref = worst_case(f, rays)
+    assert ref[2]["list_retry"] == 0
+    for a in ((rgb, depth), (rgb2, depth2)):
+        assert torch.equal(a[0], ref[0]) and torch.equal(a[1], ref[1])
+    assert int(lib.t2n_field_list_retries(h)) == 0
+    tf._WORKSPACE.clear()
+
+
+def test_overflowing_budget_is_detected_and_repaired(tiny_params):
+    """A 256x256 frame of the small field needs ~5 entries per ray: handed a workspace for 2, the call must come back with the
+    worst-case result, say so in its stats, and ask for more room next time."""
+    lib = _lib.load()
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    f.materialize_weights = False
+    f.frame_width = 256
+    rays = torch.from_numpy(synth.frame_rays_np(256, 256, c2w=synth.look_pose(0.3, -0.1, (0.2, 0.1, -1.0)))).to(dev())
+    R, N = rays.shape[0], f.nSamples
+    ref_rgb, ref_depth, ref_st = worst_case(f, rays)
+    per_ray = ref_st["appearance"] / R
+    assert per_ray > 3, per_ray
+    h = f.sync_params()
+    f.workspace_bytes_override = int(lib.t2n_render_workspace_bytes_budget(R, N, 2))
+    assert f.workspace_bytes_override < int(lib.t2n_render_workspace_bytes(R, N))
+    before = int(lib.t2n_field_list_retries(h))
+    rgb, depth, st = render(f, rays)
+    assert st["list_retry"] == 1 and int(lib.t2n_field_list_retries(h)) == before + 1
+    assert st["appearance"] == ref_st["appearance"] and st["evaluated"] == ref_st["evaluated"]
+    assert torch.equal(rgb, ref_rgb) and torch.equal(depth, ref_depth)
+    # the next hint asks for more than the failed budget
+    f.workspace_bytes_override = None
+    assert int(lib.t2n_render_workspace_bytes_hint(h, R, N)) > int(lib.t2n_render_workspace_bytes_budget(R, N, 2))
+    # a budget with room: one launch, no retry, same pixels
+    f.workspace_bytes_override = int(lib.t2n_render_workspace_bytes_budget(R, N, int(per_ray * 1.5) + 8))
+    if f.workspace_bytes_override < int(lib.t2n_render_workspace_bytes(R, N)):
+        rgb3, depth3, st3 = render(f, rays)
+        assert st3["list_retry"] == 0
+        assert torch.equal(rgb3, ref_rgb) and torch.equal(depth3, ref_depth)
+    f.workspace_bytes_override = None
+    from text2nerf_amd import tensorf as tf
+    tf._WORKSPACE.clear()

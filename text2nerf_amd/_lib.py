@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("T2N_LIB") or os.path.join(_HERE, "libt2n_hip.so")
 T2N_STAT_COUNT = 8
 T2N_K_COUNT = 9
 KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_mlp", "bwd_scatter", "density", "app_features")
-STAT_EVALUATED, STAT_APPEARANCE, STAT_RAYS, STAT_OVERFLOW, STAT_F16_REDO = 0, 1, 2, 3, 4
+STAT_EVALUATED, STAT_APPEARANCE, STAT_RAYS, STAT_OVERFLOW, STAT_F16_REDO, STAT_LIST_RETRY = 0, 1, 2, 3, 4, 5
 
 FLAG_TRAIN, FLAG_ADD_BG, FLAG_KEEP_CTX, FLAG_COHERENT, FLAG_NDC = 1, 2, 4, 8, 16
 SHADE_IDS = {"MLP_Fea_noview": 0, "SH": 1, "RGB": 2, "MLP_Fea": 3, "MLP_PE": 4, "MLP": 5}   # MLP_PE: rejected in tensorf.py (broken upstream)
@@ -71,6 +71,9 @@ SIGNATURES = {
     "t2n_raw2alpha": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
     "t2n_render_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "t2n_render_workspace_bytes_hint": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int]),
+    "t2n_field_list_retries": (C.c_uint64, [C.c_void_p]),
+    "t2n_render_workspace_bytes_budget": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "t2n_render_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),

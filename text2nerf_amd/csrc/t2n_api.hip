@@ -352,9 +352,9 @@ __global__ __launch_bounds__(256) void k_ndc_rays(int H, int W, float focal, flo
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat) {
+Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat, unsigned budget) {
     Carve c;
-    c.list_cap = list_capacity(rays, n_samples);
+    c.list_cap = list_capacity_budget(rays, n_samples, budget);
     const size_t cap = (size_t)c.list_cap * kLists;
     size_t o = 0;
     c.counters = o; o = align_up(o + (size_t)kLists * kCounterStride * 4, 256);
@@ -371,7 +371,7 @@ Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat) {
     // appearance feature rows between the gather + basis kernel and the sample-stationary head: 32 rows per ray (the bench
     // scene needs ~7, BASELINE configs[0] ~44), never more than the worst case; appearance tiles past the capacity take the
     // one-kernel path
-    const size_t worst_rows = cap + (size_t)kLists * 32, want_rows = (size_t)rays * 32 + 1024;
+    const size_t worst_rows = cap + (size_t)kLists * 32, want_rows = (size_t)rays * (budget && budget < 64 ? (budget + 1) / 2 : 32) + 1024;
     c.feat_rows = (unsigned)(((worst_rows < want_rows ? worst_rows : want_rows) + 127) / 128 * 128);
     if (!feat) c.feat_rows = 0;
     c.feat = o; o = align_up(o + (size_t)c.feat_rows * 32 * sizeof(float), 256);
@@ -379,6 +379,9 @@ Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat) {
     return c;
 }
 static Carve carve(int64_t rays, int n_samples) { return carve_workspace(rays, n_samples, true); }
+constexpr unsigned kBudgetMin = 16;          // smallest per-ray entry budget the hint asks for
+constexpr unsigned kBudgetFloor = 2;         // smallest budget a launch is tried with (a caller's choice of workspace)
+constexpr int64_t kBudgetMinRays = 65536;   // small calls keep worst-case lists (no host wait on the counters)
 
 }  // namespace t2n
 
@@ -424,6 +427,8 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->buf_mlp) (void)hipFree(f->buf_mlp);
     if (f->buf_mlp_h) (void)hipFree(f->buf_mlp_h);
     if (f->buf_ss) (void)hipFree(f->buf_ss);
+    if (f->host_counts) (void)hipHostFree(f->host_counts);
+    if (f->ev_counts) (void)hipEventDestroy((hipEvent_t)f->ev_counts);
     if (f->buf_alpha) (void)hipFree(f->buf_alpha);
     for (int k = 0; k < T2N_K_COUNT; ++k)
         for (int i = 0; i < 64; ++i) {
@@ -583,18 +588,36 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     }
     // largest sub-launch whose worst case (every sample an appearance sample) fits the workspace
     int64_t per = n_rays;
-    while (!keep && per > 1 && carve(per, n_samples).total > workspace_bytes) per = (per + 1) / 2;
-    if (!keep && carve(per, n_samples).total > workspace_bytes) { set_error("t2n_render_forward: workspace %zu B too small", workspace_bytes); return T2N_ERR_WORKSPACE; }
-    while ((uint64_t)list_capacity(per, n_samples) * kLists > 0x7fffffffull) per = (per + 1) / 2;   // int slots
-    if (tiles && per < n_rays) {   // sub-launches must cover whole 8-row bands of the image
-        const int64_t band = (int64_t)8 * f->frame_w;
-        per = per / band * band;
-        if (per <= 0) { set_error("t2n_render_forward: workspace too small for one 8-row band"); return T2N_ERR_WORKSPACE; }
+    unsigned budget = 0;   // appearance entries per ray the lists are sized for (0: worst case)
+    // A frame for the tile marcher whose worst case does not fit is first tried as ONE launch with budgeted lists (the largest
+    // budget the workspace holds): a C2 frame needs ~7 entries per ray where the worst case reserves 518. The counters reach
+    // pinned host memory behind the march kernels; a launch that overflowed is redone below in worst-case sub-launches.
+    if (tiles && carve(n_rays, n_samples).total > workspace_bytes && n_rays >= kBudgetMinRays && !getenv("T2N_NO_BUDGET")) {
+        unsigned lo = 0, hi = (unsigned)n_samples;   // largest budget in [kBudgetFloor, n_samples) that fits
+        if (carve_workspace(n_rays, n_samples, true, true, kBudgetFloor).total <= workspace_bytes) {
+            lo = kBudgetFloor;
+            while (hi - lo > 1) {
+                const unsigned mid = lo + (hi - lo) / 2;
+                if (carve_workspace(n_rays, n_samples, true, true, mid).total <= workspace_bytes) lo = mid; else hi = mid;
+            }
+        }
+        if (lo >= kBudgetFloor && (uint64_t)list_capacity_budget(n_rays, n_samples, lo) * kLists <= 0x7fffffffull) budget = lo;
+    }
+retry_worst_case:
+    if (!budget) {
+        while (!keep && per > 1 && carve(per, n_samples).total > workspace_bytes) per = (per + 1) / 2;
+        if (!keep && carve(per, n_samples).total > workspace_bytes) { set_error("t2n_render_forward: workspace %zu B too small", workspace_bytes); return T2N_ERR_WORKSPACE; }
+        while ((uint64_t)list_capacity(per, n_samples) * kLists > 0x7fffffffull) per = (per + 1) / 2;   // int slots
+        if (tiles && per < n_rays) {   // sub-launches must cover whole 8-row bands of the image
+            const int64_t band = (int64_t)8 * f->frame_w;
+            per = per / band * band;
+            if (per <= 0) { set_error("t2n_render_forward: workspace too small for one 8-row band"); return T2N_ERR_WORKSPACE; }
+        }
     }
     char* ws = (char*)workspace;
     for (int64_t off = 0; off < n_rays; off += per) {
         const int64_t cnt = (n_rays - off) < per ? (n_rays - off) : per;
-        const Carve c = carve_workspace(per, n_samples, true, !keep);
+        const Carve c = carve_workspace(per, n_samples, true, !keep, budget);
         RenderLaunch L;
         L.rays = rays + off * ray_stride; L.n_rays = cnt; L.ray_stride = ray_stride; L.n_samples = n_samples; L.flags = flags;
         L.jitter = (jitter && !ndc) ? jitter + off : jitter;     // NDC: one table for every sub-launch
@@ -619,6 +642,16 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         if (tiles) {
             if ((rc = launch_march_tiles(f, L, f->frame_w, (int)(cnt / f->frame_w), (float*)(ws + c.sigma), (float4*)(ws + c.scratch), s))) return rc;
         } else if ((rc = launch_march(f, L, s))) return rc;
+        if (budget) {   // counters (sub-list fills, overflow word) -> pinned host memory, an event behind the copy
+            if (!f->host_counts) {
+                T2N_HIP(hipHostMalloc((void**)&f->host_counts, sizeof(unsigned) * kLists * kCounterStride, hipHostMallocDefault));
+                hipEvent_t ev;
+                T2N_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                f->ev_counts = (void*)ev;
+            }
+            T2N_HIP(hipMemcpyAsync(f->host_counts, L.counters, sizeof(unsigned) * kLists * kCounterStride, hipMemcpyDeviceToHost, s));
+            T2N_HIP(hipEventRecord((hipEvent_t)f->ev_counts, s));
+        }
         if (keep && (rc = ctx_counts_post(workspace, L.counters, s))) return rc;   // the backward sizes itself from these without draining the stream
         if (head_is_generic(f->desc.shading)) {
             // general head path: the appearance-row count is needed on the host to size the activation scratch (one stream
@@ -654,7 +687,49 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         }
         if ((rc = launch_composite(f, L, s))) return rc;
     }
+    if (budget) {
+        // the appearance and compositing kernels are queued behind the march; the host only waits for the march itself
+        T2N_HIP(hipEventSynchronize((hipEvent_t)f->ev_counts));
+        unsigned long long used = 0;
+        for (int l = 0; l < kLists; ++l) {
+            const unsigned c = f->host_counts[l * kCounterStride], cap = list_capacity_budget(n_rays, n_samples, budget);
+            used += c < cap ? c : cap;
+        }
+        if (f->host_counts[kOverflowWord]) {
+            // some rays found no room: everything is rendered again with worst-case lists (sub-launches sized to the workspace);
+            // the next call's hint asks for room
+            f->list_retries++;
+            f->list_hint = 2u * budget < (unsigned)n_samples ? 2u * budget : (unsigned)n_samples;   // the next hint asks for > 4x the room
+            if (stats) {
+                T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s));
+                T2N_HIP(hipMemsetD32Async((hipDeviceptr_t)(stats + T2N_STAT_LIST_RETRY), 1, 1, s));
+            }
+            budget = 0;
+            per = n_rays;
+            goto retry_worst_case;
+        }
+        f->list_hint = (unsigned)((used + (unsigned long long)n_rays - 1) / (unsigned long long)n_rays);
+        if (!f->list_hint) f->list_hint = 1;
+    }
     return T2N_OK;
+}
+
+// Workspace for one budgeted launch of a frame, from what the field's last such launch needed: twice the entries per ray it
+// used + 16, at least kBudgetMin; a quarter of the samples when nothing is known yet. Never more than the worst case.
+extern "C" size_t t2n_render_workspace_bytes_hint(const t2n_field* f, int64_t n_rays, int n_samples) {
+    if (!f || n_rays <= 0 || n_samples <= 0) return 0;
+    const size_t worst = carve(n_rays, n_samples).total;
+    if (n_rays < kBudgetMinRays) return worst;
+    unsigned b = f->list_hint ? 2u * f->list_hint + 16u : (unsigned)(n_samples / 4 > 64 ? n_samples / 4 : 64);
+    if (b < kBudgetMin) b = kBudgetMin;
+    if (b >= (unsigned)n_samples) return worst;
+    const size_t want = carve_workspace(n_rays, n_samples, true, true, b).total;
+    return want < worst ? want : worst;
+}
+extern "C" uint64_t t2n_field_list_retries(const t2n_field* f) { return f ? f->list_retries : 0; }
+extern "C" size_t t2n_render_workspace_bytes_budget(int64_t n_rays, int n_samples, int entries_per_ray) {
+    if (n_rays <= 0 || n_samples <= 0 || entries_per_ray < 0) return 0;
+    return carve_workspace(n_rays, n_samples, true, true, (unsigned)entries_per_ray).total;
 }
 
 extern "C" int t2n_field_set_alpha_mask(t2n_field* f, const float* volume, int D, int H, int W, const float* aabb_min_host,

@@ -91,6 +91,11 @@ struct t2n_field {
     int timing = 0;
     int frame_w = 0;           // image width hint for the tile marcher (0: unknown)
     t2n::TimingSlot slots[T2N_K_COUNT];
+    // optimistic (budgeted) render launches: the counters travel to pinned host memory behind the march kernels; the entries a
+    // ray needed last time size the next call's lists (t2n_render_workspace_bytes_hint)
+    unsigned* host_counts = nullptr; void* ev_counts = nullptr;
+    unsigned list_hint = 0;          // appearance entries per ray of the last budgeted launch (0: unknown)
+    unsigned long long list_retries = 0;
 };
 
 namespace t2n {
@@ -133,6 +138,15 @@ inline unsigned list_capacity(long long n_rays, int n_samples) {
     // with n_samples spare entries per list a ray that fits nowhere would imply more entries than rays x samples
     return ((nblocks >> 3) + ((nblocks & 7u) ? 1u : 0u)) * 4u * (unsigned)n_samples + (unsigned)n_samples;
 }
+// Budgeted form (optimistic launches of t2n_render_forward): `budget` appearance entries per ray on average over the launch,
+// split evenly over the sub-lists, + the same per-list slack. A launch that does not fit raises word kOverflowWord of the counter
+// block (the rays concerned keep no appearance samples) and is redone by the caller with worst-case lists.
+inline unsigned list_capacity_budget(long long n_rays, int n_samples, unsigned budget) {
+    const unsigned worst = list_capacity(n_rays, n_samples);
+    if (budget == 0 || budget >= (unsigned)n_samples) return worst;
+    const unsigned long long per = ((unsigned long long)n_rays * budget + kLists - 1) / kLists + (unsigned)n_samples;
+    return per < worst ? (unsigned)per : worst;
+}
 // Activation rows kept by the shade kernel in ctx mode (row = tile * 32 + lane sample; zero rows past a sub-list's end)
 struct ShadeCtx { float* x144; float* feat32; float* h0; float* h1; };
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
@@ -146,6 +160,7 @@ constexpr int kRangeFlagWord = 32;
 // with which capacity; the backward takes the kept path only when both match what it derives from ITS workspace size, and clears
 // the statement once it has consumed the rows (h0 / h1 are overwritten in place).
 constexpr int kKeptMagicWord = 33, kKeptRowsWord = 34;
+constexpr int kOverflowWord = 35;   // raised by the march kernels when a ray's appearance entries fit no sub-list (budgeted lists only)
 constexpr unsigned kKeptMagic = 0x4b455054u;   // "KEPT"
 int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev, unsigned list_cap, unsigned tile_hi, float4* app_rgb,
                   unsigned* range_flag, hipStream_t s);
@@ -162,7 +177,7 @@ int launch_head_in_bwd(t2n_field* f, const float* gx, const float* feat32, long 
 
 // forward-workspace carve shared by forward and backward (t2n_api.hip)
 struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, feat, total; unsigned list_cap, feat_rows; };
-Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat = true);   // ctx: also room for sigma [rays,N] and rgb_raw [rays]; feat: feature rows (last region: the other offsets do not depend on it; KEEP_CTX calls carve without)
+Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat = true, unsigned budget = 0);   // budget: appearance entries per ray (0: worst case)   // ctx: also room for sigma [rays,N] and rgb_raw [rays]; feat: feature rows (last region: the other offsets do not depend on it; KEEP_CTX calls carve without)
 int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s);
 int ctx_counts_post(const void* ws, const unsigned* counters_dev, hipStream_t s);   // KEEP_CTX forward: counts -> pinned host copy + event (t2n_backward.hip)
 // Activation rows the forward keeps for the backward when the KEEP_CTX workspace is larger than the context itself (the

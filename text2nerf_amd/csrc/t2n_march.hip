@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
         a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, (int)(nvalid - nmask), Lw > 0 ? (first | (Lw << 11)) : 0);
         a.acc[r] = acc;
         a.depth[r] = dep + (1.f - acc) * ray.last;   // :504-505
-        if (!fits && a.stats) a.stats[T2N_STAT_OVERFLOW] = 1ull;   // cannot happen: list_cap is the worst case
+        if (!fits && a.stats) a.stats[T2N_STAT_OVERFLOW] = 1ull;   // cannot happen: list_cap is the worst case on this path
+        if (!fits) a.counters[kOverflowWord] = 1u;
         if (!fits) napp = 0;
     }
     napp = __shfl(napp, 0);

@@ -414,6 +414,7 @@ __device__ __forceinline__ void reserve_slots(const CompactArgs& a, long long r,
         }
         a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, ra.z, ra.w);
         if (!fits && a.stats) a.stats[T2N_STAT_OVERFLOW] = 1ull;
+        if (!fits) a.counters[kOverflowWord] = 1u;   // budgeted lists: t2n_render_forward redoes the launch with worst-case lists
         if (!fits) napp = 0;
     }
     slot0 = __shfl(slot0, 0);

@@ -93,7 +93,8 @@ def to_device_async(t: torch.Tensor, device) -> torch.Tensor:
 def workspace_budget(device=None) -> int:
     """Largest scratch buffer a render call may take (a call needing more is split into sub-launches by the library).
     Default: an eighth of the device's memory, at most 32 GiB — on a 288 GB MI355X a whole 800x800 x 518-sample frame
-    (13.6 GiB worst-case lists, almost all of it reserved and never touched) runs as ONE launch; T2N_WORKSPACE_GIB overrides."""
+    runs as ONE launch even with worst-case lists (16 GiB; image-ordered frames ask for budgeted lists instead: ~6 GiB for the first
+    frame, ~4.7 GiB from then on, see t2n_render_workspace_bytes_hint); T2N_WORKSPACE_GIB overrides."""
     env = os.environ.get("T2N_WORKSPACE_GIB")
     if env is not None:
         return int(float(env) * (1 << 30))
@@ -800,7 +801,13 @@ class TensorVMSplit(nn.Module):
             flags |= FLAG_KEEP_CTX
         else:
             need = int(lib.t2n_render_workspace_bytes(max(R, 1), N))
+            if flags & FLAG_COHERENT:
+                # image-ordered frames: lists budgeted from what the previous frame needed instead of the worst case (the library
+                # checks the march kernels' counters and redoes an overflowed frame with worst-case lists)
+                need = min(need, int(lib.t2n_render_workspace_bytes_hint(h, max(R, 1), N)))
             ws = workspace(dev, min(need, max(workspace_budget(dev), int(lib.t2n_render_workspace_bytes(1024, N)))))
+            if getattr(self, "workspace_bytes_override", None):    # tests: hand the call exactly this much of the buffer
+                ws = workspace(dev, int(self.workspace_bytes_override))[:int(self.workspace_bytes_override)]
         with torch.cuda.device(dev):
             _lib.check(lib.t2n_render_forward(h, _lib.ptr(rays), R, rays.shape[1], N, flags, _lib.ptr(jitter),
                                               _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(w), _lib.ptr(z),
@@ -903,7 +910,8 @@ class TensorVMSplit(nn.Module):
         s = self.last_stats.cpu().tolist()
         if s[_lib.STAT_OVERFLOW]:
             raise T2NError("appearance list overflow — workspace sizing bug")
-        return {"evaluated": s[_lib.STAT_EVALUATED], "appearance": s[_lib.STAT_APPEARANCE], "f16_redo": s[_lib.STAT_F16_REDO]}
+        return {"evaluated": s[_lib.STAT_EVALUATED], "appearance": s[_lib.STAT_APPEARANCE], "f16_redo": s[_lib.STAT_F16_REDO],
+                "list_retry": s[_lib.STAT_LIST_RETRY]}
 
 
 class TensorVM(TensorVMSplit):
