@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_relayout_add(const float* __restrict__ 
 
 // Activation / gradient rows of the backward pass. Buffers whose lifetimes do not overlap (or that are rewritten
 // element-in-place by the same thread) share storage: g1 over h1, g0 over h0, gx over xpe, gf over feat32, gX over x144.
-struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, hist, tile_start, nseg, segs, recs, a_hist, a_tile_start, a_nseg, a_segs, a_recs, total; unsigned seg_cap, a_seg_cap; };
+struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, gpack, hist, tile_start, nseg, segs, recs, a_hist, a_tile_start, a_nseg, a_segs, a_recs, total; unsigned seg_cap, a_seg_cap; };
 // split of a [rows] x (M<=128) x N weight-gradient GEMM into row chunks: ~768 workgroups, chunk a multiple of 32 rows
 struct TnPlan { int chunk_rows, chunks, ng, ldp; };
 static TnPlan tn_plan(int64_t rows, int N) {
@@ -1044,6 +1044,7 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
     c.go = o; o = al256(o + R * 16);
     c.xpe = o; o = al256(o + R * (size_t)((k0 + 3) & ~3) * 4);
     c.part = o; o = al256(o + tn_part_bytes(rows, k0));
+    c.gpack = o; o = al256(o + gemm_h_pack_bytes(k0));   // packed W^T operands of the input-gradient GEMMs (t2n_gemm_h.hip)
     // tile-binned density scatter: worst case one record per sample and plane
     const size_t cap = (size_t)n_rays * (size_t)n_samples;
     c.seg_cap = (unsigned)(3 * cap / 512 + (size_t)n_tiles + 1);
@@ -1311,15 +1312,23 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         // 4. layers 1, 0, PE, basis
         if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s);
         if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
-        launch_gemm_nn(g1, 128, P->mlp_w1, 128, rows, 128, 128, h0, 128, g0, 128, s);
+        // input-gradient GEMMs: split-f16 MFMA products with a power-of-two scale per row (t2n_gemm_h.hip); T2N_BWD_GEMM_FP32=1
+        // keeps the fp32-MFMA form
+        static const bool gemm_fp32 = getenv("T2N_BWD_GEMM_FP32") != nullptr;
+        void* gpack = (void*)(bw + b.gpack);
+        if (!gemm_fp32 && (rc = gemm_h_pack(f, gpack, K0, s))) return rc;
+        if (gemm_fp32) launch_gemm_nn(g1, 128, P->mlp_w1, 128, rows, 128, 128, h0, 128, g0, 128, s);
+        else if ((rc = launch_gemm_nn_h(gpack, 0, K0, g1, 128, rows, h0, 128, g0, 128, s))) return rc;
         if (!generic) hipLaunchKernelGGL(k_pe_fwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)feat32, (long long)rows, xpe);
         if (g->mlp_w0) launch_gemm_tn<4>(g0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, s);
         if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g0, 128, (long long)rows, 128, g->mlp_b0, 128);
-        launch_gemm_nn(g0, 128, P->mlp_w0, K0, rows, 128, K0, nullptr, 0, gx, K0pad, s);
+        if (gemm_fp32) launch_gemm_nn(g0, 128, P->mlp_w0, K0, rows, 128, K0, nullptr, 0, gx, K0pad, s);
+        else if ((rc = launch_gemm_nn_h(gpack, 1, K0, g0, 128, rows, nullptr, 0, gx, K0pad, s))) return rc;
         if (!generic) hipLaunchKernelGGL(k_pe_bwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)gx, (const float*)feat32, (long long)rows, gf);
         else if ((rc = launch_head_in_bwd(f, gx, feat32, rows, gf, s))) return rc;
         if (g->basis_weight) launch_gemm_tn<1>(gf, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, s);
-        launch_gemm_nn(gf, 32, P->basis_weight, 144, rows, f->desc.app_dim, 144, nullptr, 0, gxapp, 144, s);
+        if (gemm_fp32) launch_gemm_nn(gf, 32, P->basis_weight, 144, rows, f->desc.app_dim, 144, nullptr, 0, gxapp, 144, s);
+        else if ((rc = launch_gemm_nn_h(gpack, 2, K0, gf, 32, rows, nullptr, 0, gxapp, 144, s))) return rc;
         timing_end(f, T2N_K_BWD_MLP, s);
         T2N_HIP(hipGetLastError());
         // 5. appearance scatter

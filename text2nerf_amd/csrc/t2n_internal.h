@@ -175,6 +175,11 @@ int launch_head_forward(t2n_field* f, const unsigned tiles_before[kLists + 1], l
                         float* h0, float* h1, float4* app_rgb, hipStream_t s);
 int launch_head_in_bwd(t2n_field* f, const float* gx, const float* feat32, long long rows, float* gf, hipStream_t s);
 
+// input-gradient GEMMs of the MLP backward on the f16 matrix cores (t2n_gemm_h.hip)
+size_t gemm_h_pack_bytes(int K0);
+int gemm_h_pack(t2n_field* f, void* buf, int K0, hipStream_t s);
+int launch_gemm_nn_h(void* packbuf, int which, int K0, const float* IN, int ldin, long long rows, const float* ACT, int ldact, float* OUT,
+                     int ldo, hipStream_t s);
 // forward-workspace carve shared by forward and backward (t2n_api.hip)
 struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, feat, total; unsigned list_cap, feat_rows; };
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat = true, unsigned budget = 0);   // budget: appearance entries per ray (0: worst case)   // ctx: also room for sigma [rays,N] and rgb_raw [rays]; feat: feature rows (last region: the other offsets do not depend on it; KEEP_CTX calls carve without)
