@@ -1098,8 +1098,10 @@ template <int MB>
 static void launch_gemm_tn(const float* A, int lda, const float* B, int ldb, long long rows, int M, int N, float* C, int ldc,
                            float* part, hipStream_t s) {
     const TnPlan p = tn_plan(rows, N);
-    hipLaunchKernelGGL((k_gemm_tn<MB>), dim3((unsigned)p.ng, (unsigned)p.chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part,
-                       p.ldp, p.chunk_rows);
+    static const bool gemm_fp32 = getenv("T2N_BWD_GEMM_FP32") != nullptr;   // the fp32-MFMA form instead of the bf16x3 one (t2n_gemm_h.hip)
+    if (!gemm_fp32 && MB == 4) (void)launch_gemm_tn_b(A, lda, B, ldb, rows, N, part, p.ldp, p.chunk_rows, p.ng, p.chunks, s);   // (the 27-row basis gradient is latency-bound either way: 31 us fp32, 44 us bf16x3)
+    else hipLaunchKernelGGL((k_gemm_tn<MB>), dim3((unsigned)p.ng, (unsigned)p.chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part,
+                            p.ldp, p.chunk_rows);
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((MB * 32 * p.ldp + 255) / 256)), dim3(256), 0, s, (const float*)part,
                        p.chunks, MB * 32, p.ldp, M, N, C, ldc);
 }

@@ -170,6 +170,101 @@ __global__ __launch_bounds__(256) void k_gemm_nn_h(const NnArgs a) {
     }
 }
 
+
+// ---- weight-gradient GEMMs: part[chunk][M, N] = A^T B over a row chunk (A [rows, lda] gradients, B [rows, ldb] activations; the chunks
+// are summed by k_gemm_tn_reduce). Here the contraction runs over ROWS, so no per-row scale can be factored out and the operands span
+// fp32's whole exponent range: every fp32 value is split THREE ways into bf16 parts (x = h + m + l by truncation, each residual exact;
+// bf16 has fp32's exponent range, so nothing needs scaling) and a product is the six bf16 MFMA products of weight >= 2^-16
+// (h h, h m, m h, h l, l h, m m: ~2^-24 relative, fp32 accumulate) on v_mfma_f32_32x32x16_bf16 — 192 matrix cycles per 16 rows of a
+// 32 x 32 block against 512 for v_mfma_f32_32x32x2_f32. Lane (i, kh) of a wave loads 8 consecutive rows of ONE column straight
+// from global memory (coalesced across the 32 columns of a block), which IS its MFMA operand: wave w converts A block w once per step
+// and shares it through LDS (two buffers, one barrier per step); every wave keeps its own B block in registers. One step of rows is
+// in flight under the current step's conversion and MFMAs (two steps ahead measured slower: 134 -> 162 us).
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_b(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+// two fp32 values -> packed bf16 parts (value 0 in the low half): h / m / l words
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+struct Op3 { uint4 h, m, l; };
+__device__ __forceinline__ Op3 split_unit(const float (&x)[8]) {
+    Op3 o;
+    split3(x[0], x[1], o.h.x, o.m.x, o.l.x);
+    split3(x[2], x[3], o.h.y, o.m.y, o.l.y);
+    split3(x[4], x[5], o.h.z, o.m.z, o.l.z);
+    split3(x[6], x[7], o.h.w, o.m.w, o.l.w);
+    return o;
+}
+
+template <int MB>
+__global__ __launch_bounds__(256) void k_gemm_tn_b(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                   long long rows, int N, float* __restrict__ part, int ldp, int chunk_rows) {
+    __shared__ __attribute__((aligned(16))) uint4 sA[2][MB][3][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, kh = lane >> 5;
+    const int ng = blockIdx.x;
+    const long long r0 = (long long)blockIdx.y * chunk_rows;
+    const long long r1 = (r0 + chunk_rows < rows) ? r0 + chunk_rows : rows;
+    const bool loads_a = w < MB;
+    const int bcol = ng * 128 + 32 * w + i;
+    const bool bok = bcol < ldb && bcol < N + 3;          // columns N .. ldb are padding the caller ignores
+    const float* __restrict__ Ab = A + (loads_a ? 32 * w + i : 0);
+    const float* __restrict__ Bb = B + (bok ? bcol : 0);
+    float xa[8], xb[8];
+    auto fetch = [&](long long kt) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            long long r = kt + 8 * kh + e;
+            r = r < r1 ? r : r1 - 1;                       // clamped address, masked below: no per-load branches
+            xa[e] = Ab[r * lda];
+            xb[e] = Bb[r * ldb];
+        }
+    };
+    f32x16 acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = f32x16{0};
+    if (r0 < r1) fetch(r0);
+    int buf = 0;
+    for (long long kt = r0; kt < r1; kt += 16, buf ^= 1) {
+        float a8[8], b8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = kt + 8 * kh + e < r1;
+            a8[e] = ok ? xa[e] : 0.f;
+            b8[e] = (ok && bok) ? xb[e] : 0.f;
+        }
+        if (kt + 16 < r1) fetch(kt + 16);                  // the next step's rows in flight under this step's conversion and MFMAs
+        if (loads_a) {
+            const Op3 oa = split_unit(a8);
+            sA[buf][w][0][lane] = oa.h; sA[buf][w][1][lane] = oa.m; sA[buf][w][2][lane] = oa.l;
+        }
+        const Op3 ob = split_unit(b8);
+        __syncthreads();   // this step's A blocks are in buffer `buf`; the other buffer's readers finished before the previous barrier
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const uint4 ah = sA[buf][m][0][lane], am = sA[buf][m][1][lane], al = sA[buf][m][2][lane];
+            acc[m] = mfma_b(ah, ob.h, acc[m]);
+            acc[m] = mfma_b(ah, ob.m, acc[m]);
+            acc[m] = mfma_b(am, ob.h, acc[m]);
+            acc[m] = mfma_b(ah, ob.l, acc[m]);
+            acc[m] = mfma_b(al, ob.h, acc[m]);
+            acc[m] = mfma_b(am, ob.m, acc[m]);
+        }
+    }
+    float* __restrict__ P = part + (size_t)blockIdx.y * (MB * 32) * ldp + ng * 128 + w * 32 + i;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) P[(size_t)(m * 32 + (v & 3) + 8 * (v >> 2) + 4 * kh) * ldp] = acc[m][v];
+}
+
 }  // namespace gh
 
 // ---- host side: one pack per backward (the weights change every optimiser step), three GEMM calls -------------------------------------
@@ -224,6 +319,15 @@ int launch_gemm_nn_h(void* packbuf, int which, int K0, const float* IN, int ldin
     }
     if (steps == 8) hipLaunchKernelGGL(k_gemm_nn_h<8>, dim3((unsigned)ng, (unsigned)by), dim3(256), (size_t)8 * 512 * 16, s, a);
     else hipLaunchKernelGGL(k_gemm_nn_h<2>, dim3((unsigned)ng, (unsigned)by), dim3(256), (size_t)2 * 512 * 16, s, a);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+// part[chunks][128][ldp] = per-chunk A^T B for the 128-column gradients (the caller reduces the chunks)
+int launch_gemm_tn_b(const float* A, int lda, const float* B, int ldb, long long rows, int N, float* part, int ldp, int chunk_rows,
+                     int ng, int chunks, hipStream_t s) {
+    using namespace gh;
+    hipLaunchKernelGGL(k_gemm_tn_b<4>, dim3((unsigned)ng, (unsigned)chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part, ldp, chunk_rows);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }
