@@ -1094,14 +1094,24 @@ static int ensure_grad_buffers(t2n_field* f) {
     return T2N_OK;
 }
 
+static bool gemm_fp32_mode() {
+    static const bool v = getenv("T2N_BWD_GEMM_FP32") != nullptr;   // the fp32-MFMA GEMMs instead of the f16 / bf16 split ones (t2n_gemm_h.hip)
+    return v;
+}
+// pe_feat (fused head only): B is the [rows, 352] positional encoding; on the bf16x3 path it is computed from feat [rows, 32] inside the
+// GEMM and `B` is never read. db (may be NULL): += column sums of A (the layer's bias gradient).
 template <int MB>
 static void launch_gemm_tn(const float* A, int lda, const float* B, int ldb, long long rows, int M, int N, float* C, int ldc,
-                           float* part, hipStream_t s) {
+                           float* part, hipStream_t s, const float* pe_feat = nullptr, float* db = nullptr) {
     const TnPlan p = tn_plan(rows, N);
-    static const bool gemm_fp32 = getenv("T2N_BWD_GEMM_FP32") != nullptr;   // the fp32-MFMA form instead of the bf16x3 one (t2n_gemm_h.hip)
-    if (!gemm_fp32 && MB == 4) (void)launch_gemm_tn_b(A, lda, B, ldb, rows, N, part, p.ldp, p.chunk_rows, p.ng, p.chunks, s);   // (the 27-row basis gradient is latency-bound either way: 31 us fp32, 44 us bf16x3)
-    else hipLaunchKernelGGL((k_gemm_tn<MB>), dim3((unsigned)p.ng, (unsigned)p.chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part,
-                            p.ldp, p.chunk_rows);
+    if (!gemm_fp32_mode() && MB == 4) {   // (the 27-row basis gradient is latency-bound either way: 31 us fp32, 44 us bf16x3)
+        (void)launch_gemm_tn_b(A, lda, pe_feat ? pe_feat : B, pe_feat ? 32 : ldb, rows, N, part, p.ldp, p.chunk_rows, p.ng, p.chunks,
+                               pe_feat != nullptr, db, s);
+    } else {
+        hipLaunchKernelGGL((k_gemm_tn<MB>), dim3((unsigned)p.ng, (unsigned)p.chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part,
+                           p.ldp, p.chunk_rows);
+        if (db) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, A, lda, rows, M, db, 128);
+    }
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((MB * 32 * p.ldp + 255) / 256)), dim3(256), 0, s, (const float*)part,
                        p.chunks, MB * 32, p.ldp, M, N, C, ldc);
 }
@@ -1312,18 +1322,20 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         hipLaunchKernelGGL(k_bwd_l2, dim3((unsigned)((rows + 63) / 64 < 1024 ? (rows + 63) / 64 : 1024)), dim3(256), 0, s, (const float4*)go, (const float*)h1,
                            (long long)rows, P->mlp_w2, g1, g->mlp_w2, g->mlp_b2);
         // 4. layers 1, 0, PE, basis
-        if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s);
-        if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
+        // (a bias gradient without its weight gradient does not occur: the column sums ride in the weight-gradient GEMM)
+        if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s, nullptr, g->mlp_b1);
+        else if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
         // input-gradient GEMMs: split-f16 MFMA products with a power-of-two scale per row (t2n_gemm_h.hip); T2N_BWD_GEMM_FP32=1
         // keeps the fp32-MFMA form
-        static const bool gemm_fp32 = getenv("T2N_BWD_GEMM_FP32") != nullptr;
+        const bool gemm_fp32 = gemm_fp32_mode();
         void* gpack = (void*)(bw + b.gpack);
         if (!gemm_fp32 && (rc = gemm_h_pack(f, gpack, K0, s))) return rc;
         if (gemm_fp32) launch_gemm_nn(g1, 128, P->mlp_w1, 128, rows, 128, 128, h0, 128, g0, 128, s);
         else if ((rc = launch_gemm_nn_h(gpack, 0, K0, g1, 128, rows, h0, 128, g0, 128, s))) return rc;
-        if (!generic) hipLaunchKernelGGL(k_pe_fwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)feat32, (long long)rows, xpe);
-        if (g->mlp_w0) launch_gemm_tn<4>(g0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, s);
-        if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g0, 128, (long long)rows, 128, g->mlp_b0, 128);
+        const bool pe_in_gemm = !generic && !gemm_fp32 && g->mlp_w0;   // the encoding is computed inside the weight-gradient GEMM
+        if (!generic && !pe_in_gemm && g->mlp_w0) hipLaunchKernelGGL(k_pe_fwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)feat32, (long long)rows, xpe);
+        if (g->mlp_w0) launch_gemm_tn<4>(g0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, s, pe_in_gemm ? feat32 : nullptr, g->mlp_b0);
+        else if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g0, 128, (long long)rows, 128, g->mlp_b0, 128);
         if (gemm_fp32) launch_gemm_nn(g0, 128, P->mlp_w0, K0, rows, 128, K0, nullptr, 0, gx, K0pad, s);
         else if ((rc = launch_gemm_nn_h(gpack, 1, K0, g0, 128, rows, nullptr, 0, gx, K0pad, s))) return rc;
         if (!generic) hipLaunchKernelGGL(k_pe_bwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)gx, (const float*)feat32, (long long)rows, gf);

@@ -204,9 +204,14 @@ __device__ __forceinline__ Op3 split_unit(const float (&x)[8]) {
     return o;
 }
 
-template <int MB>
+// PE: B is not read but computed — column c of the positional encoding of the 27 features in `B` (= feat [rows, 32]; reference column
+// order, models/tensorBase.py:11-17: [f | sin(f 2^o) feature-major | cos(f 2^o)]) by the forward head's hardware sin on the reduced
+// argument (4.2e-7 absolute): the [rows, 352] encoding is never written or read (k_pe_fwd: 73 us + 2 x 161 MB per C3 iteration).
+// bsum (may be NULL): += column sums of A (the bias gradient, [128]), added by the ng == 0 blocks.
+template <int MB, bool PE>
 __global__ __launch_bounds__(256) void k_gemm_tn_b(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                   long long rows, int N, float* __restrict__ part, int ldp, int chunk_rows) {
+                                                   long long rows, int N, float* __restrict__ part, int ldp, int chunk_rows,
+                                                   float* __restrict__ bsum) {
     __shared__ __attribute__((aligned(16))) uint4 sA[2][MB][3][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, kh = lane >> 5;
     const int ng = blockIdx.x;
@@ -214,9 +219,18 @@ __global__ __launch_bounds__(256) void k_gemm_tn_b(const float* __restrict__ A, 
     const long long r1 = (r0 + chunk_rows < rows) ? r0 + chunk_rows : rows;
     const bool loads_a = w < MB;
     const int bcol = ng * 128 + 32 * w + i;
-    const bool bok = bcol < ldb && bcol < N + 3;          // columns N .. ldb are padding the caller ignores
+    // PE: the lane's column as (feature, 2^octave, phase offset in revolutions: 0 = sin, 0.25 = cos), raw features apart
+    int pf = 0; float pscale = 1.f, poff = 0.f; bool praw = false;
+    bool bok;
+    if constexpr (PE) {
+        bok = bcol < 351;
+        if (bcol < 27) { pf = bcol; praw = true; }
+        else if (bok) { const int q = (bcol - 27) % 162; pf = q / 6; pscale = (float)(1 << (q % 6)); poff = bcol >= 189 ? 0.25f : 0.f; }
+    } else {
+        bok = bcol < ldb && bcol < N + 3;                  // columns N .. ldb are padding the caller ignores
+    }
     const float* __restrict__ Ab = A + (loads_a ? 32 * w + i : 0);
-    const float* __restrict__ Bb = B + (bok ? bcol : 0);
+    const float* __restrict__ Bb = B + (PE ? pf : (bok ? bcol : 0));
     float xa[8], xb[8];
     auto fetch = [&](long long kt) {
 #pragma unroll
@@ -230,6 +244,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_b(const float* __restrict__ A, 
     f32x16 acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[m] = f32x16{0};
+    float bs = 0.f;
     if (r0 < r1) fetch(r0);
     int buf = 0;
     for (long long kt = r0; kt < r1; kt += 16, buf ^= 1) {
@@ -238,10 +253,21 @@ __global__ __launch_bounds__(256) void k_gemm_tn_b(const float* __restrict__ A, 
         for (int e = 0; e < 8; ++e) {
             const bool ok = kt + 8 * kh + e < r1;
             a8[e] = ok ? xa[e] : 0.f;
-            b8[e] = (ok && bok) ? xb[e] : 0.f;
+            float v = xb[e];
+            if constexpr (PE) {
+                // f / (2 pi) as th + tl (two-constant product), the fraction of its 2^o multiple, + a quarter turn for the cosine
+                const float C1 = 0.15915494309189535f;
+                const float C2 = (float)(0.15915494309189533576888 - (double)C1);
+                const float th = v * C1;
+                const float tl = fmaf(v, C1, -th) + v * C2;
+                const float arg = fmaf(tl, pscale, __builtin_amdgcn_fractf(th * pscale)) + poff;
+                v = praw ? v : __builtin_amdgcn_sinf(arg);
+            }
+            b8[e] = (ok && bok) ? v : 0.f;
         }
         if (kt + 16 < r1) fetch(kt + 16);                  // the next step's rows in flight under this step's conversion and MFMAs
         if (loads_a) {
+            bs += ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
             const Op3 oa = split_unit(a8);
             sA[buf][w][0][lane] = oa.h; sA[buf][w][1][lane] = oa.m; sA[buf][w][2][lane] = oa.l;
         }
@@ -263,8 +289,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn_b(const float* __restrict__ A, 
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int v = 0; v < 16; ++v) P[(size_t)(m * 32 + (v & 3) + 8 * (v >> 2) + 4 * kh) * ldp] = acc[m][v];
+    if (bsum && ng == 0 && loads_a) {   // one atomic per column and chunk (~400 per address, like k_colsum's)
+        bs += __shfl_xor(bs, 32);
+        if (kh == 0) atomicAdd(&bsum[32 * w + i], bs);
+    }
 }
-
 }  // namespace gh
 
 // ---- host side: one pack per backward (the weights change every optimiser step), three GEMM calls -------------------------------------
@@ -323,11 +352,13 @@ int launch_gemm_nn_h(void* packbuf, int which, int K0, const float* IN, int ldin
     return T2N_OK;
 }
 
-// part[chunks][128][ldp] = per-chunk A^T B for the 128-column gradients (the caller reduces the chunks)
+// part[chunks][128][ldp] = per-chunk A^T B for the 128-column gradients (the caller reduces the chunks). pe: B = feat [rows, 32] and the
+// product is with its positional encoding (N = 351). db (may be NULL): += column sums of A.
 int launch_gemm_tn_b(const float* A, int lda, const float* B, int ldb, long long rows, int N, float* part, int ldp, int chunk_rows,
-                     int ng, int chunks, hipStream_t s) {
+                     int ng, int chunks, bool pe, float* db, hipStream_t s) {
     using namespace gh;
-    hipLaunchKernelGGL(k_gemm_tn_b<4>, dim3((unsigned)ng, (unsigned)chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part, ldp, chunk_rows);
+    if (pe) hipLaunchKernelGGL((k_gemm_tn_b<4, true>), dim3((unsigned)ng, (unsigned)chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part, ldp, chunk_rows, db);
+    else hipLaunchKernelGGL((k_gemm_tn_b<4, false>), dim3((unsigned)ng, (unsigned)chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part, ldp, chunk_rows, db);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

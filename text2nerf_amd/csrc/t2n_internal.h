@@ -181,7 +181,7 @@ int gemm_h_pack(t2n_field* f, void* buf, int K0, hipStream_t s);
 int launch_gemm_nn_h(void* packbuf, int which, int K0, const float* IN, int ldin, long long rows, const float* ACT, int ldact, float* OUT,
                      int ldo, hipStream_t s);
 int launch_gemm_tn_b(const float* A, int lda, const float* B, int ldb, long long rows, int N, float* part, int ldp, int chunk_rows,
-                     int ng, int chunks, hipStream_t s);
+                     int ng, int chunks, bool pe, float* db, hipStream_t s);
 // forward-workspace carve shared by forward and backward (t2n_api.hip)
 struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, feat, total; unsigned list_cap, feat_rows; };
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat = true, unsigned budget = 0);   // budget: appearance entries per ray (0: worst case)   // ctx: also room for sigma [rays,N] and rgb_raw [rays]; feat: feature rows (last region: the other offsets do not depend on it; KEEP_CTX calls carve without)
