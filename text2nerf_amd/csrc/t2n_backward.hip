@@ -781,19 +781,28 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
         for (int v = 0; v < 16; ++v) P[(size_t)(m * 32 + unit_of(v, h)) * ldp] = acc[m][v];
 }
 
-// C[M,N] (row-major, ldc) += sum over chunks of part[chunk][MA][ldp]
+// C[M,N] (row-major, ldc) += sum over chunks of part[chunk][MA][ldp]. A workgroup owns 32 consecutive outputs; its 8
+// thread groups of 32 each sum every 8th chunk and the partial sums meet in LDS in a fixed order (deterministic, no atomics): a
+// 128 x 128 gradient is 512 workgroups instead of 64 (one thread per output left most of the chip idle behind ~500 dependent loads)
 __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict__ part, int chunks, int MA, int ldp, int M, int N,
                                                         float* __restrict__ C, int ldc) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[8][32];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + o;
     const int row = t / ldp, col = t - row * ldp;
-    if (row >= M || col >= N) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    const float* p = part + (size_t)row * ldp + col;
-    const size_t st = (size_t)MA * ldp;
-    int c = 0;
-    for (; c + 4 <= chunks; c += 4) { s0 += p[c * st]; s1 += p[(c + 1) * st]; s2 += p[(c + 2) * st]; s3 += p[(c + 3) * st]; }
-    for (; c < chunks; ++c) s0 += p[c * st];
-    C[(size_t)row * ldc + col] += (s0 + s1) + (s2 + s3);
+    const bool live = row < M && col < N;
+    float s0 = 0.f, s1 = 0.f;
+    if (live) {
+        const float* p = part + (size_t)row * ldp + col;
+        const size_t st = (size_t)MA * ldp;
+        int c = sl;
+        for (; c + 8 < chunks; c += 16) { s0 += p[c * st]; s1 += p[(c + 8) * st]; }
+        if (c < chunks) s0 += p[c * st];
+    }
+    red[sl][o] = s0 + s1;
+    __syncthreads();
+    if (sl == 0 && live)
+        C[(size_t)row * ldc + col] += ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) + ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]));
 }
 
 // OUT[rows, N] = (IN[rows, K] W[K, N]) (* [ACT > 0] if ACT). A workgroup owns one 128-column group of N: its K x 128 slab
@@ -1014,7 +1023,10 @@ static TnPlan tn_plan(int64_t rows, int N) {
     TnPlan p;
     p.ng = (N + 127) / 128;
     p.ldp = p.ng * 128;
-    int64_t c = (rows * p.ng + 383) / 384;   // ~384 workgroups: the partial slabs (and their reduction) stay small
+#ifndef T2N_TN_BLOCKS
+#define T2N_TN_BLOCKS 512
+#endif
+    int64_t c = (rows * p.ng + T2N_TN_BLOCKS - 1) / T2N_TN_BLOCKS;   // ~512 workgroups = two per CU (384: GEMM 145 + reduce 54 us per C3 iteration; 512: 123 + 69 before the reduce was widened; 768: 122 + 97)
     c = (c + 31) / 32 * 32;
     if (c < 64) c = 64;
     p.chunk_rows = (int)c;
@@ -1112,7 +1124,7 @@ static void launch_gemm_tn(const float* A, int lda, const float* B, int ldb, lon
                            p.ldp, p.chunk_rows);
         if (db) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, A, lda, rows, M, db, 128);
     }
-    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((MB * 32 * p.ldp + 255) / 256)), dim3(256), 0, s, (const float*)part,
+    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((MB * 32 * p.ldp + 31) / 32)), dim3(256), 0, s, (const float*)part,
                        p.chunks, MB * 32, p.ldp, M, N, C, ldc);
 }
 static void launch_gemm_nn(const float* IN, int ldin, const float* W, int ldw, long long rows, int K, int N, const float* ACT,
