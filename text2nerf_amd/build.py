@@ -21,6 +21,9 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC",
            "-Wl,--no-undefined"]   # an unresolved internal symbol must fail the build, not the first dlopen on the GPU box
 FLAGS = CFLAGS + LDFLAGS[1:]      # (kept for callers that print the flag set)
+# per-file additions. t2n_mlp_bwd_ss.hip: the SLP vectoriser packs the (sin, cos) chains of neighbouring features into v_pk_* pairs,
+# which makes it evaluate every chain up front and spill them (604 B of scratch per lane against 76 B without)
+PER_FILE = {"t2n_mlp_bwd_ss.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -58,7 +61,7 @@ def build(force=False, verbose=False):
     todo = [s for s in sources() if force or _stale(s)]
 
     def compile_one(src):
-        cmd = [hipcc] + CFLAGS + ["-c", src, "-o", _obj(src)]
+        cmd = [hipcc] + CFLAGS + PER_FILE.get(os.path.basename(src), []) + ["-c", src, "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -7,7 +7,9 @@
 //   2  k_bwd_march             per ray: recompute alpha/T/w from the kept sigma, dL/dw -> dL/dalpha (reverse scan) -> dL/dsigma
 //                              -> dL/dfeature; scatter-add into the channel-last density gradient planes/lines (fp32 atomics);
 //                              emits per appearance sample go = dL/d(pre-sigmoid rgb)
-//   3  k_bwd_l2                layer 2 (3 outputs): dW2, db2, g1 = (go W2) * [h1 > 0]
+//   3  k_bwd_l2                layer 2 (3 outputs): dW2, db2 (per-workgroup partials + k_bwd_l2_reduce), g1 = (go W2) * [h1 > 0]
+//   3-4 (MLP_Fea_noview head) k_mlp_bwd_ss: the whole input-gradient chain g1 -> g0 -> gx -> gf -> gX in one kernel (t2n_mlp_bwd_ss.hip);
+//                              k_bwd_l2 then only accumulates dW2 / db2, the weight gradients stay GEMMs (t2n_gemm_h.hip)
 //   4  gemm_tn / gemm_nn       fp32-MFMA GEMMs: dW1 = g1^T h0, g0 = (g1 W1) * [h0 > 0], dW0 = g0^T PE(feat), gx = g0 W0,
 //                              PE backward -> gf, dWb = gf^T X, gX = gf Wb; k_colsum for the biases
 //   5  k_bwd_app_scatter       re-gather appearance taps, scatter-add plane/line gradients
@@ -688,7 +690,7 @@ static size_t tile_accum_lds(int C, int Lmax) {
 // ---- layer 2 (3 outputs): VALU ------------------------------------------------------------------------------------------
 // go [rows,4], h1 [rows,128] -> g1 [rows,128] = (go W2) * [h1>0]; dW2[3,128] += go^T h1; db2[3] += colsum(go)
 __global__ __launch_bounds__(256) void k_bwd_l2(const float4* __restrict__ go, const float* __restrict__ h1, long long rows,
-                                                const float* __restrict__ w2, float* g1, float* dw2, float* db2) {
+                                                const float* __restrict__ w2, float* g1, float* __restrict__ part) {
     // persistent workgroups (grid-stride over 64-row tiles): the 3 x 128 weight-gradient partial sums leave a workgroup once,
     // so the same-address atomics on dw2 stay in the hundreds per address instead of one per 64 rows
     const int u = threadIdx.x & 127, half = threadIdx.x >> 7;
@@ -702,8 +704,10 @@ __global__ __launch_bounds__(256) void k_bwd_l2(const float4* __restrict__ go, c
             for (int q = 0; q < 4; ++q) {
                 const long long r = r0 + k + q;
                 const bool ok = r < rows;
-                g[q] = ok ? go[r] : make_float4(0.f, 0.f, 0.f, 0.f);
-                h[q] = ok ? h1[r * 128 + u] : 0.f;
+                const long long rc = ok ? r : rows - 1;   // clamped address + select: a conditional load is a branch and a full wait per element
+                g[q] = go[rc];
+                h[q] = h1[rc * 128 + u];
+                if (!ok) { g[q] = make_float4(0.f, 0.f, 0.f, 0.f); h[q] = 0.f; }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -711,13 +715,39 @@ __global__ __launch_bounds__(256) void k_bwd_l2(const float4* __restrict__ go, c
                 if (r >= rows) break;
                 a0 = fmaf(g[q].x, h[q], a0); a1 = fmaf(g[q].y, h[q], a1); a2 = fmaf(g[q].z, h[q], a2);
                 s0 += g[q].x; s1 += g[q].y; s2 += g[q].z;
-                const float v = fmaf(g[q].z, w2v, fmaf(g[q].y, w1, g[q].x * w0));
-                g1[r * 128 + u] = h[q] > 0.f ? v : 0.f;
+                if (g1) {   // (NULL: the fused input-gradient chain, t2n_mlp_bwd_ss.hip, makes g1 itself and needs h1 intact)
+                    const float v = fmaf(g[q].z, w2v, fmaf(g[q].y, w1, g[q].x * w0));
+                    g1[r * 128 + u] = h[q] > 0.f ? v : 0.f;
+                }
             }
         }
     }
-    if (dw2) { atomicAdd(&dw2[u], a0); atomicAdd(&dw2[128 + u], a1); atomicAdd(&dw2[256 + u], a2); }
-    if (db2 && u == 0) { atomicAdd(&db2[0], s0); atomicAdd(&db2[1], s1); atomicAdd(&db2[2], s2); }
+    // per-workgroup partial sums [block][3 x 128 + 3]; k_bwd_l2_reduce adds them up in a fixed order (the same-address atomics of
+    // ~800 000 threads on 12 cache lines were most of this kernel: 105 us per C3 iteration)
+    __shared__ float red[388];
+    if (half == 1) { red[u] = a0; red[128 + u] = a1; red[256 + u] = a2; if (u == 0) { red[384] = s0; red[385] = s1; red[386] = s2; } }
+    __syncthreads();
+    if (half == 0) {
+        float* __restrict__ P = part + (size_t)blockIdx.x * 388;
+        P[u] = a0 + red[u]; P[128 + u] = a1 + red[128 + u]; P[256 + u] = a2 + red[256 + u];
+        if (u == 0) { P[384] = s0 + red[384]; P[385] = s1 + red[385]; P[386] = s2 + red[386]; }
+    }
+}
+// dw2 [3,128] += sum of the workgroups' partials, db2 [3] likewise: one workgroup per output, one partial per thread (nblocks <= 256),
+// fixed-order tree (deterministic)
+__global__ __launch_bounds__(256) void k_bwd_l2_reduce(const float* __restrict__ part, int nblocks, float* dw2, float* db2) {
+    __shared__ float red[4];
+    const int i = blockIdx.x, b = threadIdx.x;
+    float v = b < nblocks ? part[(size_t)b * 388 + i] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((b & 63) == 0) red[b >> 6] = v;
+    __syncthreads();
+    if (b == 0) {
+        const float s = (red[0] + red[1]) + (red[2] + red[3]);
+        if (i < 384) { if (dw2) dw2[i] += s; }
+        else if (db2) db2[i - 384] += s;
+    }
 }
 
 // ---- fp32 MFMA GEMMs -----------------------------------------------------------------------------------------------------
@@ -1035,7 +1065,7 @@ static TnPlan tn_plan(int64_t rows, int N) {
     return p;
 }
 static size_t tn_part_bytes(int64_t rows, int k0) {
-    size_t m = 0;
+    size_t m = (size_t)256 * 388 * 4;   // layer 2's per-workgroup partial sums (launch_bwd_l2) come first
     const int shapes[3][2] = {{128, 128}, {128, k0}, {32, 144}};
     for (auto& sh : shapes) {
         const TnPlan p = tn_plan(rows, sh[1]);
@@ -1056,7 +1086,7 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
     c.go = o; o = al256(o + R * 16);
     c.xpe = o; o = al256(o + R * (size_t)((k0 + 3) & ~3) * 4);
     c.part = o; o = al256(o + tn_part_bytes(rows, k0));
-    c.gpack = o; o = al256(o + gemm_h_pack_bytes(k0));   // packed W^T operands of the input-gradient GEMMs (t2n_gemm_h.hip)
+    c.gpack = o; o = al256(o + (gemm_h_pack_bytes(k0) > mlp_bwd_ss_pack_bytes() ? gemm_h_pack_bytes(k0) : mlp_bwd_ss_pack_bytes()));   // packed W^T operands of the input-gradient GEMMs (t2n_gemm_h.hip / t2n_mlp_bwd_ss.hip)
     // tile-binned density scatter: worst case one record per sample and plane
     const size_t cap = (size_t)n_rays * (size_t)n_samples;
     c.seg_cap = (unsigned)(3 * cap / 512 + (size_t)n_tiles + 1);
@@ -1106,6 +1136,15 @@ static int ensure_grad_buffers(t2n_field* f) {
     return T2N_OK;
 }
 
+// layer 2 of the backward: 256 persistent workgroups (one per CU), their partial weight / bias sums through `scratch` (>= 256 x 388 floats:
+// the weight-gradient GEMMs' partial buffer, not in use yet)
+static void launch_bwd_l2(const float4* go, const float* h1, long long rows, const float* w2, float* g1, float* dw2, float* db2,
+                          float* scratch, hipStream_t s) {
+    const long long tiles = (rows + 63) / 64;
+    const unsigned nb = (unsigned)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(k_bwd_l2, dim3(nb), dim3(256), 0, s, go, h1, rows, w2, g1, scratch);
+    if (dw2 || db2) hipLaunchKernelGGL(k_bwd_l2_reduce, dim3(387), dim3(256), 0, s, (const float*)scratch, (int)nb, dw2, db2);
+}
 static bool gemm_fp32_mode() {
     static const bool v = getenv("T2N_BWD_GEMM_FP32") != nullptr;   // the fp32-MFMA GEMMs instead of the f16 / bf16 split ones (t2n_gemm_h.hip)
     return v;
@@ -1330,17 +1369,31 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     if (rows > 0) {
         const t2n_field_params* P = &f->params_ref;
         timing_begin(f, T2N_K_BWD_MLP, s);
+        const bool gemm_fp32 = gemm_fp32_mode();
+        static const bool unfused_env = getenv("T2N_BWD_UNFUSED") != nullptr;   // A/B switch: the five-launch form of the input-gradient chain
+        const bool fused = !generic && !gemm_fp32 && !unfused_env && f->desc.app_dim == 27 && K0 == 351;
+        void* gpack = (void*)(bw + b.gpack);
+        if (fused) {
+            // the input-gradient chain as ONE kernel (t2n_mlp_bwd_ss.hip): k_bwd_l2 only accumulates dW2 / db2 (h1 stays intact for it),
+            // the chain writes g1 over h1 and g0 / gf / gX into the (otherwise unused) encoding buffer
+            float* G0 = xpe; float* GF = xpe + (size_t)rows * 128; float* GX = xpe + (size_t)rows * 160;
+            launch_bwd_l2((const float4*)go, (const float*)h1, rows, P->mlp_w2, nullptr, g->mlp_w2, g->mlp_b2, part, s);
+            if ((rc = launch_mlp_bwd_ss(f, gpack, (const float4*)go, h1, h0, feat32, G0, GF, GX, rows, s))) return rc;
+            if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s, nullptr, g->mlp_b1);
+            else if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
+            if (g->mlp_w0) launch_gemm_tn<4>(G0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, s, feat32, g->mlp_b0);
+            else if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)G0, 128, (long long)rows, 128, g->mlp_b0, 128);
+            if (g->basis_weight) launch_gemm_tn<1>(GF, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, s);
+            gxapp = GX;
+        } else {
         // 3. layer 2
-        hipLaunchKernelGGL(k_bwd_l2, dim3((unsigned)((rows + 63) / 64 < 1024 ? (rows + 63) / 64 : 1024)), dim3(256), 0, s, (const float4*)go, (const float*)h1,
-                           (long long)rows, P->mlp_w2, g1, g->mlp_w2, g->mlp_b2);
+        launch_bwd_l2((const float4*)go, (const float*)h1, rows, P->mlp_w2, g1, g->mlp_w2, g->mlp_b2, part, s);
         // 4. layers 1, 0, PE, basis
         // (a bias gradient without its weight gradient does not occur: the column sums ride in the weight-gradient GEMM)
         if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s, nullptr, g->mlp_b1);
         else if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
         // input-gradient GEMMs: split-f16 MFMA products with a power-of-two scale per row (t2n_gemm_h.hip); T2N_BWD_GEMM_FP32=1
         // keeps the fp32-MFMA form
-        const bool gemm_fp32 = gemm_fp32_mode();
-        void* gpack = (void*)(bw + b.gpack);
         if (!gemm_fp32 && (rc = gemm_h_pack(f, gpack, K0, s))) return rc;
         if (gemm_fp32) launch_gemm_nn(g1, 128, P->mlp_w1, 128, rows, 128, 128, h0, 128, g0, 128, s);
         else if ((rc = launch_gemm_nn_h(gpack, 0, K0, g1, 128, rows, h0, 128, g0, 128, s))) return rc;
@@ -1355,6 +1408,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         if (g->basis_weight) launch_gemm_tn<1>(gf, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, s);
         if (gemm_fp32) launch_gemm_nn(gf, 32, P->basis_weight, 144, rows, f->desc.app_dim, 144, nullptr, 0, gxapp, 144, s);
         else if ((rc = launch_gemm_nn_h(gpack, 2, K0, gf, 32, rows, nullptr, 0, gxapp, 144, s))) return rc;
+        }
         timing_end(f, T2N_K_BWD_MLP, s);
         T2N_HIP(hipGetLastError());
         // 5. appearance scatter

@@ -14,7 +14,8 @@ pids=()
 for f in $src/*.hip; do
   o=$obj/$(basename $f .hip).o
   if [ ! -f $o ] || [ $f -nt $o ] || [ -n "$(find $src $root/include -name '*.h' -newer $o)" ]; then
-    /opt/rocm/bin/hipcc $FLAGS -c $f -o $o &
+    per=""; [ "$(basename $f)" = t2n_mlp_bwd_ss.hip ] && per="-fno-slp-vectorize"   # as text2nerf_amd/build.py PER_FILE
+    /opt/rocm/bin/hipcc $FLAGS $per -c $f -o $o &
     pids+=($!)
   fi
 done
