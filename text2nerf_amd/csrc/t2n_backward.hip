@@ -1145,9 +1145,12 @@ static void launch_bwd_l2(const float4* go, const float* h1, long long rows, con
     hipLaunchKernelGGL(k_bwd_l2, dim3(nb), dim3(256), 0, s, go, h1, rows, w2, g1, scratch);
     if (dw2 || db2) hipLaunchKernelGGL(k_bwd_l2_reduce, dim3(387), dim3(256), 0, s, (const float*)scratch, (int)nb, dw2, db2);
 }
+// the fp32-MFMA GEMMs instead of the f16 / bf16 split ones (t2n_gemm_h.hip, t2n_mlp_bwd_ss.hip): by environment, or because the field
+// runs its MLP in exact fp32 (t2n_field_set_mlp_precision: the backward then keeps fp32 products too)
+static bool g_gemm_fp32_field = false;
 static bool gemm_fp32_mode() {
-    static const bool v = getenv("T2N_BWD_GEMM_FP32") != nullptr;   // the fp32-MFMA GEMMs instead of the f16 / bf16 split ones (t2n_gemm_h.hip)
-    return v;
+    static const bool v = getenv("T2N_BWD_GEMM_FP32") != nullptr;
+    return v || g_gemm_fp32_field;
 }
 // pe_feat (fused head only): B is the [rows, 352] positional encoding; on the bf16x3 path it is computed from feat [rows, 32] inside the
 // GEMM and `B` is never read. db (may be NULL): += column sums of A (the layer's bias gradient).
@@ -1369,6 +1372,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     if (rows > 0) {
         const t2n_field_params* P = &f->params_ref;
         timing_begin(f, T2N_K_BWD_MLP, s);
+        g_gemm_fp32_field = !f->mlp_split;
         const bool gemm_fp32 = gemm_fp32_mode();
         static const bool unfused_env = getenv("T2N_BWD_UNFUSED") != nullptr;   // A/B switch: the five-launch form of the input-gradient chain
         const bool fused = !generic && !gemm_fp32 && !unfused_env && f->desc.app_dim == 27 && K0 == 351;
