@@ -8,9 +8,11 @@
 // activations and the output never leave its registers. That works because the C/D layout of v_mfma_f32_32x32x16_f16 (lane
 // (j, h): rows 8b + 4h + t of column j) IS a B-operand layout (lane (j, h): 8 K-values of column j) once the K order of the next
 // layer is permuted accordingly — the permutation is folded into the weight packing (k_pack_ss):
-//   layer 0: lane half h owns features 14h .. 14h+13 of its sample; its 192 K-values are, per feature, (sin, cos) of octaves 0..5
-//            [octaves 0 and 3 by v_sin_f32 / v_cos_f32 on the fraction of f 2^o / (2 pi), the others by double-angle steps], then
-//            the 14 raw features, then zeros; K-step s (16 values = one MFMA) takes values 8s .. 8s+7 of both halves.
+//   layer 0: lane half h owns features 14h .. 14h+12 of its sample and half of feature 13 (octaves 0..2 / 3..5); its 176 K-values are
+//            (sin, cos) of those three octaves, then per own feature (sin, cos) of octaves 0..5 [octaves 0 and 3 by v_sin_f32 /
+//            v_cos_f32 on the fraction of f 2^o / (2 pi), the others by double-angle steps], then the 13 raw features, then
+//            (half 1) the raw feature 13: 351 values in 352 slots; K-step s (16 values = one MFMA) takes values 8s .. 8s+7 of
+//            both halves: 22 K-steps.
 //   layers 1, 2: K index (step s, half h, element e) = hidden unit 32 (s / 2) + 8 (2 (s % 2) + e / 4) + 4h + e % 4 — what the lane
 //            holds of unit tile s / 2 of the previous layer's accumulators.
 // The weights are the A operands. Layer-0 weights (196 KB as hi / lo f16 halves) stream through a three-slot LDS ring of 16-KB
@@ -112,24 +114,29 @@ __device__ __forceinline__ void unit_split(const Unit& U, float neg1, unsigned& 
     lo = __builtin_bit_cast(unsigned, (hh2)__builtin_amdgcn_cvt_pkrtz(r0, r1));
 }
 
-// Values V, V+1 of the lane's 192-value layer-0 sequence (f: features 14h .. 14h+13 of the lane's sample).
+// Values V, V+1 of the lane's 176-value layer-0 sequence. Both lane halves run the same code on their own data: values 0..5 the
+// half's three octaves of the SHARED feature 13 (octaves 0..2 for half 0, 3..5 for half 1: `hs` = 1 or 8 scales the fresh argument),
+// 6..161 the half's own 13 features x 6 octaves x (sin, cos), 162..174 their raw values, 175 the shared feature's raw value
+// (half 1; zero for half 0): 27 x 13 = 351 values in 2 x 176 slots = 22 K-steps.
+struct EncIn { float f[14]; float fh, extra, hs; };   // f[0..12]: own features 14h + i; f[13]: what column 14h + 13 held (see load_feat)
 template <int V, int PH>
-__device__ __forceinline__ void enc_unit(Unit& U, const float (&f)[14], float neg1, unsigned& hi, unsigned& lo) {
-    constexpr bool raw = V >= 168;
-    constexpr int q = raw ? 0 : (V % 12) / 2;
-    constexpr bool fresh = !raw && (q == 0 || q == 3);   // octaves 1, 2, 4, 5 from the one before
+__device__ __forceinline__ void enc_unit(Unit& U, const EncIn& I, float neg1, unsigned& hi, unsigned& lo) {
+    constexpr bool raw = V >= 162;
+    constexpr bool head = V < 6;                          // the shared feature's three octaves
+    constexpr int q = raw ? 0 : (head ? V / 2 : ((V - 6) % 12) / 2);
+    constexpr bool fresh = !raw && (head ? q == 0 : (q == 0 || q == 3));   // the other octaves from the one before
     if constexpr (PH == 0) {
         if constexpr (raw) {
-            constexpr int r = V - 168;
-            U.x0 = r < 14 ? f[r < 14 ? r : 0] : 0.f;
-            U.x1 = r + 1 < 14 ? f[r + 1 < 14 ? r + 1 : 0] : 0.f;
+            constexpr int r = V - 162;
+            U.x0 = I.f[r < 13 ? r : 0];
+            U.x1 = r + 1 < 13 ? I.f[r + 1 < 13 ? r + 1 : 0] : I.extra;
         } else if constexpr (fresh) {
             // f / (2 pi) as th + tl (two-constant product, ~2^-48 relative), then the fraction of its 2^q multiple: sin / cos take
             // revolutions and have period 1 (max abs error 4.2e-7 over |f| <= 3e4, tools/experiments/hw_sincos.hip)
             const float C1 = 0.15915494309189535f;                                   // float(1 / (2 pi))
             const float C2 = (float)(0.15915494309189533576888 - (double)C1);
-            constexpr float sc = (float)(1 << q);
-            const float x = f[V / 12];
+            const float sc = head ? I.hs : (float)(1 << q);
+            const float x = head ? I.fh : I.f[head ? 0 : (V - 6) / 12];
             const float th = x * C1;
             const float tl = fmaf(x, C1, -th) + x * C2;
             U.x1 = fmaf(tl, sc, __builtin_amdgcn_fractf(th * sc));
@@ -151,7 +158,7 @@ __device__ __forceinline__ void enc_unit(Unit& U, const float (&f)[14], float ne
 }
 
 struct Enc {
-    float f[14];             // features 14h .. 14h+13 of the lane's sample
+    EncIn in;                // the lane's features (see enc_unit)
     Unit U;                  // the encoder's unit in flight; between units (sin, cos) of the previous octave
     Unit cu;                 // the conversion fillers' unit in flight (U lives across layer 2: step 0 of the next round is encoded before it)
     unsigned ph[4], pl[4];   // packed halves of the operand being built
@@ -168,7 +175,7 @@ struct EncFill {   // layer-0 B operand of K-step S -> (Bh, Bl)
     Enc& E; uint4& Bh; uint4& Bl; float neg1;
     template <int IDX> __device__ __forceinline__ void run() {
         constexpr int u = IDX / 3;
-        enc_unit<8 * S + 2 * u, IDX % 3>(E.U, E.f, neg1, E.ph[u], E.pl[u]);
+        enc_unit<8 * S + 2 * u, IDX % 3>(E.U, E.in, neg1, E.ph[u], E.pl[u]);
     }
     __device__ __forceinline__ void done() {
         Bh = make_uint4(E.ph[0], E.ph[1], E.ph[2], E.ph[3]);
@@ -324,8 +331,9 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
     h2v amax = {(_Float16)0.f, (_Float16)0.f};   // hidden activations (non-negative, finite inputs), as packed RTZ f16 halves
     unsigned amax_u = 0u;      // raw features: max of the |bit patterns| (orders like |x| and ranks inf / NaN on top)
 
-    // features 14h .. 14h+13 of the lane's sample of round r (row = 32 (8 r + w) + j; tiles past the end re-read the last row: their
-    // results are never stored)
+    // columns 14h .. 14h+13 of the lane's feature row of round r (row = 32 (8 r + w) + j; tiles past the end re-read the last row: their
+    // results are never stored): the half's own 13 features + column 13 (the shared feature, half 0) / column 27 (the entry's
+    // compositing weight, half 1). finish_feat hands each half what the other one loaded: one lane exchange per round.
     const unsigned last = ntiles * 32u - 1u;
     auto load_feat = [&](unsigned r, float (&f)[14]) {
         unsigned i = (r * 8u + (unsigned)w) * 32u + (unsigned)j;
@@ -334,8 +342,17 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
 #pragma unroll
         for (int e = 0; e < 7; ++e) { const float2 v = row[e]; f[2 * e] = v.x; f[2 * e + 1] = v.y; }
     };
+    float wnext = 0.f;   // lanes of half 0: the compositing weight of the sample whose features were loaded last
+    auto finish_feat = [&](EncIn& I) {
+        const float xs = __shfl_xor(I.f[13], 32);
+        I.fh = h ? xs : I.f[13];
+        I.extra = h ? I.fh : 0.f;
+        wnext = xs;
+    };
     Enc E;
-    load_feat(blockIdx.x, E.f);
+    E.in.hs = h ? 8.f : 1.f;
+    load_feat(blockIdx.x, E.in.f);
+    finish_feat(E.in);
     uint4 Bh[2], Bl[2];   // [K-step parity]
     {
         EncFill<0> f{E, Bh[0], Bl[0], neg1};
@@ -365,11 +382,11 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
                 acc0[u][4 * b] = v.x; acc0[u][4 * b + 1] = v.y; acc0[u][4 * b + 2] = v.z; acc0[u][4 * b + 3] = v.w;
             }
 #pragma unroll
-        for (int e = 0; e < 14; ++e) amax_u = max(amax_u, __float_as_uint(E.f[e]) & 0x7fffffffu);
+        for (int e = 0; e < 14; ++e) amax_u = max(amax_u, __float_as_uint(E.in.f[e]) & 0x7fffffffu);
         const unsigned rn = r + gridDim.x < nrounds ? r + gridDim.x : r;
-        // column 27 of the feature row (feature "27" of half 1: zero weights) carries the entry's compositing weight: lane (j, 0)
-        // stores it next to the colour, k_composite then reads one array
-        const float wgt = __shfl(E.f[13], j + 32);
+        // column 27 of the feature row carries the entry's compositing weight: lane (j, 0) stores it next to the colour, k_composite
+        // then reads one array
+        const float wgt = wnext;
 #define SS_L0(C)                                                                                                                  \
         {                                                                                                                         \
             SS_PHASE(0);                                                                                                          \
@@ -378,27 +395,27 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
             RingOps ring{S, RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0};   /* lands before the next barrier */                  \
             SS_PHASE(6);                                                                                                          \
             const uint4* __restrict__ cur = LA0 + kW2 + (C % 3) * kChunk;                                                         \
-            const uint4* __restrict__ nxt = C < 11 ? LA0 + kW2 + ((C + 1) % 3) * kChunk : LA1;                                    \
-            /* K-step 23 (the second step of chunk 11) is all padding: 23 steps, the last one hands over to layer 1 */            \
-            if constexpr (!kExpNoFill && C < 11) {                                                                                \
-                EncFill<2 * C + 1> f0{E, Bh[1], Bl[1], neg1};                                                                     \
-                if constexpr (kExpNoRing) slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0);                                  \
-                else slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0, ring);                                                 \
-            } else if constexpr (C == 11) {                                                                                       \
-                NoFill f0;                                                                                                        \
-                if constexpr (kExpNoRing) slots<0>(acc0, A, Bh[0], Bl[0], cur, nxt, f0);                                          \
-                else slots<0>(acc0, A, Bh[0], Bl[0], cur, nxt, f0, ring);                                                         \
+            const uint4* __restrict__ nxt = C < 10 ? LA0 + kW2 + ((C + 1) % 3) * kChunk : LA1;                                    \
+            /* 22 K-steps: chunks 0..10; chunk 11 of the stream is padding (its iteration only keeps the ring's rhythm) */         \
+            if constexpr (C == 11) {                                                                                              \
+                if constexpr (!kExpNoRing) { S.dma<0>(RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0); S.dma<1>(RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0); } \
             } else {                                                                                                              \
-                NoFill f0;                                                                                                        \
-                if constexpr (kExpNoRing) slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0);                                  \
-                else slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0, ring);                                                 \
-            }                                                                                                                     \
-            if constexpr (C < 11 && !kExpNoFill) {                                                                                \
-                EncFill<(C < 11 ? 2 * C + 2 : 0)> f1{E, Bh[0], Bl[0], neg1};                                                      \
-                slots<0>(acc0, A, Bh[1], Bl[1], cur + kStep, nxt, f1);                                                            \
-            } else if constexpr (C < 11) {                                                                                        \
-                NoFill f1;                                                                                                        \
-                slots<0>(acc0, A, Bh[1], Bl[1], cur + kStep, nxt, f1);                                                            \
+                if constexpr (!kExpNoFill) {                                                                                      \
+                    EncFill<2 * C + 1> f0{E, Bh[1], Bl[1], neg1};                                                                 \
+                    if constexpr (kExpNoRing) slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0);                              \
+                    else slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0, ring);                                             \
+                } else {                                                                                                          \
+                    NoFill f0;                                                                                                    \
+                    if constexpr (kExpNoRing) slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0);                              \
+                    else slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0, ring);                                             \
+                }                                                                                                                 \
+                if constexpr (C < 10 && !kExpNoFill) {                                                                            \
+                    EncFill<(C < 10 ? 2 * C + 2 : 0)> f1{E, Bh[0], Bl[0], neg1};                                                  \
+                    slots<0>(acc0, A, Bh[1], Bl[1], cur + kStep, nxt, f1);                                                        \
+                } else {                                                                                                          \
+                    NoFill f1;                                                                                                    \
+                    slots<0>(acc0, A, Bh[1], Bl[1], cur + kStep, nxt, f1);                                                        \
+                }                                                                                                                 \
             }                                                                                                                     \
         }
         SS_L0(0) SS_L0(1) SS_L0(2) SS_L0(3) SS_L0(4) SS_L0(5) SS_L0(6) SS_L0(7) SS_L0(8) SS_L0(9) SS_L0(10) SS_L0(11)
@@ -436,7 +453,7 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
         SS_PHASE(2);
         // ---- h1 -> layer-2 B operands, layer 2 (three product chains), sigmoid, store ---------------------------------------------------
         // (layer 1's last pair fetched W2 steps 0 / 1 as if they were a tile pair: A[0][0] = step 0, A[0][1] = step 1)
-        load_feat(rn, E.f);                     // the next round's features: in flight under layer 2, encoded in its last step
+        load_feat(rn, E.in.f);                  // the next round's features: in flight under layer 2, encoded in its last step
         uint4 H1h[8], H1l[8];
         {
             ConvFill<0> f{acc1, H1h, H1l, E, inv1, neg1, amax};
@@ -462,7 +479,9 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
                 step2<St>(ch, A, H1h[St], H1l[St], nxt, f);                                                                       \
             }                                                                                                                     \
         }
-        SS_L2(0) SS_L2(1) SS_L2(2) SS_L2(3) SS_L2(4) SS_L2(5) SS_L2(6) SS_L2(7)
+        SS_L2(0) SS_L2(1) SS_L2(2) SS_L2(3) SS_L2(4) SS_L2(5) SS_L2(6)
+        finish_feat(E.in);
+        SS_L2(7)
 #undef SS_L2
         SS_PHASE(3);
         const unsigned tile = r * 8u + (unsigned)w;
@@ -539,9 +558,12 @@ __device__ __forceinline__ unsigned pack2(float x0, float x1, int part) {
 // layer-0 K index (step s, K-half kh, element e); -1: zero padding
 __host__ __device__ inline int l0_col(int s, int kh, int e) {
     const int v = 8 * s + e;
-    if (v >= 168) { const int r = v - 168, F = 14 * kh + r; return (r < 14 && F < 27) ? F : -1; }
-    const int F = 14 * kh + v / 12, o = (v % 12) >> 1, sc = v & 1;
-    return F < 27 ? (sc ? 189 : 27) + F * 6 + o : -1;
+    if (v >= 176) return -1;                                                   // K-steps 22, 23 of the stream are padding
+    if (v == 175) return kh ? 13 : -1;                                         // the shared feature's raw value rides with half 1
+    if (v >= 162) return 14 * kh + (v - 162);                                  // raw own features
+    if (v < 6) return ((v & 1) ? 189 : 27) + 13 * 6 + (kh ? 3 : 0) + v / 2;    // shared feature 13: octaves 0..2 (half 0) / 3..5 (half 1)
+    const int F = 14 * kh + (v - 6) / 12, o = ((v - 6) % 12) >> 1;
+    return ((v & 1) ? 189 : 27) + F * 6 + o;
 }
 // hidden unit of layer-1 / layer-2 K index (step s, K-half kh, element e)
 __host__ __device__ inline int hid_unit(int s, int kh, int e) { return 32 * (s / 2) + 8 * (2 * (s % 2) + e / 4) + 4 * kh + e % 4; }
