@@ -398,10 +398,13 @@ int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
     return launch_ray_stats(L, s);
 }
 
+#ifndef T2N_STATS_BLOCKS
+#define T2N_STATS_BLOCKS 128
+#endif
 int launch_ray_stats(const RenderLaunch& L, hipStream_t s) {
     if (L.stats) {
         unsigned nb = (unsigned)((L.n_rays + 255) / 256);
-        if (nb > 64) nb = 64;
+        if (nb > T2N_STATS_BLOCKS) nb = T2N_STATS_BLOCKS;
         hipLaunchKernelGGL(k_ray_stats, dim3(nb), dim3(256), 0, s, (const int4*)L.ray_app, (long long)L.n_rays,
                            (unsigned long long*)L.stats);
         T2N_HIP(hipGetLastError());
