@@ -1147,18 +1147,17 @@ static void launch_bwd_l2(const float4* go, const float* h1, long long rows, con
 }
 // the fp32-MFMA GEMMs instead of the f16 / bf16 split ones (t2n_gemm_h.hip, t2n_mlp_bwd_ss.hip): by environment, or because the field
 // runs its MLP in exact fp32 (t2n_field_set_mlp_precision: the backward then keeps fp32 products too)
-static bool g_gemm_fp32_field = false;
-static bool gemm_fp32_mode() {
+static bool gemm_fp32_mode(const t2n_field* f) {
     static const bool v = getenv("T2N_BWD_GEMM_FP32") != nullptr;
-    return v || g_gemm_fp32_field;
+    return v || !f->mlp_split;
 }
 // pe_feat (fused head only): B is the [rows, 352] positional encoding; on the bf16x3 path it is computed from feat [rows, 32] inside the
 // GEMM and `B` is never read. db (may be NULL): += column sums of A (the layer's bias gradient).
 template <int MB>
-static void launch_gemm_tn(const float* A, int lda, const float* B, int ldb, long long rows, int M, int N, float* C, int ldc,
+static void launch_gemm_tn(bool fp32, const float* A, int lda, const float* B, int ldb, long long rows, int M, int N, float* C, int ldc,
                            float* part, hipStream_t s, const float* pe_feat = nullptr, float* db = nullptr) {
     const TnPlan p = tn_plan(rows, N);
-    if (!gemm_fp32_mode() && MB == 4) {   // (the 27-row basis gradient is latency-bound either way: 31 us fp32, 44 us bf16x3)
+    if (!fp32 && MB == 4) {   // (the 27-row basis gradient is latency-bound either way: 31 us fp32, 44 us bf16x3)
         (void)launch_gemm_tn_b(A, lda, pe_feat ? pe_feat : B, pe_feat ? 32 : ldb, rows, N, part, p.ldp, p.chunk_rows, p.ng, p.chunks,
                                pe_feat != nullptr, db, s);
     } else {
@@ -1372,8 +1371,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     if (rows > 0) {
         const t2n_field_params* P = &f->params_ref;
         timing_begin(f, T2N_K_BWD_MLP, s);
-        g_gemm_fp32_field = !f->mlp_split;
-        const bool gemm_fp32 = gemm_fp32_mode();
+        const bool gemm_fp32 = gemm_fp32_mode(f);
         static const bool unfused_env = getenv("T2N_BWD_UNFUSED") != nullptr;   // A/B switch: the five-launch form of the input-gradient chain
         const bool fused = !generic && !gemm_fp32 && !unfused_env && f->desc.app_dim == 27 && K0 == 351;
         void* gpack = (void*)(bw + b.gpack);
@@ -1383,18 +1381,18 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             float* G0 = xpe; float* GF = xpe + (size_t)rows * 128; float* GX = xpe + (size_t)rows * 160;
             launch_bwd_l2((const float4*)go, (const float*)h1, rows, P->mlp_w2, nullptr, g->mlp_w2, g->mlp_b2, part, s);
             if ((rc = launch_mlp_bwd_ss(f, gpack, (const float4*)go, h1, h0, feat32, G0, GF, GX, rows, s))) return rc;
-            if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s, nullptr, g->mlp_b1);
+            if (g->mlp_w1) launch_gemm_tn<4>(gemm_fp32, g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s, nullptr, g->mlp_b1);
             else if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
-            if (g->mlp_w0) launch_gemm_tn<4>(G0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, s, feat32, g->mlp_b0);
+            if (g->mlp_w0) launch_gemm_tn<4>(gemm_fp32, G0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, s, feat32, g->mlp_b0);
             else if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)G0, 128, (long long)rows, 128, g->mlp_b0, 128);
-            if (g->basis_weight) launch_gemm_tn<1>(GF, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, s);
+            if (g->basis_weight) launch_gemm_tn<1>(gemm_fp32, GF, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, s);
             gxapp = GX;
         } else {
         // 3. layer 2
         launch_bwd_l2((const float4*)go, (const float*)h1, rows, P->mlp_w2, g1, g->mlp_w2, g->mlp_b2, part, s);
         // 4. layers 1, 0, PE, basis
         // (a bias gradient without its weight gradient does not occur: the column sums ride in the weight-gradient GEMM)
-        if (g->mlp_w1) launch_gemm_tn<4>(g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s, nullptr, g->mlp_b1);
+        if (g->mlp_w1) launch_gemm_tn<4>(gemm_fp32, g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s, nullptr, g->mlp_b1);
         else if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
         // input-gradient GEMMs: split-f16 MFMA products with a power-of-two scale per row (t2n_gemm_h.hip); T2N_BWD_GEMM_FP32=1
         // keeps the fp32-MFMA form
@@ -1403,13 +1401,13 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         else if ((rc = launch_gemm_nn_h(gpack, 0, K0, g1, 128, rows, h0, 128, g0, 128, s))) return rc;
         const bool pe_in_gemm = !generic && !gemm_fp32 && g->mlp_w0;   // the encoding is computed inside the weight-gradient GEMM
         if (!generic && !pe_in_gemm && g->mlp_w0) hipLaunchKernelGGL(k_pe_fwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)feat32, (long long)rows, xpe);
-        if (g->mlp_w0) launch_gemm_tn<4>(g0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, s, pe_in_gemm ? feat32 : nullptr, g->mlp_b0);
+        if (g->mlp_w0) launch_gemm_tn<4>(gemm_fp32, g0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, s, pe_in_gemm ? feat32 : nullptr, g->mlp_b0);
         else if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g0, 128, (long long)rows, 128, g->mlp_b0, 128);
         if (gemm_fp32) launch_gemm_nn(g0, 128, P->mlp_w0, K0, rows, 128, K0, nullptr, 0, gx, K0pad, s);
         else if ((rc = launch_gemm_nn_h(gpack, 1, K0, g0, 128, rows, nullptr, 0, gx, K0pad, s))) return rc;
         if (!generic) hipLaunchKernelGGL(k_pe_bwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, (const float*)gx, (const float*)feat32, (long long)rows, gf);
         else if ((rc = launch_head_in_bwd(f, gx, feat32, rows, gf, s))) return rc;
-        if (g->basis_weight) launch_gemm_tn<1>(gf, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, s);
+        if (g->basis_weight) launch_gemm_tn<1>(gemm_fp32, gf, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, s);
         if (gemm_fp32) launch_gemm_nn(gf, 32, P->basis_weight, 144, rows, f->desc.app_dim, 144, nullptr, 0, gxapp, 144, s);
         else if ((rc = launch_gemm_nn_h(gpack, 2, K0, gf, 32, rows, nullptr, 0, gxapp, 144, s))) return rc;
         }
