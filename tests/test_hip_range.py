@@ -126,3 +126,81 @@ def test_field_after_optimisation_steps_matches_oracle(tiny_params):
     assert st["appearance"] > 100, st
     assert float((rgb.cpu() - o_rgb).abs().max()) <= RGB_ATOL, st
     assert float(loss.detach()) < 0.2            # the steps did optimise something
+
+
+def _train_pass(params, n_samples=48, seed=5, check_grads=True):
+    """training-mode forward + backward (the activation-keeping one-kernel appearance path, then the backward on its rows) and the
+    oracle's forward + autograd on the same rays and jitter"""
+    from oracle import oracle_torch as O
+    from tests.test_hip_parity import _grad_check
+    f = make_field(params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    r = rays()
+    g = np.random.Generator(np.random.PCG64(seed))
+    ca = torch.from_numpy(g.uniform(-1, 1, (r.shape[0], 3)).astype(np.float32))
+    out = {}
+    for it in range(2):   # iteration 0: the backward recomputes the activations; iteration 1: the forward keeps them
+        for p in f.parameters():
+            p.grad = None
+        torch.manual_seed(seed)
+        jit = torch.rand(r.shape[0], 1)
+        torch.manual_seed(seed)
+        rgb, depth, z, w = f(r, is_train=True, white_bg=True, N_samples=n_samples)
+        ((rgb * ca.to(dev())).sum() + 0.1 * depth.sum()).backward()
+        out[it] = (rgb.detach().cpu().numpy(), {k: p.grad.detach().cpu().numpy().copy() for k, p in f.named_parameters()})
+    cfg = O.FieldConfig(aabb=TINY["aabb"], grid_size=TINY["grid"], near_far=TINY["near_far"])
+    P = O.params_from_numpy(params, requires_grad=True)
+    o = O.forward(cfg, P, r, white_bg=True, is_train=True, n_samples=n_samples, jitter=jit)
+    ((o[0] * ca).sum() + 0.1 * o[1].sum()).backward()
+    ref = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).numpy() for k, v in P.items()}
+    st = f.stats()
+    assert st["appearance"] > 500, st
+    for it in (0, 1):
+        assert float(np.abs(out[it][0] - o[0].detach().numpy()).max()) <= RGB_ATOL, (it, st)
+    if check_grads:
+        _grad_check(f, ref, rel=5e-4)
+    return st
+
+
+def test_training_forward_range_guard(tiny_params):
+    """The training forward and the backward's recompute run the one-kernel split path, whose weights carry a fixed 2^8 pre-scale:
+    a weight beyond 2^16 / 2^8 is found at upload (the split launch defers to the exact one behind it), an activation or feature
+    beyond the f16 range at run time (range flag -> the exact launch rewrites every entry and kept activation row). Forward and
+    gradients against the oracle in both cases, on the recompute iteration and on the kept-rows iteration."""
+    p = {k: v.copy() for k, v in tiny_params.items()}
+    p["renderModule.mlp.2.weight"][3, 5] = 300.0
+    p["renderModule.mlp.2.weight"][17, 9] = -411.0
+    _train_pass(p)
+    p = {k: v.copy() for k, v in tiny_params.items()}
+    p["renderModule.mlp.0.bias"] = p["renderModule.mlp.0.bias"] + np.float32(1.0e5)
+    p["renderModule.mlp.2.weight"] = p["renderModule.mlp.2.weight"] * np.float32(1e-3)
+    _train_pass(p)
+    # features of ~1e5: forward only (an fp32 feature of that size carries an absolute error of ~1e-2, i.e. radians of error in
+    # sin(2^5 f): the encoding's gradient is ill-conditioned there, in the reference as much as here)
+    _train_pass(scaled(tiny_params, **{"basis_mat": 1.0e7, "renderModule.mlp.0": 1.0e-7}), check_grads=False)
+    _train_pass(tiny_params)   # and the in-range field still takes the split launch (same bounds)
+
+
+def test_explicit_point_shade_range_guard(tiny_params):
+    """compute_appfeature / shade at explicit points (models/tensoRF.py:223-239 + renderModule) under the same three stresses"""
+    from oracle import oracle_torch as O
+    g = np.random.Generator(np.random.PCG64(9))
+    xyz = torch.from_numpy(g.uniform(-1, 1, (777, 3)).astype(np.float32))
+    cases = []
+    p = {k: v.copy() for k, v in tiny_params.items()}
+    p["renderModule.mlp.2.weight"][3, 5] = 300.0
+    cases.append(p)
+    p = {k: v.copy() for k, v in tiny_params.items()}
+    p["renderModule.mlp.0.bias"] = p["renderModule.mlp.0.bias"] + np.float32(1.0e5)
+    p["renderModule.mlp.2.weight"] = p["renderModule.mlp.2.weight"] * np.float32(1e-3)
+    cases.append(p)
+    cases.append(scaled(tiny_params, **{"basis_mat": 1.0e7, "renderModule.mlp.0": 1.0e-7}))
+    cases.append(tiny_params)
+    for p in cases:
+        f = make_field(p, TINY["grid"], TINY["aabb"], TINY["near_far"])
+        feat, rgb = f.shade(xyz.to(dev()))
+        P = O.params_from_numpy(p)
+        o_feat = O.app_feature(P, xyz)
+        o_rgb = O.mlp_fea_noview(P, o_feat, 6)
+        fscale = float(o_feat.abs().max()) + 1e-12
+        assert float((feat.cpu() - o_feat).abs().max()) <= 2e-5 * fscale
+        assert float((rgb.cpu() - o_rgb).abs().max()) <= RGB_ATOL

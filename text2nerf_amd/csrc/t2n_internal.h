@@ -75,6 +75,7 @@ struct t2n_field {
     int factor_bf16 = 0;
     float* buf_mlp = nullptr;  // basisA | w0A | w1A | w2A
     void* buf_mlp_h = nullptr; // split-f16 operands + scaled biases
+    const unsigned* split_unsafe = nullptr;   // device word (in buf_mlp_h): a weight x 2^8 left the f16 range at the last upload
     void* buf_ss = nullptr;    // sample-stationary head operands (t2n_mlp_ss.hip), packed lazily from params_ref
     bool ss_dirty = true;
     float* buf_alpha = nullptr; // alpha-mask volume copy

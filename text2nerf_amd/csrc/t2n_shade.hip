@@ -145,16 +145,20 @@ __device__ __forceinline__ float opaque_neg1() {
     asm("s_mov_b32 %0, 0xbf800000" : "=s"(x));
     return x;
 }
-__device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
+template <bool TRACK = true>
+__device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo, float& amax) {
     // hi = RTZ_f16(x) (packed convert), lo = RTZ_f16(x - hi): the residual is exact in fp32 (hi is a truncation of x) and is
     // formed by v_fma_mix_f32 straight from the packed halves: two instructions per value
     typedef __fp16 hh2 __attribute__((ext_vector_type(2)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    // amax: largest magnitude handed to the packed convert (it saturates silently, RTZ): the callers raise the launch's range
+    // flag when it passes the f16 range and the launch is redone on the exact path (v_max3_f32, one instruction per pair)
     const float n1 = opaque_neg1();
     u4 uh, ul;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+        if constexpr (TRACK) amax = fmaxf(fmaxf(amax, fabsf(x[2 * e])), fabsf(x[2 * e + 1]));
         const hh2 p = __builtin_amdgcn_cvt_pkrtz(x[2 * e], x[2 * e + 1]);
         const h2 ph = __builtin_bit_cast(h2, p);
         const float r0 = fmaf((float)ph[0], n1, x[2 * e]), r1 = fmaf((float)ph[1], n1, x[2 * e + 1]);
@@ -166,8 +170,8 @@ __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
 }
 
 // acc[m] += W_chunk,m (split) x B_chunk (split on the fly); A operands double-buffered one chunk ahead.
-template <int NMB, class BF>
-__device__ __forceinline__ void f16_stream(f32x16 (&acc)[NMB], const uint4* __restrict__ ap, int lane, int nchunks, BF& bf) {
+template <int NMB, bool TRACK = true, class BF>
+__device__ __forceinline__ void f16_stream(f32x16 (&acc)[NMB], const uint4* __restrict__ ap, int lane, int nchunks, BF& bf, float& amax) {
     constexpr int NR = NMB * 2;
     uint4 A0[NR], A1[NR];
     auto fetch = [&](uint4 (&A)[NR], int c) {
@@ -179,7 +183,7 @@ __device__ __forceinline__ void f16_stream(f32x16 (&acc)[NMB], const uint4* __re
         float x[8];
         bf(c, x);
         h8 bhi, blo;
-        split8(x, bhi, blo);
+        split8<TRACK>(x, bhi, blo, amax);
 #pragma unroll
         for (int m = 0; m < NMB; ++m) {
             const h8 ahi = __builtin_bit_cast(h8, A[2 * m]), alo = __builtin_bit_cast(h8, A[2 * m + 1]);
@@ -281,6 +285,7 @@ __device__ __forceinline__ f32x16 bias_init(const float* __restrict__ bp, int m,
     return r;
 }
 
+constexpr unsigned kUnsafeBasis = 1u, kUnsafeHead = 2u;   // bits of the split_unsafe word: which weights left the pre-scale's range
 struct ShadeArgs {
     FieldDev F;
     const float4* app_pos; const int* app_ray; const float* rays; int ray_stride;
@@ -292,6 +297,8 @@ struct ShadeArgs {
     unsigned tile_lo, tile_hi;        // this launch covers tiles [tile_lo, min(ntiles, tile_hi)) of the sub-lists
     const unsigned* run_if_nonzero;   // when set: the launch is a no-op unless *run_if_nonzero != 0 (exact-path redo gate)
     unsigned* range_flag;             // when set: raised by the split path when a value left the f16 range
+    const unsigned* split_unsafe;     // device word set at upload when a weight x 2^8 (the one-kernel split path's fixed pre-scale) leaves
+                                      // the f16 range: split launches then do nothing (and raise range_flag) and the exact launch behind them runs
     unsigned long long* stats;        // redo launches count themselves in stats[T2N_STAT_F16_REDO]
 };
 
@@ -323,36 +330,34 @@ __device__ __forceinline__ void gather_issue(const FactorSet& S, int it, int lan
     issue_taps_ax<1, HALF>(S, CQ, g.q, A, g.t[1]);
     issue_taps_ax<2, HALF>(S, CQ, g.q, A, g.t[2]);
 }
-template <bool TRACK = false>
-__device__ __forceinline__ void gather_consume(const GatherItem& g, float* __restrict__ X, float* ctx_x, unsigned row0, float& amax) {
+__device__ __forceinline__ void gather_consume(const GatherItem& g, float* __restrict__ X, float* ctx_x, unsigned row0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float4 p = taps_plane(g.t[k]), l = taps_line(g.t[k]);
         float4 v = make_float4(p.x * l.x, p.y * l.y, p.z * l.z, p.w * l.w);
         if (!g.live) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (TRACK) amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(amax, fmaxf(fabsf(v.z), fabsf(v.w))));   // f16 range of the split path
         float* dst = X + (size_t)(k * 48 + g.q * 4) * kXld + g.s;
         dst[0] = v.x; dst[kXld] = v.y; dst[2 * kXld] = v.z; dst[3 * kXld] = v.w;
         if (ctx_x) *reinterpret_cast<float4*>(ctx_x + (size_t)(row0 + g.s) * kAppK + k * 48 + g.q * 4) = v;
     }
 }
 
-template <bool HALF = false, bool TRACK = false>
+template <bool HALF = false>
 __device__ __forceinline__ void gather_all(const FactorSet& S, float* __restrict__ X, int lane, const float4* pos_l,
-                                           const float* xyz, unsigned base, unsigned count, float* ctx_x, unsigned row0, float& amax) {
+                                           const float* xyz, unsigned base, unsigned count, float* ctx_x, unsigned row0) {
     GatherItem g0, g1;
     gather_issue<HALF>(S, 0, lane, pos_l, xyz, base, count, g0);
     gather_issue<HALF>(S, 1, lane, pos_l, xyz, base, count, g1);
-    gather_consume<TRACK>(g0, X, ctx_x, row0, amax);
+    gather_consume(g0, X, ctx_x, row0);
     gather_issue<HALF>(S, 2, lane, pos_l, xyz, base, count, g0);
-    gather_consume<TRACK>(g1, X, ctx_x, row0, amax);
+    gather_consume(g1, X, ctx_x, row0);
     gather_issue<HALF>(S, 3, lane, pos_l, xyz, base, count, g1);
-    gather_consume<TRACK>(g0, X, ctx_x, row0, amax);
+    gather_consume(g0, X, ctx_x, row0);
     gather_issue<HALF>(S, 4, lane, pos_l, xyz, base, count, g0);
-    gather_consume<TRACK>(g1, X, ctx_x, row0, amax);
+    gather_consume(g1, X, ctx_x, row0);
     gather_issue<HALF>(S, 5, lane, pos_l, xyz, base, count, g1);
-    gather_consume<TRACK>(g0, X, ctx_x, row0, amax);
-    gather_consume<TRACK>(g1, X, ctx_x, row0, amax);
+    gather_consume(g0, X, ctx_x, row0);
+    gather_consume(g1, X, ctx_x, row0);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -383,8 +388,12 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         if (*a.run_if_nonzero == 0u) return;
         if (a.stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.stats[T2N_STAT_F16_REDO], 1ull);
     }
+    if (SPLIT && a.split_unsafe && *a.split_unsafe) {   // weights beyond the fixed pre-scale's range: the exact launch behind this one does the work
+        if (a.range_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.range_flag, 1u);
+        return;
+    }
     const unsigned wave_stride = gridDim.x * 4u;
-    float amax = 0.f;   // (range tracking lives in k_app_features / k_mlp_ss)
+    float amax = 0.f;   // largest magnitude handed to an f16 convert (split path): past the f16 range the launch is redone exactly
 
     for (unsigned tile = a.tile_lo + blockIdx.x * 4u + wid; tile < ntiles; tile += wave_stride) {
         const int li = (int)__popcll(__ballot((lane < a.nlists) & (incl <= tile)));
@@ -396,20 +405,24 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         const unsigned row0 = tile * 32u;   // activation row of lane sample 0 (ctx mode)
         const bool keep_rows = row0 + 32u <= a.ctx_rows;
         const ShadeCtx cx = keep_rows ? a.ctx : ShadeCtx{nullptr, nullptr, nullptr, nullptr};
-        gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, cx.x144, row0, amax);
+        gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, cx.x144, row0);
         wave_lds_sync();
 
         // ---- basis_mat: feat[i][s] = sum_k Wb[i][k] X[k][s] ----------------------------------------------------------
         f32x16 accb1[1] = {{0}};
         if constexpr (SPLIT) {
             LdsChunk bf{X + s, h, kBasisChunksReal};
-            f16_stream<1>(accb1, F.basisH, lane, kBasisChunks, bf);
+            f16_stream<1>(accb1, F.basisH, lane, kBasisChunks, bf, amax);
             accb1[0] *= kWUnscale;
         } else {
             LdsBNoBias bf{X + (size_t)h * kXld + s, kBasisReal};
             mfma_stream<1, kKS1>(accb1, F.basisA + lane, kBasisStages, bf);
         }
         const f32x16 accb = accb1[0];
+        if constexpr (SPLIT) {   // the features are layer 0's raw operand chunks
+#pragma unroll
+            for (int v = 0; v < 16; v += 2) amax = fmaxf(fmaxf(amax, fabsf(accb[v])), fabsf(accb[v + 1]));
+        }
         wave_lds_sync();
 #pragma unroll
         for (int v = 0; v < 16; ++v) Fe[unit_of(v, h) * kXld + s] = accb[v];
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc0[m] = bias_init(F.biasH, m, h);
                 PeChunk bf{Fe + s, h, 0.f, 1.f};
-                f16_stream<4>(acc0, F.w0H, lane, kL0Chunks, bf);
+                f16_stream<4, false>(acc0, F.w0H, lane, kL0Chunks, bf, amax);   // range: features tracked below, the encoding is bounded by 1
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc0[m] *= kWUnscale;
             } else {
@@ -469,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc1[m] = bias_init(F.biasH + 128, m, h);
                 LdsChunk bf{Hs + s, h, kL1Chunks};
-                f16_stream<4>(acc1, F.w1H, lane, kL1Chunks, bf);
+                f16_stream<4>(acc1, F.w1H, lane, kL1Chunks, bf, amax);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc1[m] *= kWUnscale;
             } else {
@@ -497,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
             if constexpr (SPLIT) {
                 acc2a[0] = bias_init(F.biasH + 256, 0, h);
                 LdsChunk bf{Hs + s, h, kL2Chunks};
-                f16_stream<1>(acc2a, F.w2H, lane, kL2Chunks, bf);
+                f16_stream<1>(acc2a, F.w2H, lane, kL2Chunks, bf, amax);
                 acc2a[0] *= kWUnscale;
             } else {
                 LdsB bf{Hs + (size_t)h * kXld + s, 64, h};
@@ -540,6 +553,7 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
         }
         wave_lds_sync();   // Fe reads done before the next tile's gather overwrites X
     }
+    if (SPLIT && a.range_flag && __any(!(amax <= 60000.f)) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
 // ---- features only (K2a of the default render path): gather + basis_mat -> fp32 feature rows [tile * 32 + sample][32] for the
@@ -566,6 +580,10 @@ __global__ __launch_bounds__(256, 2) void k_app_features(const ShadeArgs a) {
     }
     unsigned ntiles = __shfl(incl, a.nlists - 1);
     if (ntiles > a.tile_hi) ntiles = a.tile_hi;
+    if (a.split_unsafe && (*a.split_unsafe & kUnsafeBasis)) {   // basis_mat weights beyond the fixed pre-scale's range: the launch is redone on the exact path
+        if (a.range_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.range_flag, 1u);
+        return;
+    }
     const unsigned wave_stride = gridDim.x * 4u;
     float amax = 0.f;
     for (unsigned tile = blockIdx.x * 4u + wid; tile < ntiles; tile += wave_stride) {
@@ -574,11 +592,11 @@ __global__ __launch_bounds__(256, 2) void k_app_features(const ShadeArgs a) {
         const unsigned lbase = (unsigned)li * a.list_cap;
         const unsigned base = lbase + (tile - before) * 32u;
         const unsigned count = lbase + __shfl(cnt_l, li);
-        gather_all<HALF, true>(F.app, X, lane, a.app_pos, nullptr, base, count, nullptr, 0, amax);
+        gather_all<HALF>(F.app, X, lane, a.app_pos, nullptr, base, count, nullptr, 0);
         wave_lds_sync();
         f32x16 accb1[1] = {{0}};
         LdsChunk bf{X + s, h, kBasisChunksReal};
-        f16_stream<1>(accb1, F.basisH, lane, kBasisChunks, bf);
+        f16_stream<1>(accb1, F.basisH, lane, kBasisChunks, bf, amax);
         const f32x16 accb = accb1[0] * kWUnscale;
         // lane (s, h) register v holds feature (v & 3) + 8 (v >> 2) + 4 h: four float4 stores per lane. Column 27 (a zero of the
         // padded basis) carries the entry's compositing weight to the head, which hands it on in app_rgb.w
@@ -648,8 +666,8 @@ struct CoopRing {
 // One pipelined chunk: the 12 MFMAs of chunk c on the B operand prepared during the previous step, with the VALU work that
 // builds chunk c+1's B operand (`prep`) in the same basic block so the two interleave; the four accumulators are visited
 // round-robin so consecutive MFMAs never chain on one accumulator.
-template <class Prep>
-__device__ __forceinline__ void coop_step(CoopRing& R, int c, f32x16 (&acc)[4], h8& bhi, h8& blo, Prep&& prep) {
+template <bool TRACK, class Prep>
+__device__ __forceinline__ void coop_step(CoopRing& R, int c, f32x16 (&acc)[4], h8& bhi, h8& blo, float& amax, Prep&& prep) {
     uint4 A[8];
     R.advance(c, A);
 #pragma unroll
@@ -662,7 +680,7 @@ __device__ __forceinline__ void coop_step(CoopRing& R, int c, f32x16 (&acc)[4], 
     float x[8];
     prep(x);
     h8 nhi, nlo;
-    split8(x, nhi, nlo);
+    split8<TRACK>(x, nhi, nlo, amax);
     bhi = nhi; blo = nlo;
 #endif
 #ifndef T2N_EXP_NOBARRIER
@@ -719,20 +737,21 @@ __device__ __forceinline__ void coop_layer0(f32x16 (&acc)[4], const uint4* __res
     };
     PePipe P{fe_s + (size_t)14 * h * kXld, 0.f, 1.f, 0.f};
     h8 bhi, blo;
+    float unused = 0.f;   // range: the raw features are checked by the caller, the encoding is bounded by 1
     {
         float x[8];
         raw(0, x);
-        split8(x, bhi, blo);
+        split8<false>(x, bhi, blo, unused);
     }
-    coop_step(R, 0, acc, bhi, blo, [&](float (&x)[8]) { raw(1, x); });
-    coop_step(R, 1, acc, bhi, blo, [&](float (&x)[8]) { P.type_a(0, x); });
+    coop_step<false>(R, 0, acc, bhi, blo, unused, [&](float (&x)[8]) { raw(1, x); });
+    coop_step<false>(R, 1, acc, bhi, blo, unused, [&](float (&x)[8]) { P.type_a(0, x); });
 #pragma unroll 1
     for (int it = 0; it < 7; ++it) {   // chunks 2+3it .. 4+3it = features 2it, 2it+1 of each half
         const int c = 2 + 3 * it;
-        coop_step(R, c, acc, bhi, blo, [&](float (&x)[8]) { P.type_b(2 * it, x); });
-        coop_step(R, c + 1, acc, bhi, blo, [&](float (&x)[8]) { P.type_c(x); });
+        coop_step<false>(R, c, acc, bhi, blo, unused, [&](float (&x)[8]) { P.type_b(2 * it, x); });
+        coop_step<false>(R, c + 1, acc, bhi, blo, unused, [&](float (&x)[8]) { P.type_c(x); });
         // the last trip prepares a chunk past the end from zero feature rows (<= row 28 + 14 < 32 rows + pad): unused
-        coop_step(R, c + 2, acc, bhi, blo, [&](float (&x)[8]) { P.type_a(it < 6 ? 2 * it + 2 : 0, x); });
+        coop_step<false>(R, c + 2, acc, bhi, blo, unused, [&](float (&x)[8]) { P.type_a(it < 6 ? 2 * it + 2 : 0, x); });
     }
 }
 
@@ -750,7 +769,8 @@ __device__ __forceinline__ void coop_layer0_plain(f32x16 (&acc)[4], const uint4*
         float x[8];
         bf(c, x);
         h8 bhi, blo;
-        split8(x, bhi, blo);
+        float unused = 0.f;
+        split8<false>(x, bhi, blo, unused);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const h8 ahi = __builtin_bit_cast(h8, A[2 * m]), alo = __builtin_bit_cast(h8, A[2 * m + 1]);
@@ -763,7 +783,7 @@ __device__ __forceinline__ void coop_layer0_plain(f32x16 (&acc)[4], const uint4*
 }
 
 __device__ __forceinline__ void coop_layer1(f32x16 (&acc)[4], const uint4* __restrict__ w1H, const float* __restrict__ hs_s, int h,
-                                            float* __restrict__ smem, int tid, int lane) {
+                                            float* __restrict__ smem, int tid, int lane, float& amax) {
     CoopRing R{smem, w1H, tid, lane, kL1Chunks};
     R.start();
     auto rows = [&](int c, float (&x)[8]) {
@@ -775,11 +795,11 @@ __device__ __forceinline__ void coop_layer1(f32x16 (&acc)[4], const uint4* __res
     {
         float x[8];
         rows(0, x);
-        split8(x, bhi, blo);
+        split8(x, bhi, blo, amax);
     }
 #pragma unroll 1
     for (int c = 0; c < kL1Chunks; ++c)
-        coop_step(R, c, acc, bhi, blo, [&](float (&x)[8]) { rows(c < kL1Chunks - 1 ? c + 1 : c, x); });
+        coop_step<true>(R, c, acc, bhi, blo, amax, [&](float (&x)[8]) { rows(c < kL1Chunks - 1 ? c + 1 : c, x); });
 }
 
 #ifdef T2N_PHASE_TIMING
@@ -811,7 +831,12 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
     }
     unsigned ntiles = __shfl(incl, a.nlists - 1);
     if (ntiles > a.tile_hi) ntiles = a.tile_hi;
+    if (a.split_unsafe && *a.split_unsafe) {   // weights beyond the fixed pre-scale's range: the exact launch behind this one does the work
+        if (a.range_flag && a.tile_lo < ntiles && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.range_flag, 1u);
+        return;
+    }
     const unsigned block_stride = gridDim.x * 4u;
+    float amax = 0.f;   // largest magnitude handed to an f16 convert: past the f16 range the launch is redone exactly
 #ifdef T2N_PHASE_TIMING
     unsigned long long phacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -830,15 +855,14 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
 #ifdef T2N_PHASE_TIMING
         unsigned long long tph = __builtin_amdgcn_s_memtime();
 #endif
-        float amax_unused = 0.f;
-        gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, nullptr, 0, amax_unused);
+        gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, nullptr, 0);
         wave_lds_sync();
         T2N_PHASE(0);
 
         f32x16 accb1[1] = {{0}};
         {
             LdsChunk bf{X + s, h, kBasisChunksReal};
-            f16_stream<1>(accb1, F.basisH, lane, kBasisChunks, bf);
+            f16_stream<1>(accb1, F.basisH, lane, kBasisChunks, bf, amax);
             accb1[0] *= kWUnscale;
         }
         const f32x16 accb = accb1[0];
@@ -867,6 +891,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
             float fmax_ = 0.f;
 #pragma unroll
             for (int v = 0; v < 16; ++v) fmax_ = fmaxf(fmax_, fabsf(accb[v]));
+            amax = fmaxf(amax, fmax_);   // layer 0's raw-feature chunks (its encoding chunks are bounded by 1)
             // |feature| * 2^3 beyond the fast sincos' range (never, for a trained field): unpipelined libm path
             if (__builtin_expect(__any(fmax_ * 8.f > 8192.f) != 0, 0)) coop_layer0_plain(acc0, F.w0H, Fe + s, h, smem, tid, lane);
             else coop_layer0(acc0, F.w0H, Fe + s, h, smem, tid, lane);
@@ -884,7 +909,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc1[m] = bias_init(F.biasH + 128, m, h);
         T2N_PHASE(4);
-        coop_layer1(acc1, F.w1H, Hs + s, h, smem, tid, lane);
+        coop_layer1(acc1, F.w1H, Hs + s, h, smem, tid, lane, amax);
         T2N_PHASE(5);
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
@@ -897,7 +922,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
         acc2a[0] = bias_init(F.biasH + 256, 0, h);
         {
             LdsChunkT<kHld> bf{Hs + s, h, kL2Chunks};
-            f16_stream<1>(acc2a, F.w2H, lane, kL2Chunks, bf);
+            f16_stream<1>(acc2a, F.w2H, lane, kL2Chunks, bf, amax);
         }
         const f32x16 acc2 = acc2a[0] * kWUnscale;
         if (h == 0 && live) {
@@ -911,6 +936,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
 #ifdef T2N_PHASE_TIMING
     if (lane == 0) for (int i = 0; i < 7; ++i) atomicAdd(&g_phase[i], phacc[i]);
 #endif
+    if (a.range_flag && __any(!(amax <= 60000.f)) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
 // ---- parameter packing ------------------------------------------------------------------------------------------------
@@ -983,9 +1009,11 @@ struct PackHArgs {
     const float* basis; const float* w0; const float* b0; const float* w1; const float* b1; const float* w2; const float* b2;
     _Float16* basisH; _Float16* w0H; _Float16* w1H; _Float16* w2H; float* biasH;
     int app_dim, has_mlp;
+    unsigned* unsafe;   // raised when a pre-scaled weight leaves the f16 range (the split one-kernel launches then defer to the exact path)
 };
-__device__ __forceinline__ void store_split(_Float16* dst, float w, int part) {
+__device__ __forceinline__ void store_split(_Float16* dst, float w, int part, unsigned* unsafe, unsigned bit) {
     const float x = w * kWScale;
+    if (!(fabsf(x) < 60000.f)) atomicOr(unsafe, bit);
     const _Float16 hi = (_Float16)x;
     *dst = part == 0 ? hi : (_Float16)(x - (float)hi);
 }
@@ -1006,26 +1034,26 @@ __global__ __launch_bounds__(256) void k_pack_mlp_h(const PackHArgs a) {
     if (g < nb) {
         decode(g, 1, c, m, part, i, h, e);
         const int k = 16 * c + 8 * h + e;
-        store_split(a.basisH + g, (c < kBasisChunksReal && i < a.app_dim) ? a.basis[i * kAppK + k] : 0.f, part);
+        store_split(a.basisH + g, (c < kBasisChunksReal && i < a.app_dim) ? a.basis[i * kAppK + k] : 0.f, part, a.unsafe, kUnsafeBasis);
         return;
     }
     g -= nb;
     if (!a.has_mlp) return;
     if (g < n0) {
         decode(g, 4, c, m, part, i, h, e);
-        store_split(a.w0H + g, c < kL0ChunksReal ? l0_weight(a.w0, m * 32 + i, c, h, e) : 0.f, part);
+        store_split(a.w0H + g, c < kL0ChunksReal ? l0_weight(a.w0, m * 32 + i, c, h, e) : 0.f, part, a.unsafe, kUnsafeHead);
         return;
     }
     g -= n0;
     if (g < n1) {
         decode(g, 4, c, m, part, i, h, e);
-        store_split(a.w1H + g, c < kL1Chunks ? a.w1[(m * 32 + i) * 128 + 16 * c + 8 * h + e] : 0.f, part);
+        store_split(a.w1H + g, c < kL1Chunks ? a.w1[(m * 32 + i) * 128 + 16 * c + 8 * h + e] : 0.f, part, a.unsafe, kUnsafeHead);
         return;
     }
     g -= n1;
     if (g < n2) {
         decode(g, 1, c, m, part, i, h, e);
-        store_split(a.w2H + g, (c < kL2Chunks && i < 3) ? a.w2[i * 128 + 16 * c + 8 * h + e] : 0.f, part);
+        store_split(a.w2H + g, (c < kL2Chunks && i < 3) ? a.w2[i * 128 + 16 * c + 8 * h + e] : 0.f, part, a.unsafe, kUnsafeHead);
         return;
     }
     g -= n2;
@@ -1064,7 +1092,7 @@ int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
     const size_t hb = (size_t)(kBasisChunks + 1) * 1 * 2 * 64 * 8, h0 = (size_t)(kL0Chunks + 1) * 4 * 2 * 64 * 8,
                  h1 = (size_t)(kL1Chunks + 1) * 4 * 2 * 64 * 8, h2 = (size_t)(kL2Chunks + 1) * 1 * 2 * 64 * 8;
     if (!f->buf_mlp_h) {
-        T2N_HIP(hipMalloc((void**)&f->buf_mlp_h, (hb + h0 + h1 + h2) * sizeof(_Float16) + 288 * sizeof(float)));
+        T2N_HIP(hipMalloc((void**)&f->buf_mlp_h, (hb + h0 + h1 + h2) * sizeof(_Float16) + (288 + 4) * sizeof(float)));
     }
     _Float16* hbase = (_Float16*)f->buf_mlp_h;
     PackHArgs ha;
@@ -1072,6 +1100,9 @@ int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
     ha.basisH = hbase; ha.w0H = hbase + hb; ha.w1H = hbase + hb + h0; ha.w2H = hbase + hb + h0 + h1;
     ha.biasH = (float*)(hbase + hb + h0 + h1 + h2);
     ha.app_dim = f->desc.app_dim; ha.has_mlp = a.has_mlp;
+    ha.unsafe = (unsigned*)(ha.biasH + 288);
+    f->split_unsafe = ha.unsafe;
+    T2N_HIP(hipMemsetAsync(ha.unsafe, 0, 4, s));
     f->dev.basisH = (const uint4*)ha.basisH; f->dev.w0H = (const uint4*)ha.w0H; f->dev.w1H = (const uint4*)ha.w1H;
     f->dev.w2H = (const uint4*)ha.w2H; f->dev.biasH = ha.biasH;
     const size_t htotal = hb + h0 + h1 + h2 + 288;
@@ -1136,7 +1167,7 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
         fa.app_rgb = nullptr;
         fa.ctx = ShadeCtx{nullptr, feat, nullptr, nullptr};
         fa.ctx_rows = ws_tiles * 32u; fa.tile_hi = ws_tiles;
-        fa.range_flag = flag;
+        fa.range_flag = flag; fa.split_unsafe = f->split_unsafe;
         timing_begin(f, T2N_K_APPFEAT, s);
         if (half) hipLaunchKernelGGL(k_app_features<true>, grid, dim3(256), lds, s, fa);
         else hipLaunchKernelGGL(k_app_features<false>, grid, dim3(256), lds, s, fa);
@@ -1145,7 +1176,7 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
         const int rc = launch_mlp_ss(f, feat, counters_dev, list_cap, ws_tiles, app_rgb, flag, s);
         if (rc) return rc;
         ShadeArgs oa = a;
-        oa.tile_lo = ws_tiles;
+        oa.tile_lo = ws_tiles; oa.range_flag = flag; oa.split_unsafe = f->split_unsafe;
         if (half) hipLaunchKernelGGL(k_shade_coop<true>, grid, dim3(256), kCoopLds, s, oa);
         else hipLaunchKernelGGL(k_shade_coop<false>, grid, dim3(256), kCoopLds, s, oa);
         ShadeArgs ra = a;   // every tile of the launch, the one-kernel path's included
@@ -1155,11 +1186,22 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
         T2N_HIP(hipGetLastError());
         return T2N_OK;
     }
+    // one-kernel paths (training forward / backward recompute with kept activations, overflow-free A/B builds): the split launch
+    // tracks the range of everything it converts to f16; behind it an exact launch that runs only when the flag (or the
+    // upload-time weight flag) is up and rewrites every entry and activation row of the launch
+    unsigned* flag = const_cast<unsigned*>(counters_dev) + kRangeFlagWord;
+    a.range_flag = flag; a.split_unsafe = f->split_unsafe;
     timing_begin(f, T2N_K_SHADE, s);
     if (use_coop(f) && !ctx && half) hipLaunchKernelGGL(k_shade_coop<true>, grid, dim3(256), kCoopLds, s, a);
     else if (use_coop(f) && !ctx) hipLaunchKernelGGL(k_shade_coop<false>, grid, dim3(256), kCoopLds, s, a);
     else if (f->mlp_split)   /* ctx (backward recompute) too: activations at ~1e-7 relative error */ hipLaunchKernelGGL(k_shade<true>, grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL(k_shade<false>, grid, dim3(256), lds, s, a);
+    if (f->mlp_split) {
+        ShadeArgs ra = a;
+        ra.range_flag = nullptr; ra.split_unsafe = nullptr;
+        ra.run_if_nonzero = flag; ra.stats = (unsigned long long*)stats;
+        hipLaunchKernelGGL(k_shade<false>, grid, dim3(256), lds, s, ra);
+    }
     timing_end(f, T2N_K_SHADE, s);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
@@ -1181,13 +1223,13 @@ extern "C" size_t t2n_shade_workspace_bytes(int64_t n) { (void)n; return 256; }
 
 extern "C" int t2n_shade_at(const t2n_field* fc, const float* xyz_norm, const float* viewdirs, int64_t n, float* app_feat,
                             float* rgb, void* workspace, size_t workspace_bytes, t2n_stream stream) {
-    (void)workspace; (void)workspace_bytes;
     t2n_field* f = const_cast<t2n_field*>(fc);
     if (!f || !xyz_norm || n < 0 || n > 0x7fffffff) { set_error("t2n_shade_at: bad argument"); return T2N_ERR_INVALID; }
     if (!f->uploaded) { set_error("t2n_shade_at: field has no uploaded parameters"); return T2N_ERR_STATE; }
     if (f->desc.shading == T2N_SHADE_SH && rgb && !viewdirs) { set_error("t2n_shade_at: SH head needs viewdirs"); return T2N_ERR_INVALID; }
     if (head_is_generic(f->desc.shading) && rgb) { set_error("t2n_shade_at: the view-dependent MLP heads are evaluated by the render call only (features are available)"); return T2N_ERR_UNSUPPORTED; }
     if (n == 0) return T2N_OK;
+    if (f->mlp_split && (!workspace || workspace_bytes < 4)) { set_error("t2n_shade_at: workspace smaller than t2n_shade_workspace_bytes()"); return T2N_ERR_INVALID; }
     ShadeArgs a;
     memset(&a, 0, sizeof(a));
     a.F = f->dev;
@@ -1199,9 +1241,18 @@ extern "C" int t2n_shade_at(const t2n_field* fc, const float* xyz_norm, const fl
     T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
-    if (use_coop(f)) hipLaunchKernelGGL(k_shade_coop<false>, dim3(shade_grid((unsigned)n)), dim3(256), kCoopLds, (hipStream_t)stream, a);
-    else if (f->mlp_split) hipLaunchKernelGGL(k_shade<true>, dim3(shade_grid((unsigned)n)), dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(shade_grid((unsigned)n)), dim3(256), lds, (hipStream_t)stream, a);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(shade_grid((unsigned)n));
+    if (f->mlp_split) {   // workspace word 0: the launch's f16-range flag (the exact launch behind the split one runs when it is up)
+        unsigned* flag = (unsigned*)workspace;
+        T2N_HIP(hipMemsetAsync(flag, 0, 4, s));
+        a.range_flag = flag; a.split_unsafe = f->split_unsafe;
+        if (use_coop(f)) hipLaunchKernelGGL(k_shade_coop<false>, grid, dim3(256), kCoopLds, s, a);
+        else hipLaunchKernelGGL(k_shade<true>, grid, dim3(256), lds, s, a);
+        ShadeArgs ra = a;
+        ra.range_flag = nullptr; ra.split_unsafe = nullptr; ra.run_if_nonzero = flag;
+        hipLaunchKernelGGL(k_shade<false>, grid, dim3(256), lds, s, ra);
+    } else hipLaunchKernelGGL(k_shade<false>, grid, dim3(256), lds, s, a);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }
