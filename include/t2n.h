@@ -172,7 +172,8 @@ int t2n_filter_rays_bbox(const t2n_field* f, const float* rays, int64_t n_rays, 
 int t2n_density_at(const t2n_field* f, const float* xyz_norm, int64_t n, float* feat, float* sigma, t2n_stream stream);
 /* a-12 + a-13: compute_appfeature (models/tensoRF.py:223-239) and renderModule (models/tensorBase.py:29-33,88-109).
  *   viewdirs [n,3] (SH head only, else NULL); app_feat [n,app_dim] and rgb [n,3] (either may be NULL).
- *   workspace: t2n_shade_workspace_bytes(n). */
+ *   workspace: t2n_shade_workspace_bytes(n) bytes of device memory (holds the launch's f16-range flag; T2N_ERR_INVALID when
+ *   missing on a field whose head runs as split-f16 products). */
 size_t t2n_shade_workspace_bytes(int64_t n);
 int t2n_shade_at(const t2n_field* f, const float* xyz_norm, const float* viewdirs, int64_t n, float* app_feat, float* rgb,
                  void* workspace, size_t workspace_bytes, t2n_stream stream);
