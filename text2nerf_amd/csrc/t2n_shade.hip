@@ -342,9 +342,100 @@ __device__ __forceinline__ void gather_consume(const GatherItem& g, float* __res
     }
 }
 
+// bf16 factor storage: a tap is 96 contiguous bytes, fetched as six 16-B octets (8 channels each) - 192 (sample, octet) items
+// over 64 lanes, 3 per lane, half the load instructions and half the L1 bytes of the fp32 gather. Taps stay packed until they
+// are consumed; the arithmetic per channel is the fp32 gather's (bf16 -> fp32 is exact), so the products are bit-identical.
+struct OctTaps {
+    uint4 nw, ne, sw, se, l0, l1;
+    float wnw, wne, wsw, wse, wl0, wl1;
+};
+struct GatherItemH {
+    OctTaps t[3];
+    int s, o;
+    bool live;
+};
+template <int K>
+__device__ __forceinline__ void issue_octets_ax(const FactorSet& S, int o, const Axes3& A, OctTaps& t) {
+    const Axis& ax = A.a[mat0(K)];
+    const Axis& ay = A.a[mat1(K)];
+    const Axis& al = A.a[vecm(K)];
+    const unsigned W = (unsigned)S.W[K];
+    constexpr unsigned tb = 96u;   // bytes per texel: 48 channels x 2
+    const unsigned ob = (unsigned)o * 16u;
+    const unsigned r0 = __umul24((unsigned)ay.i0, W), r1 = __umul24((unsigned)ay.i1, W);
+    const char* __restrict__ P = reinterpret_cast<const char*>(S.plane_h[K]);
+    const char* __restrict__ Ln = reinterpret_cast<const char*>(S.line_h[K]);
+    t.nw = *reinterpret_cast<const uint4*>(P + ((r0 + (unsigned)ax.i0) * tb + ob));
+    t.ne = *reinterpret_cast<const uint4*>(P + ((r0 + (unsigned)ax.i1) * tb + ob));
+    t.sw = *reinterpret_cast<const uint4*>(P + ((r1 + (unsigned)ax.i0) * tb + ob));
+    t.se = *reinterpret_cast<const uint4*>(P + ((r1 + (unsigned)ax.i1) * tb + ob));
+    t.l0 = *reinterpret_cast<const uint4*>(Ln + ((unsigned)al.i0 * tb + ob));
+    t.l1 = *reinterpret_cast<const uint4*>(Ln + ((unsigned)al.i1 * tb + ob));
+    t.wnw = ay.w0 * ax.w0; t.wne = ay.w0 * ax.w1; t.wsw = ay.w1 * ax.w0; t.wse = ay.w1 * ax.w1;
+    t.wl0 = al.w0; t.wl1 = al.w1;
+}
+__device__ __forceinline__ void gather_issue_h(const FactorSet& S, int it, int lane, const float4* pos_l, const float* xyz,
+                                               unsigned base, unsigned count, GatherItemH& g) {
+    const int item = it * 64 + lane;
+    g.s = item / 6; g.o = item - g.s * 6;
+    const unsigned idx = base + (unsigned)g.s;
+    g.live = idx < count;
+    float xn = 0.f, yn = 0.f, zn = 0.f;
+    if (g.live) {
+        if (pos_l) { const float4 p = pos_l[idx]; xn = p.x; yn = p.y; zn = p.z; }
+        else { xn = xyz[(size_t)idx * 3]; yn = xyz[(size_t)idx * 3 + 1]; zn = xyz[(size_t)idx * 3 + 2]; }
+    }
+    const Axes3 A = sample_axes(S, xn, yn, zn);
+    issue_octets_ax<0>(S, g.o, A, g.t[0]);
+    issue_octets_ax<1>(S, g.o, A, g.t[1]);
+    issue_octets_ax<2>(S, g.o, A, g.t[2]);
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ void gather_consume_h(const GatherItemH& g, float* __restrict__ X, float* ctx_x, unsigned row0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const OctTaps& t = g.t[k];
+        const unsigned nw[4] = {t.nw.x, t.nw.y, t.nw.z, t.nw.w}, ne[4] = {t.ne.x, t.ne.y, t.ne.z, t.ne.w};
+        const unsigned sw[4] = {t.sw.x, t.sw.y, t.sw.z, t.sw.w}, se[4] = {t.se.x, t.se.y, t.se.z, t.se.w};
+        const unsigned l0[4] = {t.l0.x, t.l0.y, t.l0.z, t.l0.w}, l1[4] = {t.l1.x, t.l1.y, t.l1.z, t.l1.w};
+        float v[8];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            // the fp32 gather's order: plane = ((nw wnw + ne wne) + sw wsw) + se wse by fma, line = l0 wl0 + l1 wl1, product
+            float pa = bf16_lo(nw[d]) * t.wnw, pb = bf16_hi(nw[d]) * t.wnw;
+            pa = fmaf(bf16_lo(ne[d]), t.wne, pa); pb = fmaf(bf16_hi(ne[d]), t.wne, pb);
+            pa = fmaf(bf16_lo(sw[d]), t.wsw, pa); pb = fmaf(bf16_hi(sw[d]), t.wsw, pb);
+            pa = fmaf(bf16_lo(se[d]), t.wse, pa); pb = fmaf(bf16_hi(se[d]), t.wse, pb);
+            float la = bf16_lo(l0[d]) * t.wl0, lb = bf16_hi(l0[d]) * t.wl0;
+            la = fmaf(bf16_lo(l1[d]), t.wl1, la); lb = fmaf(bf16_hi(l1[d]), t.wl1, lb);
+            v[2 * d] = g.live ? pa * la : 0.f;
+            v[2 * d + 1] = g.live ? pb * lb : 0.f;
+        }
+        float* dst = X + (size_t)(k * 48 + g.o * 8) * kXld + g.s;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dst[c * kXld] = v[c];
+        if (ctx_x) {
+            float4* cp = reinterpret_cast<float4*>(ctx_x + (size_t)(row0 + g.s) * kAppK + k * 48 + g.o * 8);
+            cp[0] = make_float4(v[0], v[1], v[2], v[3]);
+            cp[1] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
 template <bool HALF = false>
 __device__ __forceinline__ void gather_all(const FactorSet& S, float* __restrict__ X, int lane, const float4* pos_l,
                                            const float* xyz, unsigned base, unsigned count, float* ctx_x, unsigned row0) {
+    if constexpr (HALF) {
+        GatherItemH h0, h1;
+        gather_issue_h(S, 0, lane, pos_l, xyz, base, count, h0);
+        gather_issue_h(S, 1, lane, pos_l, xyz, base, count, h1);
+        gather_consume_h(h0, X, ctx_x, row0);
+        gather_issue_h(S, 2, lane, pos_l, xyz, base, count, h0);
+        gather_consume_h(h1, X, ctx_x, row0);
+        gather_consume_h(h0, X, ctx_x, row0);
+        return;
+    }
     GatherItem g0, g1;
     gather_issue<HALF>(S, 0, lane, pos_l, xyz, base, count, g0);
     gather_issue<HALF>(S, 1, lane, pos_l, xyz, base, count, g1);
