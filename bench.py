@@ -534,7 +534,7 @@ def main():
                 # bound) and not the headline value: it renders the ROUNDED field
                 field.factor_storage = "bf16"
                 out["config"]["bf16_factor_storage_ms_per_step"] = timed_frames(args.steps)
-                out["config"]["bf16_factor_storage_note"] = "34.8 MB instead of 69.6 MB; appearance taps fetched as 16-B octets of 8 bf16 channels (half the gather instructions); density march: same kernel, 8-B gathers"
+                out["config"]["bf16_factor_storage_note"] = "appearance factors read as bf16 (26 MB instead of 52 MB), taps fetched as 16-B octets of 8 channels: half the gather instructions; the tile marcher reads the fp32 copy of the rounded density factors (17 MB), the per-ray marcher their bf16 copy"
                 field.factor_storage = "fp32"
             # BASELINE configs[4] on one GPU: the 48 training views of the reference's circle trajectory (cam_traj_gen, fixture), bf16
             # factor storage, rays generated on the device, one frame per view
