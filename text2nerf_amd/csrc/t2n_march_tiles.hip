@@ -180,8 +180,15 @@ constexpr int kDenseLd = 20;                          // floats per ray row of t
 constexpr int kDenseFloats = 2 * 64 * kDenseLd;       // per wave: weights tile + z tile
 struct __attribute__((aligned(4))) F4U { float x, y, z, w; };   // row segments of an [n_rays, N] tensor are only 4-B aligned for odd N
 
+// Waves per SIMD the register allocation targets. The step loop is a load -> MFMA -> LDS -> read chain that only other waves
+// hide: 3 waves 0.95 ms, 4 waves (109 VGPRs) 0.78, 5 waves (96 VGPRs; ten loop-invariant dwords go to scratch and come back
+// only where an appearance entry is stored) 0.74, 6 waves (80 VGPRs, 104 B of scratch in the loop) 0.86. The DENSE variant
+// spills inside its transpose flush at 5 (2.82 ms against 2.24) and stays at 4.
+#ifndef T2N_MT_WAVES
+#define T2N_MT_WAVES 5
+#endif
 template <bool DENSE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_march_tiles(const TileArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? 4 : T2N_MT_WAVES, DENSE ? 4 : T2N_MT_WAVES))) void k_march_tiles(const TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;

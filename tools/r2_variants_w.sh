@@ -1,0 +1,9 @@
+#!/bin/bash
+# r2_variants_w.sh NAME...: like r2_variants.sh with weights / z_vals materialised (the DENSE tile marcher)
+for v in "$@"; do
+  lib=$PWD/text2nerf_amd/libt2n_hip_$v.so; [ "$v" = main ] && lib=$PWD/text2nerf_amd/libt2n_hip.so
+  T2N_LIB=$lib python bench.py --no-train --steps 20 --quick --no-cpu-baseline --weights 1 2>/dev/null | python -c "
+import sys, json
+d = json.loads([l for l in sys.stdin if l.startswith('{')][0])
+print('$v (weights)', 'ms/step', round(d['ms_per_step'], 3), {k: round(x, 3) for k, x in d['config']['kernel_ms_per_frame'].items()})"
+done
