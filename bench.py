@@ -466,9 +466,9 @@ def main():
             t = k_ms["app_features"] * 1e-3
             lane_loads = 216.0 * A / max(k_per_step["app_features"], 1.0)
             peak = 256 * 4 * 2.4
-            roofs["app_features"] = {"bound": "texture-addresser", "kernel": "k_app_features", "unit": "G lane-loads/s",
+            roofs["app_features"] = {"bound": "texture-addresser", "kernel": "k_app_features_p", "unit": "G lane-loads/s",
                                      "achieved": lane_loads / t / 1e9, "peak": peak, "frac": lane_loads / t / 1e9 / peak,
-                                     "traffic": pmc.get("k_app_features", {}).get("hbm_bytes_per_launch"), "avg_launch_ms": k_ms["app_features"],
+                                     "traffic": (pmc.get("k_app_features_p") or pmc.get("k_app_features") or {}).get("hbm_bytes_per_launch"), "avg_launch_ms": k_ms["app_features"],
                                      "algorithmic_GBps": BYTES_PER_APP * A / max(k_per_step["app_features"], 1.0) / t / 1e9}
         dom = max(roofs, key=lambda k: frame_ms.get(k, 0.0)) if roofs else None
         roof = dict(roofs[dom]) if dom else {}

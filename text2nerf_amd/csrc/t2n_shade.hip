@@ -702,6 +702,189 @@ __global__ __launch_bounds__(256, 2) void k_app_features(const ShadeArgs a) {
     if (a.range_flag && __any(!(amax <= 60000.f)) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
+// ---- the same stage, one factor pair at a time (default) -------------------------------------------------------------------
+// k_app_features holds a 144-row X tile per wave (19 KB: eight waves per CU) and two 18-load items in flight (180 VGPRs): two
+// waves per SIMD to hide a gather that sits on the L1's 64 B/clk. Here a wave walks the three plane/line pairs in turn: gather
+// pair k (6 taps per item, 48 rows of X: 6.3 KB), three basis chunks on the matrix cores, next pair - 128 VGPRs, four waves
+// per SIMD. The sample positions are parked in LDS once per tile (the per-pair items re-derive their taps from them). Same
+// per-channel arithmetic, same chunk order, same three products per chunk: the feature rows are bit-identical.
+constexpr int kPairRows = 48;
+constexpr int kPairFloats = kPairRows * kXld + 32 * 4;   // X[48][33] + 32 positions, per wave
+
+template <int K, bool HALF>
+__device__ __forceinline__ void gather_pair(const FactorSet& S, float* __restrict__ X, const float4* __restrict__ P, int lane, unsigned nlive) {
+    // the item -> (sample, quad) maps and their LDS addresses are loop-invariant per lane: left visible, hipcc hoists ~40 of them
+    // out of the tile loop and spills them; behind an opaque lane index they are recomputed (a few VALU ops per item)
+    asm volatile("" : "+v"(lane));
+    if constexpr (HALF) {
+        auto issue = [&](int it, OctTaps& t, int& s_, int& o_) {
+            const int item = it * 64 + lane;
+            s_ = item / 6; o_ = item - s_ * 6;
+            const float4 p = P[s_];
+            const Axes3 A = sample_axes(S, p.x, p.y, p.z);
+            issue_octets_ax<K>(S, o_, A, t);
+        };
+        auto consume = [&](const OctTaps& t, int s_, int o_) {
+            const bool live = (unsigned)s_ < nlive;
+            const unsigned nw[4] = {t.nw.x, t.nw.y, t.nw.z, t.nw.w}, ne[4] = {t.ne.x, t.ne.y, t.ne.z, t.ne.w};
+            const unsigned sw[4] = {t.sw.x, t.sw.y, t.sw.z, t.sw.w}, se[4] = {t.se.x, t.se.y, t.se.z, t.se.w};
+            const unsigned l0[4] = {t.l0.x, t.l0.y, t.l0.z, t.l0.w}, l1[4] = {t.l1.x, t.l1.y, t.l1.z, t.l1.w};
+            float* dst = X + (size_t)(o_ * 8) * kXld + s_;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                float pa = bf16_lo(nw[d]) * t.wnw, pb = bf16_hi(nw[d]) * t.wnw;
+                pa = fmaf(bf16_lo(ne[d]), t.wne, pa); pb = fmaf(bf16_hi(ne[d]), t.wne, pb);
+                pa = fmaf(bf16_lo(sw[d]), t.wsw, pa); pb = fmaf(bf16_hi(sw[d]), t.wsw, pb);
+                pa = fmaf(bf16_lo(se[d]), t.wse, pa); pb = fmaf(bf16_hi(se[d]), t.wse, pb);
+                float la = bf16_lo(l0[d]) * t.wl0, lb = bf16_hi(l0[d]) * t.wl0;
+                la = fmaf(bf16_lo(l1[d]), t.wl1, la); lb = fmaf(bf16_hi(l1[d]), t.wl1, lb);
+                dst[(2 * d) * kXld] = live ? pa * la : 0.f;
+                dst[(2 * d + 1) * kXld] = live ? pb * lb : 0.f;
+            }
+        };
+        OctTaps t0, t1;
+        int s0, o0, s1, o1;
+        issue(0, t0, s0, o0);
+        issue(1, t1, s1, o1);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(t0, s0, o0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(2, t0, s0, o0);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(t1, s1, o1);
+        consume(t0, s0, o0);
+    } else {
+        auto issue = [&](int it, QuadTaps& t, int& s_, int& q_) {
+            const int item = it * 64 + lane;
+            s_ = item / 12; q_ = item - s_ * 12;
+            const float4 p = P[s_];
+            const Axes3 A = sample_axes(S, p.x, p.y, p.z);
+            issue_taps_ax<K, false>(S, 12, q_, A, t);
+        };
+        auto consume = [&](const QuadTaps& t, int s_, int q_) {
+            const float4 pv = taps_plane(t), l = taps_line(t);
+            float4 v = make_float4(pv.x * l.x, pv.y * l.y, pv.z * l.z, pv.w * l.w);
+            if (!((unsigned)s_ < nlive)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float* dst = X + (size_t)(q_ * 4) * kXld + s_;
+            dst[0] = v.x; dst[kXld] = v.y; dst[2 * kXld] = v.z; dst[3 * kXld] = v.w;
+        };
+        QuadTaps t0, t1;
+        int s0, q0, s1, q1;
+        issue(0, t0, s0, q0);
+        issue(1, t1, s1, q1);
+        // (fenced: unfenced, hipcc hoists all six items' loads to the top and needs 227 VGPRs)
+        __builtin_amdgcn_sched_barrier(0);
+#define T2N_FENCE __builtin_amdgcn_sched_barrier(0)
+        consume(t0, s0, q0); T2N_FENCE; issue(2, t0, s0, q0); T2N_FENCE;
+        consume(t1, s1, q1); T2N_FENCE; issue(3, t1, s1, q1); T2N_FENCE;
+        consume(t0, s0, q0); T2N_FENCE; issue(4, t0, s0, q0); T2N_FENCE;
+        consume(t1, s1, q1); T2N_FENCE; issue(5, t1, s1, q1); T2N_FENCE;
+        consume(t0, s0, q0);
+        consume(t1, s1, q1);
+#undef T2N_FENCE
+    }
+}
+
+// basis chunks 3K .. 3K+2 (16 K-values each) of f16_stream's operand layout, from X[48][kXld]
+template <int K>
+__device__ __forceinline__ void pair_basis(f32x16& acc, const uint4* __restrict__ basisH, const float* __restrict__ Xs, int h, int lane, float& amax) {
+    // the operand offset is made opaque here: the loads are loop-invariant, and hipcc otherwise keeps all 72 operand registers
+    // of the three pairs live across the tile loop
+    unsigned off = (unsigned)lane + (unsigned)(3 * K) * 2u * 64u;
+    asm volatile("" : "+v"(off));
+    const uint4* __restrict__ ap = basisH + off;
+    uint4 A[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { A[c][0] = ap[(c * 2) * 64]; A[c][1] = ap[(c * 2 + 1) * 64]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float x[8];
+        const float* p = Xs + (size_t)(16 * c + 8 * h) * kXld;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = p[e * kXld];
+        h8 bhi, blo;
+        split8(x, bhi, blo, amax);
+        const h8 ahi = __builtin_bit_cast(h8, A[c][0]), alo = __builtin_bit_cast(h8, A[c][1]);
+        acc = mfma16(ahi, bhi, acc);
+        acc = mfma16(ahi, blo, acc);
+        acc = mfma16(alo, bhi, acc);
+        asm volatile("" : "+v"(amax));   // the range tracking of this chunk is due here (deferred to the loop's end, its 8 values are spilled)
+    }
+}
+
+template <bool HALF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_app_features_p(const ShadeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int s = lane & 31, h = lane >> 5;
+    float* __restrict__ X = smem + (size_t)wid * kPairFloats;
+    float4* __restrict__ P = reinterpret_cast<float4*>(X + kPairRows * kXld);
+    const FieldDev& F = a.F;
+    unsigned cnt_l = 0;
+    if (lane < a.nlists) {
+        cnt_l = a.counters[lane * kCounterStride];
+        if (cnt_l > a.list_cap) cnt_l = a.list_cap;
+    }
+    unsigned incl = (cnt_l + 31u) / 32u;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    unsigned ntiles = __shfl(incl, a.nlists - 1);
+    if (ntiles > a.tile_hi) ntiles = a.tile_hi;
+    if (a.split_unsafe && (*a.split_unsafe & kUnsafeBasis)) {   // basis_mat weights beyond the fixed pre-scale's range: the launch is redone on the exact path
+        if (a.range_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.range_flag, 1u);
+        return;
+    }
+    const unsigned wave_stride = gridDim.x * 4u;
+    float amax = 0.f;
+    // tile -> (first entry, live entries) and the lane's position entry (lanes 0..31; dead entries sit at the volume centre and
+    // store zeros); the next tile's positions are fetched while this tile is processed
+    auto locate = [&](unsigned tile, unsigned& base, unsigned& nlive, float4& mine) {
+        mine = make_float4(0.f, 0.f, 0.f, 0.f);
+        base = 0u; nlive = 0u;
+        if (tile >= ntiles) return;   // wave-uniform
+        const int li = (int)__popcll(__ballot((lane < a.nlists) & (incl <= tile)));
+        const unsigned before = li ? __shfl(incl, li - 1) : 0u;
+        const unsigned lbase = (unsigned)li * a.list_cap;
+        base = lbase + (tile - before) * 32u;
+        const unsigned count = lbase + __shfl(cnt_l, li);
+        nlive = count - base < 32u ? count - base : 32u;
+        if (lane < 32 && (unsigned)lane < nlive) mine = a.app_pos[base + (unsigned)lane];
+    };
+    unsigned base, nlive, nbase, nnlive;
+    float4 mine, nmine;
+    locate(blockIdx.x * 4u + wid, base, nlive, mine);
+    for (unsigned tile = blockIdx.x * 4u + wid; tile < ntiles; tile += wave_stride, base = nbase, nlive = nnlive, mine = nmine) {
+        if (lane < 32) P[lane] = mine;
+        locate(tile + wave_stride, nbase, nnlive, nmine);
+        wave_lds_sync();
+        f32x16 acc = {0};
+        gather_pair<0, HALF>(F.app, X, P, lane, nlive);
+        wave_lds_sync();
+        pair_basis<0>(acc, F.basisH, X + s, h, lane, amax);
+        wave_lds_sync();
+        gather_pair<1, HALF>(F.app, X, P, lane, nlive);
+        wave_lds_sync();
+        pair_basis<1>(acc, F.basisH, X + s, h, lane, amax);
+        wave_lds_sync();
+        gather_pair<2, HALF>(F.app, X, P, lane, nlive);
+        wave_lds_sync();
+        pair_basis<2>(acc, F.basisH, X + s, h, lane, amax);
+        const f32x16 accb = acc * kWUnscale;
+        // lane (s, h) register v holds feature (v & 3) + 8 (v >> 2) + 4 h: four float4 stores per lane. Column 27 (a zero of the
+        // padded basis) carries the entry's compositing weight to the head, which hands it on in app_rgb.w
+        float* __restrict__ row = a.ctx.feat32 + ((size_t)tile * 32 + s) * 32 + 4 * h;
+        const float wgt = (h == 0 && (unsigned)s < nlive) ? P[s].w : 0.f;   // lane (s, 0) holds columns 24..27 in registers 12..15
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(row + 8 * g) = make_float4(accb[4 * g], accb[4 * g + 1], accb[4 * g + 2], (g == 3 && h == 0) ? wgt : accb[4 * g + 3]);
+        wave_lds_sync();   // X and P reads done before the next tile overwrites them
+    }
+    if (a.range_flag && __any(!(amax <= 60000.f)) && lane == 0) atomicOr(a.range_flag, 1u);
+}
+
 // ---- block-cooperative variant (default render path, split-f16 MLP head) ---------------------------------------------
 // k_shade streams every weight chunk from L2 once per wave: 292 KB per 32-sample tile, ~39 GB per 800x800 frame, which is
 // the cache fabric's whole budget for the kernel. Here the four waves of a block walk their four tiles in lockstep and
@@ -1260,8 +1443,17 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
         fa.ctx_rows = ws_tiles * 32u; fa.tile_hi = ws_tiles;
         fa.range_flag = flag; fa.split_unsafe = f->split_unsafe;
         timing_begin(f, T2N_K_APPFEAT, s);
-        if (half) hipLaunchKernelGGL(k_app_features<true>, grid, dim3(256), lds, s, fa);
-        else hipLaunchKernelGGL(k_app_features<false>, grid, dim3(256), lds, s, fa);
+        static const bool whole = getenv("T2N_APPFEAT_WHOLE") != nullptr;   // A/B switch: the 144-row kernel (two waves per SIMD)
+        if (whole) {
+            if (half) hipLaunchKernelGGL(k_app_features<true>, grid, dim3(256), lds, s, fa);
+            else hipLaunchKernelGGL(k_app_features<false>, grid, dim3(256), lds, s, fa);
+        } else {
+            const size_t lds_p = (size_t)4 * kPairFloats * sizeof(float);
+            const unsigned long long wg = ((unsigned long long)ws_tiles + 3u) / 4u;
+            const dim3 grid_p((unsigned)(wg < 1024u ? (wg ? wg : 1u) : 1024u));   // four workgroups (16 waves) per CU
+            if (half) hipLaunchKernelGGL(k_app_features_p<true>, grid_p, dim3(256), lds_p, s, fa);
+            else hipLaunchKernelGGL(k_app_features_p<false>, grid_p, dim3(256), lds_p, s, fa);
+        }
         timing_end(f, T2N_K_APPFEAT, s);
         timing_begin(f, T2N_K_SHADE, s);
         const int rc = launch_mlp_ss(f, feat, counters_dev, list_cap, ws_tiles, app_rgb, flag, s);
