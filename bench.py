@@ -211,8 +211,15 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_ste
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    trace = [] if os.environ.get("T2N_TRAIN_TRACE") else None   # per-iteration wall times (drains the stream every iteration)
     for k in range(iters):
         loss = it(warmup + k)
+        if trace is not None:
+            if os.environ.get("T2N_TRAIN_TRACE") != "host":   # "host": host-side timestamps only, no drain
+                torch.cuda.synchronize()
+            trace.append(round((time.perf_counter() - t0) * 1e3, 2))
+    if trace is not None:
+        print("[bench] train iteration end times (ms):", trace, file=sys.stderr, flush=True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
