@@ -247,8 +247,8 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_ste
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scene", default="S1-soft")
     ap.add_argument("--weights", type=int, default=0, help="1: also materialise weights/z_vals [R,N] like the reference")
     ap.add_argument("--factor-storage", default="fp32", choices=["fp32", "bf16"],

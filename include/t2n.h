@@ -357,7 +357,8 @@ int t2n_depth_align_global(const float* depth_rendered, const float* depth_est, 
 
 /* ---- measurement hooks (bench.py): when enabled, each kernel launch of the render call is bracketed by HIP events on
  * the launch stream. t2n_timing_read synchronises those events and returns accumulated milliseconds and launch counts
- * per kernel since the last reset. Kernel ids: */
+ * per kernel since the last reset (up to 1024 launches per kernel are timed between two reads; launches beyond that are counted and
+ * priced at the timed average). Kernel ids: */
 enum { T2N_K_MARCH = 0, T2N_K_SHADE = 1, T2N_K_COMPOSITE = 2, T2N_K_UPLOAD = 3, T2N_K_BWD_MARCH = 4, T2N_K_BWD_MLP = 5,
        T2N_K_BWD_SCATTER = 6, T2N_K_DENSITY = 7, T2N_K_APPFEAT = 8 /* appearance gather + basis_mat */, T2N_K_COUNT = 9 };
 int t2n_timing_enable(t2n_field* f, int on);

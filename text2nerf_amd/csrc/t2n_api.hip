@@ -23,7 +23,7 @@ int hip_fail(hipError_t e, const char* what) {
 void timing_begin(t2n_field* f, int k, hipStream_t s) {
     if (!f->timing) return;
     TimingSlot& t = f->slots[k];
-    if (t.used >= 64) return;
+    if (t.used >= kTimingEvents) return;
     if (!t.start[t.used]) {
         (void)hipEventCreate(&t.start[t.used]);
         (void)hipEventCreate(&t.stop[t.used]);
@@ -33,7 +33,7 @@ void timing_begin(t2n_field* f, int k, hipStream_t s) {
 void timing_end(t2n_field* f, int k, hipStream_t s) {
     if (!f->timing) return;
     TimingSlot& t = f->slots[k];
-    if (t.used >= 64) return;
+    if (t.used >= kTimingEvents) { t.untimed++; return; }
     (void)hipEventRecord(t.stop[t.used], s);
     t.used++;
 }
@@ -41,12 +41,16 @@ void timing_end(t2n_field* f, int k, hipStream_t s) {
 static void timing_flush(t2n_field* f) {
     for (int k = 0; k < T2N_K_COUNT; ++k) {
         TimingSlot& t = f->slots[k];
+        double sum = 0.0;
+        int n = 0;
         for (int i = 0; i < t.used; ++i) {
             (void)hipEventSynchronize(t.stop[i]);
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, t.start[i], t.stop[i]) == hipSuccess) { t.ms += ms; t.launches++; }
+            if (hipEventElapsedTime(&ms, t.start[i], t.stop[i]) == hipSuccess) { sum += ms; n++; }
         }
-        t.used = 0;
+        t.ms += sum; t.launches += n;
+        if (n && t.untimed) { t.ms += sum / n * (double)t.untimed; t.launches += t.untimed; }   // beyond the event pool: the timed average
+        t.used = 0; t.untimed = 0;
     }
 }
 
@@ -431,7 +435,7 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->ev_counts) (void)hipEventDestroy((hipEvent_t)f->ev_counts);
     if (f->buf_alpha) (void)hipFree(f->buf_alpha);
     for (int k = 0; k < T2N_K_COUNT; ++k)
-        for (int i = 0; i < 64; ++i) {
+        for (int i = 0; i < kTimingEvents; ++i) {
             if (f->slots[k].start[i]) (void)hipEventDestroy(f->slots[k].start[i]);
             if (f->slots[k].stop[i]) (void)hipEventDestroy(f->slots[k].stop[i]);
         }

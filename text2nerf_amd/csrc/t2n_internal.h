@@ -50,9 +50,11 @@ struct FieldDev {
     const float* ztab;
 };
 
+constexpr int kTimingEvents = 1024;   // timed launches per kernel between two reads; launches beyond are counted and priced at the timed average
 struct TimingSlot {
-    hipEvent_t start[64], stop[64];
+    hipEvent_t start[kTimingEvents], stop[kTimingEvents];
     int used = 0;
+    int64_t untimed = 0;
     double ms = 0.0;
     int64_t launches = 0;
 };
