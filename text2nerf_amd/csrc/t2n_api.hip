@@ -689,7 +689,7 @@ retry_worst_case:
             } else if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, nullptr, s, false,
                                                0xffffffffu, keep ? nullptr : L.feat, L.feat_rows, stats))) return rc;
         }
-        if ((rc = launch_composite(f, L, s))) return rc;
+        if ((rc = tiles ? launch_composite(f, L, s, f->frame_w, (int)(cnt / f->frame_w)) : launch_composite(f, L, s))) return rc;
     }
     if (budget) {
         // the appearance and compositing kernels are queued behind the march; the host only waits for the march itself

@@ -192,7 +192,7 @@ int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, 
 // forward-workspace carve shared by forward and backward (t2n_api.hip)
 struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, feat, total; unsigned list_cap, feat_rows; };
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat = true, unsigned budget = 0);   // budget: appearance entries per ray (0: worst case)   // ctx: also room for sigma [rays,N] and rgb_raw [rays]; feat: feature rows (last region: the other offsets do not depend on it; KEEP_CTX calls carve without)
-int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s);
+int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s, int img_w = 0, int img_h = 0);
 int ctx_counts_post(const void* ws, const unsigned* counters_dev, hipStream_t s);   // KEEP_CTX forward: counts -> pinned host copy + event (t2n_backward.hip)
 // Activation rows the forward keeps for the backward when the KEEP_CTX workspace is larger than the context itself (the
 // caller's guess of the appearance-row count; 1728 B per row): x144 [rows,144], feat32 [rows,32], h0 / h1 [rows,128] behind

@@ -247,15 +247,36 @@ struct CompositeArgs {
     long long n_rays; const int4* ray_app; const float4* app_pos; const float4* app_rgb; const float* acc; float* rgb;
     float4* rgb_raw;   // pre-clamp colour kept for the backward pass, or NULL
     int add_bg;
+    int img_w, img_h;   // > 0: the sub-launch is whole rows of an image and its lists were written by the tile marcher
 };
+// One thread per ray. After the tile marcher the 64 rays of an 8x8-pixel tile own ONE contiguous region of the list (their slices
+// back to back), so a wave takes a tile (lane -> pixel as in k_march_tiles): its reads stay inside that region and every line is
+// fetched once. (Row-major waves cut across eight tiles' regions: the same lines were fetched by eight waves, 312 MB of HBM
+// traffic per C2 frame for 94 MB of entries and outputs.)
 __global__ __launch_bounds__(256) void k_composite(const CompositeArgs a) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.img_w > 0) {
+        const int lane = threadIdx.x & 63;
+        const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        const int tiles_x = (a.img_w + 7) >> 3;
+        const int ty = (int)(tile / tiles_x), tx = (int)(tile - (long long)ty * tiles_x);
+        const int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
+        if (px >= a.img_w || py >= a.img_h) return;
+        r = (long long)py * a.img_w + px;
+    }
     if (r >= a.n_rays) return;
     const int4 ra = a.ray_app[r];
     float cr = 0.f, cg = 0.f, cb = 0.f;
-    for (int k = 0; k < ra.y; ++k) {
-        const float4 c = a.app_rgb[ra.x + k];   // (r, g, b, w): the shading kernels copy the entry's weight next to its colour
-        cr = fmaf(c.w, c.x, cr); cg = fmaf(c.w, c.y, cg); cb = fmaf(c.w, c.z, cb);
+    // (r, g, b, w) entries: the shading kernels copy the entry's weight next to its colour. Eight loads in flight per trip (a wave
+    // runs as long as its longest slice: one dependent round trip per entry was most of the kernel's 57 us); the sum keeps the
+    // entries' order
+    for (int k = 0; k < ra.y; k += 8) {
+        float4 c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = a.app_rgb[ra.x + min(k + j, ra.y - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k + j < ra.y) { cr = fmaf(c[j].w, c[j].x, cr); cg = fmaf(c[j].w, c[j].y, cg); cb = fmaf(c[j].w, c[j].z, cb); }
     }
     if (a.add_bg) {
         const float bg = 1.f - a.acc[r];
@@ -412,12 +433,15 @@ int launch_ray_stats(const RenderLaunch& L, hipStream_t s) {
     return T2N_OK;
 }
 
-int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
+int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s, int img_w, int img_h) {
     CompositeArgs c;
     c.n_rays = L.n_rays; c.ray_app = L.ray_app; c.app_pos = L.app_pos; c.app_rgb = L.app_rgb; c.acc = L.acc; c.rgb = L.rgb; c.rgb_raw = L.rgb_raw;
     c.add_bg = (L.flags & T2N_FLAG_ADD_BG) ? 1 : 0;
+    c.img_w = img_w; c.img_h = img_h;
+    long long blocks = (L.n_rays + 255) / 256;
+    if (img_w > 0) blocks = ((long long)((img_w + 7) >> 3) * ((img_h + 7) >> 3) + 3) / 4;   // four 8x8 tiles per workgroup
     timing_begin(f, T2N_K_COMPOSITE, s);
-    hipLaunchKernelGGL(k_composite, dim3((unsigned)((L.n_rays + 255) / 256)), dim3(256), 0, s, c);
+    hipLaunchKernelGGL(k_composite, dim3((unsigned)blocks), dim3(256), 0, s, c);
     timing_end(f, T2N_K_COMPOSITE, s);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
