@@ -389,11 +389,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? 4 :
             a.ray_app[r] = make_int4(ovf_from, (int)napp, nev, Lw > 0 ? (first | (Lw << 11)) : 0);   // k_compact_list finishes this ray
         } else {
             a.ray_app[r] = make_int4((int)slot0, fits ? (int)n : 0, nev, Lw > 0 ? (first | (Lw << 11)) : 0);
-            if (fits)
-                for (unsigned k = 0; k < n; ++k) {
-                    a.app_pos[slot0 + k] = a.scratch[(size_t)r * a.cap + k];
-                    a.app_ray[slot0 + k] = (int)r;
+            if (fits) {
+                // four entries in flight per trip (a wave's tail lasts as long as its longest slice; one dependent round trip
+                // per entry otherwise)
+                const float4* __restrict__ src = a.scratch + (size_t)r * a.cap;
+                for (unsigned k = 0; k < n; k += 4) {
+                    const float4 e0 = src[k], e1 = src[k + 1 < n ? k + 1 : n - 1], e2 = src[k + 2 < n ? k + 2 : n - 1],
+                                 e3 = src[k + 3 < n ? k + 3 : n - 1];
+                    a.app_pos[slot0 + k] = e0; a.app_ray[slot0 + k] = (int)r;
+                    if (k + 1 < n) { a.app_pos[slot0 + k + 1] = e1; a.app_ray[slot0 + k + 1] = (int)r; }
+                    if (k + 2 < n) { a.app_pos[slot0 + k + 2] = e2; a.app_ray[slot0 + k + 2] = (int)r; }
+                    if (k + 3 < n) { a.app_pos[slot0 + k + 3] = e3; a.app_ray[slot0 + k + 3] = (int)r; }
                 }
+            }
         }
     }
 }
