@@ -10,6 +10,6 @@ tail -3 $out/smoke.log
 tail -c 7000 $out/bench.json
 tail -5 $out/bench.err
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python3 bench.py --steps 20 --no-cpu-baseline --quick > $out/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --quick > $out/prof.log 2>&1
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1); cp $f $out/kernel_stats.csv; python3 tools/kstats.py $f 23 > $out/kernel_stats.txt 2>&1
 head -40 $out/kernel_stats.txt
