@@ -204,3 +204,24 @@ def test_explicit_point_shade_range_guard(tiny_params):
         fscale = float(o_feat.abs().max()) + 1e-12
         assert float((feat.cpu() - o_feat).abs().max()) <= 2e-5 * fscale
         assert float((rgb.cpu() - o_rgb).abs().max()) <= RGB_ATOL
+
+
+@pytest.mark.parametrize("switch", ["T2N_APPFEAT_WHOLE", "T2N_SHADE_NO_WS", "T2N_SHADE_NO_COOP"])
+def test_alternative_appearance_paths_stay_correct(switch):
+    """The A/B forms of the appearance stage — the 144-row feature kernel, the one-kernel cooperative path (also the production path
+    of tiles beyond the feature-row capacity), the per-wave weight stream — against the same oracle comparisons: this file's range
+    stresses and the appearance / frame goldens, in a subprocess (the switches are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import pytest\n"
+            "sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', '-k', "
+            "'not alternative_appearance_paths and (scaled_fields or weight_beyond or outside_f16 or g5_appearance or g6_forward_eval)', "
+            "%r, %r]))\n") % (root, os.path.join(root, "tests", "test_hip_range.py"), os.path.join(root, "tests", "test_hip_parity.py"))
+    env = dict(os.environ)
+    env[switch] = "1"
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:]
