@@ -785,17 +785,12 @@ __device__ __forceinline__ void gather_pair(const FactorSet& S, float* __restric
     }
 }
 
-// basis chunks 3K .. 3K+2 (16 K-values each) of f16_stream's operand layout, from X[48][kXld]
+// basis chunks 3K .. 3K+2 (16 K-values each) of f16_stream's operand layout, from X[48][kXld]; the A operands (basis_mat as hi / lo f16
+// halves, 18 KB) sit in the workgroup's LDS: streamed from L1 they were 18 of a tile's 137 load instructions, on a kernel that is bound
+// by the L1's 64 B/clk
 template <int K>
-__device__ __forceinline__ void pair_basis(f32x16& acc, const uint4* __restrict__ basisH, const float* __restrict__ Xs, int h, int lane, float& amax) {
-    // the operand offset is made opaque here: the loads are loop-invariant, and hipcc otherwise keeps all 72 operand registers
-    // of the three pairs live across the tile loop
-    unsigned off = (unsigned)lane + (unsigned)(3 * K) * 2u * 64u;
-    asm volatile("" : "+v"(off));
-    const uint4* __restrict__ ap = basisH + off;
-    uint4 A[3][2];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { A[c][0] = ap[(c * 2) * 64]; A[c][1] = ap[(c * 2 + 1) * 64]; }
+__device__ __forceinline__ void pair_basis(f32x16& acc, const uint4* __restrict__ Wl, const float* __restrict__ Xs, int h, int lane, float& amax) {
+    const uint4* __restrict__ ap = Wl + lane + (3 * K) * 2 * 64;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float x[8];
@@ -804,7 +799,7 @@ __device__ __forceinline__ void pair_basis(f32x16& acc, const uint4* __restrict_
         for (int e = 0; e < 8; ++e) x[e] = p[e * kXld];
         h8 bhi, blo;
         split8(x, bhi, blo, amax);
-        const h8 ahi = __builtin_bit_cast(h8, A[c][0]), alo = __builtin_bit_cast(h8, A[c][1]);
+        const h8 ahi = __builtin_bit_cast(h8, ap[(c * 2) * 64]), alo = __builtin_bit_cast(h8, ap[(c * 2 + 1) * 64]);
         acc = mfma16(ahi, bhi, acc);
         acc = mfma16(ahi, blo, acc);
         acc = mfma16(alo, bhi, acc);
@@ -812,14 +807,20 @@ __device__ __forceinline__ void pair_basis(f32x16& acc, const uint4* __restrict_
     }
 }
 
+constexpr int kPairWaves = 8;                               // waves per workgroup (one copy of the basis operands per workgroup)
+constexpr int kPairBasisVec = kBasisChunksReal * 2 * 64;    // uint4 elements of the nine real chunks
+
 template <bool HALF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_app_features_p(const ShadeArgs a) {
+__global__ __launch_bounds__(64 * kPairWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_app_features_p(const ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int s = lane & 31, h = lane >> 5;
-    float* __restrict__ X = smem + (size_t)wid * kPairFloats;
+    uint4* __restrict__ Wl = reinterpret_cast<uint4*>(smem);
+    float* __restrict__ X = smem + kPairBasisVec * 4 + (size_t)wid * kPairFloats;
     float4* __restrict__ P = reinterpret_cast<float4*>(X + kPairRows * kXld);
     const FieldDev& F = a.F;
+    for (int i = threadIdx.x; i < kPairBasisVec; i += 64 * kPairWaves) Wl[i] = F.basisH[i];
+    __syncthreads();   // the only workgroup barrier: from here on the waves run on their own
     unsigned cnt_l = 0;
     if (lane < a.nlists) {
         cnt_l = a.counters[lane * kCounterStride];
@@ -837,7 +838,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (a.range_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.range_flag, 1u);
         return;
     }
-    const unsigned wave_stride = gridDim.x * 4u;
+    const unsigned wave_stride = gridDim.x * (unsigned)kPairWaves;
     float amax = 0.f;
     // tile -> (first entry, live entries) and the lane's position entry (lanes 0..31; dead entries sit at the volume centre and
     // store zeros); the next tile's positions are fetched while this tile is processed
@@ -855,23 +856,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     };
     unsigned base, nlive, nbase, nnlive;
     float4 mine, nmine;
-    locate(blockIdx.x * 4u + wid, base, nlive, mine);
-    for (unsigned tile = blockIdx.x * 4u + wid; tile < ntiles; tile += wave_stride, base = nbase, nlive = nnlive, mine = nmine) {
+    locate(blockIdx.x * (unsigned)kPairWaves + wid, base, nlive, mine);
+    for (unsigned tile = blockIdx.x * (unsigned)kPairWaves + wid; tile < ntiles; tile += wave_stride, base = nbase, nlive = nnlive, mine = nmine) {
         if (lane < 32) P[lane] = mine;
         locate(tile + wave_stride, nbase, nnlive, nmine);
         wave_lds_sync();
         f32x16 acc = {0};
         gather_pair<0, HALF>(F.app, X, P, lane, nlive);
         wave_lds_sync();
-        pair_basis<0>(acc, F.basisH, X + s, h, lane, amax);
+        pair_basis<0>(acc, Wl, X + s, h, lane, amax);
         wave_lds_sync();
         gather_pair<1, HALF>(F.app, X, P, lane, nlive);
         wave_lds_sync();
-        pair_basis<1>(acc, F.basisH, X + s, h, lane, amax);
+        pair_basis<1>(acc, Wl, X + s, h, lane, amax);
         wave_lds_sync();
         gather_pair<2, HALF>(F.app, X, P, lane, nlive);
         wave_lds_sync();
-        pair_basis<2>(acc, F.basisH, X + s, h, lane, amax);
+        pair_basis<2>(acc, Wl, X + s, h, lane, amax);
         const f32x16 accb = acc * kWUnscale;
         // lane (s, h) register v holds feature (v & 3) + 8 (v >> 2) + 4 h: four float4 stores per lane. Column 27 (a zero of the
         // padded basis) carries the entry's compositing weight to the head, which hands it on in app_rgb.w
@@ -1448,11 +1449,17 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
             if (half) hipLaunchKernelGGL(k_app_features<true>, grid, dim3(256), lds, s, fa);
             else hipLaunchKernelGGL(k_app_features<false>, grid, dim3(256), lds, s, fa);
         } else {
-            const size_t lds_p = (size_t)4 * kPairFloats * sizeof(float);
-            const unsigned long long wg = ((unsigned long long)ws_tiles + 3u) / 4u;
-            const dim3 grid_p((unsigned)(wg < 1024u ? (wg ? wg : 1u) : 1024u));   // four workgroups (16 waves) per CU
-            if (half) hipLaunchKernelGGL(k_app_features_p<true>, grid_p, dim3(256), lds_p, s, fa);
-            else hipLaunchKernelGGL(k_app_features_p<false>, grid_p, dim3(256), lds_p, s, fa);
+            const size_t lds_p = (size_t)kPairBasisVec * 16 + (size_t)kPairWaves * kPairFloats * sizeof(float);
+            static bool attr_p = false;
+            if (!attr_p) {
+                T2N_HIP(hipFuncSetAttribute((const void*)k_app_features_p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+                T2N_HIP(hipFuncSetAttribute((const void*)k_app_features_p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+                attr_p = true;
+            }
+            const unsigned long long wg = ((unsigned long long)ws_tiles + kPairWaves - 1) / kPairWaves;
+            const dim3 grid_p((unsigned)(wg < 512u ? (wg ? wg : 1u) : 512u));   // two workgroups (16 waves) per CU
+            if (half) hipLaunchKernelGGL(k_app_features_p<true>, grid_p, dim3(64 * kPairWaves), lds_p, s, fa);
+            else hipLaunchKernelGGL(k_app_features_p<false>, grid_p, dim3(64 * kPairWaves), lds_p, s, fa);
         }
         timing_end(f, T2N_K_APPFEAT, s);
         timing_begin(f, T2N_K_SHADE, s);
