@@ -15,7 +15,8 @@
 // (models/tensorBase.py:23) — so no wave scan is needed; acc/depth accumulate in registers.
 //
 // Outputs per ray: acc, depth, (slot0, n_app, n_valid, first | Lw << 11) and the ray's contiguous, sample-ordered slice of
-// the appearance list (in-kernel compaction, see TileArgs); with weights / z_vals requested (DENSE) also their whole rows.
+// the appearance list (in-kernel compaction, see TileArgs); with weights requested (DENSE) also the weights of the wave's sampled
+// window (k_dense_fill writes the z_vals rows and the zeros of the weights rows beforehand).
 // Steps whose rectangles do not fit the table (incoherent rays, huge field of view) fall back to direct gathers.
 // Replaces the same reference lines as k_march (see t2n_march.hip).
 #include "t2n_device.h"
@@ -41,9 +42,10 @@ struct TileArgs {
     float* wbuf;        // [n_rays, n_samples] spill rows
     float4* scratch; int cap; unsigned* ovf_count; int* ovf_list;
     float4* app_pos; int* app_ray; unsigned* counters; unsigned list_cap; unsigned long long* stats;
-    // DENSE: the caller's [n_rays, n_samples] weights / z_vals tensors (either may be NULL), written as whole rows — zeros
-    // outside the sampled window — through a per-wave LDS transpose: 16 steps x 64 rays, then 64-B row segments per store
-    float* dense_w; float* dense_z;
+    // DENSE: the caller's [n_rays, n_samples] weights tensor. k_dense_fill has written zeros (and the z_vals rows) before this kernel;
+    // the marcher writes the weights of the 16-step blocks its wave's window touches, through a per-wave LDS transpose: 16 steps x
+    // 64 rays, then 64-B row segments per store
+    float* dense_w;
 };
 
 __device__ __forceinline__ void lds_fence_w() {
@@ -177,24 +179,26 @@ __device__ __forceinline__ float pair_dot_global(const FactorSet& S, const Axes3
 }
 
 constexpr int kDenseLd = 20;                          // floats per ray row of the transpose tile (16 steps + pad, 16-B aligned)
-constexpr int kDenseFloats = 2 * 64 * kDenseLd;       // per wave: weights tile + z tile
+constexpr int kDenseFloats = 64 * kDenseLd;           // per wave: the weights tile
 struct __attribute__((aligned(4))) F4U { float x, y, z, w; };   // row segments of an [n_rays, N] tensor are only 4-B aligned for odd N
 
 // Waves per SIMD the register allocation targets. The step loop is a load -> MFMA -> LDS -> read chain that only other waves
 // hide: 3 waves 0.95 ms, 4 waves (109 VGPRs) 0.78, 5 waves (96 VGPRs; ten loop-invariant dwords go to scratch and come back
-// only where an appearance entry is stored) 0.74, 6 waves (80 VGPRs, 104 B of scratch in the loop) 0.86. The DENSE variant
-// spills inside its transpose flush at 5 (2.82 ms against 2.24) and stays at 4.
+// only where an appearance entry is stored) 0.74, 6 waves (80 VGPRs, 104 B of scratch in the loop) 0.86. The weights-writing
+// variant (121 VGPRs) spills inside its loop at 5 (1.46 ms against 1.37 for fill + march) and stays at 4.
 #ifndef T2N_MT_WAVES
 #define T2N_MT_WAVES 5
 #endif
+#ifndef T2N_MTD_WAVES
+#define T2N_MTD_WAVES 4
+#endif
 template <bool DENSE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? 4 : T2N_MT_WAVES, DENSE ? 4 : T2N_MT_WAVES))) void k_march_tiles(const TileArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N_MTD_WAVES : T2N_MT_WAVES, DENSE ? T2N_MTD_WAVES : T2N_MT_WAVES))) void k_march_tiles(const TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     float* __restrict__ stD = smem + (size_t)wid * kStageFloats;
     float* __restrict__ wt = smem + 4 * kStageFloats + (size_t)wid * kDenseFloats;   // DENSE only
-    float* __restrict__ zt = wt + 64 * kDenseLd;
     const FieldDev& F = a.F;
     const int tiles_x = (a.img_w + 7) >> 3;
     const long long tile = (long long)blockIdx.x * 4 + wid;
@@ -231,7 +235,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? 4 :
     // steps spans 3-4 taps per axis on every pair of a pinhole frame), so the reduction, the six operand loads, the twelve
     // MFMAs and the load -> MFMA -> LDS latency chain are paid once per pair.
     constexpr int kSteps = 2;
-    const int i_begin = DENSE ? 0 : wlo, i_end = DENSE ? N - 1 : whi;
+    // DENSE: whole 16-step blocks of the weights rows (a wave without samples runs no step: wlo = N, whi = -1)
+    const int i_begin = DENSE ? (wlo & ~15) : wlo, i_end = DENSE ? min(N - 1, whi | 15) : whi;
     for (int i = i_begin; i <= i_end; i += kSteps) {
         float xn[kSteps], yn[kSteps], zn[kSteps], z[kSteps], w_out[kSteps];
         bool ok[kSteps];
@@ -246,8 +251,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? 4 :
                 z[q] = sample_z<false>(F, ray, idx, 0.f);
                 ok[q] = sample_point<false>(F, ray, z[q], xn[q], yn[q], zn[q]);
                 if (F.alpha && ok[q]) ok[q] = alpha_pass(F, ray, z[q]);      // models/tensorBase.py:451-456
-            } else if (DENSE && a.dense_z && idx < N) {
-                z[q] = sample_z<false>(F, ray, idx, 0.f);
             }
             any_ok |= ok[q];
         }
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? 4 :
 #pragma unroll
         for (int q = 0; q < kSteps; ++q) {
             const int idx = i + q;
-            const bool spill = have && idx <= i_end && napp >= (unsigned)a.cap && !(DENSE && a.dense_w);
+            const bool spill = have && idx <= i_end && napp >= (unsigned)a.cap && !DENSE;
             if (ok[q]) {
                 const float sg = feature2density(F, part[q]);
                 const float dist = idx < N - 1 ? sample_z<false>(F, ray, idx + 1, 0.f) - z[q] : 0.f;     // :448
@@ -330,7 +333,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? 4 :
                 if (idx < N) {
                     const int c16 = idx & 15;
                     wt[lane * kDenseLd + c16] = w_out[q];
-                    zt[lane * kDenseLd + c16] = z[q];
                 }
                 if ((idx < N && (idx & 15) == 15) || idx == N - 1) {
                     lds_fence_w();
@@ -340,18 +342,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? 4 :
                         if (frow[j] < 0 || col >= N) continue;
                         const int rho = (lane >> 2) + 16 * j;
                         const float4 vw = *reinterpret_cast<const float4*>(wt + rho * kDenseLd + 4 * (lane & 3));
-                        const float4 vz = *reinterpret_cast<const float4*>(zt + rho * kDenseLd + 4 * (lane & 3));
                         if (col + 3 < N) {
-                            if (a.dense_w) *reinterpret_cast<F4U*>(a.dense_w + frow[j] + col) = F4U{vw.x, vw.y, vw.z, vw.w};
-                            if (a.dense_z) *reinterpret_cast<F4U*>(a.dense_z + frow[j] + col) = F4U{vz.x, vz.y, vz.z, vz.w};
+                            *reinterpret_cast<F4U*>(a.dense_w + frow[j] + col) = F4U{vw.x, vw.y, vw.z, vw.w};
                         } else {
-                            const float ew[4] = {vw.x, vw.y, vw.z, vw.w}, ez[4] = {vz.x, vz.y, vz.z, vz.w};
+                            const float ew[4] = {vw.x, vw.y, vw.z, vw.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                if (col + e < N) {
-                                    if (a.dense_w) a.dense_w[frow[j] + col + e] = ew[e];
-                                    if (a.dense_z) a.dense_z[frow[j] + col + e] = ez[e];
-                                }
+                                if (col + e < N) a.dense_w[frow[j] + col + e] = ew[e];
                         }
                     }
                     lds_fence_w();
@@ -481,11 +478,27 @@ __global__ __launch_bounds__(256) void k_compact_list(const CompactArgs a, const
     for (unsigned k = blockIdx.x * 4u + (threadIdx.x >> 6); k < n; k += gridDim.x * 4u) compact_ray_staged(a, ovf_list[k], blockIdx.x & 7u, lane);
 }
 
+// z_vals rows (z_i of every sample index, models/tensorBase.py:313-318) and zeroed weights rows of a launch's rays: one wave per
+// ray, 256-B coalesced stores (2 x 1.33 GB per C2 frame at the HBM write rate). The tile marcher then writes the weights of the
+// sampled windows only.
+__global__ __launch_bounds__(256) void k_dense_fill(const FieldDev F, const float* __restrict__ rays, long long n_rays, int ray_stride, int N,
+                                                    float* __restrict__ w, float* __restrict__ z) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rays) return;
+    Ray ray;
+    if (z) ray = load_ray(F, rays + r * ray_stride, ray_stride);
+    for (int i = lane; i < N; i += 64) {
+        if (z) z[r * N + i] = sample_z<false>(F, ray, i, 0.f);
+        if (w) w[r * N + i] = 0.f;
+    }
+}
+
 int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h, float* spill, float4* scratch, hipStream_t s) {
     const int cap = L.n_samples / 4 > 0 ? L.n_samples / 4 : 1;
     unsigned* ovf_count = (unsigned*)((char*)scratch + (size_t)L.n_rays * cap * 16);
     int* ovf_list = (int*)((char*)ovf_count + 256);
-    const bool dense = L.weights || L.z_vals;
+    const bool dense = L.weights != nullptr;
     TileArgs a;
     a.F = f->dev;
     a.rays = L.rays; a.n_rays = L.n_rays; a.ray_stride = L.ray_stride; a.n_samples = L.n_samples; a.img_w = img_w; a.img_h = img_h;
@@ -493,11 +506,14 @@ int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h
     a.wbuf = L.weights ? L.weights : spill;
     a.scratch = scratch; a.cap = cap; a.ovf_count = ovf_count; a.ovf_list = ovf_list;
     a.app_pos = L.app_pos; a.app_ray = L.app_ray; a.counters = L.counters; a.list_cap = L.list_cap; a.stats = (unsigned long long*)L.stats;
-    a.dense_w = L.weights; a.dense_z = L.z_vals;
+    a.dense_w = L.weights;
     T2N_HIP(hipMemsetAsync(ovf_count, 0, 4, s));
     const long long tiles = (long long)((img_w + 7) / 8) * ((img_h + 7) / 8);
     const dim3 grid((unsigned)((tiles + 3) / 4));
     timing_begin(f, T2N_K_MARCH, s);
+    if (L.weights || L.z_vals)
+        hipLaunchKernelGGL(k_dense_fill, dim3((unsigned)((L.n_rays + 3) / 4)), dim3(256), 0, s, f->dev, L.rays, (long long)L.n_rays, L.ray_stride,
+                           L.n_samples, L.weights, L.z_vals);
     if (dense) hipLaunchKernelGGL(k_march_tiles<true>, grid, dim3(256), (size_t)4 * (kStageFloats + kDenseFloats) * sizeof(float), s, a);
     else hipLaunchKernelGGL(k_march_tiles<false>, grid, dim3(256), (size_t)4 * kStageFloats * sizeof(float), s, a);
     T2N_HIP(hipGetLastError());
