@@ -537,8 +537,8 @@ def main():
             out["config"]["sustained_ms_per_step"] = timed_frames(n_sus)
             out["config"]["sustained_frames"] = n_sus
             if args.factor_storage == "fp32":
-                # bf16 factor storage (configs[4] mode): halves the field's footprint; NOT faster (the gathers are addresser / VALU
-                # bound) and not the headline value: it renders the ROUNDED field
+                # bf16 factor storage (configs[4] mode): half the appearance gather's instructions and bytes (the feature kernel is L1-bound,
+                # DESIGN.md); not the headline value: it renders the ROUNDED field
                 field.factor_storage = "bf16"
                 out["config"]["bf16_factor_storage_ms_per_step"] = timed_frames(args.steps)
                 out["config"]["bf16_factor_storage_note"] = "appearance factors read as bf16 (26 MB instead of 52 MB), taps fetched as 16-B octets of 8 channels: half the gather instructions; the tile marcher reads the fp32 copy of the rounded density factors (17 MB), the per-ray marcher their bf16 copy"
