@@ -117,6 +117,21 @@ __device__ __forceinline__ Axis axis_taps(float g, int size) {
     return a;
 }
 
+// axis_taps for a coordinate known to lie in [-1, 1] (a sample that passed the box test): ix is in [0, size - 1], so both range
+// guards hold (the high tap's weight is already 0 where it would fail: f0 == size - 1 means ix == size - 1) and the clamps reduce
+// to one min. Same values, six instructions fewer per axis.
+__device__ __forceinline__ Axis axis_taps_inbox(float g, int size) {
+    const float h = (g + 1.f) / 2.f;
+    const float ix = h * (float)(size - 1);
+    const float f0 = floorf(ix);
+    Axis a;
+    a.w1 = ix - f0;
+    a.w0 = 1.f - a.w1;
+    a.i0 = (int)f0;
+    a.i1 = min(a.i0 + 1, size - 1);
+    return a;
+}
+
 // The clamped floor index of axis_taps (same arithmetic): low tap at cell i (weight 0 when i == -1), high tap at i + 1
 // (weight 0 when i == size - 1).
 __device__ __forceinline__ int axis_cell(float g, int size) {
@@ -191,6 +206,13 @@ __device__ __forceinline__ Axes3 sample_axes(const FactorSet& S, float xn, float
     A.a[0] = axis_taps(xn, S.W[0]);   // grid[0] = W of planes 0 and 1, L of line 2
     A.a[1] = axis_taps(yn, S.H[0]);   // grid[1] = H of plane 0, W of plane 2, L of line 1
     A.a[2] = axis_taps(zn, S.H[1]);   // grid[2] = H of planes 1 and 2, L of line 0
+    return A;
+}
+__device__ __forceinline__ Axes3 sample_axes_inbox(const FactorSet& S, float xn, float yn, float zn) {
+    Axes3 A;
+    A.a[0] = axis_taps_inbox(xn, S.W[0]);
+    A.a[1] = axis_taps_inbox(yn, S.H[0]);
+    A.a[2] = axis_taps_inbox(zn, S.H[1]);
     return A;
 }
 // four bf16 channels (8 B, channel 4q in the low half of .x) -> fp32: exact (bf16 is the upper half of an fp32)

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N
         for (int q = 0; q < kSteps; ++q) part[q] = 0.f;
         if (okm) {
 #pragma unroll
-            for (int q = 0; q < kSteps; ++q) A[q] = sample_axes(F.den, xn[q], yn[q], zn[q]);
+            for (int q = 0; q < kSteps; ++q) A[q] = sample_axes_inbox(F.den, xn[q], yn[q], zn[q]);   // used by samples inside the box only (ok[q])
             // the low-tap indices present in the wave, per axis, as ONE or-reduced bit set: 10 bits per axis around the first
             // live lane's index (bit 5); an index outside [-5, +4] of it raises bit 30 (the steps then gather directly)
             int sel0 = 0, sel1 = 0, sel2 = 0;
