@@ -130,6 +130,11 @@ __device__ __forceinline__ void table_build(const FactorSet& S, const int (&amn)
         }
     }
 }
+// A lane's density feature from the tables: per pair ONE table offset (low line row, low plane cell); the other seven entries sit at
+// fixed distances from it, because a high tap is the low tap + 1 wherever its weight is not zero (axis_taps: the clamp at the
+// grid's last texel comes with weight 0). There the entry one step further is read instead of the clamped one - a finite table
+// value (every slot of the 16 line rows is written by each build, the four pad floats of a row are zeroed once per wave) times a
+// zero weight: the sum is the same. 12 address computations and 24 single reads per sample became 3 and 12 paired reads.
 template <int LOG2W>
 __device__ __forceinline__ float table_read(const Axes3& A, const int (&amn)[3], const float* __restrict__ stD) {
     constexpr int WS = 1 << LOG2W, SL = WS * WS, ST = SL + 4;
@@ -140,15 +145,13 @@ __device__ __forceinline__ float table_read(const Axes3& A, const int (&amn)[3],
         const Axis& ax = A.a[m0];
         const Axis& ay = A.a[m1];
         const Axis& al = A.a[vv];
-        const int rx0 = ax.i0 - amn[m0], rx1 = ax.i1 - amn[m0];
-        const int ry0 = (ay.i0 - amn[m1]) << LOG2W, ry1 = (ay.i1 - amn[m1]) << LOG2W;
-        const float* __restrict__ D0 = stD + k * 16 * ST + (al.i0 - amn[vv]) * ST;
-        const float* __restrict__ D1 = stD + k * 16 * ST + (al.i1 - amn[vv]) * ST;
+        const int off = k * 16 * ST + (al.i0 - amn[vv]) * ST + ((ay.i0 - amn[m1]) << LOG2W) + (ax.i0 - amn[m0]);
+        const float* __restrict__ D = stD + off;
         const float wnw = ay.w0 * ax.w0, wne = ay.w0 * ax.w1, wsw = ay.w1 * ax.w0, wse = ay.w1 * ax.w1;
-        float v0 = D0[ry0 + rx0] * wnw, v1 = D1[ry0 + rx0] * wnw;
-        v0 = fmaf(D0[ry0 + rx1], wne, v0); v1 = fmaf(D1[ry0 + rx1], wne, v1);
-        v0 = fmaf(D0[ry1 + rx0], wsw, v0); v1 = fmaf(D1[ry1 + rx0], wsw, v1);
-        v0 = fmaf(D0[ry1 + rx1], wse, v0); v1 = fmaf(D1[ry1 + rx1], wse, v1);
+        float v0 = D[0] * wnw, v1 = D[ST] * wnw;
+        v0 = fmaf(D[1], wne, v0); v1 = fmaf(D[ST + 1], wne, v1);
+        v0 = fmaf(D[WS], wsw, v0); v1 = fmaf(D[ST + WS], wsw, v1);
+        v0 = fmaf(D[WS + 1], wse, v0); v1 = fmaf(D[ST + WS + 1], wse, v1);
         part = fmaf(v0, al.w0, part);
         part = fmaf(v1, al.w1, part);
     }
@@ -198,6 +201,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     float* __restrict__ stD = smem + (size_t)wid * kStageFloats;
+    for (int i = lane; i < kStageFloats; i += 64) stD[i] = 0.f;   // the rows' pad floats stay zero (table_read may touch them with weight 0)
+    lds_fence_w();
     float* __restrict__ wt = smem + 4 * kStageFloats + (size_t)wid * kDenseFloats;   // DENSE only
     const FieldDev& F = a.F;
     const int tiles_x = (a.img_w + 7) >> 3;
