@@ -112,7 +112,7 @@ __device__ __forceinline__ void table_build(const FactorSet& S, const int (&amn)
         for (int mb = 0; mb < NB; ++mb) {
             const int t = mb * 16 + l15;
             const unsigned yy = (unsigned)min(amn[m1] + (t >> LOG2W), gs[m1] - 1), xx = (unsigned)min(amn[m0] + (t & (WS - 1)), gs[m0] - 1);
-            av[k][mb] = P[(yy * (unsigned)gs[m0] + xx) * 4u + (unsigned)lq];
+            av[k][mb] = P[(__umul24(yy, (unsigned)gs[m0]) + xx) * 4u + (unsigned)lq];   // (24-bit multiply: full rate)
         }
     }
     // phase 2: D_k^T[line row][slot] = sum_c L_k[row][c] P_k[slot][c]; the lane holds slots 4 lq..+3 of line row l15
@@ -145,7 +145,8 @@ __device__ __forceinline__ float table_read(const Axes3& A, const int (&amn)[3],
         const Axis& ax = A.a[m0];
         const Axis& ay = A.a[m1];
         const Axis& al = A.a[vv];
-        const int off = k * 16 * ST + (al.i0 - amn[vv]) * ST + ((ay.i0 - amn[m1]) << LOG2W) + (ax.i0 - amn[m0]);
+        // (24-bit multiply: full rate; v_mul_lo_u32 is quarter rate)
+        const int off = k * 16 * ST + (int)__umul24((unsigned)(al.i0 - amn[vv]), (unsigned)ST) + ((ay.i0 - amn[m1]) << LOG2W) + (ax.i0 - amn[m0]);
         const float* __restrict__ D = stD + off;
         const float wnw = ay.w0 * ax.w0, wne = ay.w0 * ax.w1, wsw = ay.w1 * ax.w0, wse = ay.w1 * ax.w1;
         float v0 = D[0] * wnw, v1 = D[ST] * wnw;
