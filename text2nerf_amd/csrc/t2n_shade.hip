@@ -709,7 +709,21 @@ __global__ __launch_bounds__(256, 2) void k_app_features(const ShadeArgs a) {
 // per SIMD. The sample positions are parked in LDS once per tile (the per-pair items re-derive their taps from them). Same
 // per-channel arithmetic, same chunk order, same three products per chunk: the feature rows are bit-identical.
 constexpr int kPairRows = 48;
-constexpr int kPairFloats = kPairRows * kXld + 32 * 4;   // X[48][33] + 32 positions, per wave
+constexpr int kPairFloats = kPairRows * kXld + 32 * 8;   // X[48][33] + 32 x (axis taps, weight), per wave
+
+// The three axis taps of a tile's samples are computed ONCE per tile (lane = sample) and parked in LDS as (low tap index, high tap
+// weight) per axis: the 12 (or 6) lanes that share a sample re-derive the full taps from them in six instructions instead of
+// ~45 each, 18 times per lane and tile (the positions are samples that passed the box test: high tap = min(low + 1, size - 1),
+// low weight = 1 - high weight, exactly what axis_taps computes there).
+__device__ __forceinline__ Axes3 parked_axes(const FactorSet& S, const float4* __restrict__ P, int s_) {
+    const float4 a = P[2 * s_], b = P[2 * s_ + 1];
+    Axes3 A;
+    A.a[0].i0 = __float_as_int(a.x); A.a[1].i0 = __float_as_int(a.y); A.a[2].i0 = __float_as_int(a.z);
+    A.a[0].i1 = min(A.a[0].i0 + 1, S.W[0] - 1); A.a[1].i1 = min(A.a[1].i0 + 1, S.H[0] - 1); A.a[2].i1 = min(A.a[2].i0 + 1, S.H[1] - 1);
+    A.a[0].w1 = b.x; A.a[1].w1 = b.y; A.a[2].w1 = b.z;
+    A.a[0].w0 = 1.f - b.x; A.a[1].w0 = 1.f - b.y; A.a[2].w0 = 1.f - b.z;
+    return A;
+}
 
 template <int K, bool HALF>
 __device__ __forceinline__ void gather_pair(const FactorSet& S, float* __restrict__ X, const float4* __restrict__ P, int lane, unsigned nlive) {
@@ -720,8 +734,7 @@ __device__ __forceinline__ void gather_pair(const FactorSet& S, float* __restric
         auto issue = [&](int it, OctTaps& t, int& s_, int& o_) {
             const int item = it * 64 + lane;
             s_ = item / 6; o_ = item - s_ * 6;
-            const float4 p = P[s_];
-            const Axes3 A = sample_axes(S, p.x, p.y, p.z);
+            const Axes3 A = parked_axes(S, P, s_);
             issue_octets_ax<K>(S, o_, A, t);
         };
         auto consume = [&](const OctTaps& t, int s_, int o_) {
@@ -757,8 +770,7 @@ __device__ __forceinline__ void gather_pair(const FactorSet& S, float* __restric
         auto issue = [&](int it, QuadTaps& t, int& s_, int& q_) {
             const int item = it * 64 + lane;
             s_ = item / 12; q_ = item - s_ * 12;
-            const float4 p = P[s_];
-            const Axes3 A = sample_axes(S, p.x, p.y, p.z);
+            const Axes3 A = parked_axes(S, P, s_);
             issue_taps_ax<K, false>(S, 12, q_, A, t);
         };
         auto consume = [&](const QuadTaps& t, int s_, int q_) {
@@ -858,7 +870,11 @@ __global__ __launch_bounds__(64 * kPairWaves) __attribute__((amdgpu_waves_per_eu
     float4 mine, nmine;
     locate(blockIdx.x * (unsigned)kPairWaves + wid, base, nlive, mine);
     for (unsigned tile = blockIdx.x * (unsigned)kPairWaves + wid; tile < ntiles; tile += wave_stride, base = nbase, nlive = nnlive, mine = nmine) {
-        if (lane < 32) P[lane] = mine;
+        if (lane < 32) {   // (dead entries sit at the volume centre: in the box like every list entry)
+            const Axes3 A = sample_axes_inbox(F.app, mine.x, mine.y, mine.z);
+            P[2 * lane] = make_float4(__int_as_float(A.a[0].i0), __int_as_float(A.a[1].i0), __int_as_float(A.a[2].i0), mine.w);
+            P[2 * lane + 1] = make_float4(A.a[0].w1, A.a[1].w1, A.a[2].w1, 0.f);
+        }
         locate(tile + wave_stride, nbase, nnlive, nmine);
         wave_lds_sync();
         f32x16 acc = {0};
@@ -877,7 +893,7 @@ __global__ __launch_bounds__(64 * kPairWaves) __attribute__((amdgpu_waves_per_eu
         // lane (s, h) register v holds feature (v & 3) + 8 (v >> 2) + 4 h: four float4 stores per lane. Column 27 (a zero of the
         // padded basis) carries the entry's compositing weight to the head, which hands it on in app_rgb.w
         float* __restrict__ row = a.ctx.feat32 + ((size_t)tile * 32 + s) * 32 + 4 * h;
-        const float wgt = (h == 0 && (unsigned)s < nlive) ? P[s].w : 0.f;   // lane (s, 0) holds columns 24..27 in registers 12..15
+        const float wgt = (h == 0 && (unsigned)s < nlive) ? P[2 * s].w : 0.f;   // lane (s, 0) holds columns 24..27 in registers 12..15
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(row + 8 * g) = make_float4(accb[4 * g], accb[4 * g + 1], accb[4 * g + 2], (g == 3 && h == 0) ? wgt : accb[4 * g + 3]);
