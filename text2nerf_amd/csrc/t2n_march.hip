@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
             float part = 0.f;
             if (ok) {
                 QuadTaps t0, t1, t2;
-                const Axes3 A = sample_axes(F.den, xn, yn, zn);
+                const Axes3 A = sample_axes_inbox(F.den, xn, yn, zn);   // ok: the sample passed the box test
                 issue_taps_ax<0, HALF>(F.den, LPS, q, A, t0);
                 issue_taps_ax<1, HALF>(F.den, LPS, q, A, t1);
                 issue_taps_ax<2, HALF>(F.den, LPS, q, A, t2);
