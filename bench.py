@@ -140,6 +140,10 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_ste
     forward/backward, one flat gradient all-reduce (text2nerf_amd.parallel.allreduce_gradients), identical optimiser step."""
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
+    # the loop's CPU work is row gathers of 16 384 rays / targets: half the usable cores leaves the quota headroom for the HIP runtime's
+    # own threads (a process that outruns its cgroup CPU quota is throttled for the rest of a 100-ms period: one such stall inside a
+    # 40-ms timed region turned 1.87 ms per iteration into 2.4)
+    torch.set_num_threads(max(1, min(8, torch.get_num_threads() // 2)))
     from text2nerf_amd import OctreeRender_trilinear_fast, synth, to_device_async
     from text2nerf_amd.losses import TVLoss, TransMittanceLoss_mask
     field, params, aabb = build_field(dev)
@@ -582,9 +586,13 @@ def main():
                                "frac": FLOP_PER_APP * A / t / 1e12 / MFMA_F32_PEAK_TF})
                 out["exact_fp32"] = ex
         if world == 1 and not args.no_train:
+            host_threads = torch.get_num_threads()
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup))
+            torch.set_num_threads(host_threads)
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True))
+            torch.set_num_threads(host_threads)
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True))
+            torch.set_num_threads(host_threads)   # (train_bench runs its loop on half the cores; the CPU baseline below uses all)
         if world == 1 and not args.no_cpu_baseline:
             def hip_render(r):
                 with torch.no_grad():
