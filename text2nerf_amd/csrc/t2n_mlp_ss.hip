@@ -1,5 +1,5 @@
 // Sample-stationary appearance head: positional encoding + the 351 -> 128 -> 128 -> 3 MLP + sigmoid for rows of 27 appearance
-// features (K2b of the default render path). The features come from the gather + basis kernel (k_app_features, K2a).
+// features (K2b of the default render path). The features come from the gather + basis kernel (k_app_features_p in t2n_shade.hip, K2a).
 //
 // Replaces (reference): models/tensorBase.py:11-17 (positional_encoding), :88-109 (MLPRender_Fea_noview.forward).
 //

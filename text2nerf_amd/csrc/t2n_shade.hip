@@ -1449,7 +1449,7 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
     const bool half = f->factor_bf16 && f->dev.app.plane_h[0];
     const unsigned ws_tiles = feat ? feat_rows / 128u * 4u : 0u;
     if (use_ws(f) && !ctx && !features_only && ws_tiles >= 4u) {
-        // default render path: K2a gather + basis -> feature rows (t2n_appfeat.hip), K2b sample-stationary head (t2n_mlp_ss.hip);
+        // default render path: K2a gather + basis -> feature rows (k_app_features_p), K2b sample-stationary head (t2n_mlp_ss.hip);
         // tiles past the row capacity take the one-kernel path; a launch that met a value outside the f16 range is redone on the
         // exact fp32 path
         unsigned* flag = const_cast<unsigned*>(counters_dev) + kRangeFlagWord;
