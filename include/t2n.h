@@ -267,7 +267,10 @@ int t2n_dibr_filter_mask2(float* image, int32_t* known, double* depth, int H, in
  * Optional: a forward workspace LARGER than t2n_render_workspace_bytes_ctx by 256 + rows * 1728 bytes lets the forward keep
  * the MLP activations of up to `rows` appearance samples (a guess, e.g. 1.25 x the previous call's row count); when the
  * actual count fits — and the same byte count is passed to t2n_render_backward — the backward skips its re-run of the
- * appearance forward. Too small a guess only costs that re-run. */
+ * appearance forward. Too small a guess only costs that re-run.
+ * Streams: all work is ordered on `stream` as seen by the caller. Internally the density scatter of a call runs on a library-owned
+ * side stream that forks from `stream` behind the per-ray backward kernel and is joined into `stream` before the call's gradient
+ * writes end (so both workspaces must stay alive until `stream` has passed the call, as for any asynchronous call). */
 size_t t2n_render_workspace_bytes_ctx(int64_t n_rays, int n_samples);
 int t2n_render_ctx_rows(const void* fwd_workspace, int64_t n_rays, int n_samples, t2n_stream stream, int64_t* rows);
 size_t t2n_backward_workspace_bytes(const t2n_field* f, int64_t rows, int64_t n_rays, int n_samples);

@@ -1320,6 +1320,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     timing_end(f, T2N_K_BWD_MLP, s);
 
     // 2. per-ray backward + density scatter
+    bool side = false;   // the density scatter was put on the side stream: joined before step 6
     bool bin = false;
     size_t lds_bin = 0;
     {
@@ -1350,19 +1351,38 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             T2N_HIP(hipMemsetAsync(a.hist, 0, (size_t)geom.total * kBinCopies * 4, s));
             if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true, true>), dim3(nb), dim3(256), lds, s, a);
             else hipLaunchKernelGGL((k_bwd_march<false, true>), dim3(nb), dim3(256), lds, s, a);
-            launch_bin_scan(a.hist, geom.total, (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, 0u, kAccTargetSegs, s);
+            // The density scatter (scan -> records -> LDS accumulate: atomic-latency- and LDS-bound, little VALU, no MFMA) shares
+            // nothing with the MLP backward and the appearance scatter below but the finished k_bwd_march: it runs on a side stream
+            // beside them and is joined before the gradients leave this call (T2N_BWD_SERIAL=1: one stream).
+            static const bool serial = getenv("T2N_BWD_SERIAL") != nullptr;
+            hipStream_t sd = s;
+            if (!serial && rows > 0) {
+                if (!f->side_stream) {
+                    hipStream_t st; hipEvent_t e0, e1;
+                    T2N_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                    T2N_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+                    T2N_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+                    f->side_stream = (void*)st; f->ev_fork = (void*)e0; f->ev_join = (void*)e1;
+                }
+                sd = (hipStream_t)f->side_stream;
+                T2N_HIP(hipEventRecord((hipEvent_t)f->ev_fork, s));
+                T2N_HIP(hipStreamWaitEvent(sd, (hipEvent_t)f->ev_fork, 0));
+                side = true;
+            }
+            launch_bin_scan(a.hist, geom.total, (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, 0u, kAccTargetSegs, sd);
             BinArgs ba;
             ba.F = f->dev; ba.geom = geom; ba.rays = rays; ba.n_rays = n_rays; ba.ray_stride = ray_stride; ba.n_samples = n_samples;
             ba.jitter = jitter; ba.gfeat = a.gfeat; ba.ray_app = a.ray_app; ba.cursor = a.hist; ba.recs = (float4*)(bw + b.recs);
-            if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_bin<true>), dim3(nb), dim3(256), 0, s, ba);
-            else hipLaunchKernelGGL((k_bwd_bin<false>), dim3(nb), dim3(256), 0, s, ba);
+            if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_bin<true>), dim3(nb), dim3(256), 0, sd, ba);
+            else hipLaunchKernelGGL((k_bwd_bin<false>), dim3(nb), dim3(256), 0, sd, ba);
             TileAccumArgs ta;
             ta.S = f->dev.den; ta.G = a.gden; ta.geom = geom; ta.segs = (const int4*)(bw + b.segs);
             ta.nseg = (const unsigned*)(bw + b.nseg); ta.recs = (const float4*)(bw + b.recs);
             ta.dbg = getenv("T2N_DEBUG_ACCUM") ? atoi(getenv("T2N_DEBUG_ACCUM")) : 0;
             ta.gx = nullptr; ta.gx_ld = 0;
             T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
-            hipLaunchKernelGGL((k_bwd_tile_accum<16>), dim3(b.seg_cap < kAccGrid ? b.seg_cap : kAccGrid, 1), dim3(kAccThreads), lds_acc, s, ta);
+            hipLaunchKernelGGL((k_bwd_tile_accum<16>), dim3(b.seg_cap < kAccGrid ? b.seg_cap : kAccGrid, 1), dim3(kAccThreads), lds_acc, sd, ta);
+            if (side) T2N_HIP(hipEventRecord((hipEvent_t)f->ev_join, sd));
         }
         timing_end(f, T2N_K_BWD_MARCH, s);
         T2N_HIP(hipGetLastError());
@@ -1453,6 +1473,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         T2N_HIP(hipGetLastError());
     }
 
+    if (side) T2N_HIP(hipStreamWaitEvent(s, (hipEvent_t)f->ev_join, 0));
     // 6. channel-last gradient buffers -> += reference layouts
     for (int k = 0; k < 3; ++k) {
         const long long HW = (long long)gr[mat1(k)] * gr[mat0(k)], L = gr[vecm(k)];

@@ -97,6 +97,7 @@ struct t2n_field {
     // optimistic (budgeted) render launches: the counters travel to pinned host memory behind the march kernels; the entries a
     // ray needed last time size the next call's lists (t2n_render_workspace_bytes_hint)
     unsigned* host_counts = nullptr; void* ev_counts = nullptr;
+    void* side_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;   // backward: the density scatter runs beside the MLP backward
     unsigned list_hint = 0;          // appearance entries per ray of the last budgeted launch (0: unknown)
     unsigned long long list_retries = 0;
 };
