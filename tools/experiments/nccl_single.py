@@ -11,7 +11,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402
-torch.set_num_threads(8)   # as bench.main does: with one OpenMP thread per host core the process outruns its cgroup CPU quota and is
+torch.set_num_threads(16)  # as bench.main does (train_bench halves it for its loop): with one OpenMP thread per host core the process outruns its cgroup CPU quota and is
                             # throttled until the next 100-ms period (stalls of ~90 ms every few iterations)
 from text2nerf_amd import generate_rays  # noqa: E402
 from text2nerf_amd.parallel import all_gather_tiles, broadcast_parameters, render_sharded  # noqa: E402

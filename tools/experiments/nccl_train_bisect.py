@@ -6,7 +6,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("T2N_TRAIN_TRACE", "1")
 import bench  # noqa: E402
-torch.set_num_threads(8)   # as bench.main does: with one OpenMP thread per host core the process outruns its cgroup CPU quota and is
+torch.set_num_threads(16)  # as bench.main does (train_bench halves it for its loop): with one OpenMP thread per host core the process outruns its cgroup CPU quota and is
                             # throttled until the next 100-ms period (stalls of ~90 ms every few iterations)
 import text2nerf_amd.parallel as par  # noqa: E402
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29537")
