@@ -807,6 +807,24 @@ def test_atomic_scatter_fallback_path_gradients():
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:]
 
 
+def test_single_stream_backward_path_gradients():
+    """The backward runs its density scatter on a side stream by default; T2N_BWD_SERIAL=1 keeps everything on the caller's stream.
+    The G8 gradient check and the kept-rows variant in a subprocess under that switch (read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import pytest\n"
+            "sys.exit(pytest.main(['-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider', '-k', "
+            "'test_g8_gradients_vs_reference_autograd or test_g8_gradients_with_forward_kept_activation_rows', %r]))\n") % (
+                root, os.path.join(root, "tests", "test_hip_parity.py"))
+    env = dict(os.environ, T2N_BWD_SERIAL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:]
+
+
 def test_tile_marcher_inline_compaction_overflow_rays():
     """Lazy-output eval frames compact the appearance list inside the tile marcher (<= N/4 staged entries per ray); rays with
     more appearance samples than that go through the overflow list (k_compact_list). A fog field with few samples per ray
