@@ -121,3 +121,31 @@ def test_deferred_factor_gradients_add_up_over_chunks(tiny_params):
         o2.step(tv=[(f2.density_plane, 0.1), (f2.app_plane, 0.01)])
         assert float(f2.factor_grad_buffer().abs().max()) == 0.0      # consumed and zeroed by the step
     assert_same_trajectory(f1, f2, steps=2)
+
+
+def test_tv_terms_through_hip_kernels_match_torch_tvloss(tiny_params):
+    """TV_loss_density / TV_loss_app with a TVLoss-like regulariser run as HIP kernels (losses.tv_planes): value and gradients
+    against the plain torch evaluation of the same module (utils.py:488-504, models/tensoRF.py:193-203), with a non-unit upstream
+    gradient like the driver's TV weights (text2nerf_main.py:577-586)."""
+    from text2nerf_amd.losses import TVLoss, tv_planes
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    reg = TVLoss(1.7)
+    assert tv_planes(reg, list(f.density_plane), 1e-2) is not None         # the fused route is taken
+    for p in f.parameters():
+        p.grad = None
+    fused = f.TV_loss_density(reg) * 0.1 + f.TV_loss_app(reg) * 0.01
+    fused.backward()
+    got = {k: p.grad.detach().clone() for k, p in f.named_parameters() if p.grad is not None}
+    for p in f.parameters():
+        p.grad = None
+    plain = sum(reg(p) * 1e-2 for p in f.density_plane) * 0.1 + sum(reg(p) * 1e-2 for p in f.app_plane) * 0.01
+    plain.backward()
+    assert abs(float(fused) - float(plain)) <= 1e-5 * abs(float(plain)) + 1e-12
+    assert set(got) == {k for k, p in f.named_parameters() if p.grad is not None}
+    for k, p in f.named_parameters():
+        if p.grad is None:
+            continue
+        scale = float(p.grad.abs().max()) + 1e-20
+        assert float((got[k] - p.grad).abs().max()) <= 2e-6 * scale, k
+    # a regulariser without TVLoss_weight (any callable) takes the plain route
+    assert tv_planes(lambda x: x.sum(), list(f.density_plane), 1e-2) is None

@@ -24,6 +24,30 @@ __global__ __launch_bounds__(256) void k_tv_grad_add(const float* __restrict__ x
     g[t] += acc;
 }
 
+// TVLoss's two sums of one reference-layout plane [1,C,H,W] (utils.py:488-504): out[0] += sum (x[c,y+1,x] - x[c,y,x])^2,
+// out[1] += sum (x[c,y,x+1] - x[c,y,x])^2. Grid-stride blocks, fp32 squares summed in double, two atomics per block.
+__global__ __launch_bounds__(256) void k_tv_value(const float* __restrict__ x, int C, int H, int W, double* __restrict__ out) {
+    __shared__ double part[8];
+    const long long n = (long long)C * H * W;
+    double sh = 0.0, sw = 0.0;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int w = (int)(t % W);
+        const int h = (int)((t / W) % H);
+        const float v = x[t];
+        if (h < H - 1) { const float d = x[t + W] - v; sh += (double)(d * d); }
+        if (w < W - 1) { const float d = x[t + 1] - v; sw += (double)(d * d); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sh += __shfl_xor(sh, o); sw += __shfl_xor(sw, o); }
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[wid] = sh; part[4 + wid] = sw; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], (part[0] + part[1]) + (part[2] + part[3]));
+        atomicAdd(&out[1], (part[4] + part[5]) + (part[6] + part[7]));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                               long long n, float lr_over_bc1, float beta1, float beta2, float eps, float inv_bc2_sqrt) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,6 +261,16 @@ extern "C" int t2n_adam_step_multi(int count, float* const* params, const float*
         a.count = c; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
         if (blocks) hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     }
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_tv_value(const float* param, int C, int H, int W, double* sums, t2n_stream stream) {
+    if (!param || !sums || C <= 0 || H <= 1 || W <= 1) { set_error("t2n_tv_value: bad argument"); return T2N_ERR_INVALID; }
+    const long long n = (long long)C * H * W;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;   // same-address atomics serialise: two per block
+    hipLaunchKernelGGL(k_tv_value, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, C, H, W, sums);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

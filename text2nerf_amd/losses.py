@@ -5,6 +5,60 @@ the renderer. Plain torch ops; the fused forms are optim.TVAdam (TV + Adam) and 
 import torch
 import torch.nn as nn
 
+from . import _lib
+
+
+class _TVPlaneSum(torch.autograd.Function):
+    """sum_p scale * TVLoss_weight * TVLoss(p) over [1,C,H,W] device planes as two HIP kernels per plane (value: t2n_tv_value,
+    gradient: t2n_tv_grad_add) instead of ~15 eager elementwise / reduction kernels per plane with their 69-MB temporaries.
+    Same arithmetic as TVLoss.forward (utils.py:488-504) with the sums taken in double."""
+
+    @staticmethod
+    def forward(ctx, weight, *planes):
+        lib = _lib.load()
+        dev = planes[0].device
+        sums = torch.zeros(len(planes), 2, device=dev, dtype=torch.float64)
+        ctx.weight = float(weight)
+        ctx.save_for_backward(*planes)
+        with torch.cuda.device(dev):
+            for i, p in enumerate(planes):
+                b, c, h, w = p.shape
+                q = p.detach()
+                _lib.check(lib.t2n_tv_value(_lib.ptr(q), c, h, w, _lib.ptr(sums[i]), _lib.current_stream_ptr(dev)), "t2n_tv_value")
+        total = 0
+        for i, p in enumerate(planes):
+            b, c, h, w = p.shape
+            total = total + (sums[i, 0] / (c * (h - 1) * w) + sums[i, 1] / (c * h * (w - 1)))
+        return (total * (2.0 * ctx.weight)).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        planes = ctx.saved_tensors
+        dev = planes[0].device
+        grads = []
+        with torch.cuda.device(dev):
+            for p in planes:
+                b, c, h, w = p.shape
+                g = torch.zeros_like(p)
+                _lib.check(lib.t2n_tv_grad_add(_lib.ptr(p.detach()), _lib.ptr(g), c, h, w, ctx.weight, _lib.current_stream_ptr(dev)),
+                           "t2n_tv_grad_add")
+                grads.append(g.mul_(grad_out))    # the upstream scalar stays on the device (no host read inside backward)
+        return (None, *grads)
+
+
+def tv_planes(reg, planes, scale):
+    """sum_p reg(p) * scale for a TVLoss-like `reg` (an object with a float `TVLoss_weight`, like utils.TVLoss) on contiguous fp32
+    [1,C,H,W] device planes through the HIP kernels; None when that does not apply (the caller then evaluates reg(p) itself)."""
+    w = getattr(reg, "TVLoss_weight", None)
+    if w is None or not planes:
+        return None
+    for p in planes:
+        if not (p.is_cuda and p.dtype == torch.float32 and p.dim() == 4 and p.shape[0] == 1 and p.shape[2] > 1 and p.shape[3] > 1
+                and p.is_contiguous()):
+            return None
+    return _TVPlaneSum.apply(float(w) * float(scale), *planes)
+
 
 class TVLoss(nn.Module):
     """Total-variation regulariser on a [B,C,H,W] plane (utils.py:488-504)."""

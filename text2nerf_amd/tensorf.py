@@ -305,12 +305,22 @@ class TensorVMSplit(nn.Module):
         return groups
 
     def TV_loss_density(self, reg):
+        """models/tensoRF.py:193-197. A TVLoss-like `reg` on device planes runs as two HIP kernels per plane (losses.tv_planes)."""
+        from .losses import tv_planes
+        fused = tv_planes(reg, list(self.density_plane), 1e-2)
+        if fused is not None:
+            return fused
         total = 0
         for p in self.density_plane:
             total = total + reg(p) * 1e-2
         return total
 
     def TV_loss_app(self, reg):
+        """models/tensoRF.py:199-203."""
+        from .losses import tv_planes
+        fused = tv_planes(reg, list(self.app_plane), 1e-2)
+        if fused is not None:
+            return fused
         total = 0
         for p in self.app_plane:
             total = total + reg(p) * 1e-2
