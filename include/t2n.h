@@ -306,8 +306,10 @@ int t2n_train_loss(const float* rgb, const float* depth, const float* weights, c
  * t2n_adam_step: torch.optim.Adam's update (betas, eps; no weight decay, no amsgrad) on one tensor, `step` = 1-based
  *   step count of that tensor (text2nerf_main.py:453-454,590). */
 int t2n_tv_grad_add(const float* param, float* grad, int C, int H, int W, float weight, t2n_stream stream);
-/* TVLoss's two sums of one plane (utils.py:497-498): sums[0] += sum of squared differences along H, sums[1] += along W (device
- * doubles the caller zeroes); TVLoss(param) = weight * 2 * (sums[0] / (C (H-1) W) + sums[1] / (C H (W-1))) / batch. */
+/* TVLoss's two sums of one plane (utils.py:497-498), spread over T2N_TV_SLOTS slot pairs the caller zeroes and adds up (device
+ * doubles): sum_s sums[2 s] = sum of squared differences along H, sum_s sums[2 s + 1] = along W;
+ * TVLoss(param) = weight * 2 * (h_tv / (C (H-1) W) + w_tv / (C H (W-1))) / batch. */
+#define T2N_TV_SLOTS 32
 int t2n_tv_value(const float* param, int C, int H, int W, double* sums, t2n_stream stream);
 int t2n_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, int64_t step, t2n_stream stream);

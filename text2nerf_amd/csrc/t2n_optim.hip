@@ -10,41 +10,53 @@ namespace t2n {
 
 __global__ __launch_bounds__(256) void k_tv_grad_add(const float* __restrict__ x, float* __restrict__ g, int C, int H, int W, float sh,
                                                      float sw) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long n = (long long)C * H * W;
-    if (t >= n) return;
-    const int w = (int)(t % W);
-    const int h = (int)((t / W) % H);
-    const float v = x[t];
-    float acc = 0.f;
-    if (h > 0) acc += sh * (2.f * (v - x[t - W]));
-    if (h < H - 1) acc -= sh * (2.f * (x[t + W] - v));
-    if (w > 0) acc += sw * (2.f * (v - x[t - 1]));
-    if (w < W - 1) acc -= sw * (2.f * (x[t + 1] - v));
-    g[t] += acc;
+    // one wave per image row (c, y), lanes stride the row: no per-element divisions; same per-element arithmetic and order as before
+    const int lane = threadIdx.x & 63;
+    const long long rows = (long long)C * H;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+        const int h = (int)(r % H);
+        const float* __restrict__ row = x + r * W;
+        float* __restrict__ grow = g + r * W;
+        for (int w = lane; w < W; w += 64) {
+            const float v = row[w];
+            float acc = 0.f;
+            if (h > 0) acc += sh * (2.f * (v - row[w - W]));
+            if (h < H - 1) acc -= sh * (2.f * (row[w + W] - v));
+            if (w > 0) acc += sw * (2.f * (v - row[w - 1]));
+            if (w < W - 1) acc -= sw * (2.f * (row[w + 1] - v));
+            grow[w] += acc;
+        }
+    }
 }
 
 // TVLoss's two sums of one reference-layout plane [1,C,H,W] (utils.py:488-504): out[0] += sum (x[c,y+1,x] - x[c,y,x])^2,
 // out[1] += sum (x[c,y,x+1] - x[c,y,x])^2. Grid-stride blocks, fp32 squares summed in double, two atomics per block.
 __global__ __launch_bounds__(256) void k_tv_value(const float* __restrict__ x, int C, int H, int W, double* __restrict__ out) {
     __shared__ double part[8];
-    const long long n = (long long)C * H * W;
-    double sh = 0.0, sw = 0.0;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int w = (int)(t % W);
-        const int h = (int)((t / W) % H);
-        const float v = x[t];
-        if (h < H - 1) { const float d = x[t + W] - v; sh += (double)(d * d); }
-        if (w < W - 1) { const float d = x[t + 1] - v; sw += (double)(d * d); }
+    // one wave per image row (c, y): lanes stride the row (coalesced), the row below is the same offset + W; no per-element divisions
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const long long rows = (long long)C * H;
+    float sh = 0.f, sw = 0.f;     // per-lane partial sums of a few hundred squares; combined in double below
+    double dh = 0.0, dw = 0.0;
+    for (long long r = (long long)blockIdx.x * 4 + wid; r < rows; r += (long long)gridDim.x * 4) {
+        const int y = (int)(r % H);
+        const float* __restrict__ row = x + r * W;
+        const bool below = y < H - 1;
+        for (int i = lane; i < W; i += 64) {
+            const float v = row[i];
+            if (below) { const float d = row[i + W] - v; sh = fmaf(d, d, sh); }
+            if (i < W - 1) { const float d = row[i + 1] - v; sw = fmaf(d, d, sw); }
+        }
+        dh += (double)sh; dw += (double)sw; sh = 0.f; sw = 0.f;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sh += __shfl_xor(sh, o); sw += __shfl_xor(sw, o); }
-    const int wid = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { part[wid] = sh; part[4 + wid] = sw; }
+    for (int o = 32; o > 0; o >>= 1) { dh += __shfl_xor(dh, o); dw += __shfl_xor(dw, o); }
+    if (lane == 0) { part[wid] = dh; part[4 + wid] = dw; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&out[0], (part[0] + part[1]) + (part[2] + part[3]));
-        atomicAdd(&out[1], (part[4] + part[5]) + (part[6] + part[7]));
+    if (threadIdx.x == 0) {   // T2N_TV_SLOTS pairs of sums: same-address atomics serialise (~88 per microsecond), the caller adds the slots
+        double* o = out + 2 * (blockIdx.x & (T2N_TV_SLOTS - 1));
+        atomicAdd(&o[0], (part[0] + part[1]) + (part[2] + part[3]));
+        atomicAdd(&o[1], (part[4] + part[5]) + (part[6] + part[7]));
     }
 }
 
@@ -267,9 +279,8 @@ extern "C" int t2n_adam_step_multi(int count, float* const* params, const float*
 
 extern "C" int t2n_tv_value(const float* param, int C, int H, int W, double* sums, t2n_stream stream) {
     if (!param || !sums || C <= 0 || H <= 1 || W <= 1) { set_error("t2n_tv_value: bad argument"); return T2N_ERR_INVALID; }
-    const long long n = (long long)C * H * W;
-    long long blocks = (n + 255) / 256;
-    if (blocks > 1024) blocks = 1024;   // same-address atomics serialise: two per block
+    long long blocks = ((long long)C * H + 3) / 4;
+    if (blocks > 2048) blocks = 2048;   // same-address atomics serialise: two per block
     hipLaunchKernelGGL(k_tv_value, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, C, H, W, sums);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
@@ -280,8 +291,9 @@ extern "C" int t2n_tv_grad_add(const float* param, float* grad, int C, int H, in
     // TVLoss: weight * 2 * (h_tv / count_h + w_tv / count_w) / batch, batch = 1
     const float sh = weight * 2.f / ((float)C * (float)(H - 1) * (float)W);
     const float sw = weight * 2.f / ((float)C * (float)H * (float)(W - 1));
-    const long long n = (long long)C * H * W;
-    hipLaunchKernelGGL(k_tv_grad_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, C, H, W, sh, sw);
+    long long blocks = ((long long)C * H + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_tv_grad_add, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, C, H, W, sh, sw);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

@@ -17,7 +17,7 @@ class _TVPlaneSum(torch.autograd.Function):
     def forward(ctx, weight, *planes):
         lib = _lib.load()
         dev = planes[0].device
-        sums = torch.zeros(len(planes), 2, device=dev, dtype=torch.float64)
+        sums = torch.zeros(len(planes), 32, 2, device=dev, dtype=torch.float64)   # T2N_TV_SLOTS slot pairs per plane
         ctx.weight = float(weight)
         ctx.save_for_backward(*planes)
         with torch.cuda.device(dev):
@@ -25,6 +25,7 @@ class _TVPlaneSum(torch.autograd.Function):
                 b, c, h, w = p.shape
                 q = p.detach()
                 _lib.check(lib.t2n_tv_value(_lib.ptr(q), c, h, w, _lib.ptr(sums[i]), _lib.current_stream_ptr(dev)), "t2n_tv_value")
+        sums = sums.sum(1)
         total = 0
         for i, p in enumerate(planes):
             b, c, h, w = p.shape
