@@ -306,6 +306,9 @@ int t2n_train_loss(const float* rgb, const float* depth, const float* weights, c
  * t2n_adam_step: torch.optim.Adam's update (betas, eps; no weight decay, no amsgrad) on one tensor, `step` = 1-based
  *   step count of that tensor (text2nerf_main.py:453-454,590). */
 int t2n_tv_grad_add(const float* param, float* grad, int C, int H, int W, float weight, t2n_stream stream);
+/* the same gradient WRITTEN (not added) to `grad`, times the device scalar *upstream when that is non-NULL: the backward of an
+ * autograd node whose upstream gradient lives on the device (no host read, no zero fill, no extra scaling pass). */
+int t2n_tv_grad_set(const float* param, float* grad, int C, int H, int W, float weight, const float* upstream, t2n_stream stream);
 /* TVLoss's two sums of one plane (utils.py:497-498), spread over T2N_TV_SLOTS slot pairs the caller zeroes and adds up (device
  * doubles): sum_s sums[2 s] = sum of squared differences along H, sum_s sums[2 s + 1] = along W;
  * TVLoss(param) = weight * 2 * (h_tv / (C (H-1) W) + w_tv / (C H (W-1))) / batch. */

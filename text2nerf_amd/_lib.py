@@ -110,6 +110,7 @@ SIGNATURES = {
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "t2n_tv_grad_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "t2n_tv_value": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "t2n_tv_grad_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "t2n_field_tv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                          C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "t2n_field_upload_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,15 +1,17 @@
 // SURVEY.md §8 f-1 ("next" row): the dense, HBM-bound tail of the training step that follows the renderer's backward —
 // the total-variation regulariser on the VM planes (utils.py:488-504 through models/tensoRF.py:193-203) and the Adam update
 // (text2nerf_main.py:453-454,588-590) — as two streaming HIP kernels instead of ~60 eager torch ops:
-//   k_tv_grad_add   grad += d/dx [ weight * 2 * (sum_h (x[h]-x[h-1])^2 / count_h + sum_w (x[w]-x[w-1])^2 / count_w) / B ]
+//   k_tv_grad<SET>  grad (+)= d/dx [ weight * 2 * (sum_h (x[h]-x[h-1])^2 / count_h + sum_w (x[w]-x[w-1])^2 / count_w) / B ]
 //                   (5-point stencil on the reference-layout [1,C,H,W] plane; reads the parameters only)
 //   k_adam          torch.optim.Adam's single-tensor update (no weight decay / amsgrad), in place
 #include "t2n_device.h"
 
 namespace t2n {
 
-__global__ __launch_bounds__(256) void k_tv_grad_add(const float* __restrict__ x, float* __restrict__ g, int C, int H, int W, float sh,
-                                                     float sw) {
+template <bool SET>
+__global__ __launch_bounds__(256) void k_tv_grad(const float* __restrict__ x, float* __restrict__ g, int C, int H, int W, float sh,
+                                                 float sw, const float* __restrict__ scale) {
+    const float up = (SET && scale) ? *scale : 1.f;   // SET: g = upstream scalar (device) x gradient; ADD: g += gradient
     // one wave per image row (c, y), lanes stride the row: no per-element divisions; same per-element arithmetic and order as before
     const int lane = threadIdx.x & 63;
     const long long rows = (long long)C * H;
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(256) void k_tv_grad_add(const float* __restrict__ x
             if (h < H - 1) acc -= sh * (2.f * (row[w + W] - v));
             if (w > 0) acc += sw * (2.f * (v - row[w - 1]));
             if (w < W - 1) acc -= sw * (2.f * (row[w + 1] - v));
-            grow[w] += acc;
+            if (SET) grow[w] = acc * up; else grow[w] += acc;
         }
     }
 }
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamMulti a) {
 // (gradients -> [1,C,H,W], zero-filled gradient tensors, parameters -> channel-last). t2n_field_tv_adam_step does the whole
 // thing where the data already is: TV stencil on the channel-last parameters (neighbours at +-C and +-W*C), then one pass
 // that reads g / m / v / p channel-last, writes p / m / v channel-last and the new values into the caller's reference-layout
-// tensor through an LDS tile transpose. Same arithmetic per element as k_tv_grad_add + k_adam (bit-identical results).
+// tensor through an LDS tile transpose. Same arithmetic per element as k_tv_grad + k_adam (bit-identical results).
 __device__ __forceinline__ void tv_grad_cl_body(const float* __restrict__ x, float* __restrict__ g, long long t, int C4, int H, int W, float sh,
                                                 float sw) {
     const long long n = (long long)H * W * C4;   // t: one float4 of 4 channels
@@ -293,7 +295,18 @@ extern "C" int t2n_tv_grad_add(const float* param, float* grad, int C, int H, in
     const float sw = weight * 2.f / ((float)C * (float)H * (float)(W - 1));
     long long blocks = ((long long)C * H + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_tv_grad_add, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, C, H, W, sh, sw);
+    hipLaunchKernelGGL(k_tv_grad<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, C, H, W, sh, sw, (const float*)nullptr);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_tv_grad_set(const float* param, float* grad, int C, int H, int W, float weight, const float* upstream, t2n_stream stream) {
+    if (!param || !grad || C <= 0 || H <= 1 || W <= 1) { set_error("t2n_tv_grad_set: bad argument"); return T2N_ERR_INVALID; }
+    const float sh = weight * 2.f / ((float)C * (float)(H - 1) * (float)W);
+    const float sw = weight * 2.f / ((float)C * (float)H * (float)(W - 1));
+    long long blocks = ((long long)C * H + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_tv_grad<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, C, H, W, sh, sw, upstream);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

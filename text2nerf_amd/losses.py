@@ -10,7 +10,7 @@ from . import _lib
 
 class _TVPlaneSum(torch.autograd.Function):
     """sum_p scale * TVLoss_weight * TVLoss(p) over [1,C,H,W] device planes as two HIP kernels per plane (value: t2n_tv_value,
-    gradient: t2n_tv_grad_add) instead of ~15 eager elementwise / reduction kernels per plane with their 69-MB temporaries.
+    gradient: t2n_tv_grad_set) instead of ~15 eager elementwise / reduction kernels per plane with their 69-MB temporaries.
     Same arithmetic as TVLoss.forward (utils.py:488-504) with the sums taken in double."""
 
     @staticmethod
@@ -41,10 +41,11 @@ class _TVPlaneSum(torch.autograd.Function):
         with torch.cuda.device(dev):
             for p in planes:
                 b, c, h, w = p.shape
-                g = torch.zeros_like(p)
-                _lib.check(lib.t2n_tv_grad_add(_lib.ptr(p.detach()), _lib.ptr(g), c, h, w, ctx.weight, _lib.current_stream_ptr(dev)),
-                           "t2n_tv_grad_add")
-                grads.append(g.mul_(grad_out))    # the upstream scalar stays on the device (no host read inside backward)
+                g = torch.empty_like(p)           # written by the kernel, scaled by the upstream scalar read on the device
+                up = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+                _lib.check(lib.t2n_tv_grad_set(_lib.ptr(p.detach()), _lib.ptr(g), c, h, w, ctx.weight, _lib.ptr(up),
+                                               _lib.current_stream_ptr(dev)), "t2n_tv_grad_set")
+                grads.append(g)
         return (None, *grads)
 
 
