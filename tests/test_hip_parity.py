@@ -850,3 +850,26 @@ def test_tile_marcher_inline_compaction_overflow_rays():
         assert sa["evaluated"] == sb["evaluated"] and abs(sa["appearance"] - sb["appearance"]) <= 3
         close(b[0], a[0].cpu().numpy(), atol=3e-5)
         close(b[1], a[1].cpu().numpy(), atol=1e-4)
+
+
+def test_drop_in_evaluation_call_detects_the_raster(tiny_params):
+    """OctreeRender_trilinear_fast in eval mode with all rays of one image and no frame_width hint (the reference's evaluation loop,
+    renderer.py:85-89) detects the raster width and takes the tile marcher: bitwise the outputs of the explicit hint; shuffled rays
+    keep the per-ray marcher (bitwise the outputs without any hint)."""
+    from text2nerf_amd import OctreeRender_trilinear_fast
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    rays = torch.from_numpy(synth.frame_rays_np(40, 56, c2w=synth.look_pose(0.3, -0.1, (0.2, 0.1, -1.0))))
+    with torch.no_grad():
+        auto = OctreeRender_trilinear_fast(rays, f, chunk=4096, N_samples=-1, white_bg=True, is_train=False, device=dev())
+        assert f.frame_width == 0                    # the caller's setting is restored
+        f.frame_width = 56
+        hinted = f(rays, is_train=False, white_bg=True, N_samples=-1)
+        f.frame_width = 0
+        f.auto_frame_width = False
+        plain = OctreeRender_trilinear_fast(rays, f, chunk=4096, N_samples=-1, white_bg=True, is_train=False, device=dev())
+        f.auto_frame_width = True
+        perm = torch.randperm(rays.shape[0], generator=torch.Generator().manual_seed(3))
+        shuffled = OctreeRender_trilinear_fast(rays[perm], f, chunk=4096, N_samples=-1, white_bg=True, is_train=False, device=dev())
+    assert torch.equal(auto[0], hinted[0]) and torch.equal(auto[2], hinted[1]) and torch.equal(auto[3], hinted[3])
+    assert torch.equal(shuffled[0], plain[0][perm.to(plain[0].device)])
+    close(auto[0], plain[0].cpu().numpy(), atol=RGB_ATOL)

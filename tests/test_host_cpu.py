@@ -226,3 +226,34 @@ def test_reference_pose_fixture():
         assert np.allclose(np.einsum("vij,vkj->vik", R, R), np.eye(3)[None], atol=1e-5), k
     assert np.allclose(P["local_fixed"][0], np.eye(4))
     assert np.abs(P["local_fixed"][1:, :3, 3]).max() <= 0.2 + 1e-6          # range_center = 0.2
+
+
+def test_raster_width_detection_for_drop_in_evaluation():
+    """renderer.detect_frame_width: the width of a row-major pinhole raster (what the reference's evaluation passes to the renderer,
+    renderer.py:85-89) from its first rays — narrow and wide fields of view, normalised and unnormalised directions, ragged sizes;
+    0 for shuffled rays, several origins, too few rows, and widths that do not divide the ray count."""
+    import numpy as np
+    import torch
+    from text2nerf_amd import synth
+    from text2nerf_amd.renderer import detect_frame_width
+
+    def raster(H, W, focal, c2w, normalise=True):
+        j, i = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+        d = np.stack([(i - W / 2 + 0.5) / focal, -(j - H / 2 + 0.5) / focal, -np.ones_like(i)], -1).reshape(-1, 3)
+        if normalise:
+            d = d / np.linalg.norm(d, axis=1, keepdims=True)
+        d = d @ c2w[:3, :3].T
+        o = np.broadcast_to(c2w[:3, 3], d.shape)
+        return torch.from_numpy(np.concatenate([o, d], 1).astype(np.float32))
+
+    pose = synth.look_pose(0.7, -0.3, (0.4, -0.2, 1.5))
+    for H, W, focal, norm in ((20, 24, 30.0, True), (64, 48, 500.0, True), (100, 800, 400.0, True), (800, 800, 800.0, True),
+                              (512, 512, 128.0, True), (37, 51, 40.0, False), (8, 8, 6.0, True)):
+        assert detect_frame_width(raster(H, W, focal, pose, norm)) == W, (H, W, focal, norm)
+    r = raster(64, 64, 60.0, pose)
+    assert detect_frame_width(r[torch.randperm(r.shape[0], generator=torch.Generator().manual_seed(0))]) == 0
+    r2 = r.clone(); r2[100, :3] += 1.0
+    assert detect_frame_width(r2) == 0                       # not one camera
+    assert detect_frame_width(raster(7, 64, 60.0, pose)) == 0   # fewer than 8 rows
+    assert detect_frame_width(r[: 64 * 10 + 5]) == 0         # the width does not divide the ray count
+    assert detect_frame_width(r[:40]) == 0

@@ -21,6 +21,36 @@ class SimpleSampler:
         return self.ids[self.curr:self.curr + self.batch]
 
 
+def detect_frame_width(rays, probe=8192):
+    """Width W of a row-major pinhole raster in `rays` [R, >=6] (what `evaluation` passes: all rays of one image,
+    renderer.py:85-89), or 0. Looks at the first `probe` rays on the host: one origin, directions that change smoothly along a row
+    and jump at a row's end (consecutive direction deltas differ by more than half their size only there); the jump must repeat at
+    2W - 1 when visible, the second row must start like the first, and R must be a multiple of W with at least 8 rows of at least 8
+    pixels. The hint only selects the tile marcher (8x8-pixel tiles of coherent rays); a wrong guess costs speed, never correctness."""
+    R = int(rays.shape[0])
+    if R < 64 or rays.shape[1] < 6:
+        return 0
+    head = rays[: min(R, probe), :6].detach().float().cpu().numpy()
+    o, d = head[:, :3], head[:, 3:6]
+    if not np.all(np.abs(o - o[0]).max(axis=1) <= 1e-6 * (1.0 + np.abs(o[0]).max())):
+        return 0
+    delta = d[1:] - d[:-1]
+    n = np.linalg.norm(delta, axis=1)
+    if not np.isfinite(n).all() or n[0] <= 0:
+        return 0
+    jump = np.linalg.norm(delta[1:] - delta[:-1], axis=1) > 0.5 * np.maximum(n[:-1], 1e-30)
+    ks = np.nonzero(jump)[0]
+    if ks.size == 0:
+        return 0
+    W = int(ks[0]) + 2          # jump[k] compares delta[k+1] (the wrap d[k+2] - d[k+1]) with delta[k]: the row ends at index k + 1
+    if W < 8 or R % W or R // W < 8:
+        return 0
+    if 2 * W <= head.shape[0]:  # the second row: starts like the first, ends with the same jump
+        if np.linalg.norm(delta[W] - delta[0]) > 0.5 * n[0] or not jump[2 * W - 2]:
+            return 0
+    return W
+
+
 def OctreeRender_trilinear_fast(rays, tensorf, chunk=4096, N_samples=-1, ndc_ray=False, white_bg=True, is_train=False,
                                 device="cuda"):
     """Same signature and 5-tuple ``(rgb [R,3], None, depth [R], weights [R,N], z_vals [R,N])`` as renderer.py:28-42.
@@ -29,7 +59,15 @@ def OctreeRender_trilinear_fast(rays, tensorf, chunk=4096, N_samples=-1, ndc_ray
     reference's Python loop and is not needed here). Train: the reference draws one jitter vector per chunk from the CPU
     generator, so the chunk loop is kept to consume the RNG stream identically (the driver's batch is one chunk)."""
     if not is_train:
-        rgb, depth, z, w = tensorf(rays, is_train=False, white_bg=white_bg, ndc_ray=ndc_ray, N_samples=N_samples)
+        # the driver's evaluation hands over all rays of one image: without an explicit hint the raster width is detected, so that
+        # the frame takes the tile marcher (tensorf.auto_frame_width = False turns that off)
+        keep_w = tensorf.frame_width
+        if not keep_w and not ndc_ray and getattr(tensorf, "auto_frame_width", True):
+            tensorf.frame_width = detect_frame_width(rays)
+        try:
+            rgb, depth, z, w = tensorf(rays, is_train=False, white_bg=white_bg, ndc_ray=ndc_ray, N_samples=N_samples)
+        finally:
+            tensorf.frame_width = keep_w
         return rgb, None, depth, w, z
     outs = [[], [], [], []]
     n = rays.shape[0]
