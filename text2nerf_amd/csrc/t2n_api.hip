@@ -57,10 +57,19 @@ static void timing_flush(t2n_field* f) {
 // [1,C,H,W] -> [H][W][C]   (lines: W == 1)
 // Reference layout [C][HW] -> channel-last [HW][C] through an LDS tile of 64 texels (coalesced on both sides).
 // dsth != NULL (bf16 factor storage): round to nearest-even bf16; dst gets the rounded value as fp32, dsth the 2-byte texel.
-__global__ __launch_bounds__(256) void k_relayout(const float* __restrict__ src, float* __restrict__ dst, unsigned short* __restrict__ dsth,
-                                                  int C, long long HW) {
+// The 12 factor tensors of an upload go through ONE launch (twelve launches of mostly tiny grids cost ~7 us each).
+struct RelayoutMulti { const float* src[12]; float* dst[12]; unsigned short* dsth[12]; int C[12]; long long HW[12]; unsigned block0[13]; int count; };
+__global__ __launch_bounds__(256) void k_relayout(const RelayoutMulti a) {
     __shared__ float tile[64 * 49];                      // [64 texels][C + 1], C <= 48
-    const long long pix0 = (long long)blockIdx.x * 64;
+    int t = 0;
+#pragma unroll 1
+    for (int q = 1; q < a.count; ++q) t += (a.block0[q] <= blockIdx.x) ? 1 : 0;
+    const float* __restrict__ src = a.src[t];
+    float* __restrict__ dst = a.dst[t];
+    unsigned short* __restrict__ dsth = a.dsth[t];
+    const int C = a.C[t];
+    const long long HW = a.HW[t];
+    const long long pix0 = (long long)(blockIdx.x - a.block0[t]) * 64;
     const int lp = threadIdx.x & 63, cs = threadIdx.x >> 6;
     const int ld = C + 1;
     if (pix0 + lp < HW)
@@ -82,32 +91,39 @@ __global__ __launch_bounds__(256) void k_relayout(const float* __restrict__ src,
     }
 }
 
-static int relayout_one(const float* src, float** dst, void** dsth, bool half, int C, long long HW, hipStream_t s) {
+static int relayout_one(RelayoutMulti& m, unsigned& blocks, const float* src, float** dst, void** dsth, bool half, int C, long long HW) {
     if (!src) { set_error("t2n_field_upload: NULL factor tensor"); return T2N_ERR_INVALID; }
     if (!*dst) T2N_HIP(hipMalloc((void**)dst, (size_t)HW * C * sizeof(float)));
     if (half && !*dsth) T2N_HIP(hipMalloc(dsth, (size_t)HW * C * 2 + 16));
     if (C > 48) { set_error("t2n_field_upload: %d channels > 48", C); return T2N_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(k_relayout, dim3((unsigned)((HW + 63) / 64)), dim3(256), 0, s, src, *dst, half ? (unsigned short*)*dsth : nullptr, C, HW);
-    T2N_HIP(hipGetLastError());
+    const int i = m.count++;
+    m.src[i] = src; m.dst[i] = *dst; m.dsth[i] = half ? (unsigned short*)*dsth : nullptr; m.C[i] = C; m.HW[i] = HW; m.block0[i] = blocks;
+    blocks += (unsigned)((HW + 63) / 64);
     return T2N_OK;
 }
 
 int launch_relayout(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
     const int* g = f->desc.grid;
+    RelayoutMulti m;
+    memset(&m, 0, sizeof(m));
+    unsigned blocks = 0;
     for (int k = 0; k < 3; ++k) {
         const long long HW = (long long)g[mat1(k)] * g[mat0(k)];
         const long long L = g[vecm(k)];
         int rc;
         const bool hf = f->factor_bf16 != 0;
-        if ((rc = relayout_one(p->density_plane[k], &f->buf_den_plane[k], &f->hbuf_den_plane[k], hf, f->desc.density_n_comp, HW, s))) return rc;
-        if ((rc = relayout_one(p->density_line[k], &f->buf_den_line[k], &f->hbuf_den_line[k], hf, f->desc.density_n_comp, L, s))) return rc;
-        if ((rc = relayout_one(p->app_plane[k], &f->buf_app_plane[k], &f->hbuf_app_plane[k], hf, f->desc.app_n_comp, HW, s))) return rc;
-        if ((rc = relayout_one(p->app_line[k], &f->buf_app_line[k], &f->hbuf_app_line[k], hf, f->desc.app_n_comp, L, s))) return rc;
+        if ((rc = relayout_one(m, blocks, p->density_plane[k], &f->buf_den_plane[k], &f->hbuf_den_plane[k], hf, f->desc.density_n_comp, HW))) return rc;
+        if ((rc = relayout_one(m, blocks, p->density_line[k], &f->buf_den_line[k], &f->hbuf_den_line[k], hf, f->desc.density_n_comp, L))) return rc;
+        if ((rc = relayout_one(m, blocks, p->app_plane[k], &f->buf_app_plane[k], &f->hbuf_app_plane[k], hf, f->desc.app_n_comp, HW))) return rc;
+        if ((rc = relayout_one(m, blocks, p->app_line[k], &f->buf_app_line[k], &f->hbuf_app_line[k], hf, f->desc.app_n_comp, L))) return rc;
         f->dev.den.plane[k] = f->buf_den_plane[k]; f->dev.den.line[k] = f->buf_den_line[k];
         f->dev.app.plane[k] = f->buf_app_plane[k]; f->dev.app.line[k] = f->buf_app_line[k];
         f->dev.den.plane_h[k] = hf ? f->hbuf_den_plane[k] : nullptr; f->dev.den.line_h[k] = hf ? f->hbuf_den_line[k] : nullptr;
         f->dev.app.plane_h[k] = hf ? f->hbuf_app_plane[k] : nullptr; f->dev.app.line_h[k] = hf ? f->hbuf_app_line[k] : nullptr;
     }
+    m.block0[m.count] = blocks;
+    if (blocks) hipLaunchKernelGGL(k_relayout, dim3(blocks), dim3(256), 0, s, m);
+    T2N_HIP(hipGetLastError());
     return T2N_OK;
 }
 

@@ -1028,10 +1028,19 @@ __global__ __launch_bounds__(256) void k_bwd_app_scatter(const AppScatterArgs a)
     }
 }
 
-// channel-last gradient buffer [HW][C] -> += reference layout [1,C,H,W], through an LDS tile of 64 texels
-__global__ __launch_bounds__(256) void k_relayout_add(const float* __restrict__ src, float* dst, int C, long long HW) {
+// channel-last gradient buffer [HW][C] -> += reference layout [1,C,H,W], through an LDS tile of 64 texels; the (up to) 12 factor
+// tensors of a backward call in ONE launch (twelve launches of mostly tiny grids cost ~9 us each)
+struct RelayoutAddMulti { const float* src[12]; float* dst[12]; int C[12]; long long HW[12]; unsigned block0[13]; int count; };
+__global__ __launch_bounds__(256) void k_relayout_add(const RelayoutAddMulti a) {
     __shared__ float tile[64 * 49];
-    const long long pix0 = (long long)blockIdx.x * 64;
+    int t = 0;
+#pragma unroll 1
+    for (int q = 1; q < a.count; ++q) t += (a.block0[q] <= blockIdx.x) ? 1 : 0;
+    const float* __restrict__ src = a.src[t];
+    float* dst = a.dst[t];
+    const int C = a.C[t];
+    const long long HW = a.HW[t];
+    const long long pix0 = (long long)(blockIdx.x - a.block0[t]) * 64;
     const int ld = C + 1;
     const long long n = (HW - pix0 < 64 ? HW - pix0 : 64) * C;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -1475,12 +1484,25 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
 
     if (side) T2N_HIP(hipStreamWaitEvent(s, (hipEvent_t)f->ev_join, 0));
     // 6. channel-last gradient buffers -> += reference layouts
-    for (int k = 0; k < 3; ++k) {
-        const long long HW = (long long)gr[mat1(k)] * gr[mat0(k)], L = gr[vecm(k)];
-        if (g->density_plane[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((HW + 63) / 64)), dim3(256), 0, s, (const float*)f->gbuf_den_plane[k], g->density_plane[k], 16, HW);
-        if (g->density_line[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((L + 63) / 64)), dim3(256), 0, s, (const float*)f->gbuf_den_line[k], g->density_line[k], 16, L);
-        if (g->app_plane[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((HW + 63) / 64)), dim3(256), 0, s, (const float*)f->gbuf_app_plane[k], g->app_plane[k], 48, HW);
-        if (g->app_line[k]) hipLaunchKernelGGL(k_relayout_add, dim3((unsigned)((L + 63) / 64)), dim3(256), 0, s, (const float*)f->gbuf_app_line[k], g->app_line[k], 48, L);
+    {
+        RelayoutAddMulti ra;
+        memset(&ra, 0, sizeof(ra));
+        unsigned blocks = 0;
+        auto add = [&](const float* src, float* dst, int C, long long n) {
+            if (!dst) return;
+            ra.src[ra.count] = src; ra.dst[ra.count] = dst; ra.C[ra.count] = C; ra.HW[ra.count] = n; ra.block0[ra.count] = blocks;
+            blocks += (unsigned)((n + 63) / 64);
+            ra.count++;
+        };
+        for (int k = 0; k < 3; ++k) {
+            const long long HW = (long long)gr[mat1(k)] * gr[mat0(k)], L = gr[vecm(k)];
+            add(f->gbuf_den_plane[k], g->density_plane[k], 16, HW);
+            add(f->gbuf_den_line[k], g->density_line[k], 16, L);
+            add(f->gbuf_app_plane[k], g->app_plane[k], 48, HW);
+            add(f->gbuf_app_line[k], g->app_line[k], 48, L);
+        }
+        ra.block0[ra.count] = blocks;
+        if (blocks) hipLaunchKernelGGL(k_relayout_add, dim3(blocks), dim3(256), 0, s, ra);
     }
     T2N_HIP(hipGetLastError());
     return T2N_OK;
