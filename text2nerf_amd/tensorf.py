@@ -197,14 +197,6 @@ class MLPRender(_ViewHead):
         self._build((3 + 2 * viewpe * 3) + inChanel, featureC)
 
 
-def _adam_has_fused():
-    """torch.optim.Adam accepts `fused` (torch >= 2.0)."""
-    try:
-        return "fused" in torch.optim.Adam.__init__.__code__.co_varnames
-    except Exception:   # pragma: no cover
-        return False
-
-
 class TensorVMSplit(nn.Module):
     def __init__(self, aabb, gridSize, device, density_n_comp=8, appearance_n_comp=24, app_dim=27,
                  shadingMode="MLP_PE", alphaMask=None, near_far=[2.0, 6.0], density_shift=-10, alphaMask_thres=0.001,
@@ -303,11 +295,7 @@ class TensorVMSplit(nn.Module):
 
     # ---- optimiser / regulariser surface ----------------------------------------------------------------------------
     def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
-        """models/tensoRF.py:164-174: same groups, same order. Opt-in (``tensorf.optimizer_hints = True``, parameters on the GPU): every
-        group also carries ``"fused": True``, so that the driver's ``torch.optim.Adam(grad_vars, betas=(0.9, 0.99))``
-        (text2nerf_main.py:453-454) runs torch's single-kernel Adam over the 69.6 MB of parameters — 0.15 ms per step against 0.5 ms
-        for the default multi-pass implementation. Same update to ~1e-7 per step, but not bit-identical to the default one (Adam's
-        normalised step amplifies that into different trajectories within a few steps), hence off by default."""
+        """models/tensoRF.py:164-174: same groups, same order."""
         groups = [{"params": self.density_line, "lr": lr_init_spatialxyz},
                   {"params": self.density_plane, "lr": lr_init_spatialxyz},
                   {"params": self.app_line, "lr": lr_init_spatialxyz},
@@ -315,9 +303,6 @@ class TensorVMSplit(nn.Module):
                   {"params": self.basis_mat.parameters(), "lr": lr_init_network}]
         if isinstance(self.renderModule, nn.Module):
             groups += [{"params": self.renderModule.parameters(), "lr": lr_init_network}]
-        if getattr(self, "optimizer_hints", False) and self.basis_mat.weight.is_cuda and _adam_has_fused():
-            for g in groups:
-                g["fused"] = True
         return groups
 
     def TV_loss_density(self, reg):
