@@ -133,7 +133,15 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0, check=None):
     return out
 
 
-def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_step=False):
+def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_step=False, batch=16384):
+    keep_threads = torch.get_num_threads()
+    try:
+        return _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch)
+    finally:
+        torch.set_num_threads(keep_threads)     # the loop below runs on half the cores; callers (CPU baseline, other legs) get theirs back
+
+
+def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch):
     """C3-shaped optimisation step (text2nerf_main.py:547-601): 16 384 random rays of 9 small-baseline 512x512 views,
     N=259, is_train, MSE(rgb)+0.005 MSE(depth)+1e3 transmittance+TV(density 0.1, app 0.01), Adam(0.02/1e-3).
     With `dist` (world > 1): data-parallel — the SAME 16 384-ray batch is split into equal shards (strong scaling), local
@@ -171,7 +179,6 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_ste
     tv, tl = TVLoss(), TransMittanceLoss_mask(dev)
     np.random.seed(1024)
     torch.manual_seed(1024)
-    batch = 16384
     perm = torch.from_numpy(np.random.permutation(allrays.shape[0]))
 
     if dist is not None:
@@ -236,6 +243,8 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_ste
                 "train_dp_step": f"data-parallel x{world}: {batch} rays split into {hi - lo}/GPU (strong scaling), in-place all-reduce of the "
                                  f"{field.factor_grad_buffer().numel() * 4 / 1e6:.1f} MB channel-last factor-gradient buffer + one small flat "
                                  f"message for the head, fused loss + TV + Adam on the device copies, loss {float(loss.detach()):.4f}"}
+    if fused_step and batch != 16384:
+        return {"ms_per_iter": dt / iters * 1e3, "rays": batch}
     if fused_step:
         return {"train_iters_per_s_fused_step": iters / dt, "train_ms_per_iter_fused_step": dt / iters * 1e3,
                 "train_step_fused": "TensorVMSplit.train_step: no autograd graph, loss + its gradients in one kernel, event-based row "
@@ -246,6 +255,159 @@ def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_ste
             "train_step": f"C3-shaped: {batch} rays x {n_samples} samples, fwd+bwd HIP, TV+Adam torch (reference-form "
                           f"step), loss {float(loss.detach()):.4f}; *_fused_optim: TV gradient + Adam as HIP kernels",
             "train_appearance_samples": field.stats()["appearance"]}
+
+
+def dropin_eval_ms(field, dev, H, W, n=5):
+    """The reference's own evaluation call, unchanged (renderer.py:85-89): ALL rays of one image as a HOST tensor into
+    OctreeRender_trilinear_fast(rays, tensorf, chunk=..., N_samples=-1, ...) — H2D through the pinned ring, raster width detected
+    from the rays, (a) the full 5-tuple with weights / z_vals [R, N] materialised like the reference returns them, (b) what
+    `evaluation` keeps (rgb + depth; text2nerf_amd.renderer.evaluation switches the two [R, N] tensors off)."""
+    from text2nerf_amd import OctreeRender_trilinear_fast, synth
+    rays = torch.from_numpy(synth.frame_rays_np(H, W))
+    keep = field.frame_width, field.materialize_weights
+    out = {}
+    try:
+        field.frame_width = 0
+        for name, mat in (("full_5tuple_host_rays", True), ("rgb_depth_only_host_rays", False)):
+            field.materialize_weights = mat
+            with torch.no_grad():
+                for _ in range(2):
+                    OctreeRender_trilinear_fast(rays, field, chunk=16384, N_samples=-1, white_bg=True, device=dev)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    r = OctreeRender_trilinear_fast(rays, field, chunk=16384, N_samples=-1, white_bg=True, device=dev)
+                torch.cuda.synchronize()
+            out[name] = (time.perf_counter() - t0) / n * 1e3
+            del r
+    finally:
+        field.frame_width, field.materialize_weights = keep
+    return out
+
+
+def scaling_prediction(field, dev, fused_ms, G=8):
+    """What ONE GPU can say about N = 8 (no multi-GPU node is available to the builder): (i) C4 — the 8 tiles of the ONE 1600x1600
+    frame timed separately, as contiguous row blocks and as interleaved 8-row bands: the frame is done when the slowest tile is, so
+    predicted efficiency = mean / max of the tile times (the all-gather of 8 x 5.1 MB is priced from the xGMI link rate);
+    (ii) data-parallel training — the fused step at 16384 / G rays on one GPU is the per-rank time, plus the in-place all-reduce of
+    the 69.6 MB gradient buffer priced from the link rate."""
+    from text2nerf_amd import generate_rays
+    from text2nerf_amd.parallel import band_shard, shard_bounds
+    H = W = 1600
+    fl = float(W)
+    keep = field.frame_width, field.materialize_weights
+    field.frame_width, field.materialize_weights = W, False
+    pred = {"n_gpus": G}
+    try:
+        rays = generate_rays(H, W, [fl, fl, W // 2, H // 2], np.eye(4, dtype=np.float32), device=dev)
+        R = rays.shape[0]
+
+        def t_ms(r, n=5):
+            with torch.no_grad():
+                for _ in range(2):
+                    field(r, white_bg=True, is_train=False, N_samples=-1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    field(r, white_bg=True, is_train=False, N_samples=-1)
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+
+        full = t_ms(rays)
+        cont = [t_ms(rays[slice(*shard_bounds(R, G, r))].contiguous()) for r in range(G)]
+        inter = [t_ms(band_shard(rays, W, G, r).contiguous()) for r in range(G)]
+        # all-gather of G equal [R / G, 4] tiles: each rank's 5.12 MB goes to its 7 peers over 7 separate xGMI links (~153 GB/s
+        # each, priced at 70 %) + ~30 us of launch / synchronisation
+        ag_ms = (R // G) * 16 / (153e9 * 0.7) * 1e3 + 0.03
+        pred["c4"] = {
+            "single_gpu_frame_ms": full, "tile_ms_contiguous": cont, "tile_ms_interleaved": inter,
+            "balance_contiguous": sum(cont) / G / max(cont), "balance_interleaved": sum(inter) / G / max(inter),
+            "all_gather_estimate_ms": ag_ms,
+            "predicted_speedup_contiguous": full / (max(cont) + ag_ms), "predicted_speedup_interleaved": full / (max(inter) + ag_ms),
+            "predicted_8gpu_efficiency": full / (max(inter) + ag_ms) / G,
+            "note": "bench.py --mode c4 uses interleaved bands when the rows divide evenly (--c4-tiles); a tile's time includes its "
+                    "fixed per-frame costs (launches, counter read-back), which do not shrink with 1 / G"}
+    except Exception as e:  # noqa: BLE001
+        pred["c4"] = {"error": repr(e)[:300]}
+    finally:
+        field.frame_width, field.materialize_weights = keep
+    if fused_ms is not None:
+        try:
+            steps = {16384: fused_ms}
+            for b in (8192, 4096, 2048):
+                steps[b] = train_bench(dev, iters=20, warmup=3, fused_step=True, batch=b)["ms_per_iter"]
+            # direct reduce-scatter + all-gather of the 69.6 MB buffer over 7 links per GPU: 2 x (bytes / 8) per link
+            ar_ms = 2 * (69.6e6 / G) / (153e9 * 0.7) * 1e3 + 0.05
+            pred["train_dp"] = {"fused_step_ms_by_rays_per_gpu": {str(k): v for k, v in steps.items()},
+                                "all_reduce_estimate_ms": ar_ms,
+                                "predicted_8gpu_step_ms": steps[16384 // G] + ar_ms,
+                                "predicted_speedup": fused_ms / (steps[16384 // G] + ar_ms),
+                                "note": "strong scaling of ONE 16 384-ray batch: the step at 2 048 rays / GPU is a chain of ~30 launches whose "
+                                        "fixed cost does not shrink; the all-reduce is not overlapped with the backward (the scatter kernels "
+                                        "finish the factor gradients last)"}
+        except Exception as e:  # noqa: BLE001
+            pred["train_dp"] = {"error": repr(e)[:300]}
+    pred["weak_c2"] = {"note": "default --gpus N mode: one independent 800x800 view per GPU, the 10 MB all-gather of frame k overlaps the "
+                               "render of frame k + 1 (async): no shared resource but the host; predicted efficiency ~1.0"}
+    return pred
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: this process — which has made NO GPU call (importing torch and counting
+    devices do not initialise HIP) — starts N fresh child ranks of the same command (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / a free MASTER_PORT), relays rank 0's stdout (the ONE JSON line), lets the ranks' stderr through and
+    returns the first non-zero exit code (the other ranks are then killed by PID). Nothing is exec'ed and no process that has
+    touched the GPU is re-launched. The `python -m torch.distributed.run ... bench.py --gpus N` form (WORLD_SIZE already set)
+    never comes through here."""
+    import socket
+    import subprocess
+    same = bool(os.environ.get("T2N_BENCH_SAME_DEVICE"))
+    have = torch.cuda.device_count()
+    if have < n and not same:
+        print(f"bench.py --gpus {n}: this node shows {have} GPU(s); one rank per GPU is required "
+              f"(T2N_BENCH_SAME_DEVICE=1 T2N_BENCH_BACKEND=gloo runs the N>1 code path on one device for testing)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), T2N_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env["OMP_NUM_THREADS"] = str(max(1, HOST_CORES // n))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + float(os.environ.get("T2N_BENCH_LAUNCH_DEADLINE_S", "1500"))
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if bad or time.time() > deadline:
+            rc = bad[0] if bad else 124
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()          # the exact children started above
+            break
+        time.sleep(0.2)
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    for p in procs:
+        p.wait()
+        if rc == 0 and p.returncode != 0:
+            rc = p.returncode
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
+def device_identity(dev):
+    """What tells two GPUs apart (for the rank evidence in the JSON line): index, name, uuid / PCI ids where torch exposes them."""
+    pr = torch.cuda.get_device_properties(dev)
+    d = {"index": dev.index, "name": pr.name}
+    for k in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        v = getattr(pr, k, None)
+        if v is not None:
+            d[k] = str(v)
+    return d
 
 
 def main():
@@ -266,18 +428,22 @@ def main():
                     help="weak: one 800x800 view per GPU (C2, the headline); c4: BASELINE configs[3] — ONE 1600x1600 frame split "
                          "into contiguous ray tiles over the ranks, all-gather of the rgb+depth tiles inside every step "
                          "(strong scaling)")
+    ap.add_argument("--c4-tiles", default="auto", choices=["auto", "contiguous", "interleaved"],
+                    help="c4 mode: how the frame's rows go to the ranks — interleaved 8-row bands (balanced: every rank sees the same mix of "
+                         "border and centre rays) or contiguous row blocks; auto = interleaved when the rows divide evenly")
     ap.add_argument("--check-c4", action="store_true",
                     help="c4 mode: rank 0 also renders the whole frame alone and compares it bitwise with the gathered one")
     ap.add_argument("--train-iters", type=int, default=20)
     ap.add_argument("--train-warmup", type=int, default=3)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))      # parent of N fresh ranks; has not touched the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (plain `python bench.py --gpus N` does)")
     torch.set_num_threads(max(1, min(HOST_CORES // max(world, 1), 16)))
     same_device = bool(os.environ.get("T2N_BENCH_SAME_DEVICE"))   # functional test of the N>1 path on a 1-GPU box (gloo)
     if same_device:
@@ -314,8 +480,15 @@ def main():
                 else:
                     break
         note("gpu and process group ready")
+        ids = [None] * world
+        dist.all_gather_object(ids, dict(device_identity(dev), rank=rank, local_rank=local_rank, pid=os.getpid()))
+        key = lambda d: d.get("uuid") or d.get("pci_bus_id") or d["index"]   # noqa: E731
+        rccl = {"backend": dist.get_backend(), "is_rccl": dist.get_backend() == "nccl", "world_size": dist.get_world_size(),
+                "launcher": "bench.py self-launch" if os.environ.get("T2N_BENCH_SELF_LAUNCHED") else "external (torch.distributed.run)",
+                "ranks": ids, "distinct_devices": len({key(d) for d in ids})}
     else:
         gpu_up()
+        rccl = None
 
     from text2nerf_amd import generate_rays, synth
     from text2nerf_amd.parallel import all_gather_tiles
@@ -333,12 +506,20 @@ def main():
     pose = poses[rank % len(poses)] if world > 1 and not c4 else np.eye(4, dtype=np.float32)
     f = float(max(H, W))
     rays = generate_rays(H, W, [f, f, W // 2, H // 2], pose, device=dev)   # resident in HBM before the timed region
-    if c4:   # this rank's contiguous tile of the ONE frame (whole image rows: 1600 x 1600 / 8 ranks = 200 rows each)
-        from text2nerf_amd.parallel import shard_bounds, tile_capacity
+    bands = False
+    if c4:   # this rank's part of the ONE frame: every world-th 8-row band (1600 rows / 8 ranks = 25 bands each), or a contiguous block
+        from text2nerf_amd.parallel import band_layout, band_shard, band_unshard, shard_bounds, tile_capacity
         frame_rays, R_frame = rays, rays.shape[0]
-        lo, hi = shard_bounds(R_frame, world, rank)
-        cap = tile_capacity(R_frame, world)
-        rays = frame_rays[lo:hi].contiguous()
+        bands = args.c4_tiles != "contiguous" and band_layout(R_frame, W, world) is not None
+        if args.c4_tiles == "interleaved" and not bands:
+            raise SystemExit(f"--c4-tiles interleaved: {H} rows do not divide into {world} x 8-row bands")
+        if bands:
+            rays = band_shard(frame_rays, W, world, rank).contiguous()
+            cap = rays.shape[0]
+        else:
+            lo, hi = shard_bounds(R_frame, world, rank)
+            cap = tile_capacity(R_frame, world)
+            rays = frame_rays[lo:hi].contiguous()
         if not args.check_c4:
             del frame_rays
     R = rays.shape[0]
@@ -401,9 +582,12 @@ def main():
             with torch.no_grad():
                 s_rgb, s_depth, _, _ = field(frame_rays, white_bg=True, is_train=False, N_samples=-1)
             if world > 1:
-                g = g.view(world, cap, 4)
-                g = torch.cat([g[r, : shard_bounds(R_frame, world, r)[1] - shard_bounds(R_frame, world, r)[0]]
-                               for r in range(world)], 0)
+                if bands:
+                    g = band_unshard(g, W, world)
+                else:
+                    g = g.view(world, cap, 4)
+                    g = torch.cat([g[r, : shard_bounds(R_frame, world, r)[1] - shard_bounds(R_frame, world, r)[0]]
+                                   for r in range(world)], 0)
                 c4_equal = bool(torch.equal(g[:, :3], s_rgb) and torch.equal(g[:, 3], s_depth))
             else:
                 c4_equal = bool(torch.equal(g, s_rgb))
@@ -492,7 +676,8 @@ def main():
             "dtype": "f32" + (" (basis/MLP products as f16x2-split MFMA, fp32 accumulate)" if split else "") +
                      ("; factor tensors stored as bf16" if args.factor_storage == "bf16" else ""),
             "data": "synthetic",
-            "config": {"workload": (f"C4: TensorVMSplit 300^3, ONE 1600x1600 frame in {world} contiguous ray tiles, "
+            "config": {"workload": (f"C4: TensorVMSplit 300^3, ONE 1600x1600 frame in {world} ray tiles "
+                                    f"({'interleaved 8-row bands' if bands else 'contiguous row blocks'}), "
                                     if c4 else "C2: TensorVMSplit 300^3, 800x800 view/GPU, ") +
                                    f"{N} samples/ray, render_only, scene "
                                    f"{args.scene} seed 0, white_bg, weights/z_vals materialised: {bool(args.weights)}, "
@@ -505,16 +690,22 @@ def main():
                                                                "next frame's render)") if world > 1 else ""),
                        "kernel_ms_per_frame": frame_ms,
                        "kernel_rooflines": roofs,
-                       "scaling_measured": "no multi-GPU scaling curve has been measured by the builder (1-GPU boxes only)"},
+                       "scaling_measured": "the builder has 1-GPU boxes only: see scaling_prediction (N = 1 line) for what one GPU can "
+                                           "say about N = 8, and rccl (N > 1 lines) for the devices the ranks actually ran on"},
             "roofline": roof,
         }
         out["config"].update(dp)
+        if rccl is not None:
+            rccl["all_gather_bytes_per_rank_per_step"] = int((cap if c4 else R) * 16)
+            rccl["all_gather_bytes_total_per_step"] = int((cap if c4 else R) * 16 * world)
+            if dp:
+                rccl["all_reduce_bytes_per_train_step"] = int(sum(p.numel() for p in field._all_params()[:12]) * 4)
+            out["config"]["rccl"] = rccl
         try:   # render scratch actually reserved (appearance lists budgeted from the previous frame) next to the worst-case figure
             from text2nerf_amd import _lib as _L, tensorf as _tf
             _l = _L.load()
-            _ws = _tf._WORKSPACE.get(str(dev))
             out["config"]["workspace"] = {
-                "reserved_GiB": round((_ws.numel() if _ws is not None else 0) / 2 ** 30, 2),
+                "reserved_GiB": round(_tf.workspace_reserved(dev) / 2 ** 30, 2),
                 "worst_case_GiB": round(int(_l.t2n_render_workspace_bytes(R, N)) / 2 ** 30, 2),
                 "steady_state_hint_GiB": round(int(_l.t2n_render_workspace_bytes_hint(field.sync_params(), R, N)) / 2 ** 30, 2),
                 "list_retries": int(_l.t2n_field_list_retries(field.sync_params())),
@@ -585,14 +776,17 @@ def main():
                                "achieved_TFLOPs": FLOP_PER_APP * A / t / 1e12, "peak_TFLOPs": MFMA_F32_PEAK_TF,
                                "frac": FLOP_PER_APP * A / t / 1e12 / MFMA_F32_PEAK_TF})
                 out["exact_fp32"] = ex
+        if world == 1 and not c4 and not args.quick:
+            try:
+                out["config"]["dropin_eval_call_ms"] = dropin_eval_ms(field, dev, H, W)
+            except Exception as e:  # noqa: BLE001
+                out["config"]["dropin_eval_call_ms"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_train:
-            host_threads = torch.get_num_threads()
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup))
-            torch.set_num_threads(host_threads)
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True))
-            torch.set_num_threads(host_threads)
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True))
-            torch.set_num_threads(host_threads)   # (train_bench runs its loop on half the cores; the CPU baseline below uses all)
+        if world == 1 and not c4 and not args.quick:
+            out["scaling_prediction"] = scaling_prediction(field, dev, out["config"].get("train_ms_per_iter_fused_step"))
         if world == 1 and not args.no_cpu_baseline:
             def hip_render(r):
                 with torch.no_grad():

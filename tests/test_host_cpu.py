@@ -138,6 +138,17 @@ def fn(r):
 rgb, depth = render_sharded(rays, fn)
 full_rgb, full_depth = fn(rays)
 assert torch.equal(rgb, full_rgb) and torch.equal(depth, full_depth), "gathered tiles must equal the unsharded render bitwise"
+# a row-major frame whose rows divide into world x 8-row bands: interleaved bands, same result bitwise
+frame = torch.from_numpy(synth.frame_rays_np(32, 11, c2w=synth.look_pose(0.3, -0.1, (0.2, 0.1, -1.0))))
+seen = []
+def fn2(r):
+    seen.append(r.shape[0])
+    return fn(r)
+rgb, depth = render_sharded(frame, fn2, frame_width=11)
+full_rgb, full_depth = fn(frame)
+assert seen == [32 * 11 // 2] and torch.equal(rgb, full_rgb) and torch.equal(depth, full_depth), "interleaved bands"
+rgb, depth = render_sharded(frame[: 24 * 11], fn, frame_width=11)          # 24 rows: not 2 x 8 x k -> contiguous tiles
+assert torch.equal(rgb, fn(frame[: 24 * 11])[0])
 dist.barrier()
 dist.destroy_process_group()
 print("OK", os.environ["RANK"])
@@ -257,3 +268,113 @@ def test_raster_width_detection_for_drop_in_evaluation():
     assert detect_frame_width(raster(7, 64, 60.0, pose)) == 0   # fewer than 8 rows
     assert detect_frame_width(r[: 64 * 10 + 5]) == 0         # the width does not divide the ray count
     assert detect_frame_width(r[:40]) == 0
+
+
+def test_band_interleaved_sharding_round_trip():
+    """parallel.band_layout / band_shard / band_unshard (C4: every rank takes every world-th 8-row band of the frame)."""
+    from text2nerf_amd.parallel import band_layout, band_shard, band_unshard
+    assert band_layout(1600 * 1600, 1600, 8) == (25, 8 * 1600)
+    assert band_layout(1600 * 1600, 1600, 7) is None and band_layout(100, 0, 2) is None and band_layout(101, 10, 2) is None
+    W, H, world = 16, 64, 4
+    rays = torch.arange(W * H * 6, dtype=torch.float32).view(W * H, 6)
+    parts = [band_shard(rays, W, world, r) for r in range(world)]
+    assert all(p.shape == (W * H // world, 6) for p in parts)
+    assert torch.equal(parts[1][:8 * W], rays[8 * W:16 * W])               # rank 1's first band = image rows 8..15
+    assert torch.equal(band_unshard(torch.cat(parts), W, world), rays)
+
+
+def test_bench_gpus_n_without_launcher_refuses_cleanly_without_gpus():
+    """`python bench.py --gpus 2` with no WORLD_SIZE self-launches; on a node with fewer GPUs it must say so and exit 2 — from
+    the parent, before any rank exists."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "T2N_BENCH_SAME_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 2 and "one rank per GPU" in p.stderr and p.stdout.strip() == ""
+
+
+class _FakeDataset:
+    """What renderer.evaluation / evaluation_path read from a SceneGenDataset (dataLoader/scene_gen.py)."""
+
+    def __init__(self, split, n_views, H, W):
+        from text2nerf_amd import synth
+        self.split, self.img_wh, self.near_far = split, (W, H), [0.5, 8.0]
+        g = torch.Generator().manual_seed(0)
+        rays = torch.stack([torch.from_numpy(synth.frame_rays_np(H, W, c2w=synth.look_pose(0.1 * v, 0.0, (0.0, 0.0, 0.0))))
+                            for v in range(n_views)])
+        self.all_rays_split = rays
+        self.all_rays_sprt_split = rays[:2]
+        self.all_rays_gen_split = rays
+        self.all_rgbs_gen_split = torch.rand(n_views, H * W, 3, generator=g)
+        self.directions = torch.from_numpy(synth.ray_directions_np(H, W, float(W), float(W), W // 2, H // 2))
+        self.focal = [float(W), float(W)]
+
+
+def test_evaluation_and_evaluation_path_drop_in(tmp_path, monkeypatch):
+    """renderer.evaluation / evaluation_path with the reference's signatures (renderer.py:44-197): view selection by split /
+    preview / N_iter / N_vis, one renderer call per view with all rays of the image, file names, PSNR list. The renderer and the
+    post-processing kernel are stood in for on the CPU (fake renderer; the oracle's postprocess_frame) — the GPU forms are covered
+    by tests/test_postprocess.py and the parity suite."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from oracle import oracle_torch as O
+    from text2nerf_amd import renderer as Rm
+    H, W = 12, 16
+    calls = []
+
+    def fake_renderer(rays, tensorf, chunk=4096, N_samples=-1, ndc_ray=False, white_bg=True, is_train=False, device="cuda"):
+        calls.append((tuple(rays.shape), chunk, N_samples, white_bg, tensorf.materialize_weights))
+        t = torch.linspace(0, 1, rays.shape[0])
+        return torch.stack([t, 1 - t, 0.5 * t], 1) * 1.2 - 0.1, None, 2.0 + 5.0 * t, None, None
+
+    def fake_post(rgb, depth, near_far, push_depth=None, gt_rgb=None):
+        r8, d8, ps = O.postprocess_frame(rgb.numpy(), depth.numpy(), near_far, push_depth=push_depth,
+                                         gt_rgb=None if gt_rgb is None else gt_rgb.numpy())
+        return torch.from_numpy(r8), torch.from_numpy(d8), ps
+
+    monkeypatch.setattr(Rm, "postprocess_frame", fake_post)
+    monkeypatch.setattr(Rm, "get_rays_for_path", None, raising=False)
+    field = SimpleNamespace(materialize_weights=True, device="cpu")
+    args = SimpleNamespace(batch_size=4096, push_depth=2.0)
+    ds = _FakeDataset("train", 5, H, W)
+    out = tmp_path / "inpaint"
+    psnrs = Rm.evaluation(ds, field, args, fake_renderer, str(out), N_vis=-1, prtx="e01_", N_samples=77, white_bg=True,
+                          compute_extra_metrics=True, device="cpu", N_iter=2, preview=False)
+    assert len(psnrs) == 3 and all(np.isfinite(p) for p in psnrs)          # views [: N_iter + 1] with ground truth
+    assert calls == [((H * W, 6), 4096, 77, True, False)] * 3 and field.materialize_weights is True
+    assert sorted(os.listdir(out / "rgbs")) == [f"e01_{i:03d}_rgb.png" for i in range(3)]
+    assert sorted(os.listdir(out / "depths")) == [f"e01_{i:03d}_depth.png" for i in range(3)]
+    img = np.asarray(Image.open(out / "rgbs" / "e01_000_rgb.png"))
+    t = torch.linspace(0, 1, H * W)
+    want = ((torch.stack([t, 1 - t, 0.5 * t], 1) * 1.2 - 0.1).clamp(0, 1).numpy() * 255).astype("uint8").reshape(H, W, 3)
+    assert img.shape == (H, W, 3) and np.array_equal(img, want)
+    # PSNR of view 0 as the reference computes it (renderer.py:100-101)
+    gt = ds.all_rgbs_gen_split[0].view(H, W, 3)
+    ref = -10.0 * np.log(float(torch.mean((torch.from_numpy(want.astype(np.float32)) * 0 + (torch.stack([t, 1 - t, 0.5 * t], 1) * 1.2 - 0.1)
+                                           .clamp(0, 1).view(H, W, 3) - gt) ** 2))) / np.log(10.0)
+    assert abs(psnrs[0] - ref) < 1e-4
+    # preview = support views, no ground truth -> no PSNR; compute_extra_metrics False (the driver's per-epoch call) likewise
+    calls.clear()
+    assert Rm.evaluation(ds, field, args, fake_renderer, str(tmp_path / "sprt"), N_vis=-1, compute_extra_metrics=False, device="cpu",
+                         preview=True) == []
+    assert len(calls) == 2
+    assert Rm.evaluation(ds, field, args, fake_renderer, None, N_vis=-1, compute_extra_metrics=False, device="cpu", N_iter=4) == []
+    # test split: every view, N_vis subsampling (5 views, N_vis = 2 -> interval 2 -> views 0, 2, 4)
+    calls.clear()
+    dt = _FakeDataset("test", 5, H, W)
+    Rm.evaluation(dt, field, args, fake_renderer, str(tmp_path / "test"), N_vis=2, device="cpu", video_gen=True)
+    assert len(calls) == 3 and len(os.listdir(tmp_path / "test" / "rgbs")) == 3
+
+    # evaluation_path: rays from get_rays(directions, c2w) (a HIP kernel in the product; the oracle's here)
+    def cpu_get_rays(directions, c2w):
+        return O.get_rays(directions, c2w)
+    import text2nerf_amd.ray_utils as RU
+    monkeypatch.setattr(RU, "get_rays", cpu_get_rays)
+    calls.clear()
+    c2ws = [np.eye(4, dtype=np.float32)[:3], np.eye(4, dtype=np.float32)[:3]]
+    res = Rm.evaluation_path(dt, field, c2ws, fake_renderer, str(tmp_path / "path"), prtx="p_", N_samples=-1, white_bg=True, device="cpu")
+    assert res == [] and calls == [((H * W, 6), 8192, -1, True, False)] * 2
+    assert sorted(os.listdir(tmp_path / "path")) == ["p_000.png", "p_001.png", "rgbd"]
+    rgbd = np.asarray(Image.open(tmp_path / "path" / "rgbd" / "p_001.png"))
+    assert rgbd.shape == (H, 2 * W, 3) and np.array_equal(rgbd[:, :W], want)

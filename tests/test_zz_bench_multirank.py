@@ -88,6 +88,9 @@ def test_two_ranks_on_one_gpu_over_gloo(tmp_path):
     assert "train_dp_error" not in d["config"], d["config"].get("train_dp_error")
     assert d["config"]["train_dp_iters_per_s"] > 0 and "all-reduce" in d["config"]["train_dp_step"]
     assert "cpu_baseline" not in d                       # rank 0 at N = 1 only
+    ev = d["config"]["rccl"]                              # which devices the ranks ran on (here: gloo, both on device 0)
+    assert ev["backend"] == "gloo" and ev["world_size"] == 2 and len(ev["ranks"]) == 2 and ev["distinct_devices"] == 1
+    assert ev["all_gather_bytes_per_rank_per_step"] == 640000 * 16 and ev["all_reduce_bytes_per_train_step"] > 6e7
 
 
 def test_c4_mode_two_ranks_on_one_gpu_over_gloo(tmp_path):
@@ -101,4 +104,37 @@ def test_c4_mode_two_ranks_on_one_gpu_over_gloo(tmp_path):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["c4_gathered_equals_single_rank"] is True
-    assert "1600x1600" in d["config"]["workload"]
+    assert "1600x1600" in d["config"]["workload"] and "interleaved 8-row bands" in d["config"]["workload"]
+
+
+def test_c4_mode_contiguous_tiles_two_ranks(tmp_path):
+    rcs, outs, errs = run_ranks(tmp_path, ["--mode", "c4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-train",
+                                           "--check-c4", "--c4-tiles", "contiguous"])
+    check_finished(rcs, outs, errs)
+    d = one_json_line(outs)
+    assert d["config"]["c4_gathered_equals_single_rank"] is True and "contiguous row blocks" in d["config"]["workload"]
+
+
+def test_plain_bench_gpus_2_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent starts two fresh ranks itself (before touching
+    the GPU), relays rank 0's ONE JSON line and exits 0. Same-device / gloo here (a 1-GPU box); on an 8-GPU node the same command
+    without the two T2N_BENCH_* variables runs one rank per GPU over RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(T2N_BENCH_BACKEND="gloo", T2N_BENCH_SAME_DEVICE="1", GLOO_SOCKET_IFNAME="lo", T2N_BENCH_DEADLINE_S="150",
+               T2N_BENCH_LAUNCH_DEADLINE_S="170", PYTHONFAULTHANDLER="1")
+    with open(tmp_path / "err.log", "w+") as fe:
+        p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                              "--no-cpu-baseline", "--no-train"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=fe, text=True,
+                             start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=200)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        fe.seek(0)
+        err = fe.read()
+    if p.returncode != 0 and "gpu and process group ready" not in err:
+        pytest.skip("two ranks could not bring up the one GPU of this box (not the launcher):\n" + err[-3000:])
+    assert p.returncode == 0, err[-3000:]
+    d = one_json_line([out])
+    assert d["n_gpus"] == 2 and d["config"]["rccl"]["launcher"] == "bench.py self-launch" and len(d["config"]["rccl"]["ranks"]) == 2

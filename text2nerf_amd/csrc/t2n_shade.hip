@@ -872,7 +872,12 @@ __global__ __launch_bounds__(64 * kPairWaves) __attribute__((amdgpu_waves_per_eu
     for (unsigned tile = blockIdx.x * (unsigned)kPairWaves + wid; tile < ntiles; tile += wave_stride, base = nbase, nlive = nnlive, mine = nmine) {
         if (lane < 32) {   // (dead entries sit at the volume centre: in the box like every list entry)
             const Axes3 A = sample_axes_inbox(F.app, mine.x, mine.y, mine.z);
-            P[2 * lane] = make_float4(__int_as_float(A.a[0].i0), __int_as_float(A.a[1].i0), __int_as_float(A.a[2].i0), mine.w);
+            // list slots that were reserved but never written (a budgeted launch that overflowed: this kernel is already queued when
+            // the host learns of it) hold stale workspace bytes: whatever they decode to, the taps stay inside the planes
+            // (parked_axes: high tap = min(low + 1, size - 1)); such rows belong to no ray's slice and are never composited
+            const int ix = min(max(A.a[0].i0, 0), F.app.W[0] - 1), iy = min(max(A.a[1].i0, 0), F.app.H[0] - 1),
+                      iz = min(max(A.a[2].i0, 0), F.app.H[1] - 1);
+            P[2 * lane] = make_float4(__int_as_float(ix), __int_as_float(iy), __int_as_float(iz), mine.w);
             P[2 * lane + 1] = make_float4(A.a[0].w1, A.a[1].w1, A.a[2].w1, 0.f);
         }
         locate(tile + wave_stride, nbase, nnlive, nmine);

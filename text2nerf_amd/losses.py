@@ -49,11 +49,21 @@ class _TVPlaneSum(torch.autograd.Function):
         return (None, *grads)
 
 
+def _is_plain_tvloss(reg):
+    """The fused kernels hard-code TVLoss.forward (utils.py:488-504): take them only for that arithmetic — this module's TVLoss,
+    the reference's own class (``utils.TVLoss``, matched by qualified name since it cannot be imported here), or a regulariser that
+    opts in with ``reg.t2n_fused_tv = True``. A subclass or look-alike with a different forward (L1 TV, masked TV) is called."""
+    if getattr(reg, "t2n_fused_tv", False):
+        return True
+    t = type(reg)
+    return t is TVLoss or (t.__name__ == "TVLoss" and t.__module__.split(".")[-1] == "utils")
+
+
 def tv_planes(reg, planes, scale):
-    """sum_p reg(p) * scale for a TVLoss-like `reg` (an object with a float `TVLoss_weight`, like utils.TVLoss) on contiguous fp32
+    """sum_p reg(p) * scale for a plain TVLoss `reg` (see _is_plain_tvloss; weight = its float `TVLoss_weight`) on contiguous fp32
     [1,C,H,W] device planes through the HIP kernels; None when that does not apply (the caller then evaluates reg(p) itself)."""
     w = getattr(reg, "TVLoss_weight", None)
-    if w is None or not planes:
+    if w is None or not planes or not _is_plain_tvloss(reg):
         return None
     for p in planes:
         if not (p.is_cuda and p.dtype == torch.float32 and p.dim() == 4 and p.shape[0] == 1 and p.shape[2] > 1 and p.shape[3] > 1

@@ -55,10 +55,13 @@ class TVAdam(torch.optim.Optimizer):
                                 "(call backward, with tensorf.defer_factor_grads still set, before every step)")
         f.factor_grad_buffer()
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and not getattr(f, "_gbuf_reduced", False):
+        # (opt out with field.require_reduced_grads = False: ranks that train independent scenes, a caller that reduces the buffer
+        # itself, or a non-default process group)
+        if getattr(f, "require_reduced_grads", True) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 \
+                and not getattr(f, "_gbuf_reduced", False):
             raise _lib.T2NError("TVAdam(field=...): more than one rank — all-reduce the device-side factor gradients first "
                                 "(parallel.allreduce_gradients(params, field=tensorf)); stepping from local gradients would let the "
-                                "ranks drift apart")
+                                "ranks drift apart (field.require_reduced_grads = False turns this check off)")
         tv_d = tv_a = 0.0
         for planes, weight in tv:
             if planes is f.density_plane:

@@ -31,12 +31,46 @@ def all_gather_tiles(tile: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
-def render_sharded(rays: torch.Tensor, render_fn, group=None):
-    """Render `rays` [R, >=6] cooperatively: each rank renders its contiguous tile with `render_fn(rays_tile) ->
-    (rgb [n,3], depth [n])`, then the tiles are all-gathered. Returns (rgb [R,3], depth [R]) on every rank, bitwise
-    equal to the single-GPU result because every ray is computed by exactly one rank with the same kernels."""
+def band_layout(n_rays: int, frame_width: int, world: int, band_rows: int = 8):
+    """Interleaved assignment of a row-major frame to `world` ranks in bands of `band_rows` image rows (border and
+    centre rays cross different lengths of the box, so contiguous tiles are unevenly loaded; a rank that takes every world-th band
+    sees the same mix as its peers). Returns ``(bands_per_rank, band_rays)`` when the frame divides evenly — whole rows, a multiple
+    of ``world * band_rows`` of them — else ``None`` (the caller then uses contiguous tiles). ``band_rows = 8`` keeps every band a
+    whole row of the tile marcher's 8x8-pixel tiles."""
+    if not frame_width or frame_width <= 0 or n_rays % frame_width:
+        return None
+    rows = n_rays // frame_width
+    if rows % (world * band_rows):
+        return None
+    return rows // (world * band_rows), band_rows * frame_width
+
+
+def band_shard(rays: torch.Tensor, frame_width: int, world: int, rank: int, band_rows: int = 8):
+    """The rays of `rank` under band_layout: bands rank, rank + world, ... concatenated in image order ([R / world, C])."""
+    per, n = band_layout(rays.shape[0], frame_width, world, band_rows)
+    return rays.view(per, world, n, rays.shape[1])[:, rank].reshape(per * n, rays.shape[1])
+
+
+def band_unshard(gathered: torch.Tensor, frame_width: int, world: int, band_rows: int = 8):
+    """Inverse of band_shard on the all-gathered ``[world * R / world, C]`` tensor (rank-major) -> image order ``[R, C]``."""
+    R = gathered.shape[0]
+    per, n = band_layout(R, frame_width, world, band_rows)
+    return gathered.view(world, per, n, gathered.shape[1]).permute(1, 0, 2, 3).reshape(R, gathered.shape[1])
+
+
+def render_sharded(rays: torch.Tensor, render_fn, group=None, frame_width: int = 0):
+    """Render `rays` [R, >=6] cooperatively: each rank renders its tile with `render_fn(rays_tile) -> (rgb [n,3], depth [n])`, then
+    the tiles are all-gathered (ONE collective of equal-sized [n, 4] tiles). Returns (rgb [R,3], depth [R]) on every rank, bitwise
+    equal to the single-GPU result because every ray is computed by exactly one rank with the same kernels.
+    `frame_width` > 0 states that `rays` is a row-major frame of that width: ranks then take interleaved 8-row bands
+    (band_layout) when the frame divides evenly, contiguous tiles otherwise."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     R = rays.shape[0]
+    if band_layout(R, frame_width, world) is not None:
+        rgb, depth = render_fn(band_shard(rays, frame_width, world, rank).contiguous())
+        tile = torch.cat([rgb, depth[:, None]], 1)
+        out = band_unshard(all_gather_tiles(tile, group), frame_width, world)
+        return out[:, :3].contiguous(), out[:, 3].contiguous()
     lo, hi = shard_bounds(R, world, rank)
     cap = tile_capacity(R, world)
     rgb, depth = render_fn(rays[lo:hi])

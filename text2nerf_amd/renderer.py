@@ -1,6 +1,8 @@
 """Renderer harness with the reference's call surface (renderer.py:14-42)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -21,18 +23,36 @@ class SimpleSampler:
         return self.ids[self.curr:self.curr + self.batch]
 
 
+_FW_CACHE = {}     # (data_ptr, shape, version, device) -> detected width: a loop that re-renders the same ray tensor probes it once
+
+
 def detect_frame_width(rays, probe=8192):
     """Width W of a row-major pinhole raster in `rays` [R, >=6] (what `evaluation` passes: all rays of one image,
     renderer.py:85-89), or 0. Looks at the first `probe` rays on the host: one origin, directions that change smoothly along a row
     and jump at a row's end (consecutive direction deltas differ by more than half their size only there); the jump must repeat at
-    2W - 1 when visible, the second row must start like the first, and R must be a multiple of W with at least 8 rows of at least 8
-    pixels. The hint only selects the tile marcher (8x8-pixel tiles of coherent rays); a wrong guess costs speed, never correctness."""
+    2W - 1 when visible, the second row must start like the first, R must be a multiple of W with at least 8 rows of at least 8
+    pixels, and the first ray of every 8-row band must share the first ray's origin (several views concatenated into one tensor
+    are not one raster). The hint only selects the tile marcher (8x8-pixel tiles of coherent rays); a wrong guess costs speed,
+    never correctness. The result is cached per ray tensor (storage address, shape, version)."""
     R = int(rays.shape[0])
     if R < 64 or rays.shape[1] < 6:
         return 0
+    key = (rays.data_ptr(), tuple(rays.shape), rays._version, str(rays.device))
+    hit = _FW_CACHE.get(key)
+    if hit is not None:
+        return hit
+    W = _detect_frame_width(rays, R, probe)
+    if len(_FW_CACHE) >= 64:
+        _FW_CACHE.clear()
+    _FW_CACHE[key] = W
+    return W
+
+
+def _detect_frame_width(rays, R, probe):
     head = rays[: min(R, probe), :6].detach().float().cpu().numpy()
     o, d = head[:, :3], head[:, 3:6]
-    if not np.all(np.abs(o - o[0]).max(axis=1) <= 1e-6 * (1.0 + np.abs(o[0]).max())):
+    tol = 1e-6 * (1.0 + np.abs(o[0]).max())
+    if not np.all(np.abs(o - o[0]).max(axis=1) <= tol):
         return 0
     delta = d[1:] - d[:-1]
     n = np.linalg.norm(delta, axis=1)
@@ -48,6 +68,10 @@ def detect_frame_width(rays, probe=8192):
     if 2 * W <= head.shape[0]:  # the second row: starts like the first, ends with the same jump
         if np.linalg.norm(delta[W] - delta[0]) > 0.5 * n[0] or not jump[2 * W - 2]:
             return 0
+    if R > head.shape[0]:       # beyond the probe: one origin per 8-row band
+        bo = rays[:: 8 * W, :3].detach().float().cpu().numpy()
+        if not np.all(np.abs(bo - o[0]).max(axis=1) <= tol):
+            return 0
     return W
 
 
@@ -60,14 +84,12 @@ def OctreeRender_trilinear_fast(rays, tensorf, chunk=4096, N_samples=-1, ndc_ray
     generator, so the chunk loop is kept to consume the RNG stream identically (the driver's batch is one chunk)."""
     if not is_train:
         # the driver's evaluation hands over all rays of one image: without an explicit hint the raster width is detected, so that
-        # the frame takes the tile marcher (tensorf.auto_frame_width = False turns that off)
-        keep_w = tensorf.frame_width
-        if not keep_w and not ndc_ray and getattr(tensorf, "auto_frame_width", True):
-            tensorf.frame_width = detect_frame_width(rays)
-        try:
-            rgb, depth, z, w = tensorf(rays, is_train=False, white_bg=white_bg, ndc_ray=ndc_ray, N_samples=N_samples)
-        finally:
-            tensorf.frame_width = keep_w
+        # the frame takes the tile marcher (tensorf.auto_frame_width = False turns that off). The width travels as a call argument:
+        # the module's own frame_width is not touched.
+        fw = None
+        if not tensorf.frame_width and not ndc_ray and getattr(tensorf, "auto_frame_width", True):
+            fw = detect_frame_width(rays)
+        rgb, depth, z, w = tensorf(rays, is_train=False, white_bg=white_bg, ndc_ray=ndc_ray, N_samples=N_samples, frame_width=fw)
         return rgb, None, depth, w, z
     outs = [[], [], [], []]
     n = rays.shape[0]
@@ -150,3 +172,140 @@ def evaluation_frames(tensorf, poses, intrinsic, H, W, near_far, N_samples=-1, w
         if p is not None:
             psnrs.append(p)
     return torch.stack(out_rgb), torch.stack(out_dep), psnrs
+
+
+# ---- the reference's evaluation loops with their own signatures (renderer.py:44-197) -----------------------------------------
+# Only what the hot path produces is computed here: the render through `renderer`, the post-processing kernel (uint8 rgb, JET
+# depth map, PSNR sum on the device) and the image files. SSIM / LPIPS are metric packages outside this path: they are called
+# through the two hooks below when the integrator installs them (`text2nerf_amd.renderer.rgb_ssim = utils.rgb_ssim`), and skipped
+# otherwise. Videos need imageio (absent from this image): written when it is importable, skipped with a notice when not.
+rgb_ssim = None      # callable (img0 [H,W,3] np/tensor, img1, max_val) -> float           (utils.py:436-483)
+rgb_lpips = None     # callable (np_gt [H,W,3], np_im [H,W,3], net_name, device) -> float  (utils.py:486-495)
+
+
+def _imwrite(path, arr):
+    try:
+        import imageio
+        imageio.imwrite(path, arr)
+    except ImportError:
+        from PIL import Image
+        Image.fromarray(np.ascontiguousarray(arr)).save(path)
+
+
+def _mimwrite(path, frames, fps, quality):
+    try:
+        import imageio
+    except ImportError:
+        print(f"[text2nerf_amd] imageio is not installed: {path} not written ({len(frames)} frames were rendered)")
+        return False
+    imageio.mimwrite(path, np.stack(frames), fps=fps, quality=quality)
+    return True
+
+
+def _post_views(tensorf, rgb_map, depth_map, H, W, near_far, push_depth, gt_rgb):
+    """One view's post-processing (renderer.py:91-113 / :168-176) on the field's device; returns host uint8 arrays + PSNR."""
+    dev = tensorf.basis_mat.weight.device if hasattr(tensorf, "basis_mat") else rgb_map.device
+    r8, d8, psnr = postprocess_frame(rgb_map.to(dev).reshape(H, W, 3), depth_map.to(dev).reshape(H, W), near_far,
+                                     push_depth=push_depth, gt_rgb=gt_rgb)
+    return r8.cpu().numpy(), d8.cpu().numpy(), psnr
+
+
+class _no_materialised_weights:
+    """`evaluation` discards weights / z_vals (renderer.py:89): do not write the two [R, N] tensors while it runs."""
+
+    def __init__(self, tensorf):
+        self.t, self.keep = tensorf, getattr(tensorf, "materialize_weights", None)
+
+    def __enter__(self):
+        if self.keep is not None:
+            self.t.materialize_weights = False
+
+    def __exit__(self, *exc):
+        if self.keep is not None:
+            self.t.materialize_weights = self.keep
+
+
+@torch.no_grad()
+def evaluation(test_dataset, tensorf, args, renderer, savePath=None, N_vis=5, prtx="", N_samples=-1, white_bg=True,
+               ndc_ray=False, compute_extra_metrics=True, device="cuda", video_gen=False, N_iter=-1, preview=False,
+               stitching=True):
+    """renderer.py:44-140 with the same signature, view selection, file names and return value (the PSNR list; PSNR is taken
+    only when ground truth exists AND ``compute_extra_metrics`` is set, as there). ``stitching`` is accepted and forced off like
+    the reference does (:55). Per view: ONE ``renderer(...)`` call with all rays of the image, post-processing on the device."""
+    PSNRs, rgb_maps, depth_maps = [], [], []
+    ssims, l_alex, l_vgg = [], [], []
+    stitching = False
+    if savePath is not None:
+        os.makedirs(savePath, exist_ok=True)
+        os.makedirs(os.path.join(savePath, "rgbs"), exist_ok=True)
+        os.makedirs(os.path.join(savePath, "depths"), exist_ok=True)
+    if test_dataset.split == "train":
+        if preview:
+            all_rays, all_rgbs = test_dataset.all_rays_sprt_split, None
+        else:
+            all_rays = test_dataset.all_rays_gen_split[:N_iter + 1]
+            all_rgbs = test_dataset.all_rgbs_gen_split[:N_iter + 1]
+    elif test_dataset.split == "test" and N_iter >= 0:
+        all_rays, all_rgbs = test_dataset.all_rays_split[:N_iter + 1], None
+    else:
+        all_rays, all_rgbs = test_dataset.all_rays_split, None
+    near_far = test_dataset.near_far
+    img_eval_interval = 1 if N_vis < 0 else max(all_rays.shape[0] // N_vis, 1)
+    idxs = list(range(0, all_rays.shape[0], img_eval_interval))
+    with _no_materialised_weights(tensorf):
+        for idx, samples in enumerate(all_rays[0::img_eval_interval]):
+            W, H = test_dataset.img_wh
+            rays = samples.view(-1, samples.shape[-1])
+            rgb_map, _, depth_map, _, _ = renderer(rays, tensorf, chunk=args.batch_size, N_samples=N_samples, ndc_ray=ndc_ray,
+                                                   white_bg=white_bg, device=device)
+            want_psnr = all_rgbs is not None and compute_extra_metrics
+            gt_rgb = all_rgbs[idxs[idx]].view(H, W, 3) if want_psnr else None
+            rgb8, depth8, psnr = _post_views(tensorf, rgb_map, depth_map, H, W, near_far, args.push_depth, gt_rgb)
+            if want_psnr:
+                PSNRs.append(psnr)
+                if rgb_ssim is not None and rgb_lpips is not None:
+                    rgb_f = rgb_map.clamp(0.0, 1.0).reshape(H, W, 3).cpu()
+                    ssims.append(rgb_ssim(rgb_f, gt_rgb, 1))
+                    l_alex.append(rgb_lpips(gt_rgb.numpy(), rgb_f.numpy(), "alex", tensorf.device))
+                    l_vgg.append(rgb_lpips(gt_rgb.numpy(), rgb_f.numpy(), "vgg", tensorf.device))
+            rgb_maps.append(rgb8)
+            depth_maps.append(depth8)
+            if savePath is not None:
+                _imwrite(f"{savePath}/rgbs/{prtx}{idx:03d}_rgb.png", rgb8)
+                _imwrite(f"{savePath}/depths/{prtx}{idx:03d}_depth.png", depth8)
+    if video_gen:
+        _mimwrite(f"{savePath}/{prtx}video.mp4", rgb_maps, fps=30, quality=9)
+        _mimwrite(f"{savePath}/{prtx}depthvideo.mp4", depth_maps, fps=30, quality=9)
+    return PSNRs
+
+
+@torch.no_grad()
+def evaluation_path(test_dataset, tensorf, c2ws, renderer, savePath=None, N_vis=5, prtx="", N_samples=-1, white_bg=False,
+                    ndc_ray=False, compute_extra_metrics=True, device="cuda"):
+    """renderer.py:142-197 with the same signature and files (``{prtx}NNN.png``, ``rgbd/{prtx}NNN.png`` = rgb | depth map side
+    by side, the two videos when imageio exists). Rays come from ``get_rays(test_dataset.directions, c2w)`` (a HIP kernel here),
+    optionally through ``ndc_rays_blender``; the render call passes ``chunk=8192`` like :166."""
+    from .ray_utils import get_rays, ndc_rays_blender
+    PSNRs, rgb_maps, depth_maps = [], [], []
+    os.makedirs(savePath, exist_ok=True)
+    os.makedirs(savePath + "/rgbd", exist_ok=True)
+    near_far = test_dataset.near_far
+    with _no_materialised_weights(tensorf):
+        for idx, c2w in enumerate(c2ws):
+            W, H = test_dataset.img_wh
+            c2w = torch.FloatTensor(np.asarray(c2w, dtype=np.float32))
+            rays_o, rays_d = get_rays(test_dataset.directions, c2w)
+            if ndc_ray:
+                rays_o, rays_d = ndc_rays_blender(H, W, test_dataset.focal[0], 1.0, rays_o, rays_d)
+            rays = torch.cat([rays_o, rays_d], 1)
+            rgb_map, _, depth_map, _, _ = renderer(rays, tensorf, chunk=8192, N_samples=N_samples, ndc_ray=ndc_ray,
+                                                   white_bg=white_bg, device=device)
+            rgb8, depth8, _ = _post_views(tensorf, rgb_map, depth_map, H, W, near_far, None, None)
+            rgb_maps.append(rgb8)
+            depth_maps.append(depth8)
+            if savePath is not None:
+                _imwrite(f"{savePath}/{prtx}{idx:03d}.png", rgb8)
+                _imwrite(f"{savePath}/rgbd/{prtx}{idx:03d}.png", np.concatenate((rgb8, depth8), axis=1))
+    _mimwrite(f"{savePath}/{prtx}video.mp4", rgb_maps, fps=30, quality=8)
+    _mimwrite(f"{savePath}/{prtx}depthvideo.mp4", depth_maps, fps=30, quality=8)
+    return PSNRs     # always empty, as in the reference (no ground truth on a path; its mean.txt branch is unreachable)

@@ -29,13 +29,28 @@ VEC_MODE = [2, 1, 0]
 _WORKSPACE = {}
 
 
+def _ws_key(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        return (str(device), 0)
+    return (str(device), int(torch.cuda.current_stream(device).cuda_stream))
+
+
 def workspace(device, nbytes: int) -> torch.Tensor:
-    """Grow-only per-device scratch buffer handed to the C-ABI calls."""
-    key = str(device)
+    """Grow-only scratch buffer handed to the C-ABI calls, one per (device, stream): calls queued on one stream execute in order
+    and may share it (every call is done with it when it returns control to the stream); fields driven on DIFFERENT streams get
+    different buffers, so a render on one stream never aliases the backward scratch of another."""
+    key = _ws_key(device)
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
         _WORKSPACE[key] = buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
     return buf
+
+
+def workspace_reserved(device) -> int:
+    """Bytes of scratch currently held for `device` (all streams)."""
+    d = str(torch.device(device))
+    return sum(b.numel() for (k, _), b in _WORKSPACE.items() if k == d)
 
 
 class _PinnedRing:
@@ -456,9 +471,9 @@ class TensorVMSplit(nn.Module):
         self._gbuf_reduced = False
         self._deferred_grad_key = None
 
-    def sync_params(self, force=False):
+    def sync_params(self, force=False, frame_width=None):
         """Create the native field on first use and re-upload when any parameter changed (in-place optimiser steps
-        and load_state_dict bump tensor versions)."""
+        and load_state_dict bump tensor versions). `frame_width`: this call's raster width (default: self.frame_width)."""
         lib = _lib.load()
         ps = self._all_params()
         dev = ps[0].device
@@ -492,9 +507,10 @@ class TensorVMSplit(nn.Module):
                                                             _lib.current_stream_ptr(dev)), "t2n_field_set_alpha_mask")
                     object.__setattr__(mask, "_field", self)   # plain attribute: a Module attribute would register a cycle
             self._alpha_key = mkey
-        if getattr(self, "_frame_w_set", None) != int(self.frame_width):
-            _lib.check(lib.t2n_field_set_frame_width(self._handle, int(self.frame_width)), "t2n_field_set_frame_width")
-            self._frame_w_set = int(self.frame_width)
+        fw = int(self.frame_width if frame_width is None else frame_width)
+        if getattr(self, "_frame_w_set", None) != fw:
+            _lib.check(lib.t2n_field_set_frame_width(self._handle, fw), "t2n_field_set_frame_width")
+            self._frame_w_set = fw
         if self._precision_set != bool(self.mlp_exact_fp32):
             _lib.check(lib.t2n_field_set_mlp_precision(self._handle, 1 if self.mlp_exact_fp32 else 0),
                        "t2n_field_set_mlp_precision")
@@ -752,8 +768,9 @@ class TensorVMSplit(nn.Module):
         self.update_stepSize((int(newSize[0]), int(newSize[1]), int(newSize[2])))
 
     # ---- the render call ----------------------------------------------------------------------------------------------------
-    def forward(self, rays_chunk, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1):
-        """models/tensorBase.py:436-507: returns (rgb_map [R,3], depth_map [R], z_vals [R,N], weight [R,N])."""
+    def forward(self, rays_chunk, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1, frame_width=None):
+        """models/tensorBase.py:436-507: returns (rgb_map [R,3], depth_map [R], z_vals [R,N], weight [R,N]). `frame_width` (not in
+        the reference): the raster width of this call's rays when they are a whole row-major image (default: self.frame_width)."""
         dev = self.basis_mat.weight.device
         rays = to_device_async(rays_chunk, dev)
         if rays.dtype != torch.float32 or not rays.is_contiguous():
@@ -780,20 +797,21 @@ class TensorVMSplit(nn.Module):
         if is_train and not white_bg:
             add_bg = bool(torch.rand((1,)) < 0.5)   # models/tensorBase.py:497
         flags = (FLAG_TRAIN if is_train else 0) | (FLAG_ADD_BG if add_bg else 0) | (FLAG_NDC if ndc_ray else 0)
-        if not is_train and not ndc_ray and self.frame_width and R % int(self.frame_width) == 0:
+        fw = int(self.frame_width if frame_width is None else frame_width)
+        if not is_train and not ndc_ray and fw and R % fw == 0:
             flags |= FLAG_COHERENT
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._autograd_params())
         if needs_grad:
             rgb, depth, z, w = _RenderFn.apply(self, rays, N, flags, jitter, *self._autograd_params())
         else:
-            rgb, depth, z, w = self._render_raw(rays, N, flags, jitter, self.materialize_weights)
+            rgb, depth, z, w = self._render_raw(rays, N, flags, jitter, self.materialize_weights, frame_width=fw)
         if ndc_ray and z is not None:
             z = z[:1]          # sample_ray_ndc returns ONE [1,N] depth row (models/tensorBase.py:296-302)
         return rgb, depth, z, w
 
-    def _render_raw(self, rays, N, flags, jitter, want_wz, keep_ctx=False):
+    def _render_raw(self, rays, N, flags, jitter, want_wz, keep_ctx=False, frame_width=None):
         lib = _lib.load()
-        h = self.sync_params()
+        h = self.sync_params(frame_width=frame_width)
         dev = rays.device
         R = rays.shape[0]
         rgb = torch.empty(R, 3, device=dev, dtype=torch.float32)
@@ -862,8 +880,8 @@ class TensorVMSplit(nn.Module):
             # multi-GB torch.empty per backward would hit hipMalloc each time
             self._ctx_rows_hint = (int(rows.value * 1.25) + 95) // 32 * 32 if self.keep_activation_rows else 0
             need = int(lib.t2n_backward_workspace_bytes(self._handle, rows.value, R, N))
-            bws = workspace(dev, need) if _WORKSPACE.get(str(dev)) is not None and _WORKSPACE[str(dev)].numel() >= need \
-                else workspace(dev, int(need * 1.5))
+            have = _WORKSPACE.get(_ws_key(dev))
+            bws = workspace(dev, need) if have is not None and have.numel() >= need else workspace(dev, int(need * 1.5))
             _lib.check(lib.t2n_render_backward(self._handle, _lib.ptr(rays), R, rays.shape[1], N, flags | FLAG_KEEP_CTX,
                                                _lib.ptr(jitter), _lib.ptr(d_rgb), _lib.ptr(d_depth), _lib.ptr(d_w),
                                                C.byref(gs), _lib.ptr(ws), ws.numel(), _lib.ptr(bws), bws.numel(),
