@@ -72,6 +72,7 @@ int main() {
     run<1, 0, 512, 0>(it); run<1, 0, 512, 1>(it); run<1, 2, 512, 1>(it); run<1, 3, 512, 1>(it); run<1, 4, 512, 1>(it); run<1, 5, 512, 1>(it);
     run<1, 3, 256, 1>(it); run<1, 4, 256, 1>(it);
     run<2, 0, 256, 0>(it); run<2, 0, 256, 1>(it); run<2, 2, 256, 1>(it); run<2, 3, 256, 1>(it); run<2, 4, 256, 1>(it); run<2, 5, 256, 1>(it);
+    run<3, 0, 256, 1>(it); run<3, 3, 256, 1>(it); run<3, 4, 256, 1>(it); run<3, 5, 256, 1>(it);
     run<4, 0, 256, 1>(it); run<4, 3, 256, 1>(it); run<4, 4, 256, 1>(it); run<4, 5, 256, 1>(it);
     return 0;
 }
