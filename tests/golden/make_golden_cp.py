@@ -48,6 +48,20 @@ def main():
     for name, p in m.named_parameters():
         out["cp_grad_" + name] = p.grad.numpy()
     out["cp_state_keys"] = np.array(sorted(m.state_dict().keys()))
+    # shrink (models/tensoRF.py:387-416): the reference dereferences self.alphaMask, so it gets one (all ones, a grid that differs
+    # from the field's: the corrected-aabb branch); the render after it runs without the mask
+    from models.tensoRF import AlphaGridMask
+    m.alphaMask = AlphaGridMask("cpu", m.aabb, torch.ones(8, 8, 8))
+    new_aabb = torch.tensor([[-5.1, -3.3, -4.2], [4.4, 5.2, 3.9]])
+    quiet(m.shrink, new_aabb)
+    m.alphaMask = None
+    out["cp_shrink_in"], out["cp_shrink_aabb"] = new_aabb.numpy(), m.aabb.numpy()
+    out["cp_shrink_grid"], out["cp_shrink_nsamples"] = m.gridSize.numpy(), np.array(m.nSamples)
+    for k in range(3):
+        out[f"cp_shrink_density_line.{k}"], out[f"cp_shrink_app_line.{k}"] = m.density_line[k].detach().numpy(), m.app_line[k].detach().numpy()
+    with torch.no_grad():
+        rgb, depth, zv, wt = m(rays, is_train=False, white_bg=True, ndc_ray=False, N_samples=-1)
+    out["cp_shrink_rgb"], out["cp_shrink_depth"] = rgb.numpy(), depth.numpy()
     np.savez_compressed(os.path.join(HERE, "cp.npz"), **out)
     print({k: v.shape for k, v in out.items() if not k.startswith("cp_grad")}, "napp", int((wt > 1e-4).sum()))
 

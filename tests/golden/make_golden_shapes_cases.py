@@ -1,0 +1,17 @@
+"""Field / head shapes other than the driver's 16 / 48 / 27 / 6 / 128 (shared by the golden generator and the tests)."""
+SHAPES = {
+    # upstream TensoRF's default component counts (different per plane), the driver's head
+    "upstream": dict(density_n_comp=[16, 4, 4], appearance_n_comp=[48, 12, 12], app_dim=27, shadingMode="MLP_Fea_noview", fea_pe=6,
+                     featureC=128, view_pe=6, pos_pe=6),
+    # everything smaller: 8 / 24 components, 12 features, two octaves, 64 hidden units
+    "small": dict(density_n_comp=[8, 8, 8], appearance_n_comp=[24, 24, 24], app_dim=12, shadingMode="MLP_Fea_noview", fea_pe=2,
+                  featureC=64, view_pe=6, pos_pe=6),
+    # no feature encoding at all (fea_pe = 0: models/tensorBase.py:104 skips the PE), odd counts
+    "nope": dict(density_n_comp=[5, 16, 3], appearance_n_comp=[7, 48, 20], app_dim=9, shadingMode="MLP_Fea_noview", fea_pe=0,
+                 featureC=32, view_pe=6, pos_pe=6),
+    # a view-dependent head with a narrow hidden layer and the SH head on few components
+    "fea64": dict(density_n_comp=[8, 8, 8], appearance_n_comp=[24, 24, 24], app_dim=27, shadingMode="MLP_Fea", fea_pe=2,
+                  featureC=64, view_pe=2, pos_pe=6),
+    "sh": dict(density_n_comp=[4, 4, 4], appearance_n_comp=[12, 12, 12], app_dim=27, shadingMode="SH", fea_pe=6, featureC=128,
+               view_pe=6, pos_pe=6),
+}

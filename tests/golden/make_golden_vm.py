@@ -48,6 +48,18 @@ def main():
     for name, p in m.named_parameters():
         out["vm_grad_" + name] = p.grad.numpy()
     out["vm_state_keys"] = np.array(sorted(m.state_dict().keys()))
+    # upsample_volume_grid (models/tensoRF.py:126-136): F.interpolate of the stacked tensors (bilinear, align_corners=True; the
+    # planes by scale factor, the lines to an explicit size). The reference then calls an undefined self.compute_stepSize (an
+    # AttributeError upstream); the resized parameters are in place by then, and so is what the method evidently means: update_stepSize
+    try:
+        quiet(m.upsample_volume_grid, [27, 27, 27])
+    except AttributeError:
+        pass
+    out["vm_up27_plane"], out["vm_up27_line"] = m.plane_coef.detach().numpy(), m.line_coef.detach().numpy()
+    m.update_stepSize([27, 27, 27])
+    with torch.no_grad():
+        rgb, depth, zv, wt = m(rays, is_train=False, white_bg=True, ndc_ray=False, N_samples=-1)
+    out["vm_up27_rgb"], out["vm_up27_depth"], out["vm_up27_nsamples"] = rgb.numpy(), depth.numpy(), np.array(m.nSamples)
     np.savez_compressed(os.path.join(HERE, "vm.npz"), **out)
     print({k: v.shape for k, v in out.items() if not k.startswith("vm_grad")}, [k for k in out if k.startswith("vm_grad")])
 

@@ -271,10 +271,11 @@ def test_unsupported_configs_fail_loudly():
     aabb = torch.tensor([[-1.0] * 3, [1.0] * 3])
     with pytest.raises(T2NError):
         TensorVMSplit(aabb, [8, 8, 8], dev(), shadingMode="MLP_PE")
-    m = TensorVMSplit(aabb, [8, 8, 8], dev(), density_n_comp=[8, 8, 8], appearance_n_comp=[24, 24, 24],
-                      shadingMode="MLP_Fea_noview", fea_pe=6, step_ratio=1.0)
-    with pytest.raises(T2NError):
-        m(torch.zeros(4, 6))
+    for kw in (dict(density_n_comp=[32, 16, 16]), dict(appearance_n_comp=[96, 48, 48]), dict(featureC=256), dict(fea_pe=8), dict(app_dim=30)):
+        base = dict(density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, shadingMode="MLP_Fea_noview", fea_pe=6, step_ratio=1.0)
+        base.update(kw)
+        with pytest.raises(T2NError):       # beyond the kernels' capacity: rejected at construction (smaller shapes run zero-padded)
+            TensorVMSplit(aabb, [8, 8, 8], dev(), **base)
     ok = TensorVMSplit(aabb, [8, 8, 8], dev(), density_n_comp=[16] * 3, appearance_n_comp=[48] * 3,
                        shadingMode="MLP_Fea_noview", fea_pe=6, step_ratio=1.0)
     with pytest.raises(T2NError):

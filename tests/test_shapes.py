@@ -1,0 +1,140 @@
+"""Field / head shapes other than the driver's 16 / 48 / 27 / 6 / 128 (the reference is generic in n_lamb_sigma, n_lamb_sh,
+data_dim_color, fea_pe, featureC: models/tensoRF.py:144-160, models/tensorBase.py:88-109, e_opt.py:83-107) against goldens produced
+by the reference (tests/golden/make_golden_shapes.py). Smaller shapes run on the same HIP kernels through an exact zero-padding
+embedding (text2nerf_amd/tensorf.py::_embedded_params). CPU: the oracle vs the goldens, and the embedding's algebra (the oracle on
+the embedded tensors == the oracle on the real ones, values and gradients). GPU: the HIP render and its gradients vs the goldens."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_torch as O
+from tests.conftest import GOLDEN, TINY
+from text2nerf_amd import synth
+
+sys.path.insert(0, GOLDEN)
+from make_golden_shapes_cases import SHAPES  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gs():
+    return dict(np.load(os.path.join(GOLDEN, "shapes.npz"), allow_pickle=False))
+
+
+def _params(kw):
+    return synth.make_field_params(41, TINY["grid"], density_n_comp=kw["density_n_comp"], app_n_comp=kw["appearance_n_comp"],
+                                   app_dim=kw["app_dim"], feature_c=kw["featureC"], fea_pe=kw["fea_pe"], shading_mode=kw["shadingMode"],
+                                   density_scale=0.9, aabb=TINY["aabb"], view_pe=kw["view_pe"], pos_pe=kw["pos_pe"])
+
+
+def _cfg(kw, fea_pe=None):
+    return O.FieldConfig(aabb=TINY["aabb"], grid_size=TINY["grid"], near_far=TINY["near_far"], shading_mode=kw["shadingMode"],
+                         fea_pe=kw["fea_pe"] if fea_pe is None else fea_pe, view_pe=kw["view_pe"], pos_pe=kw["pos_pe"])
+
+
+def _field(kw, device):
+    from text2nerf_amd import TensorVMSplit
+    m = TensorVMSplit(torch.tensor(TINY["aabb"]), TINY["grid"], device, near_far=TINY["near_far"], alphaMask_thres=1e-4,
+                      density_shift=-10, distance_scale=25, step_ratio=1.0, fea2denseAct="softplus", **kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in _params(kw).items()}, strict=True)
+    return m
+
+
+@pytest.mark.parametrize("tag", list(SHAPES))
+def test_oracle_shapes_vs_reference(tiny, gs, tag):
+    kw = SHAPES[tag]
+    rays = torch.from_numpy(tiny["tiny_rays"])
+    rgb, depth, z, w = O.forward(_cfg(kw), O.params_from_numpy(_params(kw)), rays)
+    np.testing.assert_allclose(rgb.numpy(), gs[f"{tag}_eval_rgb"], atol=5e-6)
+    np.testing.assert_allclose(depth.numpy(), gs[f"{tag}_eval_depth"], atol=2e-5)
+    np.testing.assert_allclose(w.sum(-1).numpy(), gs[f"{tag}_eval_acc"], atol=5e-6)
+
+
+KEYS = [f"density_plane.{k}" for k in range(3)] + [f"density_line.{k}" for k in range(3)] + [f"app_plane.{k}" for k in range(3)] + \
+       [f"app_line.{k}" for k in range(3)] + ["basis_mat.weight"] + [f"renderModule.mlp.{i}.{n}" for i in (0, 2, 4) for n in ("weight", "bias")]
+
+
+@pytest.mark.parametrize("tag", list(SHAPES))
+def test_embedding_is_exact_on_the_oracle(tiny, gs, tag):
+    """The tensors the kernels see (16 / 48 components, the 27 / 6 / 128 head) render the SAME field: the oracle on the embedded
+    tensors equals the oracle on the real ones, and gradients taken through the embedding equal the reference's autograd goldens."""
+    kw = SHAPES[tag]
+    m = _field(kw, "cpu")
+    assert m._needs_embed()
+    emb = m._embedded_params()
+    kd, ka, kdim, kpe, kfc = m._kernel_shape()
+    assert all(t.shape[1] == kd for t in emb[:6]) and all(t.shape[1] == ka for t in emb[6:12]) and emb[12].shape == (kdim, 3 * ka)
+    if m.renderModule is not None:
+        assert emb[13].shape[0] == kfc and emb[15].shape == (kfc, kfc) and emb[17].shape == (3, kfc)
+    P = {k: t for k, t in zip(KEYS, emb)}
+    rays = torch.from_numpy(tiny["tiny_rays"])
+    with torch.no_grad():
+        rgb, depth, z, w = O.forward(_cfg(kw, fea_pe=kpe), P, rays)
+    np.testing.assert_allclose(rgb.numpy(), gs[f"{tag}_eval_rgb"], atol=5e-6)
+    np.testing.assert_allclose(depth.numpy(), gs[f"{tag}_eval_depth"], atol=2e-5)
+    # gradients through the embedding (train mode, the generator's jitter and loss)
+    torch.manual_seed(55)
+    jitter = torch.rand(rays.shape[0], 1)
+    emb = m._embedded_params()        # rebuilt with grad mode on
+    assert emb[0].requires_grad and m._embedded_params()[0] is emb[0]       # cached per parameter version
+    P = {k: t for k, t in zip(KEYS, emb)}
+    rgb, depth, z, w = O.forward(_cfg(kw, fea_pe=kpe), P, rays, white_bg=True, is_train=True, n_samples=36, jitter=jitter)
+    np.testing.assert_allclose(rgb.detach().numpy(), gs[f"{tag}_train_rgb"], atol=5e-6)
+    ca = torch.from_numpy(gs[f"{tag}_ca"])
+    ((rgb * ca).sum() + 0.1 * depth.sum() + (w ** 2).sum()).backward()
+    for k, p in m.named_parameters():
+        g = gs[f"{tag}_grad_" + k]
+        assert p.grad is not None and tuple(p.grad.shape) == g.shape, k
+        assert float(np.abs(p.grad.numpy() - g).max()) <= 2e-5 * float(np.abs(g).max()) + 1e-9, k
+    with torch.no_grad():
+        m.basis_mat.weight.mul_(1.5)
+    assert m._embedded_params()[12] is not emb[12]                              # a parameter changed: rebuilt
+
+
+def test_shapes_beyond_the_kernels_are_rejected_on_construction():
+    from text2nerf_amd import TensorVMSplit
+    from text2nerf_amd._lib import T2NError
+    aabb = torch.tensor([[-1.0] * 3, [1.0] * 3])
+    for kw in (dict(density_n_comp=[32, 16, 16]), dict(appearance_n_comp=[48, 48, 96]), dict(featureC=256), dict(fea_pe=7), dict(app_dim=28)):
+        base = dict(density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, shadingMode="MLP_Fea_noview", fea_pe=6, step_ratio=1.0)
+        base.update(kw)
+        with pytest.raises(T2NError):
+            TensorVMSplit(aabb, [8, 8, 8], "cpu", **base)
+    ok = TensorVMSplit(aabb, [8, 8, 8], "cpu", density_n_comp=[16, 4, 4], appearance_n_comp=[48, 12, 12], shadingMode="MLP_Fea_noview",
+                       fea_pe=2, featureC=64, app_dim=12, step_ratio=1.0)
+    assert ok._needs_embed() and not ok.supports_deferred_factor_grads()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(SHAPES))
+def test_hip_shapes_forward_and_gradients_vs_reference(tiny, gs, tag):
+    from tests.test_hip_parity import DEPTH_ATOL, RGB_ATOL, close, dev
+    kw = SHAPES[tag]
+    m = _field(kw, dev())
+    rays = torch.from_numpy(tiny["tiny_rays"])
+    with torch.no_grad():
+        rgb, depth, z, w = m(rays)
+    close(rgb, gs[f"{tag}_eval_rgb"], atol=RGB_ATOL)
+    close(depth, gs[f"{tag}_eval_depth"], atol=DEPTH_ATOL)
+    close(w.sum(-1), gs[f"{tag}_eval_acc"], atol=2e-5)
+    torch.manual_seed(55)
+    rgb, depth, z, w = m(rays, is_train=True, white_bg=True, N_samples=36)
+    close(rgb, gs[f"{tag}_train_rgb"], atol=RGB_ATOL)
+    ca = torch.from_numpy(gs[f"{tag}_ca"]).to(dev())
+    ((rgb * ca).sum() + 0.1 * depth.sum() + (w ** 2).sum()).backward()
+    bad = {}
+    for k, p in m.named_parameters():
+        g = gs[f"{tag}_grad_" + k]
+        assert p.grad is not None and tuple(p.grad.shape) == g.shape, k
+        err = float(np.abs(p.grad.detach().cpu().numpy() - g).max()) / (float(np.abs(g).max()) + 1e-12)
+        if err > 3e-4:
+            bad[k] = err
+    assert not bad, bad
+    # an optimiser step on the REAL parameters reaches the kernels (re-embedded, re-uploaded)
+    opt = torch.optim.Adam(m.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    opt.step()
+    with torch.no_grad():
+        rgb2, _, _, _ = m(rays)
+    assert float((rgb2.cpu() - torch.from_numpy(gs[f"{tag}_eval_rgb"])).abs().max()) > 1e-4

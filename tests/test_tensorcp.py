@@ -81,3 +81,38 @@ def test_hip_tensorcp_forward_and_gradients_vs_reference(tiny, gc, cp_params):
     with torch.no_grad():
         rgb2 = m(rays)[0]
     assert bool(torch.isfinite(rgb2).all()) and not torch.equal(rgb2, again)
+
+
+def _cp(device, cp_params):
+    from text2nerf_amd import TensorCP
+    m = TensorCP(torch.tensor(TINY["aabb"]), TINY["grid"], device, density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, app_dim=27,
+                 near_far=TINY["near_far"], shadingMode="MLP_Fea_noview", alphaMask_thres=1e-4, density_shift=-10, distance_scale=25,
+                 pos_pe=0, view_pe=0, fea_pe=6, featureC=128, step_ratio=1.0, fea2denseAct="softplus")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in cp_params.items()}, strict=True)
+    return m
+
+
+def test_tensorcp_shrink_host_logic_vs_reference(gc, cp_params):
+    """TensorCP.shrink (models/tensoRF.py:387-416) is host index arithmetic + slicing: cropped lines, corrected aabb, grid and sample
+    count against the reference's."""
+    m = _cp("cpu", cp_params)
+    m.shrink(torch.from_numpy(gc["cp_shrink_in"]))
+    np.testing.assert_allclose(m.aabb.numpy(), gc["cp_shrink_aabb"], atol=1e-6)
+    assert m.gridSize.tolist() == gc["cp_shrink_grid"].tolist() and m.nSamples == int(gc["cp_shrink_nsamples"])
+    for k in range(3):
+        assert np.array_equal(m.density_line[k].detach().numpy(), gc[f"cp_shrink_density_line.{k}"])
+        assert np.array_equal(m.app_line[k].detach().numpy(), gc[f"cp_shrink_app_line.{k}"])
+
+
+@pytest.mark.gpu
+def test_hip_tensorcp_render_after_shrink(tiny, gc, cp_params):
+    from tests.test_hip_parity import DEPTH_ATOL, RGB_ATOL, close
+    m = _cp(torch.device("cuda:0"), cp_params)
+    rays = torch.from_numpy(tiny["tiny_rays"])
+    with torch.no_grad():
+        m(rays)
+    m.shrink(torch.from_numpy(gc["cp_shrink_in"]))
+    with torch.no_grad():
+        rgb, depth, _, _ = m(rays)
+    close(rgb, gc["cp_shrink_rgb"], atol=RGB_ATOL)
+    close(depth, gc["cp_shrink_depth"], atol=DEPTH_ATOL)

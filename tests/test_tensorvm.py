@@ -89,3 +89,37 @@ def test_hip_tensorvm_forward_and_gradients_vs_reference(tiny, gv, vm_params):
     assert bool(torch.isfinite(rgb2).all()) and not torch.equal(rgb2.cpu(), torch.from_numpy(gv["vm_eval_rgb"]))
     kw = m.get_kwargs()
     assert kw["density_n_comp"] == 16 and kw["appearance_n_comp"] == 48
+
+
+def test_oracle_vm_upsample_vs_reference(tiny, gv, vm_params):
+    """TensorVM.upsample_volume_grid (models/tensoRF.py:126-136): the oracle's align_corners bilinear resize reproduces the reference's
+    resized stacked tensors and the render after them."""
+    P = O.params_from_numpy(vm_params)
+    pl = P["plane_coef"]
+    up_p = O.upsample_bilinear(pl.reshape(1, -1, 20, 20), 27, 27).reshape(3, -1, 27, 27)
+    up_l = O.upsample_bilinear(P["line_coef"].reshape(1, -1, 20, 1), 27, 1).reshape(3, -1, 27, 1)
+    np.testing.assert_allclose(up_p.numpy(), gv["vm_up27_plane"], atol=2e-6)
+    np.testing.assert_allclose(up_l.numpy(), gv["vm_up27_line"], atol=2e-6)
+    cfg = O.FieldConfig(aabb=TINY["aabb"], grid_size=[27] * 3, near_far=TINY["near_far"])
+    assert cfg.n_samples == int(gv["vm_up27_nsamples"])
+    P2 = dict(P, plane_coef=torch.from_numpy(gv["vm_up27_plane"]), line_coef=torch.from_numpy(gv["vm_up27_line"]))
+    rgb, depth, _, _ = O.forward(cfg, O.vm_to_split(P2, 16, 48), torch.from_numpy(tiny["tiny_rays"]))
+    np.testing.assert_allclose(rgb.numpy(), gv["vm_up27_rgb"], atol=5e-6)
+
+
+@pytest.mark.gpu
+def test_hip_tensorvm_upsample_volume_grid(tiny, gv, vm_params):
+    from tests.test_hip_parity import DEPTH_ATOL, RGB_ATOL, close
+    m = _make_vm(vm_params)
+    rays = torch.from_numpy(tiny["tiny_rays"])
+    with torch.no_grad():
+        m(rays)                                  # a native field at 20^3 exists before the resize
+    m.upsample_volume_grid([27, 27, 27])
+    assert tuple(m.plane_coef.shape) == (3, 64, 27, 27) and tuple(m.line_coef.shape) == (3, 64, 27, 1)
+    close(m.plane_coef, gv["vm_up27_plane"], atol=2e-6)
+    close(m.line_coef, gv["vm_up27_line"], atol=2e-6)
+    assert m.nSamples == int(gv["vm_up27_nsamples"]) and m.gridSize.tolist() == [27, 27, 27]
+    with torch.no_grad():
+        rgb, depth, _, _ = m(rays)
+    close(rgb, gv["vm_up27_rgb"], atol=RGB_ATOL)
+    close(depth, gv["vm_up27_depth"], atol=DEPTH_ATOL)

@@ -270,6 +270,7 @@ class TensorVMSplit(nn.Module):
             self.renderModule = MLPRender(self.app_dim, view_pe, featureC).to(device)
         else:
             self.renderModule = None
+        self._kernel_shape()      # shapes beyond the kernels' capacity fail here, loudly
 
     # ---- containers (models/tensoRF.py:144-160) -------------------------------------------------------------------
     def init_svd_volume(self, res, device):
@@ -399,11 +400,10 @@ class TensorVMSplit(nn.Module):
         for k in range(3):
             d.aabb_min[k], d.aabb_max[k], d.inv_aabb_size[k] = float(a[0, k]), float(a[1, k]), float(inv[k])
             d.grid[k] = int(self.gridSize[k])
-        if len(set(self.density_n_comp)) != 1 or len(set(self.app_n_comp)) != 1:
-            raise T2NError("the HIP renderer needs equal n_comp on the three planes")
-        d.density_n_comp, d.app_n_comp, d.app_dim = self.density_n_comp[0], self.app_n_comp[0], self.app_dim
+        kd, ka, kdim, kpe, kfc = self._kernel_shape()
+        d.density_n_comp, d.app_n_comp, d.app_dim = kd, ka, kdim
         d.shading = _lib.SHADE_IDS[self.shadingMode]
-        d.fea_pe, d.feature_c = self.fea_pe, self.featureC
+        d.fea_pe, d.feature_c = kpe, kfc
         d.act = _lib.ACT_IDS[self.fea2denseAct]
         d.density_shift, d.distance_scale = float(self.density_shift), float(self.distance_scale)
         d.weight_thres = float(self.rayMarch_weight_thres)
@@ -413,13 +413,100 @@ class TensorVMSplit(nn.Module):
         d.view_pe, d.pos_pe = int(self.view_pe), int(self.pos_pe)
         return d
 
-    def _all_params(self):
+    # ---- field / head shapes other than the kernels' own (the reference is generic in n_lamb_sigma, n_lamb_sh,
+    # data_dim_color, fea_pe, featureC: models/tensoRF.py:144-160, models/tensorBase.py:88-100, e_opt.py:83-107) -----------------------
+    # The kernels are built for 16 density / 48 appearance components per plane and the 27 / 6 / 128 MLP_Fea_noview head. Smaller
+    # shapes — fewer components (also different counts per plane: upstream TensoRF's [16,4,4] / [48,12,12]), app_dim < 27,
+    # fea_pe < 6, featureC < 128 — run on the SAME kernels through an exact algebraic embedding: missing components are zero
+    # channels (they add 0 * 0 to the sum over components), a missing feature is a zero row of basis_mat whose encoding columns have
+    # zero weights (sin 0 = 0, cos 0 = 1 meet a zero weight), missing octaves are zero weight columns, missing hidden units have zero
+    # weights and biases (relu(0) = 0). The embedded tensors are built with differentiable torch ops (cached per parameter version), so
+    # autograd carries the kernels' gradients back to the real parameters: a slow path (one padded copy per parameter change), not an
+    # error. Larger shapes have no embedding and are rejected.
+    KERNEL_DEN, KERNEL_APP, KERNEL_DIM, KERNEL_PE, KERNEL_FC = 16, 48, 27, 6, 128
+
+    def _kernel_shape(self):
+        """(density comps, appearance comps, app_dim, fea_pe, featureC) the native field is created with."""
+        if max(self.density_n_comp) > self.KERNEL_DEN or max(self.app_n_comp) > self.KERNEL_APP:
+            raise T2NError(f"n_comp {self.density_n_comp} / {self.app_n_comp}: the HIP kernels hold at most {self.KERNEL_DEN} density and "
+                           f"{self.KERNEL_APP} appearance components per plane (smaller counts run zero-padded)")
+        if self.renderModule is not None and self.featureC > self.KERNEL_FC:
+            raise T2NError(f"featureC {self.featureC}: the HIP heads hold at most {self.KERNEL_FC} hidden units (smaller run zero-padded)")
+        if self.shadingMode == "MLP_Fea_noview":
+            if self.app_dim > self.KERNEL_DIM or self.fea_pe > self.KERNEL_PE or self.fea_pe < 0:
+                raise T2NError(f"MLP_Fea_noview with app_dim {self.app_dim} / fea_pe {self.fea_pe}: at most {self.KERNEL_DIM} / "
+                               f"{self.KERNEL_PE} (smaller run zero-padded)")
+            return self.KERNEL_DEN, self.KERNEL_APP, self.KERNEL_DIM, self.KERNEL_PE, self.KERNEL_FC
+        return self.KERNEL_DEN, self.KERNEL_APP, self.app_dim, self.fea_pe, self.KERNEL_FC if self.renderModule is not None else self.featureC
+
+    def _needs_embed(self):
+        kd, ka, kdim, kpe, kfc = self._kernel_shape()
+        return (any(c != kd for c in self.density_n_comp) or any(c != ka for c in self.app_n_comp) or kdim != self.app_dim
+                or kpe != self.fea_pe or (self.renderModule is not None and kfc != self.featureC))
+
+    def _real_params(self):
         ps = list(self.density_plane) + list(self.density_line) + list(self.app_plane) + list(self.app_line)
         ps.append(self.basis_mat.weight)
         if self.renderModule is not None:
             ps += [self.renderModule.mlp[0].weight, self.renderModule.mlp[0].bias, self.renderModule.mlp[2].weight,
                    self.renderModule.mlp[2].bias, self.renderModule.mlp[4].weight, self.renderModule.mlp[4].bias]
         return ps
+
+    def _embedded_params(self):
+        """The 19 kernel-order tensors in the kernels' shapes, as differentiable functions of the real parameters."""
+        leaves = self._real_params()
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in leaves)
+        key = tuple((p.data_ptr(), p._version) for p in leaves)
+        cache = getattr(self, "_embed_cache", None)
+        if cache is not None and cache[0] == key and (cache[1] or not grad):
+            return cache[2]     # (backward runs with grad mode off: it must see the forward's tensors, not rebuild them)
+        kd, ka, kdim, kpe, kfc = self._kernel_shape()
+        dev = self.basis_mat.weight.device
+        F = torch.nn.functional
+        with torch.set_grad_enabled(grad):
+            def pad_c(t, c):      # [1, C, H, W] -> [1, c, H, W]
+                return t if t.shape[1] == c else F.pad(t, (0, 0, 0, 0, 0, c - t.shape[1])).contiguous()
+            out = [pad_c(t, kd) for t in leaves[0:6]] + [pad_c(t, ka) for t in leaves[6:12]]
+            # basis_mat [app_dim, sum C_k] -> [kdim, 3 ka]: the columns of plane k's components move to 48 k ..
+            B = leaves[12]
+            cols, off = [], 0
+            for k, c in enumerate(self.app_n_comp):
+                cols.append(torch.arange(c, device=dev) + k * ka)
+                off += c
+            cols = torch.cat(cols)
+            Bk = B.new_zeros((kdim, 3 * ka))
+            Bk[: self.app_dim, cols] = B
+            out.append(Bk)
+            if self.renderModule is not None:
+                w0, b0, w1, b1, w2, b2 = leaves[13:19]
+                fc = self.featureC
+                if self.shadingMode == "MLP_Fea_noview":
+                    # reference columns (models/tensorBase.py:11-17,101-104): [features | sin: feature-major, octave-minor | cos: same]
+                    a, pe = self.app_dim, self.fea_pe
+                    f = torch.arange(a, device=dev)
+                    src = [f]
+                    dst = [f]
+                    if pe > 0:
+                        fo = (f[:, None] * pe + torch.arange(pe, device=dev)[None]).reshape(-1)          # f * pe + o
+                        fo_k = (f[:, None] * kpe + torch.arange(pe, device=dev)[None]).reshape(-1)       # f * 6 + o
+                        src += [a + fo, a + a * pe + fo]
+                        dst += [kdim + fo_k, kdim + kdim * kpe + fo_k]
+                    src, dst = torch.cat(src), torch.cat(dst)
+                    W0 = w0.new_zeros((kfc, kdim * (1 + 2 * kpe)))
+                    W0[:fc, dst] = w0[:, src]
+                else:   # view-dependent heads: the input row keeps the reference's own column order; only the hidden width is padded
+                    W0 = w0.new_zeros((kfc, w0.shape[1]))
+                    W0[:fc] = w0
+                W1 = w1.new_zeros((kfc, kfc))
+                W1[:fc, :fc] = w1
+                W2 = w2.new_zeros((3, kfc))
+                W2[:, :fc] = w2
+                out += [W0, F.pad(b0, (0, kfc - fc)), W1, F.pad(b1, (0, kfc - fc)), W2, b2]
+        self._embed_cache = (key, grad, out)
+        return out
+
+    def _all_params(self):
+        return self._embedded_params() if self._needs_embed() else self._real_params()
 
     # autograd hooks: the tensors autograd tracks (the module's leaf parameters) and, for a list of same-shaped buffers (the
     # gradients), the 19 kernel-order views into them. Identity for the VM-split layout; TensorVM overrides both.
@@ -447,7 +534,7 @@ class TensorVMSplit(nn.Module):
         embedded TensorCP) and the device keeps fp32 master copies: then ``defer_factor_grads`` lets the backward leave the
         plane / line gradients in the library's channel-last buffers for ``optim.TVAdam(field=...)`` to consume in place."""
         return type(self)._kernel_views is TensorVMSplit._kernel_views and type(self)._autograd_params is TensorVMSplit._autograd_params \
-            and self.factor_storage == "fp32"
+            and self.factor_storage == "fp32" and not self._needs_embed()
 
     def factor_grad_buffer(self):
         """The channel-last gradients of the 12 plane / line tensors as ONE flat fp32 tensor owned here and handed to the native
@@ -898,6 +985,9 @@ class TensorVMSplit(nn.Module):
         lambda: parallel.allreduce_gradients(params, field=self)). Returns the device tensor [mse, depth loss, transmittance loss,
         total] of this batch (no host synchronisation). Same arithmetic as the autograd path: tests/test_train_step.py."""
         lib = _lib.load()
+        if any(not p.is_leaf for p in self._autograd_params()):
+            raise T2NError("train_step needs the kernels' own field shape (the parameters ARE the kernel tensors); embedded shapes, "
+                           "TensorVM and TensorCP train through the autograd form (OctreeRender_trilinear_fast + loss.backward())")
         dev = self.basis_mat.weight.device
         rays = to_device_async(rays, dev)
         if rays.dtype != torch.float32 or not rays.is_contiguous():
@@ -1013,11 +1103,42 @@ class TensorVM(TensorVMSplit):
             total = total + torch.mean(torch.abs(dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]))
         return total
 
-    def _unsupported(self, *a, **k):
-        raise T2NError("TensorVM: only the render path (forward / backward / checkpoints) is implemented; the reference's own "
-                       "TensorVM.upsample_volume_grid calls an undefined compute_stepSize (models/tensoRF.py:136)")
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        """models/tensoRF.py:126-136: bilinear (align_corners=True) resize of the stacked tensors — the planes by the scale factor
+        res_target[0] / res (output size floor(res * scale), as F.interpolate computes it), the lines to res_target[0] — through the
+        ATen-exact resize kernel. The reference then calls an undefined ``compute_stepSize`` (an AttributeError upstream); what it
+        evidently means, ``update_stepSize``, is what runs here."""
+        lib = _lib.load()
+        res = int(self.line_coef.shape[2])
+        scale = res_target[0] / res                      # python floats, like the reference
+        out_p = int(math.floor(float(res) * scale))      # F.interpolate(scale_factor=...): floor(input_size * scale_factor)
+        out_l = int(res_target[0])
 
-    upsample_volume_grid = shrink = TV_loss_density = TV_loss_app = density_L1 = _unsupported
+        def resize(t, Hout, Wout):
+            t = t.detach().contiguous().float()
+            n, c, Hin, Win = t.shape
+            out = torch.empty((n, c, Hout, Wout), device=t.device, dtype=torch.float32)
+            with torch.cuda.device(t.device):
+                _lib.check(lib.t2n_upsample_bilinear(_lib.ptr(t), n * c, Hin, Win, _lib.ptr(out), Hout, Wout,
+                                                     _lib.current_stream_ptr(t.device)), "t2n_upsample_bilinear")
+            return out
+
+        if self.plane_coef.device.type != "cuda":
+            raise T2NError("TensorVM.upsample_volume_grid runs on the MI355X only (no CPU fallback)")
+        if out_p != out_l:
+            raise T2NError(f"TensorVM.upsample_volume_grid: planes would become {out_p}^2 but lines {out_l} (res_target must be "
+                           "reachable by the scale factor, as in the reference)")
+        self.plane_coef = nn.Parameter(resize(self.plane_coef.data, out_p, out_p))
+        self.line_coef = nn.Parameter(resize(self.line_coef.data, out_l, 1))
+        self._drop_handle()
+        self.update_stepSize([out_l] * 3)
+        print(f"upsamping to {res_target}")
+
+    def _unsupported(self, *a, **k):
+        raise T2NError("TensorVM has no shrink / TV / L1 terms in the reference either (models/tensoRF.py:4-136 defines none)")
+
+    shrink = TV_loss_density = TV_loss_app = density_L1 = _unsupported
 
 
 class TensorCP(TensorVMSplit):
@@ -1114,8 +1235,31 @@ class TensorCP(TensorVMSplit):
         self._drop_handle()
         self.update_stepSize(res_target)
 
+    @torch.no_grad()
     def shrink(self, new_aabb):
-        raise T2NError("TensorCP.shrink is not implemented (the reference's version dereferences a missing alphaMask)")
+        """models/tensoRF.py:387-416: crop the six lines to the voxel range covering new_aabb (host index arithmetic + slicing). The
+        reference dereferences ``self.alphaMask`` unconditionally; without a mask the aabb is corrected to the voxel range here, as
+        it is when the mask's grid differs from the field's."""
+        new_aabb = torch.as_tensor(new_aabb, dtype=torch.float32).to(self.aabb.device)
+        xyz_min, xyz_max = new_aabb
+        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
+        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+        b_r = torch.stack([b_r, self.gridSize]).amin(0)
+        for i in range(3):
+            v = VEC_MODE[i]
+            self.density_line[i] = nn.Parameter(self.density_line[i].data[..., t_l[v]:b_r[v], :].contiguous())
+            self.app_line[i] = nn.Parameter(self.app_line[i].data[..., t_l[v]:b_r[v], :].contiguous())
+        if self.alphaMask is None or not torch.all(self.alphaMask.gridSize.to(self.gridSize.device) == self.gridSize):
+            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
+            correct_aabb = torch.zeros_like(new_aabb)
+            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
+            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
+            new_aabb = correct_aabb
+        newSize = b_r - t_l
+        self.aabb = new_aabb
+        self._virt = None
+        self._drop_handle()
+        self.update_stepSize((int(newSize[0]), int(newSize[1]), int(newSize[2])))
 
 
 class _RenderFn(torch.autograd.Function):
