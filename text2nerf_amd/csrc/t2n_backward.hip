@@ -16,6 +16,8 @@
 //   6  k_relayout_add          channel-last gradient buffers -> += reference-layout [1,C,H,W] gradient tensors
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "t2n_device.h"
 
 namespace t2n {
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(256) void k_bwd_bin(const BinArgs a) {
 // values, and issue 4 + 2 ds_add_f64.
 constexpr int kAccThreads = 512;
 struct TileAccumArgs {
-    FactorSet S; GradSet G; BinGeom geom; const int4* segs; const unsigned* nseg; const float4* recs; int dbg;
+    FactorSet S; GradSet G; BinGeom geom; const int4* segs; const unsigned* nseg; const float4* recs;
     // appearance: rec.w holds the activation row (int bits) and the gradient of channel c of pair K is gx[row * gx_ld + K * CT + c];
     // density (gx == NULL): rec.w is dL/dfeature itself, the same for all channels
     const float* gx; int gx_ld;
@@ -619,21 +621,20 @@ __global__ __launch_bounds__(kAccThreads) void k_bwd_tile_accum(const TileAccumA
     }
     for (int idx = threadIdx.x; idx < (TP + (L + 2) * C) / 2; idx += kAccThreads) reinterpret_cast<float4*>(Pa)[idx] = zero4;
     __syncthreads();
-    if (a.dbg & 8) {}
-    else if (k == 0) tile_accum_records<CT, 0>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
+    if (k == 0) tile_accum_records<CT, 0>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
     else if (k == 1) tile_accum_records<CT, 1>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
     else tile_accum_records<CT, 2>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
     __syncthreads();
     for (int idx = threadIdx.x; idx < TP; idx += kAccThreads) {
         const float v = (float)Pa[idx];
-        if (v != 0.f && !(a.dbg & 2)) {
+        if (v != 0.f) {
             const int cell = idx / C, c = idx - cell * C, ly = cell / T1, lx = cell - ly * T1, y = y0 + ly, x = x0 + lx;
             if (x >= 0 && x < W && y >= 0 && y < H) atomicAdd(gP + ((size_t)y * W + x) * CT + coff + c, v);
         }
     }
     for (int idx = threadIdx.x; idx < L * C; idx += kAccThreads) {
         const float v = (float)La[C + idx];
-        if (v != 0.f && !(a.dbg & 1)) atomicAdd(gL + (size_t)(idx / C) * CT + coff + (idx % C), v);
+        if (v != 0.f) atomicAdd(gL + (size_t)(idx / C) * CT + coff + (idx % C), v);
     }
     }   // segments
 }
@@ -1198,15 +1199,30 @@ using namespace t2n;
 // t2n_render_forward) with an event behind the copy: the backward waits for THAT event, not for the stream — the loss ops queued
 // between forward and backward keep the GPU busy while the host sizes and launches the backward. Slots are matched by workspace
 // pointer; a forward from another library build / an evicted slot falls back to the stream-draining read.
-struct CtxSlot { const void* ws; hipEvent_t ev; unsigned* host; bool valid; };
-static CtxSlot g_ctx[8];
+// The ring is process-wide (the C-ABI's t2n_render_ctx_rows takes the workspace, not the field): slots are keyed by (device,
+// workspace), guarded by a mutex (fields driven from several host threads), and a slot's event and pinned buffer belong to the device
+// that was current when they were made — a slot taken over by another device re-creates them there. 32 slots: a forward whose slot
+// has been evicted before its backward only falls back to the stream-draining read.
+struct CtxSlot { const void* ws; hipEvent_t ev; unsigned* host; bool valid; int dev; };
+constexpr int kCtxSlots = 32;
+static CtxSlot g_ctx[kCtxSlots];
 static unsigned g_ctx_next = 0;
+static std::mutex g_ctx_mutex;
 int t2n::ctx_counts_post(const void* ws, const unsigned* counters_dev, hipStream_t s) {
-    for (auto& q : g_ctx) if (q.valid && q.ws == ws) q.valid = false;
-    CtxSlot& c = g_ctx[g_ctx_next++ % 8];
+    int dev = 0;
+    T2N_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    for (auto& q : g_ctx) if (q.valid && q.ws == ws && q.dev == dev) q.valid = false;
+    CtxSlot& c = g_ctx[g_ctx_next++ % kCtxSlots];
+    if (c.host && c.dev != dev) {
+        (void)hipEventDestroy(c.ev);
+        (void)hipHostFree(c.host);
+        c.host = nullptr;
+    }
     if (!c.host) {
         T2N_HIP(hipHostMalloc((void**)&c.host, sizeof(unsigned) * kLists * kCounterStride, hipHostMallocDefault));
         T2N_HIP(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+        c.dev = dev;
     }
     c.ws = ws;
     T2N_HIP(hipMemcpyAsync(c.host, counters_dev, sizeof(unsigned) * kLists * kCounterStride, hipMemcpyDeviceToHost, s));
@@ -1220,18 +1236,28 @@ static int read_counts(const void* fwd_ws, int64_t n_rays, int n_samples, hipStr
     const Carve c = carve_workspace(n_rays, n_samples, true, false);
     unsigned raw[kLists * kCounterStride];
     CtxSlot* slot = nullptr;
-    for (auto& q : g_ctx) if (q.valid && q.ws == fwd_ws) slot = &q;
+    int dev = 0;
+    T2N_HIP(hipGetDevice(&dev));
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        for (auto& q : g_ctx) if (q.valid && q.ws == fwd_ws && q.dev == dev) slot = &q;
+        if (slot) ev = slot->ev;
+    }
     if (slot) {
-        T2N_HIP(hipEventSynchronize(slot->ev));
-        memcpy(raw, slot->host, sizeof(raw));
-    } else {
+        T2N_HIP(hipEventSynchronize(ev));     // (outside the lock: other threads keep posting)
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        if (slot->valid && slot->ws == fwd_ws && slot->dev == dev) memcpy(raw, slot->host, sizeof(raw));
+        else slot = nullptr;                    // taken over meanwhile: read from the device below
+    }
+    if (!slot) {
         T2N_HIP(hipMemcpyAsync(raw, (const char*)fwd_ws + c.counters, sizeof(raw), hipMemcpyDeviceToHost, s));
         T2N_HIP(hipStreamSynchronize(s));
     }
     for (int l = 0; l < kLists; ++l) counts[l] = raw[l * kCounterStride];
     if (kept_rows_stated) *kept_rows_stated = raw[kKeptMagicWord] == kKeptMagic ? raw[kKeptRowsWord] : 0u;
     if (consume) {   // the backward overwrites the kept rows in place: a second backward on this workspace must recompute
-        if (slot) slot->host[kKeptMagicWord] = 0u;
+        if (slot) { std::lock_guard<std::mutex> lock(g_ctx_mutex); if (slot->valid && slot->ws == fwd_ws) slot->host[kKeptMagicWord] = 0u; }
         T2N_HIP(hipMemsetAsync((char*)const_cast<void*>(fwd_ws) + c.counters + kKeptMagicWord * 4, 0, 4, s));
     }
     unsigned t = 0;
@@ -1387,7 +1413,6 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             TileAccumArgs ta;
             ta.S = f->dev.den; ta.G = a.gden; ta.geom = geom; ta.segs = (const int4*)(bw + b.segs);
             ta.nseg = (const unsigned*)(bw + b.nseg); ta.recs = (const float4*)(bw + b.recs);
-            ta.dbg = getenv("T2N_DEBUG_ACCUM") ? atoi(getenv("T2N_DEBUG_ACCUM")) : 0;
             ta.gx = nullptr; ta.gx_ld = 0;
             T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
             hipLaunchKernelGGL((k_bwd_tile_accum<16>), dim3(b.seg_cap < kAccGrid ? b.seg_cap : kAccGrid, 1), dim3(kAccThreads), lds_acc, sd, ta);
@@ -1462,16 +1487,9 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             TileAccumArgs ta;
             ta.S = f->dev.app; ta.G = sa.gapp; ta.geom = ab.geom; ta.segs = (const int4*)(bw + b.a_segs);
             ta.nseg = (const unsigned*)(bw + b.a_nseg); ta.recs = (const float4*)(bw + b.a_recs);
-            ta.dbg = 0; ta.gx = gxapp; ta.gx_ld = 144;
+            ta.gx = gxapp; ta.gx_ld = 144;
             T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bin));
             hipLaunchKernelGGL((k_bwd_tile_accum<48>), dim3(b.a_seg_cap < kAccGrid ? b.a_seg_cap : kAccGrid, 3), dim3(kAccThreads), lds_bin, s, ta);
-            if (getenv("T2N_DEBUG_NSEG")) {
-                unsigned nd = 0, na = 0;
-                (void)hipStreamSynchronize(s);
-                (void)hipMemcpy(&nd, bw + b.nseg, 4, hipMemcpyDeviceToHost);
-                (void)hipMemcpy(&na, bw + b.a_nseg, 4, hipMemcpyDeviceToHost);
-                fprintf(stderr, "[t2n] segments: density %u (cap %u), appearance %u (cap %u), rows %lld\n", nd, b.seg_cap, na, b.a_seg_cap, (long long)rows);
-            }
         } else {
             unsigned blocks = (unsigned)((rows / 32 + 3) / 4);
             if (blocks > 2048) blocks = 2048;

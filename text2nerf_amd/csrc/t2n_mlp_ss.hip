@@ -68,35 +68,6 @@ struct Args {
 
 #define SS_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// timing-only experiment switches (wrong results): which part of a chunk's time belongs to what
-#ifdef T2N_SS_EXP_NOFILL
-constexpr bool kExpNoFill = true;
-#else
-constexpr bool kExpNoFill = false;
-#endif
-#ifdef T2N_SS_EXP_NOBAR
-constexpr bool kExpNoBar = true;
-#else
-constexpr bool kExpNoBar = false;
-#endif
-#ifdef T2N_SS_EXP_NORING
-constexpr bool kExpNoRing = true;
-#else
-constexpr bool kExpNoRing = false;
-#endif
-#ifdef T2N_SS_EXP_NOA
-constexpr bool kExpNoA = true;
-#else
-constexpr bool kExpNoA = false;
-#endif
-
-#ifdef T2N_PHASE_TIMING
-__device__ unsigned long long g_ss_phase[8 * 16];   // [wave][phase]
-#define SS_PHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); phacc[i] += t_ - tph; tph = t_; } while (0)
-#else
-#define SS_PHASE(i) do {} while (0)
-#endif
-
 __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
@@ -224,7 +195,7 @@ __device__ __forceinline__ void slots(f32x16 (&acc)[4], AOp (&A)[2][2], const ui
     if constexpr (M < 12) {
         constexpr int g = M / 6, k = M % 6, p = k / 2, i = k % 2, u = 2 * g + i;
         acc[u] = mfma(p == 1 ? A[g][i].l : A[g][i].h, p == 2 ? Bl : Bh, acc[u]);
-        if constexpr (k == 0 && !kExpNoA) {
+        if constexpr (k == 0) {
             if constexpr (g == 0) {
                 A[1][0].h = cur[2 * 128]; A[1][0].l = cur[2 * 128 + 64]; A[1][1].h = cur[3 * 128]; A[1][1].l = cur[3 * 128 + 64];
             } else {
@@ -251,7 +222,7 @@ __device__ __forceinline__ void step2(f32x16 (&ch)[3], AOp (&A)[2][2], const uin
     F.template run<4>(); F.template run<5>(); F.template run<6>(); F.template run<7>();
     SS_FENCE();
     ch[2] = mfma(A[0][b].h, Hl, ch[2]);
-    if constexpr (!kExpNoA) { A[0][b].h = nxt[0]; A[0][b].l = nxt[64]; }
+    A[0][b].h = nxt[0]; A[0][b].l = nxt[64];
     F.template run<8>(); F.template run<9>(); F.template run<10>(); F.template run<11>();
     F.done();
     SS_FENCE();
@@ -358,20 +329,11 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
         EncFill<0> f{E, Bh[0], Bl[0], neg1};
         fill_all(f);
     }
-    if constexpr (kExpNoFill) { Bh[1] = Bl[0]; Bl[1] = Bh[0]; }
     __syncthreads();   // W1 / W2 / bias / ring slots 0, 1 visible
     AOp A[2][2];
     A[0][0].h = LA0[kW2]; A[0][0].l = LA0[kW2 + 64]; A[0][1].h = LA0[kW2 + 128]; A[0][1].l = LA0[kW2 + 128 + 64];
-#ifdef T2N_PHASE_TIMING
-    unsigned long long phacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tph = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef T2N_SS_PRIO
-    if (w >= 4) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every arbitration otherwise
-#endif
 
     for (unsigned r = blockIdx.x; r < nrounds; r += gridDim.x) {
-        SS_PHASE(15);
         // ---- layer 0: 12 chunks of two K-steps; a step multiplies while the next one is encoded, chunk C + 2 enters the ring -------
         f32x16 acc0[4];
 #pragma unroll
@@ -389,27 +351,17 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
         const float wgt = wnext;
 #define SS_L0(C)                                                                                                                  \
         {                                                                                                                         \
-            SS_PHASE(0);                                                                                                          \
-            if constexpr (!kExpNoBar) __syncthreads();   /* chunk C + 1 written by every wave; chunk C - 1 read by every wave */  \
-            SS_PHASE(5);                                                                                                          \
+            __syncthreads();   /* chunk C + 1 written by every wave; chunk C - 1 read by every wave */                            \
             RingOps ring{S, RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0};   /* lands before the next barrier */                  \
-            SS_PHASE(6);                                                                                                          \
             const uint4* __restrict__ cur = LA0 + kW2 + (C % 3) * kChunk;                                                         \
             const uint4* __restrict__ nxt = C < 10 ? LA0 + kW2 + ((C + 1) % 3) * kChunk : LA1;                                    \
             /* 22 K-steps: chunks 0..10; chunk 11 of the stream is padding (its iteration only keeps the ring's rhythm) */         \
             if constexpr (C == 11) {                                                                                              \
-                if constexpr (!kExpNoRing) { S.dma<0>(RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0); S.dma<1>(RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0); } \
+                S.dma<0>(RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0); S.dma<1>(RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0);   \
             } else {                                                                                                              \
-                if constexpr (!kExpNoFill) {                                                                                      \
-                    EncFill<2 * C + 1> f0{E, Bh[1], Bl[1], neg1};                                                                 \
-                    if constexpr (kExpNoRing) slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0);                              \
-                    else slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0, ring);                                             \
-                } else {                                                                                                          \
-                    NoFill f0;                                                                                                    \
-                    if constexpr (kExpNoRing) slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0);                              \
-                    else slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0, ring);                                             \
-                }                                                                                                                 \
-                if constexpr (C < 10 && !kExpNoFill) {                                                                            \
+                EncFill<2 * C + 1> f0{E, Bh[1], Bl[1], neg1};                                                                     \
+                slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0, ring);                                                      \
+                if constexpr (C < 10) {                                                                                           \
                     EncFill<(C < 10 ? 2 * C + 2 : 0)> f1{E, Bh[0], Bl[0], neg1};                                                  \
                     slots<0>(acc0, A, Bh[1], Bl[1], cur + kStep, nxt, f1);                                                        \
                 } else {                                                                                                          \
@@ -420,14 +372,12 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
         }
         SS_L0(0) SS_L0(1) SS_L0(2) SS_L0(3) SS_L0(4) SS_L0(5) SS_L0(6) SS_L0(7) SS_L0(8) SS_L0(9) SS_L0(10) SS_L0(11)
 #undef SS_L0
-        SS_PHASE(0);
         // ---- h0 -> layer-1 B operands (step 0 here, steps 1..7 in the slots of layer 1); no barrier from here to the next round ------
         uint4 H0h[8], H0l[8];
         {
             ConvFill<0> f{acc0, H0h, H0l, E, inv0, neg1, amax};
             fill_all(f);
         }
-        SS_PHASE(1);
         f32x16 acc1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -450,7 +400,6 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
         }
         SS_L1(0) SS_L1(1) SS_L1(2) SS_L1(3) SS_L1(4) SS_L1(5) SS_L1(6) SS_L1(7)
 #undef SS_L1
-        SS_PHASE(2);
         // ---- h1 -> layer-2 B operands, layer 2 (three product chains), sigmoid, store ---------------------------------------------------
         // (layer 1's last pair fetched W2 steps 0 / 1 as if they were a tile pair: A[0][0] = step 0, A[0][1] = step 1)
         load_feat(rn, E.in.f);                  // the next round's features: in flight under layer 2, encoded in its last step
@@ -483,7 +432,6 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
         finish_feat(E.in);
         SS_L2(7)
 #undef SS_L2
-        SS_PHASE(3);
         const unsigned tile = r * 8u + (unsigned)w;
         if (tile < ntiles && h == 0) {   // output rows 0..2 live in registers 0..2 of lanes 0..31
             const uint4 i0 = *reinterpret_cast<const uint4*>(LT), i1 = *reinterpret_cast<const uint4*>(LT + 4);
@@ -503,12 +451,8 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
                                              __builtin_amdgcn_rcpf(1.f + __expf(-bb)), wgt);
             }
         }
-        SS_PHASE(4);
     }
-#ifdef T2N_PHASE_TIMING
-    if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_ss_phase[w * 16 + i], phacc[i]);
-#endif
-    if (!(kExpNoFill || kExpNoBar || kExpNoRing || kExpNoA) && __any(!((float)amax[0] < kRange) || !((float)amax[1] < kRange) || amax_u > __float_as_uint(kRange)) && lane == 0) atomicOr(a.range_flag, 1u);
+    if (__any(!((float)amax[0] < kRange) || !((float)amax[1] < kRange) || amax_u > __float_as_uint(kRange)) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
 // ---- operand packing -----------------------------------------------------------------------------------------------------
@@ -652,10 +596,3 @@ int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev,
 
 }  // namespace t2n
 
-#ifdef T2N_PHASE_TIMING
-extern "C" int t2n_debug_ss_phase_read(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(t2n::ss::g_ss_phase), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[128] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(t2n::ss::g_ss_phase), z, sizeof(z)) != hipSuccess) return -1; }
-    return 0;
-}
-#endif

@@ -648,61 +648,8 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
 }
 
 // ---- features only (K2a of the default render path): gather + basis_mat -> fp32 feature rows [tile * 32 + sample][32] for the
-// sample-stationary head (t2n_mlp_ss.hip). The gather and basis stages of k_shade<true> without the head's code and registers:
-// one wave per 32-sample tile, X[144][33] through the wave's LDS tile, basis_mat as split-f16 MFMA products (weights x 2^8).
-// Raises *range_flag when a plane x line product left the f16 range (inf / NaN features are caught by the head's own check).
-template <bool HALF>
-__global__ __launch_bounds__(256, 2) void k_app_features(const ShadeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int s = lane & 31, h = lane >> 5;
-    float* __restrict__ X = smem + (size_t)wid * kTileFloats;
-    const FieldDev& F = a.F;
-    unsigned cnt_l = 0;
-    if (lane < a.nlists) {
-        cnt_l = a.counters[lane * kCounterStride];
-        if (cnt_l > a.list_cap) cnt_l = a.list_cap;
-    }
-    unsigned incl = (cnt_l + 31u) / 32u;
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-        const unsigned t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    unsigned ntiles = __shfl(incl, a.nlists - 1);
-    if (ntiles > a.tile_hi) ntiles = a.tile_hi;
-    if (a.split_unsafe && (*a.split_unsafe & kUnsafeBasis)) {   // basis_mat weights beyond the fixed pre-scale's range: the launch is redone on the exact path
-        if (a.range_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.range_flag, 1u);
-        return;
-    }
-    const unsigned wave_stride = gridDim.x * 4u;
-    float amax = 0.f;
-    for (unsigned tile = blockIdx.x * 4u + wid; tile < ntiles; tile += wave_stride) {
-        const int li = (int)__popcll(__ballot((lane < a.nlists) & (incl <= tile)));
-        const unsigned before = li ? __shfl(incl, li - 1) : 0u;
-        const unsigned lbase = (unsigned)li * a.list_cap;
-        const unsigned base = lbase + (tile - before) * 32u;
-        const unsigned count = lbase + __shfl(cnt_l, li);
-        gather_all<HALF>(F.app, X, lane, a.app_pos, nullptr, base, count, nullptr, 0);
-        wave_lds_sync();
-        f32x16 accb1[1] = {{0}};
-        LdsChunk bf{X + s, h, kBasisChunksReal};
-        f16_stream<1>(accb1, F.basisH, lane, kBasisChunks, bf, amax);
-        const f32x16 accb = accb1[0] * kWUnscale;
-        // lane (s, h) register v holds feature (v & 3) + 8 (v >> 2) + 4 h: four float4 stores per lane. Column 27 (a zero of the
-        // padded basis) carries the entry's compositing weight to the head, which hands it on in app_rgb.w
-        float* __restrict__ row = a.ctx.feat32 + ((size_t)tile * 32 + s) * 32 + 4 * h;
-        const unsigned eidx = base + (unsigned)s;
-        const float wgt = (h == 0 && eidx < count) ? a.app_pos[eidx].w : 0.f;   // lane (s, 0) holds columns 24..27 in registers 12..15
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(row + 8 * g) = make_float4(accb[4 * g], accb[4 * g + 1], accb[4 * g + 2], (g == 3 && h == 0) ? wgt : accb[4 * g + 3]);
-        wave_lds_sync();   // X reads done before the next tile's gather
-    }
-    if (a.range_flag && __any(!(amax <= 60000.f)) && lane == 0) atomicOr(a.range_flag, 1u);
-}
-
-// ---- the same stage, one factor pair at a time (default) -------------------------------------------------------------------
+// sample-stationary head (t2n_mlp_ss.hip), one factor pair at a time. (The first form of this stage, a 144-row X tile per wave
+// with two waves per SIMD, ran 0.64 ms per C2 frame against 0.58: DESIGN.md, v23 / v25; it lives in the history, not here.)
 // k_app_features holds a 144-row X tile per wave (19 KB: eight waves per CU) and two 18-load items in flight (180 VGPRs): two
 // waves per SIMD to hide a gather that sits on the L1's 64 B/clk. Here a wave walks the three plane/line pairs in turn: gather
 // pair k (6 taps per item, 48 rows of X: 6.3 KB), three basis chunks on the matrix cores, next pair - 128 VGPRs, four waves
@@ -946,13 +893,8 @@ struct CoopRing {
     }
     __device__ __forceinline__ void advance(int c, uint4 (&A)[8]) {
         const int b = c & 1;
-#ifndef T2N_EXP_NOA
 #pragma unroll
         for (int i = 0; i < 8; ++i) A[i] = *slot(b, i * 64 + lane);
-#else
-#pragma unroll
-        for (int i = 0; i < 8; ++i) A[i] = make_uint4(c, lane, c, lane);
-#endif
         *slot(b ^ 1, tid) = n0; *slot(b ^ 1, 256 + tid) = n1;
         n0 = nn0; n1 = nn1;
         gload(nn0, nn1, c + 3);
@@ -972,16 +914,12 @@ __device__ __forceinline__ void coop_step(CoopRing& R, int c, f32x16 (&acc)[4], 
     for (int m = 0; m < 4; ++m) acc[m] = mfma16(__builtin_bit_cast(h8, A[2 * m]), blo, acc[m]);
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = mfma16(__builtin_bit_cast(h8, A[2 * m + 1]), bhi, acc[m]);
-#ifndef T2N_EXP_NOPREP
     float x[8];
     prep(x);
     h8 nhi, nlo;
     split8<TRACK>(x, nhi, nlo, amax);
     bhi = nhi; blo = nlo;
-#endif
-#ifndef T2N_EXP_NOBARRIER
     __syncthreads();
-#endif
 }
 
 // Layer-0 B operands in PeChunk's order, unrolled over the three-chunk period of (four pairs per chunk, six octaves per
@@ -1098,12 +1036,6 @@ __device__ __forceinline__ void coop_layer1(f32x16 (&acc)[4], const uint4* __res
         coop_step<true>(R, c, acc, bhi, blo, amax, [&](float (&x)[8]) { rows(c < kL1Chunks - 1 ? c + 1 : c, x); });
 }
 
-#ifdef T2N_PHASE_TIMING
-__device__ unsigned long long g_phase[8];
-#define T2N_PHASE(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); phacc[i] += t_ - tph; tph = t_; } while (0)
-#else
-#define T2N_PHASE(i) do {} while (0)
-#endif
 
 template <bool HALF>
 __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
@@ -1133,9 +1065,6 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
     }
     const unsigned block_stride = gridDim.x * 4u;
     float amax = 0.f;   // largest magnitude handed to an f16 convert: past the f16 range the launch is redone exactly
-#ifdef T2N_PHASE_TIMING
-    unsigned long long phacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
 
     // the block's four waves take tiles tile0 .. tile0+3 together; a wave past the end runs an all-dead tile
     for (unsigned tile0 = a.tile_lo + blockIdx.x * 4u; tile0 < ntiles; tile0 += block_stride) {
@@ -1148,12 +1077,8 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
             base = lbase + (tile - before) * 32u;
             count = lbase + __shfl(cnt_l, li);
         }
-#ifdef T2N_PHASE_TIMING
-        unsigned long long tph = __builtin_amdgcn_s_memtime();
-#endif
         gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, nullptr, 0);
         wave_lds_sync();
-        T2N_PHASE(0);
 
         f32x16 accb1[1] = {{0}};
         {
@@ -1162,9 +1087,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
             accb1[0] *= kWUnscale;
         }
         const f32x16 accb = accb1[0];
-        T2N_PHASE(1);
         __syncthreads();   // every wave is done with X (whose tail overlaps the ring slices)
-        T2N_PHASE(2);
 #pragma unroll
         for (int v = 0; v < 16; ++v) Fe[unit_of(v, h) * kXld + s] = accb[v];
         wave_lds_sync();
@@ -1192,7 +1115,6 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
             if (__builtin_expect(__any(fmax_ * 8.f > 8192.f) != 0, 0)) coop_layer0_plain(acc0, F.w0H, Fe + s, h, smem, tid, lane);
             else coop_layer0(acc0, F.w0H, Fe + s, h, smem, tid, lane);
         }
-        T2N_PHASE(3);
         // the stream's last barrier also orders every wave's Fe reads before the H writes below
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
@@ -1204,9 +1126,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
         f32x16 acc1[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc1[m] = bias_init(F.biasH + 128, m, h);
-        T2N_PHASE(4);
         coop_layer1(acc1, F.w1H, Hs + s, h, smem, tid, lane, amax);
-        T2N_PHASE(5);
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
 #pragma unroll
@@ -1227,11 +1147,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
             if (a.rgb_out) { a.rgb_out[(size_t)idx * 3] = cr; a.rgb_out[(size_t)idx * 3 + 1] = cg; a.rgb_out[(size_t)idx * 3 + 2] = cb; }
         }
         wave_lds_sync();   // H reads done before the next tile's gather overwrites the tile
-        T2N_PHASE(6);
     }
-#ifdef T2N_PHASE_TIMING
-    if (lane == 0) for (int i = 0; i < 7; ++i) atomicAdd(&g_phase[i], phacc[i]);
-#endif
     if (a.range_flag && __any(!(amax <= 60000.f)) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
@@ -1418,13 +1334,11 @@ static int shade_grid(unsigned long long count_max) {
 
 constexpr size_t kCoopLds = (size_t)4 * kWaveFloats * sizeof(float);
 static bool use_coop(const t2n_field* f) {
-    static const bool off = getenv("T2N_SHADE_NO_COOP") != nullptr;   // A/B switch for profiling
-    return !off && f->mlp_split && f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW;
+    return f->mlp_split && f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW;
 }
 
 static bool use_ws(const t2n_field* f) {
-    static const bool off = getenv("T2N_SHADE_NO_WS") != nullptr;   // A/B switch: the one-kernel cooperative path instead of features + head
-    return !off && use_coop(f);
+    return use_coop(f);
 }
 
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
@@ -1444,8 +1358,6 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
     if (!attr_set) {
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        T2N_HIP(hipFuncSetAttribute((const void*)k_app_features<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        T2N_HIP(hipFuncSetAttribute((const void*)k_app_features<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds));
         attr_set = true;
@@ -1465,11 +1377,7 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
         fa.ctx_rows = ws_tiles * 32u; fa.tile_hi = ws_tiles;
         fa.range_flag = flag; fa.split_unsafe = f->split_unsafe;
         timing_begin(f, T2N_K_APPFEAT, s);
-        static const bool whole = getenv("T2N_APPFEAT_WHOLE") != nullptr;   // A/B switch: the 144-row kernel (two waves per SIMD)
-        if (whole) {
-            if (half) hipLaunchKernelGGL(k_app_features<true>, grid, dim3(256), lds, s, fa);
-            else hipLaunchKernelGGL(k_app_features<false>, grid, dim3(256), lds, s, fa);
-        } else {
+        {
             const size_t lds_p = (size_t)kPairBasisVec * 16 + (size_t)kPairWaves * kPairFloats * sizeof(float);
             static bool attr_p = false;
             if (!attr_p) {
@@ -1522,13 +1430,6 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
 
 using namespace t2n;
 
-#ifdef T2N_PHASE_TIMING
-extern "C" int t2n_debug_phase_read(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(t2n::g_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(t2n::g_phase), z, sizeof(z)) != hipSuccess) return -1; }
-    return 0;
-}
-#endif
 
 extern "C" size_t t2n_shade_workspace_bytes(int64_t n) { (void)n; return 256; }
 
