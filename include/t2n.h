@@ -259,9 +259,11 @@ int t2n_dibr_filter_mask2(float* image, int32_t* known, double* depth, int H, in
 /* ---- a-15: backward of the render call w.r.t. all field parameters (what autograd derives in the reference,
  * text2nerf_main.py:589; coordinates are detached there, models/tensoRF.py:208-210,226-228, so no ray gradients exist).
  * Protocol: (1) forward with T2N_FLAG_KEEP_CTX as ONE launch (workspace >= t2n_render_workspace_bytes_ctx), weights and
- * z_vals materialised; (2) t2n_render_ctx_rows reads the appearance-sample count back (SYNCHRONISES the stream) and
- * returns the padded activation row count; (3) t2n_render_backward with a second workspace of
- * t2n_backward_workspace_bytes(field, rows, n_rays, n_samples). Only the MLP_Fea_noview head is differentiable here (the driver's head).
+ * z_vals materialised; (2) t2n_render_ctx_rows returns the padded activation row count: the forward posted the
+ * appearance-sample counts to pinned host memory behind its march kernel, so this waits for THAT copy's event (the stream keeps
+ * running; a forward whose slot was evicted falls back to a stream-draining read); (3) t2n_render_backward with a second workspace of
+ * t2n_backward_workspace_bytes(field, rows, n_rays, n_samples). Differentiable heads: MLP_Fea_noview (fused chain), MLP_Fea and
+ * MLP (general path), SH, RGB — tests/test_hip_parity.py::test_g8_*, tests/test_heads.py, tests/test_shapes.py.
  * d_weights may be NULL. Gradients are ACCUMULATED into `g` (reference layouts; NULL members are skipped: the channel-last
  * plane / line gradients then stay in the field for t2n_field_tv_adam_step).
  * Optional: a forward workspace LARGER than t2n_render_workspace_bytes_ctx by 256 + rows * 1728 bytes lets the forward keep

@@ -12,6 +12,11 @@ SHAPES = {
     # a view-dependent head with a narrow hidden layer and the SH head on few components
     "fea64": dict(density_n_comp=[8, 8, 8], appearance_n_comp=[24, 24, 24], app_dim=27, shadingMode="MLP_Fea", fea_pe=2,
                   featureC=64, view_pe=2, pos_pe=6),
+    # the parameter-free heads at the kernels' own component counts (their backward: dL/dfeatures from the colour gradients)
+    "rgb": dict(density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=3, shadingMode="RGB", fea_pe=6, featureC=128,
+                view_pe=6, pos_pe=6),
+    "sh16": dict(density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=27, shadingMode="SH", fea_pe=6, featureC=128,
+                 view_pe=6, pos_pe=6),
     "sh": dict(density_n_comp=[4, 4, 4], appearance_n_comp=[12, 12, 12], app_dim=27, shadingMode="SH", fea_pe=6, featureC=128,
                view_pe=6, pos_pe=6),
 }

@@ -62,6 +62,9 @@ def test_embedding_is_exact_on_the_oracle(tiny, gs, tag):
     tensors equals the oracle on the real ones, and gradients taken through the embedding equal the reference's autograd goldens."""
     kw = SHAPES[tag]
     m = _field(kw, "cpu")
+    if tag in ("rgb", "sh16"):
+        assert not m._needs_embed()
+        return
     assert m._needs_embed()
     emb = m._embedded_params()
     kd, ka, kdim, kpe, kfc = m._kernel_shape()

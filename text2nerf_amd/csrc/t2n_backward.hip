@@ -1293,7 +1293,9 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     }
     if (!f->uploaded) { set_error("t2n_render_backward: field has no uploaded parameters"); return T2N_ERR_STATE; }
     const bool generic = head_is_generic(f->desc.shading);
-    if (f->desc.shading != T2N_SHADE_MLP_FEA_NOVIEW && !generic) { set_error("t2n_render_backward: the SH / RGB heads have no parameters to differentiate here"); return T2N_ERR_UNSUPPORTED; }
+    // SH / RGB: no head parameters, but the colour gradients still reach basis_mat and the appearance factors
+    const bool simple = f->desc.shading == T2N_SHADE_SH || f->desc.shading == T2N_SHADE_RGB;
+    if (f->desc.shading != T2N_SHADE_MLP_FEA_NOVIEW && !generic && !simple) { set_error("t2n_render_backward: unknown shading head %d", f->desc.shading); return T2N_ERR_UNSUPPORTED; }
     const int K0 = generic ? head_dims(f->desc).K0 : 351, K0pad = (K0 + 3) & ~3;
     if (!(flags & T2N_FLAG_KEEP_CTX)) { set_error("t2n_render_backward: forward was not run with T2N_FLAG_KEEP_CTX"); return T2N_ERR_STATE; }
     if ((flags & (T2N_FLAG_TRAIN | T2N_FLAG_NDC)) && !jitter) { set_error("t2n_render_backward: train / NDC mode needs the jitter draws / depth table"); return T2N_ERR_INVALID; }
@@ -1429,7 +1431,12 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         static const bool unfused_env = getenv("T2N_BWD_UNFUSED") != nullptr;   // A/B switch: the five-launch form of the input-gradient chain
         const bool fused = !generic && !gemm_fp32 && !unfused_env && f->desc.app_dim == 27 && K0 == 351;
         void* gpack = (void*)(bw + b.gpack);
-        if (fused) {
+        if (simple) {
+            // parameter-free heads: dL/dfeatures straight from the colour gradients, then basis_mat's two products on the exact path
+            if ((rc = launch_simple_head_bwd(f, tp.t, rows, (const float4*)go, app_rgb, app_ray, rays, ray_stride, counters, c.list_cap, gf, s))) return rc;
+            if (g->basis_weight) launch_gemm_tn<1>(true, gf, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, s);
+            launch_gemm_nn(gf, 32, P->basis_weight, 144, rows, f->desc.app_dim, 144, nullptr, 0, gxapp, 144, s);
+        } else if (fused) {
             // the input-gradient chain as ONE kernel (t2n_mlp_bwd_ss.hip): k_bwd_l2 only accumulates dW2 / db2 (h1 stays intact for it),
             // the chain writes g1 over h1 and g0 / gf / gX into the (otherwise unused) encoding buffer
             float* G0 = xpe; float* GF = xpe + (size_t)rows * 128; float* GX = xpe + (size_t)rows * 160;

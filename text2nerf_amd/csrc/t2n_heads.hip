@@ -119,6 +119,67 @@ __global__ __launch_bounds__(256) void k_head_in_bwd(const HeadDims H, const flo
     gf[r * 32 + f] = g;
 }
 
+// Backward of the parameter-free heads: gf [rows,32] = dL/dfeatures from go [rows] = dL/drgb of the appearance samples.
+// RGBRender (models/tensorBase.py:35-38): rgb = features -> gf[c] = go[c]. SHRender (:29-33, models/sh.py:87-112, degree 2):
+// rgb[c] = relu(sum_b sh_b(viewdir) feat[9 c + b] + 0.5) -> gf[9 c + b] = go[c] [rgb[c] > 0] sh_b.
+struct SimpleHeadBwdArgs {
+    int shading, ndc; const float4* go; const float4* app_rgb; const int* app_ray; const float* rays; int ray_stride;
+    const unsigned* counters; unsigned list_cap; TilePrefixH tp; long long rows; float* gf;
+};
+__global__ __launch_bounds__(256) void k_simple_head_bwd(const SimpleHeadBwdArgs a) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long r = t / 32;
+    const int f = (int)(t % 32);
+    if (r >= a.rows) return;
+    unsigned idx;
+    const bool live = row_entry(r, a.tp, a.counters, a.list_cap, idx);
+    float g = 0.f;
+    if (live) {
+        const float4 go = a.go[r];
+        if (a.shading == T2N_SHADE_RGB) {
+            g = f == 0 ? go.x : (f == 1 ? go.y : (f == 2 ? go.z : 0.f));
+        } else if (f < 27) {
+            const int c = f / 9, b = f - 9 * c;
+            const float4 rgb = a.app_rgb[idx];
+            const float gc = c == 0 ? go.x : (c == 1 ? go.y : go.z), vc = c == 0 ? rgb.x : (c == 1 ? rgb.y : rgb.z);
+            if (vc > 0.f) {
+                const float* rp = a.rays + (size_t)a.app_ray[idx] * a.ray_stride;
+                float dx = rp[3], dy = rp[4], dz = rp[5];
+                if (a.ndc) { const float n = sqrtf((dx * dx + dy * dy) + dz * dz); dx = dx / n; dy = dy / n; dz = dz / n; }
+                const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+                const float C20 = 1.0925484305920792f, C21 = -1.0925484305920792f, C22 = 0.31539156525252005f,
+                            C23 = -1.0925484305920792f, C24 = 0.5462742152960396f;
+                float sh;
+                switch (b) {
+                    case 0: sh = C0; break;
+                    case 1: sh = -C1 * dy; break;
+                    case 2: sh = C1 * dz; break;
+                    case 3: sh = -C1 * dx; break;
+                    case 4: sh = C20 * (dx * dy); break;
+                    case 5: sh = C21 * (dy * dz); break;
+                    case 6: sh = C22 * (2.0f * (dz * dz) - dx * dx - dy * dy); break;
+                    case 7: sh = C23 * (dx * dz); break;
+                    default: sh = C24 * (dx * dx - dy * dy); break;
+                }
+                g = gc * sh;
+            }
+        }
+    }
+    a.gf[r * 32 + f] = g;
+}
+
+int launch_simple_head_bwd(t2n_field* f, const unsigned tiles_before[kLists + 1], long long rows, const float4* go, const float4* app_rgb,
+                           const int* app_ray, const float* rays, int ray_stride, const unsigned* counters, unsigned list_cap, float* gf,
+                           hipStream_t s) {
+    SimpleHeadBwdArgs a;
+    a.shading = f->desc.shading; a.ndc = f->dev.ztab ? 1 : 0; a.go = go; a.app_rgb = app_rgb; a.app_ray = app_ray; a.rays = rays;
+    a.ray_stride = ray_stride; a.counters = counters; a.list_cap = list_cap; a.rows = rows; a.gf = gf;
+    for (int l = 0; l <= kLists; ++l) a.tp.t[l] = tiles_before[l];
+    hipLaunchKernelGGL(k_simple_head_bwd, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, s, a);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
 // OUT[rows, N] = act(IN[rows, K] Wt[N, K]^T + bias): a workgroup owns one 64-column group of N; its K x 64 slab of W^T is
 // staged once (row stride 65: conflict-free both ways), 4 waves walk 32-row tiles, rows on the MFMA N axis, columns on M.
 // K <= 512 (LDS), ldin % 4 == 0 with finite padding columns, ldo % 4 == 0.

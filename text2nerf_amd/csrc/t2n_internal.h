@@ -178,6 +178,10 @@ int launch_head_forward(t2n_field* f, const unsigned tiles_before[kLists + 1], l
                         const int* app_ray, const float* rays, int ray_stride, const unsigned* counters, unsigned list_cap, float* x0,
                         float* h0, float* h1, float4* app_rgb, hipStream_t s);
 int launch_head_in_bwd(t2n_field* f, const float* gx, const float* feat32, long long rows, float* gf, hipStream_t s);
+// backward of the parameter-free SH / RGB heads: dL/dfeatures rows from the per-sample colour gradients (t2n_heads.hip)
+int launch_simple_head_bwd(t2n_field* f, const unsigned tiles_before[kLists + 1], long long rows, const float4* go, const float4* app_rgb,
+                           const int* app_ray, const float* rays, int ray_stride, const unsigned* counters, unsigned list_cap, float* gf,
+                           hipStream_t s);
 
 // input-gradient GEMMs of the MLP backward on the f16 matrix cores (t2n_gemm_h.hip)
 size_t gemm_h_pack_bytes(int K0);
