@@ -2,7 +2,9 @@
 data_dim_color, fea_pe, featureC: models/tensoRF.py:144-160, models/tensorBase.py:88-109, e_opt.py:83-107) against goldens produced
 by the reference (tests/golden/make_golden_shapes.py). Smaller shapes run on the same HIP kernels through an exact zero-padding
 embedding (text2nerf_amd/tensorf.py::_embedded_params). CPU: the oracle vs the goldens, and the embedding's algebra (the oracle on
-the embedded tensors == the oracle on the real ones, values and gradients). GPU: the HIP render and its gradients vs the goldens."""
+the embedded tensors == the oracle on the real ones, values and gradients). GPU: the HIP render and its gradients vs the goldens.
+The generator picks, per shape, the first parameter seed whose train pass keeps every ReLU input at least 5e-6 away from zero: a
+gradient comparison across implementations is only meaningful then (see make_golden_shapes.py::relu_margin)."""
 import os
 import sys
 
@@ -23,8 +25,8 @@ def gs():
     return dict(np.load(os.path.join(GOLDEN, "shapes.npz"), allow_pickle=False))
 
 
-def _params(kw):
-    return synth.make_field_params(41, TINY["grid"], density_n_comp=kw["density_n_comp"], app_n_comp=kw["appearance_n_comp"],
+def _params(kw, seed):
+    return synth.make_field_params(int(seed), TINY["grid"], density_n_comp=kw["density_n_comp"], app_n_comp=kw["appearance_n_comp"],
                                    app_dim=kw["app_dim"], feature_c=kw["featureC"], fea_pe=kw["fea_pe"], shading_mode=kw["shadingMode"],
                                    density_scale=0.9, aabb=TINY["aabb"], view_pe=kw["view_pe"], pos_pe=kw["pos_pe"])
 
@@ -34,11 +36,11 @@ def _cfg(kw, fea_pe=None):
                          fea_pe=kw["fea_pe"] if fea_pe is None else fea_pe, view_pe=kw["view_pe"], pos_pe=kw["pos_pe"])
 
 
-def _field(kw, device):
+def _field(kw, device, seed):
     from text2nerf_amd import TensorVMSplit
     m = TensorVMSplit(torch.tensor(TINY["aabb"]), TINY["grid"], device, near_far=TINY["near_far"], alphaMask_thres=1e-4,
                       density_shift=-10, distance_scale=25, step_ratio=1.0, fea2denseAct="softplus", **kw)
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in _params(kw).items()}, strict=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in _params(kw, seed).items()}, strict=True)
     return m
 
 
@@ -46,7 +48,7 @@ def _field(kw, device):
 def test_oracle_shapes_vs_reference(tiny, gs, tag):
     kw = SHAPES[tag]
     rays = torch.from_numpy(tiny["tiny_rays"])
-    rgb, depth, z, w = O.forward(_cfg(kw), O.params_from_numpy(_params(kw)), rays)
+    rgb, depth, z, w = O.forward(_cfg(kw), O.params_from_numpy(_params(kw, gs[f"{tag}_seed"])), rays)
     np.testing.assert_allclose(rgb.numpy(), gs[f"{tag}_eval_rgb"], atol=5e-6)
     np.testing.assert_allclose(depth.numpy(), gs[f"{tag}_eval_depth"], atol=2e-5)
     np.testing.assert_allclose(w.sum(-1).numpy(), gs[f"{tag}_eval_acc"], atol=5e-6)
@@ -61,7 +63,7 @@ def test_embedding_is_exact_on_the_oracle(tiny, gs, tag):
     """The tensors the kernels see (16 / 48 components, the 27 / 6 / 128 head) render the SAME field: the oracle on the embedded
     tensors equals the oracle on the real ones, and gradients taken through the embedding equal the reference's autograd goldens."""
     kw = SHAPES[tag]
-    m = _field(kw, "cpu")
+    m = _field(kw, "cpu", gs[f"{tag}_seed"])
     if tag in ("rgb", "sh16"):
         assert not m._needs_embed()
         return
@@ -115,7 +117,7 @@ def test_shapes_beyond_the_kernels_are_rejected_on_construction():
 def test_hip_shapes_forward_and_gradients_vs_reference(tiny, gs, tag):
     from tests.test_hip_parity import DEPTH_ATOL, RGB_ATOL, close, dev
     kw = SHAPES[tag]
-    m = _field(kw, dev())
+    m = _field(kw, dev(), gs[f"{tag}_seed"])
     rays = torch.from_numpy(tiny["tiny_rays"])
     with torch.no_grad():
         rgb, depth, z, w = m(rays)

@@ -277,9 +277,12 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
             const unsigned slot = (unsigned)ra.x + run + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
             const float4 c = a.app_rgb[slot];
             cr = c.x; cg = c.y; cb = c.z;
-            // rgb = sigmoid(o): dL/do = dL/drgb * rgb (1 - rgb), dL/drgb_sample = g_c * w
+            // MLP heads: rgb = sigmoid(o): dL/do = dL/drgb * rgb (1 - rgb), dL/drgb_sample = g_c * w. SH / RGB heads end without a
+            // sigmoid: their backward (k_simple_head_bwd) takes dL/drgb itself
+            const bool sig = F.shading != T2N_SHADE_SH && F.shading != T2N_SHADE_RGB;
             a.go[slot_to_row(slot, a.list_cap, a.tp)] =
-                make_float4(gr * w * cr * (1.f - cr), gg * w * cg * (1.f - cg), gb * w * cb * (1.f - cb), 0.f);
+                make_float4(gr * w * (sig ? cr * (1.f - cr) : 1.f), gg * w * (sig ? cg * (1.f - cg) : 1.f),
+                            gb * w * (sig ? cb * (1.f - cb) : 1.f), 0.f);
         }
         run += (unsigned)__popcll(bal);
         if (j < Lw) {
