@@ -13,6 +13,8 @@ class _TVPlaneSum(torch.autograd.Function):
     gradient: t2n_tv_grad_set) instead of ~15 eager elementwise / reduction kernels per plane with their 69-MB temporaries.
     Same arithmetic as TVLoss.forward (utils.py:488-504) with the sums taken in double."""
 
+    _COEF = {}     # (device, plane shapes) -> [P, 2] normalisers 1 / (c (h-1) w), 1 / (c h (w-1)) as a device tensor (float64)
+
     @staticmethod
     def forward(ctx, weight, *planes):
         lib = _lib.load()
@@ -21,16 +23,18 @@ class _TVPlaneSum(torch.autograd.Function):
         ctx.weight = float(weight)
         ctx.save_for_backward(*planes)
         with torch.cuda.device(dev):
+            st = _lib.current_stream_ptr(dev)
             for i, p in enumerate(planes):
                 b, c, h, w = p.shape
-                q = p.detach()
-                _lib.check(lib.t2n_tv_value(_lib.ptr(q), c, h, w, _lib.ptr(sums[i]), _lib.current_stream_ptr(dev)), "t2n_tv_value")
-        sums = sums.sum(1)
-        total = 0
-        for i, p in enumerate(planes):
-            b, c, h, w = p.shape
-            total = total + (sums[i, 0] / (c * (h - 1) * w) + sums[i, 1] / (c * h * (w - 1)))
-        return (total * (2.0 * ctx.weight)).to(torch.float32)
+                _lib.check(lib.t2n_tv_value(_lib.ptr(p.detach()), c, h, w, _lib.ptr(sums[i]), st), "t2n_tv_value")
+        key = (str(dev), tuple(tuple(p.shape) for p in planes))
+        coef = _TVPlaneSum._COEF.get(key)
+        if coef is None:
+            coef = torch.tensor([[1.0 / (p.shape[1] * (p.shape[2] - 1) * p.shape[3]), 1.0 / (p.shape[1] * p.shape[2] * (p.shape[3] - 1))]
+                                 for p in planes], dtype=torch.float64, device=dev)
+            _TVPlaneSum._COEF[key] = coef
+        # three small device ops for all planes (the host-bound training loop pays ~10 us per eager launch)
+        return ((sums.sum(1) * coef).sum() * (2.0 * ctx.weight)).to(torch.float32)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -38,13 +42,13 @@ class _TVPlaneSum(torch.autograd.Function):
         planes = ctx.saved_tensors
         dev = planes[0].device
         grads = []
+        up = grad_out.detach().to(torch.float32).reshape(1).contiguous()   # the upstream scalar, read on the device by the kernels
         with torch.cuda.device(dev):
+            st = _lib.current_stream_ptr(dev)
             for p in planes:
                 b, c, h, w = p.shape
-                g = torch.empty_like(p)           # written by the kernel, scaled by the upstream scalar read on the device
-                up = grad_out.detach().to(torch.float32).reshape(1).contiguous()
-                _lib.check(lib.t2n_tv_grad_set(_lib.ptr(p.detach()), _lib.ptr(g), c, h, w, ctx.weight, _lib.ptr(up),
-                                               _lib.current_stream_ptr(dev)), "t2n_tv_grad_set")
+                g = torch.empty_like(p)           # written by the kernel, scaled by the upstream scalar
+                _lib.check(lib.t2n_tv_grad_set(_lib.ptr(p.detach()), _lib.ptr(g), c, h, w, ctx.weight, _lib.ptr(up), st), "t2n_tv_grad_set")
                 grads.append(g)
         return (None, *grads)
 

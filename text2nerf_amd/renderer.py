@@ -98,7 +98,8 @@ def OctreeRender_trilinear_fast(rays, tensorf, chunk=4096, N_samples=-1, ndc_ray
                     N_samples=N_samples)
         for lst, t in zip(outs, o):
             lst.append(t)
-    rgb, depth, z, w = [torch.cat(x) if x[0] is not None else None for x in outs]
+    # (one chunk — the driver's batch — is handed through as it is: torch.cat of a single tensor is a copy of 2 x 17 MB per step)
+    rgb, depth, z, w = [(x[0] if len(x) == 1 else torch.cat(x)) if x[0] is not None else None for x in outs]
     return rgb, None, depth, w, z
 
 

@@ -951,7 +951,15 @@ class TensorVMSplit(nn.Module):
         if head_grads is not None and defer:
             grads = [None] * 12 + list(head_grads)
         else:
-            grads = [None if (defer and i < 12) else torch.zeros_like(p) for i, p in enumerate(params)]
+            # ONE zero-filled allocation for the gradient tensors (19 zeros_like calls are 19 allocations and 19 fill launches on a loop
+            # whose host side is the bottleneck); fresh per backward: autograd may adopt the views as the parameters' .grad
+            want = [p for i, p in enumerate(params) if not (defer and i < 12)]
+            flat = torch.zeros(sum(p.numel() for p in want), device=dev, dtype=torch.float32)
+            views, off = [], 0
+            for p in want:
+                views.append(flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            grads = [None] * (len(params) - len(want)) + views if defer else views
         gs = self._param_struct(self._kernel_views(grads), _lib.FieldGrads)
         R = rays.shape[0]
         d_rgb = torch.zeros(R, 3, device=dev) if d_rgb is None else d_rgb.contiguous().float()
