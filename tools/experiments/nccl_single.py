@@ -40,6 +40,12 @@ with torch.no_grad():
     assert torch.equal(out, tile) and torch.equal(rgb2, rgb)
     s_rgb, s_depth = render_sharded(rays, lambda r: field(r, white_bg=True, is_train=False, N_samples=-1)[:2])
     assert torch.equal(s_rgb, rgb) and torch.equal(s_depth, depth)
+    # round 3: interleaved 8-row bands (frame_width given) and the rank evidence bench.py gathers
+    s_rgb, s_depth = render_sharded(rays, lambda r: field(r, white_bg=True, is_train=False, N_samples=-1)[:2], frame_width=400)
+    assert torch.equal(s_rgb, rgb) and torch.equal(s_depth, depth)
+ids = [None]
+dist.all_gather_object(ids, dict(bench.device_identity(dev), rank=0))
+print("rank evidence:", ids, flush=True)
 broadcast_parameters(field.parameters())
 dist.barrier()
 torch.cuda.synchronize()
