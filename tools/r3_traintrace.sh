@@ -1,0 +1,9 @@
+#!/bin/bash
+out=gpurun_out/${1:-r3_traintrace}; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
+rocprofv3 --kernel-trace --output-format csv -d $out/prof -o t -- python3 tools/experiments/train_only.py 2 30 > $out/train.log 2>&1
+f=$(find $out/prof -name "*kernel_trace.csv" | head -1)
+python3 tools/train_timeline.py $f > $out/timeline.txt 2>&1
+cat $out/timeline.txt
+tail -1 $out/train.log | cut -c1-300
+rm -rf $out/prof
