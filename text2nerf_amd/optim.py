@@ -71,7 +71,7 @@ class TVAdam(torch.optim.Optimizer):
             else:
                 raise _lib.T2NError("TVAdam(field=...): tv entries must be tensorf.density_plane / tensorf.app_plane")
         lr_of = {id(p): float(g["lr"]) for g in self.param_groups for p in g["params"]}
-        lrs, steps, ms, vs = [], [], [], []
+        lrs, ms, vs = [], [], []
         for p in fac:
             if id(p) not in lr_of:
                 raise _lib.T2NError("TVAdam(field=...): every plane / line tensor of the field must be in a parameter group")
@@ -81,15 +81,23 @@ class TVAdam(torch.optim.Optimizer):
                 st["exp_avg_cl"] = torch.zeros(p.numel(), device=p.device, dtype=torch.float32)
                 st["exp_avg_sq_cl"] = torch.zeros(p.numel(), device=p.device, dtype=torch.float32)
             st["step"] += 1
-            lrs.append(lr_of[id(p)]); steps.append(int(st["step"])); ms.append(st["exp_avg_cl"]); vs.append(st["exp_avg_sq_cl"])
+            lrs.append(lr_of[id(p)]); ms.append(st["exp_avg_cl"]); vs.append(st["exp_avg_sq_cl"])
         dev = fac[0].device
-        VP = C.c_void_p * 12
+        # the pointer arrays only change when a moment tensor is re-created: built once, re-used every step (host-bound loops)
+        key = tuple(t.data_ptr() for t in ms) + tuple(t.data_ptr() for t in vs)
+        cache = getattr(self, "_cl_args", None)
+        if cache is None or cache[0] != key:
+            VP = C.c_void_p * 12
+            cache = self._cl_args = (key, VP(*[t.data_ptr() for t in ms]), VP(*[t.data_ptr() for t in vs]), (C.c_float * 12)(), (C.c_int64 * 12)())
+        _, ms_arr, vs_arr, lr_arr, step_arr = cache
+        for i, p in enumerate(fac):
+            lr_arr[i] = lrs[i]
+            step_arr[i] = int(self.state[p]["step"])
         with torch.cuda.device(dev):
             pst = f._param_struct([p.detach() for p in ps])
-            _lib.check(_lib.load().t2n_field_tv_adam_step(f._handle, C.byref(pst), VP(*[t.data_ptr() for t in ms]),
-                                                          VP(*[t.data_ptr() for t in vs]), (C.c_float * 12)(*lrs),
-                                                          (C.c_int64 * 12)(*steps), float(betas[0]), float(betas[1]), eps, tv_d, tv_a,
-                                                          _lib.current_stream_ptr(dev)), "t2n_field_tv_adam_step")
+            _lib.check(_lib.load().t2n_field_tv_adam_step(f._handle, C.byref(pst), ms_arr, vs_arr, lr_arr, step_arr, float(betas[0]),
+                                                          float(betas[1]), eps, tv_d, tv_a, _lib.current_stream_ptr(dev)),
+                       "t2n_field_tv_adam_step")
         for p in fac:
             _bump_version(p)
         f._device_factor_key = tuple((p.data_ptr(), p._version) for p in fac)   # the device copies are these values

@@ -89,7 +89,48 @@ class _PinnedRing:
         return out
 
 
+    def copy_many(self, ts, device):
+        """Several CPU tensors through ONE staging slot and ONE host -> device copy (a training step moves rays, jitter and two
+        target tensors: four copies, four event records otherwise). Returns device tensors shaped like the inputs (256-B aligned
+        slices of one buffer)."""
+        offs, total = [], 0
+        for t in ts:
+            offs.append(total)
+            total += (t.numel() * t.element_size() + 255) // 256 * 256
+        i = self.next
+        self.next = (i + 1) % self.SLOTS
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        if self.bufs[i] is None or self.bufs[i].numel() < total:
+            self.bufs[i] = torch.empty(max(total, 1 << 20), dtype=torch.uint8).pin_memory()
+        stage = self.bufs[i][:total]
+        for t, o in zip(ts, offs):
+            stage[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape).copy_(t)
+        dev_buf = stage.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self.events[i] = ev
+        return [dev_buf[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for t, o in zip(ts, offs)]
+
+
 _RING = {}
+
+
+def to_device_async_many(ts, device):
+    """``[t.to(device) for t in ts]`` with the CPU tensors among them staged together (see _PinnedRing.copy_many)."""
+    device = torch.device(device)
+    cpu = [k for k, t in enumerate(ts) if isinstance(t, torch.Tensor) and t.device.type == "cpu" and t.numel() and not t.is_pinned()]
+    if device.type != "cuda" or len(cpu) < 2:
+        return [to_device_async(t, device) for t in ts]
+    ring = _RING.get(str(device))
+    if ring is None:
+        ring = _RING[str(device)] = _PinnedRing()
+    out = [None if k in cpu else to_device_async(t, device) for k, t in enumerate(ts)]
+    with torch.cuda.device(device):
+        moved = ring.copy_many([ts[k].contiguous() for k in cpu], device)
+    for k, m in zip(cpu, moved):
+        out[k] = m
+    return out
 
 
 def to_device_async(t: torch.Tensor, device) -> torch.Tensor:
@@ -440,16 +481,25 @@ class TensorVMSplit(nn.Module):
         return self.KERNEL_DEN, self.KERNEL_APP, self.app_dim, self.fea_pe, self.KERNEL_FC if self.renderModule is not None else self.featureC
 
     def _needs_embed(self):
-        kd, ka, kdim, kpe, kfc = self._kernel_shape()
-        return (any(c != kd for c in self.density_n_comp) or any(c != ka for c in self.app_n_comp) or kdim != self.app_dim
-                or kpe != self.fea_pe or (self.renderModule is not None and kfc != self.featureC))
+        flag = self.__dict__.get("_embed_flag")
+        if flag is None:     # (component counts and head sizes are fixed at construction)
+            kd, ka, kdim, kpe, kfc = self._kernel_shape()
+            flag = (any(c != kd for c in self.density_n_comp) or any(c != ka for c in self.app_n_comp) or kdim != self.app_dim
+                    or kpe != self.fea_pe or (self.renderModule is not None and kfc != self.featureC))
+            self.__dict__["_embed_flag"] = flag
+        return flag
 
     def _real_params(self):
-        ps = list(self.density_plane) + list(self.density_line) + list(self.app_plane) + list(self.app_line)
-        ps.append(self.basis_mat.weight)
-        if self.renderModule is not None:
-            ps += [self.renderModule.mlp[0].weight, self.renderModule.mlp[0].bias, self.renderModule.mlp[2].weight,
-                   self.renderModule.mlp[2].bias, self.renderModule.mlp[4].weight, self.renderModule.mlp[4].bias]
+        """The 13 (+6) parameter tensors in kernel order. Read straight from the containers' dicts: nn.ParameterList / nn.Sequential
+        indexing costs ~2 us per element, and this list is built several times per training step on a host-bound loop."""
+        mods = self._modules
+        ps = [*mods["density_plane"]._parameters.values(), *mods["density_line"]._parameters.values(),
+              *mods["app_plane"]._parameters.values(), *mods["app_line"]._parameters.values(), mods["basis_mat"]._parameters["weight"]]
+        rm = mods.get("renderModule")
+        if rm is not None:
+            m = rm._modules["mlp"]._modules
+            ps += [m["0"]._parameters["weight"], m["0"]._parameters["bias"], m["2"]._parameters["weight"], m["2"]._parameters["bias"],
+                   m["4"]._parameters["weight"], m["4"]._parameters["bias"]]
         return ps
 
     def _embedded_params(self):
@@ -541,6 +591,8 @@ class TensorVMSplit(nn.Module):
         field (t2n_field_set_grad_buffer): deferred backward calls ACCUMULATE into it — a batch split into chunks, gradient
         accumulation, a data-parallel all-reduce in place (parallel.allreduce_gradients(field=...)) — and TVAdam(field=...) consumes
         and zeroes it."""
+        if getattr(self, "_gbuf", None) is not None:
+            return self._gbuf
         h = self.sync_params()
         if getattr(self, "_gbuf", None) is None:
             lib = _lib.load()
@@ -993,20 +1045,22 @@ class TensorVMSplit(nn.Module):
         lambda: parallel.allreduce_gradients(params, field=self)). Returns the device tensor [mse, depth loss, transmittance loss,
         total] of this batch (no host synchronisation). Same arithmetic as the autograd path: tests/test_train_step.py."""
         lib = _lib.load()
-        if any(not p.is_leaf for p in self._autograd_params()):
+        params = self._autograd_params()
+        if any(not p.is_leaf for p in params):
             raise T2NError("train_step needs the kernels' own field shape (the parameters ARE the kernel tensors); embedded shapes, "
                            "TensorVM and TensorCP train through the autograd form (OctreeRender_trilinear_fast + loss.backward())")
         dev = self.basis_mat.weight.device
-        rays = to_device_async(rays, dev)
-        if rays.dtype != torch.float32 or not rays.is_contiguous():
-            rays = rays.contiguous().float()
         R = rays.shape[0]
         N = int(N_samples) if N_samples > 0 else self.nSamples
-        jitter = to_device_async(torch.rand(R, 1), dev).reshape(-1).contiguous()
+        # rays, the jitter draw (CPU generator, like the reference) and the two targets travel as ONE staged host -> device copy
+        rays, jitter, rgb_t, dep_t = to_device_async_many([rays, torch.rand(R, 1), rgb_target, depth_target], dev)
+        if rays.dtype != torch.float32 or not rays.is_contiguous():
+            rays = rays.contiguous().float()
+        jitter = jitter.reshape(-1).contiguous()
         flags = FLAG_TRAIN | (FLAG_ADD_BG if (white_bg or bool(torch.rand((1,)) < 0.5)) else 0)
-        rgb_t = to_device_async(rgb_target, dev).contiguous().float()
-        dep_t = to_device_async(depth_target, dev).contiguous().float()
-        head = self._autograd_params()[12:]
+        rgb_t = rgb_t.contiguous().float()
+        dep_t = dep_t.contiguous().float()
+        head = params[12:]
         if getattr(self, "_head_flat", None) is None or self._head_flat.numel() != sum(p.numel() for p in head):
             self._head_flat = torch.zeros(sum(p.numel() for p in head), device=dev)
         with torch.no_grad():
@@ -1025,7 +1079,7 @@ class TensorVMSplit(nn.Module):
                 views.append(self._head_flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
             grads = self._backward_raw(rays, jitter, N, flags, ws, d_rgb, d_depth, d_w, head_grads=views)
-            for p, g in zip(self._autograd_params(), grads):
+            for p, g in zip(params, grads):
                 p.grad = g
             if all_reduce is not None:
                 all_reduce()
