@@ -911,7 +911,14 @@ class TensorVMSplit(nn.Module):
         """models/tensorBase.py:436-507: returns (rgb_map [R,3], depth_map [R], z_vals [R,N], weight [R,N]). `frame_width` (not in
         the reference): the raster width of this call's rays when they are a whole row-major image (default: self.frame_width)."""
         dev = self.basis_mat.weight.device
-        rays = to_device_async(rays_chunk, dev)
+        jitter = None
+        if is_train and not ndc_ray and rays_chunk.shape[0]:
+            # the reference draws on the CPU default generator even for GPU runs (models/tensorBase.py:313-317); host rays and the
+            # draw travel as one staged copy
+            rays, jitter = to_device_async_many([rays_chunk, torch.rand(rays_chunk.shape[0], 1)], dev)
+            jitter = jitter.reshape(-1).contiguous()
+        else:
+            rays = to_device_async(rays_chunk, dev)
         if rays.dtype != torch.float32 or not rays.is_contiguous():
             rays = rays.contiguous().float()
         R = rays.shape[0]
@@ -919,7 +926,6 @@ class TensorVMSplit(nn.Module):
         if R == 0:
             e = torch.empty(0, N, device=dev) if self.materialize_weights or is_train else None
             return torch.empty(0, 3, device=dev), torch.empty(0, device=dev), e, e
-        jitter = None
         add_bg = bool(white_bg)
         if ndc_ray:
             # sample_ray_ndc (models/tensorBase.py:293-299): one depth table for all rays, linspace(near, far, N) on the rays'
@@ -930,9 +936,6 @@ class TensorVMSplit(nn.Module):
             if is_train:
                 interpx += torch.rand_like(interpx).to(rays) * ((far - near) / N)
             jitter = interpx.reshape(-1).contiguous()
-        elif is_train:
-            # the reference draws on the CPU default generator even for GPU runs (models/tensorBase.py:313-317)
-            jitter = to_device_async(torch.rand(R, 1), dev).reshape(-1).contiguous()
         if is_train and not white_bg:
             add_bg = bool(torch.rand((1,)) < 0.5)   # models/tensorBase.py:497
         flags = (FLAG_TRAIN if is_train else 0) | (FLAG_ADD_BG if add_bg else 0) | (FLAG_NDC if ndc_ray else 0)
