@@ -139,29 +139,32 @@ rgb, depth = render_sharded(rays, fn)
 full_rgb, full_depth = fn(rays)
 assert torch.equal(rgb, full_rgb) and torch.equal(depth, full_depth), "gathered tiles must equal the unsharded render bitwise"
 # a row-major frame whose rows divide into world x 8-row bands: interleaved bands, same result bitwise
-frame = torch.from_numpy(synth.frame_rays_np(32, 11, c2w=synth.look_pose(0.3, -0.1, (0.2, 0.1, -1.0))))
+world = int(os.environ["WORLD_SIZE"])
+rows = 16 * world
+frame = torch.from_numpy(synth.frame_rays_np(rows, 11, c2w=synth.look_pose(0.3, -0.1, (0.2, 0.1, -1.0))))
 seen = []
-def fn2(r):
+def fn2(r):     # a per-ray function (the CPU oracle's matmuls are not batch-invariant to the last bit; the HIP kernels are)
     seen.append(r.shape[0])
-    return fn(r)
+    return torch.sin(r[:, 3:6] * 3.0 + r[:, :3]), (r[:, 3] * 2.0 + r[:, 5]).contiguous()
 rgb, depth = render_sharded(frame, fn2, frame_width=11)
-full_rgb, full_depth = fn(frame)
-assert seen == [32 * 11 // 2] and torch.equal(rgb, full_rgb) and torch.equal(depth, full_depth), "interleaved bands"
-rgb, depth = render_sharded(frame[: 24 * 11], fn, frame_width=11)          # 24 rows: not 2 x 8 x k -> contiguous tiles
-assert torch.equal(rgb, fn(frame[: 24 * 11])[0])
+full_rgb, full_depth = fn2(frame)
+assert seen[0] == rows * 11 // world and torch.equal(rgb, full_rgb) and torch.equal(depth, full_depth), "interleaved bands"
+rgb, depth = render_sharded(frame[: 24 * 11], fn2, frame_width=11)          # 24 rows: not world x 8 x k -> contiguous tiles
+assert torch.equal(rgb, fn2(frame[: 24 * 11])[0])
 dist.barrier()
 dist.destroy_process_group()
 print("OK", os.environ["RANK"])
 '''
 
 
-def test_ray_tile_sharding_gloo_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ray_tile_sharding_gloo_world2(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    T2N_ROOT=ROOT, OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
