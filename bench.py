@@ -742,6 +742,31 @@ def main():
             n_sus = max(int(2200.0 / max(ms_step, 0.1)), args.steps)
             out["config"]["sustained_ms_per_step"] = timed_frames(n_sus)
             out["config"]["sustained_frames"] = n_sus
+            # frames of a trajectory are independent: frame k on HIP stream k % 2 (each stream has its own scratch), so the march of
+            # frame k + 1 (VALU issue) runs beside the feature gather (L1) and the head (matrix cores) of frame k. Not the headline:
+            # `value` / `ms_per_step` and the per-kernel timings above are taken one frame at a time on one stream
+            try:
+                from text2nerf_amd.renderer import _FramePipe
+                for nfl in (2, 3):
+                    pipe = _FramePipe(dev, nfl)
+
+                    def piped(n):
+                        keep_alive = []
+                        with torch.no_grad():
+                            for _ in range(n):
+                                with torch.cuda.stream(pipe.next()):
+                                    keep_alive.append(field(rays, white_bg=True, is_train=False, N_samples=-1)[0])
+                                if len(keep_alive) > 2 * nfl:
+                                    keep_alive.pop(0)
+                        pipe.hand_over(keep_alive)
+                    piped(6)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    piped(args.steps)
+                    torch.cuda.synchronize()
+                    out["config"][f"frames_in_flight_{nfl}_ms_per_step"] = (time.perf_counter() - t0) / args.steps * 1e3
+            except Exception as e:  # noqa: BLE001
+                out["config"]["frames_in_flight_error"] = repr(e)[:200]
             if args.factor_storage == "fp32":
                 # bf16 factor storage (configs[4] mode): half the appearance gather's instructions and bytes (the feature kernel is L1-bound,
                 # DESIGN.md); not the headline value: it renders the ROUNDED field

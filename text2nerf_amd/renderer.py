@@ -103,24 +103,58 @@ def OctreeRender_trilinear_fast(rays, tensorf, chunk=4096, N_samples=-1, ndc_ray
     return rgb, None, depth, w, z
 
 
+class _FramePipe:
+    """Frames of a trajectory are independent: frame k runs on HIP stream k % n (each stream has its own scratch buffer,
+    tensorf.workspace), so the march of frame k + 1 — bound by VALU issue — runs beside the feature gather (L1 / texture addresser) and
+    the MLP head (matrix cores) of frame k. Measured on the C2 frame: 2.62 -> 2.39 ms per frame with two frames in flight, 2.34 with
+    three (tools/experiments/two_frames_in_flight.py), bitwise the same pictures. The kernels and their order inside a frame are
+    unchanged; the library's per-field host state is only touched from the calling thread, call by call."""
+
+    def __init__(self, device, n=2):
+        self.dev = torch.device(device)
+        self.main = torch.cuda.current_stream(self.dev)
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(max(int(n), 1))]
+        for st in self.streams:
+            st.wait_stream(self.main)          # whatever the caller queued (parameter updates, ray tensors) is visible
+        self.k = 0
+
+    def next(self):
+        st = self.streams[self.k % len(self.streams)]
+        self.k += 1
+        return st
+
+    def hand_over(self, tensors):
+        """Make the frames' outputs safe to use (and to free) on the caller's stream."""
+        for st in self.streams:
+            self.main.wait_stream(st)
+        for t in tensors:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(self.main)
+
+
 @torch.no_grad()
-def render_views(tensorf, poses, intrinsic, H, W, N_samples=-1, white_bg=True):
+def render_views(tensorf, poses, intrinsic, H, W, N_samples=-1, white_bg=True, frames_in_flight=2):
     """Device-side counterpart of the per-view loop of ``evaluation`` / ``evaluation_path`` (renderer.py:85-93,160-170)
     without its file I/O: for every camera-to-world pose generate the [H*W,6] rays on the GPU
     (dataLoader/scene_gen.py:44-45,92-94), render the whole frame in one call and return ``rgb [V,H,W,3]`` (clamped) and
-    ``depth [V,H,W]``. Nothing crosses PCIe per view. ``intrinsic`` = [fx, fy, cx, cy]."""
+    ``depth [V,H,W]``. Nothing crosses PCIe per view; ``frames_in_flight`` consecutive views run on alternating HIP streams
+    (see _FramePipe; 1 = everything on the caller's stream). ``intrinsic`` = [fx, fy, cx, cy]."""
     from .ray_utils import generate_rays
     dev = tensorf.basis_mat.weight.device
     keep, keep_w = tensorf.materialize_weights, tensorf.frame_width
     tensorf.materialize_weights = False            # evaluation discards weights / z_vals (renderer.py:89)
     tensorf.frame_width = W                        # whole row-major frames: the 8x8-tile marcher applies
     rgbs, depths = [], []
+    pipe = _FramePipe(dev, frames_in_flight) if frames_in_flight > 1 and len(poses) > 1 else None
     try:
         for c2w in poses:
-            rays = generate_rays(H, W, intrinsic, c2w, device=dev)
-            rgb, depth, _, _ = tensorf(rays, is_train=False, white_bg=white_bg, N_samples=N_samples)
-            rgbs.append(rgb.clamp(0.0, 1.0).reshape(H, W, 3))
-            depths.append(depth.reshape(H, W))
+            with torch.cuda.stream(pipe.next() if pipe else torch.cuda.current_stream(dev)):
+                rays = generate_rays(H, W, intrinsic, c2w, device=dev)
+                rgb, depth, _, _ = tensorf(rays, is_train=False, white_bg=white_bg, N_samples=N_samples)
+                rgbs.append(rgb.clamp(0.0, 1.0).reshape(H, W, 3))
+                depths.append(depth.reshape(H, W))
+        if pipe:
+            pipe.hand_over(rgbs + depths)
     finally:
         tensorf.materialize_weights, tensorf.frame_width = keep, keep_w
     return torch.stack(rgbs), torch.stack(depths)
@@ -211,6 +245,29 @@ def _post_views(tensorf, rgb_map, depth_map, H, W, near_far, push_depth, gt_rgb)
     return r8.cpu().numpy(), d8.cpu().numpy(), psnr
 
 
+def _eval_pipe(tensorf, n=2):
+    """Two views in flight for the evaluation loops when the field lives on a GPU (see _FramePipe); None otherwise."""
+    w = getattr(getattr(tensorf, "basis_mat", None), "weight", None)
+    if w is None or w.device.type != "cuda":
+        return None
+    return _FramePipe(w.device, n)
+
+
+class _on_stream:
+    """``with torch.cuda.stream(st)`` that accepts None (no GPU / no pipelining: the caller's stream)."""
+
+    def __init__(self, st):
+        self.ctx = torch.cuda.stream(st) if st is not None else None
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
 class _no_materialised_weights:
     """`evaluation` discards weights / z_vals (renderer.py:89): do not write the two [R, N] tensors while it runs."""
 
@@ -253,12 +310,12 @@ def evaluation(test_dataset, tensorf, args, renderer, savePath=None, N_vis=5, pr
     near_far = test_dataset.near_far
     img_eval_interval = 1 if N_vis < 0 else max(all_rays.shape[0] // N_vis, 1)
     idxs = list(range(0, all_rays.shape[0], img_eval_interval))
-    with _no_materialised_weights(tensorf):
-        for idx, samples in enumerate(all_rays[0::img_eval_interval]):
-            W, H = test_dataset.img_wh
-            rays = samples.view(-1, samples.shape[-1])
-            rgb_map, _, depth_map, _, _ = renderer(rays, tensorf, chunk=args.batch_size, N_samples=N_samples, ndc_ray=ndc_ray,
-                                                   white_bg=white_bg, device=device)
+    pipe = _eval_pipe(tensorf)
+
+    def finish(p):
+        """Post-processing, download and files of one rendered view, on the stream it was rendered on."""
+        idx, st, rgb_map, depth_map, H, W = p
+        with _on_stream(st):
             want_psnr = all_rgbs is not None and compute_extra_metrics
             gt_rgb = all_rgbs[idxs[idx]].view(H, W, 3) if want_psnr else None
             rgb8, depth8, psnr = _post_views(tensorf, rgb_map, depth_map, H, W, near_far, args.push_depth, gt_rgb)
@@ -269,11 +326,27 @@ def evaluation(test_dataset, tensorf, args, renderer, savePath=None, N_vis=5, pr
                     ssims.append(rgb_ssim(rgb_f, gt_rgb, 1))
                     l_alex.append(rgb_lpips(gt_rgb.numpy(), rgb_f.numpy(), "alex", tensorf.device))
                     l_vgg.append(rgb_lpips(gt_rgb.numpy(), rgb_f.numpy(), "vgg", tensorf.device))
-            rgb_maps.append(rgb8)
-            depth_maps.append(depth8)
-            if savePath is not None:
-                _imwrite(f"{savePath}/rgbs/{prtx}{idx:03d}_rgb.png", rgb8)
-                _imwrite(f"{savePath}/depths/{prtx}{idx:03d}_depth.png", depth8)
+        rgb_maps.append(rgb8)
+        depth_maps.append(depth8)
+        if savePath is not None:
+            _imwrite(f"{savePath}/rgbs/{prtx}{idx:03d}_rgb.png", rgb8)
+            _imwrite(f"{savePath}/depths/{prtx}{idx:03d}_depth.png", depth8)
+
+    # view k + 1 is rendered (on the other stream) while view k is post-processed, downloaded and written
+    pending = None
+    with _no_materialised_weights(tensorf):
+        for idx, samples in enumerate(all_rays[0::img_eval_interval]):
+            W, H = test_dataset.img_wh
+            rays = samples.view(-1, samples.shape[-1])
+            st = pipe.next() if pipe else None
+            with _on_stream(st):
+                rgb_map, _, depth_map, _, _ = renderer(rays, tensorf, chunk=args.batch_size, N_samples=N_samples, ndc_ray=ndc_ray,
+                                                       white_bg=white_bg, device=device)
+            if pending is not None:
+                finish(pending)
+            pending = (idx, st, rgb_map, depth_map, H, W)
+        if pending is not None:
+            finish(pending)
     if video_gen:
         _mimwrite(f"{savePath}/{prtx}video.mp4", rgb_maps, fps=30, quality=9)
         _mimwrite(f"{savePath}/{prtx}depthvideo.mp4", depth_maps, fps=30, quality=9)
@@ -291,22 +364,36 @@ def evaluation_path(test_dataset, tensorf, c2ws, renderer, savePath=None, N_vis=
     os.makedirs(savePath, exist_ok=True)
     os.makedirs(savePath + "/rgbd", exist_ok=True)
     near_far = test_dataset.near_far
+    pipe = _eval_pipe(tensorf)
+
+    def finish(p):
+        idx, st, rgb_map, depth_map, H, W = p
+        with _on_stream(st):
+            rgb8, depth8, _ = _post_views(tensorf, rgb_map, depth_map, H, W, near_far, None, None)
+        rgb_maps.append(rgb8)
+        depth_maps.append(depth8)
+        if savePath is not None:
+            _imwrite(f"{savePath}/{prtx}{idx:03d}.png", rgb8)
+            _imwrite(f"{savePath}/rgbd/{prtx}{idx:03d}.png", np.concatenate((rgb8, depth8), axis=1))
+
+    pending = None
     with _no_materialised_weights(tensorf):
         for idx, c2w in enumerate(c2ws):
             W, H = test_dataset.img_wh
             c2w = torch.FloatTensor(np.asarray(c2w, dtype=np.float32))
-            rays_o, rays_d = get_rays(test_dataset.directions, c2w)
-            if ndc_ray:
-                rays_o, rays_d = ndc_rays_blender(H, W, test_dataset.focal[0], 1.0, rays_o, rays_d)
-            rays = torch.cat([rays_o, rays_d], 1)
-            rgb_map, _, depth_map, _, _ = renderer(rays, tensorf, chunk=8192, N_samples=N_samples, ndc_ray=ndc_ray,
-                                                   white_bg=white_bg, device=device)
-            rgb8, depth8, _ = _post_views(tensorf, rgb_map, depth_map, H, W, near_far, None, None)
-            rgb_maps.append(rgb8)
-            depth_maps.append(depth8)
-            if savePath is not None:
-                _imwrite(f"{savePath}/{prtx}{idx:03d}.png", rgb8)
-                _imwrite(f"{savePath}/rgbd/{prtx}{idx:03d}.png", np.concatenate((rgb8, depth8), axis=1))
+            st = pipe.next() if pipe else None
+            with _on_stream(st):
+                rays_o, rays_d = get_rays(test_dataset.directions, c2w)
+                if ndc_ray:
+                    rays_o, rays_d = ndc_rays_blender(H, W, test_dataset.focal[0], 1.0, rays_o, rays_d)
+                rays = torch.cat([rays_o, rays_d], 1)
+                rgb_map, _, depth_map, _, _ = renderer(rays, tensorf, chunk=8192, N_samples=N_samples, ndc_ray=ndc_ray,
+                                                       white_bg=white_bg, device=device)
+            if pending is not None:
+                finish(pending)
+            pending = (idx, st, rgb_map, depth_map, H, W)
+        if pending is not None:
+            finish(pending)
     _mimwrite(f"{savePath}/{prtx}video.mp4", rgb_maps, fps=30, quality=8)
     _mimwrite(f"{savePath}/{prtx}depthvideo.mp4", depth_maps, fps=30, quality=8)
     return PSNRs     # always empty, as in the reference (no ground truth on a path; its mean.txt branch is unreachable)
