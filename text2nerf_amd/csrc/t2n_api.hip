@@ -452,6 +452,9 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->ev_fork) (void)hipEventDestroy((hipEvent_t)f->ev_fork);
     if (f->ev_join) (void)hipEventDestroy((hipEvent_t)f->ev_join);
     if (f->side_stream) (void)hipStreamDestroy((hipStream_t)f->side_stream);
+    if (f->ev_fork2) (void)hipEventDestroy((hipEvent_t)f->ev_fork2);
+    if (f->ev_join2) (void)hipEventDestroy((hipEvent_t)f->ev_join2);
+    if (f->gemm_stream) (void)hipStreamDestroy((hipStream_t)f->gemm_stream);
     if (f->buf_alpha) (void)hipFree(f->buf_alpha);
     for (int k = 0; k < T2N_K_COUNT; ++k)
         for (int i = 0; i < kTimingEvents; ++i) {

@@ -5,14 +5,18 @@
 // Pipeline (all on the caller's stream; `rows` = padded appearance-sample rows, 32 per shade tile):
 //   1  k_shade (ctx mode)      re-run the appearance forward, keeping X[rows,144], feat[rows,32], h0/h1[rows,128]
 //   2  k_bwd_march             per ray: recompute alpha/T/w from the kept sigma, dL/dw -> dL/dalpha (reverse scan) -> dL/dsigma
-//                              -> dL/dfeature; scatter-add into the channel-last density gradient planes/lines (fp32 atomics);
-//                              emits per appearance sample go = dL/d(pre-sigmoid rgb)
+//                              -> dL/dfeature; emits per appearance sample go = dL/d(pre-sigmoid rgb); counts the samples of every
+//                              15^3-cell block of the grid
+//   2b k_bin_scan, k_bwd_bin,  density scatter (side stream): one record per sample sorted by block; per block the trilinear splat of
+//      k_bwd_den_block         dL/dfeature into a 16^3 corner field in LDS, from which all six density gradients are small MFMA
+//                              contractions with the block's line rows / plane texels (global-atomic path: k_bwd_march<.,false>)
 //   3  k_bwd_l2                layer 2 (3 outputs): dW2, db2 (per-workgroup partials + k_bwd_l2_reduce), g1 = (go W2) * [h1 > 0]
 //   3-4 (MLP_Fea_noview head) k_mlp_bwd_ss: the whole input-gradient chain g1 -> g0 -> gx -> gf -> gX in one kernel (t2n_mlp_bwd_ss.hip);
 //                              k_bwd_l2 then only accumulates dW2 / db2, the weight gradients stay GEMMs (t2n_gemm_h.hip)
 //   4  gemm_tn / gemm_nn       fp32-MFMA GEMMs: dW1 = g1^T h0, g0 = (g1 W1) * [h0 > 0], dW0 = g0^T PE(feat), gx = g0 W0,
 //                              PE backward -> gf, dWb = gf^T X, gX = gf Wb; k_colsum for the biases
-//   5  k_bwd_app_scatter       re-gather appearance taps, scatter-add plane/line gradients
+//   5  k_app_bin, k_bin_scan,  appearance scatter: records sorted by 16x16-texel plane tile, accumulated in LDS (ds_add_f64), flushed once per
+//      k_bwd_tile_accum<48>    tile segment (global-atomic path: k_bwd_app_scatter); runs beside the weight-gradient GEMMs (third stream)
 //   6  k_relayout_add          channel-last gradient buffers -> += reference-layout [1,C,H,W] gradient tensors
 #include <stdlib.h>
 
@@ -166,17 +170,16 @@ __device__ __forceinline__ void scatter_win(const FactorSet& S, const GradSet& G
 }
 
 
-// ---- tile-binned scatter ---------------------------------------------------------------------------------------------------
+// ---- binned scatters -------------------------------------------------------------------------------------------------------
 // A training batch puts ~28 samples into every texel of every density plane, from unrelated rays: global fp32 atomics per
-// tap (even merged along a ray) run at the L2 atomic rate. Instead: (1) count the samples of every 16x16-texel plane tile,
-// (2) prefix-sum, (3) write a 16-B record (x, y, z, dL/dfeature) per sample and plane into its tile's run, (4) one
-// workgroup per segment of one tile's records (segment size picked on the device by k_bin_scan) accumulates plane AND line
-// gradients in LDS (ds_add_f64 on a staged 17x17xC tile + the whole line) and flushes the non-zero texels once. Global
-// atomics drop ~15x.
+// tap (even merged along a ray) run at the L2 atomic rate. Instead: (1) count the samples of every bin, (2) prefix-sum,
+// (3) write a 16-B record per sample into its bin's run, (4) one workgroup per segment of one bin's records accumulates in
+// LDS and flushes once. Appearance: bins = 16x16-texel plane tiles (one record per sample AND plane; ds_add_f64 on a staged
+// 17x17x16 tile + the whole line, k_bwd_tile_accum). Density: bins = 15^3-cell blocks, one record per sample (k_bwd_den_block).
 constexpr int kBinTile = 16;      // texels per tile edge (footprints reach one texel further: 17 staged)
 constexpr int kBinCopies = 32;    // privatised histogram / cursor copies (every ray starts in the camera's tile)
 constexpr int kBinSegApp = 512;   // smallest segment (sizes the segment list); the scan picks the actual size per call
-constexpr unsigned kAccTargetSegs = 1024, kAccTargetSegsApp = 512;   // accumulate work items aimed at: whole rounds over 256 CUs
+constexpr unsigned kAccTargetSegsApp = 512;   // accumulate work items aimed at: whole rounds over 256 CUs
 constexpr unsigned kAccGrid = 2048;   // accumulate workgroups launched (grid-stride over the segment list)
 
 struct BinGeom { int tw[3], before[3], total; };
@@ -198,6 +201,29 @@ __device__ __forceinline__ void bin_keys(const FactorSet& S, const BinGeom& G, f
     key[0] = G.before[0] + cy * G.tw[0] + cx;
     key[1] = G.before[1] + cz * G.tw[1] + cx;
     key[2] = G.before[2] + cz * G.tw[2] + cy;
+}
+// Density: 3-D blocks of kBlk^3 cells (k_bwd_den_block). The three density pairs share their axes (plane k spans two of them, line k the
+// third), so ONE key per sample serves all six gradients. cell + 1 lies in [0, size]: (size + kBlk) / kBlk blocks per axis.
+constexpr int kBlk = 15;          // cells per block edge: taps reach one further, 16 per axis = the MFMA tile edge
+struct BlockGeom { int nb[3]; int size[3]; int total; int copies; };
+static BlockGeom block_geom(const FactorSet& S) {
+    BlockGeom g;
+    g.size[0] = S.W[0]; g.size[1] = S.H[0]; g.size[2] = S.H[1];
+    for (int a = 0; a < 3; ++a) g.nb[a] = (g.size[a] + kBlk) / kBlk;
+    g.total = g.nb[0] * g.nb[1] * g.nb[2];
+    // privatised histogram copies (every ray starts in the camera's block): as many as keep the scan's histogram in LDS
+    int c = 32;
+    while (c > 1 && (size_t)g.total * c * 4 > 148 * 1024) c >>= 1;
+    g.copies = c;
+    return g;
+}
+// the density pairs really share their axes (TensorVMSplit: plane k = grid[mat1] x grid[mat0], line k = grid[vec])
+static bool block_geom_ok(const FactorSet& S) {
+    return S.C == 16 && S.W[1] == S.W[0] && S.L[2] == S.W[0] && S.W[2] == S.H[0] && S.L[1] == S.H[0] && S.H[2] == S.H[1] && S.L[0] == S.H[1];
+}
+__device__ __forceinline__ int block_key(const BlockGeom& G, float xn, float yn, float zn) {
+    const int bx = (axis_cell(xn, G.size[0]) + 1) / kBlk, by = (axis_cell(yn, G.size[1]) + 1) / kBlk, bz = (axis_cell(zn, G.size[2]) + 1) / kBlk;
+    return (bz * G.nb[1] + by) * G.nb[0] + bx;
 }
 // Runs of equal keys along the 64 lanes (consecutive samples of a ray stay in a tile for many steps): the first lane of a
 // run is its leader and reserves for the whole run. Must be called by all 64 lanes.
@@ -221,7 +247,7 @@ struct BwdMarchArgs {
     float4* go;   // [rows] dL/d(pre-sigmoid rgb) per appearance row
     unsigned list_cap; TilePrefix tp; int add_bg;
     // BIN: dL/dfeature per sample goes to gfeat [n_rays, N] (aliases sigma) and the (plane, tile) histogram is counted
-    float* gfeat; unsigned* hist; BinGeom geom;
+    float* gfeat; unsigned* hist; BlockGeom geom;
 };
 
 // BIN = false: scatter with sliding windows + global atomics (any grid). BIN = true: first pass of the tile-binned scatter.
@@ -324,26 +350,23 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
     wave_lds_sync();
 
     if constexpr (BIN) {
-        // ---- dL/dfeature of every live sample -> gfeat; count the samples of each (plane, tile) bin ------------------------
-        const unsigned copy = (unsigned)(r >> 2) & (kBinCopies - 1);
+        // ---- dL/dfeature of every live sample -> gfeat; count the samples of each block bin -----------------------------------
+        const unsigned copy = (unsigned)(r >> 2) & (unsigned)(a.geom.copies - 1);
         for (int base = 0; base < Lw; base += 64) {
             const int j = base + lane, i = first + j;
-            int key[3] = {-1, -1, -1};
+            int key = -1;
             if (j < Lw) {
                 float gf = Gw[j];
                 float xn, yn, zn;
                 const float z = sample_z<TRAIN>(F, ray, i, u);
                 bool ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
                 if (F.alpha && ok) ok = alpha_pass(F, ray, z);
-                if (ok && gf != 0.f) bin_keys(F.den, a.geom, xn, yn, zn, key); else gf = 0.f;
+                if (ok && gf != 0.f) key = block_key(a.geom, xn, yn, zn); else gf = 0.f;
                 a.gfeat[r * N + i] = gf;
             }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                bool leader; int runlen, ll;
-                run_leader(key[k], lane, leader, runlen, ll);
-                if (leader && key[k] >= 0) atomicAdd(&a.hist[(unsigned)key[k] * kBinCopies + copy], (unsigned)runlen);
-            }
+            bool leader; int runlen, ll;
+            run_leader(key, lane, leader, runlen, ll);
+            if (leader && key >= 0) atomicAdd(&a.hist[copy * (unsigned)a.geom.total + (unsigned)key], (unsigned)runlen);
         }
         return;
     }
@@ -381,17 +404,24 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
 // segment list of the accumulate pass. The histogram is pulled into LDS with coalesced loads first (LDS = true) so the
 // per-thread serial runs do not chain ~70 dependent global round trips.
 template <bool LDS>
-__global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, unsigned* tile_start, int4* segs, unsigned* nseg_out,
-                                                   unsigned seg_cap, unsigned seg_size_in, unsigned target_segs) {
+__global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, int copies, unsigned* tile_start, int4* segs, unsigned* nseg_out,
+                                                   unsigned seg_cap, unsigned seg_size_in, unsigned target_segs, unsigned seg_min) {
     extern __shared__ unsigned sh_hist[];
     __shared__ unsigned sh[1024];
     const int t = threadIdx.x;
-    const int n = n_tiles * kBinCopies;
+    const int n = n_tiles * copies;
     if (LDS) {
-        for (int i = t; i < n; i += 1024) sh_hist[i] = hist[i];
+        for (int j = t; j < n; j += 1024) sh_hist[j] = hist[j];
         __syncthreads();
     }
-    unsigned* H = LDS ? sh_hist : hist;
+    // the scan runs tile-major (index i = tile * copies + copy: a tile's copies are consecutive runs of its records); the counters lie
+    // copy-major ([copy][tile]: the copies of a hot tile sit in different cache lines — side by side their atomics serialise on ONE
+    // line: k_bwd_bin 122 -> 65 us, k_bwd_march 124 -> 64 us per C3 iteration with four copies). copies is a power of two.
+    struct Hist {
+        unsigned* p; int n_tiles, mask, shift;
+        __device__ unsigned& operator[](int i) const { return p[(i & mask) * n_tiles + (i >> shift)]; }
+    };
+    const Hist H{LDS ? sh_hist : hist, n_tiles, copies - 1, 31 - __clz(copies)};
     const int per = (n + 1023) / 1024;
     const int b = t * per, e = min(n, b + per);
     unsigned sum = 0;
@@ -412,14 +442,14 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
         run += c;
     }
     __syncthreads();
-    if (LDS) for (int i = t; i < n; i += 1024) hist[i] = sh_hist[i];
+    if (LDS) for (int j = t; j < n; j += 1024) hist[j] = sh_hist[j];
     // tile starts (+ sentinel); non-empty tiles; segment size such that the accumulate pass gets ~target_segs work items
     // (a whole number of rounds over the CUs: with fixed 8192-record segments 1079 items ran as 4.2 rounds on 256 CUs)
     const int pt = (n_tiles + 1023) / 1024;
     const int tb = t * pt, te = min(n_tiles, tb + pt);
     unsigned ne = 0;
     for (int j = tb; j < te; ++j) {
-        const unsigned s0 = H[j * kBinCopies], s1 = j + 1 < n_tiles ? H[(j + 1) * kBinCopies] : total;
+        const unsigned s0 = H[j * copies], s1 = j + 1 < n_tiles ? H[(j + 1) * copies] : total;
         tile_start[j] = s0;
         ne += s1 > s0 ? 1u : 0u;
     }
@@ -440,11 +470,11 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
         const unsigned room = target_segs > nonempty + 64 ? target_segs - nonempty / 2 : 64;   // every tile ends in a partial segment
         seg_size = (total + room - 1) / room;
         seg_size = (seg_size + 63) / 64 * 64;
-        seg_size = seg_size < 512 ? 512 : (seg_size > 16384 ? 16384 : seg_size);
+        seg_size = seg_size < seg_min ? seg_min : (seg_size > 16384 ? 16384 : seg_size);
     }
     unsigned ns = 0;
     for (int j = tb; j < te; ++j) {
-        const unsigned s0 = H[j * kBinCopies], s1 = j + 1 < n_tiles ? H[(j + 1) * kBinCopies] : total;
+        const unsigned s0 = H[j * copies], s1 = j + 1 < n_tiles ? H[(j + 1) * copies] : total;
         ns += (s1 - s0 + seg_size - 1) / seg_size;
     }
     sh[t] = ns;
@@ -457,7 +487,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
     }
     unsigned si = sh[t] - ns;
     for (int j = tb; j < te; ++j) {
-        const unsigned s0 = H[j * kBinCopies], s1 = j + 1 < n_tiles ? H[(j + 1) * kBinCopies] : total;
+        const unsigned s0 = H[j * copies], s1 = j + 1 < n_tiles ? H[(j + 1) * copies] : total;
         for (unsigned s = s0; s < s1; s += seg_size) {
             if (si < seg_cap) segs[si] = make_int4(j, (int)s, (int)min(s1, s + seg_size), 0);
             ++si;
@@ -465,21 +495,21 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
     }
     if (t == 1023) *nseg_out = min(sh[1023], seg_cap);
 }
-static void launch_bin_scan(unsigned* hist, int n_tiles, unsigned* tile_start, int4* segs, unsigned* nseg, unsigned seg_cap, unsigned seg_size,
-                            unsigned target_segs, hipStream_t s) {
-    const size_t lds = (size_t)n_tiles * kBinCopies * 4;
+static void launch_bin_scan(unsigned* hist, int n_tiles, int copies, unsigned* tile_start, int4* segs, unsigned* nseg, unsigned seg_cap, unsigned seg_size,
+                            unsigned target_segs, unsigned seg_min, hipStream_t s) {
+    const size_t lds = (size_t)n_tiles * copies * 4;
     if (lds <= 150 * 1024) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_bin_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-        hipLaunchKernelGGL((k_bin_scan<true>), dim3(1), dim3(1024), lds, s, hist, n_tiles, tile_start, segs, nseg, seg_cap, seg_size, target_segs);
+        hipLaunchKernelGGL((k_bin_scan<true>), dim3(1), dim3(1024), lds, s, hist, n_tiles, copies, tile_start, segs, nseg, seg_cap, seg_size, target_segs, seg_min);
     } else {
-        hipLaunchKernelGGL((k_bin_scan<false>), dim3(1), dim3(1024), 0, s, hist, n_tiles, tile_start, segs, nseg, seg_cap, seg_size, target_segs);
+        hipLaunchKernelGGL((k_bin_scan<false>), dim3(1), dim3(1024), 0, s, hist, n_tiles, copies, tile_start, segs, nseg, seg_cap, seg_size, target_segs, seg_min);
     }
 }
 
 // (3) per ray (same ray -> wave -> copy map as the counting pass): write the records into their tiles' runs
 struct BinArgs {
-    FieldDev F; BinGeom geom;
+    FieldDev F; BlockGeom geom;
     const float* rays; long long n_rays; int ray_stride; int n_samples;
     const float* jitter; const float* gfeat; const int4* ray_app; unsigned* cursor; float4* recs;
 };
@@ -495,27 +525,140 @@ __global__ __launch_bounds__(256) void k_bwd_bin(const BinArgs a) {
     const int N = a.n_samples;
     const Ray ray = load_ray(F, a.rays + r * a.ray_stride, a.ray_stride);
     const float u = (TRAIN && !F.ztab) ? a.jitter[r] : 0.f;   // NDC: `jitter` is the depth table
-    const unsigned copy = (unsigned)(r >> 2) & (kBinCopies - 1);
+    const unsigned copy = (unsigned)(r >> 2) & (unsigned)(a.geom.copies - 1);
     for (int base = 0; base < Lw; base += 64) {
         const int j = base + lane, i = first + j;
-        int key[3] = {-1, -1, -1};
+        int key = -1;
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j < Lw) {
             rec.w = a.gfeat[r * N + i];
             if (rec.w != 0.f) {
                 const float z = sample_z<TRAIN>(F, ray, i, u);
                 (void)sample_point<TRAIN>(F, ray, z, rec.x, rec.y, rec.z);
-                bin_keys(F.den, a.geom, rec.x, rec.y, rec.z, key);
+                key = block_key(a.geom, rec.x, rec.y, rec.z);
             }
         }
+        bool leader; int runlen, ll;
+        run_leader(key, lane, leader, runlen, ll);
+        unsigned pos = 0;
+        if (leader && key >= 0) pos = atomicAdd(&a.cursor[copy * (unsigned)a.geom.total + (unsigned)key], (unsigned)runlen);
+        pos = __shfl(pos, ll) + (unsigned)(lane - ll);
+        if (key >= 0) a.recs[pos] = rec;
+    }
+}
+
+// (4d) density: accumulate one segment of one block's records. The density feature is sum_k sum_c P_k[c](two axes) L_k[c](third axis) with
+// ONE gradient g per sample for all channels and pairs, so every gradient of the block is a contraction of the same scalar field
+//     G[z][y][x] = sum over samples of g * (trilinear weight of the sample at corner (x, y, z)):
+//     dP_0[y][x][c] = sum_z G L_0[z][c],  dP_1[z][x][c] = sum_y G L_1[y][c],  dP_2[z][y][c] = sum_x G L_2[x][c],
+//     dL_0[z][c] = sum_yx G P_0[y][x][c], dL_1[y][c] = sum_zx G P_1[z][x][c], dL_2[x][c] = sum_zy G P_2[z][y][c].
+// Phase 1: lane = record, eight ds_add_f64 into the 16^3 corner field of the block (padded strides: the three contractions read it along
+// different axes). Phase 2: the six contractions as 16x16x4 fp32 MFMAs (A = G as fp32, B = line rows from LDS / plane texels straight
+// from global memory), 16 x 16 result tiles flushed with global atomics. The per-plane tile form of this scatter (one record per sample
+// AND plane, 6 x 16 LDS atomics per record) spent 430 us per C3 iteration at the LDS atomic rate.
+constexpr int kBlkE = kBlk + 1;                    // taps per axis
+constexpr int kGsy = kBlkE + 1, kGsz = kBlkE * kGsy + 1;   // strides of G in doubles (x: 1): bank-conflict-free along every axis
+constexpr int kGsize = kBlkE * kGsz;
+constexpr int kDenThreads = 512;
+// records per segment: a block's six result tiles are flushed (12 288 + 1 536 global atomics) once per SEGMENT, and the splat itself is
+// cheap (~8 ns per 1000 records per CU), so blocks are split only when they hold very many records (the camera's block of a C3
+// batch: 57 000 of 2.5 M): 4 000 segments of ~700 records took 262 us, 1 300 of up to 16 384 take 73
+constexpr unsigned kDenSeg = 16384;
+struct DenBlockArgs {
+    FactorSet S; GradSet G; BlockGeom geom; const int4* segs; const unsigned* nseg; const float4* recs;
+};
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kDenThreads) void k_bwd_den_block(const DenBlockArgs a) {
+    __shared__ double Gs[kGsize];
+    __shared__ float Ls[3][kBlkE][16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned nseg = *a.nseg;
+    const int X = a.geom.size[0], Y = a.geom.size[1], Z = a.geom.size[2];
+    for (unsigned seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        if (seg != blockIdx.x) __syncthreads();   // the previous segment's contractions have finished reading G and the lines
+        const int4 sg = a.segs[seg];
+        const int bx = sg.x % a.geom.nb[0], byz = sg.x / a.geom.nb[0], by = byz % a.geom.nb[1], bz = byz / a.geom.nb[1];
+        const int ox = bx * kBlk - 1, oy = by * kBlk - 1, oz = bz * kBlk - 1;   // cell of local (0, 0, 0)
+        for (int i = tid; i < kGsize; i += kDenThreads) Gs[i] = 0.0;
+        if (tid < 3 * kBlkE * 4) {   // line rows of the block: L_0 over z, L_1 over y, L_2 over x
+            const int k = tid / (kBlkE * 4), rq = tid % (kBlkE * 4), row = rq >> 2, q = rq & 3;
+            const int g = (k == 0 ? oz : (k == 1 ? oy : ox)) + row, n = k == 0 ? Z : (k == 1 ? Y : X);
+            const float* __restrict__ Ln = k == 0 ? a.S.line[0] : (k == 1 ? a.S.line[1] : a.S.line[2]);
+            const float4 v = (g >= 0 && g < n) ? *reinterpret_cast<const float4*>(Ln + (size_t)g * 16 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&Ls[k][row][q * 4]) = v;
+        }
+        __syncthreads();
+        // ---- phase 1: the trilinear splat of the segment's records ---------------------------------------------------------------
+        for (int i = sg.y + tid; i < sg.z; i += kDenThreads) {
+            const float4 p = a.recs[i];
+            const Axis ax = axis_taps(p.x, X), ay = axis_taps(p.y, Y), az = axis_taps(p.z, Z);
+            const int lx = axis_cell(p.x, X) - ox, ly = axis_cell(p.y, Y) - oy, lz = axis_cell(p.z, Z) - oz;
+            const int b = lz * kGsz + ly * kGsy + lx;
+            const float g0 = p.w * az.w0, g1 = p.w * az.w1;
+            const float w00 = ay.w0 * ax.w0, w01 = ay.w0 * ax.w1, w10 = ay.w1 * ax.w0, w11 = ay.w1 * ax.w1;
+            atomicAdd(&Gs[b], (double)(g0 * w00)); atomicAdd(&Gs[b + 1], (double)(g0 * w01));
+            atomicAdd(&Gs[b + kGsy], (double)(g0 * w10)); atomicAdd(&Gs[b + kGsy + 1], (double)(g0 * w11));
+            atomicAdd(&Gs[b + kGsz], (double)(g1 * w00)); atomicAdd(&Gs[b + kGsz + 1], (double)(g1 * w01));
+            atomicAdd(&Gs[b + kGsz + kGsy], (double)(g1 * w10)); atomicAdd(&Gs[b + kGsz + kGsy + 1], (double)(g1 * w11));
+        }
+        __syncthreads();
+        // ---- phase 2: contractions. MFMA 16x16x4 fp32: A lane (i, kk) = A[i][kk], B lane (j, kk) = B[kk][j], D lane (j, q) regs r = D[4q + r][j]
+        const int li = lane & 15, kk = lane >> 4;
+        // planes: 48 tiles of 16 cells x 16 channels (pair k, tile t): wave w takes tiles w, w + 8, ...
+        for (int pt = w; pt < 48; pt += 8) {
+            const int k = pt >> 4, t = pt & 15;
+            // pair 0: tile = y row t, cell i = x, contraction over z; pair 1: tile = z row t, cell i = x, over y; pair 2: tile = z row t, cell i = y, over x
+            const int abase = k == 0 ? t * kGsy + li : (k == 1 ? t * kGsz + li : t * kGsz + li * kGsy);
+            const int astep = k == 0 ? kGsz : (k == 1 ? kGsy : 1);
+            f32x4_t d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            bool leader; int runlen, ll;
-            run_leader(key[k], lane, leader, runlen, ll);
-            unsigned pos = 0;
-            if (leader && key[k] >= 0) pos = atomicAdd(&a.cursor[(unsigned)key[k] * kBinCopies + copy], (unsigned)runlen);
-            pos = __shfl(pos, ll) + (unsigned)(lane - ll);
-            if (key[k] >= 0) a.recs[pos] = rec;
+            for (int ks = 0; ks < 4; ++ks) {
+                const int c = 4 * ks + kk;
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32((float)Gs[abase + c * astep], Ls[k][c][li], d, 0, 0, 0);
+            }
+            // D[cell 4 kk + r][channel li]
+            const int W = k == 2 ? Y : X, H = k == 0 ? Y : Z;
+            const int gy = (k == 0 ? oy : oz) + t, gx0 = (k == 2 ? oy : ox) + 4 * kk;
+            float* __restrict__ gP = k == 0 ? a.G.plane[0] : (k == 1 ? a.G.plane[1] : a.G.plane[2]);
+            if (gy >= 0 && gy < H) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gx = gx0 + r;
+                    if (d[r] != 0.f && gx >= 0 && gx < W) atomicAdd(gP + ((size_t)gy * W + gx) * 16 + li, d[r]);
+                }
+            }
+        }
+        // lines: pair k = w / 2 for waves 0..5, half (w & 1) of the 256 plane cells each: D[line row][channel] += sum_cells G P
+        if (w < 6) {
+            const int k = w >> 1, half = w & 1;
+            const int W = k == 2 ? Y : X, H = k == 0 ? Y : Z;
+            const float* __restrict__ P = k == 0 ? a.S.plane[0] : (k == 1 ? a.S.plane[1] : a.S.plane[2]);
+            const int py0 = k == 0 ? oy : oz, px0 = k == 2 ? oy : ox;
+            // A[i = line row][cell (u, v)]: pair 0 row z, cell (y, x); pair 1 row y, cell (z, x); pair 2 row x, cell (z, y)
+            const int arow = k == 0 ? li * kGsz : (k == 1 ? li * kGsy : li);
+            const int au = k == 0 ? kGsy : kGsz, av = k == 2 ? kGsy : 1;
+            f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+            for (int s8 = 0; s8 < 32; s8 += 8) {
+                float bv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int cell = (half * 32 + s8 + e) * 4 + kk, u = cell >> 4, v = cell & 15;
+                    const int gy = py0 + u, gx = px0 + v;
+                    bv[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? P[((size_t)gy * W + gx) * 16 + li] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int cell = (half * 32 + s8 + e) * 4 + kk, u = cell >> 4, v = cell & 15;
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32((float)Gs[arow + u * au + v * av], bv[e], d, 0, 0, 0);
+                }
+            }
+            const int n = k == 0 ? Z : (k == 1 ? Y : X), g0 = (k == 0 ? oz : (k == 1 ? oy : ox)) + 4 * kk;
+            float* __restrict__ gL = k == 0 ? a.G.line[0] : (k == 1 ? a.G.line[1] : a.G.line[2]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int g = g0 + r;
+                if (d[r] != 0.f && g >= 0 && g < n) atomicAdd(gL + (size_t)g * 16 + li, d[r]);
+            }
         }
     }
 }
@@ -676,10 +819,10 @@ __global__ __launch_bounds__(256) void k_app_bin(const AppBinArgs a) {
         bool leader; int runlen, ll;
         run_leader(key[k], lane, leader, runlen, ll);
         if (PASS == 0) {
-            if (leader && key[k] >= 0) atomicAdd(&a.hist[(unsigned)key[k] * kBinCopies + copy], (unsigned)runlen);
+            if (leader && key[k] >= 0) atomicAdd(&a.hist[copy * (unsigned)a.geom.total + (unsigned)key[k]], (unsigned)runlen);
         } else {
             unsigned pos = 0;
-            if (leader && key[k] >= 0) pos = atomicAdd(&a.hist[(unsigned)key[k] * kBinCopies + copy], (unsigned)runlen);
+            if (leader && key[k] >= 0) pos = atomicAdd(&a.hist[copy * (unsigned)a.geom.total + (unsigned)key[k]], (unsigned)runlen);
             pos = __shfl(pos, ll) + (unsigned)(lane - ll);
             if (key[k] >= 0) a.recs[pos] = rec;
         }
@@ -695,54 +838,63 @@ static size_t tile_accum_lds(int C, int Lmax) {
 // go [rows,4], h1 [rows,128] -> g1 [rows,128] = (go W2) * [h1>0]; dW2[3,128] += go^T h1; db2[3] += colsum(go)
 __global__ __launch_bounds__(256) void k_bwd_l2(const float4* __restrict__ go, const float* __restrict__ h1, long long rows,
                                                 const float* __restrict__ w2, float* g1, float* __restrict__ part) {
-    // persistent workgroups (grid-stride over 64-row tiles): the 3 x 128 weight-gradient partial sums leave a workgroup once,
-    // so the same-address atomics on dw2 stay in the hundreds per address instead of one per 64 rows
-    const int u = threadIdx.x & 127, half = threadIdx.x >> 7;
-    const float w0 = w2[u], w1 = w2[128 + u], w2v = w2[256 + u];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (long long tile = blockIdx.x; tile * 64 < rows; tile += gridDim.x) {
-        const long long r0 = tile * 64 + half * 32;
-        for (int k = 0; k < 32; k += 4) {           // four rows in flight per thread
-            float4 g[4]; float h[4];
+    // The kernel is a [rows, 128] stream with 3 x 128 running sums: memory-latency bound unless enough of it is in flight. Thread
+    // (c, q) = (tid & 31, tid >> 5) owns units 4c .. 4c+3 (one 16-byte load per row) of rows base + 8k + q, k = 0..7: eight rows per
+    // thread and 64 rows per workgroup in flight, 1024 workgroups (grid-stride). The one-dword-per-thread, four-rows-in-flight,
+    // one-workgroup-per-CU form of this kernel took 183 us per C3 iteration for 150 MB.
+    const int tid = threadIdx.x, c = tid & 31, q = tid >> 5;
+    const float4 w0 = *reinterpret_cast<const float4*>(w2 + 4 * c), w1 = *reinterpret_cast<const float4*>(w2 + 128 + 4 * c),
+                 w2v = *reinterpret_cast<const float4*>(w2 + 256 + 4 * c);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (long long base = (long long)blockIdx.x * 64; base < rows; base += (long long)gridDim.x * 64) {
+        float4 g[8], h[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long long r = r0 + k + q;
-                const bool ok = r < rows;
-                const long long rc = ok ? r : rows - 1;   // clamped address + select: a conditional load is a branch and a full wait per element
-                g[q] = go[rc];
-                h[q] = h1[rc * 128 + u];
-                if (!ok) { g[q] = make_float4(0.f, 0.f, 0.f, 0.f); h[q] = 0.f; }
-            }
+        for (int k = 0; k < 8; ++k) {
+            const long long r = base + 8 * k + q;
+            const long long rc = r < rows ? r : rows - 1;   // clamped address + select: a conditional load is a branch and a full wait per element
+            g[k] = go[rc];
+            h[k] = *reinterpret_cast<const float4*>(h1 + rc * 128 + 4 * c);
+        }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long long r = r0 + k + q;
-                if (r >= rows) break;
-                a0 = fmaf(g[q].x, h[q], a0); a1 = fmaf(g[q].y, h[q], a1); a2 = fmaf(g[q].z, h[q], a2);
-                s0 += g[q].x; s1 += g[q].y; s2 += g[q].z;
-                if (g1) {   // (NULL: the fused input-gradient chain, t2n_mlp_bwd_ss.hip, makes g1 itself and needs h1 intact)
-                    const float v = fmaf(g[q].z, w2v, fmaf(g[q].y, w1, g[q].x * w0));
-                    g1[r * 128 + u] = h[q] > 0.f ? v : 0.f;
-                }
+        for (int k = 0; k < 8; ++k) {
+            const long long r = base + 8 * k + q;
+            const bool ok = r < rows;
+            const float gx = ok ? g[k].x : 0.f, gy = ok ? g[k].y : 0.f, gz = ok ? g[k].z : 0.f;
+            const float4 hv = h[k];
+            a0.x = fmaf(gx, hv.x, a0.x); a0.y = fmaf(gx, hv.y, a0.y); a0.z = fmaf(gx, hv.z, a0.z); a0.w = fmaf(gx, hv.w, a0.w);
+            a1.x = fmaf(gy, hv.x, a1.x); a1.y = fmaf(gy, hv.y, a1.y); a1.z = fmaf(gy, hv.z, a1.z); a1.w = fmaf(gy, hv.w, a1.w);
+            a2.x = fmaf(gz, hv.x, a2.x); a2.y = fmaf(gz, hv.y, a2.y); a2.z = fmaf(gz, hv.z, a2.z); a2.w = fmaf(gz, hv.w, a2.w);
+            s0 += gx; s1 += gy; s2 += gz;
+            if (g1 && ok) {   // (NULL: the fused input-gradient chain, t2n_mlp_bwd_ss.hip, makes g1 itself and needs h1 intact)
+                float4 v;
+                v.x = hv.x > 0.f ? fmaf(gz, w2v.x, fmaf(gy, w1.x, gx * w0.x)) : 0.f;
+                v.y = hv.y > 0.f ? fmaf(gz, w2v.y, fmaf(gy, w1.y, gx * w0.y)) : 0.f;
+                v.z = hv.z > 0.f ? fmaf(gz, w2v.z, fmaf(gy, w1.z, gx * w0.z)) : 0.f;
+                v.w = hv.w > 0.f ? fmaf(gz, w2v.w, fmaf(gy, w1.w, gx * w0.w)) : 0.f;
+                *reinterpret_cast<float4*>(g1 + r * 128 + 4 * c) = v;   // in place over h1: this thread read the element above
             }
         }
     }
-    // per-workgroup partial sums [block][3 x 128 + 3]; k_bwd_l2_reduce adds them up in a fixed order (the same-address atomics of
-    // ~800 000 threads on 12 cache lines were most of this kernel: 105 us per C3 iteration)
-    __shared__ float red[388];
-    if (half == 1) { red[u] = a0; red[128 + u] = a1; red[256 + u] = a2; if (u == 0) { red[384] = s0; red[385] = s1; red[386] = s2; } }
+    // per-workgroup partial sums [block][3 x 128 + 3]: the eight row slots meet in LDS, k_bwd_l2_reduce adds the workgroups up in a
+    // fixed order (the same-address atomics of ~800 000 threads on 12 cache lines were most of the first form: 105 us per C3 iteration)
+    __shared__ float red[8][388];
+    *reinterpret_cast<float4*>(&red[q][4 * c]) = a0;
+    *reinterpret_cast<float4*>(&red[q][128 + 4 * c]) = a1;
+    *reinterpret_cast<float4*>(&red[q][256 + 4 * c]) = a2;
+    if (c == 0) { red[q][384] = s0; red[q][385] = s1; red[q][386] = s2; }
     __syncthreads();
-    if (half == 0) {
-        float* __restrict__ P = part + (size_t)blockIdx.x * 388;
-        P[u] = a0 + red[u]; P[128 + u] = a1 + red[128 + u]; P[256 + u] = a2 + red[256 + u];
-        if (u == 0) { P[384] = s0 + red[384]; P[385] = s1 + red[385]; P[386] = s2 + red[386]; }
-    }
+    float* __restrict__ P = part + (size_t)blockIdx.x * 388;
+    for (int i = tid; i < 387; i += 256)
+        P[i] = ((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + ((red[4][i] + red[5][i]) + (red[6][i] + red[7][i]));
 }
-// dw2 [3,128] += sum of the workgroups' partials, db2 [3] likewise: one workgroup per output, one partial per thread (nblocks <= 256),
-// fixed-order tree (deterministic)
+// dw2 [3,128] += sum of the workgroups' partials, db2 [3] likewise: one workgroup per output, thread b sums partials b, b + 256, ...
+// in order, then a fixed-order tree (deterministic)
 __global__ __launch_bounds__(256) void k_bwd_l2_reduce(const float* __restrict__ part, int nblocks, float* dw2, float* db2) {
     __shared__ float red[4];
     const int i = blockIdx.x, b = threadIdx.x;
-    float v = b < nblocks ? part[(size_t)b * 388 + i] : 0.f;
+    float v = 0.f;
+    for (int k = b; k < nblocks; k += 256) v += part[(size_t)k * 388 + i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     if ((b & 63) == 0) red[b >> 6] = v;
@@ -1061,6 +1213,7 @@ __global__ __launch_bounds__(256) void k_relayout_add(const RelayoutAddMulti a) 
 // element-in-place by the same thread) share storage: g1 over h1, g0 over h0, gx over xpe, gf over feat32, gX over x144.
 struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, gpack, hist, tile_start, nseg, segs, recs, a_hist, a_tile_start, a_nseg, a_segs, a_recs, total; unsigned seg_cap, a_seg_cap; };
 // split of a [rows] x (M<=128) x N weight-gradient GEMM into row chunks: ~768 workgroups, chunk a multiple of 32 rows
+constexpr int kL2Blocks = 1024;   // workgroups of k_bwd_l2 (four per CU)
 struct TnPlan { int chunk_rows, chunks, ng, ldp; };
 static TnPlan tn_plan(int64_t rows, int N) {
     TnPlan p;
@@ -1078,7 +1231,7 @@ static TnPlan tn_plan(int64_t rows, int N) {
     return p;
 }
 static size_t tn_part_bytes(int64_t rows, int k0) {
-    size_t m = (size_t)256 * 388 * 4;   // layer 2's per-workgroup partial sums (launch_bwd_l2) come first
+    size_t m = (size_t)kL2Blocks * 388 * 4;   // layer 2's per-workgroup partial sums (launch_bwd_l2) come first
     const int shapes[3][2] = {{128, 128}, {128, k0}, {32, 144}};
     for (auto& sh : shapes) {
         const TnPlan p = tn_plan(rows, sh[1]);
@@ -1088,7 +1241,7 @@ static size_t tn_part_bytes(int64_t rows, int k0) {
     return m;
 }
 static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
-static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_tiles, int k0 = 351) {   // k0: inputs of MLP layer 0
+static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_tiles, int n_blocks, int k0 = 351) {   // k0: inputs of MLP layer 0; n_blocks: density bins x copies
     BwdCarve c;
     size_t o = 0;
     const size_t R = (size_t)rows;
@@ -1100,14 +1253,14 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
     c.xpe = o; o = al256(o + R * (size_t)((k0 + 3) & ~3) * 4);
     c.part = o; o = al256(o + tn_part_bytes(rows, k0));
     c.gpack = o; o = al256(o + (gemm_h_pack_bytes(k0) > mlp_bwd_ss_pack_bytes() ? gemm_h_pack_bytes(k0) : mlp_bwd_ss_pack_bytes()));   // packed W^T operands of the input-gradient GEMMs (t2n_gemm_h.hip / t2n_mlp_bwd_ss.hip)
-    // tile-binned density scatter: worst case one record per sample and plane
+    // block-binned density scatter: worst case one record per sample
     const size_t cap = (size_t)n_rays * (size_t)n_samples;
-    c.seg_cap = (unsigned)(3 * cap / 512 + (size_t)n_tiles + 1);
-    c.hist = o; o = al256(o + (size_t)n_tiles * kBinCopies * 4);
-    c.tile_start = o; o = al256(o + ((size_t)n_tiles + 1) * 4);
+    c.seg_cap = (unsigned)(cap / kDenSeg + (size_t)n_blocks + 1);
+    c.hist = o; o = al256(o + (size_t)n_blocks * 4);
+    c.tile_start = o; o = al256(o + ((size_t)n_blocks + 1) * 4);
     c.nseg = o; o = al256(o + 4);
     c.segs = o; o = al256(o + (size_t)c.seg_cap * 16);
-    c.recs = o; o = al256(o + 3 * cap * 16);
+    c.recs = o; o = al256(o + cap * 16);
     // the same for the appearance samples (one record per activation row and plane)
     c.a_seg_cap = (unsigned)(3 * R / kBinSegApp + (size_t)n_tiles + 1);
     c.a_hist = o; o = al256(o + (size_t)n_tiles * kBinCopies * 4);
@@ -1149,12 +1302,12 @@ static int ensure_grad_buffers(t2n_field* f) {
     return T2N_OK;
 }
 
-// layer 2 of the backward: 256 persistent workgroups (one per CU), their partial weight / bias sums through `scratch` (>= 256 x 388 floats:
-// the weight-gradient GEMMs' partial buffer, not in use yet)
+// layer 2 of the backward: up to kL2Blocks workgroups of 64 rows in flight each, their partial weight / bias sums through `scratch`
+// (>= kL2Blocks x 388 floats: the weight-gradient GEMMs' partial buffer, not in use yet)
 static void launch_bwd_l2(const float4* go, const float* h1, long long rows, const float* w2, float* g1, float* dw2, float* db2,
                           float* scratch, hipStream_t s) {
     const long long tiles = (rows + 63) / 64;
-    const unsigned nb = (unsigned)(tiles < 256 ? tiles : 256);
+    const unsigned nb = (unsigned)(tiles < kL2Blocks ? tiles : kL2Blocks);
     hipLaunchKernelGGL(k_bwd_l2, dim3(nb), dim3(256), 0, s, go, h1, rows, w2, g1, scratch);
     if (dw2 || db2) hipLaunchKernelGGL(k_bwd_l2_reduce, dim3(387), dim3(256), 0, s, (const float*)scratch, (int)nb, dw2, db2);
 }
@@ -1283,7 +1436,8 @@ extern "C" int t2n_render_ctx_rows(const void* fwd_workspace, int64_t n_rays, in
 extern "C" size_t t2n_backward_workspace_bytes(const t2n_field* f, int64_t rows, int64_t n_rays, int n_samples) {
     if (!f || n_rays <= 0 || n_samples <= 0) return 0;
     const int k0 = head_is_generic(f->desc.shading) ? head_dims(f->desc).K0 : 351;
-    return bwd_carve(rows < 32 ? 32 : rows, n_rays, n_samples, bin_geom(f->dev.den).total, k0).total;
+    const BlockGeom bg = block_geom(f->dev.den);
+    return bwd_carve(rows < 32 ? 32 : rows, n_rays, n_samples, bin_geom(f->dev.den).total, bg.total * bg.copies, k0).total;
 }
 
 extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
@@ -1316,7 +1470,8 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     if (rc) return rc;
     const int64_t rows_alloc = rows < 32 ? 32 : rows;
     const BinGeom geom = bin_geom(f->dev.den);
-    const BwdCarve b = bwd_carve(rows_alloc, n_rays, n_samples, geom.total, K0);
+    const BlockGeom bgeom = block_geom(f->dev.den);
+    const BwdCarve b = bwd_carve(rows_alloc, n_rays, n_samples, geom.total, bgeom.total * bgeom.copies, K0);
     if (b.total > bwd_workspace_bytes) { set_error("t2n_render_backward: backward workspace %zu B < %zu B", bwd_workspace_bytes, b.total); return T2N_ERR_WORKSPACE; }
     if ((rc = ensure_grad_buffers(f))) return rc;
 
@@ -1361,6 +1516,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
 
     // 2. per-ray backward + density scatter
     bool side = false;   // the density scatter was put on the side stream: joined before step 6
+    bool side_gemm = false;   // the weight-gradient GEMMs were put on the third stream: joined before step 6
     bool bin = false;
     size_t lds_bin = 0;
     {
@@ -1374,21 +1530,21 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         a.add_bg = (flags & T2N_FLAG_ADD_BG) ? 1 : 0;
         const size_t lds = (size_t)4 * 4 * a.npad * sizeof(float);
         const unsigned nb = (unsigned)((n_rays + 3) / 4);
-        // tile-binned scatter unless the grid's lines do not fit the LDS budget (or T2N_BWD_ATOMIC_SCATTER=1 asks for the
-        // sliding-window global-atomic path)
+        // binned scatters (density: 3-D blocks; appearance: plane tiles, as long as the grid's lines fit the LDS budget) unless
+        // T2N_BWD_ATOMIC_SCATTER=1 asks for the sliding-window global-atomic path
         int Lmax = 0;
         for (int k = 0; k < 3; ++k) Lmax = f->dev.den.L[k] > Lmax ? f->dev.den.L[k] : Lmax;
         const size_t lds_acc = tile_accum_lds(16, Lmax);
         static const bool force_atomic = getenv("T2N_BWD_ATOMIC_SCATTER") && atoi(getenv("T2N_BWD_ATOMIC_SCATTER")) != 0;
-        bin = !force_atomic && lds_acc <= 160 * 1024 && (uint64_t)n_rays * n_samples * 3 < 0x7fffffffull;
+        bin = !force_atomic && lds_acc <= 160 * 1024 && block_geom_ok(f->dev.den) && (uint64_t)n_rays * n_samples * 3 < 0x7fffffffull;
         lds_bin = lds_acc;
-        a.gfeat = (float*)(fw + c.sigma); a.hist = (unsigned*)(bw + b.hist); a.geom = geom;
+        a.gfeat = (float*)(fw + c.sigma); a.hist = (unsigned*)(bw + b.hist); a.geom = bgeom;
         timing_begin(f, T2N_K_BWD_MARCH, s);
         if (!bin) {
             if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true, false>), dim3(nb), dim3(256), lds, s, a);
             else hipLaunchKernelGGL((k_bwd_march<false, false>), dim3(nb), dim3(256), lds, s, a);
         } else {
-            T2N_HIP(hipMemsetAsync(a.hist, 0, (size_t)geom.total * kBinCopies * 4, s));
+            T2N_HIP(hipMemsetAsync(a.hist, 0, (size_t)bgeom.total * bgeom.copies * 4, s));
             if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true, true>), dim3(nb), dim3(256), lds, s, a);
             else hipLaunchKernelGGL((k_bwd_march<false, true>), dim3(nb), dim3(256), lds, s, a);
             // The density scatter (scan -> records -> LDS accumulate: atomic-latency- and LDS-bound, little VALU, no MFMA) shares
@@ -1409,18 +1565,17 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
                 T2N_HIP(hipStreamWaitEvent(sd, (hipEvent_t)f->ev_fork, 0));
                 side = true;
             }
-            launch_bin_scan(a.hist, geom.total, (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, 0u, kAccTargetSegs, sd);
+            launch_bin_scan(a.hist, bgeom.total, bgeom.copies, (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, kDenSeg,
+                            0u, kDenSeg, sd);
             BinArgs ba;
-            ba.F = f->dev; ba.geom = geom; ba.rays = rays; ba.n_rays = n_rays; ba.ray_stride = ray_stride; ba.n_samples = n_samples;
+            ba.F = f->dev; ba.geom = bgeom; ba.rays = rays; ba.n_rays = n_rays; ba.ray_stride = ray_stride; ba.n_samples = n_samples;
             ba.jitter = jitter; ba.gfeat = a.gfeat; ba.ray_app = a.ray_app; ba.cursor = a.hist; ba.recs = (float4*)(bw + b.recs);
             if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_bin<true>), dim3(nb), dim3(256), 0, sd, ba);
             else hipLaunchKernelGGL((k_bwd_bin<false>), dim3(nb), dim3(256), 0, sd, ba);
-            TileAccumArgs ta;
-            ta.S = f->dev.den; ta.G = a.gden; ta.geom = geom; ta.segs = (const int4*)(bw + b.segs);
-            ta.nseg = (const unsigned*)(bw + b.nseg); ta.recs = (const float4*)(bw + b.recs);
-            ta.gx = nullptr; ta.gx_ld = 0;
-            T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc));
-            hipLaunchKernelGGL((k_bwd_tile_accum<16>), dim3(b.seg_cap < kAccGrid ? b.seg_cap : kAccGrid, 1), dim3(kAccThreads), lds_acc, sd, ta);
+            DenBlockArgs da;
+            da.S = f->dev.den; da.G = a.gden; da.geom = bgeom; da.segs = (const int4*)(bw + b.segs);
+            da.nseg = (const unsigned*)(bw + b.nseg); da.recs = (const float4*)(bw + b.recs);
+            hipLaunchKernelGGL(k_bwd_den_block, dim3(b.seg_cap < kAccGrid ? b.seg_cap : kAccGrid), dim3(kDenThreads), 0, sd, da);
             if (side) T2N_HIP(hipEventRecord((hipEvent_t)f->ev_join, sd));
         }
         timing_end(f, T2N_K_BWD_MARCH, s);
@@ -1445,11 +1600,30 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             float* G0 = xpe; float* GF = xpe + (size_t)rows * 128; float* GX = xpe + (size_t)rows * 160;
             launch_bwd_l2((const float4*)go, (const float*)h1, rows, P->mlp_w2, nullptr, g->mlp_w2, g->mlp_b2, part, s);
             if ((rc = launch_mlp_bwd_ss(f, gpack, (const float4*)go, h1, h0, feat32, G0, GF, GX, rows, s))) return rc;
-            if (g->mlp_w1) launch_gemm_tn<4>(gemm_fp32, g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s, nullptr, g->mlp_b1);
-            else if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
-            if (g->mlp_w0) launch_gemm_tn<4>(gemm_fp32, G0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, s, feat32, g->mlp_b0);
-            else if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)G0, 128, (long long)rows, 128, g->mlp_b0, 128);
-            if (g->basis_weight) launch_gemm_tn<1>(gemm_fp32, GF, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, s);
+            // From here two chains share nothing but read-only rows: the weight-gradient GEMMs (g1 / G0 / GF with h0 / features / x144
+            // -> the MLP gradients, through `part`) and the appearance scatter (GX -> the factor gradient buffers). The GEMMs wait on
+            // memory latency and workgroup barriers, the scatter on LDS atomics: they run side by side, the GEMMs on a third stream
+            // that is joined before the gradients leave this call (T2N_BWD_SERIAL=1: one stream).
+            hipStream_t sg = s;
+            if (side) {
+                if (!f->gemm_stream) {
+                    hipStream_t st; hipEvent_t e0, e1;
+                    T2N_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                    T2N_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+                    T2N_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+                    f->gemm_stream = (void*)st; f->ev_fork2 = (void*)e0; f->ev_join2 = (void*)e1;
+                }
+                sg = (hipStream_t)f->gemm_stream;
+                T2N_HIP(hipEventRecord((hipEvent_t)f->ev_fork2, s));
+                T2N_HIP(hipStreamWaitEvent(sg, (hipEvent_t)f->ev_fork2, 0));
+                side_gemm = true;
+            }
+            if (g->mlp_w1) launch_gemm_tn<4>(gemm_fp32, g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, sg, nullptr, g->mlp_b1);
+            else if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, sg, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
+            if (g->mlp_w0) launch_gemm_tn<4>(gemm_fp32, G0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, sg, feat32, g->mlp_b0);
+            else if (g->mlp_b0) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, sg, (const float*)G0, 128, (long long)rows, 128, g->mlp_b0, 128);
+            if (g->basis_weight) launch_gemm_tn<1>(gemm_fp32, GF, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, sg);
+            if (side_gemm) T2N_HIP(hipEventRecord((hipEvent_t)f->ev_join2, sg));
             gxapp = GX;
         } else {
         // 3. layer 2
@@ -1491,8 +1665,8 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             T2N_HIP(hipMemsetAsync(ab.hist, 0, (size_t)ab.geom.total * kBinCopies * 4, s));
             const unsigned nbk = (unsigned)((rows + 255) / 256);
             hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, s, ab);
-            launch_bin_scan(ab.hist, ab.geom.total, (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),
-                            b.a_seg_cap, 0u, kAccTargetSegsApp, s);
+            launch_bin_scan(ab.hist, ab.geom.total, kBinCopies, (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),
+                            b.a_seg_cap, 0u, kAccTargetSegsApp, 512u, s);
             hipLaunchKernelGGL((k_app_bin<1>), dim3(nbk), dim3(256), 0, s, ab);
             TileAccumArgs ta;
             ta.S = f->dev.app; ta.G = sa.gapp; ta.geom = ab.geom; ta.segs = (const int4*)(bw + b.a_segs);
@@ -1511,6 +1685,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     }
 
     if (side) T2N_HIP(hipStreamWaitEvent(s, (hipEvent_t)f->ev_join, 0));
+    if (side_gemm) T2N_HIP(hipStreamWaitEvent(s, (hipEvent_t)f->ev_join2, 0));
     // 6. channel-last gradient buffers -> += reference layouts
     {
         RelayoutAddMulti ra;

@@ -1,5 +1,7 @@
 #!/bin/bash
-out=gpurun_out/${1:-r3_traintrace}; mkdir -p $out
+# kernel timeline of one C3 train iteration (mode 2 = fused step); further arguments: NAME=VALUE environment for the traced run
+out=gpurun_out/${1:-r3_traintrace}; shift; mkdir -p $out
+for v in "$@"; do export $v; done
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
 rocprofv3 --kernel-trace --output-format csv -d $out/prof -o t -- python3 tools/experiments/train_only.py 2 30 > $out/train.log 2>&1
 f=$(find $out/prof -name "*kernel_trace.csv" | head -1)
