@@ -133,15 +133,15 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0, check=None):
     return out
 
 
-def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_step=False, batch=16384):
+def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_step=False, batch=16384, resident=False):
     keep_threads = torch.get_num_threads()
     try:
-        return _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch)
+        return _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resident)
     finally:
         torch.set_num_threads(keep_threads)     # the loop below runs on half the cores; callers (CPU baseline, other legs) get theirs back
 
 
-def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch):
+def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resident=False):
     """C3-shaped optimisation step (text2nerf_main.py:547-601): 16 384 random rays of 9 small-baseline 512x512 views,
     N=259, is_train, MSE(rgb)+0.005 MSE(depth)+1e3 transmittance+TV(density 0.1, app 0.01), Adam(0.02/1e-3).
     With `dist` (world > 1): data-parallel — the SAME 16 384-ray batch is split into equal shards (strong scaling), local
@@ -188,8 +188,13 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch):
         lo, hi = shard_batch(batch, world, rank)
 
     tv_terms = [(field.density_plane, 0.1), (field.app_plane, 0.01)]
+    if resident:   # the whole training set (9 views: 94 MB) and the permutation live in HBM: the batch is three device gathers
+        allrays_d, allrgb_d, alldepth_d, perm_d = allrays.to(dev), allrgb.to(dev), alldepth.to(dev), perm.to(dev)
 
     def it(k):
+        if resident:
+            idx = perm_d[(k * batch) % (perm.numel() - batch):][:batch]
+            return field.train_step(allrays_d[idx], allrgb_d[idx], alldepth_d[idx], opt, N_samples=n_samples, white_bg=True, tv=tv_terms)[3]
         idx = perm[(k * batch) % (perm.numel() - batch):][:batch]
         if dist is not None:
             idx = idx[lo:hi]
@@ -245,6 +250,11 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch):
                                  f"message for the head, fused loss + TV + Adam on the device copies, loss {float(loss.detach()):.4f}"}
     if fused_step and batch != 16384:
         return {"ms_per_iter": dt / iters * 1e3, "rays": batch}
+    if resident:
+        return {"train_iters_per_s_fused_step_resident": iters / dt, "train_ms_per_iter_fused_step_resident": dt / iters * 1e3,
+                "train_step_fused_resident": "train_step with the training set (rays, colours, depths of the 9 views) resident in HBM: the "
+                                             "batch is gathered on the device, only the jitter draws (CPU generator, like the reference) "
+                                             "cross PCIe"}
     if fused_step:
         return {"train_iters_per_s_fused_step": iters / dt, "train_ms_per_iter_fused_step": dt / iters * 1e3,
                 "train_step_fused": "TensorVMSplit.train_step: no autograd graph, loss + its gradients in one kernel, event-based row "
@@ -821,6 +831,7 @@ def main():
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True))
+            out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True, resident=True))
         if world == 1 and not c4 and not args.quick:
             out["scaling_prediction"] = scaling_prediction(field, dev, out["config"].get("train_ms_per_iter_fused_step"))
         if world == 1 and not args.no_cpu_baseline:

@@ -6,7 +6,7 @@ mkdir -p $out
 tail -3 $out/tests.log
 for rep in 1 2 3; do
   for v in "$@"; do
-    for mode in 2 0; do
+    for mode in 3 2 0; do
       echo -n "rep $rep [$v] mode $mode: "
       ( export $v; python3 tools/experiments/train_only.py $mode 60 2>/dev/null | tail -1 | python3 -c "
 import sys, json
