@@ -586,6 +586,33 @@ extern "C" size_t t2n_render_workspace_bytes_ctx(int64_t n_rays, int n_samples) 
     return carve_workspace(n_rays, n_samples, true, false).total;
 }
 
+namespace t2n {
+__global__ __launch_bounds__(256) void k_setup(const SetupOps o) {
+    const int r = blockIdx.y;
+    if (r < o.nz) {
+        unsigned* __restrict__ p = r == 0 ? o.zero_ptr[0] : (r == 1 ? o.zero_ptr[1] : (r == 2 ? o.zero_ptr[2] : (r == 3 ? o.zero_ptr[3] : (r == 4 ? o.zero_ptr[4] : o.zero_ptr[5]))));
+        const unsigned long long n = r == 0 ? o.zero_words[0] : (r == 1 ? o.zero_words[1] : (r == 2 ? o.zero_words[2] : (r == 3 ? o.zero_words[3] : (r == 4 ? o.zero_words[4] : o.zero_words[5]))));
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) p[i] = 0u;
+    }
+    if (blockIdx.x == 0 && r == 0 && (int)threadIdx.x < o.ns) {
+        const int t = threadIdx.x;
+        unsigned* q = t == 0 ? o.set_ptr[0] : (t == 1 ? o.set_ptr[1] : (t == 2 ? o.set_ptr[2] : o.set_ptr[3]));
+        *q = t == 0 ? o.set_val[0] : (t == 1 ? o.set_val[1] : (t == 2 ? o.set_val[2] : o.set_val[3]));
+    }
+}
+// (a word both zeroed and set must not occur: the two parts of the kernel are unordered)
+int launch_setup(const SetupOps& o, hipStream_t s) {
+    if (o.nz == 0 && o.ns == 0) return T2N_OK;
+    unsigned long long mx = 1;
+    for (int r = 0; r < o.nz; ++r) mx = o.zero_words[r] > mx ? o.zero_words[r] : mx;
+    unsigned bx = (unsigned)((mx + 1023) / 1024);   // four words per thread
+    bx = bx > 512 ? 512 : (bx < 1 ? 1 : bx);
+    hipLaunchKernelGGL(k_setup, dim3(bx, o.nz > 0 ? (unsigned)o.nz : 1u), dim3(256), 0, s, o);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+}  // namespace t2n
+
 extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
                                   const float* jitter, float* rgb, float* depth, float* weights, float* z_vals, uint64_t* stats,
                                   void* workspace, size_t workspace_bytes, t2n_stream stream) {
@@ -598,8 +625,8 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     f->dev.ztab = (flags & T2N_FLAG_NDC) ? jitter : nullptr;
     const bool ndc = (flags & T2N_FLAG_NDC) != 0;
     hipStream_t s = (hipStream_t)stream;
-    if (stats) T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s));
-    if (n_rays == 0) return T2N_OK;
+    if (n_rays == 0) { if (stats) T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s)); return T2N_OK; }
+    bool stats_pending = stats != nullptr;   // zeroed by the first sub-launch's setup kernel
     const bool keep = (flags & T2N_FLAG_KEEP_CTX) != 0;
     // tile marcher: image-ordered eval rays with a known width (hint), whole rows per sub-launch
     const bool tiles = (flags & T2N_FLAG_COHERENT) != 0 && !ndc && !keep && !(flags & T2N_FLAG_TRAIN) && f->frame_w >= 8 &&
@@ -657,13 +684,23 @@ retry_worst_case:
         L.feat = (float*)(ws + c.feat); L.feat_rows = c.feat_rows;
         L.sigma_ctx = keep ? (float*)(ws + c.sigma) : nullptr;
         L.rgb_raw = keep ? (float4*)(ws + c.rgb_raw) : nullptr;
-        T2N_HIP(hipMemsetAsync(L.counters, 0, (size_t)kLists * kCounterStride * 4, s));
         int rc;
         const KeptRows kr = keep && f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW ? kept_rows(c.total, workspace_bytes) : KeptRows{0, 0, 0, 0, 0};
-        if (kr.rows >= 32) {   // recorded in the workspace itself (and in the counts' host copy): the backward checks it
-            // device-side fills (a copy from pageable host memory would drain the stream)
-            T2N_HIP(hipMemsetD32Async((hipDeviceptr_t)(L.counters + kKeptMagicWord), (int)kKeptMagic, 1, s));
-            T2N_HIP(hipMemsetD32Async((hipDeviceptr_t)(L.counters + kKeptRowsWord), (int)kr.rows, 1, s));
+        {   // the launch's counters (and, once per call, the statistics) zeroed, the kept-rows marker set: one kernel
+            SetupOps so;
+            const bool mark = kr.rows >= 32;   // recorded in the workspace itself (and in the counts' host copy): the backward checks it
+            // the marker words lie inside the counter block: zero around them when they are set (the kernel's two parts are unordered)
+            if (!mark) so.zero(L.counters, (size_t)kLists * kCounterStride * 4);
+            else {
+                const unsigned lo = kKeptMagicWord < kKeptRowsWord ? kKeptMagicWord : kKeptRowsWord, hi = kKeptMagicWord < kKeptRowsWord ? kKeptRowsWord : kKeptMagicWord;
+                so.zero(L.counters, (size_t)lo * 4);
+                if (hi > lo + 1) so.zero(L.counters + lo + 1, (size_t)(hi - lo - 1) * 4);
+                if ((unsigned)(kLists * kCounterStride) > hi + 1) so.zero(L.counters + hi + 1, (size_t)(kLists * kCounterStride - hi - 1) * 4);
+                so.set(L.counters + kKeptMagicWord, kKeptMagic);
+                so.set(L.counters + kKeptRowsWord, (unsigned)kr.rows);
+            }
+            if (stats_pending) { so.zero(stats, sizeof(uint64_t) * T2N_STAT_COUNT); stats_pending = false; }
+            if ((rc = launch_setup(so, s))) return rc;
         }
         if (tiles) {
             if ((rc = launch_march_tiles(f, L, f->frame_w, (int)(cnt / f->frame_w), (float*)(ws + c.sigma), (float4*)(ws + c.scratch), s))) return rc;

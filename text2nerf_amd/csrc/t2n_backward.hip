@@ -403,11 +403,29 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
 // (2) single workgroup: exclusive scan of the [tile][copy] histogram -> absolute cursors (in place), tile starts, and the
 // segment list of the accumulate pass. The histogram is pulled into LDS with coalesced loads first (LDS = true) so the
 // per-thread serial runs do not chain ~70 dependent global round trips.
+// inclusive scan of one value per thread over a 1024-thread workgroup: shuffles inside the waves, the 16 wave totals through LDS (two
+// barriers; the Hillis-Steele form over LDS took twenty). `total` = the sum over the workgroup. sh: 17 words.
+__device__ __forceinline__ unsigned block_scan_1024(unsigned v, unsigned* sh, unsigned& total) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = (unsigned)__shfl_up((int)v, o);
+        if (lane >= o) v += u;
+    }
+    __syncthreads();            // the previous use of sh is over
+    if (lane == 63) sh[w] = v;
+    __syncthreads();
+    unsigned before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const unsigned x = sh[q]; all += x; before += q < w ? x : 0u; }
+    total = all;
+    return v + before;
+}
 template <bool LDS>
 __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, int copies, unsigned* tile_start, int4* segs, unsigned* nseg_out,
                                                    unsigned seg_cap, unsigned seg_size_in, unsigned target_segs, unsigned seg_min) {
     extern __shared__ unsigned sh_hist[];
-    __shared__ unsigned sh[1024];
+    __shared__ unsigned sh[17];
     const int t = threadIdx.x;
     const int n = n_tiles * copies;
     if (LDS) {
@@ -426,16 +444,8 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
     const int b = t * per, e = min(n, b + per);
     unsigned sum = 0;
     for (int i = b; i < e; ++i) sum += H[i];
-    sh[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned v = t >= o ? sh[t - o] : 0u;
-        __syncthreads();
-        sh[t] += v;
-        __syncthreads();
-    }
-    unsigned run = sh[t] - sum;
-    const unsigned total = sh[1023];
+    unsigned total;
+    unsigned run = block_scan_1024(sum, sh, total) - sum;
     for (int i = b; i < e; ++i) {
         const unsigned c = H[i];
         H[i] = run;
@@ -454,19 +464,10 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
         ne += s1 > s0 ? 1u : 0u;
     }
     if (t == 0) tile_start[n_tiles] = total;
-    __syncthreads();
-    sh[t] = ne;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned v = t >= o ? sh[t - o] : 0u;
-        __syncthreads();
-        sh[t] += v;
-        __syncthreads();
-    }
-    const unsigned nonempty = sh[1023];
-    __syncthreads();
     unsigned seg_size = seg_size_in;
-    if (seg_size == 0) {
+    if (seg_size == 0) {   // (uniform over the workgroup)
+        unsigned nonempty;
+        (void)block_scan_1024(ne, sh, nonempty);
         const unsigned room = target_segs > nonempty + 64 ? target_segs - nonempty / 2 : 64;   // every tile ends in a partial segment
         seg_size = (total + room - 1) / room;
         seg_size = (seg_size + 63) / 64 * 64;
@@ -477,15 +478,8 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
         const unsigned s0 = H[j * copies], s1 = j + 1 < n_tiles ? H[(j + 1) * copies] : total;
         ns += (s1 - s0 + seg_size - 1) / seg_size;
     }
-    sh[t] = ns;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned v = t >= o ? sh[t - o] : 0u;
-        __syncthreads();
-        sh[t] += v;
-        __syncthreads();
-    }
-    unsigned si = sh[t] - ns;
+    unsigned nsegs;
+    unsigned si = block_scan_1024(ns, sh, nsegs) - ns;
     for (int j = tb; j < te; ++j) {
         const unsigned s0 = H[j * copies], s1 = j + 1 < n_tiles ? H[(j + 1) * copies] : total;
         for (unsigned s = s0; s < s1; s += seg_size) {
@@ -493,7 +487,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
             ++si;
         }
     }
-    if (t == 1023) *nseg_out = min(sh[1023], seg_cap);
+    if (t == 0) *nseg_out = min(nsegs, seg_cap);
 }
 static void launch_bin_scan(unsigned* hist, int n_tiles, int copies, unsigned* tile_start, int4* segs, unsigned* nseg, unsigned seg_cap, unsigned seg_size,
                             unsigned target_segs, unsigned seg_min, hipStream_t s) {
@@ -1500,7 +1494,8 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     // a library-owned gradient buffer holds the gradients of THIS call; a caller-owned one (t2n_field_set_grad_buffer) accumulates
     // and is zeroed by its owner
     if (!f->gbuf_external) T2N_HIP(hipMemsetAsync(f->gbuf_all, 0, f->gbuf_bytes, s));
-    T2N_HIP(hipMemsetAsync(go, 0, (size_t)rows_alloc * 16, s));
+    SetupOps so;   // go, the two bin histograms: zeroed by one kernel once the scatter paths are known (below)
+    so.zero(go, (size_t)rows_alloc * 16);
 
     // 1. appearance forward recompute with activations kept
     timing_begin(f, T2N_K_BWD_MLP, s);
@@ -1539,12 +1534,16 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         bin = !force_atomic && lds_acc <= 160 * 1024 && block_geom_ok(f->dev.den) && (uint64_t)n_rays * n_samples * 3 < 0x7fffffffull;
         lds_bin = lds_acc;
         a.gfeat = (float*)(fw + c.sigma); a.hist = (unsigned*)(bw + b.hist); a.geom = bgeom;
+        if (bin) {
+            so.zero(a.hist, (size_t)bgeom.total * bgeom.copies * 4);
+            if (rows > 0 && f->dev.app.C == 48) so.zero(bw + b.a_hist, (size_t)bin_geom(f->dev.app).total * kBinCopies * 4);
+        }
+        if ((rc = launch_setup(so, s))) return rc;
         timing_begin(f, T2N_K_BWD_MARCH, s);
         if (!bin) {
             if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true, false>), dim3(nb), dim3(256), lds, s, a);
             else hipLaunchKernelGGL((k_bwd_march<false, false>), dim3(nb), dim3(256), lds, s, a);
         } else {
-            T2N_HIP(hipMemsetAsync(a.hist, 0, (size_t)bgeom.total * bgeom.copies * 4, s));
             if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true, true>), dim3(nb), dim3(256), lds, s, a);
             else hipLaunchKernelGGL((k_bwd_march<false, true>), dim3(nb), dim3(256), lds, s, a);
             // The density scatter (scan -> records -> LDS accumulate: atomic-latency- and LDS-bound, little VALU, no MFMA) shares
@@ -1662,7 +1661,6 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             AppBinArgs ab;
             ab.S = f->dev.app; ab.geom = bin_geom(f->dev.app); ab.app_pos = app_pos; ab.counters = counters; ab.list_cap = c.list_cap;
             ab.tp = tp; ab.rows = rows; ab.hist = (unsigned*)(bw + b.a_hist); ab.recs = (float4*)(bw + b.a_recs);
-            T2N_HIP(hipMemsetAsync(ab.hist, 0, (size_t)ab.geom.total * kBinCopies * 4, s));
             const unsigned nbk = (unsigned)((rows + 255) / 256);
             hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, s, ab);
             launch_bin_scan(ab.hist, ab.geom.total, kBinCopies, (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),

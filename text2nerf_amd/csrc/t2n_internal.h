@@ -180,6 +180,15 @@ int launch_head_forward(t2n_field* f, const unsigned tiles_before[kLists + 1], l
                         float* h0, float* h1, float4* app_rgb, hipStream_t s);
 int launch_head_in_bwd(t2n_field* f, const float* gx, const float* feat32, long long rows, float* gf, hipStream_t s);
 // backward of the parameter-free SH / RGB heads: dL/dfeatures rows from the per-sample colour gradients (t2n_heads.hip)
+// Several small device-side initialisations as ONE launch (every hipMemsetAsync / hipMemsetD32Async is a 5-us kernel of its own on the
+// stream): up to 6 regions zeroed (4-byte words) and up to 4 words set.
+struct SetupOps {
+    unsigned* zero_ptr[6]; unsigned long long zero_words[6]; int nz = 0;
+    unsigned* set_ptr[4]; unsigned set_val[4]; int ns = 0;
+    void zero(void* p, size_t bytes) { if (p && bytes) { zero_ptr[nz] = (unsigned*)p; zero_words[nz] = (bytes + 3) / 4; ++nz; } }
+    void set(void* p, unsigned v) { set_ptr[ns] = (unsigned*)p; set_val[ns] = v; ++ns; }
+};
+int launch_setup(const SetupOps& o, hipStream_t s);
 int launch_simple_head_bwd(t2n_field* f, const unsigned tiles_before[kLists + 1], long long rows, const float4* go, const float4* app_rgb,
                            const int* app_ray, const float* rays, int ray_stride, const unsigned* counters, unsigned list_cap, float* gf,
                            hipStream_t s);
