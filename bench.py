@@ -358,9 +358,12 @@ def scaling_prediction(field, dev, fused_ms, G=8):
                                 "all_reduce_estimate_ms": ar_ms,
                                 "predicted_8gpu_step_ms": steps[16384 // G] + ar_ms,
                                 "predicted_speedup": fused_ms / (steps[16384 // G] + ar_ms),
-                                "note": "strong scaling of ONE 16 384-ray batch: the step at 2 048 rays / GPU is a chain of ~30 launches whose "
+                                # the other way to use 8 GPUs (the driver's --batch_size x 8): every GPU keeps its 16 384 rays
+                                "predicted_8gpu_weak_step_ms": fused_ms + ar_ms,
+                                "predicted_weak_rays_per_s_ratio": G * fused_ms / (fused_ms + ar_ms),
+                                "note": "strong scaling of ONE 16 384-ray batch: the step at 2 048 rays / GPU is a chain of ~40 launches whose "
                                         "fixed cost does not shrink; the all-reduce is not overlapped with the backward (the scatter kernels "
-                                        "finish the factor gradients last)"}
+                                        "finish the factor gradients last). *_weak_*: 16 384 rays per GPU (8 x the batch), rays/s against one GPU"}
         except Exception as e:  # noqa: BLE001
             pred["train_dp"] = {"error": repr(e)[:300]}
     pred["weak_c2"] = {"note": "default --gpus N mode: one independent 800x800 view per GPU, the 10 MB all-gather of frame k overlaps the "
