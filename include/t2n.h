@@ -335,6 +335,12 @@ int t2n_adam_step_multi(int count, float* const* params, const float* const* gra
 int t2n_field_tv_adam_step(t2n_field* f, const t2n_field_params* params, float* const* exp_avg, float* const* exp_avg_sq,
                            const float* lrs, const int64_t* steps, float beta1, float beta2, float eps,
                            float tv_weight_density, float tv_weight_app, t2n_stream stream);
+/* The TV terms the other way round: the factor gradient buffer (t2n_field_set_grad_buffer, or the library's own) is INITIALISED to the
+ * TV gradient of the current device copies — zero for the lines and for a zero weight — before the backward accumulates into it
+ * (replaces a zero fill + the TV pass of t2n_field_tv_adam_step, which is then called with both weights 0). One write-only pass that
+ * depends on nothing but the parameters: it may run on another stream beside the forward; the backward must be ordered behind it.
+ * Replaces (reference): the autograd of TV_loss_density / TV_loss_app (models/tensoRF.py:193-203, text2nerf_main.py:577-586). */
+int t2n_field_tv_seed(t2n_field* f, float tv_weight_density, float tv_weight_app, t2n_stream stream);
 /* re-pack basis_mat / renderModule only (the factor copies of an uploaded field are left as they are) */
 int t2n_field_upload_head(t2n_field* f, const t2n_field_params* p, t2n_stream stream);
 

@@ -113,6 +113,7 @@ SIGNATURES = {
     "t2n_tv_grad_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "t2n_field_tv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                          C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "t2n_field_tv_seed": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     "t2n_field_upload_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2n_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_int64, C.c_void_p]),

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamMulti a) {
 // thing where the data already is: TV stencil on the channel-last parameters (neighbours at +-C and +-W*C), then one pass
 // that reads g / m / v / p channel-last, writes p / m / v channel-last and the new values into the caller's reference-layout
 // tensor through an LDS tile transpose. Same arithmetic per element as k_tv_grad + k_adam (bit-identical results).
+template <bool SET>
 __device__ __forceinline__ void tv_grad_cl_body(const float* __restrict__ x, float* __restrict__ g, long long t, int C4, int H, int W, float sh,
                                                 float sw) {
     const long long n = (long long)H * W * C4;   // t: one float4 of 4 channels
@@ -121,6 +122,7 @@ __device__ __forceinline__ void tv_grad_cl_body(const float* __restrict__ x, flo
     if (w > 0) { const float4 l = X[t - C4]; acc.x += sw * (2.f * (v.x - l.x)); acc.y += sw * (2.f * (v.y - l.y)); acc.z += sw * (2.f * (v.z - l.z)); acc.w += sw * (2.f * (v.w - l.w)); }
     if (w < W - 1) { const float4 r = X[t + C4]; acc.x -= sw * (2.f * (r.x - v.x)); acc.y -= sw * (2.f * (r.y - v.y)); acc.z -= sw * (2.f * (r.z - v.z)); acc.w -= sw * (2.f * (r.w - v.w)); }
     float4* G = reinterpret_cast<float4*>(g);
+    if (SET) { G[t] = acc; return; }   // the gradient buffer STARTS as the TV gradient (t2n_field_tv_seed)
     float4 gv = G[t];
     gv.x += acc.x; gv.y += acc.y; gv.z += acc.z; gv.w += acc.w;
     G[t] = gv;
@@ -180,7 +182,16 @@ __global__ __launch_bounds__(256) void k_tv_grad_cl_multi(const FactorStep a) {
 #pragma unroll 1
     for (int q = 1; q < 12; ++q) t += (a.tblock0[q] <= blockIdx.x) ? 1 : 0;
     const long long i = (long long)(blockIdx.x - a.tblock0[t]) * 256 + threadIdx.x;
-    tv_grad_cl_body(a.p[t], a.g[t], i, a.C[t] / 4, a.H[t], a.W[t], a.sh[t], a.sw[t]);
+    tv_grad_cl_body<false>(a.p[t], a.g[t], i, a.C[t] / 4, a.H[t], a.W[t], a.sh[t], a.sw[t]);
+}
+// every factor gradient tensor initialised: the TV gradient where a tensor has a TV weight, zero elsewhere (tblock0 spans all 12)
+__global__ __launch_bounds__(256) void k_tv_seed_cl_multi(const FactorStep a) {
+    int t = 0;
+#pragma unroll 1
+    for (int q = 1; q < 12; ++q) t += (a.tblock0[q] <= blockIdx.x) ? 1 : 0;
+    const long long i = (long long)(blockIdx.x - a.tblock0[t]) * 256 + threadIdx.x;
+    if (a.sh[t] != 0.f || a.sw[t] != 0.f) tv_grad_cl_body<true>(a.p[t], a.g[t], i, a.C[t] / 4, a.H[t], a.W[t], a.sh[t], a.sw[t]);
+    else if (i < a.npos[t] * (a.C[t] / 4)) reinterpret_cast<float4*>(a.g[t])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __global__ __launch_bounds__(256) void k_adam_cl_multi(const FactorStep a) {
     __shared__ float tile[48 * 65];
@@ -242,6 +253,44 @@ extern "C" int t2n_field_tv_adam_step(t2n_field* f, const t2n_field_params* para
     A.tblock0[12] = tb; A.ablock0[12] = ab;
     if (tb) hipLaunchKernelGGL(k_tv_grad_cl_multi, dim3(tb), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_adam_cl_multi, dim3(ab), dim3(256), 0, s, A);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+// The factor gradient buffer of the next backward call initialised to the TV gradient of the CURRENT device copies (zero for the
+// lines and for a zero weight) instead of being zero-filled and TV-incremented after the backward: one pass that only writes the
+// buffer, and one that may run on another stream beside the forward (it reads the parameters the forward reads and nothing else).
+// Same per-element arithmetic as the TV pass of t2n_field_tv_adam_step; the scatter kernels then accumulate on top.
+extern "C" int t2n_field_tv_seed(t2n_field* f, float tv_weight_density, float tv_weight_app, t2n_stream stream) {
+    if (!f) { set_error("t2n_field_tv_seed: NULL field"); return T2N_ERR_INVALID; }
+    if (!f->uploaded || !f->gbuf_den_plane[0]) { set_error("t2n_field_tv_seed: needs an uploaded field with a gradient buffer"); return T2N_ERR_INVALID; }
+    if (f->factor_bf16) { set_error("t2n_field_tv_seed: bf16 factor storage keeps no fp32 master copy on the device"); return T2N_ERR_UNSUPPORTED; }
+    const int* gr = f->desc.grid;
+    FactorStep A;
+    memset(&A, 0, sizeof(A));
+    unsigned tb = 0;
+    for (int q = 0; q < 4; ++q)
+        for (int k = 0; k < 3; ++k) {
+            const int idx = q * 3 + k;
+            const int H = gr[mat1(k)], W = gr[mat0(k)];
+            const long long HW = (long long)H * W, L = gr[vecm(k)];
+            float* pcl[4] = {f->buf_den_plane[k], f->buf_den_line[k], f->buf_app_plane[k], f->buf_app_line[k]};
+            float* gcl[4] = {f->gbuf_den_plane[k], f->gbuf_den_line[k], f->gbuf_app_plane[k], f->gbuf_app_line[k]};
+            const int C = q < 2 ? 16 : 48;
+            const bool plane = (q & 1) == 0;
+            const float tvw = q == 0 ? tv_weight_density : (q == 2 ? tv_weight_app : 0.f);
+            A.p[idx] = pcl[q]; A.g[idx] = gcl[q];
+            A.npos[idx] = plane ? HW : L; A.C[idx] = C; A.H[idx] = plane ? H : (int)L; A.W[idx] = plane ? W : 1;
+            if (tvw != 0.f) {
+                if (H < 2 || W < 2) { set_error("t2n_field_tv_seed: TV needs planes of at least 2x2"); return T2N_ERR_INVALID; }
+                A.sh[idx] = tvw * 2.f / ((float)C * (float)(H - 1) * (float)W);
+                A.sw[idx] = tvw * 2.f / ((float)C * (float)H * (float)(W - 1));
+            }
+            A.tblock0[idx] = tb;
+            tb += (unsigned)((A.npos[idx] * (C / 4) + 255) / 256);
+        }
+    A.tblock0[12] = tb;
+    hipLaunchKernelGGL(k_tv_seed_cl_multi, dim3(tb), dim3(256), 0, (hipStream_t)stream, A);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

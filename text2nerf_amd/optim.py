@@ -101,7 +101,7 @@ class TVAdam(torch.optim.Optimizer):
         for p in fac:
             _bump_version(p)
         f._device_factor_key = tuple((p.data_ptr(), p._version) for p in fac)   # the device copies are these values
-        f.zero_factor_grads()      # consumed: the next step's backward calls accumulate from zero
+        f.zero_factor_grads(lazy=True)   # consumed: zeroed in front of the next accumulating backward (or seeded by train_step)
         return {id(p) for p in fac}
 
     def zero_grad(self, set_to_none=True):

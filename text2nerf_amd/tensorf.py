@@ -586,12 +586,16 @@ class TensorVMSplit(nn.Module):
         return type(self)._kernel_views is TensorVMSplit._kernel_views and type(self)._autograd_params is TensorVMSplit._autograd_params \
             and self.factor_storage == "fp32" and not self._needs_embed()
 
-    def factor_grad_buffer(self):
+    def factor_grad_buffer(self, _raw=False):
         """The channel-last gradients of the 12 plane / line tensors as ONE flat fp32 tensor owned here and handed to the native
         field (t2n_field_set_grad_buffer): deferred backward calls ACCUMULATE into it — a batch split into chunks, gradient
         accumulation, a data-parallel all-reduce in place (parallel.allreduce_gradients(field=...)) — and TVAdam(field=...) consumes
         and zeroes it."""
         if getattr(self, "_gbuf", None) is not None:
+            if getattr(self, "_gbuf_stale", False) and not _raw:   # consumed by the optimiser: readers see it zeroed
+                self._gbuf.zero_()
+                self._gbuf_stale = False
+                self._gbuf_dirty = False
             return self._gbuf
         h = self.sync_params()
         if getattr(self, "_gbuf", None) is None:
@@ -603,12 +607,47 @@ class TensorVMSplit(nn.Module):
             self._gbuf_dirty = False
         return self._gbuf
 
-    def zero_factor_grads(self):
+    def zero_factor_grads(self, lazy=False):
+        """The factor gradient buffer back to zero. `lazy` (TVAdam after it consumed the gradients): only marked — the fill runs in front
+        of the next accumulating backward, or never, when train_step seeds the buffer with the TV gradient instead."""
         if getattr(self, "_gbuf", None) is not None and self._gbuf_dirty:
-            self._gbuf.zero_()
-        self._gbuf_dirty = False
+            if lazy:
+                self._gbuf_stale = True
+            else:
+                self._gbuf.zero_()
+                self._gbuf_stale = False
+        if not lazy or not getattr(self, "_gbuf_stale", False):
+            self._gbuf_dirty = False
         self._gbuf_reduced = False
         self._deferred_grad_key = None
+
+    def seed_factor_grads_with_tv(self, tv):
+        """Initialise the factor gradient buffer to the TV gradient of the current parameters (t2n_field_tv_seed) on a side stream, beside
+        whatever the current stream does next (the forward): returns the event the backward has to wait for. `tv`: [(tensorf.density_plane,
+        weight), (tensorf.app_plane, weight)] as for TVAdam.step."""
+        lib = _lib.load()
+        tv_d = tv_a = 0.0
+        for planes, weight in tv:
+            if planes is self.density_plane:
+                tv_d = float(weight) * 1e-2
+            elif planes is self.app_plane:
+                tv_a = float(weight) * 1e-2
+            else:
+                raise T2NError("train_step: tv entries must be tensorf.density_plane / tensorf.app_plane")
+        h = self.sync_params()
+        self.factor_grad_buffer(_raw=True)     # (every element is overwritten: a pending zero fill is dropped)
+        dev = self.basis_mat.weight.device
+        cur = torch.cuda.current_stream(dev)
+        side = self.__dict__.get("_seed_stream")
+        if side is None:
+            side = self.__dict__["_seed_stream"] = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)            # the previous step's Adam has read the buffer and written the parameters
+        with torch.cuda.device(dev):
+            _lib.check(lib.t2n_field_tv_seed(h, tv_d, tv_a, side.cuda_stream), "t2n_field_tv_seed")
+        self._gbuf_stale = False
+        self._gbuf_dirty = True
+        self._gbuf_reduced = False
+        return side.record_event()
 
     def sync_params(self, force=False, frame_width=None):
         """Create the native field on first use and re-upload when any parameter changed (in-place optimiser steps
@@ -1001,8 +1040,8 @@ class TensorVMSplit(nn.Module):
         # zero-filled 69.6 MB of gradient tensors); optim.TVAdam(field=...) steps from there
         defer = bool(getattr(self, "defer_factor_grads", False)) and self.supports_deferred_factor_grads()
         if defer:
-            self.factor_grad_buffer()     # caller-owned: this backward accumulates into it (chunked batches add up)
-            self._gbuf_dirty = True
+            self.factor_grad_buffer()     # caller-owned: this backward accumulates into it (chunked batches add up; a zero fill the
+            self._gbuf_dirty = True       # optimiser left pending runs here)
         if head_grads is not None and defer:
             grads = [None] * 12 + list(head_grads)
         else:
@@ -1063,6 +1102,13 @@ class TensorVMSplit(nn.Module):
         flags = FLAG_TRAIN | (FLAG_ADD_BG if (white_bg or bool(torch.rand((1,)) < 0.5)) else 0)
         rgb_t = rgb_t.contiguous().float()
         dep_t = dep_t.contiguous().float()
+        # TV terms: the gradient buffer starts as the TV gradient (one write-only pass on a side stream beside the forward) instead of
+        # being zero-filled, accumulated into and TV-incremented after the backward
+        seed_ev = None
+        if tv and getattr(optimizer, "field", None) is self and getattr(self, "defer_factor_grads", False) \
+                and self.supports_deferred_factor_grads():
+            seed_ev = self.seed_factor_grads_with_tv(tv)
+            tv = ()
         head = params[12:]
         if getattr(self, "_head_flat", None) is None or self._head_flat.numel() != sum(p.numel() for p in head):
             self._head_flat = torch.zeros(sum(p.numel() for p in head), device=dev)
@@ -1081,6 +1127,8 @@ class TensorVMSplit(nn.Module):
             for p in head:
                 views.append(self._head_flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
+            if seed_ev is not None:
+                torch.cuda.current_stream(dev).wait_event(seed_ev)
             grads = self._backward_raw(rays, jitter, N, flags, ws, d_rgb, d_depth, d_w, head_grads=views)
             for p, g in zip(params, grads):
                 p.grad = g
