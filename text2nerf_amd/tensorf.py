@@ -292,6 +292,7 @@ class TensorVMSplit(nn.Module):
         self._uploaded_key = None
         self._gbuf = None
         self._gbuf_dirty = False
+        self._gbuf_stale = False
         self.last_stats = None
 
         if shadingMode not in _lib.SHADE_IDS:
@@ -605,18 +606,19 @@ class TensorVMSplit(nn.Module):
             self._gbuf = torch.zeros(n // 4, device=dev, dtype=torch.float32)
             _lib.check(lib.t2n_field_set_grad_buffer(h, _lib.ptr(self._gbuf), n), "t2n_field_set_grad_buffer")
             self._gbuf_dirty = False
+            self._gbuf_stale = False
         return self._gbuf
 
     def zero_factor_grads(self, lazy=False):
         """The factor gradient buffer back to zero. `lazy` (TVAdam after it consumed the gradients): only marked — the fill runs in front
         of the next accumulating backward, or never, when train_step seeds the buffer with the TV gradient instead."""
-        if getattr(self, "_gbuf", None) is not None and self._gbuf_dirty:
-            if lazy:
-                self._gbuf_stale = True
-            else:
+        have = getattr(self, "_gbuf", None) is not None
+        if lazy and have and self._gbuf_dirty:
+            self._gbuf_stale = True           # (stays dirty: a later eager call still fills)
+        else:
+            if have and self._gbuf_dirty:
                 self._gbuf.zero_()
-                self._gbuf_stale = False
-        if not lazy or not getattr(self, "_gbuf_stale", False):
+            self._gbuf_stale = False
             self._gbuf_dirty = False
         self._gbuf_reduced = False
         self._deferred_grad_key = None
@@ -829,6 +831,7 @@ class TensorVMSplit(nn.Module):
         self._uploaded_key = None
         self._gbuf = None            # channel-last factor gradients: sized by the grid
         self._gbuf_dirty = False
+        self._gbuf_stale = False
 
     @torch.no_grad()
     def compute_alpha(self, xyz_locs, length=1):

@@ -7,7 +7,9 @@ for r in rows:
 rows.sort(key=lambda r: r["s"])
 names = [r["Kernel_Name"] for r in rows]
 # iteration boundaries: every k_train_loss marks one iteration; take the requested one from the k_march<true> before it to the next one
-idx = [i for i, n in enumerate(names) if "k_march<true" in n.replace(" ", "") or "k_marchILb1" in n]
+import os
+mark = os.environ.get("T2N_TIMELINE_MARK", "k_march<true")     # first kernel of an iteration (render frames: k_march_tiles)
+idx = [i for i, n in enumerate(names) if mark in n.replace(" ", "") or (mark == "k_march<true" and "k_marchILb1" in n)]
 it = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 a, b = idx[it], idx[it + 1]
 t0 = rows[a]["s"]
