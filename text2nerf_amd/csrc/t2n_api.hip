@@ -700,6 +700,10 @@ retry_worst_case:
                 so.set(L.counters + kKeptRowsWord, (unsigned)kr.rows);
             }
             if (stats_pending) { so.zero(stats, sizeof(uint64_t) * T2N_STAT_COUNT); stats_pending = false; }
+            if (tiles) {   // the tile marcher's overflow-ray counter (behind the per-ray staging slices: launch_march_tiles)
+                const int cap_e = n_samples / 4 > 0 ? n_samples / 4 : 1;
+                so.zero(ws + c.scratch + (size_t)cnt * cap_e * 16, 4);
+            }
             if ((rc = launch_setup(so, s))) return rc;
         }
         if (tiles) {

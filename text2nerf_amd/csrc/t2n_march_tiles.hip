@@ -513,7 +513,7 @@ int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h
     a.scratch = scratch; a.cap = cap; a.ovf_count = ovf_count; a.ovf_list = ovf_list;
     a.app_pos = L.app_pos; a.app_ray = L.app_ray; a.counters = L.counters; a.list_cap = L.list_cap; a.stats = (unsigned long long*)L.stats;
     a.dense_w = L.weights;
-    T2N_HIP(hipMemsetAsync(ovf_count, 0, 4, s));
+    // (*ovf_count was zeroed by the launch's setup kernel, t2n_render_forward)
     const long long tiles = (long long)((img_w + 7) / 8) * ((img_h + 7) / 8);
     const dim3 grid((unsigned)((tiles + 3) / 4));
     timing_begin(f, T2N_K_MARCH, s);

@@ -1156,10 +1156,12 @@ struct PackArgs {
     const float* basis; const float* w0; const float* b0; const float* w1; const float* b1; const float* w2; const float* b2;
     float* basisA; float* w0A; float* w1A; float* w2A;
     int app_dim, has_mlp;
+    unsigned* clear_word;   // the split packing's range flag, cleared here (k_pack_mlp_h, the next launch, ORs into it)
 };
 
 __global__ __launch_bounds__(256) void k_pack_mlp(const PackArgs a) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid == 0 && a.clear_word) *a.clear_word = 0u;
     const int nb = kBasisSteps * 64, n0 = kL0Steps * 256, n1 = kL1Steps * 256, n2 = kL2Steps * 64;
     if (gid < nb) {
         const int t = gid / 64, l = gid % 64, i = l & 31, h = l >> 5;
@@ -1298,8 +1300,6 @@ int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
     a.app_dim = f->desc.app_dim;
     a.has_mlp = f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW;
     const size_t total = nb + n0 + n1 + n2;
-    hipLaunchKernelGGL(k_pack_mlp, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
-    T2N_HIP(hipGetLastError());
     // split-f16 operands
     const size_t hb = (size_t)(kBasisChunks + 1) * 1 * 2 * 64 * 8, h0 = (size_t)(kL0Chunks + 1) * 4 * 2 * 64 * 8,
                  h1 = (size_t)(kL1Chunks + 1) * 4 * 2 * 64 * 8, h2 = (size_t)(kL2Chunks + 1) * 1 * 2 * 64 * 8;
@@ -1307,6 +1307,9 @@ int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
         T2N_HIP(hipMalloc((void**)&f->buf_mlp_h, (hb + h0 + h1 + h2) * sizeof(_Float16) + (288 + 4) * sizeof(float)));
     }
     _Float16* hbase = (_Float16*)f->buf_mlp_h;
+    a.clear_word = (unsigned*)((float*)(hbase + hb + h0 + h1 + h2) + 288);
+    hipLaunchKernelGGL(k_pack_mlp, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    T2N_HIP(hipGetLastError());
     PackHArgs ha;
     ha.basis = p->basis_weight; ha.w0 = p->mlp_w0; ha.b0 = p->mlp_b0; ha.w1 = p->mlp_w1; ha.b1 = p->mlp_b1; ha.w2 = p->mlp_w2; ha.b2 = p->mlp_b2;
     ha.basisH = hbase; ha.w0H = hbase + hb; ha.w1H = hbase + hb + h0; ha.w2H = hbase + hb + h0 + h1;
@@ -1314,7 +1317,6 @@ int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
     ha.app_dim = f->desc.app_dim; ha.has_mlp = a.has_mlp;
     ha.unsafe = (unsigned*)(ha.biasH + 288);
     f->split_unsafe = ha.unsafe;
-    T2N_HIP(hipMemsetAsync(ha.unsafe, 0, 4, s));
     f->dev.basisH = (const uint4*)ha.basisH; f->dev.w0H = (const uint4*)ha.w0H; f->dev.w1H = (const uint4*)ha.w1H;
     f->dev.w2H = (const uint4*)ha.w2H; f->dev.biasH = ha.biasH;
     const size_t htotal = hb + h0 + h1 + h2 + 288;
