@@ -594,6 +594,7 @@ class TensorVMSplit(nn.Module):
         and zeroes it."""
         if getattr(self, "_gbuf", None) is not None:
             if getattr(self, "_gbuf_stale", False) and not _raw:   # consumed by the optimiser: readers see it zeroed
+                self._drop_preseed()
                 self._gbuf.zero_()
                 self._gbuf_stale = False
                 self._gbuf_dirty = False
@@ -616,6 +617,7 @@ class TensorVMSplit(nn.Module):
         if lazy and have and self._gbuf_dirty:
             self._gbuf_stale = True           # (stays dirty: a later eager call still fills)
         else:
+            self._drop_preseed()
             if have and self._gbuf_dirty:
                 self._gbuf.zero_()
             self._gbuf_stale = False
@@ -623,11 +625,14 @@ class TensorVMSplit(nn.Module):
         self._gbuf_reduced = False
         self._deferred_grad_key = None
 
-    def seed_factor_grads_with_tv(self, tv):
-        """Initialise the factor gradient buffer to the TV gradient of the current parameters (t2n_field_tv_seed) on a side stream, beside
-        whatever the current stream does next (the forward): returns the event the backward has to wait for. `tv`: [(tensorf.density_plane,
-        weight), (tensorf.app_plane, weight)] as for TVAdam.step."""
-        lib = _lib.load()
+    def _drop_preseed(self):
+        """A TV seed written ahead for a train_step that is not coming: whoever fills the buffer next is ordered behind that kernel."""
+        pre = self.__dict__.get("_gbuf_preseed")
+        if pre is not None:
+            torch.cuda.current_stream(self.basis_mat.weight.device).wait_event(pre[3])
+            self.__dict__["_gbuf_preseed"] = None
+
+    def _tv_weights(self, tv):
         tv_d = tv_a = 0.0
         for planes, weight in tv:
             if planes is self.density_plane:
@@ -636,9 +641,30 @@ class TensorVMSplit(nn.Module):
                 tv_a = float(weight) * 1e-2
             else:
                 raise T2NError("train_step: tv entries must be tensorf.density_plane / tensorf.app_plane")
+        return tv_d, tv_a
+
+    def _factor_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self._all_params()[:12])
+
+    def seed_factor_grads_with_tv(self, tv, ahead=False):
+        """Initialise the factor gradient buffer to the TV gradient of the current parameters (t2n_field_tv_seed) on a side stream, beside
+        whatever the current stream does next: returns the event the backward has to wait for. `tv`: [(tensorf.density_plane, weight),
+        (tensorf.app_plane, weight)] as for TVAdam.step. `ahead` (train_step, right behind its optimiser step): the seed of the NEXT
+        step, written while the iteration's tail of small launches runs instead of beside the next forward's march (which it slows by a
+        quarter); to everybody but a train_step with the same terms on unchanged parameters the buffer then counts as consumed
+        (zero-filled before use)."""
+        lib = _lib.load()
+        tv_d, tv_a = self._tv_weights(tv)
+        dev = self.basis_mat.weight.device
+        pre = self.__dict__.get("_gbuf_preseed")
+        if not ahead and pre is not None and getattr(self, "_gbuf_stale", False) and pre[:2] == (tv_d, tv_a) and pre[2] == self._factor_key():
+            self.__dict__["_gbuf_preseed"] = None          # written ahead by the previous step: take it
+            self._gbuf_stale = False
+            self._gbuf_dirty = True
+            self._gbuf_reduced = False
+            return pre[3]
         h = self.sync_params()
         self.factor_grad_buffer(_raw=True)     # (every element is overwritten: a pending zero fill is dropped)
-        dev = self.basis_mat.weight.device
         cur = torch.cuda.current_stream(dev)
         side = self.__dict__.get("_seed_stream")
         if side is None:
@@ -646,10 +672,16 @@ class TensorVMSplit(nn.Module):
         side.wait_stream(cur)            # the previous step's Adam has read the buffer and written the parameters
         with torch.cuda.device(dev):
             _lib.check(lib.t2n_field_tv_seed(h, tv_d, tv_a, side.cuda_stream), "t2n_field_tv_seed")
-        self._gbuf_stale = False
+        ev = side.record_event()
         self._gbuf_dirty = True
         self._gbuf_reduced = False
-        return side.record_event()
+        if ahead:
+            self._gbuf_stale = True
+            self.__dict__["_gbuf_preseed"] = (tv_d, tv_a, self._factor_key(), ev)
+        else:
+            self._gbuf_stale = False
+            self.__dict__["_gbuf_preseed"] = None
+        return ev
 
     def sync_params(self, force=False, frame_width=None):
         """Create the native field on first use and re-upload when any parameter changed (in-place optimiser steps
@@ -825,6 +857,8 @@ class TensorVMSplit(nn.Module):
     # ---- coarse-to-fine / occupancy maintenance ----------------------------------------------------------
     def _drop_handle(self):
         """Grid shape or aabb changed: the native field is rebuilt on the next use."""
+        if self.__dict__.get("_gbuf_preseed") is not None:
+            self._drop_preseed()      # a seed kernel in flight reads the old field and writes the old buffer
         if self._handle is not None:
             _lib.load().t2n_field_destroy(self._handle)
             self._handle = None
@@ -832,6 +866,7 @@ class TensorVMSplit(nn.Module):
         self._gbuf = None            # channel-last factor gradients: sized by the grid
         self._gbuf_dirty = False
         self._gbuf_stale = False
+        self.__dict__["_gbuf_preseed"] = None
 
     @torch.no_grad()
     def compute_alpha(self, xyz_locs, length=1):
@@ -1107,11 +1142,11 @@ class TensorVMSplit(nn.Module):
         dep_t = dep_t.contiguous().float()
         # TV terms: the gradient buffer starts as the TV gradient (one write-only pass on a side stream beside the forward) instead of
         # being zero-filled, accumulated into and TV-incremented after the backward
-        seed_ev = None
+        seed_ev = seed_terms = None
         if tv and getattr(optimizer, "field", None) is self and getattr(self, "defer_factor_grads", False) \
                 and self.supports_deferred_factor_grads():
             seed_ev = self.seed_factor_grads_with_tv(tv)
-            tv = ()
+            seed_terms, tv = list(tv), ()
         head = params[12:]
         if getattr(self, "_head_flat", None) is None or self._head_flat.numel() != sum(p.numel() for p in head):
             self._head_flat = torch.zeros(sum(p.numel() for p in head), device=dev)
@@ -1138,6 +1173,8 @@ class TensorVMSplit(nn.Module):
             if all_reduce is not None:
                 all_reduce()
             optimizer.step(tv=tv) if tv else optimizer.step()
+            if seed_terms is not None:
+                self.seed_factor_grads_with_tv(seed_terms, ahead=True)
         return losses
 
     def stats(self):
