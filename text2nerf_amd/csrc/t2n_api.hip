@@ -602,6 +602,7 @@ __global__ __launch_bounds__(256) void k_setup(const SetupOps o) {
 }
 // (a word both zeroed and set must not occur: the two parts of the kernel are unordered)
 int launch_setup(const SetupOps& o, hipStream_t s) {
+    if (o.overflow) { set_error("launch_setup: more initialisations than the kernel has slots"); return T2N_ERR_INVALID; }
     if (o.nz == 0 && o.ns == 0) return T2N_OK;
     unsigned long long mx = 1;
     for (int r = 0; r < o.nz; ++r) mx = o.zero_words[r] > mx ? o.zero_words[r] : mx;

@@ -185,8 +185,16 @@ int launch_head_in_bwd(t2n_field* f, const float* gx, const float* feat32, long 
 struct SetupOps {
     unsigned* zero_ptr[6]; unsigned long long zero_words[6]; int nz = 0;
     unsigned* set_ptr[4]; unsigned set_val[4]; int ns = 0;
-    void zero(void* p, size_t bytes) { if (p && bytes) { zero_ptr[nz] = (unsigned*)p; zero_words[nz] = (bytes + 3) / 4; ++nz; } }
-    void set(void* p, unsigned v) { set_ptr[ns] = (unsigned*)p; set_val[ns] = v; ++ns; }
+    bool overflow = false;   // more entries than slots: launch_setup refuses (never silently drops an initialisation)
+    void zero(void* p, size_t bytes) {
+        if (!p || !bytes) return;
+        if (nz >= 6) { overflow = true; return; }
+        zero_ptr[nz] = (unsigned*)p; zero_words[nz] = (bytes + 3) / 4; ++nz;
+    }
+    void set(void* p, unsigned v) {
+        if (ns >= 4) { overflow = true; return; }
+        set_ptr[ns] = (unsigned*)p; set_val[ns] = v; ++ns;
+    }
 };
 int launch_setup(const SetupOps& o, hipStream_t s);
 int launch_simple_head_bwd(t2n_field* f, const unsigned tiles_before[kLists + 1], long long rows, const float4* go, const float4* app_rgb,
