@@ -1037,7 +1037,8 @@ __device__ __forceinline__ void coop_layer1(f32x16 (&acc)[4], const uint4* __res
 }
 
 
-template <bool HALF>
+// CTX: the activation rows of tiles below ctx_rows are kept (training forward / backward recompute), as k_shade does
+template <bool HALF, bool CTX = false>
 __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1077,7 +1078,11 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
             base = lbase + (tile - before) * 32u;
             count = lbase + __shfl(cnt_l, li);
         }
-        gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, nullptr, 0);
+        [[maybe_unused]] const unsigned row0 = tile * 32u;
+        [[maybe_unused]] const bool keep_rows = CTX && tile < ntiles && row0 + 32u <= a.ctx_rows;
+        [[maybe_unused]] const ShadeCtx cx = keep_rows ? a.ctx : ShadeCtx{nullptr, nullptr, nullptr, nullptr};
+        if constexpr (CTX) gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, cx.x144, row0);
+        else gather_all<HALF>(F.app, X, lane, a.app_pos, a.xyz, base, count, nullptr, 0);
         wave_lds_sync();
 
         f32x16 accb1[1] = {{0}};
@@ -1094,6 +1099,14 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
 
         const unsigned idx = base + (unsigned)s;
         const bool live = idx < count;
+        if constexpr (CTX) {
+            if (cx.feat32) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(cx.feat32 + (size_t)(row0 + s) * 32 + 8 * g + 4 * h) =
+                        make_float4(accb[4 * g], accb[4 * g + 1], accb[4 * g + 2], accb[4 * g + 3]);
+            }
+        }
         if (a.feat_out && live) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
@@ -1121,6 +1134,17 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) Hs[(ms * 32 + unit_of(v, h)) * kHld + s] = fmaxf(acc0[ms][v] * kWUnscale, 0.f);
         }
+        if constexpr (CTX) {
+            if (cx.h0) {
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(cx.h0 + (size_t)(row0 + s) * 128 + ms * 32 + 8 * g + 4 * h) =
+                            make_float4(fmaxf(acc0[ms][4 * g] * kWUnscale, 0.f), fmaxf(acc0[ms][4 * g + 1] * kWUnscale, 0.f),
+                                        fmaxf(acc0[ms][4 * g + 2] * kWUnscale, 0.f), fmaxf(acc0[ms][4 * g + 3] * kWUnscale, 0.f));
+            }
+        }
         wave_lds_sync();
         // ---- layer 1 ---------------------------------------------------------------------------------------------------
         f32x16 acc1[4];
@@ -1131,6 +1155,17 @@ __global__ __launch_bounds__(256, 2) void k_shade_coop(const ShadeArgs a) {
         for (int ms = 0; ms < 4; ++ms) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) Hs[(ms * 32 + unit_of(v, h)) * kHld + s] = fmaxf(acc1[ms][v] * kWUnscale, 0.f);
+        }
+        if constexpr (CTX) {
+            if (cx.h1) {
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(cx.h1 + (size_t)(row0 + s) * 128 + ms * 32 + 8 * g + 4 * h) =
+                            make_float4(fmaxf(acc1[ms][4 * g] * kWUnscale, 0.f), fmaxf(acc1[ms][4 * g + 1] * kWUnscale, 0.f),
+                                        fmaxf(acc1[ms][4 * g + 2] * kWUnscale, 0.f), fmaxf(acc1[ms][4 * g + 3] * kWUnscale, 0.f));
+            }
         }
         wave_lds_sync();
         // ---- layer 2 (3 live rows), wave-private weight stream -----------------------------------------------------------
@@ -1415,6 +1450,11 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
     timing_begin(f, T2N_K_SHADE, s);
     if (use_coop(f) && !ctx && half) hipLaunchKernelGGL(k_shade_coop<true>, grid, dim3(256), kCoopLds, s, a);
     else if (use_coop(f) && !ctx) hipLaunchKernelGGL(k_shade_coop<false>, grid, dim3(256), kCoopLds, s, a);
+    else if (use_coop(f) && ctx && !half && !features_only) {   // kept activation rows on the cooperative kernel (weights shared through LDS: 106 against 118 us per C3 iteration)
+        static bool attr_c = false;
+        if (!attr_c) { T2N_HIP(hipFuncSetAttribute((const void*)k_shade_coop<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCoopLds)); attr_c = true; }
+        hipLaunchKernelGGL((k_shade_coop<false, true>), grid, dim3(256), kCoopLds, s, a);
+    }
     else if (f->mlp_split)   /* ctx (backward recompute) too: activations at ~1e-7 relative error */ hipLaunchKernelGGL(k_shade<true>, grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL(k_shade<false>, grid, dim3(256), lds, s, a);
     if (f->mlp_split) {
