@@ -209,8 +209,9 @@ def test_explicit_point_shade_range_guard(tiny_params):
 def test_one_kernel_appearance_paths_stay_correct():
     """The appearance forms beside the default two-kernel one are all production paths and are reached here without switches: the
     cooperative one-kernel form (`f.shade` at explicit points: t2n_shade_at; tiles beyond the feature-row capacity of a render) and
-    the per-wave form with kept activation rows (training forward) — the range stresses and goldens of this file and of
-    test_hip_parity.py cover the first through f.shade and the second through the gradient tests; here the overflow-tile route: a
+    the same cooperative form with kept activation rows (training forward; the per-wave form keeps them under bf16 factor storage)
+    — the range stresses and goldens of this file and of test_hip_parity.py cover the first through f.shade and the second through
+    the gradient tests; here the overflow-tile route: a
     render whose feature-row capacity is forced down to a few tiles must equal the default render bitwise-close (<= 2e-7: the two
     forms order their f16-split sums differently)."""
     from text2nerf_amd import _lib, tensorf as tf
