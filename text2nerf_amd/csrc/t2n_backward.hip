@@ -211,10 +211,7 @@ static BlockGeom block_geom(const FactorSet& S) {
     g.size[0] = S.W[0]; g.size[1] = S.H[0]; g.size[2] = S.H[1];
     for (int a = 0; a < 3; ++a) g.nb[a] = (g.size[a] + kBlk) / kBlk;
     g.total = g.nb[0] * g.nb[1] * g.nb[2];
-    // privatised histogram copies (every ray starts in the camera's block): as many as keep the scan's histogram in LDS
-    int c = 32;
-    while (c > 1 && (size_t)g.total * c * 4 > 148 * 1024) c >>= 1;
-    g.copies = c;
+    g.copies = kBinCopies;   // privatised histogram copies (every ray starts in the camera's block)
     return g;
 }
 // the density pairs really share their axes (TensorVMSplit: plane k = grid[mat1] x grid[mat0], line k = grid[vec])
@@ -421,25 +418,50 @@ __device__ __forceinline__ unsigned block_scan_1024(unsigned v, unsigned* sh, un
     total = all;
     return v + before;
 }
+// (2a) the privatised copies of every bin's counter -> within-bin offsets (in place) and the bin's total. The counters lie copy-major
+// ([copy][bin]): side by side, the copies of a hot bin share one 128-byte line, and same-LINE atomics serialise at the L2 like
+// same-address ones (k_bwd_bin 122 -> 65 us, k_bwd_march 124 -> 64 us per C3 iteration when four copies moved apart; 32 copies here).
+__global__ __launch_bounds__(256) void k_bin_reduce(unsigned* __restrict__ hist, int n_bins, int copies, unsigned* __restrict__ bin_total) {
+    if (copies == 32) {   // lane = copy: 32 lanes per bin, a shuffle scan instead of a 32-step loop per thread (1 083 appearance bins are 5 workgroups of loops)
+        const int j = blockIdx.x * 8 + (threadIdx.x >> 5), c = threadIdx.x & 31;
+        const bool ok = j < n_bins;
+        const unsigned v = ok ? hist[(size_t)c * n_bins + j] : 0u;
+        unsigned incl = v;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const unsigned u = (unsigned)__shfl_up((int)incl, o, 32);
+            if (c >= o) incl += u;
+        }
+        if (ok) {
+            hist[(size_t)c * n_bins + j] = incl - v;
+            if (c == 31) bin_total[j] = incl;
+        }
+        return;
+    }
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_bins) return;
+    unsigned run = 0;
+    for (int c = 0; c < copies; ++c) {
+        const unsigned v = hist[(size_t)c * n_bins + j];
+        hist[(size_t)c * n_bins + j] = run;
+        run += v;
+    }
+    bin_total[j] = run;
+}
+// (2b) single workgroup: exclusive scan of the bin totals -> bin starts (+ sentinel) and the segment list of the accumulate pass. A record's
+// position is start[bin] + the running within-bin cursor of its copy.
 template <bool LDS>
-__global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, int copies, unsigned* tile_start, int4* segs, unsigned* nseg_out,
+__global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, unsigned* tile_start, int4* segs, unsigned* nseg_out,
                                                    unsigned seg_cap, unsigned seg_size_in, unsigned target_segs, unsigned seg_min) {
     extern __shared__ unsigned sh_hist[];
     __shared__ unsigned sh[17];
     const int t = threadIdx.x;
-    const int n = n_tiles * copies;
+    const int n = n_tiles;
     if (LDS) {
         for (int j = t; j < n; j += 1024) sh_hist[j] = hist[j];
         __syncthreads();
     }
-    // the scan runs tile-major (index i = tile * copies + copy: a tile's copies are consecutive runs of its records); the counters lie
-    // copy-major ([copy][tile]: the copies of a hot tile sit in different cache lines — side by side their atomics serialise on ONE
-    // line: k_bwd_bin 122 -> 65 us, k_bwd_march 124 -> 64 us per C3 iteration with four copies). copies is a power of two.
-    struct Hist {
-        unsigned* p; int n_tiles, mask, shift;
-        __device__ unsigned& operator[](int i) const { return p[(i & mask) * n_tiles + (i >> shift)]; }
-    };
-    const Hist H{LDS ? sh_hist : hist, n_tiles, copies - 1, 31 - __clz(copies)};
+    unsigned* H = LDS ? sh_hist : hist;
     const int per = (n + 1023) / 1024;
     const int b = t * per, e = min(n, b + per);
     unsigned sum = 0;
@@ -459,7 +481,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
     const int tb = t * pt, te = min(n_tiles, tb + pt);
     unsigned ne = 0;
     for (int j = tb; j < te; ++j) {
-        const unsigned s0 = H[j * copies], s1 = j + 1 < n_tiles ? H[(j + 1) * copies] : total;
+        const unsigned s0 = H[j], s1 = j + 1 < n_tiles ? H[j + 1] : total;
         tile_start[j] = s0;
         ne += s1 > s0 ? 1u : 0u;
     }
@@ -475,13 +497,13 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
     }
     unsigned ns = 0;
     for (int j = tb; j < te; ++j) {
-        const unsigned s0 = H[j * copies], s1 = j + 1 < n_tiles ? H[(j + 1) * copies] : total;
+        const unsigned s0 = H[j], s1 = j + 1 < n_tiles ? H[j + 1] : total;
         ns += (s1 - s0 + seg_size - 1) / seg_size;
     }
     unsigned nsegs;
     unsigned si = block_scan_1024(ns, sh, nsegs) - ns;
     for (int j = tb; j < te; ++j) {
-        const unsigned s0 = H[j * copies], s1 = j + 1 < n_tiles ? H[(j + 1) * copies] : total;
+        const unsigned s0 = H[j], s1 = j + 1 < n_tiles ? H[j + 1] : total;
         for (unsigned s = s0; s < s1; s += seg_size) {
             if (si < seg_cap) segs[si] = make_int4(j, (int)s, (int)min(s1, s + seg_size), 0);
             ++si;
@@ -489,15 +511,16 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
     }
     if (t == 0) *nseg_out = min(nsegs, seg_cap);
 }
-static void launch_bin_scan(unsigned* hist, int n_tiles, int copies, unsigned* tile_start, int4* segs, unsigned* nseg, unsigned seg_cap, unsigned seg_size,
-                            unsigned target_segs, unsigned seg_min, hipStream_t s) {
-    const size_t lds = (size_t)n_tiles * copies * 4;
+static void launch_bin_scan(unsigned* hist, int n_tiles, int copies, unsigned* bin_total, unsigned* tile_start, int4* segs, unsigned* nseg, unsigned seg_cap,
+                            unsigned seg_size, unsigned target_segs, unsigned seg_min, hipStream_t s) {
+    hipLaunchKernelGGL(k_bin_reduce, dim3((unsigned)(copies == 32 ? (n_tiles + 7) / 8 : (n_tiles + 255) / 256)), dim3(256), 0, s, hist, n_tiles, copies, bin_total);
+    const size_t lds = (size_t)n_tiles * 4;
     if (lds <= 150 * 1024) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_bin_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-        hipLaunchKernelGGL((k_bin_scan<true>), dim3(1), dim3(1024), lds, s, hist, n_tiles, copies, tile_start, segs, nseg, seg_cap, seg_size, target_segs, seg_min);
+        hipLaunchKernelGGL((k_bin_scan<true>), dim3(1), dim3(1024), lds, s, bin_total, n_tiles, tile_start, segs, nseg, seg_cap, seg_size, target_segs, seg_min);
     } else {
-        hipLaunchKernelGGL((k_bin_scan<false>), dim3(1), dim3(1024), 0, s, hist, n_tiles, copies, tile_start, segs, nseg, seg_cap, seg_size, target_segs, seg_min);
+        hipLaunchKernelGGL((k_bin_scan<false>), dim3(1), dim3(1024), 0, s, bin_total, n_tiles, tile_start, segs, nseg, seg_cap, seg_size, target_segs, seg_min);
     }
 }
 
@@ -505,7 +528,7 @@ static void launch_bin_scan(unsigned* hist, int n_tiles, int copies, unsigned* t
 struct BinArgs {
     FieldDev F; BlockGeom geom;
     const float* rays; long long n_rays; int ray_stride; int n_samples;
-    const float* jitter; const float* gfeat; const int4* ray_app; unsigned* cursor; float4* recs;
+    const float* jitter; const float* gfeat; const int4* ray_app; unsigned* cursor; const unsigned* tile_start; float4* recs;
 };
 template <bool TRAIN>
 __global__ __launch_bounds__(256) void k_bwd_bin(const BinArgs a) {
@@ -535,7 +558,7 @@ __global__ __launch_bounds__(256) void k_bwd_bin(const BinArgs a) {
         bool leader; int runlen, ll;
         run_leader(key, lane, leader, runlen, ll);
         unsigned pos = 0;
-        if (leader && key >= 0) pos = atomicAdd(&a.cursor[copy * (unsigned)a.geom.total + (unsigned)key], (unsigned)runlen);
+        if (leader && key >= 0) pos = a.tile_start[key] + atomicAdd(&a.cursor[copy * (unsigned)a.geom.total + (unsigned)key], (unsigned)runlen);
         pos = __shfl(pos, ll) + (unsigned)(lane - ll);
         if (key >= 0) a.recs[pos] = rec;
     }
@@ -783,7 +806,7 @@ __global__ __launch_bounds__(kAccThreads) void k_bwd_tile_accum(const TileAccumA
 // Row r of the activation buffers <-> list entry: tile r / 32 belongs to sub-list l (tp.t[l] <= tile < tp.t[l + 1]).
 struct AppBinArgs {
     FactorSet S; BinGeom geom; const float4* app_pos; const unsigned* counters; unsigned list_cap; TilePrefix tp; long long rows;
-    unsigned* hist; float4* recs;
+    unsigned* hist; const unsigned* tile_start; float4* recs;
 };
 template <int PASS>
 __global__ __launch_bounds__(256) void k_app_bin(const AppBinArgs a) {
@@ -816,7 +839,7 @@ __global__ __launch_bounds__(256) void k_app_bin(const AppBinArgs a) {
             if (leader && key[k] >= 0) atomicAdd(&a.hist[copy * (unsigned)a.geom.total + (unsigned)key[k]], (unsigned)runlen);
         } else {
             unsigned pos = 0;
-            if (leader && key[k] >= 0) pos = atomicAdd(&a.hist[copy * (unsigned)a.geom.total + (unsigned)key[k]], (unsigned)runlen);
+            if (leader && key[k] >= 0) pos = a.tile_start[key[k]] + atomicAdd(&a.hist[copy * (unsigned)a.geom.total + (unsigned)key[k]], (unsigned)runlen);
             pos = __shfl(pos, ll) + (unsigned)(lane - ll);
             if (key[k] >= 0) a.recs[pos] = rec;
         }
@@ -1205,7 +1228,7 @@ __global__ __launch_bounds__(256) void k_relayout_add(const RelayoutAddMulti a) 
 
 // Activation / gradient rows of the backward pass. Buffers whose lifetimes do not overlap (or that are rewritten
 // element-in-place by the same thread) share storage: g1 over h1, g0 over h0, gx over xpe, gf over feat32, gX over x144.
-struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, gpack, hist, tile_start, nseg, segs, recs, a_hist, a_tile_start, a_nseg, a_segs, a_recs, total; unsigned seg_cap, a_seg_cap; };
+struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, gpack, hist, bin_total, tile_start, nseg, segs, recs, a_hist, a_bin_total, a_tile_start, a_nseg, a_segs, a_recs, total; unsigned seg_cap, a_seg_cap; };
 // split of a [rows] x (M<=128) x N weight-gradient GEMM into row chunks: ~768 workgroups, chunk a multiple of 32 rows
 constexpr int kL2Blocks = 1024;   // workgroups of k_bwd_l2 (four per CU)
 struct TnPlan { int chunk_rows, chunks, ng, ldp; };
@@ -1251,6 +1274,7 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
     const size_t cap = (size_t)n_rays * (size_t)n_samples;
     c.seg_cap = (unsigned)(cap / kDenSeg + (size_t)n_blocks + 1);
     c.hist = o; o = al256(o + (size_t)n_blocks * 4);
+    c.bin_total = o; o = al256(o + (size_t)n_blocks * 4);
     c.tile_start = o; o = al256(o + ((size_t)n_blocks + 1) * 4);
     c.nseg = o; o = al256(o + 4);
     c.segs = o; o = al256(o + (size_t)c.seg_cap * 16);
@@ -1258,6 +1282,7 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
     // the same for the appearance samples (one record per activation row and plane)
     c.a_seg_cap = (unsigned)(3 * R / kBinSegApp + (size_t)n_tiles + 1);
     c.a_hist = o; o = al256(o + (size_t)n_tiles * kBinCopies * 4);
+    c.a_bin_total = o; o = al256(o + (size_t)n_tiles * 4);
     c.a_tile_start = o; o = al256(o + ((size_t)n_tiles + 1) * 4);
     c.a_nseg = o; o = al256(o + 4);
     c.a_segs = o; o = al256(o + (size_t)c.a_seg_cap * 16);
@@ -1564,11 +1589,11 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
                 T2N_HIP(hipStreamWaitEvent(sd, (hipEvent_t)f->ev_fork, 0));
                 side = true;
             }
-            launch_bin_scan(a.hist, bgeom.total, bgeom.copies, (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, kDenSeg,
+            launch_bin_scan(a.hist, bgeom.total, bgeom.copies, (unsigned*)(bw + b.bin_total), (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, kDenSeg,
                             0u, kDenSeg, sd);
             BinArgs ba;
             ba.F = f->dev; ba.geom = bgeom; ba.rays = rays; ba.n_rays = n_rays; ba.ray_stride = ray_stride; ba.n_samples = n_samples;
-            ba.jitter = jitter; ba.gfeat = a.gfeat; ba.ray_app = a.ray_app; ba.cursor = a.hist; ba.recs = (float4*)(bw + b.recs);
+            ba.jitter = jitter; ba.gfeat = a.gfeat; ba.ray_app = a.ray_app; ba.cursor = a.hist; ba.tile_start = (const unsigned*)(bw + b.tile_start); ba.recs = (float4*)(bw + b.recs);
             if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_bin<true>), dim3(nb), dim3(256), 0, sd, ba);
             else hipLaunchKernelGGL((k_bwd_bin<false>), dim3(nb), dim3(256), 0, sd, ba);
             DenBlockArgs da;
@@ -1660,10 +1685,10 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             // tile-binned: count -> scan -> write records -> LDS accumulate, 16 channels per workgroup
             AppBinArgs ab;
             ab.S = f->dev.app; ab.geom = bin_geom(f->dev.app); ab.app_pos = app_pos; ab.counters = counters; ab.list_cap = c.list_cap;
-            ab.tp = tp; ab.rows = rows; ab.hist = (unsigned*)(bw + b.a_hist); ab.recs = (float4*)(bw + b.a_recs);
+            ab.tp = tp; ab.rows = rows; ab.hist = (unsigned*)(bw + b.a_hist); ab.tile_start = (const unsigned*)(bw + b.a_tile_start); ab.recs = (float4*)(bw + b.a_recs);
             const unsigned nbk = (unsigned)((rows + 255) / 256);
             hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, s, ab);
-            launch_bin_scan(ab.hist, ab.geom.total, kBinCopies, (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),
+            launch_bin_scan(ab.hist, ab.geom.total, kBinCopies, (unsigned*)(bw + b.a_bin_total), (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),
                             b.a_seg_cap, 0u, kAccTargetSegsApp, 512u, s);
             hipLaunchKernelGGL((k_app_bin<1>), dim3(nbk), dim3(256), 0, s, ab);
             TileAccumArgs ta;
