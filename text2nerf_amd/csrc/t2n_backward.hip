@@ -1537,6 +1537,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     // 2. per-ray backward + density scatter
     bool side = false;   // the density scatter was put on the side stream: joined before step 6
     bool side_gemm = false;   // the weight-gradient GEMMs were put on the third stream: joined before step 6
+    bool packed_early = false;   // k_mlp_bwd_ss's operands were packed in front of k_bwd_march
     bool bin = false;
     size_t lds_bin = 0;
     {
@@ -1563,7 +1564,13 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             so.zero(a.hist, (size_t)bgeom.total * bgeom.copies * 4);
             if (rows > 0 && f->dev.app.C == 48) so.zero(bw + b.a_hist, (size_t)bin_geom(f->dev.app).total * kBinCopies * 4);
         }
+        // the fused input-gradient chain's operands are packed now, while the stream is alone on the GPU
+        static const bool unfused_env0 = getenv("T2N_BWD_UNFUSED") != nullptr;
+        const bool pack_now = rows > 0 && !generic && !simple && !gemm_fp32_mode(f) && !unfused_env0 && f->desc.app_dim == 27 && K0 == 351;
+        if (pack_now) so.zero(mlp_bwd_ss_absmax_words((void*)(bw + b.gpack)), 16);
         if ((rc = launch_setup(so, s))) return rc;
+        if (pack_now && (rc = mlp_bwd_ss_pack(f, (void*)(bw + b.gpack), s, true))) return rc;
+        packed_early = pack_now;
         timing_begin(f, T2N_K_BWD_MARCH, s);
         if (!bin) {
             if (flags & T2N_FLAG_TRAIN) hipLaunchKernelGGL((k_bwd_march<true, false>), dim3(nb), dim3(256), lds, s, a);
@@ -1623,7 +1630,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             // the chain writes g1 over h1 and g0 / gf / gX into the (otherwise unused) encoding buffer
             float* G0 = xpe; float* GF = xpe + (size_t)rows * 128; float* GX = xpe + (size_t)rows * 160;
             launch_bwd_l2((const float4*)go, (const float*)h1, rows, P->mlp_w2, nullptr, g->mlp_w2, g->mlp_b2, part, s);
-            if ((rc = launch_mlp_bwd_ss(f, gpack, (const float4*)go, h1, h0, feat32, G0, GF, GX, rows, s))) return rc;
+            if ((rc = launch_mlp_bwd_ss(f, gpack, (const float4*)go, h1, h0, feat32, G0, GF, GX, rows, s, packed_early))) return rc;
             // From here two chains share nothing but read-only rows: the weight-gradient GEMMs (g1 / G0 / GF with h0 / features / x144
             // -> the MLP gradients, through `part`) and the appearance scatter (GX -> the factor gradient buffers). The GEMMs wait on
             // memory latency and workgroup barriers, the scatter on LDS atomics: they run side by side, the GEMMs on a third stream

@@ -211,7 +211,9 @@ int launch_gemm_tn_b(const float* A, int lda, const float* B, int ldb, long long
 // fused input-gradient chain of the MLP_Fea_noview head's backward (t2n_mlp_bwd_ss.hip)
 size_t mlp_bwd_ss_pack_bytes();
 int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, const float* h0, const float* feat, float* g0, float* gf,
-                      float* gx, long long rows, hipStream_t s);
+                      float* gx, long long rows, hipStream_t s, bool packed = false);
+int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed);
+void* mlp_bwd_ss_absmax_words(void* packbuf);
 // forward-workspace carve shared by forward and backward (t2n_api.hip)
 struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, feat, total; unsigned list_cap, feat_rows; };
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat = true, unsigned budget = 0);   // budget: appearance entries per ray (0: worst case)   // ctx: also room for sigma [rays,N] and rgb_raw [rays]; feat: feature rows (last region: the other offsets do not depend on it; KEEP_CTX calls carve without)

@@ -448,8 +448,15 @@ size_t mlp_bwd_ss_pack_bytes() {
 }
 // the fused chain for the MLP_Fea_noview head (app_dim 27, 351 encoded inputs): packs the transposed weights (once per backward), then
 // g1 -> h1 (in place), g0, gf, gx for `rows` (a multiple of 32) appearance rows
-int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, const float* h0, const float* feat, float* g0, float* gf,
-                      float* gx, long long rows, hipStream_t s) {
+// the four absmax words of the pack buffer (the caller may zero them with its own setup kernel: mlp_bwd_ss_pack(..., zeroed = true))
+void* mlp_bwd_ss_absmax_words(void* packbuf) {
+    using namespace bss;
+    return (void*)((uint4*)packbuf + kA2 + kA1 + kA0 + kAb);
+}
+// The transposed split-f16 operands of the chain from the CURRENT weights: two small launches that depend on nothing but the parameters —
+// the backward runs them before it forks its side streams (queued behind the density scatter's workgroups, the 6-us pack kernel sat
+// 50 us on the critical path in front of k_mlp_bwd_ss).
+int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed) {
     using namespace bss;
     const t2n_field_params& p = f->params_ref;
     uint4* base = (uint4*)packbuf;
@@ -458,12 +465,24 @@ int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, 
     pa.a2 = base; pa.a1 = base + kA2; pa.a0 = base + kA2 + kA1; pa.ab = base + kA2 + kA1 + kA0;
     unsigned* am = (unsigned*)(base + kA2 + kA1 + kA0 + kAb);
     pa.absmax = am; pa.scales = (float*)(am + 4);
-    T2N_HIP(hipMemsetAsync(am, 0, 16, s));
+    if (!zeroed) T2N_HIP(hipMemsetAsync(am, 0, 16, s));
     AbsMaxArgs m;
     m.p[0] = p.mlp_w2; m.n[0] = 3 * 128; m.p[1] = p.mlp_w1; m.n[1] = 128 * 128; m.p[2] = p.mlp_w0; m.n[2] = 128 * 351; m.p[3] = p.basis_weight; m.n[3] = 27 * 144;
     m.out = am;
     hipLaunchKernelGGL(k_bss_absmax, dim3(16, 4), dim3(256), 0, s, m);
     hipLaunchKernelGGL(k_pack_bwd_ss, dim3(64), dim3(256), 0, s, pa);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, const float* h0, const float* feat, float* g0, float* gf,
+                      float* gx, long long rows, hipStream_t s, bool packed) {
+    using namespace bss;
+    if (!packed) { const int rc = mlp_bwd_ss_pack(f, packbuf, s, false); if (rc) return rc; }
+    uint4* base = (uint4*)packbuf;
+    PackArgs pa;
+    pa.a2 = base; pa.a1 = base + kA2; pa.a0 = base + kA2 + kA1; pa.ab = base + kA2 + kA1 + kA0;
+    pa.scales = (float*)((unsigned*)(base + kA2 + kA1 + kA0 + kAb) + 4);
     static bool attr_set = false;
     if (!attr_set) {
         T2N_HIP(hipFuncSetAttribute((const void*)k_mlp_bwd_ss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
