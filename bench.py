@@ -243,7 +243,8 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
     if dist is None and trace is None:
         # the loop's host side runs under a cgroup CPU quota: one throttled 100-ms period inside a 25-50 ms timed block doubles it.
         # One more block of the same length and the faster of the two is reported (both on stderr). Not more: the noisy targets turn the
-        # field into fog after ~45 steps (twice the appearance samples, 2.1 ms per fused step), which is another workload
+        # field into fog after ~45 steps (114 000 appearance samples until step 40, 311 000 at 50, 674 000 at 60: 2.1 ms per fused step;
+        # tools/experiments/train_sample_growth.py), which is another workload
         blocks = [dt]
         t0 = time.perf_counter()
         for k in range(iters):
