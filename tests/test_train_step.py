@@ -83,8 +83,13 @@ def step_autograd(f, opt, rays, rgb_t, dep_t, chunk=None):
     return torch.stack([mse, dl, tl, tot]).detach()
 
 
-def test_train_step_equals_the_autograd_step(tiny_params):
+@pytest.mark.parametrize("seeded", [True, False])
+def test_train_step_equals_the_autograd_step(tiny_params, seeded, monkeypatch):
+    """`seeded`: the TV terms written into the gradient buffer on a side stream in front of the backward (t2n_field_tv_seed; what train_step
+    does for batches of 8 192 rays and more, forced here for the small test batch) against the TV pass inside the optimiser step."""
+    from text2nerf_amd import tensorf as tf
     from text2nerf_amd.optim import TVAdam
+    monkeypatch.setattr(tf, "_SEED_MIN_RAYS", 0 if seeded else 1 << 30)
     rays, rgb_t, dep_t = batch()
     fa = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
     fb = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])

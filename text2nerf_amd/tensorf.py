@@ -26,6 +26,9 @@ from ._lib import FLAG_ADD_BG, FLAG_COHERENT, FLAG_KEEP_CTX, FLAG_NDC, FLAG_TRAI
 MAT_MODE = [[0, 1], [0, 2], [1, 2]]
 VEC_MODE = [2, 1, 0]
 
+# train_step seeds the TV terms on a side stream (two more library calls and two stream hand-overs per step) only for batches whose step is
+# GPU-bound; below, the TV pass stays inside the optimiser step
+_SEED_MIN_RAYS = int(os.environ.get("T2N_SEED_MIN_RAYS", "8192"))
 _WORKSPACE = {}
 
 
@@ -1143,7 +1146,7 @@ class TensorVMSplit(nn.Module):
         # TV terms: the gradient buffer starts as the TV gradient (one write-only pass on a side stream beside the forward) instead of
         # being zero-filled, accumulated into and TV-incremented after the backward
         seed_ev = seed_terms = None
-        if tv and getattr(optimizer, "field", None) is self and getattr(self, "defer_factor_grads", False) \
+        if tv and R >= _SEED_MIN_RAYS and getattr(optimizer, "field", None) is self and getattr(self, "defer_factor_grads", False) \
                 and self.supports_deferred_factor_grads():
             seed_ev = self.seed_factor_grads_with_tv(tv)
             seed_terms, tv = list(tv), ()
