@@ -14,6 +14,8 @@
 // (grid-stride). A lane loads its half of the row once (K <= 128: 64 values), finds the row's scale with its partner lane, converts
 // to packed hi / lo halves in registers, and the K loop is LDS reads + MFMAs only. The fp32 form of this GEMM (k_gemm_nn,
 // v_mfma_f32_32x32x2_f32) ran at 40-50 % of the fp32 matrix peak: 236 us per C3 iteration for the three calls.
+#include <type_traits>
+
 #include "t2n_device.h"
 
 namespace t2n {
@@ -229,14 +231,18 @@ __global__ __launch_bounds__(256) void k_gemm_tn_b(const float* __restrict__ A, 
     } else {
         bok = bcol < ldb && bcol < N + 3;                  // columns N .. ldb are padding the caller ignores
     }
-    const float* __restrict__ Ab = A + (loads_a ? 32 * w + i : 0);
-    const float* __restrict__ Bb = B + (PE ? pf : (bok ? bcol : 0));
+    const float* __restrict__ Ab = A + (loads_a ? 32 * w + i : 0) + r0 * lda;
+    const float* __restrict__ Bb = B + (PE ? pf : (bok ? bcol : 0)) + r0 * ldb;
+    // rows are addressed chunk-relative with 32-bit offsets, and only a chunk's LAST step can be partial: the full steps run without the
+    // per-element row clamps and masks (64-bit compares and selects on 16 elements were a third of the kernel's VALU instructions, and the
+    // kernel is VALU-bound: 346 instructions per 16-row step against 24 MFMAs)
+    const int nrows = (int)(r1 - r0);
     float xa[8], xb[8];
-    auto fetch = [&](long long kt) {
+    auto fetch = [&](int kt, auto masked) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            long long r = kt + 8 * kh + e;
-            r = r < r1 ? r : r1 - 1;                       // clamped address, masked below: no per-load branches
+            int r = kt + 8 * kh + e;
+            if constexpr (decltype(masked)::value) r = r < nrows ? r : nrows - 1;   // clamped address, masked at the conversion
             xa[e] = Ab[r * lda];
             xb[e] = Bb[r * ldb];
         }
@@ -245,13 +251,13 @@ __global__ __launch_bounds__(256) void k_gemm_tn_b(const float* __restrict__ A, 
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[m] = f32x16{0};
     float bs = 0.f;
-    if (r0 < r1) fetch(r0);
     int buf = 0;
-    for (long long kt = r0; kt < r1; kt += 16, buf ^= 1) {
+    auto step = [&](int kt, auto masked) {
         float a8[8], b8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const bool ok = kt + 8 * kh + e < r1;
+            bool ok = true;
+            if constexpr (decltype(masked)::value) ok = kt + 8 * kh + e < nrows;
             a8[e] = ok ? xa[e] : 0.f;
             float v = xb[e];
             if constexpr (PE) {
@@ -265,7 +271,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn_b(const float* __restrict__ A, 
             }
             b8[e] = (ok && bok) ? v : 0.f;
         }
-        if (kt + 16 < r1) fetch(kt + 16);                  // the next step's rows in flight under this step's conversion and MFMAs
+        // the next step's rows in flight under this step's conversion and MFMAs (the one after the last full step may be the partial one)
+        if (kt + 32 <= nrows) fetch(kt + 16, std::false_type{});
+        else if (kt + 16 < nrows) fetch(kt + 16, std::true_type{});
         if (loads_a) {
             bs += ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
             const Op3 oa = split_unit(a8);
@@ -283,7 +291,13 @@ __global__ __launch_bounds__(256) void k_gemm_tn_b(const float* __restrict__ A, 
             acc[m] = mfma_b(al, ob.h, acc[m]);
             acc[m] = mfma_b(am, ob.m, acc[m]);
         }
-    }
+        buf ^= 1;
+    };
+    if (nrows >= 16) fetch(0, std::false_type{});
+    else if (nrows > 0) fetch(0, std::true_type{});
+    int kt = 0;
+    for (; kt + 16 <= nrows; kt += 16) step(kt, std::false_type{});
+    if (kt < nrows) step(kt, std::true_type{});
     float* __restrict__ P = part + (size_t)blockIdx.y * (MB * 32) * ldp + ng * 128 + w * 32 + i;
 #pragma unroll
     for (int m = 0; m < MB; ++m)
