@@ -39,4 +39,4 @@ print("host loop %.3f ms/iter, with drain %.3f ms/iter (torch fused Adam: %s)" %
 pr = cProfile.Profile(); pr.enable()
 for k in range(20): it(30 + k)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumtime").print_stats(45)
+pstats.Stats(pr).sort_stats("tottime").print_stats(40)
