@@ -148,6 +148,15 @@ int t2n_field_set_mlp_precision(t2n_field* f, int exact_fp32);
 int t2n_field_set_alpha_mask(t2n_field* f, const float* volume, int D, int H, int W, const float* aabb_min_host,
                              const float* inv_size_host, t2n_stream stream);
 int t2n_alpha_at(const t2n_field* f, const float* xyz_world, int64_t n, float* alpha, t2n_stream stream);
+/* Early ray termination for EVAL launches that materialise neither weights nor z_vals (and keep no backward context): once a ray's
+ * transmittance T fell below eps it evaluates no further sample — per 8x8-pixel tile in the tile marcher (the wave leaves its step
+ * loop when all 64 rays are done), per 64-sample block in the per-ray marcher. The reference has no such mode: it evaluates every
+ * in-box sample whatever T is (models/tensorBase.py:19-26 raw2alpha, :494-505 compositing), so this is a bounded deviation, not
+ * parity: what the skipped samples could add is < eps to acc, < eps to each colour channel, < eps * (z_max - d_z) to depth; the
+ * evaluated-sample count (T2N_STAT_EVALUATED) becomes a lower bound of the reference's. eps in [0, weight_thres]; 0 (default of a new
+ * handle) = off = the reference's arithmetic sample for sample. Train launches, launches with weights / z_vals outputs and
+ * T2N_FLAG_KEEP_CTX launches ignore it. */
+int t2n_field_set_early_termination(t2n_field* f, float eps);
 /* Image width of the row-major frames passed with T2N_FLAG_COHERENT (0 = unknown: the flag is ignored). */
 int t2n_field_set_frame_width(t2n_field* f, int width);
 
@@ -161,6 +170,14 @@ int t2n_get_rays(const float* dirs /*[n,3]*/, int64_t n, const float* c2w_host /
 /* fused: pixel -> [H*W,6] ray rows (ox,oy,oz,dx,dy,dz), SceneGen recipe (scene_gen.py:44-45,92-94) */
 int t2n_generate_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_host, float* rays6,
                       t2n_stream stream);
+
+/* ---- a-5 as a stage of its own: TensorBase.sample_ray (models/tensorBase.py:304-323; ndc = 0) and sample_ray_ndc (:293-302; ndc = 1).
+ * rays_o / rays_d [n,3] -> pts [n,N,3] = o + d z, valid [n,N] = 1 inside the box (the complement of mask_outbbox; no z gate: forward
+ * applies that one itself, :459-462). ndc = 0: z_i = t_min + step (i [+ jitter[ray]]) goes to z_vals [n,N]; jitter = the per-ray
+ * U[0,1) draws of train mode or NULL. ndc = 1: `jitter` is the caller's table of the N depths shared by all rays (linspace(near, far, N)
+ * [+ its jitter row]); z_vals is not written (the reference returns the [1,N] table itself). */
+int t2n_sample_ray(const t2n_field* f, const float* rays_o, const float* rays_d, int64_t n, int n_samples, const float* jitter, int ndc,
+                   float* pts /*[n,N,3]*/, float* z_vals /*[n,N] or NULL*/, uint8_t* valid /*[n,N]*/, t2n_stream stream);
 
 /* ---- a-16: TensorBase.filtering_rays(bbox_only=True) slab test (models/tensorBase.py:385-391) */
 int t2n_filter_rays_bbox(const t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, uint8_t* mask,

@@ -1,0 +1,91 @@
+"""Early ray termination (SURVEY.md 7 hard parts): an eval-only mode of both marchers. The reference never
+terminates (models/tensorBase.py:19-26 raw2alpha, :494-505 compositing evaluate every in-box sample), so these tests bound the
+deviation against the oracle instead of asking for parity: acc / colour < eps, depth < eps * z range, evaluated samples <= the
+reference's; and they check that the mode is OFF wherever the reference's per-sample outputs are handed out (weights, z_vals,
+training)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from text2nerf_amd import synth
+from tests.conftest import TINY
+from tests.test_hip_parity import DEPTH_ATOL, RGB_ATOL, dev, make_field
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(params, rays_np, n_samples):
+    from oracle import oracle_torch as O
+    from oracle.oracle_c import COracle
+    co = COracle(O.FieldConfig(aabb=TINY["aabb"], grid_size=TINY["grid"], near_far=TINY["near_far"]), params)
+    rgb, depth, _, _ = co.render(rays_np, n_samples=n_samples, want_weights=False)
+    return rgb, depth, co.last_stats
+
+
+@pytest.mark.parametrize("frame_width", [0, 48])      # per-ray marcher (64-sample blocks) / 8x8-tile marcher
+@pytest.mark.parametrize("density_scale", [0.9, 3.0])  # the tiny goldens' field / an opaque one (most rays die within a few steps)
+def test_termination_bounds_vs_oracle(frame_width, density_scale):
+    params = synth.make_field_params(11, TINY["grid"], density_scale=density_scale, aabb=TINY["aabb"])
+    f = make_field(params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    f.materialize_weights = False
+    f.frame_width = frame_width
+    rays_np = synth.frame_rays_np(40, 48, c2w=synth.look_pose(0.2, -0.1, (0.3, 0.2, -1.5)))
+    rays = torch.from_numpy(rays_np).to(dev())
+    o_rgb, o_depth, o_stats = _oracle(params, rays_np, f.nSamples)
+    with torch.no_grad():
+        rgb0, depth0, _, _ = f(rays)
+    ev0 = f.stats()["evaluated"]
+    assert ev0 == o_stats["evaluated"]                      # off (make_field): sample for sample
+    f.early_termination = 1e-6
+    with torch.no_grad():
+        rgb1, depth1, _, _ = f(rays)
+    ev1 = f.stats()["evaluated"]
+    assert ev1 <= ev0
+    if density_scale > 1.0:
+        assert ev1 < 0.8 * ev0, (ev1, ev0)                   # an opaque field: most of the window behind the surface is skipped
+    # against the oracle at the parity tolerances, and against the un-terminated render at the mode's own bound
+    assert np.abs(rgb1.cpu().numpy() - o_rgb).max() <= RGB_ATOL
+    assert np.abs(depth1.cpu().numpy() - o_depth).max() <= DEPTH_ATOL
+    assert float((rgb1 - rgb0).abs().max()) <= 2e-6
+    zmax = TINY["near_far"][0] + float(f.stepSize) * f.nSamples
+    assert float((depth1 - depth0).abs().max()) <= 1e-6 * zmax + 1e-6
+    print(f"frame_width {frame_width}, density x{density_scale}: evaluated {ev1} of {ev0}, max colour change "
+          f"{float((rgb1 - rgb0).abs().max()):.1e}, max depth change {float((depth1 - depth0).abs().max()):.1e}")
+
+
+def test_termination_is_off_where_weights_are_returned(tiny_params):
+    """OctreeRender_trilinear_fast hands the reference's weights / z_vals rows to its caller (renderer.py:28-42) and training needs
+    every sample: neither is terminated, whatever the field's setting."""
+    from text2nerf_amd import OctreeRender_trilinear_fast
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    rays = torch.from_numpy(synth.frame_rays_np(16, 24))
+    with torch.no_grad():
+        ref = OctreeRender_trilinear_fast(rays, f, chunk=4096, N_samples=-1, white_bg=True, is_train=False, device=dev())
+    ev0 = f.stats()["evaluated"]
+    f.early_termination = 1e-4
+    with torch.no_grad():
+        got = OctreeRender_trilinear_fast(rays, f, chunk=4096, N_samples=-1, white_bg=True, is_train=False, device=dev())
+    assert f.stats()["evaluated"] == ev0
+    for a, b in zip(ref, got):
+        if a is not None:
+            assert torch.equal(a, b)
+    torch.manual_seed(5)
+    out0 = f(rays.to(dev()), is_train=True, N_samples=40)
+    f.early_termination = 0.0
+    torch.manual_seed(5)
+    out1 = f(rays.to(dev()), is_train=True, N_samples=40)
+    assert torch.equal(out0[0], out1[0]) and torch.equal(out0[3], out1[3])
+
+
+def test_termination_threshold_is_bounded_by_the_appearance_threshold(tiny_params):
+    """Above rayMarch_weight_thres a skipped sample could have been an appearance-list entry: rejected."""
+    from text2nerf_amd import _lib
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    lib = _lib.load()
+    h = f.sync_params()
+    assert lib.t2n_field_set_early_termination(h, C.c_float(1e-3)) != 0
+    assert lib.t2n_field_set_early_termination(h, C.c_float(-1.0)) != 0
+    assert lib.t2n_field_set_early_termination(h, C.c_float(1e-4)) == 0
+    assert lib.t2n_field_set_early_termination(h, C.c_float(0.0)) == 0

@@ -77,3 +77,28 @@ def test_frames_in_flight_render_the_same_pictures(tiny_params):
     a_rgb, a_dep = render_views(big, p5, i8, 800, 800, frames_in_flight=1)
     b_rgb, b_dep = render_views(big, p5, i8, 800, 800, frames_in_flight=2)
     assert torch.equal(a_rgb, b_rgb) and torch.equal(a_dep, b_dep)
+
+
+def test_parameter_upload_is_ordered_across_the_pipe_streams(tiny_params):
+    """the lazy device upload (relayout + pack kernels on the caller's stream) of a field whose parameters just changed —
+    the state evaluation() finds after training steps — must be complete before a view on ANOTHER stream reads the copies. Small frames
+    (no host-side wait anywhere in the call), fresh parameters before every trajectory, pipelined against serial, repeated."""
+    from text2nerf_amd import render_views, release_workspaces, workspace_reserved
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    poses = [synth.look_pose(0.15 * v - 0.3, 0.05, (0.1, 0.0, -1.2)) for v in range(4)]
+    intr = [64.0, 64.0, 32, 32]
+    g = torch.Generator().manual_seed(3)
+    for trial in range(6):
+        with torch.no_grad():      # an "optimiser step": every tensor changes in place (versions bump, the device copies are stale)
+            for p in f.parameters():
+                p.add_(0.01 * torch.randn(p.shape, generator=g).to(p.device))
+        a_rgb, a_dep = render_views(f, poses, intr, 64, 64, frames_in_flight=2)
+        torch.cuda.synchronize()
+        b_rgb, b_dep = render_views(f, poses, intr, 64, 64, frames_in_flight=1)
+        assert torch.equal(a_rgb, b_rgb) and torch.equal(a_dep, b_dep), f"trial {trial}: pipelined views differ from serial ones"
+    # the pipes of repeated calls share their side streams: the scratch held for the device does not grow call by call
+    held = workspace_reserved(dev())
+    for _ in range(5):
+        render_views(f, poses, intr, 64, 64, frames_in_flight=2)
+    assert workspace_reserved(dev()) == held
+    assert release_workspaces(dev(), keep_current=False) == held and workspace_reserved(dev()) == 0

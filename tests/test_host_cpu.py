@@ -381,3 +381,49 @@ def test_evaluation_and_evaluation_path_drop_in(tmp_path, monkeypatch):
     assert sorted(os.listdir(tmp_path / "path")) == ["p_000.png", "p_001.png", "rgbd"]
     rgbd = np.asarray(Image.open(tmp_path / "path" / "rgbd" / "p_001.png"))
     assert rgbd.shape == (H, 2 * W, 3) and np.array_equal(rgbd[:, :W], want)
+
+
+def test_signatures_match_the_reference():
+    """Every callable of the reference's hot-path surface (tests/golden/signatures.json <- make_golden_signatures.py, which imports the
+    reference) exists in the mirror under the same name with the same parameters — names, order, kinds, defaults. The mirror may ADD
+    trailing keyword parameters with defaults (device=, normalize=, frame_width=, ...): a call written for the reference binds the same."""
+    import inspect
+    import json
+    import text2nerf_amd as T
+    from text2nerf_amd import ray_utils, renderer, sh, tensorf
+    from tests.conftest import GOLDEN
+    want = json.load(open(os.path.join(GOLDEN, "signatures.json")))
+    bases = want.pop("_bases")
+    mods = {"renderer": renderer, "tensorBase": tensorf, "sh": sh, "ray_utils": ray_utils}
+    # what the mirror deliberately differs in, each with its reason
+    allowed = {
+        # list-valued defaults print differently but are equal; checked by value below
+    }
+    problems = []
+    for key, params in sorted(want.items()):
+        owner, name = key.split(".")
+        obj = getattr(mods[owner], name, None) if owner in mods else getattr(getattr(T, owner, None), name, None)
+        if obj is None:
+            problems.append(f"{key}: missing")
+            continue
+        got = [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+               for p in inspect.signature(obj).parameters.values()]
+        for i, w in enumerate(params):
+            if i >= len(got):
+                problems.append(f"{key}: parameter {w[0]!r} missing")
+                break
+            g = got[i]
+            same_default = g[2] == w[2] or (g[2] is not None and w[2] is not None and eval(g[2]) == eval(w[2]))   # (2, 6) vs [2, 6] etc. aside
+            if g[0] != w[0] or g[1] != w[1] or not same_default:
+                if key not in allowed:
+                    problems.append(f"{key}: parameter {i} is {g}, the reference has {w}")
+        for g in got[len(params):]:
+            if g[2] is None and g[1] not in ("VAR_POSITIONAL", "VAR_KEYWORD"):
+                problems.append(f"{key}: extra parameter {g[0]!r} without a default")
+    for cname, bs in bases.items():
+        cls = getattr(T, cname, None) or getattr(renderer, cname)
+        have = [b.__name__ for b in cls.__mro__[1:-1]]
+        for b in bs:
+            if b not in have:
+                problems.append(f"{cname}: the reference derives from {b}, the mirror's bases are {have}")
+    assert not problems, "\n".join(problems)

@@ -71,7 +71,7 @@ def test_embedding_is_exact_on_the_oracle(tiny, gs, tag):
     emb = m._embedded_params()
     kd, ka, kdim, kpe, kfc = m._kernel_shape()
     assert all(t.shape[1] == kd for t in emb[:6]) and all(t.shape[1] == ka for t in emb[6:12]) and emb[12].shape == (kdim, 3 * ka)
-    if m.renderModule is not None:
+    if isinstance(m.renderModule, torch.nn.Module):
         assert emb[13].shape[0] == kfc and emb[15].shape == (kfc, kfc) and emb[17].shape == (3, kfc)
     P = {k: t for k, t in zip(KEYS, emb)}
     rays = torch.from_numpy(tiny["tiny_rays"])

@@ -53,6 +53,9 @@ SIGNATURES = {
     "t2n_field_upload": (C.c_int, [C.c_void_p, C.POINTER(FieldParams), C.c_void_p]),
     "t2n_field_set_desc": (C.c_int, [C.c_void_p, C.POINTER(FieldDesc)]),
     "t2n_field_set_mlp_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "t2n_field_set_early_termination": (C.c_int, [C.c_void_p, C.c_float]),
+    "t2n_sample_ray": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
     "t2n_field_set_frame_width": (C.c_int, [C.c_void_p, C.c_int]),
     "t2n_field_set_alpha_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                            C.POINTER(C.c_float), C.c_void_p]),

@@ -165,6 +165,7 @@ static int apply_desc(t2n_field* f, const t2n_field_desc* d) {
     D.den.C = d->density_n_comp; D.app.C = d->app_n_comp;
     D.shift = d->density_shift; D.dscale = d->distance_scale; D.thres = d->weight_thres; D.step = d->step_size;
     D.near = d->near; D.far = d->far; D.zgate = d->z_gate; D.act = d->act; D.shading = d->shading; D.app_dim = d->app_dim;
+    D.term_eps = 0.f;   // the marchers' launchers set it per launch (eval, no weights / z_vals / context)
     return T2N_OK;
 }
 
@@ -447,6 +448,7 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->buf_mlp) (void)hipFree(f->buf_mlp);
     if (f->buf_mlp_h) (void)hipFree(f->buf_mlp_h);
     if (f->buf_ss) (void)hipFree(f->buf_ss);
+    if (f->ss_event) (void)hipEventDestroy((hipEvent_t)f->ss_event);
     if (f->host_counts) (void)hipHostFree(f->host_counts);
     if (f->ev_counts) (void)hipEventDestroy((hipEvent_t)f->ev_counts);
     if (f->ev_fork) (void)hipEventDestroy((hipEvent_t)f->ev_fork);
@@ -829,6 +831,15 @@ extern "C" int t2n_field_set_factor_storage(t2n_field* f, int bf16) {
         for (int k = 0; k < 3; ++k) {
             f->dev.den.plane_h[k] = f->dev.den.line_h[k] = f->dev.app.plane_h[k] = f->dev.app.line_h[k] = nullptr;
         }
+    return T2N_OK;
+}
+
+extern "C" int t2n_field_set_early_termination(t2n_field* f, float eps) {
+    if (!f || !(eps >= 0.f) || eps > f->desc.weight_thres) {   // above the appearance threshold a skipped sample could have been a list entry
+        set_error("t2n_field_set_early_termination: eps must lie in [0, weight_thres]");
+        return T2N_ERR_INVALID;
+    }
+    f->term_eps = eps;
     return T2N_OK;
 }
 

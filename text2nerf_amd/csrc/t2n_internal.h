@@ -48,6 +48,10 @@ struct FieldDev {
     // NDC sampling (T2N_FLAG_NDC, models/tensorBase.py:293-302,441-446): per-call table of the n_samples depths shared by all
     // rays; NULL on the regular path (z_i = t_min + step * (i [+ u]))
     const float* ztab;
+    // early ray termination (eval launches that materialise neither weights nor z_vals nor a backward context; 0 = off): a ray whose
+    // transmittance fell below term_eps evaluates no further sample. The reference never terminates (models/tensorBase.py:19-26,
+    // 494-505: every in-box sample is evaluated); what the rest of a ray could add is bounded by T: acc < eps, rgb < eps, depth < eps z_max.
+    float term_eps;
 };
 
 constexpr int kTimingEvents = 1024;   // timed launches per kernel between two reads; launches beyond are counted and priced at the timed average
@@ -80,6 +84,7 @@ struct t2n_field {
     const unsigned* split_unsafe = nullptr;   // device word (in buf_mlp_h): a weight x 2^8 left the f16 range at the last upload
     void* buf_ss = nullptr;    // sample-stationary head operands (t2n_mlp_ss.hip), packed lazily from params_ref
     bool ss_dirty = true;
+    void* ss_event = nullptr; void* ss_stream = nullptr;   // the pack's stream + an event behind it: a render on ANOTHER stream waits for it
     float* buf_alpha = nullptr; // alpha-mask volume copy
     int mlp_split = 1;         // 1: f16 two-way split products (default), 0: exact fp32 MFMA
     // channel-last gradient accumulators (backward), allocated on first use
@@ -93,6 +98,7 @@ struct t2n_field {
     bool uploaded = false;
     int timing = 0;
     int frame_w = 0;           // image width hint for the tile marcher (0: unknown)
+    float term_eps = 0.f;      // early ray termination threshold of eval launches (t2n_field_set_early_termination; 0 = off)
     t2n::TimingSlot slots[T2N_K_COUNT];
     // optimistic (budgeted) render launches: the counters travel to pinned host memory behind the march kernels; the entries a
     // ray needed last time size the next call's lists (t2n_render_workspace_bytes_hint)

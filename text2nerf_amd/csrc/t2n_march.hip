@@ -119,21 +119,29 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
     const int Lw = last - first + 1;   // window length (<= 0: empty ray)
 
     unsigned nmask = 0;   // in-interval samples rejected by the alpha mask
+    int Le = Lw;          // evaluated part of the window (shorter than Lw after an early termination)
     if (Lw > 0) {
+      // early termination (t2n_field_set_early_termination; eval without weights / context only): passes B and C alternate over
+      // 64-sample blocks and the ray stops behind the block that took its transmittance below term_eps
+      const bool et = !TRAIN && F.term_eps > 0.f;
+      const int blk = et ? 64 : Lw;
+      float carry = 1.f;
+      for (int b0 = 0; b0 < Lw; b0 += blk) {
+        const int b1 = min(Lw, b0 + blk);
         // ---- pass B: density -------------------------------------------------------------------------------------
         const int q = lane & (LPS - 1);
         const int sl = lane / LPS;
-        for (int base = 0; base < Lw; base += SPW) {
+        for (int base = b0; base < b1; base += SPW) {
             const int j = base + sl;
             const int i = first + j;
             float xn = 0.f, yn = 0.f, zn = 0.f;
             bool ok = false;
-            if (j < Lw) {
+            if (j < b1) {
                 const float z = sample_z<TRAIN>(F, ray, i, u);
                 ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
                 if (F.alpha && ok) ok = alpha_pass(F, ray, z);      // models/tensorBase.py:451-456
             }
-            if (F.alpha) nmask += (unsigned)__popcll(__ballot((j < Lw) & !ok & (q == 0)));
+            if (F.alpha) nmask += (unsigned)__popcll(__ballot((j < b1) & !ok & (q == 0)));
             float part = 0.f;
             if (ok) {
                 QuadTaps t0, t1, t2;
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
                 part = fmaf(p.x, l.x, part); part = fmaf(p.y, l.y, part); part = fmaf(p.z, l.z, part); part = fmaf(p.w, l.w, part);
             }
             const float feat = group_sum<LPS>(part);
-            if (q == 0 && j < Lw) {
+            if (q == 0 && j < b1) {
                 const float sg = ok ? feature2density(F, feat) : 0.f;
                 sig[j] = sg;
                 if (a.sigma_ctx) a.sigma_ctx[r * N + i] = sg;
@@ -161,12 +169,11 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
         __builtin_amdgcn_wave_barrier();
 
         // ---- pass C: alpha, transmittance scan, weights ------------------------------------------------------------
-        float carry = 1.f;
-        for (int base = 0; base < Lw; base += 64) {
+        for (int base = b0; base < b1; base += 64) {
             const int j = base + lane;
             const int i = first + j;
             float sg = 0.f, z = 0.f, dist = 0.f;
-            if (j < Lw) {
+            if (j < b1) {
                 sg = sig[j];
                 z = sample_z<TRAIN>(F, ray, i, u);
                 if (i < N - 1) dist = sample_z<TRAIN>(F, ray, i + 1, u) - z;   // :448, last sample gets 0
@@ -181,13 +188,15 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
             const float T = carry * excl;
             const float w = alpha * T;
             carry = carry * __shfl(incl, 63);
-            if (j < Lw) {
+            if (j < b1) {
                 wts[j] = w;
                 acc += w;
                 dep = fmaf(w, z, dep);
             }
-            napp += (unsigned)__popcll(__ballot((j < Lw) & (w > F.thres)));
+            napp += (unsigned)__popcll(__ballot((j < b1) & (w > F.thres)));
         }
+        if (et && carry < F.term_eps) { Le = b1; break; }
+      }
         acc = wave_sum(acc);
         dep = wave_sum(dep);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
         if (napp) slot0 = atomicAdd(&a.counters[list * kCounterStride], napp);
         const bool fits = slot0 + napp <= a.list_cap;
         slot0 += list * a.list_cap;
-        a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, (int)(nvalid - nmask), Lw > 0 ? (first | (Lw << 11)) : 0);
+        a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, (int)((Le < Lw ? (unsigned)Le : nvalid) - nmask), Le > 0 ? (first | (Le << 11)) : 0);
         a.acc[r] = acc;
         a.depth[r] = dep + (1.f - acc) * ray.last;   // :504-505
         if (!fits && a.stats) a.stats[T2N_STAT_OVERFLOW] = 1ull;   // cannot happen: list_cap is the worst case on this path
@@ -223,10 +232,10 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
     // ---- pass D: appearance list -------------------------------------------------------------------------------------
     if (napp) {
         unsigned run = 0;
-        for (int base = 0; base < Lw; base += 64) {
+        for (int base = 0; base < Le; base += 64) {
             const int j = base + lane;
-            const float w = j < Lw ? wts[j] : 0.f;
-            const bool m = (j < Lw) & (w > F.thres);
+            const float w = j < Le ? wts[j] : 0.f;
+            const bool m = (j < Le) & (w > F.thres);
             const unsigned long long bal = __ballot(m);
             if (m) {
                 const unsigned pre = (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
@@ -405,6 +414,7 @@ int launch_march(t2n_field* f, const RenderLaunch& L, hipStream_t s) {
     a.nblocks = (unsigned)((L.n_rays + 3) / 4);
     const size_t lds = (size_t)4 * 2 * a.npad * sizeof(float);
     const bool train = (L.flags & T2N_FLAG_TRAIN) != 0;
+    a.F.term_eps = (!train && !L.weights && !L.z_vals && !L.sigma_ctx) ? f->term_eps : 0.f;
     timing_begin(f, T2N_K_MARCH, s);
     const bool half = f->factor_bf16 && f->dev.den.plane_h[0];
     if (train) {
@@ -447,9 +457,46 @@ int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s, int img
     return T2N_OK;
 }
 
+// TensorBase.sample_ray / sample_ray_ndc as a stage of their own (models/tensorBase.py:293-323): one thread per (ray, sample)
+__global__ __launch_bounds__(256) void k_sample_ray(FieldDev F, const float* __restrict__ ro, const float* __restrict__ rd, long long n, int N,
+                                                    const float* __restrict__ u, float* __restrict__ pts, float* __restrict__ zs,
+                                                    unsigned char* __restrict__ valid) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * N) return;
+    const long long r = t / N;
+    const int i = (int)(t - r * N);
+    Ray ray;
+    ray.ox = ro[r * 3]; ray.oy = ro[r * 3 + 1]; ray.oz = ro[r * 3 + 2];
+    ray.dx = rd[r * 3]; ray.dy = rd[r * 3 + 1]; ray.dz = rd[r * 3 + 2];
+    ray.tmin = F.ztab ? 0.f : ray_tmin(F, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz);
+    const float z = u ? sample_z<true>(F, ray, i, u[r]) : sample_z<false>(F, ray, i, 0.f);
+    const float mx = ray.dx * z, my = ray.dy * z, mz = ray.dz * z;
+    const float px = ray.ox + mx, py = ray.oy + my, pz = ray.oz + mz;
+    const bool out = (F.aabb0[0] > px) | (px > F.aabb1[0]) | (F.aabb0[1] > py) | (py > F.aabb1[1]) | (F.aabb0[2] > pz) | (pz > F.aabb1[2]);
+    pts[t * 3] = px; pts[t * 3 + 1] = py; pts[t * 3 + 2] = pz;
+    if (zs) zs[t] = z;
+    valid[t] = out ? 0 : 1;
+}
+
 }  // namespace t2n
 
 using namespace t2n;
+
+extern "C" int t2n_sample_ray(const t2n_field* f, const float* rays_o, const float* rays_d, int64_t n, int n_samples, const float* jitter,
+                              int ndc, float* pts, float* z_vals, uint8_t* valid, t2n_stream stream) {
+    if (!f || !rays_o || !rays_d || !pts || !valid || n < 0 || n_samples <= 0 || (ndc && !jitter)) {
+        set_error("t2n_sample_ray: bad argument");
+        return T2N_ERR_INVALID;
+    }
+    if (n == 0) return T2N_OK;
+    FieldDev F = f->dev;
+    F.ztab = ndc ? jitter : nullptr;
+    const long long total = (long long)n * n_samples;
+    hipLaunchKernelGGL(k_sample_ray, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, F, rays_o, rays_d, (long long)n,
+                       n_samples, ndc ? nullptr : jitter, pts, ndc ? nullptr : z_vals, valid);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
 
 extern "C" int t2n_density_at(const t2n_field* f, const float* xyz_norm, int64_t n, float* feat, float* sigma,
                               t2n_stream stream) {

@@ -243,7 +243,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N
     constexpr int kSteps = 2;
     // DENSE: whole 16-step blocks of the weights rows (a wave without samples runs no step: wlo = N, whi = -1)
     const int i_begin = DENSE ? (wlo & ~15) : wlo, i_end = DENSE ? min(N - 1, whi | 15) : whi;
+    // early termination (t2n_field_set_early_termination; never with weights rows): a ray below term_eps evaluates nothing further,
+    // the wave leaves the loop when none of its rays has anything left to evaluate
+    const float eps = DENSE ? 0.f : F.term_eps;
     for (int i = i_begin; i <= i_end; i += kSteps) {
+        if (eps > 0.f && !__any(have && i <= hi && !(T < eps))) break;
         float xn[kSteps], yn[kSteps], zn[kSteps], z[kSteps], w_out[kSteps];
         bool ok[kSteps];
         Axes3 A[kSteps];
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N
             const int idx = i + q;
             xn[q] = yn[q] = zn[q] = z[q] = w_out[q] = 0.f;
             ok[q] = false;
-            if (have && idx >= lo && idx <= hi && idx <= i_end) {
+            if (have && idx >= lo && idx <= hi && idx <= i_end && !(T < eps)) {   // (T is the transmittance in front of the step pair)
                 z[q] = sample_z<false>(F, ray, idx, 0.f);
                 ok[q] = sample_point<false>(F, ray, z[q], xn[q], yn[q], zn[q]);
                 if (F.alpha && ok[q]) ok[q] = alpha_pass(F, ray, z[q]);      // models/tensorBase.py:451-456
@@ -513,6 +517,7 @@ int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h
     a.scratch = scratch; a.cap = cap; a.ovf_count = ovf_count; a.ovf_list = ovf_list;
     a.app_pos = L.app_pos; a.app_ray = L.app_ray; a.counters = L.counters; a.list_cap = L.list_cap; a.stats = (unsigned long long*)L.stats;
     a.dense_w = L.weights;
+    a.F.term_eps = (!L.weights && !L.z_vals && !L.sigma_ctx) ? f->term_eps : 0.f;   // (eval only: this marcher has no train form)
     // (*ovf_count was zeroed by the launch's setup kernel, t2n_render_forward)
     const long long tiles = (long long)((img_w + 7) / 8) * ((img_h + 7) / 8);
     const dim3 grid((unsigned)((tiles + 3) / 4));

@@ -64,6 +64,9 @@ struct Args {
     float4* app_rgb;
     unsigned* range_flag;
     float neg1;                   // -1.0f at run time: x - hi stays an FMA with an f16 operand (v_fma_mix_f32, no convert)
+#ifdef SS3_PROF
+    unsigned long long* prof;     // [waves][8] cycle sums (instrumented build)
+#endif
 };
 
 #define SS_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -455,6 +458,483 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
     if (__any(!((float)amax[0] < kRange) || !((float)amax[1] < kRange) || amax_u > __float_as_uint(kRange)) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
+// =====================================================================================================================================
+// Three tiles per wave, one wave per SIMD (k_mlp_ss3): the same layouts, operand packing and arithmetic as k_mlp_ss above, with
+// layer 0 (69 % of the MFMAs) of THREE 32-sample tiles running on shared A operands. A 256-thread workgroup per CU; a round is
+// 12 tiles (384 samples). Per MFMA that is a third of the A-operand ds_read_b128, two thirds of the ring's LDS-DMA pieces and a
+// third of the barriers of the two-waves-per-SIMD form.
+//
+// Register plan (one wave owns its SIMD's whole 512-register file): the accumulators live in the AccVGPRs, named literally in
+// inline asm — the compiler allocates only the architectural half (operands, encoders, conversion units):
+//   a[64 t + 16 u .. +15]  layer-0 accumulators of tile t, unit tile u (192 registers); once tile t's layer 1 has consumed them
+//                          a[64 t .. 64 t + 47] hold the three product chains of its layer 2
+//   layer-1 accumulators of the tile in flight (layers 1 and 2 run tile by tile): 64 ARCHITECTURAL registers (compiler-visible MFMAs)
+// Accumulators start from the constant 0 in their first MFMA (srcC = 0); the biases are added where an accumulator is converted
+// (one v_fma_f32 instead of the scale multiply), from unscaled copies in LDS.
+// A operands go through a ring of four register buffers in consumption order (208 per round: 22 x 4 of layer 0, then per tile
+// 8 x 4 of layer 1 and 8 of layer 2); the buffer of element k is refilled with element k + 4 right behind k's last MFMA.
+// What the compiler cannot see inside the asm statements, and how it is covered:
+//   * MFMA result -> v_accvgpr_read: every read sits >= 9 MFMA issues (>= 288 cycles) behind the last MFMA of its accumulator,
+//     except the final read of the layer-2 chains, which waits 16 states (s_nop 15; an 8-pass MFMA needs 12);
+//   * a VALU-written B operand -> MFMA: the operands are finished >= 2 slots ahead; the first MFMA of a K-step carries s_nop 1;
+//   * the compiler keeps nothing in the AccVGPRs: every MFMA statement clobbers all 256 of them.
+#define SS3_AGPRS \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", \
+    "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", \
+    "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", \
+    "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", \
+    "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", \
+    "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", \
+    "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", \
+    "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", \
+    "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", \
+    "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", \
+    "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", \
+    "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", \
+    "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", \
+    "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", \
+    "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", \
+    "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", \
+    "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef short s2v __attribute__((ext_vector_type(2)));
+constexpr int kT3 = 3;                                   // tiles per wave
+constexpr int kE0 = 88, kEL = 40, kER = kE0 + kT3 * kEL;   // A elements per round: layer 0, per tile (32 + 8), all
+static_assert(kER % 4 == 0, "the A ring keeps its phase from round to round");
+
+template <int ACC, bool ZERO, bool NOP>
+__device__ __forceinline__ void mfma_acc(const u4v& a, const u4v& b) {
+    if constexpr (ZERO) {
+        if constexpr (NOP) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c0:%c1], %2, %3, 0" :: "n"(ACC), "n"(ACC + 15), "v"(a), "v"(b) : SS3_AGPRS);
+        else asm volatile("v_mfma_f32_32x32x16_f16 a[%c0:%c1], %2, %3, 0" :: "n"(ACC), "n"(ACC + 15), "v"(a), "v"(b) : SS3_AGPRS);
+    } else {
+        if constexpr (NOP) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c0:%c1], %2, %3, a[%c0:%c1]" :: "n"(ACC), "n"(ACC + 15), "v"(a), "v"(b) : SS3_AGPRS);
+        else asm volatile("v_mfma_f32_32x32x16_f16 a[%c0:%c1], %2, %3, a[%c0:%c1]" :: "n"(ACC), "n"(ACC + 15), "v"(a), "v"(b) : SS3_AGPRS);
+    }
+}
+template <int R>
+__device__ __forceinline__ float acc_read() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "n"(R));
+    return x;
+}
+
+struct AEl { u4v h, l; };
+// element K of the round's A stream -> LDS operand address (uint4 units; base 0: W2 / ring, base 1: W1)
+template <int K> struct ElAddr {
+    static constexpr int k = K % kER;
+    static constexpr bool l0 = k < kE0;
+    static constexpr int q = l0 ? 0 : (k - kE0) % kEL;
+    static constexpr bool l1 = !l0 && q < 32;
+    static constexpr int s = l0 ? k / 4 : (l1 ? q / 4 : q - 32), ut = l0 ? k % 4 : (l1 ? q % 4 : 0);
+    static constexpr int off = l0 ? kW2 + ((s / 2) % 3) * kChunk + (s % 2) * kStep + ut * 128 : (l1 ? s * kStep + ut * 128 : s * 128);
+};
+struct LdsA { const u4v* a0; const u4v* a1; };
+template <int K>
+__device__ __forceinline__ void fetch(AEl (&A)[4], const LdsA& L) {
+    if constexpr (K >= kER) return;   // the next round fetches its first four elements itself (32 registers less across the round boundary)
+#ifdef SS3_ABL_NO_AFETCH
+    if (K >= 4) return;
+#endif
+    using E = ElAddr<K>;
+    const u4v* __restrict__ p = (E::l1 ? L.a1 : L.a0) + E::off;
+    A[K % 4].h = p[0]; A[K % 4].l = p[64];
+}
+
+struct Enc3 {   // a tile's encoder (see Enc)
+    EncIn in; Unit U; unsigned ph[4], pl[4];
+};
+template <int S>
+struct EncFill3 {   // layer-0 B operand of K-step S of one tile -> (Bh, Bl)
+    Enc3& E; u4v& Bh; u4v& Bl; float neg1;
+    template <int IDX> __device__ __forceinline__ void run() {
+#ifdef SS3_ABL_NO_ENC
+        if (S > 0) return;
+#endif
+        constexpr int u = IDX / 3;
+        enc_unit<8 * S + 2 * u, IDX % 3>(E.U, E.in, neg1, E.ph[u], E.pl[u]);
+    }
+    __device__ __forceinline__ void done() {
+#ifdef SS3_ABL_NO_ENC
+        if (S > 0) return;
+#endif
+        Bh = u4v{E.ph[0], E.ph[1], E.ph[2], E.ph[3]};
+        Bl = u4v{E.pl[0], E.pl[1], E.pl[2], E.pl[3]};
+    }
+};
+struct Conv3 {   // the conversion fillers' state (one tile at a time)
+    Unit cu; unsigned ph[4], pl[4];
+    float4 bq[2][2];   // [K-step parity][half]: the biases of the eight units a step converts
+};
+// biases of conversion step S (units 32 (S / 2) + 8 b + 4 h + t, b = 2 (S % 2), 2 (S % 2) + 1) -> bq[S % 2]; issued a step ahead
+template <int S, int BOFF>
+__device__ __forceinline__ void conv_bias(Conv3& V, const float* __restrict__ LBh) {
+    V.bq[S % 2][0] = *reinterpret_cast<const float4*>(LBh + BOFF + 32 * (S / 2) + 16 * (S % 2));
+    V.bq[S % 2][1] = *reinterpret_cast<const float4*>(LBh + BOFF + 32 * (S / 2) + 16 * (S % 2) + 8);
+}
+template <int S, int BASE, int BOFF>
+struct ConvFill3 {   // relu(acc * inv + bias) of registers 8 (S % 2) .. +7 of unit tile S / 2 -> B operand of K-step S; the accumulators are
+                     // AccVGPRs from BASE (>= 0) or the architectural registers src[4] (BASE < 0)
+    u4v (&Hh)[8]; u4v (&Hl)[8]; Conv3& V; float inv, neg1; s2v& amax; const float* __restrict__ LBh; const f32x16* src;
+    template <int IDX> __device__ __forceinline__ void run() {
+#ifdef SS3_ABL_NO_CONV
+        if (S > 0) return;
+#endif
+        constexpr int j = IDX / 3, PH = IDX % 3;
+        Unit& U = V.cu;
+        if constexpr (PH == 0) {
+            float a0, a1;
+            if constexpr (BASE >= 0) {
+                constexpr int reg = BASE + 16 * (S / 2) + 8 * (S % 2) + 2 * j;
+                a0 = acc_read<reg>(); a1 = acc_read<reg + 1>();
+            } else {
+                a0 = src[S / 2][8 * (S % 2) + 2 * j]; a1 = src[S / 2][8 * (S % 2) + 2 * j + 1];
+            }
+            const float4& b = V.bq[S % 2][j / 2];
+            U.x0 = fmaxf(fmaf(a0, inv, (j % 2) ? b.z : b.x), 0.f);
+            U.x1 = fmaxf(fmaf(a1, inv, (j % 2) ? b.w : b.y), 0.f);
+        } else if constexpr (PH == 1) {
+            unit_pack(U);
+            amax = __builtin_elementwise_max(amax, __builtin_bit_cast(s2v, U.hi));   // bit patterns of non-negative halves order like their values
+            if constexpr (IDX == 1 && S < 7) conv_bias<(S < 7 ? S + 1 : 0), BOFF>(V, LBh);
+        } else {
+            unit_split(U, neg1, V.ph[j], V.pl[j]);
+        }
+    }
+    __device__ __forceinline__ void done() {
+#ifdef SS3_ABL_NO_CONV
+        if (S > 0) { Hh[S] = Hh[0]; Hl[S] = Hl[0]; return; }
+#endif
+        Hh[S] = u4v{V.ph[0], V.ph[1], V.ph[2], V.ph[3]};
+        Hl[S] = u4v{V.pl[0], V.pl[1], V.pl[2], V.pl[3]};
+        asm volatile("" : "+v"(amax));   // pinned to its K-step: left alone, hipcc defers the maxima to the next round and spills the halves for it
+    }
+};
+
+// the layer-0 weight stream for four waves: wave w moves KB 4 p + w of a 16-KB chunk in piece p
+struct Stream3 {
+    const uint4* wp; int tid;
+    template <int P> __device__ __forceinline__ void dma(uint4* __restrict__ slot, int c) const {
+        typedef __attribute__((address_space(3))) void* lp;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wp), 0, 0x7fffffff, 0x00020000);
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lp)(slot + P * 256 + w * 64), 16, tid * 16, c * (kChunk * 16) + P * 4096, 0, 0);
+    }
+};
+struct RingOps3 {
+    const Stream3& S; uint4* __restrict__ slot; int chunk;
+    template <int M> __device__ __forceinline__ void run() {
+#ifdef SS3_ABL_NO_DMA
+        return;
+#endif
+        if (chunk == kC0 - 1) return;   // the stream's padding chunk (K-steps 22, 23) is never read
+        if constexpr (M == 1) S.template dma<0>(slot, chunk);
+        if constexpr (M == 10) S.template dma<1>(slot, chunk);
+        if constexpr (M == 19) S.template dma<2>(slot, chunk);
+        if constexpr (M == 28) S.template dma<3>(slot, chunk);
+    }
+    __device__ __forceinline__ void all() { run<1>(); run<10>(); run<19>(); run<28>(); }
+};
+
+// Slot M (0..35) of K-step S of layer 0: unit tile M / 9, product (M % 9) / 3 (hi*hi, lo*hi, hi*lo), tile M % 3 — an accumulator is
+// touched every third slot; tile t's encoder runs phase M / 3 in the slots M % 3 == t.
+template <int M, int S, class F, class R>
+__device__ __forceinline__ void l0_slots(AEl (&A)[4], const u4v (&Bh)[kT3], const u4v (&Bl)[kT3], F (&f)[kT3], R ring, const LdsA& L) {
+    if constexpr (M < 36) {
+        constexpr int ut = M / 9, p = (M % 9) / 3, t = M % 3, k = 4 * S + ut;
+        mfma_acc<64 * t + 16 * ut, (S == 0 && p == 0), (M == 0)>(p == 1 ? A[k % 4].l : A[k % 4].h, p == 2 ? Bl[t] : Bh[t]);
+        if constexpr (M % 9 == 8) fetch<k + 4>(A, L);
+        f[t].template run<M / 3>();
+        if constexpr (M / 3 == 11) f[t].done();
+        ring.template run<M>();
+        SS_FENCE();
+        l0_slots<M + 1, S>(A, Bh, Bl, f, ring, L);
+    }
+}
+// Slot M (0..11) of a K-step of layer 1 of the tile in flight: unit tile M / 3, product M % 3; K0 = the A element of unit tile 0
+template <int M, int K0, bool FIRST, class F>
+__device__ __forceinline__ void l1_slots(f32x16 (&acc1)[4], AEl (&A)[4], const u4v& Hh, const u4v& Hl, F& f, const LdsA& L) {
+    if constexpr (M < 12) {
+        constexpr int ut = M / 3, p = M % 3, k = K0 + ut;
+        // (architectural accumulators, still through asm: a compiler-visible MFMA here made hipcc stage values in AccVGPRs of its own choice)
+        const u4v& av = p == 1 ? A[k % 4].l : A[k % 4].h;
+        const u4v& bv = p == 2 ? Hl : Hh;
+        if constexpr (FIRST && p == 0) {
+            if constexpr (M == 0) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc1[ut]) : "v"(av), "v"(bv));
+            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc1[ut]) : "v"(av), "v"(bv));
+        } else {
+            if constexpr (M == 0) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1[ut]) : "v"(av), "v"(bv));
+            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1[ut]) : "v"(av), "v"(bv));
+        }
+        if constexpr (p == 2) fetch<k + 4>(A, L);
+        f.template run<M>();
+        if constexpr (M == 11) f.done();
+        SS_FENCE();
+        l1_slots<M + 1, K0, FIRST>(acc1, A, Hh, Hl, f, L);
+    }
+}
+// Layer 2, K-step of A element K: three products on their own chains a[BASE + 16 p ..]; four filler phases per slot
+template <int K, int BASE, bool FIRST, class F>
+__device__ __forceinline__ void l2_step(AEl (&A)[4], const u4v& Hh, const u4v& Hl, F& f, const LdsA& L) {
+    mfma_acc<BASE, FIRST, true>(A[K % 4].h, Hh);
+    f.template run<0>(); f.template run<1>(); f.template run<2>(); f.template run<3>();
+    SS_FENCE();
+    mfma_acc<BASE + 16, FIRST, false>(A[K % 4].l, Hh);
+    f.template run<4>(); f.template run<5>(); f.template run<6>(); f.template run<7>();
+    SS_FENCE();
+    mfma_acc<BASE + 32, FIRST, false>(A[K % 4].h, Hl);
+    fetch<K + 4>(A, L);
+    f.template run<8>(); f.template run<9>(); f.template run<10>(); f.template run<11>();
+    f.done();
+    SS_FENCE();
+}
+
+#ifdef SS3_ABL_NO_BARRIER
+#define SS3_BARRIER() do {} while (0)
+#elif defined(SS3_PROF)
+#define SS3_BARRIER() do { const unsigned long long tb = __builtin_readcyclecounter(); __syncthreads(); p_bar += __builtin_readcyclecounter() - tb; } while (0)
+#else
+#define SS3_BARRIER() __syncthreads()
+#endif
+#ifdef SS3_PROF
+#define SS3_T(var) do { const unsigned long long tn = __builtin_readcyclecounter(); var += tn - p_t; p_t = tn; } while (0)
+#else
+#define SS3_T(var) do {} while (0)
+#endif
+// the round's last layer-2 step: slot p carries all twelve encoder phases of tile p's first operand of the next round
+template <int K, int BASE, class F>
+__device__ __forceinline__ void l2_last(AEl (&A)[4], const u4v& Hh, const u4v& Hl, F (&f)[kT3], const LdsA& L) {
+    mfma_acc<BASE, false, true>(A[K % 4].h, Hh);
+    fill_all(f[0]);
+    SS_FENCE();
+    mfma_acc<BASE + 16, false, false>(A[K % 4].l, Hh);
+    fill_all(f[1]);
+    SS_FENCE();
+    mfma_acc<BASE + 32, false, false>(A[K % 4].h, Hl);
+    fetch<K + 4>(A, L);
+    fill_all(f[2]);
+    SS_FENCE();
+}
+
+__global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    // LDS map as k_mlp_ss: W2 [0, 16 KB) | ring [16 KB, 64 KB) | W1 [64 KB, 128 KB) | biases (UNSCALED here) | sub-list table
+    uint4* __restrict__ W2 = lds;
+    uint4* __restrict__ RING = lds + kW2;
+    uint4* __restrict__ W1 = RING + kRing;
+    float* __restrict__ LB = reinterpret_cast<float*>(W1 + kW1);
+    unsigned* __restrict__ LT = reinterpret_cast<unsigned*>(LB + kBias);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    unsigned ob0 = (unsigned)lane * 16u, ob1 = (unsigned)lane * 16u + 65536u, obb = (unsigned)((kW2 + kRing + kW1) * 16) + 16u * (unsigned)h;
+    asm volatile("" : "+v"(ob0));
+    asm volatile("" : "+v"(ob1));
+    asm volatile("" : "+v"(obb));
+    const LdsA L{reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(lds) + ob0), reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(lds) + ob1)};
+    const float* __restrict__ LBh = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + obb);
+
+    unsigned cnt_l = 0;
+    if (lane < a.nlists) {
+        cnt_l = a.counters[lane * kCounterStride];
+        if (cnt_l > a.list_cap) cnt_l = a.list_cap;
+    }
+    unsigned incl = (cnt_l + 31u) / 32u;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    unsigned ntiles = __shfl(incl, a.nlists - 1);
+    if (ntiles > a.tile_hi) ntiles = a.tile_hi;
+    const unsigned nrounds = (ntiles + 11u) / 12u;
+    if (blockIdx.x >= nrounds) return;
+    if (tid < 8) { LT[tid] = tid < a.nlists ? incl : 0xffffffffu; LT[8 + tid] = cnt_l; }
+
+    const float inv0 = a.inv_scale[0], inv1 = a.inv_scale[1], inv2 = a.inv_scale[2];
+    for (int i = tid; i < kW1; i += 256) W1[i] = a.w1[i];
+    for (int i = tid; i < kW2; i += 256) W2[i] = a.w2[i];
+    for (int i = tid; i < kBias; i += 256) LB[i] = a.bias[i] * (i < 128 ? inv0 : (i < 256 ? inv1 : inv2));   // power-of-two scales: exact
+    const Stream3 S{a.w0, tid};
+    S.dma<0>(RING, 0); S.dma<1>(RING, 0); S.dma<2>(RING, 0); S.dma<3>(RING, 0);
+    S.dma<0>(RING + kChunk, 1); S.dma<1>(RING + kChunk, 1); S.dma<2>(RING + kChunk, 1); S.dma<3>(RING + kChunk, 1);
+    const float neg1 = a.neg1;
+    s2v amax = {0, 0};   // hidden activations: max of the packed RTZ halves' bit patterns (non-negative values; -0 and NaN never reach here)
+    unsigned amax_u = 0u;
+
+    // rows of round r: tile 12 r + 3 w + t, row 32 tile + j (see k_mlp_ss::load_feat)
+    const unsigned last = ntiles * 32u - 1u;
+    auto load_feat = [&](unsigned r, int t, float (&f)[14]) {
+        unsigned i = ((r * 4u + (unsigned)w) * 3u + (unsigned)t) * 32u + (unsigned)j;
+        i = i < last ? i : last;
+        const float2* __restrict__ row = reinterpret_cast<const float2*>(a.feat + (size_t)i * 32 + 14 * h);
+#pragma unroll
+        for (int e = 0; e < 7; ++e) { const float2 v = row[e]; f[2 * e] = v.x; f[2 * e + 1] = v.y; }
+    };
+    float wnext[kT3] = {0.f, 0.f, 0.f};
+    auto finish_feat = [&](EncIn& I, float& wn) {
+        const float xs = __shfl_xor(I.f[13], 32);
+        I.fh = h ? xs : I.f[13];
+        I.extra = h ? I.fh : 0.f;
+        wn = xs;
+    };
+    Enc3 E[kT3];
+    u4v Bh[2][kT3], Bl[2][kT3];   // [K-step parity][tile]
+#pragma unroll
+    for (int t = 0; t < kT3; ++t) {
+        E[t].in.hs = h ? 8.f : 1.f;
+        load_feat(blockIdx.x, t, E[t].in.f);
+    }
+#pragma unroll
+    for (int t = 0; t < kT3; ++t) {
+        finish_feat(E[t].in, wnext[t]);
+        EncFill3<0> f{E[t], Bh[0][t], Bl[0][t], neg1};
+        fill_all(f);
+    }
+    __syncthreads();   // W1 / W2 / bias / ring slots 0, 1 visible
+    AEl A[4];
+    Conv3 V;
+
+#ifdef SS3_PROF
+    unsigned long long p_bar = 0, p_l0 = 0, p_tile[3] = {0, 0, 0}, p_top = 0, p_rounds = 0;
+    const unsigned long long p_start = __builtin_readcyclecounter();
+    unsigned long long p_t = p_start;
+#endif
+    for (unsigned r = blockIdx.x; r < nrounds; r += gridDim.x) {
+        float wgt[kT3];
+#pragma unroll
+        for (int t = 0; t < kT3; ++t) {
+#pragma unroll
+            for (int e = 0; e < 14; ++e) amax_u = max(amax_u, __float_as_uint(E[t].in.f[e]) & 0x7fffffffu);
+            wgt[t] = wnext[t];
+        }
+        asm volatile("" : "+v"(amax_u));   // pinned here: left alone, hipcc sinks these maxima to the end of the round and keeps (spills) the 42 features for it
+        const unsigned rn = r + gridDim.x < nrounds ? r + gridDim.x : r;
+        SS3_T(p_top);
+        // ---- layer 0, three tiles on shared A operands: 11 chunks of two K-steps (+ the ring's padding chunk) ----------------------------
+#define SS3_ENC(S_, P_) {{E[0], Bh[P_][0], Bl[P_][0], neg1}, {E[1], Bh[P_][1], Bl[P_][1], neg1}, {E[2], Bh[P_][2], Bl[P_][2], neg1}}
+#define SS3_L0(C)                                                                                                                 \
+        {                                                                                                                         \
+            SS3_BARRIER();   /* chunk C + 1 written by every wave; chunk C - 1 read by every wave */                              \
+            if constexpr (C == 0) { fetch<0>(A, L); fetch<1>(A, L); fetch<2>(A, L); fetch<3>(A, L); }                             \
+            RingOps3 ring{S, RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0};                                                       \
+            if constexpr (C == 11) {                                                                                              \
+                ring.all();                                                                                                       \
+            } else {                                                                                                              \
+                {                                                                                                                 \
+                    EncFill3<2 * C + 1> f0[kT3] = SS3_ENC(2 * C + 1, 1);                                                          \
+                    l0_slots<0, 2 * C>(A, Bh[0], Bl[0], f0, ring, L);                                                             \
+                }                                                                                                                 \
+                if constexpr (C < 10) {                                                                                           \
+                    EncFill3<(C < 10 ? 2 * C + 2 : 0)> f1[kT3] = SS3_ENC(2 * C + 2, 0);                                           \
+                    l0_slots<0, 2 * C + 1>(A, Bh[1], Bl[1], f1, NoRing(), L);                                                     \
+                } else {                                                                                                          \
+                    NoFill f1[kT3];                                                                                               \
+                    conv_bias<0, 0>(V, LBh);   /* tile 0's first conversion step */                                               \
+                    l0_slots<0, 2 * C + 1>(A, Bh[1], Bl[1], f1, NoRing(), L);                                                     \
+                }                                                                                                                 \
+            }                                                                                                                     \
+        }
+#ifndef SS3_ABL_TAIL_ONLY
+        SS3_L0(0) SS3_L0(1) SS3_L0(2) SS3_L0(3) SS3_L0(4) SS3_L0(5) SS3_L0(6) SS3_L0(7) SS3_L0(8) SS3_L0(9) SS3_L0(10) SS3_L0(11)
+#endif
+#undef SS3_L0
+        SS3_T(p_l0);
+
+        // ---- layers 1 and 2, tile by tile -------------------------------------------------------------------------------------------------
+#define SS3_L1(T_, St)                                                                                                            \
+        {                                                                                                                         \
+            if constexpr (St < 7) {                                                                                               \
+                ConvFill3<(St < 7 ? St + 1 : 0), 64 * T_, 0> f{H0h, H0l, V, inv0, neg1, amax, LBh, nullptr};                      \
+                l1_slots<0, kE0 + kEL * T_ + 4 * St, St == 0>(acc1, A, H0h[St], H0l[St], f, L);                                   \
+            } else {                                                                                                              \
+                NoFill f;                                                                                                         \
+                conv_bias<0, 128>(V, LBh);                                                                                        \
+                l1_slots<0, kE0 + kEL * T_ + 4 * St, St == 0>(acc1, A, H0h[St], H0l[St], f, L);                                   \
+            }                                                                                                                     \
+        }
+#define SS3_L2(T_, St)                                                                                                            \
+        {                                                                                                                         \
+            if constexpr (St < 7) {                                                                                               \
+                ConvFill3<(St < 7 ? St + 1 : 0), -1, 128> f{H1h, H1l, V, inv1, neg1, amax, LBh, acc1};                            \
+                l2_step<kE0 + kEL * T_ + 32 + St, 64 * T_, St == 0>(A, H1h[St], H1l[St], f, L);                                   \
+            } else if constexpr (T_ + 1 < kT3) {                                                                                  \
+                NoFill f;                                                                                                         \
+                conv_bias<0, 0>(V, LBh);   /* the next tile's first conversion step */                                            \
+                l2_step<kE0 + kEL * T_ + 32 + St, 64 * T_, St == 0>(A, H1h[St], H1l[St], f, L);                                   \
+            } else {   /* the round's last step: the next round's first operands of the three tiles, one tile per slot */        \
+                _Pragma("unroll") for (int t = 0; t < kT3; ++t) finish_feat(E[t].in, wnext[t]);                                   \
+                EncFill3<0> f3[kT3] = SS3_ENC(0, 0);                                                                              \
+                l2_last<kE0 + kEL * T_ + 32 + St, 64 * T_>(A, H1h[St], H1l[St], f3, L);                                           \
+            }                                                                                                                     \
+            /* the next round's features (needed from its first encoder phase to its last layer-0 step): loaded here, not */     \
+            /* earlier — 42 registers that nothing in the tile-by-tile part needs */                                             \
+            if constexpr (T_ + 1 == kT3 && St == 0) { _Pragma("unroll") for (int t = 0; t < kT3; ++t) load_feat(rn, t, E[t].in.f); } \
+        }
+#define SS3_TILE(T_)                                                                                                              \
+        {                                                                                                                         \
+            u4v H0h[8], H0l[8], H1h[8], H1l[8];                                                                                   \
+            f32x16 acc1[4];                                                                                                       \
+            {                                                                                                                     \
+                ConvFill3<0, 64 * T_, 0> f{H0h, H0l, V, inv0, neg1, amax, LBh, nullptr};                                          \
+                fill_all(f);                                                                                                      \
+            }                                                                                                                     \
+            SS3_L1(T_, 0) SS3_L1(T_, 1) SS3_L1(T_, 2) SS3_L1(T_, 3) SS3_L1(T_, 4) SS3_L1(T_, 5) SS3_L1(T_, 6) SS3_L1(T_, 7)       \
+            {                                                                                                                     \
+                ConvFill3<0, -1, 128> f{H1h, H1l, V, inv1, neg1, amax, LBh, acc1};                                                \
+                fill_all(f);                                                                                                      \
+            }                                                                                                                     \
+            SS3_L2(T_, 0) SS3_L2(T_, 1) SS3_L2(T_, 2) SS3_L2(T_, 3) SS3_L2(T_, 4) SS3_L2(T_, 5) SS3_L2(T_, 6) SS3_L2(T_, 7)       \
+            asm volatile("s_nop 15");   /* the chains' last MFMAs -> their reads */                                              \
+            const float c00 = acc_read<64 * T_>(), c01 = acc_read<64 * T_ + 1>(), c02 = acc_read<64 * T_ + 2>();                  \
+            const float c10 = acc_read<64 * T_ + 16>(), c11 = acc_read<64 * T_ + 17>(), c12 = acc_read<64 * T_ + 18>();           \
+            const float c20 = acc_read<64 * T_ + 32>(), c21 = acc_read<64 * T_ + 33>(), c22 = acc_read<64 * T_ + 34>();           \
+            const unsigned tile = (r * 4u + (unsigned)w) * 3u + T_;                                                               \
+            if (tile < ntiles && h == 0) {   /* output rows 0..2 live in registers 0..2 of lanes 0..31 */                         \
+                const uint4 i0 = *reinterpret_cast<const uint4*>(LT), i1 = *reinterpret_cast<const uint4*>(LT + 4);               \
+                const unsigned pre[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};                                         \
+                int li = 0;                                                                                                       \
+                unsigned before = 0u;                                                                                             \
+                _Pragma("unroll") for (int l = 0; l < 8; ++l) if (pre[l] <= tile) { li = l + 1; before = pre[l]; }                \
+                const unsigned lbase = (unsigned)li * a.list_cap;                                                                 \
+                const unsigned count = lbase + LT[8 + li];                                                                        \
+                const unsigned idx = lbase + (tile - before) * 32u + (unsigned)j;                                                 \
+                if (idx < count) {                                                                                                \
+                    const float4 b2 = *reinterpret_cast<const float4*>(LB + 256);                                                 \
+                    const float rr = fmaf((c00 + c20) + c10, inv2, b2.x), gg = fmaf((c01 + c21) + c11, inv2, b2.y),               \
+                                bb = fmaf((c02 + c22) + c12, inv2, b2.z);                                                         \
+                    a.app_rgb[idx] = make_float4(__builtin_amdgcn_rcpf(1.f + __expf(-rr)), __builtin_amdgcn_rcpf(1.f + __expf(-gg)), \
+                                                 __builtin_amdgcn_rcpf(1.f + __expf(-bb)), wgt[T_]);                              \
+                }                                                                                                                 \
+            }                                                                                                                     \
+        }
+#ifndef SS3_ABL_L0_ONLY
+#ifdef SS3_PROF
+        SS3_TILE(0) SS3_T(p_tile[0]); SS3_TILE(1) SS3_T(p_tile[1]); SS3_TILE(2) SS3_T(p_tile[2]); ++p_rounds;
+#else
+        SS3_TILE(0) SS3_TILE(1) SS3_TILE(2)
+#endif
+#endif
+#undef SS3_TILE
+#undef SS3_L2
+#undef SS3_L1
+#undef SS3_ENC
+    }
+#ifdef SS3_PROF
+    if (lane == 0 && a.prof) {
+        unsigned long long* o = a.prof + (size_t)(blockIdx.x * 4 + w) * 8;
+        o[0] = p_bar; o[1] = p_l0; o[2] = p_tile[0]; o[3] = p_tile[1]; o[4] = p_tile[2]; o[5] = p_top; o[6] = p_rounds;
+        o[7] = __builtin_readcyclecounter() - p_start;
+    }
+#endif
+    const h2v am = __builtin_bit_cast(h2v, amax);
+#if defined(SS3_ABL_NO_DMA) || defined(SS3_ABL_NO_ENC) || defined(SS3_ABL_NO_CONV) || defined(SS3_ABL_TAIL_ONLY) || defined(SS3_ABL_L0_ONLY)
+    if (am[0] == (_Float16)12345.f) atomicOr(a.range_flag, 1u);   // timing-only build: garbage values must not trigger the exact redo
+#else
+    if (__any(!((float)am[0] < kRange) || !((float)am[1] < kRange) || amax_u > __float_as_uint(kRange)) && lane == 0) atomicOr(a.range_flag, 1u);
+#endif
+}
+
 // ---- operand packing -----------------------------------------------------------------------------------------------------
 // scales[l] = 2^k with max|W_l| * 2^k in [2^12, 2^13): hi halves use the top of the f16 range, lo halves stay normal for
 // every weight within 2^-11 of the largest one. inv_scale = 1 / scale. [0..2] scale, [4..6] inverse.
@@ -567,6 +1047,10 @@ int ss_pack(t2n_field* f, hipStream_t s) {
     const size_t total = nw + kBias;
     hipLaunchKernelGGL(k_pack_ss, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     T2N_HIP(hipGetLastError());
+    // frames of a trajectory run on alternating streams (renderer._FramePipe): the other streams' head launches wait for this pack
+    if (!f->ss_event) { hipEvent_t e; T2N_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); f->ss_event = (void*)e; }
+    T2N_HIP(hipEventRecord((hipEvent_t)f->ss_event, s));
+    f->ss_stream = (void*)s;
     f->ss_dirty = false;
     return T2N_OK;
 }
@@ -577,9 +1061,14 @@ int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev,
                   unsigned* range_flag, hipStream_t s) {
     using namespace ss;
     if (f->ss_dirty || !f->buf_ss) { const int rc = ss_pack(f, s); if (rc) return rc; }
+    else if (f->ss_event && f->ss_stream != (void*)s) T2N_HIP(hipStreamWaitEvent(s, (hipEvent_t)f->ss_event, 0));
     static bool attr_set = false;
+    static bool two_wave = false;   // T2N_SS_TWO_WAVE=1: the two-waves-per-SIMD form (A/B against the three-tile kernel)
     if (!attr_set) {
         T2N_HIP(hipFuncSetAttribute((const void*)k_mlp_ss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        T2N_HIP(hipFuncSetAttribute((const void*)k_mlp_ss3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        const char* e = getenv("T2N_SS_TWO_WAVE");
+        two_wave = e && e[0] == '1';
         attr_set = true;
     }
     const size_t nw = (size_t)kW0 + kW1 + kW2;
@@ -589,7 +1078,26 @@ int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev,
     a.bias = (const float*)(base + nw); a.inv_scale = a.bias + kBias + 4;
     a.feat = feat; a.counters = counters_dev; a.list_cap = list_cap; a.nlists = kLists; a.tile_hi = tile_hi; a.app_rgb = app_rgb;
     a.range_flag = range_flag; a.neg1 = -1.f;
-    hipLaunchKernelGGL(k_mlp_ss, dim3(256), dim3(512), kLds, s, a);
+#ifdef SS3_PROF
+    static unsigned long long* prof = nullptr;
+    static int prof_calls = 0;
+    if (!prof) { T2N_HIP(hipMalloc((void**)&prof, 1024 * 8 * 8)); }
+    T2N_HIP(hipMemsetAsync(prof, 0, 1024 * 8 * 8, s));
+    a.prof = prof;
+#endif
+    if (two_wave) hipLaunchKernelGGL(k_mlp_ss, dim3(256), dim3(512), kLds, s, a);
+    else hipLaunchKernelGGL(k_mlp_ss3, dim3(256), dim3(256), kLds, s, a);
+#ifdef SS3_PROF
+    if (++prof_calls == 20) {   // one report per process: per-wave cycle sums, averaged over the waves
+        static unsigned long long h[1024 * 8];
+        T2N_HIP(hipStreamSynchronize(s));
+        T2N_HIP(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 1024; ++i) for (int k = 0; k < 8; ++k) sum[k] += (double)h[i * 8 + k];
+        fprintf(stderr, "[ss3 prof] per wave: barrier-wait %.0f, layer0 (incl. barriers) %.0f, tile0 %.0f, tile1 %.0f, tile2 %.0f, top %.0f, rounds %.1f, total %.0f cycles\n",
+                sum[0] / 1024, sum[1] / 1024, sum[2] / 1024, sum[3] / 1024, sum[4] / 1024, sum[5] / 1024, sum[6] / 1024, sum[7] / 1024);
+    }
+#endif
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

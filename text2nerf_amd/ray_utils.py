@@ -25,6 +25,62 @@ def get_ray_directions(H, W, focal, center=None, device="cuda", normalize=False)
     return out
 
 
+def get_ray_directions_blender(H, W, focal, center=None, device="cuda"):
+    """dataLoader/ray_utils.py:45-63: the same pixel-centre grid in the OpenGL / Blender camera frame (y up, looking down -z): the
+    OpenCV directions of the HIP kernel with the signs of y and z flipped (an exact operation)."""
+    d = get_ray_directions(H, W, focal, center=center, device=device)
+    return d * torch.tensor([1.0, -1.0, -1.0], device=d.device)
+
+
+def _on_gpu(name, *ts):
+    for t in ts:
+        if t.device.type != "cuda":
+            raise _lib.T2NError(f"{name}: the mirror computes on the MI355X only (tensor on {t.device})")
+
+
+def depth2dist(z_vals, cos_angle):
+    """dataLoader/ray_utils.py:9-15: sample spacings along a ray from its depths (the last one 1e10), times the ray's cosine."""
+    _on_gpu("depth2dist", z_vals, cos_angle)
+    gap = z_vals[..., 1:] - z_vals[..., :-1]
+    far = torch.full_like(z_vals[..., :1], 1e10)
+    return torch.cat([gap, far], -1) * cos_angle.unsqueeze(-1)
+
+
+def ndc2dist(ndc_pts, cos_angle):
+    """dataLoader/ray_utils.py:18-21: Euclidean spacings of consecutive NDC points [R, N, 3]; the last one is 1e10 cos."""
+    _on_gpu("ndc2dist", ndc_pts, cos_angle)
+    gap = (ndc_pts[:, 1:] - ndc_pts[:, :-1]).norm(dim=-1)
+    return torch.cat([gap, 1e10 * cos_angle.unsqueeze(-1)], -1)
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    """dataLoader/ray_utils.py:129-171 (hierarchical sampling; no caller in the driver): inverse-CDF samples of the piecewise-constant
+    density `weights` [B, M] over `bins` [B, M + 1]. det: evenly spaced quantiles; pytest: numpy's seed-0 draws, as there."""
+    import numpy as np
+    _on_gpu("sample_pdf", bins, weights)
+    dev = weights.device
+    w = weights + 1e-5
+    cdf = torch.cumsum(w / w.sum(-1, keepdim=True), -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    shape = list(cdf.shape[:-1]) + [N_samples]
+    if pytest:
+        np.random.seed(0)
+        u = torch.Tensor(np.broadcast_to(np.linspace(0.0, 1.0, N_samples), shape).copy() if det else np.random.rand(*shape)).to(dev)
+    elif det:
+        u = torch.linspace(0.0, 1.0, steps=N_samples, device=dev).expand(shape)
+    else:
+        u = torch.rand(shape, device=dev)
+    u = u.contiguous()
+    hi = torch.searchsorted(cdf.detach(), u, right=True)
+    lo = (hi - 1).clamp(min=0)
+    hi = hi.clamp(max=cdf.shape[-1] - 1)
+    c_lo, c_hi = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
+    b_lo, b_hi = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
+    span = c_hi - c_lo
+    span = torch.where(span < 1e-5, torch.ones_like(span), span)
+    return b_lo + (u - c_lo) / span * (b_hi - b_lo)
+
+
 def get_rays(directions, c2w):
     """rays_o, rays_d ([H*W,3] each) in world coordinates; directions are rotated, not re-normalised."""
     lib = _lib.load()

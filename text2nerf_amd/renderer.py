@@ -110,10 +110,18 @@ class _FramePipe:
     three (tools/experiments/two_frames_in_flight.py), bitwise the same pictures. The kernels and their order inside a frame are
     unchanged; the library's per-field host state is only touched from the calling thread, call by call."""
 
+    _STREAMS = {}     # device -> the side streams every pipe on that device shares
+
     def __init__(self, device, n=2):
         self.dev = torch.device(device)
         self.main = torch.cuda.current_stream(self.dev)
-        self.streams = [torch.cuda.Stream(self.dev) for _ in range(max(int(n), 1))]
+        # The scratch buffers are per (device, stream) and grow-only (tensorf.workspace: several GiB for a large frame): every pipe on
+        # a device reuses the SAME side streams, so repeated evaluation calls during a training run hold n buffers, not one per
+        # stream torch's pool hands out.
+        pool = _FramePipe._STREAMS.setdefault(str(self.dev), [])
+        while len(pool) < max(int(n), 1):
+            pool.append(torch.cuda.Stream(self.dev))
+        self.streams = pool[: max(int(n), 1)]
         for st in self.streams:
             st.wait_stream(self.main)          # whatever the caller queued (parameter updates, ray tensors) is visible
         self.k = 0

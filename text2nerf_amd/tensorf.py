@@ -50,6 +50,21 @@ def workspace(device, nbytes: int) -> torch.Tensor:
     return buf
 
 
+def release_workspaces(device=None, keep_current=True) -> int:
+    """Drop the scratch buffers of `device` (all devices when None) — all of them, or all but the current stream's. Returns the bytes
+    released to torch's caching allocator. For long runs that drove a field from many streams; a pipelined evaluation keeps its
+    side streams (renderer._FramePipe) and needs no call."""
+    freed = 0
+    for key in list(_WORKSPACE):
+        d, st = key
+        if device is not None and d != str(torch.device(device)):
+            continue
+        if keep_current and key == _ws_key(d):
+            continue
+        freed += _WORKSPACE.pop(key).numel()
+    return freed
+
+
 def workspace_reserved(device) -> int:
     """Bytes of scratch currently held for `device` (all streams)."""
     d = str(torch.device(device))
@@ -175,6 +190,31 @@ def raw2alpha(sigma: torch.Tensor, dist: torch.Tensor):
     return alpha, w, bg
 
 
+def positional_encoding(positions, freqs):
+    """models/tensorBase.py:11-17: ``[sin(p 2^k) ..., cos(p 2^k) ...]`` with the sines of all (channel, octave) pairs first (channel-major,
+    octave-minor), then the cosines. The render path never calls this: the head kernels encode in registers (csrc/t2n_mlp_ss.hip,
+    t2n_shade.hip); it is here for callers of the reference's module-level name."""
+    if positions.device.type != "cuda":
+        raise T2NError("positional_encoding: the mirror computes on the MI355X only")
+    octaves = torch.pow(2.0, torch.arange(freqs, device=positions.device, dtype=torch.float32))
+    arg = (positions.unsqueeze(-1) * octaves).flatten(-2)
+    return torch.cat([arg.sin(), arg.cos()], dim=-1)
+
+
+def SHRender(xyz_sampled, viewdirs, features):
+    """models/tensorBase.py:29-33: degree-2 spherical-harmonics colour, ``relu(sum_b Y_b(dir) f[c, b] + 0.5)``; the basis comes from the
+    HIP kernel behind ``eval_sh_bases``. (Inside a render the SH head runs in the shade kernel, csrc/t2n_heads.hip.)"""
+    from .sh import eval_sh_bases
+    basis = eval_sh_bases(2, viewdirs)
+    coeff = features.reshape(-1, 3, basis.shape[-1])
+    return torch.relu((coeff * basis[:, None]).sum(-1) + 0.5)
+
+
+def RGBRender(xyz_sampled, viewdirs, features):
+    """models/tensorBase.py:36-39: the features are the colour."""
+    return features
+
+
 class AlphaGridMask(nn.Module):
     """Occupancy volume with the reference's attributes (models/tensorBase.py:41-59). ``sample_alpha`` runs the trilinear
     lookup on the GPU through the owning field (t2n_alpha_at); the render kernels apply the mask themselves."""
@@ -256,7 +296,13 @@ class MLPRender(_ViewHead):
         self._build((3 + 2 * viewpe * 3) + inChanel, featureC)
 
 
-class TensorVMSplit(nn.Module):
+class TensorBase(nn.Module):
+    """models/tensorBase.py:163-507: what every field of the reference shares — constructor keywords, step size, ray sampling, the
+    render call, checkpoints, occupancy-mask maintenance — on the HIP kernels. The factor containers and what depends on their
+    layout (init_svd_volume, get_optparam_groups, the TV terms, compute_densityfeature / compute_appfeature, up-sampling, shrink)
+    come from the subclass, as in the reference; the kernels read VM-split factor tensors (TensorVMSplit, and TensorVM / TensorCP
+    through views / an exact embedding)."""
+
     def __init__(self, aabb, gridSize, device, density_n_comp=8, appearance_n_comp=24, app_dim=27,
                  shadingMode="MLP_PE", alphaMask=None, near_far=[2.0, 6.0], density_shift=-10, alphaMask_thres=0.001,
                  distance_scale=25, rayMarch_weight_thres=0.0001, pos_pe=6, view_pe=6, fea_pe=6, featureC=128,
@@ -291,6 +337,12 @@ class TensorVMSplit(nn.Module):
         # 'fp32' (default) or 'bf16' (BASELINE configs[4]): the forward gathers read bf16 copies of the 12 factor tensors;
         # the render equals the fp32 render of the bf16-rounded tensors bit for bit, the parameters stay fp32 masters
         self.factor_storage = os.environ.get("T2N_FACTOR_STORAGE", "fp32")
+        # Early ray termination of eval renders that return neither weights nor z_vals (evaluation(), render_views, ...): a ray whose
+        # transmittance fell below this evaluates no further sample. The reference never terminates (models/tensorBase.py:19-26,
+        # 494-505), so this is a bounded deviation (< eps on acc and colour, < eps * z range on depth), not its arithmetic: set 0.0
+        # for the reference's sample-for-sample behaviour (exact evaluated-sample counts). OctreeRender_trilinear_fast (weights
+        # returned) and training are never terminated.
+        self.early_termination = float(os.environ.get("T2N_EARLY_TERMINATION", "1e-6"))
         self._handle = None
         self._uploaded_key = None
         self._gbuf = None
@@ -303,6 +355,11 @@ class TensorVMSplit(nn.Module):
                            f"(supported: {sorted(_lib.SHADE_IDS)})")
         self.update_stepSize(gridSize)
         self.init_svd_volume(gridSize[0], device)
+        self.init_render_func(shadingMode, pos_pe, view_pe, fea_pe, featureC, device)
+        self._kernel_shape()      # shapes beyond the kernels' capacity fail here, loudly
+
+    def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):
+        """models/tensorBase.py:200-217: the head's parameter container (its arithmetic runs in the shade kernels)."""
         if shadingMode == "MLP_Fea_noview":
             self.renderModule = MLPRender_Fea_noview(self.app_dim, fea_pe, featureC).to(device)
         elif shadingMode == "MLP_PE":        # models/tensorBase.py:201-208
@@ -313,24 +370,54 @@ class TensorVMSplit(nn.Module):
             self.renderModule = MLPRender_Fea(self.app_dim, view_pe, fea_pe, featureC).to(device)
         elif shadingMode == "MLP":
             self.renderModule = MLPRender(self.app_dim, view_pe, featureC).to(device)
+        elif shadingMode == "SH":
+            self.renderModule = SHRender
+        elif shadingMode == "RGB":
+            assert self.app_dim == 3
+            self.renderModule = RGBRender
         else:
-            self.renderModule = None
-        self._kernel_shape()      # shapes beyond the kernels' capacity fail here, loudly
+            raise T2NError(f"Unrecognized shading module {shadingMode!r}")
 
-    # ---- containers (models/tensoRF.py:144-160) -------------------------------------------------------------------
-    def init_svd_volume(self, res, device):
-        self.density_plane, self.density_line = self.init_one_svd(self.density_n_comp, self.gridSize, 0.1, device)
-        self.app_plane, self.app_line = self.init_one_svd(self.app_n_comp, self.gridSize, 0.1, device)
-        self.basis_mat = nn.Linear(sum(self.app_n_comp), self.app_dim, bias=False).to(device)
+    # ---- sampling as a stage of its own (models/tensorBase.py:293-323); forward() samples inside the march kernels ----------------
+    def _sample(self, rays_o, rays_d, N, jitter, ndc):
+        lib = _lib.load()
+        h = self.sync_params()
+        dev = self.basis_mat.weight.device if hasattr(self, "basis_mat") else self._all_params()[0].device
+        o = rays_o.detach().reshape(-1, 3).contiguous().float().to(dev)
+        d = rays_d.detach().reshape(-1, 3).contiguous().float().to(dev)
+        n = o.shape[0]
+        pts = torch.empty(n, N, 3, device=dev, dtype=torch.float32)
+        z = None if ndc else torch.empty(n, N, device=dev, dtype=torch.float32)
+        valid = torch.empty(n, N, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            _lib.check(lib.t2n_sample_ray(h, _lib.ptr(o), _lib.ptr(d), n, int(N), _lib.ptr(jitter), 1 if ndc else 0, _lib.ptr(pts),
+                                          _lib.ptr(z), _lib.ptr(valid), _lib.current_stream_ptr(dev)), "t2n_sample_ray")
+        return pts, z, valid.bool()
 
-    def init_one_svd(self, n_component, gridSize, scale, device):
-        planes, lines = [], []
-        g = [int(x) for x in gridSize]
-        for i in range(3):
-            m0, m1 = MAT_MODE[i]
-            planes.append(nn.Parameter(scale * torch.randn((1, n_component[i], g[m1], g[m0]))))
-            lines.append(nn.Parameter(scale * torch.randn((1, n_component[i], g[VEC_MODE[i]], 1))))
-        return nn.ParameterList(planes).to(device), nn.ParameterList(lines).to(device)
+    def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1):
+        """models/tensorBase.py:304-323: ``(rays_pts [R,N,3], interpx [R,N], ~mask_outbbox [R,N])``. Train mode draws the per-ray offset
+        from the CPU default generator, like the reference (its ``rng`` lives on the CPU, :313-317)."""
+        N = int(N_samples) if N_samples > 0 else self.nSamples
+        jitter = None
+        if is_train:
+            jitter = to_device_async(torch.rand(rays_d.reshape(-1, 3).shape[0], 1), self._all_params()[0].device).reshape(-1).contiguous()
+        pts, z, valid = self._sample(rays_o, rays_d, N, jitter, False)
+        lead = tuple(rays_o.shape[:-1])
+        return pts.reshape(lead + (N, 3)), z.reshape(lead + (N,)), valid.reshape(lead + (N,))
+
+    def sample_ray_ndc(self, rays_o, rays_d, is_train=True, N_samples=-1):
+        """models/tensorBase.py:293-302: one depth row ``linspace(near, far, N)`` for all rays (+ one shared jitter row drawn on the rays'
+        device in train mode); returns ``(rays_pts [R,N,3], interpx [1,N], ~mask_outbbox [R,N])``."""
+        N = int(N_samples) if N_samples > 0 else self.nSamples
+        near, far = self.near_far
+        dev = self._all_params()[0].device
+        interpx = torch.linspace(near, far, N).unsqueeze(0).to(rays_o)
+        if is_train:
+            interpx += torch.rand_like(interpx).to(rays_o) * ((far - near) / N)
+        table = interpx.to(dev).reshape(-1).contiguous().float()
+        pts, _, valid = self._sample(rays_o, rays_d, N, table, True)
+        lead = tuple(rays_o.shape[:-1])
+        return pts.reshape(lead + (N, 3)), interpx, valid.reshape(lead + (N,))
 
     def update_stepSize(self, gridSize):
         """models/tensorBase.py:220-231, same fp32 tensor arithmetic — evaluated on the HOST so that the scalars that
@@ -353,58 +440,6 @@ class TensorVMSplit(nn.Module):
             lib = _lib.load()
             d = self._desc()
             _lib.check(lib.t2n_field_set_desc(self._handle, C.byref(d)), "t2n_field_set_desc")
-
-    # ---- optimiser / regulariser surface ----------------------------------------------------------------------------
-    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
-        """models/tensoRF.py:164-174: same groups, same order."""
-        groups = [{"params": self.density_line, "lr": lr_init_spatialxyz},
-                  {"params": self.density_plane, "lr": lr_init_spatialxyz},
-                  {"params": self.app_line, "lr": lr_init_spatialxyz},
-                  {"params": self.app_plane, "lr": lr_init_spatialxyz},
-                  {"params": self.basis_mat.parameters(), "lr": lr_init_network}]
-        if isinstance(self.renderModule, nn.Module):
-            groups += [{"params": self.renderModule.parameters(), "lr": lr_init_network}]
-        return groups
-
-    def TV_loss_density(self, reg):
-        """models/tensoRF.py:193-197. A TVLoss-like `reg` on device planes runs as two HIP kernels per plane (losses.tv_planes)."""
-        from .losses import tv_planes
-        fused = tv_planes(reg, list(self.density_plane), 1e-2)
-        if fused is not None:
-            return fused
-        total = 0
-        for p in self.density_plane:
-            total = total + reg(p) * 1e-2
-        return total
-
-    def TV_loss_app(self, reg):
-        """models/tensoRF.py:199-203."""
-        from .losses import tv_planes
-        fused = tv_planes(reg, list(self.app_plane), 1e-2)
-        if fused is not None:
-            return fused
-        total = 0
-        for p in self.app_plane:
-            total = total + reg(p) * 1e-2
-        return total
-
-    def density_L1(self):
-        total = 0
-        for p, l in zip(self.density_plane, self.density_line):
-            total = total + torch.mean(torch.abs(p)) + torch.mean(torch.abs(l))
-        return total
-
-    def vectorDiffs(self, vector_comps):
-        total = 0
-        for v in vector_comps:
-            n_comp, n_size = v.shape[1:-1]
-            m = v.view(n_comp, n_size)
-            dotp = m @ m.transpose(-1, -2)
-            total = total + torch.mean(torch.abs(dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]))
-        return total
-
-    def vector_comp_diffs(self):
-        return self.vectorDiffs(self.density_line) + self.vectorDiffs(self.app_line)
 
     # ---- checkpoint surface (models/tensorBase.py:251-290) --------------------------------------------------------------
     def get_kwargs(self):
@@ -475,21 +510,21 @@ class TensorVMSplit(nn.Module):
         if max(self.density_n_comp) > self.KERNEL_DEN or max(self.app_n_comp) > self.KERNEL_APP:
             raise T2NError(f"n_comp {self.density_n_comp} / {self.app_n_comp}: the HIP kernels hold at most {self.KERNEL_DEN} density and "
                            f"{self.KERNEL_APP} appearance components per plane (smaller counts run zero-padded)")
-        if self.renderModule is not None and self.featureC > self.KERNEL_FC:
+        if isinstance(self.renderModule, nn.Module) and self.featureC > self.KERNEL_FC:
             raise T2NError(f"featureC {self.featureC}: the HIP heads hold at most {self.KERNEL_FC} hidden units (smaller run zero-padded)")
         if self.shadingMode == "MLP_Fea_noview":
             if self.app_dim > self.KERNEL_DIM or self.fea_pe > self.KERNEL_PE or self.fea_pe < 0:
                 raise T2NError(f"MLP_Fea_noview with app_dim {self.app_dim} / fea_pe {self.fea_pe}: at most {self.KERNEL_DIM} / "
                                f"{self.KERNEL_PE} (smaller run zero-padded)")
             return self.KERNEL_DEN, self.KERNEL_APP, self.KERNEL_DIM, self.KERNEL_PE, self.KERNEL_FC
-        return self.KERNEL_DEN, self.KERNEL_APP, self.app_dim, self.fea_pe, self.KERNEL_FC if self.renderModule is not None else self.featureC
+        return self.KERNEL_DEN, self.KERNEL_APP, self.app_dim, self.fea_pe, self.KERNEL_FC if isinstance(self.renderModule, nn.Module) else self.featureC
 
     def _needs_embed(self):
         flag = self.__dict__.get("_embed_flag")
         if flag is None:     # (component counts and head sizes are fixed at construction)
             kd, ka, kdim, kpe, kfc = self._kernel_shape()
             flag = (any(c != kd for c in self.density_n_comp) or any(c != ka for c in self.app_n_comp) or kdim != self.app_dim
-                    or kpe != self.fea_pe or (self.renderModule is not None and kfc != self.featureC))
+                    or kpe != self.fea_pe or (isinstance(self.renderModule, nn.Module) and kfc != self.featureC))
             self.__dict__["_embed_flag"] = flag
         return flag
 
@@ -531,7 +566,7 @@ class TensorVMSplit(nn.Module):
             Bk = B.new_zeros((kdim, 3 * ka))
             Bk[: self.app_dim, cols] = B
             out.append(Bk)
-            if self.renderModule is not None:
+            if isinstance(self.renderModule, nn.Module):
                 w0, b0, w1, b1, w2, b2 = leaves[13:19]
                 fc = self.featureC
                 if self.shadingMode == "MLP_Fea_noview":
@@ -703,12 +738,15 @@ class TensorVMSplit(nn.Module):
             _lib.check(lib.t2n_field_create(C.byref(d), C.byref(h)), "t2n_field_create")
             self._handle = h
             self._precision_set = None
+            self._term_set = None
             self._storage_set = None
             self._frame_w_set = None
             self._alpha_key = "unset"
+        queued = False     # device work queued by this call (mask / parameter uploads)
         mask = self.alphaMask
         mkey = None if mask is None else (mask.alpha_volume.data_ptr(), mask.alpha_volume._version, tuple(mask.alpha_volume.shape))
         if getattr(self, "_alpha_key", "unset") != mkey:
+            queued = True
             with torch.cuda.device(dev):
                 if mask is None:
                     _lib.check(lib.t2n_field_set_alpha_mask(self._handle, None, 0, 0, 0, None, None, _lib.current_stream_ptr(dev)),
@@ -730,6 +768,10 @@ class TensorVMSplit(nn.Module):
             _lib.check(lib.t2n_field_set_mlp_precision(self._handle, 1 if self.mlp_exact_fp32 else 0),
                        "t2n_field_set_mlp_precision")
             self._precision_set = bool(self.mlp_exact_fp32)
+        et = float(self.early_termination or 0.0)
+        if getattr(self, "_term_set", None) != et:
+            _lib.check(lib.t2n_field_set_early_termination(self._handle, et), "t2n_field_set_early_termination")
+            self._term_set = et
         if self.factor_storage not in ("fp32", "bf16"):
             raise T2NError(f"factor_storage {self.factor_storage!r}: expected 'fp32' or 'bf16'")
         if getattr(self, "_storage_set", None) != self.factor_storage:
@@ -750,6 +792,18 @@ class TensorVMSplit(nn.Module):
                                "t2n_field_upload")
             self._uploaded_key = key
             self._device_factor_key = key[:12]
+            queued = True
+        # The uploads above are asynchronous kernels on the CALLER's stream. Renders of this field on other streams (frames in flight
+        # on alternating streams: renderer._FramePipe) must not read half-written factor / head / mask copies: an event behind the
+        # upload, waited for once by every other stream that comes through here.
+        cur = torch.cuda.current_stream(dev)
+        if queued:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._upload_event, self._upload_seen = ev, {int(cur.cuda_stream)}
+        elif getattr(self, "_upload_event", None) is not None and int(cur.cuda_stream) not in self._upload_seen:
+            cur.wait_event(self._upload_event)
+            self._upload_seen.add(int(cur.cuda_stream))
         return self._handle
 
     def __del__(self):
@@ -772,10 +826,6 @@ class TensorVMSplit(nn.Module):
     # ---- stage methods (reference names) ---------------------------------------------------------------------------------
     def normalize_coord(self, xyz_sampled):
         return (xyz_sampled - self.aabb[0]) * self.invaabbSize - 1
-
-    def compute_densityfeature(self, xyz_sampled):
-        """models/tensoRF.py:205-220 — xyz already normalised to [-1,1]."""
-        return self._density_at(xyz_sampled, want_sigma=False)
 
     def feature2density(self, density_features):
         if self.fea2denseAct == "softplus":
@@ -823,10 +873,6 @@ class TensorVMSplit(nn.Module):
             _lib.check(lib.t2n_shade_at(h, _lib.ptr(xyz), _lib.ptr(vd), n, _lib.ptr(feat), _lib.ptr(rgb), _lib.ptr(ws),
                                         ws.numel(), _lib.current_stream_ptr(dev)), "t2n_shade_at")
         return feat, rgb
-
-    def compute_appfeature(self, xyz_sampled):
-        """models/tensoRF.py:223-239."""
-        return self.shade(xyz_sampled, want_rgb=False)[0]
 
     @torch.no_grad()
     def filtering_rays(self, all_rays, all_rgbs, all_depth=None, N_samples=256, chunk=10240 * 5, bbox_only=False):
@@ -928,63 +974,6 @@ class TensorVMSplit(nn.Module):
         total = int(g[0] * g[1] * g[2])
         print(f"bbox: {lo, hi} alpha rest %%%f" % (float(vol.sum()) / total * 100))
         return new_aabb
-
-    @torch.no_grad()
-    def up_sampling_VM(self, plane_coef, line_coef, res_target):
-        """models/tensoRF.py:258-272: bilinear (align_corners=True) resize of the three planes and lines."""
-        lib = _lib.load()
-        res = [int(x) for x in res_target]
-
-        def resize(t, Hout, Wout):
-            t = t.detach().contiguous().float()
-            _, Cn, Hin, Win = t.shape
-            out = torch.empty((1, Cn, Hout, Wout), device=t.device, dtype=torch.float32)
-            with torch.cuda.device(t.device):
-                _lib.check(lib.t2n_upsample_bilinear(_lib.ptr(t), Cn, Hin, Win, _lib.ptr(out), Hout, Wout,
-                                                     _lib.current_stream_ptr(t.device)), "t2n_upsample_bilinear")
-            return out
-
-        for i in range(3):
-            m0, m1 = MAT_MODE[i]
-            plane_coef[i] = nn.Parameter(resize(plane_coef[i].data, res[m1], res[m0]))
-            line_coef[i] = nn.Parameter(resize(line_coef[i].data, res[VEC_MODE[i]], 1))
-        return plane_coef, line_coef
-
-    @torch.no_grad()
-    def upsample_volume_grid(self, res_target):
-        """models/tensoRF.py:274-280."""
-        self.app_plane, self.app_line = self.up_sampling_VM(self.app_plane, self.app_line, res_target)
-        self.density_plane, self.density_line = self.up_sampling_VM(self.density_plane, self.density_line, res_target)
-        self._drop_handle()
-        self.update_stepSize(res_target)
-        print(f"upsamping to {res_target}")
-
-    @torch.no_grad()
-    def shrink(self, new_aabb):
-        """models/tensoRF.py:282-320: crop every factor to the voxel range covering new_aabb (host index arithmetic +
-        tensor slicing; nothing to compute on the device)."""
-        new_aabb = torch.as_tensor(new_aabb, dtype=torch.float32).to(self.aabb.device)
-        xyz_min, xyz_max = new_aabb
-        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
-        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
-        b_r = torch.stack([b_r, self.gridSize]).amin(0)
-        for i in range(3):
-            v = VEC_MODE[i]
-            self.density_line[i] = nn.Parameter(self.density_line[i].data[..., t_l[v]:b_r[v], :].contiguous())
-            self.app_line[i] = nn.Parameter(self.app_line[i].data[..., t_l[v]:b_r[v], :].contiguous())
-            m0, m1 = MAT_MODE[i]
-            self.density_plane[i] = nn.Parameter(self.density_plane[i].data[..., t_l[m1]:b_r[m1], t_l[m0]:b_r[m0]].contiguous())
-            self.app_plane[i] = nn.Parameter(self.app_plane[i].data[..., t_l[m1]:b_r[m1], t_l[m0]:b_r[m0]].contiguous())
-        if self.alphaMask is None or not torch.all(self.alphaMask.gridSize.to(self.gridSize.device) == self.gridSize):
-            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
-            correct_aabb = torch.zeros_like(new_aabb)
-            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
-            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
-            new_aabb = correct_aabb
-        newSize = b_r - t_l
-        self.aabb = new_aabb
-        self._drop_handle()
-        self.update_stepSize((int(newSize[0]), int(newSize[1]), int(newSize[2])))
 
     # ---- the render call ----------------------------------------------------------------------------------------------------
     def forward(self, rays_chunk, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1, frame_width=None):
@@ -1189,6 +1178,145 @@ class TensorVMSplit(nn.Module):
                 "list_retry": s[_lib.STAT_LIST_RETRY]}
 
 
+class TensorVMSplit(TensorBase):
+    """models/tensoRF.py:139-304: three plane / line factor pairs per quantity, stored as separate tensors."""
+
+    def __init__(self, aabb, gridSize, device, **kargs):
+        super().__init__(aabb, gridSize, device, **kargs)
+
+    # ---- containers (models/tensoRF.py:144-160) -------------------------------------------------------------------
+    def init_svd_volume(self, res, device):
+        self.density_plane, self.density_line = self.init_one_svd(self.density_n_comp, self.gridSize, 0.1, device)
+        self.app_plane, self.app_line = self.init_one_svd(self.app_n_comp, self.gridSize, 0.1, device)
+        self.basis_mat = nn.Linear(sum(self.app_n_comp), self.app_dim, bias=False).to(device)
+
+    def init_one_svd(self, n_component, gridSize, scale, device):
+        planes, lines = [], []
+        g = [int(x) for x in gridSize]
+        for i in range(3):
+            m0, m1 = MAT_MODE[i]
+            planes.append(nn.Parameter(scale * torch.randn((1, n_component[i], g[m1], g[m0]))))
+            lines.append(nn.Parameter(scale * torch.randn((1, n_component[i], g[VEC_MODE[i]], 1))))
+        return nn.ParameterList(planes).to(device), nn.ParameterList(lines).to(device)
+
+    # ---- optimiser / regulariser surface ----------------------------------------------------------------------------
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        """models/tensoRF.py:164-174: same groups, same order."""
+        groups = [{"params": self.density_line, "lr": lr_init_spatialxyz},
+                  {"params": self.density_plane, "lr": lr_init_spatialxyz},
+                  {"params": self.app_line, "lr": lr_init_spatialxyz},
+                  {"params": self.app_plane, "lr": lr_init_spatialxyz},
+                  {"params": self.basis_mat.parameters(), "lr": lr_init_network}]
+        if isinstance(self.renderModule, nn.Module):
+            groups += [{"params": self.renderModule.parameters(), "lr": lr_init_network}]
+        return groups
+
+    def TV_loss_density(self, reg):
+        """models/tensoRF.py:193-197. A TVLoss-like `reg` on device planes runs as two HIP kernels per plane (losses.tv_planes)."""
+        from .losses import tv_planes
+        fused = tv_planes(reg, list(self.density_plane), 1e-2)
+        if fused is not None:
+            return fused
+        total = 0
+        for p in self.density_plane:
+            total = total + reg(p) * 1e-2
+        return total
+
+    def TV_loss_app(self, reg):
+        """models/tensoRF.py:199-203."""
+        from .losses import tv_planes
+        fused = tv_planes(reg, list(self.app_plane), 1e-2)
+        if fused is not None:
+            return fused
+        total = 0
+        for p in self.app_plane:
+            total = total + reg(p) * 1e-2
+        return total
+
+    def density_L1(self):
+        total = 0
+        for p, l in zip(self.density_plane, self.density_line):
+            total = total + torch.mean(torch.abs(p)) + torch.mean(torch.abs(l))
+        return total
+
+    def vectorDiffs(self, vector_comps):
+        total = 0
+        for v in vector_comps:
+            n_comp, n_size = v.shape[1:-1]
+            m = v.view(n_comp, n_size)
+            dotp = m @ m.transpose(-1, -2)
+            total = total + torch.mean(torch.abs(dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]))
+        return total
+
+    def vector_comp_diffs(self):
+        return self.vectorDiffs(self.density_line) + self.vectorDiffs(self.app_line)
+
+    def compute_densityfeature(self, xyz_sampled):
+        """models/tensoRF.py:205-220 — xyz already normalised to [-1,1]."""
+        return self._density_at(xyz_sampled, want_sigma=False)
+
+    def compute_appfeature(self, xyz_sampled):
+        """models/tensoRF.py:223-239."""
+        return self.shade(xyz_sampled, want_rgb=False)[0]
+
+    @torch.no_grad()
+    def up_sampling_VM(self, plane_coef, line_coef, res_target):
+        """models/tensoRF.py:258-272: bilinear (align_corners=True) resize of the three planes and lines."""
+        lib = _lib.load()
+        res = [int(x) for x in res_target]
+
+        def resize(t, Hout, Wout):
+            t = t.detach().contiguous().float()
+            _, Cn, Hin, Win = t.shape
+            out = torch.empty((1, Cn, Hout, Wout), device=t.device, dtype=torch.float32)
+            with torch.cuda.device(t.device):
+                _lib.check(lib.t2n_upsample_bilinear(_lib.ptr(t), Cn, Hin, Win, _lib.ptr(out), Hout, Wout,
+                                                     _lib.current_stream_ptr(t.device)), "t2n_upsample_bilinear")
+            return out
+
+        for i in range(3):
+            m0, m1 = MAT_MODE[i]
+            plane_coef[i] = nn.Parameter(resize(plane_coef[i].data, res[m1], res[m0]))
+            line_coef[i] = nn.Parameter(resize(line_coef[i].data, res[VEC_MODE[i]], 1))
+        return plane_coef, line_coef
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        """models/tensoRF.py:274-280."""
+        self.app_plane, self.app_line = self.up_sampling_VM(self.app_plane, self.app_line, res_target)
+        self.density_plane, self.density_line = self.up_sampling_VM(self.density_plane, self.density_line, res_target)
+        self._drop_handle()
+        self.update_stepSize(res_target)
+        print(f"upsamping to {res_target}")
+
+    @torch.no_grad()
+    def shrink(self, new_aabb):
+        """models/tensoRF.py:282-320: crop every factor to the voxel range covering new_aabb (host index arithmetic +
+        tensor slicing; nothing to compute on the device)."""
+        new_aabb = torch.as_tensor(new_aabb, dtype=torch.float32).to(self.aabb.device)
+        xyz_min, xyz_max = new_aabb
+        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
+        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+        b_r = torch.stack([b_r, self.gridSize]).amin(0)
+        for i in range(3):
+            v = VEC_MODE[i]
+            self.density_line[i] = nn.Parameter(self.density_line[i].data[..., t_l[v]:b_r[v], :].contiguous())
+            self.app_line[i] = nn.Parameter(self.app_line[i].data[..., t_l[v]:b_r[v], :].contiguous())
+            m0, m1 = MAT_MODE[i]
+            self.density_plane[i] = nn.Parameter(self.density_plane[i].data[..., t_l[m1]:b_r[m1], t_l[m0]:b_r[m0]].contiguous())
+            self.app_plane[i] = nn.Parameter(self.app_plane[i].data[..., t_l[m1]:b_r[m1], t_l[m0]:b_r[m0]].contiguous())
+        if self.alphaMask is None or not torch.all(self.alphaMask.gridSize.to(self.gridSize.device) == self.gridSize):
+            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
+            correct_aabb = torch.zeros_like(new_aabb)
+            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
+            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
+            new_aabb = correct_aabb
+        newSize = b_r - t_l
+        self.aabb = new_aabb
+        self._drop_handle()
+        self.update_stepSize((int(newSize[0]), int(newSize[1]), int(newSize[2])))
+
+
 class TensorVM(TensorVMSplit):
     """models/tensoRF.py:4-136: the stacked-coefficient VM field — ``plane_coef [3, A + D, res, res]`` and
     ``line_coef [3, A + D, res, 1]`` with the appearance components first (``[:, :A]``) and the density components last
@@ -1198,12 +1326,16 @@ class TensorVM(TensorVMSplit):
     TensoRF (the reference class cannot be built from this driver's list-valued options) and must be 16 / 48 here; the
     grid is cubic (``res = gridSize[0]``, models/tensoRF.py:9-14)."""
 
-    def __init__(self, aabb, gridSize, device, density_n_comp=16, appearance_n_comp=48, **kargs):
-        d, a = int(density_n_comp), int(appearance_n_comp)
+    def __init__(self, aabb, gridSize, device, **kargs):
+        d, a = int(kargs.pop("density_n_comp", 16)), int(kargs.pop("appearance_n_comp", 48))
         if len(set(int(g) for g in gridSize)) != 1:
             raise T2NError("TensorVM stores res x res planes for all three pairs: the grid must be cubic")
         super().__init__(aabb, gridSize, device, density_n_comp=[d] * 3, appearance_n_comp=[a] * 3, **kargs)
         self._d, self._a = d, a
+
+    def compute_features(self, xyz_sampled):
+        """models/tensoRF.py:24-44: ``(sigma_feature [n], app_features [n, app_dim])`` at normalised points, both through the gather kernels."""
+        return self.compute_densityfeature(xyz_sampled), self.compute_appfeature(xyz_sampled)
 
     def init_svd_volume(self, res, device):
         res = int(res)
@@ -1220,7 +1352,7 @@ class TensorVM(TensorVMSplit):
         return groups
 
     def _mlp_params(self):
-        if self.renderModule is None:
+        if not isinstance(self.renderModule, nn.Module):
             return []
         m = self.renderModule.mlp
         return [m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias]
@@ -1305,6 +1437,9 @@ class TensorCP(TensorVMSplit):
     differentiable torch ops, so autograd carries the kernels' plane / line gradients back to the six line parameters.
     "Supported cheaply" (SURVEY.md 8a footnote): two thirds of the gathers read zeros; n_comp must be 16 / 48."""
 
+    def __init__(self, aabb, gridSize, device, **kargs):
+        super().__init__(aabb, gridSize, device, **kargs)
+
     def init_svd_volume(self, res, device):
         if self.density_n_comp[0] != 16 or self.app_n_comp[0] != 48:
             raise T2NError("TensorCP on the HIP kernels needs density_n_comp[0] == 16 and appearance_n_comp[0] == 48")
@@ -1326,7 +1461,7 @@ class TensorCP(TensorVMSplit):
 
     def _leaves(self):
         ps = list(self.density_line) + list(self.app_line) + [self.basis_mat.weight]
-        if self.renderModule is not None:
+        if isinstance(self.renderModule, nn.Module):
             m = self.renderModule.mlp
             ps += [m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias]
         return ps

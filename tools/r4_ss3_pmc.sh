@@ -1,0 +1,19 @@
+#!/bin/bash
+# SQ / instruction-cache counters of the head kernel (one counter set per pass, kernel-trace free)
+OUT=gpurun_out/${1:-r4_ss3_pmc}; shift
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+cd $REPO
+i=0
+for set in \
+  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
+  "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+  "SQ_IFETCH SQ_IFETCH_LEVEL SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE" \
+  "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" \
+  "SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT SQ_INST_LEVEL_VMEM SQ_WAVES_EQ_64 SQ_INSTS_WAVE32_LDS SQ_THREAD_CYCLES_VALU"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pass$i -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --quick "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
+done
+python3 tools/pmc_summary.py $OUT > $OUT/summary.txt
+grep -A60 "k_mlp_ss" $OUT/summary.txt | head -80
