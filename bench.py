@@ -53,9 +53,42 @@ BYTES_PER_APP = 3456
 BYTES_PER_RAY = 40
 FLOP_PER_APP = 131168    # 2*(144*27 + 351*128 + 128*128 + 128*3)
 FLOP_HEAD = 123392       # 2*(351*128 + 128*128 + 128*3): the MLP head without basis_mat
-PMC_FILE = "round3_pmc.json"
+PMC_FILES = ("round4_pmc.json", "round3_pmc.json")   # the newest committed counter record is used (profiles/)
 MFMA_F32_PEAK_TF = 157.3
 MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def kernel_source_sha16():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, include/t2n.h), first 16 hex digits: ties a counter record to the code it was
+    taken on (tools/pmc_round2.py stores the same value in the record)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "text2nerf_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "text2nerf_amd", "csrc", "*.h")) +
+                    [os.path.join(ROOT, "include", "t2n.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    """(counters, record): the per-launch PMC means of a SEPARATE profiled run of this command (rocprofv3 --pmc cannot ride along with a
+    timed run) and what identifies that record: file, git blob id, the kernel-source hash it was taken on and whether that still is the
+    hash of the sources this process runs."""
+    import hashlib
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            raw = open(path, "rb").read()
+            pmc = json.loads(raw)
+        except Exception:
+            continue
+        blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()
+        now = kernel_source_sha16()
+        rec = {"file": "profiles/" + name, "git_blob": blob, "taken_on_kernel_source_sha16": pmc.get("_kernel_source_sha16"),
+               "current_kernel_source_sha16": now, "stale": pmc.get("_kernel_source_sha16") != now}
+        return pmc, rec
+    return {}, {"file": None}
 
 
 def reference_poses(name, n=None):
@@ -169,13 +202,15 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
               torch.from_numpy(g.normal(0, 0.05, (allrays.shape[0], 3)).astype(np.float32))).clamp(0, 1)
     alldepth = dep_s.cpu().repeat_interleave(4, 0)[: allrays.shape[0]] + torch.from_numpy(
         g.normal(0, 0.05, (allrays.shape[0],)).astype(np.float32))
-    if fused_optim or fused_step:   # TV gradient + Adam as HIP streaming kernels (text2nerf_amd/optim.py)
-        from text2nerf_amd.optim import TVAdam
-        # the plane / line tensors are stepped on the device's channel-last copies from device-side gradients; data-parallel runs
-        # all-reduce that contiguous gradient buffer in place
-        opt = TVAdam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=field)
-    else:
-        opt = torch.optim.Adam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    def make_opt():
+        if fused_optim or fused_step:   # TV gradient + Adam as HIP streaming kernels (text2nerf_amd/optim.py)
+            from text2nerf_amd.optim import TVAdam
+            # the plane / line tensors are stepped on the device's channel-last copies from device-side gradients; data-parallel runs
+            # all-reduce that contiguous gradient buffer in place
+            return TVAdam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=field)
+        return torch.optim.Adam(field.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    opt = make_opt()
+    init_state = {k: v.detach().clone() for k, v in field.state_dict().items()}   # every timed block starts from these parameters
     tv, tl = TVLoss(), TransMittanceLoss_mask(dev)
     np.random.seed(1024)
     torch.manual_seed(1024)
@@ -240,19 +275,27 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    blocks_ms = None
     if dist is None and trace is None:
         # the loop's host side runs under a cgroup CPU quota: one throttled 100-ms period inside a 25-50 ms timed block doubles it.
-        # One more block of the same length and the faster of the two is reported (both on stderr). Not more: the noisy targets turn the
-        # field into fog after ~45 steps (114 000 appearance samples until step 40, 311 000 at 50, 674 000 at 60: 2.1 ms per fused step;
-        # tools/experiments/train_sample_growth.py), which is another workload
+        # THREE blocks, each from the same initial parameters and a fresh optimiser (the noisy targets turn the field into fog after
+        # ~45 steps — 114 000 appearance samples until step 40, 674 000 at 60, tools/experiments/train_sample_growth.py — so later
+        # steps of one trajectory would be another workload), warm-up included; the MEDIAN is reported and all three are in the line
         blocks = [dt]
-        t0 = time.perf_counter()
-        for k in range(iters):
-            loss = it(warmup + iters + k)
-        torch.cuda.synchronize()
-        blocks.append(time.perf_counter() - t0)
-        print("[bench] train blocks of %d iterations (ms/iter): %s" % (iters, [round(b / iters * 1e3, 3) for b in blocks]), file=sys.stderr, flush=True)
-        dt = min(blocks)
+        for _ in range(2):
+            field.load_state_dict(init_state)
+            opt = make_opt()
+            for k in range(warmup):
+                it(k)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(iters):
+                loss = it(warmup + k)
+            torch.cuda.synchronize()
+            blocks.append(time.perf_counter() - t0)
+        blocks_ms = [round(b / iters * 1e3, 4) for b in blocks]
+        print("[bench] train blocks of %d iterations (ms/iter): %s" % (iters, blocks_ms), file=sys.stderr, flush=True)
+        dt = sorted(blocks)[1]
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -265,17 +308,22 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
         return {"ms_per_iter": dt / iters * 1e3, "rays": batch}
     if resident:
         return {"train_iters_per_s_fused_step_resident": iters / dt, "train_ms_per_iter_fused_step_resident": dt / iters * 1e3,
+                "train_ms_per_iter_fused_step_resident_blocks": blocks_ms,
                 "train_step_fused_resident": "train_step with the training set (rays, colours, depths of the 9 views) resident in HBM: the "
                                              "batch is gathered on the device, only the jitter draws (CPU generator, like the reference) "
                                              "cross PCIe"}
     if fused_step:
         return {"train_iters_per_s_fused_step": iters / dt, "train_ms_per_iter_fused_step": dt / iters * 1e3,
+                "train_ms_per_iter_fused_step_blocks": blocks_ms,
                 "train_step_fused": "TensorVMSplit.train_step: no autograd graph, loss + its gradients in one kernel, event-based row "
                                     f"count, TV + Adam on the device copies; loss {float(loss.detach()):.4f}"}
     if fused_optim:
-        return {"train_iters_per_s_fused_optim": iters / dt, "train_ms_per_iter_fused_optim": dt / iters * 1e3}
+        return {"train_iters_per_s_fused_optim": iters / dt, "train_ms_per_iter_fused_optim": dt / iters * 1e3,
+                "train_ms_per_iter_fused_optim_blocks": blocks_ms}
     return {"train_iters_per_s": iters / dt, "train_ms_per_iter": dt / iters * 1e3, "train_iters": iters,
-            "train_timing": "the faster of two consecutive blocks of train_iters iterations (every train_* figure; both blocks on stderr)",
+            "train_ms_per_iter_blocks": blocks_ms,
+            "train_timing": "MEDIAN of three blocks of train_iters iterations, each from the same initial parameters with a fresh optimiser "
+                            "(every train_* figure; the three block times are in *_blocks)",
             "train_step": f"C3-shaped: {batch} rays x {n_samples} samples, fwd+bwd HIP, TV+Adam torch (reference-form "
                           f"step), loss {float(loss.detach()):.4f}; *_fused_optim: TV gradient + Adam as HIP kernels",
             "train_appearance_samples": field.stats()["appearance"]}
@@ -385,18 +433,40 @@ def scaling_prediction(field, dev, fused_ms, G=8):
     return pred
 
 
+def count_gpus_sysfs():
+    """GPUs of this node WITHOUT touching the HIP runtime: KFD topology nodes with SIMDs (CPU nodes have simd_count 0), narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set. 0 without a KFD topology, None when it cannot be parsed."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return 0       # no KFD topology: no AMD GPU is visible to this process
+    n = 0
+    for f in nodes:
+        try:
+            props = dict(l.split()[:2] for l in open(f).read().splitlines() if len(l.split()) >= 2)
+            n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+        except Exception:
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(n):
-    """`python bench.py --gpus N` without a launcher: this process — which has made NO GPU call (importing torch and counting
-    devices do not initialise HIP) — starts N fresh child ranks of the same command (RANK / LOCAL_RANK / WORLD_SIZE /
+    """`python bench.py --gpus N` without a launcher: this process — which makes NO GPU call (it imports torch but never asks the
+    runtime anything: the device count comes from sysfs) — starts N fresh child ranks of the same command (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR=127.0.0.1 / a free MASTER_PORT), relays rank 0's stdout (the ONE JSON line), lets the ranks' stderr through and
     returns the first non-zero exit code (the other ranks are then killed by PID). Nothing is exec'ed and no process that has
     touched the GPU is re-launched. The `python -m torch.distributed.run ... bench.py --gpus N` form (WORLD_SIZE already set)
     never comes through here."""
     import socket
     import subprocess
+    import threading
     same = bool(os.environ.get("T2N_BENCH_SAME_DEVICE"))
-    have = torch.cuda.device_count()
-    if have < n and not same:
+    have = count_gpus_sysfs()
+    if have is not None and have < n and not same:
         print(f"bench.py --gpus {n}: this node shows {have} GPU(s); one rank per GPU is required "
               f"(T2N_BENCH_SAME_DEVICE=1 T2N_BENCH_BACKEND=gloo runs the N>1 code path on one device for testing)", file=sys.stderr)
         return 2
@@ -411,6 +481,11 @@ def self_launch(n):
         env["OMP_NUM_THREADS"] = str(max(1, HOST_CORES // n))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # rank 0's stdout (the JSON line, plus whatever a library prints there) is drained WHILE the ranks run: a full 64-KiB pipe would
+    # block rank 0 in write() with its peers waiting in a collective
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     deadline = time.time() + float(os.environ.get("T2N_BENCH_LAUNCH_DEADLINE_S", "1500"))
     rc = 0
     while any(p.poll() is None for p in procs):
@@ -422,12 +497,12 @@ def self_launch(n):
                     p.kill()          # the exact children started above
             break
         time.sleep(0.2)
-    out = procs[0].stdout.read() if procs[0].stdout else ""
     for p in procs:
         p.wait()
         if rc == 0 and p.returncode != 0:
             rc = p.returncode
-    sys.stdout.write(out)
+    reader.join(timeout=10)
+    sys.stdout.write("".join(chunks))
     sys.stdout.flush()
     return rc
 
@@ -643,12 +718,7 @@ def main():
         k_ms = {k: v[0] / max(v[1], 1) for k, v in timing.items()}        # avg ms per launch
         k_per_step = {k: v[1] / args.steps for k, v in timing.items()}     # launches per step
         frame_ms = {k: v[0] / args.steps for k, v in timing.items()}       # kernel ms per frame
-        pmc = {}
-        try:   # per-launch PMC figures of the same command (tools/pmc_traffic.sh, tools/pmc_shade.sh), committed under profiles/
-            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as fh:
-                pmc = json.load(fh)
-        except Exception:
-            pass
+        pmc, pmc_rec = load_pmc()   # per-launch PMC figures of the same command (tools/pmc_round2.sh), committed under profiles/
         split = not field.mlp_exact_fp32
         two_kernel = "app_features" in frame_ms    # default path: gather + basis kernel, then the sample-stationary head
         roofs = {}
@@ -660,7 +730,7 @@ def main():
             alg = flop_per * A / launches
             t = k_ms["shade"] * 1e-3
             peak = MFMA_F16_PEAK_TF if split else MFMA_F32_PEAK_TF
-            kname = "k_mlp_ss" if two_kernel else ("k_shade_coop" if split else "k_shade<exact>")
+            kname = "k_mlp_ss3" if two_kernel else ("k_shade_coop" if split else "k_shade<exact>")
             roofs["shade"] = {
                 "bound": "mfma", "kernel": kname, "achieved": alg / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": alg / t / 1e12 / peak, "traffic": pmc.get(kname, {}).get("hbm_bytes_per_launch"),
@@ -668,9 +738,9 @@ def main():
                 # every fp32 product runs as three f16 MFMA products of hi/lo splits: what the matrix pipe actually executes
                 "executed_frac": (3.0 if split else 1.0) * alg / t / 1e12 / peak,
                 "mfma_busy_frac_pmc": pmc.get(kname, {}).get("mfma_busy_frac"),
-                # what a bare stream of v_mfma_f32_32x32x16_f16 sustains on this part (two waves per SIMD, no other instructions,
+                # what a bare stream of v_mfma_f32_32x32x16_f16 sustains on this part (no other instructions,
                 # tools/experiments/mfma_fillers.hip: 16.2 ns per MFMA and SIMD = 2.07 PFLOP/s at the clock the chip holds under
-                # that load) - the kernel's practical ceiling; with 4-6 other instructions per MFMA the same loop runs 18.7-19.4 ns
+                # that load) - the kernel's practical ceiling; profiles/round4_head_issue_accounting.txt says where the rest goes
                 "executed_frac_of_sustained_mfma_rate": ((3.0 * alg / t / 1e12 / 2070.0) if split else None),
                 "note": ("frac = algorithmic fp32-equivalent flop (123 392 per appearance sample: 351x128 + 128x128 + 128x3 MACs) / time / "
                          "dense f16 MFMA peak; executed_frac counts the 3 f16 products per fp32 product" if split else "exact fp32 MFMA")}
@@ -728,6 +798,10 @@ def main():
                                                                "next frame's render)") if world > 1 else ""),
                        "kernel_ms_per_frame": frame_ms,
                        "kernel_rooflines": roofs,
+                       # which counter record fed roofline.traffic / mfma_busy_frac_pmc / the march's `achieved` (not measured in THIS run)
+                       "pmc_record": pmc_rec,
+                       "value_evaluated_samples_per_s": world * V * args.steps / dt,
+                       "early_termination_eps": float(getattr(field, "early_termination", 0.0) or 0.0),
                        "scaling_measured": "the builder has 1-GPU boxes only: see scaling_prediction (N = 1 line) for what one GPU can "
                                            "say about N = 8, and rccl (N > 1 lines) for the devices the ranks actually ran on"},
             "roofline": roof,
@@ -839,7 +913,40 @@ def main():
                                "achieved_TFLOPs": FLOP_PER_APP * A / t / 1e12, "peak_TFLOPs": MFMA_F32_PEAK_TF,
                                "frac": FLOP_PER_APP * A / t / 1e12 / MFMA_F32_PEAK_TF})
                 out["exact_fp32"] = ex
+                # the strict same-arithmetic figure travels in `config` (the driver keeps config, unknown top-level keys only by name)
+                out["config"]["exact_fp32_ms_per_step"] = ms_exact
+                out["config"]["exact_fp32_value_ray_samples_per_s"] = R * N / (ms_exact * 1e-3)
+                out["config"]["exact_fp32_shade_frac_of_f32_mfma_peak"] = ex.get("frac")
         if world == 1 and not c4 and not args.quick:
+            # early ray termination (eval renders without weights / z_vals; the mirror's default eps 1e-6): frame time and evaluated
+            # samples with it on and off, on the bench scene (soft walls: T ~ 4e-4 behind them, nothing to skip), on fog (S2) and on
+            # opaque walls (S1-sharp)
+            et = {}
+            keep_eps = field.early_termination
+            for sc, sd in (("S1-soft", 0), ("S2", 1), ("S1-sharp", 0)):
+                try:
+                    fld = field if sc == args.scene else build_field(dev, scene=sc, seed=sd)[0]
+                    fld.materialize_weights, fld.frame_width = False, W
+                    row = {}
+                    for tag, eps in (("on", 1e-6), ("off", 0.0)):
+                        fld.early_termination = eps
+                        with torch.no_grad():
+                            for _ in range(3):
+                                fld(rays, white_bg=True, is_train=False, N_samples=-1)
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            for _ in range(20):
+                                fld(rays, white_bg=True, is_train=False, N_samples=-1)
+                            torch.cuda.synchronize()
+                        row[f"ms_per_frame_{tag}"] = (time.perf_counter() - t0) / 20 * 1e3
+                        row[f"evaluated_samples_{tag}"] = fld.stats()["evaluated"]
+                    et[sc] = row
+                    if fld is not field:
+                        del fld
+                except Exception as e:  # noqa: BLE001
+                    et[sc] = {"error": repr(e)[:200]}
+            field.early_termination = keep_eps
+            out["config"]["early_termination"] = et
             try:
                 out["config"]["dropin_eval_call_ms"] = dropin_eval_ms(field, dev, H, W)
             except Exception as e:  # noqa: BLE001
@@ -850,7 +957,14 @@ def main():
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True, resident=True))
         if world == 1 and not c4 and not args.quick:
-            out["scaling_prediction"] = scaling_prediction(field, dev, out["config"].get("train_ms_per_iter_fused_step"))
+            out["scaling_prediction"] = sp = scaling_prediction(field, dev, out["config"].get("train_ms_per_iter_fused_step"))
+            out["config"]["scaling_prediction_headline"] = {
+                "c4_predicted_8gpu_speedup": sp.get("c4", {}).get("predicted_speedup_interleaved"),
+                "c4_tile_balance": sp.get("c4", {}).get("balance_interleaved"),
+                "train_dp_predicted_8gpu_speedup": sp.get("train_dp", {}).get("predicted_speedup"),
+                "train_dp_step_ms_at_2048_rays": sp.get("train_dp", {}).get("fused_step_ms_by_rays_per_gpu", {}).get("2048"),
+                "train_dp_all_reduce_estimate_ms": sp.get("train_dp", {}).get("all_reduce_estimate_ms"),
+                "note": "one-GPU predictions (tile times, link-rate estimates), not measurements: see scaling_prediction"}
         if world == 1 and not args.no_cpu_baseline:
             def hip_render(r):
                 with torch.no_grad():
@@ -861,7 +975,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(params, aabb, 300, N, check=hip_render)
             pv = out["cpu_baseline"].get("parity_vs_oracle")
             if pv:
-                pv["evaluated_samples_equal"] = bool(pv.pop("oracle_evaluated") == hip_render.evaluated)
+                oe = pv.pop("oracle_evaluated")
+                pv["evaluated_samples_equal"] = bool(oe == hip_render.evaluated)
+                pv["evaluated_samples_hip_over_oracle"] = hip_render.evaluated / max(oe, 1)   # < 1 only through early termination (config.early_termination_eps)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

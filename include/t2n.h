@@ -306,6 +306,14 @@ int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray
  * it. Replaces the autograd accumulation of text2nerf_main.py:588-590 for those tensors. */
 size_t t2n_field_grad_buffer_bytes(const t2n_field* f);
 int t2n_field_set_grad_buffer(t2n_field* f, void* buf, size_t bytes);
+/* Layout of that buffer: [density planes 0..2 | density lines 0..2 | appearance planes 0..2 | appearance lines 0..2], every tensor
+ * channel-last and 256-B aligned. The density part (the first t2n_field_grad_buffer_density_bytes bytes) is final when the backward's
+ * density scatter is done — about half a millisecond of a C3 step before the appearance scatter: t2n_field_wait_density_grads makes
+ * `waiter` wait for that point of the LAST t2n_render_backward call (no-op before the first one), so that a data-parallel caller
+ * can start all-reducing the density bucket on `waiter` while the rest of the backward still runs on its own stream
+ * (text2nerf_amd/parallel.py; the reference trains on one GPU: text2nerf_main.py:547-601). */
+size_t t2n_field_grad_buffer_density_bytes(const t2n_field* f);
+int t2n_field_wait_density_grads(const t2n_field* f, t2n_stream waiter);
 
 /* The driver's loss of one training batch (text2nerf_main.py:559-575; TransMittanceLoss_mask, utils.py:67-80) in one pass over the
  * render outputs: loss = mean((rgb - rgb_t)^2) + w_depth * mean((depth - depth_t)^2) + w_trans * mean_r(m_r^2) with

@@ -367,10 +367,11 @@ def forward(cfg: FieldConfig, params, rays, white_bg=True, is_train=False, n_sam
     rgb_map = (weight[..., None] * rgb).sum(-2)
     if white_bg or (is_train and bool(bg_coin)):
         rgb_map = rgb_map + (1.0 - acc[..., None])
+    rgb_raw = rgb_map
     rgb_map = rgb_map.clamp(0, 1)
     depth = (weight * z).sum(-1) + (1.0 - acc) * rays[..., -1]
     if return_aux:
-        return rgb_map, depth, z, weight, dict(sigma=sigma, valid=valid, app_mask=app_mask, acc=acc, alpha=alpha)
+        return rgb_map, depth, z, weight, dict(sigma=sigma, valid=valid, app_mask=app_mask, acc=acc, alpha=alpha, rgb_pre_clamp=rgb_raw)
     return rgb_map, depth, z, weight
 
 

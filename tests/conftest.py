@@ -7,6 +7,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The parity tests compare with the reference sample for sample (evaluated-sample counts included): the mirror's early ray termination
+# (TensorBase.early_termination, default 1e-6: a bounded deviation from the reference, not its arithmetic) is OFF for every field the
+# suite builds; tests/test_early_termination.py and the whole-frame tests switch it on explicitly.
+os.environ.setdefault("T2N_EARLY_TERMINATION", "0")
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

@@ -283,16 +283,28 @@ def test_unsupported_configs_fail_loudly():
         ok.cpu()(torch.zeros(4, 6))   # parameters moved off the GPU: no host fallback
 
 
-def _grad_check(f, named_ref, rel):
-    worst = {}
+def _grad_check(f, named_ref, rel, rel_l2=None, cos_gap=None):
+    """Per tensor: max |dg| / max |g| <= rel (sensitive to ONE flipped sample); optionally also relative L2 error <= rel_l2 and
+    1 - cosine <= cos_gap (whole-tensor agreement, insensitive to a single knife-edge element). Returns the worst of the first."""
+    worst, l2, cg = {}, {}, {}
     for k, p in f.named_parameters():
-        g = named_ref[k]
+        g = named_ref[k].astype(np.float64)
         assert p.grad is not None, k
+        h = p.grad.detach().cpu().numpy().astype(np.float64)
         scale = float(np.abs(g).max()) + 1e-12
-        err = float(np.abs(p.grad.detach().cpu().numpy() - g).max())
-        worst[k] = err / scale
+        worst[k] = float(np.abs(h - g).max()) / scale
+        ng, nh = float(np.linalg.norm(g)), float(np.linalg.norm(h))
+        l2[k] = float(np.linalg.norm(h - g)) / (ng + 1e-30)
+        cg[k] = 1.0 - float((h * g).sum()) / (ng * nh + 1e-30) if ng > 0 and nh > 0 else 0.0
     bad = {k: v for k, v in worst.items() if v > rel}
     assert not bad, f"gradient mismatch (max abs err / max |g|): {bad}"
+    if rel_l2 is not None:
+        bad = {k: v for k, v in l2.items() if v > rel_l2}
+        assert not bad, f"gradient mismatch (relative L2 error): {bad}"
+    if cos_gap is not None:
+        bad = {k: v for k, v in cg.items() if v > cos_gap}
+        assert not bad, f"gradient mismatch (1 - cosine): {bad}"
+    _grad_check.last = {"rel_l2": l2, "one_minus_cos": cg}
     return worst
 
 

@@ -206,6 +206,21 @@ for k, a, b in zip(names, params, refp):
     gb = b.grad if b.grad is not None else torch.zeros_like(b)
     tol = 1e-6 * float(gb.abs().max()) + 1e-12
     assert float((a.grad - gb).abs().max()) <= tol, (k, float((a.grad - gb).abs().max()), tol)
+# the factor-gradient buffer's two buckets (density prefix | appearance rest, parallel.allreduce_buckets) against ONE flat message:
+# bitwise the same sums, for a split in the middle, at the ends and for a first bucket that is handed a "ready" hook
+from text2nerf_amd.parallel import allreduce_buckets
+gen = torch.Generator().manual_seed(100 + rank)
+base = torch.randn(100003, generator=gen)
+flat = base.clone()
+dist.all_reduce(flat)
+for split in (0, 1, 25001, 100002, 100003):
+    b = base.clone()
+    allreduce_buckets(b, split)
+    assert torch.equal(b, flat), split
+called = []
+b = base.clone()
+allreduce_buckets(b, 25001, first_ready=lambda st: called.append(st))     # CPU tensors: the hook is for device streams only
+assert torch.equal(b, flat) and not called
 dist.barrier()
 dist.destroy_process_group()
 print("OK", rank)

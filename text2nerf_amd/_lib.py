@@ -85,6 +85,8 @@ SIGNATURES = {
                                          C.c_void_p]),
     "t2n_field_grad_buffer_bytes": (C.c_size_t, [C.c_void_p]),
     "t2n_field_set_grad_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "t2n_field_grad_buffer_density_bytes": (C.c_size_t, [C.c_void_p]),
+    "t2n_field_wait_density_grads": (C.c_int, [C.c_void_p, C.c_void_p]),
     "t2n_train_loss_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "t2n_train_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,
                                  C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -1293,13 +1293,19 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
 
 // the 12 channel-last gradient buffers are slices of ONE allocation (density planes, density lines, appearance planes, appearance
 // lines; 256-B aligned slices): one memset, one in-place all-reduce
-static size_t grad_layout(const t2n_field* f, size_t (&off)[12]) {
+// [density planes 0..2 | density lines 0..2 | appearance planes 0..2 | appearance lines 0..2]: the density gradients (final when the
+// density scatter is done, ~0.5 ms before the appearance scatter) are ONE contiguous prefix — the first bucket of a data-parallel
+// all-reduce that overlaps the rest of the backward (t2n_field_wait_density_grads). *den_bytes: the prefix's size.
+static size_t grad_layout(const t2n_field* f, size_t (&off)[12], size_t* den_bytes = nullptr) {
     const int* g = f->desc.grid;
     size_t o = 0;
-    for (int k = 0; k < 3; ++k) {
-        const size_t HW = (size_t)g[mat1(k)] * g[mat0(k)], L = (size_t)g[vecm(k)];
-        const size_t sz[4] = {HW * 16 * 4, L * 16 * 4, HW * 48 * 4, L * 48 * 4};
-        for (int q = 0; q < 4; ++q) { off[q * 3 + k] = o; o += (sz[q] + 255) / 256 * 256; }
+    for (int q = 0; q < 4; ++q) {
+        if (q == 2 && den_bytes) *den_bytes = o;
+        for (int k = 0; k < 3; ++k) {
+            const size_t HW = (size_t)g[mat1(k)] * g[mat0(k)], L = (size_t)g[vecm(k)];
+            const size_t sz[4] = {HW * 16 * 4, L * 16 * 4, HW * 48 * 4, L * 48 * 4};
+            off[q * 3 + k] = o; o += (sz[q] + 255) / 256 * 256;
+        }
     }
     return o;
 }
@@ -1536,6 +1542,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
 
     // 2. per-ray backward + density scatter
     bool side = false;   // the density scatter was put on the side stream: joined before step 6
+    hipStream_t den_stream = s;   // the stream the density gradients are finished on
     bool side_gemm = false;   // the weight-gradient GEMMs were put on the third stream: joined before step 6
     bool packed_early = false;   // k_mlp_bwd_ss's operands were packed in front of k_bwd_march
     bool bin = false;
@@ -1608,7 +1615,11 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             da.nseg = (const unsigned*)(bw + b.nseg); da.recs = (const float4*)(bw + b.recs);
             hipLaunchKernelGGL(k_bwd_den_block, dim3(b.seg_cap < kAccGrid ? b.seg_cap : kAccGrid), dim3(kDenThreads), 0, sd, da);
             if (side) T2N_HIP(hipEventRecord((hipEvent_t)f->ev_join, sd));
+            den_stream = sd;
         }
+        // the density gradients of this call are final behind this point of `den_stream` (t2n_field_wait_density_grads)
+        if (!f->ev_den) { hipEvent_t e; T2N_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); f->ev_den = (void*)e; }
+        T2N_HIP(hipEventRecord((hipEvent_t)f->ev_den, den_stream));
         timing_end(f, T2N_K_BWD_MARCH, s);
         T2N_HIP(hipGetLastError());
     }
@@ -1840,5 +1851,18 @@ extern "C" int t2n_train_loss(const float* rgb, const float* depth, const float*
     hipLaunchKernelGGL(k_train_loss, dim3(a.nblocks), dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(k_train_loss_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" size_t t2n_field_grad_buffer_density_bytes(const t2n_field* f) {
+    if (!f) return 0;
+    size_t off[12], den = 0;
+    (void)grad_layout(f, off, &den);
+    return den;
+}
+
+extern "C" int t2n_field_wait_density_grads(const t2n_field* f, t2n_stream waiter) {
+    if (!f) { set_error("t2n_field_wait_density_grads: NULL field"); return T2N_ERR_INVALID; }
+    if (f->ev_den) T2N_HIP(hipStreamWaitEvent((hipStream_t)waiter, (hipEvent_t)f->ev_den, 0));
     return T2N_OK;
 }

@@ -104,6 +104,7 @@ struct t2n_field {
     // ray needed last time size the next call's lists (t2n_render_workspace_bytes_hint)
     unsigned* host_counts = nullptr; void* ev_counts = nullptr;
     void* side_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;   // backward: the density scatter runs beside the MLP backward
+    void* ev_den = nullptr;      // recorded behind the density scatter of the last backward (t2n_field_wait_density_grads)
     void* gemm_stream = nullptr; void* ev_fork2 = nullptr; void* ev_join2 = nullptr;  // backward: the weight-gradient GEMMs run beside the appearance scatter
     unsigned list_hint = 0;          // appearance entries per ray of the last budgeted launch (0: unknown)
     unsigned long long list_retries = 0;

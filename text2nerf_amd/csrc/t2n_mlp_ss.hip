@@ -3,11 +3,11 @@
 //
 // Replaces (reference): models/tensorBase.py:11-17 (positional_encoding), :88-109 (MLPRender_Fea_noview.forward).
 //
-// Mapping (gfx950, wave64): ONE 512-thread workgroup per CU (two waves per SIMD), persistent over rounds of 256 samples. Every
-// wave owns ONE 32-sample tile of the appearance lists from the feature rows to the colours: the encoded inputs, both hidden
-// activations and the output never leave its registers. That works because the C/D layout of v_mfma_f32_32x32x16_f16 (lane
-// (j, h): rows 8b + 4h + t of column j) IS a B-operand layout (lane (j, h): 8 K-values of column j) once the K order of the next
-// layer is permuted accordingly — the permutation is folded into the weight packing (k_pack_ss):
+// Mapping (gfx950, wave64): ONE 256-thread workgroup per CU — ONE wave per SIMD, owning its SIMD's whole 512-entry register file —
+// persistent over rounds of 12 tiles (384 samples). Every wave owns THREE 32-sample tiles of the appearance lists from the feature
+// rows to the colours: the encoded inputs, both hidden activations and the output never leave its registers. That works because the
+// C/D layout of v_mfma_f32_32x32x16_f16 (lane (j, h): rows 8b + 4h + t of column j) IS a B-operand layout (lane (j, h): 8 K-values of
+// column j) once the K order of the next layer is permuted accordingly — the permutation is folded into the weight packing (k_pack_ss):
 //   layer 0: lane half h owns features 14h .. 14h+12 of its sample and half of feature 13 (octaves 0..2 / 3..5); its 176 K-values are
 //            (sin, cos) of those three octaves, then per own feature (sin, cos) of octaves 0..5 [octaves 0 and 3 by v_sin_f32 /
 //            v_cos_f32 on the fraction of f 2^o / (2 pi), the others by double-angle steps], then the 13 raw features, then
@@ -15,24 +15,27 @@
 //            both halves: 22 K-steps.
 //   layers 1, 2: K index (step s, half h, element e) = hidden unit 32 (s / 2) + 8 (2 (s % 2) + e / 4) + 4h + e % 4 — what the lane
 //            holds of unit tile s / 2 of the previous layer's accumulators.
-// The weights are the A operands. Layer-0 weights (196 KB as hi / lo f16 halves) stream through a three-slot LDS ring of 16-KB
-// chunks (two K-steps) that the eight waves share (filled by LDS-DMA two chunks ahead; one barrier per chunk); layers 1 and 2
-// (80 KB) stay resident in LDS.
+// The weights are the A operands. Layer-0 weights (176 KB as hi / lo f16 halves) stream through a three-slot LDS ring of 16-KB
+// chunks (two K-steps) that the four waves share (filled by LDS-DMA two chunks ahead; one barrier per chunk); layers 1 and 2
+// (80 KB) stay resident in LDS. Layer 0 (69 % of the MFMAs) runs for the wave's three tiles at once on SHARED A operands (every
+// ds_read_b128 of an operand feeds nine MFMAs); layers 1 and 2 run tile by tile, software-pipelined (see stage()).
 //
 // fp32 products are three f16 products of hi / lo splits (x = hi + lo, hi = RTZ_f16(x), lo = RTZ_f16(x - hi); the lo*lo term is
 // dropped: ~2^-21 relative), fp32 accumulate. Weights are pre-split and scaled by a per-layer power of two chosen from max|W| at
 // upload (k_ss_scales); activations are split where they are produced; any activation beyond the f16 range raises a flag that
 // makes the caller's exact-fp32 kernel redo the launch.
 //
-// Why not weight-stationary (the round-2 first form, 1.51 ms per C2 frame against 1.24 ms: profiles/round2_v16_* / round2_v17_*): there the samples went through LDS between the layers, so
-// every layer boundary was a workgroup barrier around a VALU-only phase (split + store) with the matrix pipe idle: a quarter of
-// the kernel. Here the conversion work rides in the MFMA slots of the wave's own stream, and the waves only meet at the ring.
-// Why 32x32x16 tiles: measured on the 16x16x32 form of this kernel, every non-MFMA instruction of a wave costs its ~4 issue
-// cycles on top of the MFMA time (17 cycles per 16x16x32 MFMA + 2.9 other instructions = 29 cycles); the 32-cycle MFMA has room
-// for about five such instructions in its shadow, and the same work needs half as many MFMA issues.
+// History of the shape (records under profiles/): weight-stationary with the samples through LDS between the layers, 1.51 ms per C2
+// frame (round 2: every layer boundary a workgroup barrier around a VALU-only phase); sample-stationary, ONE tile per wave and two
+// waves per SIMD, 1.18-1.24 ms (rounds 2-3: 47 cycles per MFMA — 295 A-operand reads, 44 LDS-DMA pieces and 12 barriers per
+// 384 MFMAs); three tiles per wave in HIP source with compiler-allocated accumulators, 1.74-1.86 ms (round 3: 149 spilled
+// registers); this form, 1.18-1.22 ms (round 4: same-box A/B against the two-wave kernel 1.178-1.182 vs 1.184-1.187 ms; where its
+// 45 cycles per MFMA go is accounted region by region in profiles/round4_head_issue_accounting.txt).
 //
 // hipcc schedules a region MFMAs first, VALU after. The instruction stream is therefore laid out by hand: a K-step is cut into
-// 12 SLOTS of one MFMA plus the VALU / LDS work that should issue in its shadow, with a full scheduling fence after every slot.
+// SLOTS of one MFMA plus the VALU / LDS work that should issue in its shadow, with a full scheduling fence after every slot.
+// Timing-only build switches (-DSS3_PROF: per-region cycle sums through s_memtime; -DSS3_ABL_*: ablations whose pictures are wrong)
+// exist for tools/r4_head_accounting.sh; the shipped build defines none of them.
 #include "t2n_device.h"
 
 namespace t2n {
@@ -71,9 +74,6 @@ struct Args {
 
 #define SS_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-__device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
-}
 
 // ---- one pair of values -> packed hi / lo halves, in three phases of about equal issue time (one phase per slot) -----------
 struct Unit { float x0, x1; unsigned hi; };
@@ -131,52 +131,11 @@ __device__ __forceinline__ void enc_unit(Unit& U, const EncIn& I, float neg1, un
     }
 }
 
-struct Enc {
-    EncIn in;                // the lane's features (see enc_unit)
-    Unit U;                  // the encoder's unit in flight; between units (sin, cos) of the previous octave
-    Unit cu;                 // the conversion fillers' unit in flight (U lives across layer 2: step 0 of the next round is encoded before it)
-    unsigned ph[4], pl[4];   // packed halves of the operand being built
-};
-
 // ---- fillers: the VALU work that rides in a K-step's MFMA slots; run<IDX>() for IDX = 0..11 (unit IDX / 3 of four, phase IDX % 3),
 // done() once the four units are through -----------------------------------------------------------------------------------------
 struct NoFill {
     template <int IDX> __device__ __forceinline__ void run() {}
     __device__ __forceinline__ void done() {}
-};
-template <int S>
-struct EncFill {   // layer-0 B operand of K-step S -> (Bh, Bl)
-    Enc& E; uint4& Bh; uint4& Bl; float neg1;
-    template <int IDX> __device__ __forceinline__ void run() {
-        constexpr int u = IDX / 3;
-        enc_unit<8 * S + 2 * u, IDX % 3>(E.U, E.in, neg1, E.ph[u], E.pl[u]);
-    }
-    __device__ __forceinline__ void done() {
-        Bh = make_uint4(E.ph[0], E.ph[1], E.ph[2], E.ph[3]);
-        Bl = make_uint4(E.pl[0], E.pl[1], E.pl[2], E.pl[3]);
-    }
-};
-template <int S>
-struct ConvFill {   // relu(acc * inv) of registers 8 (S % 2) .. +7 of unit tile S / 2 -> the next layer's B operand of K-step S
-    const f32x16 (&src)[4]; uint4 (&Hh)[8]; uint4 (&Hl)[8]; Enc& E; float inv, neg1; h2v& amax;
-    template <int IDX> __device__ __forceinline__ void run() {
-        constexpr int j = IDX / 3, PH = IDX % 3;
-        Unit& U = E.cu;
-        if constexpr (PH == 0) {
-            const f32x16& a = src[S / 2];
-            U.x0 = fmaxf(a[8 * (S % 2) + 2 * j] * inv, 0.f);
-            U.x1 = fmaxf(a[8 * (S % 2) + 2 * j + 1] * inv, 0.f);
-        } else if constexpr (PH == 1) {
-            unit_pack(U);
-            amax = __builtin_elementwise_max(amax, __builtin_bit_cast(h2v, U.hi));   // RTZ halves: a value beyond the range packs to 65504
-        } else {
-            unit_split(U, neg1, E.ph[j], E.pl[j]);
-        }
-    }
-    __device__ __forceinline__ void done() {
-        Hh[S] = make_uint4(E.ph[0], E.ph[1], E.ph[2], E.ph[3]);
-        Hl[S] = make_uint4(E.pl[0], E.pl[1], E.pl[2], E.pl[3]);
-    }
 };
 template <class F>
 __device__ __forceinline__ void fill_all(F& f) {   // unscheduled form (prologue, layer boundaries)
@@ -185,294 +144,20 @@ __device__ __forceinline__ void fill_all(F& f) {   // unscheduled form (prologue
 #undef SS_U
 }
 
-// ---- MFMA streams ---------------------------------------------------------------------------------------------------------------
-struct AOp { uint4 h, l; };
-
-// Slot M (0..11) of one K-step of a 128-unit layer: unit-tile pair M / 6, product (M % 6) / 2 (hi*hi, lo*hi, hi*lo), tile of the pair
-// M % 2 — an accumulator is touched every second slot. The A operands of the next pair (cur + tile * 128 [+ 64: lo part]; the second
-// pair fetches the first pair of the next step, nxt) are fetched in a pair's first slot. One filler phase per slot.
-struct NoRing { template <int M> __device__ __forceinline__ void run() {} };
-template <int M, class Fill, class Ring = NoRing>
-__device__ __forceinline__ void slots(f32x16 (&acc)[4], AOp (&A)[2][2], const uint4& Bh, const uint4& Bl,
-                                      const uint4* __restrict__ cur, const uint4* __restrict__ nxt, Fill& F, Ring R = Ring()) {
-    if constexpr (M < 12) {
-        constexpr int g = M / 6, k = M % 6, p = k / 2, i = k % 2, u = 2 * g + i;
-        acc[u] = mfma(p == 1 ? A[g][i].l : A[g][i].h, p == 2 ? Bl : Bh, acc[u]);
-        if constexpr (k == 0) {
-            if constexpr (g == 0) {
-                A[1][0].h = cur[2 * 128]; A[1][0].l = cur[2 * 128 + 64]; A[1][1].h = cur[3 * 128]; A[1][1].l = cur[3 * 128 + 64];
-            } else {
-                A[0][0].h = nxt[0]; A[0][0].l = nxt[64]; A[0][1].h = nxt[128]; A[0][1].l = nxt[128 + 64];
-            }
-        }
-        F.template run<M>();
-        if constexpr (M == 11) F.done();
-        R.template run<M>();
-        SS_FENCE();   // (MFMAs of a tile pair or of a whole K-step issued back to back, fillers behind them: 2-3 % slower)
-        slots<M + 1>(acc, A, Bh, Bl, cur, nxt, F, R);
-    }
-}
-
-// Layer 2, K-step S (0..7): three products, each on its own accumulator chain; four filler phases per slot. The step's operand pair
-// sits in A[0][S % 2]; once its three MFMAs are issued that slot takes the operand of step S + 2 (nxt).
-template <int S, class Fill>
-__device__ __forceinline__ void step2(f32x16 (&ch)[3], AOp (&A)[2][2], const uint4& Hh, const uint4& Hl, const uint4* __restrict__ nxt, Fill& F) {
-    constexpr int b = S % 2;
-    ch[0] = mfma(A[0][b].h, Hh, ch[0]);
-    F.template run<0>(); F.template run<1>(); F.template run<2>(); F.template run<3>();
-    SS_FENCE();
-    ch[1] = mfma(A[0][b].l, Hh, ch[1]);
-    F.template run<4>(); F.template run<5>(); F.template run<6>(); F.template run<7>();
-    SS_FENCE();
-    ch[2] = mfma(A[0][b].h, Hl, ch[2]);
-    A[0][b].h = nxt[0]; A[0][b].l = nxt[64];
-    F.template run<8>(); F.template run<9>(); F.template run<10>(); F.template run<11>();
-    F.done();
-    SS_FENCE();
-}
-
-// the layer-0 weight stream: LDS-DMA (buffer_load ... lds: descriptor in SGPRs, the chunk as a scalar byte offset, the thread as one
-// 32-bit VGPR offset; the data never touches a VGPR). Wave w moves KB w and 8 + w of a 16-KB chunk, one
-// 1-KB piece per instruction (the LDS side of the instruction is wave-linear: M0 base + lane * 16).
-struct Stream {
-    const uint4* wp; int tid;
-    template <int HALF> __device__ __forceinline__ void dma(uint4* __restrict__ slot, int c) const {
-        typedef __attribute__((address_space(3))) void* lp;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wp), 0, 0x7fffffff, 0x00020000);
-        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lp)(slot + HALF * 512 + w * 64), 16, tid * 16, c * (kChunk * 16) + HALF * 8192, 0, 0);
-    }
-};
-// the ring traffic of one chunk iteration rides in the MFMA slots of its first K-step (the piece lands one iteration later:
-// hipcc waits vmcnt(0) in front of the next barrier, by which time it has long arrived)
-struct RingOps {
-    const Stream& S; uint4* __restrict__ slot; int chunk;
-    template <int M> __device__ __forceinline__ void run() {
-        if constexpr (M == 1) S.template dma<0>(slot, chunk);
-        if constexpr (M == 5) S.template dma<1>(slot, chunk);
-    }
-};
-
-__global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
-    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-    // LDS map: W2 [0, 16 KB) | ring [16 KB, 64 KB) | W1 [64 KB, 128 KB) | biases | sub-list table. A DS instruction carries a 16-bit
-    // byte offset: with the lane's operand addresses written as TWO opaque bases (lane * 16 and lane * 16 + 64 KB) plus
-    // constants every fetch is base + immediate; left to itself hipcc materialises one base register per 64-KB-crossing constant
-    // (nine of them) ahead of the loop and spills them.
-    uint4* __restrict__ W2 = lds;
-    uint4* __restrict__ RING = lds + kW2;
-    uint4* __restrict__ W1 = RING + kRing;
-    float* __restrict__ LB = reinterpret_cast<float*>(W1 + kW1);
-    unsigned* __restrict__ LT = reinterpret_cast<unsigned*>(LB + kBias);   // [0..7] inclusive tile prefix of the sub-lists, [8..15] their counts
-    static_assert((kW2 + kRing) * 16 == 65536, "W2 + ring fill the first 64 KB");
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
-    unsigned ob0 = (unsigned)lane * 16u, ob1 = (unsigned)lane * 16u + 65536u, obb = (unsigned)((kW2 + kRing + kW1) * 16) + 16u * (unsigned)h;
-    asm volatile("" : "+v"(ob0));
-    asm volatile("" : "+v"(ob1));
-    asm volatile("" : "+v"(obb));
-    const uint4* __restrict__ LA0 = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lds) + ob0);   // W2 / ring, + lane
-    const uint4* __restrict__ LA1 = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lds) + ob1);   // W1, + lane
-    const float* __restrict__ LBh = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + obb);   // biases, + 4 h
-
-    // tile enumeration over the appearance sub-lists (as k_shade): 32-sample tile -> (list, offset)
-    unsigned cnt_l = 0;
-    if (lane < a.nlists) {
-        cnt_l = a.counters[lane * kCounterStride];
-        if (cnt_l > a.list_cap) cnt_l = a.list_cap;
-    }
-    unsigned incl = (cnt_l + 31u) / 32u;
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-        const unsigned t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    unsigned ntiles = __shfl(incl, a.nlists - 1);
-    if (ntiles > a.tile_hi) ntiles = a.tile_hi;
-    const unsigned nrounds = (ntiles + 7u) / 8u;
-    if (blockIdx.x >= nrounds) return;
-    if (tid < 8) { LT[tid] = tid < a.nlists ? incl : 0xffffffffu; LT[8 + tid] = cnt_l; }   // kept in LDS: no live registers across the loop
-
-    // resident operands: layers 1 / 2 and the biases; ring slots 0 / 1 <- chunks 0 / 1
-    for (int i = tid; i < kW1; i += 512) W1[i] = a.w1[i];
-    for (int i = tid; i < kW2; i += 512) W2[i] = a.w2[i];
-    for (int i = tid; i < kBias; i += 512) LB[i] = a.bias[i];
-    const Stream S{a.w0, tid};
-    S.dma<0>(RING, 0); S.dma<1>(RING, 0);
-    S.dma<0>(RING + kChunk, 1); S.dma<1>(RING + kChunk, 1);
-    const float inv0 = a.inv_scale[0], inv1 = a.inv_scale[1], inv2 = a.inv_scale[2];
-    const float neg1 = a.neg1;
-    h2v amax = {(_Float16)0.f, (_Float16)0.f};   // hidden activations (non-negative, finite inputs), as packed RTZ f16 halves
-    unsigned amax_u = 0u;      // raw features: max of the |bit patterns| (orders like |x| and ranks inf / NaN on top)
-
-    // columns 14h .. 14h+13 of the lane's feature row of round r (row = 32 (8 r + w) + j; tiles past the end re-read the last row: their
-    // results are never stored): the half's own 13 features + column 13 (the shared feature, half 0) / column 27 (the entry's
-    // compositing weight, half 1). finish_feat hands each half what the other one loaded: one lane exchange per round.
-    const unsigned last = ntiles * 32u - 1u;
-    auto load_feat = [&](unsigned r, float (&f)[14]) {
-        unsigned i = (r * 8u + (unsigned)w) * 32u + (unsigned)j;
-        i = i < last ? i : last;
-        const float2* __restrict__ row = reinterpret_cast<const float2*>(a.feat + (size_t)i * 32 + 14 * h);
-#pragma unroll
-        for (int e = 0; e < 7; ++e) { const float2 v = row[e]; f[2 * e] = v.x; f[2 * e + 1] = v.y; }
-    };
-    float wnext = 0.f;   // lanes of half 0: the compositing weight of the sample whose features were loaded last
-    auto finish_feat = [&](EncIn& I) {
-        const float xs = __shfl_xor(I.f[13], 32);
-        I.fh = h ? xs : I.f[13];
-        I.extra = h ? I.fh : 0.f;
-        wnext = xs;
-    };
-    Enc E;
-    E.in.hs = h ? 8.f : 1.f;
-    load_feat(blockIdx.x, E.in.f);
-    finish_feat(E.in);
-    uint4 Bh[2], Bl[2];   // [K-step parity]
-    {
-        EncFill<0> f{E, Bh[0], Bl[0], neg1};
-        fill_all(f);
-    }
-    __syncthreads();   // W1 / W2 / bias / ring slots 0, 1 visible
-    AOp A[2][2];
-    A[0][0].h = LA0[kW2]; A[0][0].l = LA0[kW2 + 64]; A[0][1].h = LA0[kW2 + 128]; A[0][1].l = LA0[kW2 + 128 + 64];
-
-    for (unsigned r = blockIdx.x; r < nrounds; r += gridDim.x) {
-        // ---- layer 0: 12 chunks of two K-steps; a step multiplies while the next one is encoded, chunk C + 2 enters the ring -------
-        f32x16 acc0[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float4 v = *reinterpret_cast<const float4*>(LBh + 32 * u + 8 * b);
-                acc0[u][4 * b] = v.x; acc0[u][4 * b + 1] = v.y; acc0[u][4 * b + 2] = v.z; acc0[u][4 * b + 3] = v.w;
-            }
-#pragma unroll
-        for (int e = 0; e < 14; ++e) amax_u = max(amax_u, __float_as_uint(E.in.f[e]) & 0x7fffffffu);
-        const unsigned rn = r + gridDim.x < nrounds ? r + gridDim.x : r;
-        // column 27 of the feature row carries the entry's compositing weight: lane (j, 0) stores it next to the colour, k_composite
-        // then reads one array
-        const float wgt = wnext;
-#define SS_L0(C)                                                                                                                  \
-        {                                                                                                                         \
-            __syncthreads();   /* chunk C + 1 written by every wave; chunk C - 1 read by every wave */                            \
-            RingOps ring{S, RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0};   /* lands before the next barrier */                  \
-            const uint4* __restrict__ cur = LA0 + kW2 + (C % 3) * kChunk;                                                         \
-            const uint4* __restrict__ nxt = C < 10 ? LA0 + kW2 + ((C + 1) % 3) * kChunk : LA1;                                    \
-            /* 22 K-steps: chunks 0..10; chunk 11 of the stream is padding (its iteration only keeps the ring's rhythm) */         \
-            if constexpr (C == 11) {                                                                                              \
-                S.dma<0>(RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0); S.dma<1>(RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0);   \
-            } else {                                                                                                              \
-                EncFill<2 * C + 1> f0{E, Bh[1], Bl[1], neg1};                                                                     \
-                slots<0>(acc0, A, Bh[0], Bl[0], cur, cur + kStep, f0, ring);                                                      \
-                if constexpr (C < 10) {                                                                                           \
-                    EncFill<(C < 10 ? 2 * C + 2 : 0)> f1{E, Bh[0], Bl[0], neg1};                                                  \
-                    slots<0>(acc0, A, Bh[1], Bl[1], cur + kStep, nxt, f1);                                                        \
-                } else {                                                                                                          \
-                    NoFill f1;                                                                                                    \
-                    slots<0>(acc0, A, Bh[1], Bl[1], cur + kStep, nxt, f1);                                                        \
-                }                                                                                                                 \
-            }                                                                                                                     \
-        }
-        SS_L0(0) SS_L0(1) SS_L0(2) SS_L0(3) SS_L0(4) SS_L0(5) SS_L0(6) SS_L0(7) SS_L0(8) SS_L0(9) SS_L0(10) SS_L0(11)
-#undef SS_L0
-        // ---- h0 -> layer-1 B operands (step 0 here, steps 1..7 in the slots of layer 1); no barrier from here to the next round ------
-        uint4 H0h[8], H0l[8];
-        {
-            ConvFill<0> f{acc0, H0h, H0l, E, inv0, neg1, amax};
-            fill_all(f);
-        }
-        f32x16 acc1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float4 v = *reinterpret_cast<const float4*>(LBh + 128 + 32 * u + 8 * b);
-                acc1[u][4 * b] = v.x; acc1[u][4 * b + 1] = v.y; acc1[u][4 * b + 2] = v.z; acc1[u][4 * b + 3] = v.w;
-            }
-#define SS_L1(St)                                                                                                                 \
-        {                                                                                                                         \
-            const uint4* __restrict__ cur = LA1 + St * kStep;                                                                     \
-            const uint4* __restrict__ nxt = St < 7 ? LA1 + (St + 1) * kStep : LA0;                                                \
-            if constexpr (St < 7) {                                                                                               \
-                ConvFill<(St < 7 ? St + 1 : 0)> f{acc0, H0h, H0l, E, inv0, neg1, amax};                                           \
-                slots<0>(acc1, A, H0h[St], H0l[St], cur, nxt, f);                                                                 \
-            } else {                                                                                                              \
-                NoFill f;                                                                                                         \
-                slots<0>(acc1, A, H0h[St], H0l[St], cur, nxt, f);                                                                 \
-            }                                                                                                                     \
-        }
-        SS_L1(0) SS_L1(1) SS_L1(2) SS_L1(3) SS_L1(4) SS_L1(5) SS_L1(6) SS_L1(7)
-#undef SS_L1
-        // ---- h1 -> layer-2 B operands, layer 2 (three product chains), sigmoid, store ---------------------------------------------------
-        // (layer 1's last pair fetched W2 steps 0 / 1 as if they were a tile pair: A[0][0] = step 0, A[0][1] = step 1)
-        load_feat(rn, E.in.f);                  // the next round's features: in flight under layer 2, encoded in its last step
-        uint4 H1h[8], H1l[8];
-        {
-            ConvFill<0> f{acc1, H1h, H1l, E, inv1, neg1, amax};
-            fill_all(f);
-        }
-        f32x16 ch[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) ch[p][i] = 0.f;
-        if (h == 0) {
-            const float4 v = *reinterpret_cast<const float4*>(LB + 256);
-            ch[0][0] = v.x; ch[0][1] = v.y; ch[0][2] = v.z; ch[0][3] = v.w;
-        }
-#define SS_L2(St)                                                                                                                 \
-        {                                                                                                                         \
-            const uint4* __restrict__ nxt = St < 6 ? LA0 + (St + 2) * 128 : LA0 + kW2 + (St - 6) * 128;                           \
-            if constexpr (St < 7) {                                                                                               \
-                ConvFill<(St < 7 ? St + 1 : 0)> f{acc1, H1h, H1l, E, inv1, neg1, amax};                                           \
-                step2<St>(ch, A, H1h[St], H1l[St], nxt, f);                                                                       \
-            } else {                                                                                                              \
-                EncFill<0> f{E, Bh[0], Bl[0], neg1};   /* the next round's first operand */                                       \
-                step2<St>(ch, A, H1h[St], H1l[St], nxt, f);                                                                       \
-            }                                                                                                                     \
-        }
-        SS_L2(0) SS_L2(1) SS_L2(2) SS_L2(3) SS_L2(4) SS_L2(5) SS_L2(6)
-        finish_feat(E.in);
-        SS_L2(7)
-#undef SS_L2
-        const unsigned tile = r * 8u + (unsigned)w;
-        if (tile < ntiles && h == 0) {   // output rows 0..2 live in registers 0..2 of lanes 0..31
-            const uint4 i0 = *reinterpret_cast<const uint4*>(LT), i1 = *reinterpret_cast<const uint4*>(LT + 4);
-            const unsigned pre[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
-            int li = 0;
-            unsigned before = 0u;
-#pragma unroll
-            for (int l = 0; l < 8; ++l) if (pre[l] <= tile) { li = l + 1; before = pre[l]; }
-            const unsigned lbase = (unsigned)li * a.list_cap;
-            const unsigned count = lbase + LT[8 + li];
-            const unsigned idx = lbase + (tile - before) * 32u + (unsigned)j;
-            if (idx < count) {
-                const float rr = ((ch[0][0] + ch[2][0]) + ch[1][0]) * inv2, gg = ((ch[0][1] + ch[2][1]) + ch[1][1]) * inv2,
-                            bb = ((ch[0][2] + ch[2][2]) + ch[1][2]) * inv2;
-                // sigmoid by v_exp_f32 / v_rcp_f32 (1 ulp each: ~2e-7 absolute on a value in (0, 1))
-                a.app_rgb[idx] = make_float4(__builtin_amdgcn_rcpf(1.f + __expf(-rr)), __builtin_amdgcn_rcpf(1.f + __expf(-gg)),
-                                             __builtin_amdgcn_rcpf(1.f + __expf(-bb)), wgt);
-            }
-        }
-    }
-    if (__any(!((float)amax[0] < kRange) || !((float)amax[1] < kRange) || amax_u > __float_as_uint(kRange)) && lane == 0) atomicOr(a.range_flag, 1u);
-}
-
 // =====================================================================================================================================
-// Three tiles per wave, one wave per SIMD (k_mlp_ss3): the same layouts, operand packing and arithmetic as k_mlp_ss above, with
-// layer 0 (69 % of the MFMAs) of THREE 32-sample tiles running on shared A operands. A 256-thread workgroup per CU; a round is
-// 12 tiles (384 samples). Per MFMA that is a third of the A-operand ds_read_b128, two thirds of the ring's LDS-DMA pieces and a
-// third of the barriers of the two-waves-per-SIMD form.
+// The kernel: three tiles per wave, one wave per SIMD.
 //
 // Register plan (one wave owns its SIMD's whole 512-register file): the accumulators live in the AccVGPRs, named literally in
 // inline asm — the compiler allocates only the architectural half (operands, encoders, conversion units):
 //   a[64 t + 16 u .. +15]  layer-0 accumulators of tile t, unit tile u (192 registers); once tile t's layer 1 has consumed them
 //                          a[64 t .. 64 t + 47] hold the three product chains of its layer 2
-//   layer-1 accumulators of the tile in flight (layers 1 and 2 run tile by tile): 64 ARCHITECTURAL registers (compiler-visible MFMAs)
+//   a[192 + 16 u .. +15]   layer-1 accumulators of tile 1; tiles 0 and 2 keep theirs in 64 ARCHITECTURAL registers ("+v" operands of
+//                          the asm MFMAs), so that a tile's layer-1 accumulators can be converted while the next tile's accumulate
 // Accumulators start from the constant 0 in their first MFMA (srcC = 0); the biases are added where an accumulator is converted
 // (one v_fma_f32 instead of the scale multiply), from unscaled copies in LDS.
-// A operands go through a ring of four register buffers in consumption order (208 per round: 22 x 4 of layer 0, then per tile
-// 8 x 4 of layer 1 and 8 of layer 2); the buffer of element k is refilled with element k + 4 right behind k's last MFMA.
+// A operands go through a ring of four register buffers in consumption order (184 per round: 22 x 4 of layer 0, then 8 x 4 of
+// layer 1 per tile); the buffer of element k is refilled with element k + 4 right behind k's last MFMA. Layer 2's eight operands
+// have a double buffer of their own (A2).
 // What the compiler cannot see inside the asm statements, and how it is covered:
 //   * MFMA result -> v_accvgpr_read: every read sits >= 9 MFMA issues (>= 288 cycles) behind the last MFMA of its accumulator,
 //     except the final read of the layer-2 chains, which waits 16 states (s_nop 15; an 8-pass MFMA needs 12);
@@ -500,7 +185,7 @@ __global__ __launch_bounds__(512) void k_mlp_ss(const Args a) {
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef short s2v __attribute__((ext_vector_type(2)));
 constexpr int kT3 = 3;                                   // tiles per wave
-constexpr int kE0 = 88, kEL = 40, kER = kE0 + kT3 * kEL;   // A elements per round: layer 0, per tile (32 + 8), all
+constexpr int kE0 = 88, kEL = 32, kER = kE0 + kT3 * kEL;   // A elements per round in the ring: layer 0, layer 1 per tile (layer 2's eight go through A2)
 static_assert(kER % 4 == 0, "the A ring keeps its phase from round to round");
 
 template <int ACC, bool ZERO, bool NOP>
@@ -524,11 +209,10 @@ struct AEl { u4v h, l; };
 // element K of the round's A stream -> LDS operand address (uint4 units; base 0: W2 / ring, base 1: W1)
 template <int K> struct ElAddr {
     static constexpr int k = K % kER;
-    static constexpr bool l0 = k < kE0;
+    static constexpr bool l0 = k < kE0, l1 = !l0;
     static constexpr int q = l0 ? 0 : (k - kE0) % kEL;
-    static constexpr bool l1 = !l0 && q < 32;
-    static constexpr int s = l0 ? k / 4 : (l1 ? q / 4 : q - 32), ut = l0 ? k % 4 : (l1 ? q % 4 : 0);
-    static constexpr int off = l0 ? kW2 + ((s / 2) % 3) * kChunk + (s % 2) * kStep + ut * 128 : (l1 ? s * kStep + ut * 128 : s * 128);
+    static constexpr int s = l0 ? k / 4 : q / 4, ut = l0 ? k % 4 : q % 4;
+    static constexpr int off = l0 ? kW2 + ((s / 2) % 3) * kChunk + (s % 2) * kStep + ut * 128 : s * kStep + ut * 128;
 };
 struct LdsA { const u4v* a0; const u4v* a1; };
 template <int K>
@@ -541,8 +225,29 @@ __device__ __forceinline__ void fetch(AEl (&A)[4], const LdsA& L) {
     const u4v* __restrict__ p = (E::l1 ? L.a1 : L.a0) + E::off;
     A[K % 4].h = p[0]; A[K % 4].l = p[64];
 }
+template <int K, bool LO>   // one half of element K (layer 1 frees an element's lo half eight slots before its hi half)
+__device__ __forceinline__ void fetch_half(AEl (&A)[4], const LdsA& L) {
+    if constexpr (K >= kER) return;
+#ifdef SS3_ABL_NO_AFETCH
+    return;
+#endif
+    using E = ElAddr<K>;
+    const u4v* __restrict__ p = (E::l1 ? L.a1 : L.a0) + E::off;
+    if constexpr (LO) A[K % 4].l = p[64];
+    else A[K % 4].h = p[0];
+}
 
-struct Enc3 {   // a tile's encoder (see Enc)
+// layer 2's operand of K-step St (W2 is resident at the start of LDS) -> A2[St % 2]: a double buffer of its own, because a layer-2 step of
+// the previous tile rides in a layer-1 step of the current one and its operand lives across that step's twelve slots
+template <int St>
+__device__ __forceinline__ void fetch2(AEl (&A2)[2], const LdsA& L) {
+    if constexpr (St < kS2) {
+        const u4v* __restrict__ p = L.a0 + St * 128;
+        A2[St % 2].h = p[0]; A2[St % 2].l = p[64];
+    }
+}
+
+struct Enc3 {   // a tile's encoder: its features, the unit in flight ((sin, cos) of the previous octave between units), the operand being built
     EncIn in; Unit U; unsigned ph[4], pl[4];
 };
 template <int S>
@@ -581,23 +286,35 @@ struct ConvFill3 {   // relu(acc * inv + bias) of registers 8 (S % 2) .. +7 of u
 #ifdef SS3_ABL_NO_CONV
         if (S > 0) return;
 #endif
-        constexpr int j = IDX / 3, PH = IDX % 3;
-        Unit& U = V.cu;
+        phase<IDX / 3, IDX % 3, (IDX == 1)>(V.cu);
+    }
+    // the twelve phases as three passes over FOUR units in flight: four independent dependency chains per pass instead of one chain of
+    // twelve (where no MFMA stream needs the phases spread out: a stage's first conversion step, the round's last tile)
+    __device__ __forceinline__ void all() {
+        Unit U[4];
+        phase<0, 0, false>(U[0]); phase<1, 0, false>(U[1]); phase<2, 0, false>(U[2]); phase<3, 0, false>(U[3]);
+        phase<0, 1, true>(U[0]); phase<1, 1, false>(U[1]); phase<2, 1, false>(U[2]); phase<3, 1, false>(U[3]);
+        phase<0, 2, false>(U[0]); phase<1, 2, false>(U[1]); phase<2, 2, false>(U[2]); phase<3, 2, false>(U[3]);
+        done();
+    }
+    template <int j, int PH, bool NEXT_BIAS> __device__ __forceinline__ void phase(Unit& U) {
         if constexpr (PH == 0) {
-            float a0, a1;
+            const float4& b = V.bq[S % 2][j / 2];
+            const float b0 = (j % 2) ? b.z : b.x, b1 = (j % 2) ? b.w : b.y;
             if constexpr (BASE >= 0) {
                 constexpr int reg = BASE + 16 * (S / 2) + 8 * (S % 2) + 2 * j;
-                a0 = acc_read<reg>(); a1 = acc_read<reg + 1>();
+                const float a0 = acc_read<reg>(), a1 = acc_read<reg + 1>();
+                U.x0 = fmaxf(fmaf(a0, inv, b0), 0.f);
+                U.x1 = fmaxf(fmaf(a1, inv, b1), 0.f);
             } else {
-                a0 = src[S / 2][8 * (S % 2) + 2 * j]; a1 = src[S / 2][8 * (S % 2) + 2 * j + 1];
+                const float a0 = src[S / 2][8 * (S % 2) + 2 * j], a1 = src[S / 2][8 * (S % 2) + 2 * j + 1];
+                U.x0 = fmaxf(fmaf(a0, inv, b0), 0.f);
+                U.x1 = fmaxf(fmaf(a1, inv, b1), 0.f);
             }
-            const float4& b = V.bq[S % 2][j / 2];
-            U.x0 = fmaxf(fmaf(a0, inv, (j % 2) ? b.z : b.x), 0.f);
-            U.x1 = fmaxf(fmaf(a1, inv, (j % 2) ? b.w : b.y), 0.f);
         } else if constexpr (PH == 1) {
             unit_pack(U);
             amax = __builtin_elementwise_max(amax, __builtin_bit_cast(s2v, U.hi));   // bit patterns of non-negative halves order like their values
-            if constexpr (IDX == 1 && S < 7) conv_bias<(S < 7 ? S + 1 : 0), BOFF>(V, LBh);
+            if constexpr (NEXT_BIAS && S < 7) conv_bias<(S < 7 ? S + 1 : 0), BOFF>(V, LBh);
         } else {
             unit_split(U, neg1, V.ph[j], V.pl[j]);
         }
@@ -622,6 +339,7 @@ struct Stream3 {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lp)(slot + P * 256 + w * 64), 16, tid * 16, c * (kChunk * 16) + P * 4096, 0, 0);
     }
 };
+struct NoRing { template <int M> __device__ __forceinline__ void run() {} };
 struct RingOps3 {
     const Stream3& S; uint4* __restrict__ slot; int chunk;
     template <int M> __device__ __forceinline__ void run() {
@@ -629,6 +347,7 @@ struct RingOps3 {
         return;
 #endif
         if (chunk == kC0 - 1) return;   // the stream's padding chunk (K-steps 22, 23) is never read
+        // (the four pieces of a chunk spread over the K-step: issued back to back they cost 15 k cycles per wave and frame more)
         if constexpr (M == 1) S.template dma<0>(slot, chunk);
         if constexpr (M == 10) S.template dma<1>(slot, chunk);
         if constexpr (M == 19) S.template dma<2>(slot, chunk);
@@ -652,41 +371,113 @@ __device__ __forceinline__ void l0_slots(AEl (&A)[4], const u4v (&Bh)[kT3], cons
         l0_slots<M + 1, S>(A, Bh, Bl, f, ring, L);
     }
 }
-// Slot M (0..11) of a K-step of layer 1 of the tile in flight: unit tile M / 3, product M % 3; K0 = the A element of unit tile 0
-template <int M, int K0, bool FIRST, class F>
-__device__ __forceinline__ void l1_slots(f32x16 (&acc1)[4], AEl (&A)[4], const u4v& Hh, const u4v& Hl, F& f, const LdsA& L) {
+// ---- layers 1 and 2, software-pipelined over the three tiles ------------------------------------------------------------------------
+// Stage t = layer 1 of tile t (96 MFMA slots, the conversion of ITS layer-0 accumulators one phase per slot, just in time) with, from
+// the second stage on, the previous tile riding along: the conversion of its layer-1 accumulators (one more phase per slot) and its
+// layer 2 (K-step St - 1 as three extra MFMAs in slots 3, 7, 11 of layer-1 step St). Alone, a tile's layer 2 is 24 MFMAs under ~340
+// conversion instructions (VALU-bound, the matrix pipe idle two thirds of the time: 2.1 of a tile's 6.6 k cycles); under the next
+// tile's layer 1 it costs its instructions only. Layer-1 accumulators alternate between the architectural registers (tiles 0, 2)
+// and a[192..255] (tile 1), so that a tile's accumulators can be converted while the next tile's accumulate.
+struct NoL2 { template <int M> __device__ __forceinline__ void run() {} };
+template <int BASE, bool FIRST>
+struct L2Ops {   // the three products of one layer-2 K-step, each on its own chain a[BASE + 16 p ..]
+    const AEl& W; const u4v& Hh; const u4v& Hl;
+    template <int M> __device__ __forceinline__ void run() {
+        if constexpr (M == 3) mfma_acc<BASE, FIRST, true>(W.h, Hh);
+        if constexpr (M == 7) mfma_acc<BASE + 16, FIRST, false>(W.l, Hh);
+        if constexpr (M == 11) mfma_acc<BASE + 32, FIRST, false>(W.h, Hl);
+    }
+};
+// Slot M (0..11) of a K-step of layer 1: unit tile M % 4, product by slot group M / 4 (lo*hi, hi*hi, hi*lo): an accumulator is touched
+// every FOURTH slot. (Unit tile M / 3, product M % 3 — three dependent MFMAs back to back on one accumulator — ran 43 cycles per
+// slot with one filler phase and 67 with two: a dependent MFMA waits ~12 cycles beyond the pipe's 32 for its predecessor, and an
+// in-order wave issues nothing meanwhile.) K0 = the A element of unit tile 0; ACC >= 0: accumulators a[ACC + 16 u ..], ACC < 0: the
+// architectural accv[u]. fa / fb: one filler phase each per slot; l2: see L2Ops. An element's lo half is refilled (with the next
+// K-step's) behind slot u, its hi half behind slot 8 + u.
+template <int M, int K0, bool FIRST, int ACC, class FA, class FB, class L2C>
+__device__ __forceinline__ void l1_slots(f32x16 (&accv)[4], AEl (&A)[4], const u4v& Hh, const u4v& Hl, FA& fa, FB& fb, L2C l2, const LdsA& L) {
     if constexpr (M < 12) {
-        constexpr int ut = M / 3, p = M % 3, k = K0 + ut;
-        // (architectural accumulators, still through asm: a compiler-visible MFMA here made hipcc stage values in AccVGPRs of its own choice)
+        constexpr int ut = M % 4, g = M / 4, p = g == 0 ? 1 : (g == 1 ? 0 : 2), k = K0 + ut;
         const u4v& av = p == 1 ? A[k % 4].l : A[k % 4].h;
         const u4v& bv = p == 2 ? Hl : Hh;
-        if constexpr (FIRST && p == 0) {
-            if constexpr (M == 0) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc1[ut]) : "v"(av), "v"(bv));
-            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc1[ut]) : "v"(av), "v"(bv));
+        if constexpr (ACC >= 0) {
+            mfma_acc<ACC + 16 * ut, (FIRST && g == 0), (M == 0)>(av, bv);
+        } else if constexpr (FIRST && g == 0) {   // (architectural accumulators, still through asm: a compiler-visible MFMA made hipcc stage values in AccVGPRs of its own choice)
+            if constexpr (M == 0) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(accv[ut]) : "v"(av), "v"(bv));
+            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(accv[ut]) : "v"(av), "v"(bv));
         } else {
-            if constexpr (M == 0) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1[ut]) : "v"(av), "v"(bv));
-            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1[ut]) : "v"(av), "v"(bv));
+            if constexpr (M == 0) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(accv[ut]) : "v"(av), "v"(bv));
+            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(accv[ut]) : "v"(av), "v"(bv));
         }
-        if constexpr (p == 2) fetch<k + 4>(A, L);
-        f.template run<M>();
-        if constexpr (M == 11) f.done();
+        if constexpr (g == 0) fetch_half<k + 4, true>(A, L);
+        if constexpr (g == 2) fetch_half<k + 4, false>(A, L);
+        fa.template run<M>();
+        if constexpr (M == 11) fa.done();
+        fb.template run<M>();
+        if constexpr (M == 11) fb.done();
+        l2.template run<M>();
         SS_FENCE();
-        l1_slots<M + 1, K0, FIRST>(acc1, A, Hh, Hl, f, L);
+        l1_slots<M + 1, K0, FIRST, ACC>(accv, A, Hh, Hl, fa, fb, l2, L);
     }
 }
-// Layer 2, K-step of A element K: three products on their own chains a[BASE + 16 p ..]; four filler phases per slot
-template <int K, int BASE, bool FIRST, class F>
-__device__ __forceinline__ void l2_step(AEl (&A)[4], const u4v& Hh, const u4v& Hl, F& f, const LdsA& L) {
-    mfma_acc<BASE, FIRST, true>(A[K % 4].h, Hh);
-    f.template run<0>(); f.template run<1>(); f.template run<2>(); f.template run<3>();
-    SS_FENCE();
-    mfma_acc<BASE + 16, FIRST, false>(A[K % 4].l, Hh);
-    f.template run<4>(); f.template run<5>(); f.template run<6>(); f.template run<7>();
-    SS_FENCE();
-    mfma_acc<BASE + 32, FIRST, false>(A[K % 4].h, Hl);
-    fetch<K + 4>(A, L);
-    f.template run<8>(); f.template run<9>(); f.template run<10>(); f.template run<11>();
-    f.done();
+struct TileCtx {   // what the stages share (references: everything is inlined into the kernel)
+    f32x16 (&accv)[4]; AEl (&A)[4]; AEl (&A2)[2]; Conv3& V0; Conv3& V1; s2v& amax; float inv0, inv1, neg1; const float* __restrict__ LBh;
+    const LdsA& L; u4v (&H0h)[8]; u4v (&H0l)[8]; u4v (&H1h)[8]; u4v (&H1l)[8];
+};
+constexpr int acc1_of(int t) { return t == 1 ? 192 : -1; }   // where tile t's layer-1 accumulators live (see above)
+template <int T_, int St>
+__device__ __forceinline__ void stage_step(TileCtx& c) {
+    constexpr int K0 = kE0 + kEL * T_ + 4 * St;
+    if constexpr (T_ > 0) fetch2<St>(c.A2, c.L);   // consumed by the layer-2 step riding in the NEXT layer-1 step (step 7: the stage's epilogue)
+    auto run = [&](auto& fa, auto& fb, auto l2) { l1_slots<0, K0, St == 0, acc1_of(T_)>(c.accv, c.A, c.H0h[St], c.H0l[St], fa, fb, l2, c.L); };
+    auto with_a = [&](auto& fb, auto l2) {
+#ifdef SS3_ABL_S0_NOCONV
+        if constexpr (T_ == 0) { NoFill fa; run(fa, fb, l2); return; }
+#endif
+        if constexpr (St < 7) {
+            ConvFill3<St + 1, 64 * T_, 0> fa{c.H0h, c.H0l, c.V0, c.inv0, c.neg1, c.amax, c.LBh, nullptr};
+            run(fa, fb, l2);
+        } else {
+            NoFill fa;
+            run(fa, fb, l2);
+        }
+    };
+    if constexpr (T_ == 0) {
+        NoFill fb;
+        with_a(fb, NoL2());
+    } else {
+        ConvFill3<St, acc1_of(T_ - 1), 128> fb{c.H1h, c.H1l, c.V1, c.inv1, c.neg1, c.amax, c.LBh, c.accv};
+        if constexpr (St == 0) with_a(fb, NoL2());
+        else with_a(fb, L2Ops<64 * (T_ - 1), St == 1>{c.A2[(St - 1) % 2], c.H1h[St - 1], c.H1l[St - 1]});
+    }
+}
+template <int T_>
+__device__ __forceinline__ void stage(TileCtx& c) {
+    if constexpr (T_ > 0) conv_bias<0, 128>(c.V1, c.LBh);   // the previous tile's first layer-1 conversion step (in flight under the block below)
+    {
+        ConvFill3<0, 64 * T_, 0> f{c.H0h, c.H0l, c.V0, c.inv0, c.neg1, c.amax, c.LBh, nullptr};
+        f.all();
+    }
+    stage_step<T_, 0>(c); stage_step<T_, 1>(c); stage_step<T_, 2>(c); stage_step<T_, 3>(c);
+    stage_step<T_, 4>(c); stage_step<T_, 5>(c); stage_step<T_, 6>(c); stage_step<T_, 7>(c);
+    if constexpr (T_ + 1 < kT3) conv_bias<0, 0>(c.V0, c.LBh);   // the next tile's first layer-0 conversion step
+    if constexpr (T_ > 0) {   // the previous tile's last layer-2 step
+        L2Ops<64 * (T_ - 1), false> l2{c.A2[1], c.H1h[7], c.H1l[7]};
+        l2.template run<3>(); l2.template run<7>(); l2.template run<11>();
+        SS_FENCE();
+    }
+}
+// The last tile's layer 2 (nothing of this round is left to ride under): K-step St on the chains a[BASE ..], four conversion phases per
+// slot; W2 operands through A2
+template <int St, int BASE, class F>
+__device__ __forceinline__ void l2_step(AEl (&A2)[2], const u4v& Hh, const u4v& Hl, F& f, const LdsA& L) {
+    // (VALU-bound: 3 MFMAs under ~100 conversion instructions. What matters is the instructions' own issue rate: the four units of the
+    // step run side by side, f.all())
+    mfma_acc<BASE, St == 0, true>(A2[St % 2].h, Hh);
+    mfma_acc<BASE + 16, St == 0, false>(A2[St % 2].l, Hh);
+    mfma_acc<BASE + 32, St == 0, false>(A2[St % 2].h, Hl);
+    fetch2<St + 2>(A2, L);
+    f.all();
     SS_FENCE();
 }
 
@@ -703,17 +494,16 @@ __device__ __forceinline__ void l2_step(AEl (&A)[4], const u4v& Hh, const u4v& H
 #define SS3_T(var) do {} while (0)
 #endif
 // the round's last layer-2 step: slot p carries all twelve encoder phases of tile p's first operand of the next round
-template <int K, int BASE, class F>
-__device__ __forceinline__ void l2_last(AEl (&A)[4], const u4v& Hh, const u4v& Hl, F (&f)[kT3], const LdsA& L) {
-    mfma_acc<BASE, false, true>(A[K % 4].h, Hh);
-    fill_all(f[0]);
-    SS_FENCE();
-    mfma_acc<BASE + 16, false, false>(A[K % 4].l, Hh);
-    fill_all(f[1]);
-    SS_FENCE();
-    mfma_acc<BASE + 32, false, false>(A[K % 4].h, Hl);
-    fetch<K + 4>(A, L);
-    fill_all(f[2]);
+template <int BASE, class F>
+__device__ __forceinline__ void l2_last(AEl (&A2)[2], const u4v& Hh, const u4v& Hl, F (&f)[kT3]) {
+    mfma_acc<BASE, false, true>(A2[1].h, Hh);
+    mfma_acc<BASE + 16, false, false>(A2[1].l, Hh);
+    mfma_acc<BASE + 32, false, false>(A2[1].h, Hl);
+    // the three tiles' encoders phase by phase: three independent chains side by side
+#define SS3_E(I) f[0].template run<I>(); f[1].template run<I>(); f[2].template run<I>()
+    SS3_E(0); SS3_E(1); SS3_E(2); SS3_E(3); SS3_E(4); SS3_E(5); SS3_E(6); SS3_E(7); SS3_E(8); SS3_E(9); SS3_E(10); SS3_E(11);
+#undef SS3_E
+    f[0].done(); f[1].done(); f[2].done();
     SS_FENCE();
 }
 
@@ -792,8 +582,8 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
         fill_all(f);
     }
     __syncthreads();   // W1 / W2 / bias / ring slots 0, 1 visible
-    AEl A[4];
-    Conv3 V;
+    AEl A[4], A2[2];
+    Conv3 V, V1;   // conversion fillers of a stage's own tile (layer-0 accumulators) / of the tile riding along (layer-1 accumulators)
 
 #ifdef SS3_PROF
     unsigned long long p_bar = 0, p_l0 = 0, p_tile[3] = {0, 0, 0}, p_top = 0, p_rounds = 0;
@@ -811,6 +601,7 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
         asm volatile("" : "+v"(amax_u));   // pinned here: left alone, hipcc sinks these maxima to the end of the round and keeps (spills) the 42 features for it
         const unsigned rn = r + gridDim.x < nrounds ? r + gridDim.x : r;
         SS3_T(p_top);
+        asm volatile("; SS3_MARK layer0");
         // ---- layer 0, three tiles on shared A operands: 11 chunks of two K-steps (+ the ring's padding chunk) ----------------------------
 #define SS3_ENC(S_, P_) {{E[0], Bh[P_][0], Bl[P_][0], neg1}, {E[1], Bh[P_][1], Bl[P_][1], neg1}, {E[2], Bh[P_][2], Bl[P_][2], neg1}}
 #define SS3_L0(C)                                                                                                                 \
@@ -835,56 +626,13 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
                 }                                                                                                                 \
             }                                                                                                                     \
         }
-#ifndef SS3_ABL_TAIL_ONLY
         SS3_L0(0) SS3_L0(1) SS3_L0(2) SS3_L0(3) SS3_L0(4) SS3_L0(5) SS3_L0(6) SS3_L0(7) SS3_L0(8) SS3_L0(9) SS3_L0(10) SS3_L0(11)
-#endif
 #undef SS3_L0
         SS3_T(p_l0);
 
-        // ---- layers 1 and 2, tile by tile -------------------------------------------------------------------------------------------------
-#define SS3_L1(T_, St)                                                                                                            \
+        // ---- layers 1 and 2: three pipelined stages and the last tile's layer 2 (see stage()) -------------------------------------------
+#define SS3_FINAL(T_)                                                                                                             \
         {                                                                                                                         \
-            if constexpr (St < 7) {                                                                                               \
-                ConvFill3<(St < 7 ? St + 1 : 0), 64 * T_, 0> f{H0h, H0l, V, inv0, neg1, amax, LBh, nullptr};                      \
-                l1_slots<0, kE0 + kEL * T_ + 4 * St, St == 0>(acc1, A, H0h[St], H0l[St], f, L);                                   \
-            } else {                                                                                                              \
-                NoFill f;                                                                                                         \
-                conv_bias<0, 128>(V, LBh);                                                                                        \
-                l1_slots<0, kE0 + kEL * T_ + 4 * St, St == 0>(acc1, A, H0h[St], H0l[St], f, L);                                   \
-            }                                                                                                                     \
-        }
-#define SS3_L2(T_, St)                                                                                                            \
-        {                                                                                                                         \
-            if constexpr (St < 7) {                                                                                               \
-                ConvFill3<(St < 7 ? St + 1 : 0), -1, 128> f{H1h, H1l, V, inv1, neg1, amax, LBh, acc1};                            \
-                l2_step<kE0 + kEL * T_ + 32 + St, 64 * T_, St == 0>(A, H1h[St], H1l[St], f, L);                                   \
-            } else if constexpr (T_ + 1 < kT3) {                                                                                  \
-                NoFill f;                                                                                                         \
-                conv_bias<0, 0>(V, LBh);   /* the next tile's first conversion step */                                            \
-                l2_step<kE0 + kEL * T_ + 32 + St, 64 * T_, St == 0>(A, H1h[St], H1l[St], f, L);                                   \
-            } else {   /* the round's last step: the next round's first operands of the three tiles, one tile per slot */        \
-                _Pragma("unroll") for (int t = 0; t < kT3; ++t) finish_feat(E[t].in, wnext[t]);                                   \
-                EncFill3<0> f3[kT3] = SS3_ENC(0, 0);                                                                              \
-                l2_last<kE0 + kEL * T_ + 32 + St, 64 * T_>(A, H1h[St], H1l[St], f3, L);                                           \
-            }                                                                                                                     \
-            /* the next round's features (needed from its first encoder phase to its last layer-0 step): loaded here, not */     \
-            /* earlier — 42 registers that nothing in the tile-by-tile part needs */                                             \
-            if constexpr (T_ + 1 == kT3 && St == 0) { _Pragma("unroll") for (int t = 0; t < kT3; ++t) load_feat(rn, t, E[t].in.f); } \
-        }
-#define SS3_TILE(T_)                                                                                                              \
-        {                                                                                                                         \
-            u4v H0h[8], H0l[8], H1h[8], H1l[8];                                                                                   \
-            f32x16 acc1[4];                                                                                                       \
-            {                                                                                                                     \
-                ConvFill3<0, 64 * T_, 0> f{H0h, H0l, V, inv0, neg1, amax, LBh, nullptr};                                          \
-                fill_all(f);                                                                                                      \
-            }                                                                                                                     \
-            SS3_L1(T_, 0) SS3_L1(T_, 1) SS3_L1(T_, 2) SS3_L1(T_, 3) SS3_L1(T_, 4) SS3_L1(T_, 5) SS3_L1(T_, 6) SS3_L1(T_, 7)       \
-            {                                                                                                                     \
-                ConvFill3<0, -1, 128> f{H1h, H1l, V, inv1, neg1, amax, LBh, acc1};                                                \
-                fill_all(f);                                                                                                      \
-            }                                                                                                                     \
-            SS3_L2(T_, 0) SS3_L2(T_, 1) SS3_L2(T_, 2) SS3_L2(T_, 3) SS3_L2(T_, 4) SS3_L2(T_, 5) SS3_L2(T_, 6) SS3_L2(T_, 7)       \
             asm volatile("s_nop 15");   /* the chains' last MFMAs -> their reads */                                              \
             const float c00 = acc_read<64 * T_>(), c01 = acc_read<64 * T_ + 1>(), c02 = acc_read<64 * T_ + 2>();                  \
             const float c10 = acc_read<64 * T_ + 16>(), c11 = acc_read<64 * T_ + 17>(), c12 = acc_read<64 * T_ + 18>();           \
@@ -908,16 +656,54 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
                 }                                                                                                                 \
             }                                                                                                                     \
         }
-#ifndef SS3_ABL_L0_ONLY
+#define SS3_L2(St)                                                                                                                \
+        {                                                                                                                         \
+            ConvFill3<St + 1, -1, 128> f{H1h, H1l, V1, inv1, neg1, amax, LBh, accv};                                              \
+            l2_step<St, 128>(A2, H1h[St], H1l[St], f, L);                                                                         \
+        }
+        {
+            f32x16 accv[4];
+            u4v H0h[8], H0l[8], H1h[8], H1l[8];
+            TileCtx ctx{accv, A, A2, V, V1, amax, inv0, inv1, neg1, LBh, L, H0h, H0l, H1h, H1l};
+            asm volatile("; SS3_MARK stage0");
+            stage<0>(ctx);
+            SS3_T(p_tile[0]);
+            asm volatile("; SS3_MARK stage1");
+            // the next round's features (needed from the round's last step on): 42 registers in flight through two stages — loaded at the
+            // tail instead, their HBM / MALL latency (~2 us behind the gather kernel's 548 MB of rows) stalled every round for ~2.5 k cycles
+#pragma unroll
+            for (int t = 0; t < kT3; ++t) load_feat(rn, t, E[t].in.f);
+            stage<1>(ctx);
+            SS3_FINAL(0)
+            SS3_T(p_tile[1]);
+            asm volatile("; SS3_MARK stage2");
+            stage<2>(ctx);
+            SS3_FINAL(1)
+            asm volatile("; SS3_MARK tail");
+            // the last tile: its layer-1 accumulators (architectural) -> layer 2, alone. The next round's features (needed from its
+            // first encoder phase to its last layer-0 step: 42 registers that nothing above needs) are loaded here.
+            fetch2<0>(A2, L); fetch2<1>(A2, L);
+            conv_bias<0, 128>(V1, LBh);
+            {
+                ConvFill3<0, -1, 128> f{H1h, H1l, V1, inv1, neg1, amax, LBh, accv};
+                f.all();
+            }
+            SS3_L2(0) SS3_L2(1) SS3_L2(2) SS3_L2(3) SS3_L2(4) SS3_L2(5) SS3_L2(6)
+            {   // the round's last step: the next round's first operands of the three tiles, one tile per slot
+#pragma unroll
+                for (int t = 0; t < kT3; ++t) finish_feat(E[t].in, wnext[t]);
+                EncFill3<0> f3[kT3] = SS3_ENC(0, 0);
+                l2_last<128>(A2, H1h[7], H1l[7], f3);
+            }
+            SS3_FINAL(2)
+            asm volatile("; SS3_MARK end");
+            SS3_T(p_tile[2]);
 #ifdef SS3_PROF
-        SS3_TILE(0) SS3_T(p_tile[0]); SS3_TILE(1) SS3_T(p_tile[1]); SS3_TILE(2) SS3_T(p_tile[2]); ++p_rounds;
-#else
-        SS3_TILE(0) SS3_TILE(1) SS3_TILE(2)
+            ++p_rounds;
 #endif
-#endif
-#undef SS3_TILE
+        }
 #undef SS3_L2
-#undef SS3_L1
+#undef SS3_FINAL
 #undef SS3_ENC
     }
 #ifdef SS3_PROF
@@ -928,7 +714,7 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
     }
 #endif
     const h2v am = __builtin_bit_cast(h2v, amax);
-#if defined(SS3_ABL_NO_DMA) || defined(SS3_ABL_NO_ENC) || defined(SS3_ABL_NO_CONV) || defined(SS3_ABL_TAIL_ONLY) || defined(SS3_ABL_L0_ONLY)
+#if defined(SS3_ABL_NO_DMA) || defined(SS3_ABL_NO_ENC) || defined(SS3_ABL_NO_CONV) || defined(SS3_ABL_S0_NOCONV)
     if (am[0] == (_Float16)12345.f) atomicOr(a.range_flag, 1u);   // timing-only build: garbage values must not trigger the exact redo
 #else
     if (__any(!((float)am[0] < kRange) || !((float)am[1] < kRange) || amax_u > __float_as_uint(kRange)) && lane == 0) atomicOr(a.range_flag, 1u);
@@ -1063,12 +849,8 @@ int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev,
     if (f->ss_dirty || !f->buf_ss) { const int rc = ss_pack(f, s); if (rc) return rc; }
     else if (f->ss_event && f->ss_stream != (void*)s) T2N_HIP(hipStreamWaitEvent(s, (hipEvent_t)f->ss_event, 0));
     static bool attr_set = false;
-    static bool two_wave = false;   // T2N_SS_TWO_WAVE=1: the two-waves-per-SIMD form (A/B against the three-tile kernel)
     if (!attr_set) {
-        T2N_HIP(hipFuncSetAttribute((const void*)k_mlp_ss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
         T2N_HIP(hipFuncSetAttribute((const void*)k_mlp_ss3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-        const char* e = getenv("T2N_SS_TWO_WAVE");
-        two_wave = e && e[0] == '1';
         attr_set = true;
     }
     const size_t nw = (size_t)kW0 + kW1 + kW2;
@@ -1085,8 +867,7 @@ int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev,
     T2N_HIP(hipMemsetAsync(prof, 0, 1024 * 8 * 8, s));
     a.prof = prof;
 #endif
-    if (two_wave) hipLaunchKernelGGL(k_mlp_ss, dim3(256), dim3(512), kLds, s, a);
-    else hipLaunchKernelGGL(k_mlp_ss3, dim3(256), dim3(256), kLds, s, a);
+    hipLaunchKernelGGL(k_mlp_ss3, dim3(256), dim3(256), kLds, s, a);
 #ifdef SS3_PROF
     if (++prof_calls == 20) {   // one report per process: per-wave cycle sums, averaged over the waves
         static unsigned long long h[1024 * 8];

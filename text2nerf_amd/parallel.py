@@ -100,16 +100,61 @@ def shard_batch(n: int, world: int, rank: int):
     return rank * per, (rank + 1) * per
 
 
-def allreduce_gradients(params, group=None, average=True, field=None):
+_BUCKET_STREAMS = {}
+
+
+def allreduce_buckets(buf: torch.Tensor, split: int, group=None, first_ready=None):
+    """All-reduce (sum) the flat buffer `buf` in place as TWO messages, [0, split) and [split, n): the same element-wise sums as one
+    flat message (bitwise: every element is reduced with the same operands either way on a two-rank group; on larger groups the ring's
+    chunking may differ). `first_ready(stream)`: called with a side stream on which the first bucket's collective is then issued — the
+    caller makes that stream wait for whatever finishes the first bucket EARLY (the density half of the factor gradients is final
+    ~0.5 ms before the appearance half: its 17 MB are on the links while the appearance scatter still runs). Without it both go out on
+    the current stream, back to back."""
+    n = buf.numel()
+    split = max(0, min(int(split), n))
+    if split == 0 or split == n:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        return
+    a, b = buf[:split], buf[split:]
+    if first_ready is not None and buf.is_cuda:
+        key = str(buf.device)
+        side = _BUCKET_STREAMS.get(key)
+        if side is None:
+            side = _BUCKET_STREAMS[key] = torch.cuda.Stream(buf.device)
+        first_ready(side)
+        with torch.cuda.stream(side):
+            wa = dist.all_reduce(a, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        wb = dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        wa.wait()      # (stream-level for RCCL: the CURRENT stream waits for both collectives; gloo blocks the host)
+        wb.wait()
+        torch.cuda.current_stream(buf.device).wait_stream(side)
+    else:
+        wa = dist.all_reduce(a, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        wb = dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        wa.wait()
+        wb.wait()
+
+
+def allreduce_gradients(params, group=None, average=True, field=None, overlap=True):
     """Sum (or average) the gradients over the ranks. `field` with ``defer_factor_grads`` set (optim.TVAdam(field=...)): the 12 plane /
-    line gradients are all-reduced IN PLACE in the field's contiguous channel-last buffer (69.6 MB at 300^3: one message, no
-    concatenation or copy-back), the remaining (head) tensors as one small flat message. Without `field`: one flat all-reduce of
-    the .grad of `params`; a None grad counts as zero on this rank (every rank must pass the same parameter list)."""
+    line gradients are all-reduced IN PLACE in the field's contiguous channel-last buffer (69.6 MB at 300^3, no concatenation or
+    copy-back) as two buckets — density (17.5 MB, issued on a side stream as soon as the backward's density scatter is done:
+    t2n_field_wait_density_grads) and appearance (52 MB, behind the whole backward); `overlap=False`: one flat message behind the
+    backward. The remaining (head) tensors travel as one small flat message. Without `field`: one flat all-reduce of the .grad of
+    `params`; a None grad counts as zero on this rank (every rank must pass the same parameter list)."""
     world = dist.get_world_size(group)
     deferred = field is not None and bool(getattr(field, "defer_factor_grads", False)) and field.supports_deferred_factor_grads()
     if deferred:
         buf = field.factor_grad_buffer()
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        if overlap:
+            from . import _lib
+            lib = _lib.load()
+            h = field.sync_params()
+            nden = int(lib.t2n_field_grad_buffer_density_bytes(h)) // 4
+            allreduce_buckets(buf, nden, group, first_ready=lambda st: _lib.check(
+                lib.t2n_field_wait_density_grads(h, st.cuda_stream), "t2n_field_wait_density_grads"))
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         if average:
             buf.div_(world)
         field._gbuf_dirty = True

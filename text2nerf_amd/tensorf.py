@@ -1012,6 +1012,10 @@ class TensorBase(nn.Module):
         if not is_train and not ndc_ray and fw and R % fw == 0:
             flags |= FLAG_COHERENT
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._autograd_params())
+        if needs_grad and self._needs_embed():
+            # every differentiable forward gets its own embedding graph: a second forward + backward at an unchanged parameter version
+            # (gradient accumulation) must not walk the first one's freed graph
+            self._embed_cache = None
         if needs_grad:
             rgb, depth, z, w = _RenderFn.apply(self, rays, N, flags, jitter, *self._autograd_params())
         else:
@@ -1109,12 +1113,14 @@ class TensorBase(nn.Module):
         return grads
 
     def train_step(self, rays, rgb_target, depth_target, optimizer, N_samples=-1, white_bg=True, w_depth=0.005, w_trans=1e3, delta=0.1,
-                   tv=(), all_reduce=None):
+                   tv=(), all_reduce=None, all_reduce_averages=True):
         """One optimisation step of text2nerf_main.py:547-590 without the autograd graph: render (train mode, CPU-generator jitter
         like models/tensorBase.py:313-317) -> the driver's loss as ONE kernel that emits d_rgb / d_depth / d_weights
         (t2n_train_loss) -> t2n_render_backward -> optimizer.step(). `optimizer`: optim.TVAdam(field=self) (TV terms via `tv`, as
         in TVAdam.step); `all_reduce`: optional callable run between backward and step (data-parallel:
-        lambda: parallel.allreduce_gradients(params, field=self)). Returns the device tensor [mse, depth loss, transmittance loss,
+        lambda: parallel.allreduce_gradients(params, field=self)); it must AVERAGE over the ranks (the TV terms, identical on every
+        rank, may already sit in the gradient buffer when it runs: a mean leaves them as they are, a sum would multiply them by the
+        world size) — pass all_reduce_averages=False for any other reduction and the TV terms are added after it. Returns the device tensor [mse, depth loss, transmittance loss,
         total] of this batch (no host synchronisation). Same arithmetic as the autograd path: tests/test_train_step.py."""
         lib = _lib.load()
         params = self._autograd_params()
@@ -1136,7 +1142,7 @@ class TensorBase(nn.Module):
         # being zero-filled, accumulated into and TV-incremented after the backward
         seed_ev = seed_terms = None
         if tv and R >= _SEED_MIN_RAYS and getattr(optimizer, "field", None) is self and getattr(self, "defer_factor_grads", False) \
-                and self.supports_deferred_factor_grads():
+                and self.supports_deferred_factor_grads() and (all_reduce is None or all_reduce_averages):
             seed_ev = self.seed_factor_grads_with_tv(tv)
             seed_terms, tv = list(tv), ()
         head = params[12:]

@@ -37,7 +37,14 @@ def discrete_margins(seed):
     rgb, depth, z, w, aux = O.forward(cfg, P, rays, white_bg=True, is_train=is_train, n_samples=n, jitter=jit, return_aux=True)
     pts, _, _ = O.sample_ray(cfg, rays[:, :3], rays[:, 3:6], n, jit)
     m = aux["app_mask"]
-    out = {"w_vs_threshold": float((w - 1e-4).abs().min()), "rays_on_clamp_bound": int(((rgb == 1.0) | (rgb == 0.0)).any(-1).sum())}
+    # a ray sits ON the clamp bound only if it has opacity (a background ray is exactly 1.0 in every implementation, with zero gradient:
+    # it explains nothing) and its colour before the clamp is within rounding of 0 or 1 (163 of 168 background rays made any
+    # failing seed a "knife edge")
+    acc = w.sum(-1)
+    raw = aux.get("rgb_pre_clamp", rgb)
+    on_bound = (((raw - 1.0).abs() < 1e-6) | (raw.abs() < 1e-6)).any(-1) & (acc > 1e-6)
+    out = {"w_vs_threshold": float((w - 1e-4).abs().min()), "rays_on_clamp_bound": int(on_bound.sum()),
+           "background_rays": int((acc <= 1e-6).sum())}
     if m.any():
         f = O.app_feature(P, O.normalize_coord(cfg, pts)[m])
         x = torch.cat([f, O.positional_encoding(f, 6)], -1)
