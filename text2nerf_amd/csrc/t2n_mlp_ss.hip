@@ -15,9 +15,9 @@
 //            both halves: 22 K-steps.
 //   layers 1, 2: K index (step s, half h, element e) = hidden unit 32 (s / 2) + 8 (2 (s % 2) + e / 4) + 4h + e % 4 — what the lane
 //            holds of unit tile s / 2 of the previous layer's accumulators.
-// The weights are the A operands. Layer-0 weights (176 KB as hi / lo f16 halves) stream through a three-slot LDS ring of 16-KB
-// chunks (two K-steps) that the four waves share (filled by LDS-DMA two chunks ahead; one barrier per chunk); layers 1 and 2
-// (80 KB) stay resident in LDS. Layer 0 (69 % of the MFMAs) runs for the wave's three tiles at once on SHARED A operands (every
+// The weights are the A operands. Layer-0 weights (176 KB as hi / lo f16 halves) stream through a four-slot LDS ring of 16-KB
+// chunks (two K-steps) that the four waves share (filled by LDS-DMA three chunks ahead; one barrier per chunk, which waits only for
+// the pieces issued two iterations ago); layers 1 and 2 (80 KB) stay resident in LDS. Layer 0 (69 % of the MFMAs) runs for the wave's three tiles at once on SHARED A operands (every
 // ds_read_b128 of an operand feeds nine MFMAs); layers 1 and 2 run tile by tile, software-pipelined (see stage()).
 //
 // fp32 products are three f16 products of hi / lo splits (x = hi + lo, hi = RTZ_f16(x), lo = RTZ_f16(x - hi); the lo*lo term is
@@ -51,7 +51,8 @@ constexpr int kC0 = 12, kC1 = 4;              // chunks (two K-steps of 16 value
 constexpr int kS2 = 8;                        // K-steps of layer 2
 constexpr int kStep = 4 * 2 * 64;             // uint4 per K-step of layers 0 / 1: [unit tile][part][lane]
 constexpr int kChunk = 2 * kStep;
-constexpr int kRing = 3 * kChunk;
+constexpr int kRingSlots = 4;                 // chunks of the layer-0 stream in LDS: the chunk in use, the next one, two in flight
+constexpr int kRing = kRingSlots * kChunk;
 constexpr int kW0 = kC0 * kChunk;
 constexpr int kW1 = kC1 * kChunk;
 constexpr int kW2 = kS2 * 2 * 64;             // [step][part][lane], one unit tile (rows 0..2 live)
@@ -212,9 +213,9 @@ template <int K> struct ElAddr {
     static constexpr bool l0 = k < kE0, l1 = !l0;
     static constexpr int q = l0 ? 0 : (k - kE0) % kEL;
     static constexpr int s = l0 ? k / 4 : q / 4, ut = l0 ? k % 4 : q % 4;
-    static constexpr int off = l0 ? kW2 + ((s / 2) % 3) * kChunk + (s % 2) * kStep + ut * 128 : s * kStep + ut * 128;
+    static constexpr int off = l0 ? ((s / 2) % kRingSlots) * kChunk + (s % 2) * kStep + ut * 128 : s * kStep + ut * 128;
 };
-struct LdsA { const u4v* a0; const u4v* a1; };
+struct LdsA { const u4v* a0; const u4v* a1; const u4v* a2; };   // + lane: the ring, W1, W2 (a DS instruction's immediate offset reaches 64 KB)
 template <int K>
 __device__ __forceinline__ void fetch(AEl (&A)[4], const LdsA& L) {
     if constexpr (K >= kER) return;   // the next round fetches its first four elements itself (32 registers less across the round boundary)
@@ -242,7 +243,7 @@ __device__ __forceinline__ void fetch_half(AEl (&A)[4], const LdsA& L) {
 template <int St>
 __device__ __forceinline__ void fetch2(AEl (&A2)[2], const LdsA& L) {
     if constexpr (St < kS2) {
-        const u4v* __restrict__ p = L.a0 + St * 128;
+        const u4v* __restrict__ p = L.a2 + St * 128;
         A2[St % 2].h = p[0]; A2[St % 2].l = p[64];
     }
 }
@@ -481,12 +482,18 @@ __device__ __forceinline__ void l2_step(AEl (&A2)[2], const u4v& Hh, const u4v& 
     SS_FENCE();
 }
 
+// The chunk barrier: every wave has its OWN older LDS-DMA pieces landed (vmcnt(KEEP): the KEEP most recent ones may stay in flight — a
+// __syncthreads() would drain them all and make every barrier wait for the landing of pieces nobody needs for another iteration: 3 k of
+// a round's 52 k cycles with the three-slot ring this kernel started with) and its LDS reads done, then s_barrier.
+// (the wait as a builtin — simm16: vmcnt[3:0], expcnt[6:4] = 7, lgkmcnt[11:8] = 0, vmcnt[5:4] in [15:14] — so that hipcc's own counter
+// bookkeeping sees it: behind an opaque wait it kept re-waiting for LDS reads that were long complete)
+#define SS3_BAR_ASM(KEEP) do { __builtin_amdgcn_s_waitcnt((KEEP) == 0 ? 0x0070 : 0x0074); asm volatile("s_barrier" ::: "memory"); } while (0)
 #ifdef SS3_ABL_NO_BARRIER
-#define SS3_BARRIER() do {} while (0)
+#define SS3_BARRIER(KEEP) do {} while (0)
 #elif defined(SS3_PROF)
-#define SS3_BARRIER() do { const unsigned long long tb = __builtin_readcyclecounter(); __syncthreads(); p_bar += __builtin_readcyclecounter() - tb; } while (0)
+#define SS3_BARRIER(KEEP) do { const unsigned long long tb = __builtin_readcyclecounter(); SS3_BAR_ASM(KEEP); p_bar += __builtin_readcyclecounter() - tb; } while (0)
 #else
-#define SS3_BARRIER() __syncthreads()
+#define SS3_BARRIER(KEEP) SS3_BAR_ASM(KEEP)
 #endif
 #ifdef SS3_PROF
 #define SS3_T(var) do { const unsigned long long tn = __builtin_readcyclecounter(); var += tn - p_t; p_t = tn; } while (0)
@@ -509,19 +516,25 @@ __device__ __forceinline__ void l2_last(AEl (&A2)[2], const u4v& Hh, const u4v& 
 
 __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-    // LDS map as k_mlp_ss: W2 [0, 16 KB) | ring [16 KB, 64 KB) | W1 [64 KB, 128 KB) | biases (UNSCALED here) | sub-list table
-    uint4* __restrict__ W2 = lds;
-    uint4* __restrict__ RING = lds + kW2;
+    // LDS map: ring [0, 64 KB) | W1 [64 KB, 128 KB) | W2 [128 KB, 144 KB) | biases (unscaled) | sub-list table. A DS instruction carries a
+    // 16-bit byte offset: with the lane's operand addresses written as THREE opaque bases (lane * 16 + 0 / 64 KB / 128 KB) plus constants
+    // every fetch is base + immediate; left to itself hipcc materialises one base register per 64-KB-crossing constant and spills them.
+    uint4* __restrict__ RING = lds;
     uint4* __restrict__ W1 = RING + kRing;
-    float* __restrict__ LB = reinterpret_cast<float*>(W1 + kW1);
+    uint4* __restrict__ W2 = W1 + kW1;
+    float* __restrict__ LB = reinterpret_cast<float*>(W2 + kW2);
+    static_assert(kRing * 16 == 65536 && kW1 * 16 == 65536, "the ring and W1 each fill one 64-KB window");
     unsigned* __restrict__ LT = reinterpret_cast<unsigned*>(LB + kBias);
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    unsigned ob0 = (unsigned)lane * 16u, ob1 = (unsigned)lane * 16u + 65536u, obb = (unsigned)((kW2 + kRing + kW1) * 16) + 16u * (unsigned)h;
+    unsigned ob0 = (unsigned)lane * 16u, ob1 = (unsigned)lane * 16u + 65536u, ob2 = (unsigned)lane * 16u + 131072u,
+             obb = (unsigned)((kW2 + kRing + kW1) * 16) + 16u * (unsigned)h;
     asm volatile("" : "+v"(ob0));
     asm volatile("" : "+v"(ob1));
+    asm volatile("" : "+v"(ob2));
     asm volatile("" : "+v"(obb));
-    const LdsA L{reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(lds) + ob0), reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(lds) + ob1)};
+    const LdsA L{reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(lds) + ob0), reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(lds) + ob1),
+                 reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(lds) + ob2)};
     const float* __restrict__ LBh = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + obb);
 
     unsigned cnt_l = 0;
@@ -548,6 +561,7 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
     const Stream3 S{a.w0, tid};
     S.dma<0>(RING, 0); S.dma<1>(RING, 0); S.dma<2>(RING, 0); S.dma<3>(RING, 0);
     S.dma<0>(RING + kChunk, 1); S.dma<1>(RING + kChunk, 1); S.dma<2>(RING + kChunk, 1); S.dma<3>(RING + kChunk, 1);
+    S.dma<0>(RING + 2 * kChunk, 2); S.dma<1>(RING + 2 * kChunk, 2); S.dma<2>(RING + 2 * kChunk, 2); S.dma<3>(RING + 2 * kChunk, 2);
     const float neg1 = a.neg1;
     s2v amax = {0, 0};   // hidden activations: max of the packed RTZ halves' bit patterns (non-negative values; -0 and NaN never reach here)
     unsigned amax_u = 0u;
@@ -606,11 +620,14 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
 #define SS3_ENC(S_, P_) {{E[0], Bh[P_][0], Bl[P_][0], neg1}, {E[1], Bh[P_][1], Bl[P_][1], neg1}, {E[2], Bh[P_][2], Bl[P_][2], neg1}}
 #define SS3_L0(C)                                                                                                                 \
         {                                                                                                                         \
-            SS3_BARRIER();   /* chunk C + 1 written by every wave; chunk C - 1 read by every wave */                              \
+            /* chunk C + 1 written by every wave (issued two iterations ago: the four pieces of the LAST iteration - chunk C + 2 - may  */ \
+            /* still be in flight, except behind iteration 8, which issues none: the stream's padding chunk), chunk C - 1 read by all  */ \
+            SS3_BARRIER(C == 9 ? 0 : 4);                                                                                          \
             if constexpr (C == 0) { fetch<0>(A, L); fetch<1>(A, L); fetch<2>(A, L); fetch<3>(A, L); }                             \
-            RingOps3 ring{S, RING + ((C + 2) % 3) * kChunk, (C + 2) % kC0};                                                       \
+            RingOps3 ring{S, RING + ((C + 3) % kRingSlots) * kChunk, (C + 3) % kC0};                                              \
             if constexpr (C == 11) {                                                                                              \
-                ring.all();                                                                                                       \
+                /* nothing to multiply (the stream's padding chunk): this iteration is the barrier behind chunk 10's last reads. The   */ \
+                /* DMA it would issue (the next round's chunk 2) goes out at the END of the round instead: see there                  */ \
             } else {                                                                                                              \
                 {                                                                                                                 \
                     EncFill3<2 * C + 1> f0[kT3] = SS3_ENC(2 * C + 1, 1);                                                          \
@@ -621,7 +638,6 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
                     l0_slots<0, 2 * C + 1>(A, Bh[1], Bl[1], f1, NoRing(), L);                                                     \
                 } else {                                                                                                          \
                     NoFill f1[kT3];                                                                                               \
-                    conv_bias<0, 0>(V, LBh);   /* tile 0's first conversion step */                                               \
                     l0_slots<0, 2 * C + 1>(A, Bh[1], Bl[1], f1, NoRing(), L);                                                     \
                 }                                                                                                                 \
             }                                                                                                                     \
@@ -666,6 +682,9 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
             u4v H0h[8], H0l[8], H1h[8], H1l[8];
             TileCtx ctx{accv, A, A2, V, V1, amax, inv0, inv1, neg1, LBh, L, H0h, H0l, H1h, H1l};
             asm volatile("; SS3_MARK stage0");
+            // (hipcc cannot tell the bias reads from the LDS-DMA's destination and drains vmcnt in front of the first one behind a DMA issue:
+            // none is issued between here and the round's last bias read — the next round's chunk 2 goes out at the end of the round)
+            conv_bias<0, 0>(V, LBh);   // tile 0's first conversion step
             stage<0>(ctx);
             SS3_T(p_tile[0]);
             asm volatile("; SS3_MARK stage1");
@@ -696,6 +715,9 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
                 l2_last<128>(A2, H1h[7], H1l[7], f3);
             }
             SS3_FINAL(2)
+            // the next round's chunk 2 -> ring slot 2 (chunk 10's, free since the barrier of iteration 11): issued here, behind the round's
+            // last bias read; it has the next round's whole first iteration to land
+            { RingOps3 ring{S, RING + 2 * kChunk, 2}; ring.all(); }
             asm volatile("; SS3_MARK end");
             SS3_T(p_tile[2]);
 #ifdef SS3_PROF
