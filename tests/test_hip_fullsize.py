@@ -79,10 +79,11 @@ def test_c3_full_batch_gradients_vs_oracle():
     parts, ref = oracle_driver_loss_and_grads(cfg, params, rays, jitter, rgb_t, dep_t, 259)
     got = np.array([float(mse), float(dl), float(tl)])
     np.testing.assert_allclose(got, parts, rtol=2e-5, atol=1e-9)
-    # three metrics per tensor: max |dg| / max |g| (one flipped knife-edge sample shows here), relative L2 and 1 - cosine (whole-tensor
-    # agreement). Both sides sum in fp32 in different orders (each of the 4 800 density-line elements collects ~1 500 signed
-    # contributions of 2.5 M samples): round 4 measured relative L2 <= 1.3e-4 (the two density lines with the walls), 1 - cosine <= 1e-8
-    worst = _grad_check(f, ref, rel=1e-3, rel_l2=2e-4, cos_gap=5e-8)
+    # three metrics per tensor: max |dg| / max |g| (one flipped knife-edge sample shows here: an appearance sample per few thousand sits
+    # on the 1e-4 list threshold), relative L2 and 1 - cosine (whole-tensor agreement). Round 4, after the softplus-derivative fix
+    # (profiles/round4_fuzz_campaign_4000_300.txt): density tensors 2.5e-5 / 2.2e-5 / 2e-10, appearance tensors 8.6e-4 / 8e-5 / 3e-9
+    worst = _grad_check(f, ref, rel=1e-3, rel_l2=1e-4, cos_gap=1e-8)
+    assert max(v for k, v in worst.items() if k.startswith("density")) <= 1e-4, worst
     print("C3 full batch: losses", got, "max relative gradient errors:", {k: f"{v:.1e}" for k, v in worst.items()})
     print("   relative L2:", {k: f"{v:.1e}" for k, v in _grad_check.last["rel_l2"].items()})
     print("   1 - cosine:", {k: f"{v:.1e}" for k, v in _grad_check.last["one_minus_cos"].items()})

@@ -340,7 +340,11 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
             const float f = (1.f - al) + 1e-10f;
             const float dalpha = G * T - after / f;
             const float dsigma = dalpha * scaled_dist(F, ray, dist) * (1.f - al);
-            const float dact = F.act == T2N_ACT_RELU ? (sg > 0.f ? 1.f : 0.f) : (1.f - expf(-sg));
+            // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x)), from the kept sigma. As -expm1(-sigma): in empty space sigma is
+            // softplus(-10) = 4.5e-5, and 1.f - expf(-4.5e-5f) carries the rounding of a value next to 1 (6e-8 absolute = 1.3e-3 of the
+            // result) into every density gradient — what the round-3 / round-4 fuzz campaigns saw on nearly empty batches (seeds 3027,
+            // 4295: all six density tensors 6e-4 ... 1.6e-3 off the float64 oracle, both scatters alike; tools/experiments/fuzz_scatter_diag.py)
+            const float dact = F.act == T2N_ACT_RELU ? (sg > 0.f ? 1.f : 0.f) : -expm1f(-sg);
             Gw[j] = dsigma * dact;
         }
     }
@@ -1336,12 +1340,9 @@ static void launch_bwd_l2(const float4* go, const float* h1, long long rows, con
     hipLaunchKernelGGL(k_bwd_l2, dim3(nb), dim3(256), 0, s, go, h1, rows, w2, g1, scratch);
     if (dw2 || db2) hipLaunchKernelGGL(k_bwd_l2_reduce, dim3(387), dim3(256), 0, s, (const float*)scratch, (int)nb, dw2, db2);
 }
-// the fp32-MFMA GEMMs instead of the f16 / bf16 split ones (t2n_gemm_h.hip, t2n_mlp_bwd_ss.hip): by environment, or because the field
-// runs its MLP in exact fp32 (t2n_field_set_mlp_precision: the backward then keeps fp32 products too)
-static bool gemm_fp32_mode(const t2n_field* f) {
-    static const bool v = getenv("T2N_BWD_GEMM_FP32") != nullptr;
-    return v || !f->mlp_split;
-}
+// the fp32-MFMA GEMMs instead of the f16 / bf16 split ones (t2n_gemm_h.hip, t2n_mlp_bwd_ss.hip): when the field runs its MLP in exact
+// fp32 (t2n_field_set_mlp_precision: the backward then keeps fp32 products too)
+static bool gemm_fp32_mode(const t2n_field* f) { return !f->mlp_split; }
 // pe_feat (fused head only): B is the [rows, 352] positional encoding; on the bf16x3 path it is computed from feat [rows, 32] inside the
 // GEMM and `B` is never read. db (may be NULL): += column sums of A (the layer's bias gradient).
 template <int MB>
@@ -1572,8 +1573,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             if (rows > 0 && f->dev.app.C == 48) so.zero(bw + b.a_hist, (size_t)bin_geom(f->dev.app).total * kBinCopies * 4);
         }
         // the fused input-gradient chain's operands are packed now, while the stream is alone on the GPU
-        static const bool unfused_env0 = getenv("T2N_BWD_UNFUSED") != nullptr;
-        const bool pack_now = rows > 0 && !generic && !simple && !gemm_fp32_mode(f) && !unfused_env0 && f->desc.app_dim == 27 && K0 == 351;
+        const bool pack_now = rows > 0 && !generic && !simple && !gemm_fp32_mode(f) && f->desc.app_dim == 27 && K0 == 351;
         if (pack_now) so.zero(mlp_bwd_ss_absmax_words((void*)(bw + b.gpack)), 16);
         if ((rc = launch_setup(so, s))) return rc;
         if (pack_now && (rc = mlp_bwd_ss_pack(f, (void*)(bw + b.gpack), s, true))) return rc;
@@ -1628,8 +1628,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         const t2n_field_params* P = &f->params_ref;
         timing_begin(f, T2N_K_BWD_MLP, s);
         const bool gemm_fp32 = gemm_fp32_mode(f);
-        static const bool unfused_env = getenv("T2N_BWD_UNFUSED") != nullptr;   // A/B switch: the five-launch form of the input-gradient chain
-        const bool fused = !generic && !gemm_fp32 && !unfused_env && f->desc.app_dim == 27 && K0 == 351;
+        const bool fused = !generic && !gemm_fp32 && f->desc.app_dim == 27 && K0 == 351;   // (the five-launch form below serves the general heads and the exact mode)
         void* gpack = (void*)(bw + b.gpack);
         if (simple) {
             // parameter-free heads: dL/dfeatures straight from the colour gradients, then basis_mat's two products on the exact path
@@ -1674,7 +1673,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         // (a bias gradient without its weight gradient does not occur: the column sums ride in the weight-gradient GEMM)
         if (g->mlp_w1) launch_gemm_tn<4>(gemm_fp32, g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, s, nullptr, g->mlp_b1);
         else if (g->mlp_b1) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, (const float*)g1, 128, (long long)rows, 128, g->mlp_b1, 128);
-        // input-gradient GEMMs: split-f16 MFMA products with a power-of-two scale per row (t2n_gemm_h.hip); T2N_BWD_GEMM_FP32=1
+        // input-gradient GEMMs: split-f16 MFMA products with a power-of-two scale per row (t2n_gemm_h.hip)
         // keeps the fp32-MFMA form
         if (!gemm_fp32 && (rc = gemm_h_pack(f, gpack, K0, s))) return rc;
         if (gemm_fp32) launch_gemm_nn(g1, 128, P->mlp_w1, 128, rows, 128, 128, h0, 128, g0, 128, s);

@@ -247,7 +247,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N
     // the wave leaves the loop when none of its rays has anything left to evaluate
     const float eps = DENSE ? 0.f : F.term_eps;
     for (int i = i_begin; i <= i_end; i += kSteps) {
-        if (eps > 0.f && !__any(have && i <= hi && !(T < eps))) break;
+        // (looked at every eighth step pair: the vote is a handful of instructions in a kernel bound by VALU issue)
+        if (eps > 0.f && (((i - i_begin) & 15) == 0) && !__any(have && i <= hi && !(T < eps))) break;
         float xn[kSteps], yn[kSteps], zn[kSteps], z[kSteps], w_out[kSteps];
         bool ok[kSteps];
         Axes3 A[kSteps];

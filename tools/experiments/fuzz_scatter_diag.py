@@ -1,6 +1,8 @@
 """A failed gradient-fuzz seed: the HIP gradients with the binned scatters against the sliding-window global-atomic scatter
-(T2N_BWD_ATOMIC_SCATTER=1, an independent implementation of the same sums) and against the oracle's autograd, per tensor."""
+(T2N_BWD_ATOMIC_SCATTER=1, an independent implementation of the same sums), against the oracle's autograd in float32 and against the
+oracle in FLOAT64 (what tells fp32 summation noise in a nearly empty batch from a wrong sum), per tensor."""
 import os, sys, subprocess
+os.environ.setdefault("T2N_EARLY_TERMINATION", "0")
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -28,10 +30,11 @@ if len(sys.argv) > 2:
     out = f(rays, is_train=is_train, white_bg=True, N_samples=n)
     ((out[0] * ca.to(dev())).sum() + 0.1 * out[1].sum() + (out[3] ** 2).sum()).backward()
     res = {k: p.grad.cpu().numpy() for k, p in f.named_parameters()}
-    if sys.argv[2] == "oracle":
-        P = O.params_from_numpy(params, requires_grad=True)
-        o = O.forward(cfg, P, rays, white_bg=True, is_train=is_train, n_samples=n, jitter=jit)
-        ((o[0] * ca).sum() + 0.1 * o[1].sum() + (o[3] ** 2).sum()).backward()
+    if sys.argv[2] in ("oracle", "oracle64"):
+        dt = torch.float64 if sys.argv[2] == "oracle64" else torch.float32
+        P = O.params_from_numpy(params, requires_grad=True, dtype=dt)
+        o = O.forward(cfg, P, rays.to(dt), white_bg=True, is_train=is_train, n_samples=n, jitter=None if jit is None else jit.to(dt))
+        ((o[0] * ca.to(dt)).sum() + 0.1 * o[1].sum() + (o[3] ** 2).sum()).backward()
         res = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).numpy() for k, v in P.items()}
         print("grid", grid, "train", is_train, "n", n)
     np.savez(sys.argv[3], **res)
@@ -39,9 +42,13 @@ if len(sys.argv) > 2:
 env = dict(os.environ)
 subprocess.check_call([sys.executable, __file__, str(seed), "hip", "/tmp/fz_bin.npz"], env=env)
 subprocess.check_call([sys.executable, __file__, str(seed), "oracle", "/tmp/fz_or.npz"], env=env)
+subprocess.check_call([sys.executable, __file__, str(seed), "oracle64", "/tmp/fz_or64.npz"], env=env)
 env["T2N_BWD_ATOMIC_SCATTER"] = "1"
 subprocess.check_call([sys.executable, __file__, str(seed), "hip", "/tmp/fz_at.npz"], env=env)
-a, b, o = np.load("/tmp/fz_bin.npz"), np.load("/tmp/fz_at.npz"), np.load("/tmp/fz_or.npz")
+a, b, o, o64 = np.load("/tmp/fz_bin.npz"), np.load("/tmp/fz_at.npz"), np.load("/tmp/fz_or.npz"), np.load("/tmp/fz_or64.npz")
+print("seed", seed, ": errors as max |difference| / max |float64 gradient| per tensor")
 for k in a.files:
-    s = np.abs(o[k]).max() + 1e-12
-    print("%-28s binned-vs-atomic %.1e   binned-vs-oracle %.1e   atomic-vs-oracle %.1e" % (k, np.abs(a[k] - b[k]).max() / s, np.abs(a[k] - o[k]).max() / s, np.abs(b[k] - o[k]).max() / s))
+    s = np.abs(o64[k]).max() + 1e-300
+    print("%-28s binned-vs-atomic %.1e   binned-vs-f32-oracle %.1e   binned-vs-f64 %.1e   atomic-vs-f64 %.1e   f32-oracle-vs-f64 %.1e   max|g| %.2e" % (
+        k, np.abs(a[k] - b[k]).max() / s, np.abs(a[k] - o[k]).max() / s, np.abs(a[k] - o64[k]).max() / s, np.abs(b[k] - o64[k]).max() / s,
+        np.abs(o[k] - o64[k]).max() / s, np.abs(o64[k]).max()))
