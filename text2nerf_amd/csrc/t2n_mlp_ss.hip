@@ -269,55 +269,63 @@ struct EncFill3 {   // layer-0 B operand of K-step S of one tile -> (Bh, Bl)
         Bl = u4v{E.pl[0], E.pl[1], E.pl[2], E.pl[3]};
     }
 };
-struct Conv3 {   // the conversion fillers' state (one tile at a time)
-    Unit cu; unsigned ph[4], pl[4];
-    float4 bq[2][2];   // [K-step parity][half]: the biases of the eight units a step converts
+struct Conv3 {   // the conversion fillers' state (one tile at a time): up to three of a step's four units are in flight
+    float x[4][2]; unsigned ph[4], pl[4];
+    u4v bq[2][2];      // [K-step parity][half]: the biases of the eight units a step converts (bit patterns: loaded as the A operands
+                       // are — a typed vector load carries TBAA, and hipcc drains the LDS-DMA counter in front of LDS loads that carry none)
 };
 // biases of conversion step S (units 32 (S / 2) + 8 b + 4 h + t, b = 2 (S % 2), 2 (S % 2) + 1) -> bq[S % 2]; issued a step ahead
 template <int S, int BOFF>
 __device__ __forceinline__ void conv_bias(Conv3& V, const float* __restrict__ LBh) {
-    V.bq[S % 2][0] = *reinterpret_cast<const float4*>(LBh + BOFF + 32 * (S / 2) + 16 * (S % 2));
-    V.bq[S % 2][1] = *reinterpret_cast<const float4*>(LBh + BOFF + 32 * (S / 2) + 16 * (S % 2) + 8);
+    const u4v* __restrict__ p = reinterpret_cast<const u4v*>(LBh + BOFF + 32 * (S / 2) + 16 * (S % 2));
+    V.bq[S % 2][0] = p[0];
+    V.bq[S % 2][1] = p[2];
 }
+// relu(acc * inv + bias) of registers 8 (S % 2) .. +7 of unit tile S / 2 -> B operand of K-step S; the accumulators are AccVGPRs from
+// BASE (>= 0) or the architectural registers src[4] (BASE < 0). A unit (two values) goes through SIX micro-operations — read, scale +
+// bias, ReLU, hi halves, residuals (+ range tracking), lo halves — each depending on the one before; call IDX (0..11, one per MFMA slot)
+// runs micro-operation IDX - 2 j of unit j, so that a slot holds at most three instructions groups of three DIFFERENT units and no
+// instruction sits next to its producer. (One wave per SIMD: an instruction issued right behind the one it depends on costs 8 cycles
+// instead of 4, and v_fma_mix -> v_cvt_pkrtz needs a wait state on top: tools/experiments/issue_cost.hip, 8.0 against 5.6 cycles per
+// instruction for the split sequence alone.)
 template <int S, int BASE, int BOFF>
-struct ConvFill3 {   // relu(acc * inv + bias) of registers 8 (S % 2) .. +7 of unit tile S / 2 -> B operand of K-step S; the accumulators are
-                     // AccVGPRs from BASE (>= 0) or the architectural registers src[4] (BASE < 0)
+struct ConvFill3 {
     u4v (&Hh)[8]; u4v (&Hl)[8]; Conv3& V; float inv, neg1; s2v& amax; const float* __restrict__ LBh; const f32x16* src;
     template <int IDX> __device__ __forceinline__ void run() {
 #ifdef SS3_ABL_NO_CONV
         if (S > 0) return;
 #endif
-        phase<IDX / 3, IDX % 3, (IDX == 1)>(V.cu);
+        micro<3, IDX - 6>(); micro<2, IDX - 4>(); micro<1, IDX - 2>(); micro<0, IDX>();
+        if constexpr (IDX == 1 && S < 7) conv_bias<(S < 7 ? S + 1 : 0), BOFF>(V, LBh);
     }
-    // the twelve phases as three passes over FOUR units in flight: four independent dependency chains per pass instead of one chain of
-    // twelve (where no MFMA stream needs the phases spread out: a stage's first conversion step, the round's last tile)
-    __device__ __forceinline__ void all() {
-        Unit U[4];
-        phase<0, 0, false>(U[0]); phase<1, 0, false>(U[1]); phase<2, 0, false>(U[2]); phase<3, 0, false>(U[3]);
-        phase<0, 1, true>(U[0]); phase<1, 1, false>(U[1]); phase<2, 1, false>(U[2]); phase<3, 1, false>(U[3]);
-        phase<0, 2, false>(U[0]); phase<1, 2, false>(U[1]); phase<2, 2, false>(U[2]); phase<3, 2, false>(U[3]);
+    __device__ __forceinline__ void all() {   // (where no MFMA stream needs the calls spread out: a stage's first conversion step, the round's last tile)
+        run<0>(); run<1>(); run<2>(); run<3>(); run<4>(); run<5>(); run<6>(); run<7>(); run<8>(); run<9>(); run<10>(); run<11>();
         done();
     }
-    template <int j, int PH, bool NEXT_BIAS> __device__ __forceinline__ void phase(Unit& U) {
-        if constexpr (PH == 0) {
-            const float4& b = V.bq[S % 2][j / 2];
-            const float b0 = (j % 2) ? b.z : b.x, b1 = (j % 2) ? b.w : b.y;
+    template <int j, int m> __device__ __forceinline__ void micro() {
+        if constexpr (m == 0) {
             if constexpr (BASE >= 0) {
                 constexpr int reg = BASE + 16 * (S / 2) + 8 * (S % 2) + 2 * j;
-                const float a0 = acc_read<reg>(), a1 = acc_read<reg + 1>();
-                U.x0 = fmaxf(fmaf(a0, inv, b0), 0.f);
-                U.x1 = fmaxf(fmaf(a1, inv, b1), 0.f);
+                V.x[j][0] = acc_read<reg>(); V.x[j][1] = acc_read<reg + 1>();
             } else {
-                const float a0 = src[S / 2][8 * (S % 2) + 2 * j], a1 = src[S / 2][8 * (S % 2) + 2 * j + 1];
-                U.x0 = fmaxf(fmaf(a0, inv, b0), 0.f);
-                U.x1 = fmaxf(fmaf(a1, inv, b1), 0.f);
+                V.x[j][0] = src[S / 2][8 * (S % 2) + 2 * j]; V.x[j][1] = src[S / 2][8 * (S % 2) + 2 * j + 1];
             }
-        } else if constexpr (PH == 1) {
-            unit_pack(U);
-            amax = __builtin_elementwise_max(amax, __builtin_bit_cast(s2v, U.hi));   // bit patterns of non-negative halves order like their values
-            if constexpr (NEXT_BIAS && S < 7) conv_bias<(S < 7 ? S + 1 : 0), BOFF>(V, LBh);
-        } else {
-            unit_split(U, neg1, V.ph[j], V.pl[j]);
+        } else if constexpr (m == 1) {
+            const u4v& b = V.bq[S % 2][j / 2];
+            V.x[j][0] = fmaf(V.x[j][0], inv, __uint_as_float((j % 2) ? b[2] : b[0]));
+            V.x[j][1] = fmaf(V.x[j][1], inv, __uint_as_float((j % 2) ? b[3] : b[1]));
+        } else if constexpr (m == 2) {
+            V.x[j][0] = fmaxf(V.x[j][0], 0.f);
+            V.x[j][1] = fmaxf(V.x[j][1], 0.f);
+        } else if constexpr (m == 3) {
+            V.ph[j] = __builtin_bit_cast(unsigned, (hh2)__builtin_amdgcn_cvt_pkrtz(V.x[j][0], V.x[j][1]));
+        } else if constexpr (m == 4) {
+            const h2v ph = __builtin_bit_cast(h2v, V.ph[j]);
+            V.x[j][0] = fmaf((float)ph[0], neg1, V.x[j][0]);
+            V.x[j][1] = fmaf((float)ph[1], neg1, V.x[j][1]);
+            amax = __builtin_elementwise_max(amax, __builtin_bit_cast(s2v, V.ph[j]));   // bit patterns of non-negative halves order like their values
+        } else if constexpr (m == 5) {
+            V.pl[j] = __builtin_bit_cast(unsigned, (hh2)__builtin_amdgcn_cvt_pkrtz(V.x[j][0], V.x[j][1]));
         }
     }
     __device__ __forceinline__ void done() {
@@ -655,8 +663,8 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
             const float c20 = acc_read<64 * T_ + 32>(), c21 = acc_read<64 * T_ + 33>(), c22 = acc_read<64 * T_ + 34>();           \
             const unsigned tile = (r * 4u + (unsigned)w) * 3u + T_;                                                               \
             if (tile < ntiles && h == 0) {   /* output rows 0..2 live in registers 0..2 of lanes 0..31 */                         \
-                const uint4 i0 = *reinterpret_cast<const uint4*>(LT), i1 = *reinterpret_cast<const uint4*>(LT + 4);               \
-                const unsigned pre[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};                                         \
+                const u4v i0 = *reinterpret_cast<const u4v*>(LT), i1 = *reinterpret_cast<const u4v*>(LT + 4);   /* (typed: see Conv3) */ \
+                const unsigned pre[8] = {i0[0], i0[1], i0[2], i0[3], i1[0], i1[1], i1[2], i1[3]};                                 \
                 int li = 0;                                                                                                       \
                 unsigned before = 0u;                                                                                             \
                 _Pragma("unroll") for (int l = 0; l < 8; ++l) if (pre[l] <= tile) { li = l + 1; before = pre[l]; }                \
