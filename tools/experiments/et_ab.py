@@ -1,0 +1,28 @@
+"""Early termination on / off, three scenes, C2 frame: ms per frame (alternating blocks) and evaluated samples. argv: repetitions."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import bench
+dev = torch.device("cuda:0")
+from text2nerf_amd import synth
+rays = torch.from_numpy(synth.frame_rays_np(800, 800)).to(dev)
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+for sc, sd in (("S1-soft", 0), ("S2", 1), ("S1-sharp", 0)):
+    fld = bench.build_field(dev, scene=sc, seed=sd)[0]
+    fld.materialize_weights, fld.frame_width = False, 800
+    res = {"on": [], "off": []}
+    ev = {}
+    for r in range(reps):
+        for tag, eps in (("on", 1e-6), ("off", 0.0)):
+            fld.early_termination = eps
+            with torch.no_grad():
+                for _ in range(3):
+                    fld(rays, white_bg=True, is_train=False, N_samples=-1)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(20):
+                    fld(rays, white_bg=True, is_train=False, N_samples=-1)
+                torch.cuda.synchronize()
+            res[tag].append(round((time.perf_counter() - t0) / 20 * 1e3, 3))
+            ev[tag] = fld.stats()["evaluated"]
+    print(sc, "on", res["on"], "off", res["off"], "evaluated on/off", ev["on"], ev["off"], round(ev["on"] / ev["off"], 3), flush=True)
+    del fld
