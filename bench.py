@@ -927,19 +927,23 @@ def main():
                 try:
                     fld = field if sc == args.scene else build_field(dev, scene=sc, seed=sd)[0]
                     fld.materialize_weights, fld.frame_width = False, W
-                    row = {}
-                    for tag, eps in (("on", 1e-6), ("off", 0.0)):
-                        fld.early_termination = eps
-                        with torch.no_grad():
-                            for _ in range(3):
-                                fld(rays, white_bg=True, is_train=False, N_samples=-1)
-                            torch.cuda.synchronize()
-                            t0 = time.perf_counter()
-                            for _ in range(20):
-                                fld(rays, white_bg=True, is_train=False, N_samples=-1)
-                            torch.cuda.synchronize()
-                        row[f"ms_per_frame_{tag}"] = (time.perf_counter() - t0) / 20 * 1e3
-                        row[f"evaluated_samples_{tag}"] = fld.stats()["evaluated"]
+                    row, blocks = {}, {"on": [], "off": []}
+                    for rep in range(3):   # alternating blocks, medians: the first block behind a field build runs 1-4 % slow whatever its mode
+                        for tag, eps in (("on", 1e-6), ("off", 0.0)):
+                            fld.early_termination = eps
+                            with torch.no_grad():
+                                for _ in range(3):
+                                    fld(rays, white_bg=True, is_train=False, N_samples=-1)
+                                torch.cuda.synchronize()
+                                t0 = time.perf_counter()
+                                for _ in range(10):
+                                    fld(rays, white_bg=True, is_train=False, N_samples=-1)
+                                torch.cuda.synchronize()
+                            blocks[tag].append((time.perf_counter() - t0) / 10 * 1e3)
+                            row[f"evaluated_samples_{tag}"] = fld.stats()["evaluated"]
+                    for tag in ("on", "off"):
+                        row[f"ms_per_frame_{tag}"] = sorted(blocks[tag])[1]
+                        row[f"ms_per_frame_{tag}_blocks"] = [round(b, 4) for b in blocks[tag]]
                     et[sc] = row
                     if fld is not field:
                         del fld
