@@ -272,6 +272,11 @@ int t2n_warp_finish(const uint8_t* filled, const uint8_t* image_u8, int H, int W
  * the rest of the scan. Runs as skewed wavefronts (t = col + 3 row) in one workgroup. image [H,W,3] fp32, known [H,W]
  * int32 (0 / non-zero), depth [H,W] fp64 or NULL; all updated in place. */
 int t2n_dibr_filter_mask2(float* image, int32_t* known, double* depth, int H, int W, float threshold, t2n_stream stream);
+/* dibr_filter_mask (utils.py:345-392; the reference's driver does not call it): the scan above with threshold 0.6 and no depth, then a
+ * 3x3 fill scan (unknown pixels whose 3x3 neighbourhood is known to more than 0.5), the four border lines (copy the inner neighbour
+ * where it is known) and a 3x3 erase scan (known pixels whose neighbourhood is known to less than 0.45 become 255 / unknown), all in
+ * place and in raster order (fronts t = col + 2 row). image [H,W,3] fp32, known [H,W] int32. */
+int t2n_dibr_filter_mask(float* image, int32_t* known, int H, int W, t2n_stream stream);
 
 /* ---- a-15: backward of the render call w.r.t. all field parameters (what autograd derives in the reference,
  * text2nerf_main.py:589; coordinates are detached there, models/tensoRF.py:208-210,226-228, so no ray gradients exist).

@@ -174,6 +174,45 @@ def dibr_filter_mask2(image, known, depth=None, thr=0.65):
     return (image, known) if depth is None else (image, known, depth)
 
 
+FILL_W3 = np.array([[1, 3, 1], [3, 0, 3], [1, 3, 1]], np.int64)
+
+
+def dibr_filter_mask(image, known):
+    """utils.py:345-392 (no call site in the driver): five in-place stages over the merged warp. (1) the scan of dibr_filter_mask2 with
+    threshold 0.6 and no depth; (2) a second raster scan over rows 1..H-2, cols 1..W-2: an unknown pixel whose 3x3 neighbourhood is known
+    to more than 0.5 (weights FILL_W3 / 16) takes the mean of its known 3x3 neighbours and becomes known immediately; (3) the four border
+    lines — top row, bottom row, left column, right column, in that order — copy their inner neighbour where it is known; (4) an erase
+    scan in raster order: a KNOWN pixel whose 3x3 neighbourhood is known to less than 0.45 is set to 255 and becomes unknown
+    immediately. In-place semantics restated on copies; fp64 means."""
+    image, known = dibr_filter_mask2(image, known, None, thr=0.6)
+    H, W, _ = image.shape
+    for i in range(1, H - 1):
+        for j in range(1, W - 1):
+            if known[i, j] != 0 or int((known[i - 1:i + 2, j - 1:j + 2] * FILL_W3).sum()) / 16.0 <= 0.5:
+                continue
+            k3 = known[i - 1:i + 2, j - 1:j + 2].astype(np.float64)
+            n = k3.sum()
+            for c in range(3):
+                image[i, j, c] = (image[i - 1:i + 2, j - 1:j + 2, c].astype(np.float64) * k3).sum() / n
+            known[i, j] = 1
+    for i, ii in ((0, 1), (H - 1, H - 2)):
+        for j in range(W):
+            if known[i, j] == 0 and known[ii, j] > 0:
+                image[i, j, :] = image[ii, j, :]
+                known[i, j] = 1
+    for j, jj in ((0, 1), (W - 1, W - 2)):
+        for i in range(H):
+            if known[i, j] == 0 and known[i, jj] > 0:
+                image[i, j, :] = image[i, jj, :]
+                known[i, j] = 1
+    for i in range(1, H - 1):
+        for j in range(1, W - 1):
+            if known[i, j] == 1 and int((known[i - 1:i + 2, j - 1:j + 2] * FILL_W3).sum()) / 16.0 < 0.45:
+                image[i, j, :] = 255
+                known[i, j] = 0
+    return image, known
+
+
 def align_depth_global(depth_rendered, depth_est, pixel_sample, push_depth):
     """text2nerf_main.py:241-270 (the part after the pixel list has been drawn with random.sample, :234-240): global scale from the
     ratios of depth differences between CONSECUTIVE sampled pixels — kept when finite, non-negative and within 5 |thresh - 1| of 1,

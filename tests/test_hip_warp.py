@@ -106,3 +106,24 @@ def test_hole_filling_vs_reference_golden_and_oracle(gw):
     o_img, o_map = OW.dibr_filter_mask2(rgb, k2)
     h_img, h_map = dibr_filter_mask2(rgb.copy(), k2.copy())
     assert np.array_equal(h_map, o_map) and np.array_equal(h_img, o_img) and (o_map != k2).sum() > 3000
+
+
+def test_four_stage_hole_filling_vs_reference_golden_and_oracle(gw):
+    """dibr_filter_mask (utils.py:345-392) through t2n_dibr_filter_mask: the reference's goldens bit-exact, then a larger frame with
+    many holes against the oracle."""
+    import os
+    from tests.test_oracle_warp import _fill1_inputs
+    from text2nerf_amd.warp import dibr_filter_mask
+    gf = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fill.npz"))
+    for tag, (img, known) in _fill1_inputs(gw).items():
+        f_img, f_map = dibr_filter_mask(img.copy(), known.copy())
+        assert f_map.dtype == np.int64 and np.array_equal(f_map, gf[f"fill1_{tag}_mask"])
+        assert np.array_equal(f_img, gf[f"fill1_{tag}_image"])
+    rgb, d = synth.rgbd_frame(73, 131, 177, n_boxes=5)
+    g = np.random.Generator(np.random.PCG64(74))
+    k2 = (g.uniform(0, 1, d.shape) > 0.45).astype(np.int64)
+    rgb[k2 == 0] = 1.0
+    o_img, o_map = OW.dibr_filter_mask(rgb, k2)
+    h_img, h_map = dibr_filter_mask(rgb.copy(), k2.copy())
+    assert np.array_equal(h_map, o_map) and np.array_equal(h_img, o_img)
+    assert (o_map != k2).sum() > 3000 and int((o_img == 255).all(-1).sum()) > 0

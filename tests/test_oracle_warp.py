@@ -69,3 +69,25 @@ def test_hole_filling_vs_reference(gw):
     assert np.array_equal(f_img, gw["fill_image"])
     np.testing.assert_allclose(f_dep, gw["fill_depth"], rtol=1e-13, atol=0)
     assert (f_map != known).sum() > 200
+
+
+def _fill1_inputs(gw):
+    """The inputs tests/golden/make_golden_fill.py fed the reference's dibr_filter_mask (rebuilt from warp.npz and a seed)."""
+    known = gw["fill_in_mask"].astype(np.int64)
+    img = gw["warp_image"].copy()
+    img[(known == 0) & (gw["warp_mask"] == 1)] = 1.0
+    g = np.random.Generator(np.random.PCG64(43))
+    known2 = (g.uniform(0, 1, known.shape) < 0.55).astype(np.int64)
+    img2 = gw["warp_image"].copy()
+    img2[known2 == 0] = 1.0
+    return {"a": (img, known), "b": (img2, known2)}
+
+
+def test_four_stage_hole_filling_vs_reference(gw):
+    """dibr_filter_mask (utils.py:345-392): 5x5 scan, 3x3 scan, border lines, erase scan — bit-exact against the reference's output."""
+    gf = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fill.npz"))
+    for tag, (img, known) in _fill1_inputs(gw).items():
+        f_img, f_map = OW.dibr_filter_mask(img, known)
+        assert np.array_equal(f_map, gf[f"fill1_{tag}_mask"])
+        assert np.array_equal(f_img, gf[f"fill1_{tag}_image"])
+    assert int((gf["fill1_b_image"] == 255).all(-1).sum()) >= 1      # the erase stage fires in case b

@@ -105,6 +105,7 @@ SIGNATURES = {
     "t2n_ray_marcher": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_void_p,
                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2n_dibr_filter_mask2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "t2n_dibr_filter_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "t2n_eval_sh_bases": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "t2n_ndc_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                      C.c_void_p, C.c_void_p]),

@@ -237,6 +237,69 @@ __global__ __launch_bounds__(1024) void k_fill_fronts(float* image, int* known, 
     }
 }
 
+// ---- hole filling: dibr_filter_mask (utils.py:345-392; no call site in the driver) ---------------------------------------------------
+// After the 5x5 scan above (threshold 0.6, no depth): a 3x3 fill scan, the four border lines, a 3x3 erase scan — each raster scan in
+// place. A 3x3 scan's pixel (i, j) needs rows < i and (i, j - 1) final, (i, j + 1) and row i + 1 original: fronts t = j + 2 i.
+// ERASE false: unknown pixel, 3x3 weights (1 3 1 / 3 0 3 / 1 3 1) of the known map > 8 (sum / 16 > 0.5) -> mean of the known 3x3
+// neighbours, known; ERASE true: known pixel (== 1), weighted sum <= 7 (sum / 16 < 0.45) -> 255, unknown.
+template <bool ERASE>
+__device__ __forceinline__ void fronts3(float* image, int* known, int H, int W) {
+    const int w3[9] = {1, 3, 1, 3, 0, 3, 1, 3, 1};
+    const int t0 = 1 + 2 * 1, t1 = (W - 2) + 2 * (H - 2);
+    for (int t = t0; t <= t1; ++t) {
+        const int ilo = max(1, (t - (W - 2) + 1) / 2), ihi = min(H - 2, (t - 1) / 2);
+        for (int i = ilo + (int)threadIdx.x; i <= ihi; i += blockDim.x) {
+            const int j = t - 2 * i;
+            if (j < 1 || j > W - 2) continue;
+            const int kc = ld_i(known + i * W + j);
+            if (ERASE ? kc != 1 : kc != 0) continue;
+            int k3i[9], s = 0;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                k3i[q] = ld_i(known + (i + q / 3 - 1) * W + j + q % 3 - 1);
+                s += w3[q] * k3i[q];
+            }
+            if (ERASE) {
+                if (s > 7) continue;
+                for (int c = 0; c < 3; ++c) image[((size_t)i * W + j) * 3 + c] = 255.f;
+                known[i * W + j] = 0;
+            } else {
+                if (s <= 8) continue;
+                double k3[9], v[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) k3[q] = (double)k3i[q];
+                const double n = np_sum9(k3);
+                for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) v[q] = (double)ld_f(image + ((size_t)(i + q / 3 - 1) * W + j + q % 3 - 1) * 3 + c) * k3[q];
+                    image[((size_t)i * W + j) * 3 + c] = (float)(np_sum9(v) / n);
+                }
+                known[i * W + j] = 1;
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void k_fill_mask1_tail(float* image, int* known, int H, int W) {
+    fronts3<false>(image, known, H, W);
+    // border lines, in the reference's order (each line's pixels are independent: they read the neighbouring line only)
+    for (int pass = 0; pass < 4; ++pass) {
+        const int n = pass < 2 ? W : H;
+        for (int x = (int)threadIdx.x; x < n; x += blockDim.x) {
+            const int i = pass == 0 ? 0 : (pass == 1 ? H - 1 : x), j = pass < 2 ? x : (pass == 2 ? 0 : W - 1);
+            const int ii = pass == 0 ? 1 : (pass == 1 ? H - 2 : x), jj = pass < 2 ? x : (pass == 2 ? 1 : W - 2);
+            if (ld_i(known + i * W + j) == 0 && ld_i(known + ii * W + jj) > 0) {
+                for (int c = 0; c < 3; ++c) image[((size_t)i * W + j) * 3 + c] = ld_f(image + ((size_t)ii * W + jj) * 3 + c);
+                known[i * W + j] = 1;
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+    fronts3<true>(image, known, H, W);
+}
+
 }  // namespace t2n
 
 using namespace t2n;
@@ -327,6 +390,15 @@ extern "C" int t2n_dibr_filter_mask2(float* image, int32_t* known, double* depth
     // numpy: float64(sum) / float32(36) > threshold (python float). 2 * sum is an integer: the pixel passes iff 2 sum > 72 thr
     const int twice = (int)floor(72.0 * (double)threshold + 1e-9);
     hipLaunchKernelGGL(k_fill_fronts, dim3(1), dim3(1024), 0, (hipStream_t)stream, image, known, depth, H, W, twice);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_dibr_filter_mask(float* image, int32_t* known, int H, int W, t2n_stream stream) {
+    if (!image || !known || H < 5 || W < 5) { set_error("t2n_dibr_filter_mask: bad argument"); return T2N_ERR_INVALID; }
+    const int rc = t2n_dibr_filter_mask2(image, known, nullptr, H, W, 0.6f, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fill_mask1_tail, dim3(1), dim3(1024), 0, (hipStream_t)stream, image, known, H, W);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

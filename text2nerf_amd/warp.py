@@ -3,7 +3,8 @@
 
 * ``sparse_bilateral_filtering`` — dataLoader/bilateral_filtering.py:5-35 (an O(H W) Python loop in the reference)
 * ``bilinear_splat_warping_multiview`` — utils.py:83-119 over ``Warper.forward_warp`` (scripts/Warper.py:21-186, numpy add.at)
-* ``dibr_filter_mask2`` — utils.py:393-409, the raster-order hole filling (skewed wavefronts on the GPU)
+* ``dibr_filter_mask2`` — utils.py:393-409, the raster-order hole filling (skewed wavefronts on the GPU); ``dibr_filter_mask`` —
+  utils.py:345-392, its four-stage sibling (unused by the driver)
 
 Inputs may be numpy arrays (as in the driver) or torch tensors; numpy in -> numpy out. No CPU fallback."""
 from __future__ import annotations
@@ -117,6 +118,23 @@ def dibr_filter_mask2(output_image, myMap, output_depth=None, device=None):
         return out if dep is None else out + (dep.cpu().numpy(),)
     out = (img, known.to(myMap.dtype))
     return out if dep is None else out + (dep,)
+
+
+def dibr_filter_mask(output_image, myMap, device=None):
+    """Same signature / return as utils.py:345: ``(output_image, myMap)`` after the 5x5 fill scan (threshold 0.6), the 3x3 fill scan, the
+    border lines and the erase scan (pixels set to 255 / unknown). The reference's driver does not call it; it is here for scripts that
+    do. Results are returned, not written into the numpy arguments."""
+    lib = _lib.load()
+    as_numpy = isinstance(output_image, np.ndarray)
+    dev = _dev(device if device is not None else (None if as_numpy else output_image.device))
+    img = _to(output_image, dev, torch.float32).clone()
+    known = _to(myMap, dev, torch.int32).clone()
+    H, W = known.shape
+    with torch.cuda.device(dev):
+        _lib.check(lib.t2n_dibr_filter_mask(_lib.ptr(img), _lib.ptr(known), H, W, _lib.current_stream_ptr(dev)), "t2n_dibr_filter_mask")
+    if as_numpy:
+        return img.cpu().numpy(), known.cpu().numpy().astype(np.asarray(myMap).dtype)
+    return img, known.to(myMap.dtype)
 
 
 def align_depth_global(depth_rendered, depth_est, pixel_sample, push_depth=2.0, device=None):
