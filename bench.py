@@ -881,12 +881,16 @@ def main():
                 from text2nerf_amd import render_views
                 c5 = reference_poses("circle_train_96")
                 field.factor_storage = "bf16"
-                render_views(field, c5[:2], [f, f, W // 2, H // 2], H, W)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                render_views(field, c5, [f, f, W // 2, H // 2], H, W)
-                torch.cuda.synchronize()
-                out["config"]["c5_circle_48_views_bf16_ms_per_view"] = (time.perf_counter() - t0) / c5.shape[0] * 1e3
+                render_views(field, c5, [f, f, W // 2, H // 2], H, W)   # untimed pass: the 48 views' output tensors (0.5 GB) come out of the allocator's pool afterwards
+                c5_ms = []
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    render_views(field, c5, [f, f, W // 2, H // 2], H, W)
+                    torch.cuda.synchronize()
+                    c5_ms.append((time.perf_counter() - t0) / c5.shape[0] * 1e3)
+                out["config"]["c5_circle_48_views_bf16_ms_per_view"] = min(c5_ms)
+                out["config"]["c5_circle_48_views_bf16_ms_per_view_passes"] = [round(x, 4) for x in c5_ms]
             except Exception as e:  # noqa: BLE001
                 out["config"]["c5_circle_error"] = repr(e)[:200]
             field.factor_storage = "fp32"
