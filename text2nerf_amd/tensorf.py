@@ -1296,31 +1296,42 @@ class TensorVMSplit(TensorBase):
         print(f"upsamping to {res_target}")
 
     @torch.no_grad()
-    def shrink(self, new_aabb):
-        """models/tensoRF.py:282-320: crop every factor to the voxel range covering new_aabb (host index arithmetic +
-        tensor slicing; nothing to compute on the device)."""
-        new_aabb = torch.as_tensor(new_aabb, dtype=torch.float32).to(self.aabb.device)
-        xyz_min, xyz_max = new_aabb
-        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
-        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
-        b_r = torch.stack([b_r, self.gridSize]).amin(0)
-        for i in range(3):
-            v = VEC_MODE[i]
-            self.density_line[i] = nn.Parameter(self.density_line[i].data[..., t_l[v]:b_r[v], :].contiguous())
-            self.app_line[i] = nn.Parameter(self.app_line[i].data[..., t_l[v]:b_r[v], :].contiguous())
-            m0, m1 = MAT_MODE[i]
-            self.density_plane[i] = nn.Parameter(self.density_plane[i].data[..., t_l[m1]:b_r[m1], t_l[m0]:b_r[m0]].contiguous())
-            self.app_plane[i] = nn.Parameter(self.app_plane[i].data[..., t_l[m1]:b_r[m1], t_l[m0]:b_r[m0]].contiguous())
-        if self.alphaMask is None or not torch.all(self.alphaMask.gridSize.to(self.gridSize.device) == self.gridSize):
-            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
-            correct_aabb = torch.zeros_like(new_aabb)
-            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
-            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
-            new_aabb = correct_aabb
-        newSize = b_r - t_l
-        self.aabb = new_aabb
+    def _voxel_window(self, new_aabb):
+        """Voxel range [lo, hi) per axis that covers ``new_aabb`` and the box that range spans — what both ``shrink`` forms need.
+        Same fp32 arithmetic as models/tensoRF.py:283-287,297-303 (the lower index is rounded twice there, the upper one once, then
+        made exclusive and clipped to the grid; the box is re-derived from the indices by linear interpolation between the old corners)
+        unless the alpha mask lives on this very grid, in which case the requested box is kept (:296)."""
+        box = torch.as_tensor(new_aabb, dtype=torch.float32).to(self.aabb.device)
+        origin, far = self.aabb[0], self.aabb[1]
+        lo = torch.round(torch.round((box[0] - origin) / self.units)).long()
+        hi = torch.minimum(torch.round((box[1] - origin) / self.units).long() + 1, self.gridSize)
+        mask_on_this_grid = self.alphaMask is not None and bool(torch.all(self.alphaMask.gridSize.to(self.gridSize.device) == self.gridSize))
+        if not mask_on_this_grid:
+            steps = self.gridSize - 1
+            f_lo, f_hi = lo / steps, (hi - 1) / steps
+            box = torch.stack([(1 - f_lo) * origin + f_lo * far, (1 - f_hi) * origin + f_hi * far])
+        return lo, hi, box
+
+    def _adopt_window(self, lo, hi, box):
+        self.aabb = box
         self._drop_handle()
-        self.update_stepSize((int(newSize[0]), int(newSize[1]), int(newSize[2])))
+        self.update_stepSize(tuple(int(n) for n in (hi - lo)))
+
+    def shrink(self, new_aabb):
+        """models/tensoRF.py:282-320: crop every factor to the voxel range covering new_aabb (host index arithmetic + tensor slicing;
+        nothing to compute on the device)."""
+        lo, hi, box = self._voxel_window(new_aabb)
+
+        def window(t, *axes):   # keep [lo, hi) along the grid axes `axes` of a [1, C, ...] factor (last listed axis = innermost)
+            idx = [slice(None), slice(None)] + [slice(int(lo[a]), int(hi[a])) for a in axes]
+            return nn.Parameter(t.data[tuple(idx)].contiguous())
+
+        for i in range(3):
+            m0, m1 = MAT_MODE[i]
+            for planes, lines in ((self.density_plane, self.density_line), (self.app_plane, self.app_line)):
+                planes[i] = window(planes[i], m1, m0)
+                lines[i] = nn.Parameter(lines[i].data[:, :, int(lo[VEC_MODE[i]]):int(hi[VEC_MODE[i]]), :].contiguous())
+        self._adopt_window(lo, hi, box)
 
 
 class TensorVM(TensorVMSplit):
@@ -1537,26 +1548,13 @@ class TensorCP(TensorVMSplit):
         """models/tensoRF.py:387-416: crop the six lines to the voxel range covering new_aabb (host index arithmetic + slicing). The
         reference dereferences ``self.alphaMask`` unconditionally; without a mask the aabb is corrected to the voxel range here, as
         it is when the mask's grid differs from the field's."""
-        new_aabb = torch.as_tensor(new_aabb, dtype=torch.float32).to(self.aabb.device)
-        xyz_min, xyz_max = new_aabb
-        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
-        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
-        b_r = torch.stack([b_r, self.gridSize]).amin(0)
+        lo, hi, box = self._voxel_window(new_aabb)
         for i in range(3):
-            v = VEC_MODE[i]
-            self.density_line[i] = nn.Parameter(self.density_line[i].data[..., t_l[v]:b_r[v], :].contiguous())
-            self.app_line[i] = nn.Parameter(self.app_line[i].data[..., t_l[v]:b_r[v], :].contiguous())
-        if self.alphaMask is None or not torch.all(self.alphaMask.gridSize.to(self.gridSize.device) == self.gridSize):
-            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
-            correct_aabb = torch.zeros_like(new_aabb)
-            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
-            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
-            new_aabb = correct_aabb
-        newSize = b_r - t_l
-        self.aabb = new_aabb
+            a = VEC_MODE[i]
+            for lines in (self.density_line, self.app_line):
+                lines[i] = nn.Parameter(lines[i].data[:, :, int(lo[a]):int(hi[a]), :].contiguous())
         self._virt = None
-        self._drop_handle()
-        self.update_stepSize((int(newSize[0]), int(newSize[1]), int(newSize[2])))
+        self._adopt_window(lo, hi, box)
 
 
 class _RenderFn(torch.autograd.Function):
