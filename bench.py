@@ -663,7 +663,10 @@ def main():
         step()
     drain()
     st = field.stats()
-    field.timing(True)
+    # HIP events on the launch stream around the DOMINANT kernel only inside the timed region (the roofline's kernel: the head); an event
+    # pair costs the stream ~10 us of bubble per bracketed kernel group — all four groups of a frame were 1.8 % of it
+    # (profiles/round4_frame_timeline.txt). The other kernels' times come from a short untimed pass below.
+    field.timing(True, kernels=("shade",))
     field.read_timing(reset=True)
     if dist is not None:
         dist.barrier()
@@ -677,6 +680,16 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timing = field.read_timing(reset=True)
+    field.timing(True)
+    field.read_timing(reset=True)
+    aux_steps = max(min(args.steps, 30), 1)
+    with torch.no_grad():
+        for _ in range(aux_steps):
+            field(rays, white_bg=True, is_train=False, N_samples=-1)
+    torch.cuda.synchronize()
+    for k, v in field.read_timing(reset=True).items():   # scaled to the timed region's step count (what the per-step figures below divide by)
+        if k not in timing:
+            timing[k] = (v[0] * args.steps / aux_steps, v[1] * args.steps / aux_steps)
     field.timing(False)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

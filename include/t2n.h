@@ -410,7 +410,7 @@ int t2n_depth_align_global(const float* depth_rendered, const float* depth_est, 
  * priced at the timed average). Kernel ids: */
 enum { T2N_K_MARCH = 0, T2N_K_SHADE = 1, T2N_K_COMPOSITE = 2, T2N_K_UPLOAD = 3, T2N_K_BWD_MARCH = 4, T2N_K_BWD_MLP = 5,
        T2N_K_BWD_SCATTER = 6, T2N_K_DENSITY = 7, T2N_K_APPFEAT = 8 /* appearance gather + basis_mat */, T2N_K_COUNT = 9 };
-int t2n_timing_enable(t2n_field* f, int on);
+int t2n_timing_enable(t2n_field* f, int on);   /* on: 0 off, 1 every kernel, else a mask: bit (k + 1) brackets kernel id k only */
 int t2n_timing_read(t2n_field* f, double* ms /*[T2N_K_COUNT]*/, int64_t* launches /*[T2N_K_COUNT]*/, int reset);
 
 #ifdef __cplusplus

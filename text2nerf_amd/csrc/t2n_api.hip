@@ -21,7 +21,7 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 void timing_begin(t2n_field* f, int k, hipStream_t s) {
-    if (!f->timing) return;
+    if (!((f->timing >> k) & 1)) return;
     TimingSlot& t = f->slots[k];
     if (t.used >= kTimingEvents) return;
     if (!t.start[t.used]) {
@@ -31,7 +31,7 @@ void timing_begin(t2n_field* f, int k, hipStream_t s) {
     (void)hipEventRecord(t.start[t.used], s);
 }
 void timing_end(t2n_field* f, int k, hipStream_t s) {
-    if (!f->timing) return;
+    if (!((f->timing >> k) & 1)) return;
     TimingSlot& t = f->slots[k];
     if (t.used >= kTimingEvents) { t.untimed++; return; }
     (void)hipEventRecord(t.stop[t.used], s);
@@ -852,7 +852,9 @@ extern "C" int t2n_field_set_mlp_precision(t2n_field* f, int exact_fp32) {
 
 extern "C" int t2n_timing_enable(t2n_field* f, int on) {
     if (!f) return T2N_ERR_INVALID;
-    f->timing = on ? 1 : 0;
+    // 0: off; 1: every kernel; otherwise a mask, bit k + 1 = kernel id k (an event pair costs the stream ~10 us of bubble per bracketed
+    // group: a caller who needs one kernel's time inside a timed region asks for that kernel only)
+    f->timing = on == 0 ? 0 : (on == 1 ? (1 << T2N_K_COUNT) - 1 : (on >> 1) & ((1 << T2N_K_COUNT) - 1));
     return T2N_OK;
 }
 

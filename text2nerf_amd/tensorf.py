@@ -814,8 +814,13 @@ class TensorBase(nn.Module):
         except Exception:
             pass
 
-    def timing(self, on=True):
-        _lib.check(_lib.load().t2n_timing_enable(self.sync_params(), 1 if on else 0), "t2n_timing_enable")
+    def timing(self, on=True, kernels=None):
+        """Bracket kernel launches with HIP events (t2n_timing_enable). ``kernels``: names from ``_lib.KERNEL_NAMES`` to bracket only those
+        (an event pair costs the stream a ~10 us bubble per bracketed group: inside a timed region ask for the kernel you need)."""
+        mode = 1 if on else 0
+        if on and kernels is not None:
+            mode = sum(1 << (_lib.KERNEL_NAMES.index(k) + 1) for k in kernels)
+        _lib.check(_lib.load().t2n_timing_enable(self.sync_params(), mode), "t2n_timing_enable")
 
     def read_timing(self, reset=True):
         ms = (C.c_double * _lib.T2N_K_COUNT)()
