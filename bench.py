@@ -681,9 +681,12 @@ def main():
     dt = time.perf_counter() - t0
     timing = field.read_timing(reset=True)
     field.timing(True)
-    field.read_timing(reset=True)
     aux_steps = max(min(args.steps, 30), 1)
     with torch.no_grad():
+        for _ in range(min(aux_steps, 10)):   # (the clocks sag while the host reads the timed region's events: not part of this pass)
+            field(rays, white_bg=True, is_train=False, N_samples=-1)
+        torch.cuda.synchronize()
+        field.read_timing(reset=True)
         for _ in range(aux_steps):
             field(rays, white_bg=True, is_train=False, N_samples=-1)
     torch.cuda.synchronize()
