@@ -541,6 +541,8 @@ def main():
                          "border and centre rays) or contiguous row blocks; auto = interleaved when the rows divide evenly")
     ap.add_argument("--check-c4", action="store_true",
                     help="c4 mode: rank 0 also renders the whole frame alone and compares it bitwise with the gathered one")
+    ap.add_argument("--no-inregion-timing", action="store_true",
+                    help="no HIP timing events inside the timed region (the head's launch time then comes from the untimed pass behind it)")
     ap.add_argument("--train-iters", type=int, default=20)
     ap.add_argument("--train-warmup", type=int, default=3)
     args = ap.parse_args()
@@ -666,20 +668,28 @@ def main():
     # HIP events on the launch stream around the DOMINANT kernel only inside the timed region (the roofline's kernel: the head); an event
     # pair costs the stream ~10 us of bubble per bracketed kernel group — all four groups of a frame were 1.8 % of it
     # (profiles/round4_frame_timeline.txt). The other kernels' times come from a short untimed pass below.
-    field.timing(True, kernels=("shade",))
+    if args.no_inregion_timing:
+        field.timing(False)
+    else:
+        field.timing(True, kernels=("shade",))
     field.read_timing(reset=True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timing = field.read_timing(reset=True)
+    # THREE back-to-back blocks of `steps` frames, each bracketed by barrier + synchronize on both sides; ms_per_step is the MEDIAN block
+    # (max over ranks per block). One 20-frame block is ~50 ms of wall clock: a single descheduling of this process (the boxes run
+    # under a cgroup CPU quota) inside it would be the whole figure.
+    block_dt = []
+    for _ in range(3):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        block_dt.append(time.perf_counter() - t0)
+    timing = {k: (v[0] / 3.0, v[1] / 3.0) for k, v in field.read_timing(reset=True).items()}   # three blocks -> per block of `steps` frames
     field.timing(True)
     aux_steps = max(min(args.steps, 30), 1)
     with torch.no_grad():
@@ -695,9 +705,10 @@ def main():
             timing[k] = (v[0] * args.steps / aux_steps, v[1] * args.steps / aux_steps)
     field.timing(False)
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor(block_dt, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        block_dt = [float(x) for x in t.tolist()]
+    dt = sorted(block_dt)[1]
 
     c4_equal = None
     if c4 and args.check_c4:   # the gathered frame against the whole frame rendered by rank 0 alone (untimed; every rank gathers)
@@ -788,42 +799,85 @@ def main():
         roof = dict(roofs[dom]) if dom else {}
         if dom and roof.get("bound") not in ("hbm", "mfma"):
             roof["bound_contract"] = "hbm"     # the contract's two classes: everything that is not matrix work
+        # whole-frame SIMD-issue model: the counter record's instruction counts per kernel x the measured issue costs
+        # (profiles/round4_issue_cost_microbench.txt: an MFMA ~21 cycles of its SIMD's issue, a wave64 VALU instruction ~5 on the 16-lane
+        # pipe, an LDS instruction ~8) over 1 024 SIMDs at the ~2.1 GHz the part holds under these kernels. What the frame would take if
+        # issue were the only limit and nothing overlapped: the distance to ms_per_step is latency the occupancy does not hide
+        issue = {}
+        for kn in ("k_march_tiles", "k_app_features_p", "k_mlp_ss3", "k_composite"):
+            c = pmc.get(kn)
+            if c:
+                cyc = 21.0 * c.get("mfma_insts_per_launch", 0.0) + 5.0 * c.get("valu_insts_per_launch", 0.0) + 8.0 * c.get("lds_insts_per_launch", 0.0)
+                issue[kn] = cyc / (1024 * 2.1e9) * 1e3
+        kernel_sum = sum(frame_ms.values())
+        cfg = {
+            # the driver's record keeps the first 24 keys of `config` and only their scalar values: the figures a reader needs come first
+            "workload": (f"C4 300^3 ONE 1600x1600 frame in {world} ray tiles" if c4 else "C2 300^3 800x800 view/GPU") +
+                        f", N={N}, S1-soft seed 0, white_bg, weights={int(bool(args.weights))}, {'per-ray' if args.per_ray_marcher else 'tile'} marcher",
+            "ms_per_step_blocks": " / ".join(f"{b / args.steps * 1e3:.4f}" for b in block_dt) + " (three blocks of `steps` frames; ms_per_step = median)",
+            "sustained_ms_per_step": None,
+            "kernel_ms_per_frame_sum": kernel_sum,
+            "host_gap_ms_per_step": ms_step - kernel_sum,
+            "issue_model_ms": sum(issue.values()) if issue else None,
+            "exact_fp32_ms_per_step": None,
+            "weights_materialised_ms_per_step": None,
+            "bf16_factor_storage_ms_per_step": None,
+            "c5_circle_48_views_bf16_ms_per_view": None,
+            "train_ms_per_iter": None,
+            "train_ms_per_iter_fused_optim": None,
+            "train_ms_per_iter_fused_step": None,
+            "train_ms_per_iter_fused_step_2048_rays": None,
+            "train_iters_per_s_fused_step": None,
+            "evaluated_samples_per_s": world * V * args.steps / dt,
+            "rays_per_s": (R_frame if c4 else world * R) * args.steps / dt,
+            "evaluated_samples_per_frame": V,
+            "appearance_samples_per_frame": A,
+            "memory_reserved_GiB_render": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 3),
+            "memory_reserved_GiB_train": None,
+            "pmc_blob": (pmc_rec.get("git_blob") or "")[:12] + (" STALE" if pmc_rec.get("stale") else ""),
+            "rccl_version": None,
+            "early_termination_eps": float(getattr(field, "early_termination", 0.0) or 0.0),
+            # ---- past the driver's cut: details ----
+            "workload_detail": (f"C4: TensorVMSplit 300^3, ONE 1600x1600 frame in {world} ray tiles "
+                                f"({'interleaved 8-row bands' if bands else 'contiguous row blocks'}), "
+                                if c4 else "C2: TensorVMSplit 300^3, 800x800 view/GPU, ") +
+                               f"{N} samples/ray, render_only, scene {args.scene} seed 0, white_bg, weights/z_vals materialised: "
+                               f"{bool(args.weights)}, marcher: {'per-ray' if args.per_ray_marcher else '8x8-pixel tiles'}",
+            "rays_per_gpu": R, "samples_per_ray": N,
+            "ms_per_step_block_list": [round(b / args.steps * 1e3, 4) for b in block_dt],
+            "inregion_timing": "none" if args.no_inregion_timing else "head only",
+            "parallelism": f"ray-tile x{world}" + ((" + RCCL all-gather of rgb+depth tiles inside every step" if c4 else
+                                                    " + RCCL all-gather of rgb+depth tiles (async, overlapped with the "
+                                                    "next frame's render)") if world > 1 else ""),
+            "kernel_ms_per_frame": frame_ms,
+            "issue_model_ms_by_kernel": issue,
+            "kernel_rooflines": roofs,
+            # which counter record fed roofline.traffic / mfma_busy_frac_pmc / the march's `achieved` (not measured in THIS run)
+            "pmc_record": pmc_rec,
+        }
         out = {
             "metric": "ray-samples/s (render) + iters/s (train), 300^3 VM-split, 800x800",
             "value": nominal, "unit": "ray-samples/s",
-            # `value` counts the reference's tensors (rays x samples per ray, what BASELINE.json's metric names); 76.6 % of those samples lie
-            # outside the box or behind the z gate and are evaluated by nobody (the reference masks them too): the rate of samples that
-            # actually read the field stands next to it
-            "value_evaluated_samples_per_s": world * V * args.steps / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if c4 else "weak", "vs_baseline": None,
             "dtype": "f32" + (" (basis/MLP products as f16x2-split MFMA, fp32 accumulate)" if split else "") +
                      ("; factor tensors stored as bf16" if args.factor_storage == "bf16" else ""),
             "data": "synthetic",
-            "config": {"workload": (f"C4: TensorVMSplit 300^3, ONE 1600x1600 frame in {world} ray tiles "
-                                    f"({'interleaved 8-row bands' if bands else 'contiguous row blocks'}), "
-                                    if c4 else "C2: TensorVMSplit 300^3, 800x800 view/GPU, ") +
-                                   f"{N} samples/ray, render_only, scene "
-                                   f"{args.scene} seed 0, white_bg, weights/z_vals materialised: {bool(args.weights)}, "
-                                   f"marcher: {'per-ray' if args.per_ray_marcher else '8x8-pixel tiles'}",
-                       "rays_per_gpu": R, "samples_per_ray": N, "evaluated_samples_per_frame": V,
-                       "appearance_samples_per_frame": A, "rays_per_s": (R_frame if c4 else world * R) * args.steps / dt,
-                       "evaluated_samples_per_s": world * V * args.steps / dt,
-                       "parallelism": f"ray-tile x{world}" + ((" + RCCL all-gather of rgb+depth tiles inside every step" if c4 else
-                                                               " + RCCL all-gather of rgb+depth tiles (async, overlapped with the "
-                                                               "next frame's render)") if world > 1 else ""),
-                       "kernel_ms_per_frame": frame_ms,
-                       "kernel_rooflines": roofs,
-                       # which counter record fed roofline.traffic / mfma_busy_frac_pmc / the march's `achieved` (not measured in THIS run)
-                       "pmc_record": pmc_rec,
-                       "value_evaluated_samples_per_s": world * V * args.steps / dt,
-                       "early_termination_eps": float(getattr(field, "early_termination", 0.0) or 0.0),
-                       "scaling_measured": "the builder has 1-GPU boxes only: see scaling_prediction (N = 1 line) for what one GPU can "
-                                           "say about N = 8, and rccl (N > 1 lines) for the devices the ranks actually ran on"},
+            "config": cfg,
             "roofline": roof,
+            # `value` counts the reference's tensors (rays x samples per ray, what BASELINE.json's metric names); 76.6 % of those samples lie
+            # outside the box or behind the z gate and are evaluated by nobody (the reference masks them too): config.evaluated_samples_per_s
+            # is the rate of samples that actually read the field
+            "notes": {"scaling_measured": "the builder has 1-GPU boxes only: see scaling_prediction (N = 1 line) for what one GPU can "
+                                          "say about N = 8, and config.rccl (N > 1 lines) for the devices the ranks actually ran on"},
         }
         out["config"].update(dp)
         if rccl is not None:
+            try:
+                rccl["version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception as e:  # noqa: BLE001
+                rccl["version"] = repr(e)[:80]
+            out["config"]["rccl_version"] = rccl["version"] if rccl.get("is_rccl") else f"(backend {rccl.get('backend')})"
             rccl["all_gather_bytes_per_rank_per_step"] = int((cap if c4 else R) * 16)
             rccl["all_gather_bytes_total_per_step"] = int((cap if c4 else R) * 16 * world)
             if dp:
@@ -837,8 +891,8 @@ def main():
                 "worst_case_GiB": round(int(_l.t2n_render_workspace_bytes(R, N)) / 2 ** 30, 2),
                 "steady_state_hint_GiB": round(int(_l.t2n_render_workspace_bytes_hint(field.sync_params(), R, N)) / 2 ** 30, 2),
                 "list_retries": int(_l.t2n_field_list_retries(field.sync_params())),
-                "note": "image-ordered frames run as one launch with appearance lists sized from the previous frame's counters; "
-                        "an overflowing frame is rendered again with worst-case lists (counted in list_retries)"}
+                "note": "image-ordered frames run as one launch with appearance lists sized from earlier frames' counters (read back "
+                        "without waiting); rays that find no room are finished on the device (frames with such rays: list_retries)"}
         except Exception as e:   # reporting only
             out["config"]["workspace"] = {"error": repr(e)}
         if c4_equal is not None:
@@ -889,7 +943,7 @@ def main():
                 # DESIGN.md); not the headline value: it renders the ROUNDED field
                 field.factor_storage = "bf16"
                 out["config"]["bf16_factor_storage_ms_per_step"] = timed_frames(args.steps)
-                out["config"]["bf16_factor_storage_note"] = "appearance factors read as bf16 (26 MB instead of 52 MB), taps fetched as 16-B octets of 8 channels: half the gather instructions; the tile marcher reads the fp32 copy of the rounded density factors (17 MB), the per-ray marcher their bf16 copy"
+                out["notes"]["bf16_factor_storage"] = "appearance factors read as bf16 (26 MB instead of 52 MB), taps fetched as 16-B octets of 8 channels: half the gather instructions; the tile marcher reads the fp32 copy of the rounded density factors (17 MB), the per-ray marcher their bf16 copy"
                 field.factor_storage = "fp32"
             # BASELINE configs[4] on one GPU: the 48 training views of the reference's circle trajectory (cam_traj_gen, fixture), bf16
             # factor storage, rays generated on the device, one frame per view
@@ -899,13 +953,13 @@ def main():
                 field.factor_storage = "bf16"
                 render_views(field, c5, [f, f, W // 2, H // 2], H, W)   # untimed pass: the 48 views' output tensors (0.5 GB) come out of the allocator's pool afterwards
                 c5_ms = []
-                for _ in range(2):
+                for _ in range(3):
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     render_views(field, c5, [f, f, W // 2, H // 2], H, W)
                     torch.cuda.synchronize()
                     c5_ms.append((time.perf_counter() - t0) / c5.shape[0] * 1e3)
-                out["config"]["c5_circle_48_views_bf16_ms_per_view"] = min(c5_ms)
+                out["config"]["c5_circle_48_views_bf16_ms_per_view"] = sorted(c5_ms)[1]   # median of three passes
                 out["config"]["c5_circle_48_views_bf16_ms_per_view_passes"] = [round(x, 4) for x in c5_ms]
             except Exception as e:  # noqa: BLE001
                 out["config"]["c5_circle_error"] = repr(e)[:200]
@@ -980,8 +1034,10 @@ def main():
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True, resident=True))
+            out["config"]["memory_reserved_GiB_train"] = round(torch.cuda.memory_reserved(dev) / 2 ** 30, 3)
         if world == 1 and not c4 and not args.quick:
             out["scaling_prediction"] = sp = scaling_prediction(field, dev, out["config"].get("train_ms_per_iter_fused_step"))
+            out["config"]["train_ms_per_iter_fused_step_2048_rays"] = sp.get("train_dp", {}).get("fused_step_ms_by_rays_per_gpu", {}).get("2048")
             out["config"]["scaling_prediction_headline"] = {
                 "c4_predicted_8gpu_speedup": sp.get("c4", {}).get("predicted_speedup_interleaved"),
                 "c4_tile_balance": sp.get("c4", {}).get("balance_interleaved"),

@@ -7,10 +7,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# The parity tests compare with the reference sample for sample (evaluated-sample counts included): the mirror's early ray termination
-# (TensorBase.early_termination, default 1e-6: a bounded deviation from the reference, not its arithmetic) is OFF for every field the
-# suite builds; tests/test_early_termination.py and the whole-frame tests switch it on explicitly.
-os.environ.setdefault("T2N_EARLY_TERMINATION", "0")
+# The suite runs the product defaults (no environment overrides): early ray termination is opt-in (TensorBase.early_termination = 0.0,
+# the reference's sample-for-sample arithmetic); tests/test_early_termination.py and one whole-frame test switch it on explicitly.
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

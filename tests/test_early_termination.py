@@ -114,3 +114,33 @@ def test_termination_threshold_is_bounded_by_the_appearance_threshold(tiny_param
     assert lib.t2n_field_set_early_termination(h, C.c_float(-1.0)) != 0
     assert lib.t2n_field_set_early_termination(h, C.c_float(1e-4)) == 0
     assert lib.t2n_field_set_early_termination(h, C.c_float(0.0)) == 0
+
+
+def test_zero_appearance_threshold_with_termination_requested(tiny_params):
+    """rayMarch_weight_thres = 0 (`weight > thres`, models/tensorBase.py:477) is a legitimate reference setting; a requested
+    termination threshold above it is clamped (0 = off) instead of failing every sync_params(), and a threshold lowered on a live
+    handle takes the termination bound with it."""
+    from text2nerf_amd import _lib
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    f.materialize_weights = False
+    rays = torch.from_numpy(synth.frame_rays_np(16, 24)).to(dev())
+    f.early_termination = 1e-6
+    with torch.no_grad():
+        f(rays)                                   # handle live with eps = 1e-6 under thres = 1e-4
+    f.rayMarch_weight_thres = 0.0
+    f.update_stepSize(f.gridSize.tolist() if hasattr(f.gridSize, "tolist") else list(f.gridSize))   # t2n_field_set_desc on the live handle: the bound follows
+    with torch.no_grad():
+        a = f(rays)
+    ev = f.stats()["evaluated"]
+    g = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])     # a fresh field built with thres = 0 and eps requested
+    g.materialize_weights = False
+    g.rayMarch_weight_thres = 0.0
+    g.early_termination = 1e-6
+    with torch.no_grad():
+        c = g(rays)                               # sync_params() clamps instead of raising
+    g.early_termination = 0.0
+    with torch.no_grad():
+        b = g(rays)
+    assert g.stats()["evaluated"] == ev
+    for x in (a, c):
+        assert torch.equal(x[0], b[0]) and torch.equal(x[1], b[1])

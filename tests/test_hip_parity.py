@@ -35,8 +35,7 @@ def make_field(params, grid, aabb, near_far, shading="MLP_Fea_noview"):
                       alphaMask_thres=1e-4, density_shift=-10, distance_scale=25, pos_pe=0, view_pe=0, fea_pe=6,
                       featureC=128, step_ratio=1.0, fea2denseAct="softplus")
     m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
-    m.early_termination = 0.0   # the parity tests compare sample for sample (evaluated counts included); tests/test_early_termination.py
-    return m                    # and the whole-frame tests switch the termination on
+    return m                    # (product defaults: early termination is opt-in, tests/test_early_termination.py switches it on)
 
 
 @pytest.fixture(scope="module")

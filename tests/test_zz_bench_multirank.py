@@ -104,7 +104,7 @@ def test_c4_mode_two_ranks_on_one_gpu_over_gloo(tmp_path):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["c4_gathered_equals_single_rank"] is True
-    assert "1600x1600" in d["config"]["workload"] and "interleaved 8-row bands" in d["config"]["workload"]
+    assert "1600x1600" in d["config"]["workload"] and "interleaved 8-row bands" in d["config"]["workload_detail"]
 
 
 def test_c4_mode_contiguous_tiles_two_ranks(tmp_path):
@@ -112,7 +112,7 @@ def test_c4_mode_contiguous_tiles_two_ranks(tmp_path):
                                            "--check-c4", "--c4-tiles", "contiguous"])
     check_finished(rcs, outs, errs)
     d = one_json_line(outs)
-    assert d["config"]["c4_gathered_equals_single_rank"] is True and "contiguous row blocks" in d["config"]["workload"]
+    assert d["config"]["c4_gathered_equals_single_rank"] is True and "contiguous row blocks" in d["config"]["workload_detail"]
 
 
 def test_plain_bench_gpus_2_launches_its_own_ranks(tmp_path):

@@ -155,6 +155,7 @@ static int apply_desc(t2n_field* f, const t2n_field_desc* d) {
     for (int k = 0; k < 3; ++k)
         if (d->grid[k] < 2 || d->grid[k] > 4096) { set_error("grid[%d]=%d out of range [2,4096]", k, d->grid[k]); return T2N_ERR_INVALID; }
     f->desc = *d;
+    if (f->term_eps > d->weight_thres) f->term_eps = d->weight_thres;   // the early-termination bound follows a changed appearance threshold
     FieldDev& D = f->dev;
     for (int k = 0; k < 3; ++k) {
         D.aabb0[k] = d->aabb_min[k]; D.aabb1[k] = d->aabb_max[k]; D.inv[k] = d->inv_aabb_size[k];
@@ -449,8 +450,10 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->buf_mlp_h) (void)hipFree(f->buf_mlp_h);
     if (f->buf_ss) (void)hipFree(f->buf_ss);
     if (f->ss_event) (void)hipEventDestroy((hipEvent_t)f->ss_event);
-    if (f->host_counts) (void)hipHostFree(f->host_counts);
-    if (f->ev_counts) (void)hipEventDestroy((hipEvent_t)f->ev_counts);
+    for (auto& c : f->count_slots) {
+        if (c.host) (void)hipHostFree(c.host);
+        if (c.ev) (void)hipEventDestroy((hipEvent_t)c.ev);
+    }
     if (f->ev_fork) (void)hipEventDestroy((hipEvent_t)f->ev_fork);
     if (f->ev_join) (void)hipEventDestroy((hipEvent_t)f->ev_join);
     if (f->ev_den) (void)hipEventDestroy((hipEvent_t)f->ev_den);
@@ -617,6 +620,47 @@ int launch_setup(const SetupOps& o, hipStream_t s) {
 }
 }  // namespace t2n
 
+namespace t2n {
+// Budgeted launches post their counter block (sub-list fills, overflow word, entries of the rays the finisher took) to pinned host
+// memory behind the march kernels, with an event; nobody waits for it. A later call that finds the event complete turns the
+// counters into the next budget (list_hint) and the retry count. kCountSlots launches may be in flight; one more skips its post.
+static void counts_consume(t2n_field* f, t2n_field::CountSlot& c) {
+    const unsigned cap = list_capacity_budget(c.n_rays, c.n_samples, c.budget);
+    unsigned long long used = c.host[kFailEntriesWord];
+    for (int l = 0; l < kLists; ++l) {
+        const unsigned n = c.host[l * kCounterStride];
+        used += n < cap ? n : cap;
+    }
+    if (c.host[kOverflowWord]) f->list_retries++;
+    f->list_hint = (unsigned)((used + (unsigned long long)c.n_rays - 1) / (unsigned long long)c.n_rays);
+    if (!f->list_hint) f->list_hint = 1;
+    c.pending = false;
+}
+void counts_poll(t2n_field* f, bool wait) {
+    for (int i = 0; i < t2n_field::kCountSlots; ++i) {   // oldest first
+        t2n_field::CountSlot& c = f->count_slots[(f->count_next + i) % t2n_field::kCountSlots];
+        if (!c.pending) continue;
+        if (wait) { if (hipEventSynchronize((hipEvent_t)c.ev) != hipSuccess) { (void)hipGetLastError(); break; } }
+        else if (hipEventQuery((hipEvent_t)c.ev) != hipSuccess) { (void)hipGetLastError(); break; }
+        counts_consume(f, c);
+    }
+}
+static void counts_post(t2n_field* f, const unsigned* counters_dev, int64_t n_rays, int n_samples, unsigned budget, hipStream_t s) {
+    t2n_field::CountSlot& c = f->count_slots[f->count_next];
+    if (c.pending) return;   // the host is kCountSlots launches ahead of the device: this launch's counters are not looked at
+    if (!c.host) {
+        if (hipHostMalloc((void**)&c.host, sizeof(unsigned) * kLists * kCounterStride, hipHostMallocDefault) != hipSuccess) { c.host = nullptr; (void)hipGetLastError(); return; }
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+        c.ev = (void*)ev;
+    }
+    if (hipMemcpyAsync(c.host, counters_dev, sizeof(unsigned) * kLists * kCounterStride, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipEventRecord((hipEvent_t)c.ev, s) != hipSuccess) { (void)hipGetLastError(); return; }
+    c.pending = true; c.n_rays = n_rays; c.n_samples = n_samples; c.budget = budget;
+    f->count_next = (f->count_next + 1) % t2n_field::kCountSlots;
+}
+}  // namespace t2n
+
 extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
                                   const float* jitter, float* rgb, float* depth, float* weights, float* z_vals, uint64_t* stats,
                                   void* workspace, size_t workspace_bytes, t2n_stream stream) {
@@ -646,6 +690,8 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     // largest sub-launch whose worst case (every sample an appearance sample) fits the workspace
     int64_t per = n_rays;
     unsigned budget = 0;   // appearance entries per ray the lists are sized for (0: worst case)
+    bool generic_overflow = false;
+    counts_poll(f, false);   // counters of earlier budgeted launches that have landed meanwhile: the hint, list_retries (never waits)
     // A frame for the tile marcher whose worst case does not fit is first tried as ONE launch with budgeted lists (the largest
     // budget the workspace holds): a C2 frame needs ~7 entries per ray where the worst case reserves 518. The counters reach
     // pinned host memory behind the march kernels; a launch that overflowed is redone below in worst-case sub-launches.
@@ -713,16 +759,7 @@ retry_worst_case:
         if (tiles) {
             if ((rc = launch_march_tiles(f, L, f->frame_w, (int)(cnt / f->frame_w), (float*)(ws + c.sigma), (float4*)(ws + c.scratch), s))) return rc;
         } else if ((rc = launch_march(f, L, s))) return rc;
-        if (budget) {   // counters (sub-list fills, overflow word) -> pinned host memory, an event behind the copy
-            if (!f->host_counts) {
-                T2N_HIP(hipHostMalloc((void**)&f->host_counts, sizeof(unsigned) * kLists * kCounterStride, hipHostMallocDefault));
-                hipEvent_t ev;
-                T2N_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-                f->ev_counts = (void*)ev;
-            }
-            T2N_HIP(hipMemcpyAsync(f->host_counts, L.counters, sizeof(unsigned) * kLists * kCounterStride, hipMemcpyDeviceToHost, s));
-            T2N_HIP(hipEventRecord((hipEvent_t)f->ev_counts, s));
-        }
+        if (budget) counts_post(f, L.counters, n_rays, n_samples, budget, s);   // -> pinned host memory behind the march; read by a LATER call
         if (keep && (rc = ctx_counts_post(workspace, L.counters, s))) return rc;   // the backward sizes itself from these without draining the stream
         if (head_is_generic(f->desc.shading)) {
             // general head path: the appearance-row count is needed on the host to size the activation scratch (one stream
@@ -730,6 +767,7 @@ retry_worst_case:
             unsigned raw[kLists * kCounterStride], tb[kLists + 1];
             T2N_HIP(hipMemcpyAsync(raw, L.counters, sizeof(raw), hipMemcpyDeviceToHost, s));
             T2N_HIP(hipStreamSynchronize(s));
+            if (budget && raw[kOverflowWord]) generic_overflow = true;
             unsigned t = 0;
             for (int l = 0; l < kLists; ++l) { unsigned cnt = raw[l * kCounterStride]; if (cnt > L.list_cap) cnt = L.list_cap; tb[l] = t; t += (cnt + 31u) / 32u; }
             tb[kLists] = t;
@@ -757,30 +795,22 @@ retry_worst_case:
                                                0xffffffffu, keep ? nullptr : L.feat, L.feat_rows, stats))) return rc;
         }
         if ((rc = tiles ? launch_composite(f, L, s, f->frame_w, (int)(cnt / f->frame_w)) : launch_composite(f, L, s))) return rc;
+        // budgeted lists: the rays that found no room are shaded and composited from their staging slices, on the device
+        if (budget && finish_supported(f) && (rc = launch_finish_rays(f, L, (const float*)(ws + c.sigma), (const float4*)(ws + c.scratch), s))) return rc;
     }
-    if (budget) {
-        // the appearance and compositing kernels are queued behind the march; the host only waits for the march itself
-        T2N_HIP(hipEventSynchronize((hipEvent_t)f->ev_counts));
-        unsigned long long used = 0;
-        for (int l = 0; l < kLists; ++l) {
-            const unsigned c = f->host_counts[l * kCounterStride], cap = list_capacity_budget(n_rays, n_samples, budget);
-            used += c < cap ? c : cap;
+    if (budget && generic_overflow) {
+        // the general view-dependent heads (no device-side finisher; their path synchronises per sub-launch anyway): some rays
+        // found no room, everything is rendered again with worst-case lists (sub-launches sized to the workspace)
+        f->list_retries++;
+        f->list_hint = 2u * budget < (unsigned)n_samples ? 2u * budget : (unsigned)n_samples;   // the next hint asks for > 4x the room
+        if (stats) {
+            T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s));
+            T2N_HIP(hipMemsetD32Async((hipDeviceptr_t)(stats + T2N_STAT_LIST_RETRY), 1, 1, s));
         }
-        if (f->host_counts[kOverflowWord]) {
-            // some rays found no room: everything is rendered again with worst-case lists (sub-launches sized to the workspace);
-            // the next call's hint asks for room
-            f->list_retries++;
-            f->list_hint = 2u * budget < (unsigned)n_samples ? 2u * budget : (unsigned)n_samples;   // the next hint asks for > 4x the room
-            if (stats) {
-                T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s));
-                T2N_HIP(hipMemsetD32Async((hipDeviceptr_t)(stats + T2N_STAT_LIST_RETRY), 1, 1, s));
-            }
-            budget = 0;
-            per = n_rays;
-            goto retry_worst_case;
-        }
-        f->list_hint = (unsigned)((used + (unsigned long long)n_rays - 1) / (unsigned long long)n_rays);
-        if (!f->list_hint) f->list_hint = 1;
+        generic_overflow = false;
+        budget = 0;
+        per = n_rays;
+        goto retry_worst_case;
     }
     return T2N_OK;
 }
@@ -789,6 +819,7 @@ retry_worst_case:
 // used + 16, at least kBudgetMin; a quarter of the samples when nothing is known yet. Never more than the worst case.
 extern "C" size_t t2n_render_workspace_bytes_hint(const t2n_field* f, int64_t n_rays, int n_samples) {
     if (!f || n_rays <= 0 || n_samples <= 0) return 0;
+    counts_poll(const_cast<t2n_field*>(f), false);
     const size_t worst = carve(n_rays, n_samples).total;
     if (n_rays < kBudgetMinRays) return worst;
     unsigned b = f->list_hint ? 2u * f->list_hint + 16u : (unsigned)(n_samples / 4 > 64 ? n_samples / 4 : 64);
@@ -797,7 +828,11 @@ extern "C" size_t t2n_render_workspace_bytes_hint(const t2n_field* f, int64_t n_
     const size_t want = carve_workspace(n_rays, n_samples, true, true, b).total;
     return want < worst ? want : worst;
 }
-extern "C" uint64_t t2n_field_list_retries(const t2n_field* f) { return f ? f->list_retries : 0; }
+extern "C" uint64_t t2n_field_list_retries(const t2n_field* f) {
+    if (!f) return 0;
+    counts_poll(const_cast<t2n_field*>(f), true);   // a query, not a render: waits for the counters still on their way
+    return f->list_retries;
+}
 extern "C" size_t t2n_render_workspace_bytes_budget(int64_t n_rays, int n_samples, int entries_per_ray) {
     if (n_rays <= 0 || n_samples <= 0 || entries_per_ray < 0) return 0;
     return carve_workspace(n_rays, n_samples, true, true, (unsigned)entries_per_ray).total;

@@ -102,7 +102,9 @@ struct t2n_field {
     t2n::TimingSlot slots[T2N_K_COUNT];
     // optimistic (budgeted) render launches: the counters travel to pinned host memory behind the march kernels; the entries a
     // ray needed last time size the next call's lists (t2n_render_workspace_bytes_hint)
-    unsigned* host_counts = nullptr; void* ev_counts = nullptr;
+    static constexpr int kCountSlots = 4;
+    struct CountSlot { unsigned* host = nullptr; void* ev = nullptr; bool pending = false; int64_t n_rays = 0; int n_samples = 0; unsigned budget = 0; };
+    CountSlot count_slots[kCountSlots]; int count_next = 0;
     void* side_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;   // backward: the density scatter runs beside the MLP backward
     void* ev_den = nullptr;      // recorded behind the density scatter of the last backward (t2n_field_wait_density_grads)
     void* gemm_stream = nullptr; void* ev_fork2 = nullptr; void* ev_join2 = nullptr;  // backward: the weight-gradient GEMMs run beside the appearance scatter
@@ -121,6 +123,7 @@ int hip_fail(hipError_t e, const char* what);
         if (e__ != hipSuccess) return t2n::hip_fail(e__, #call); \
     } while (0)
 
+void counts_poll(t2n_field* f, bool wait);   // budgeted launches' counters that reached the host -> list_hint / list_retries (t2n_api.hip)
 // timing helpers (t2n_api.hip)
 void timing_begin(t2n_field* f, int k, hipStream_t s);
 void timing_end(t2n_field* f, int k, hipStream_t s);
@@ -173,6 +176,7 @@ constexpr int kRangeFlagWord = 32;
 // the statement once it has consumed the rows (h0 / h1 are overwritten in place).
 constexpr int kKeptMagicWord = 33, kKeptRowsWord = 34;
 constexpr int kOverflowWord = 35;   // raised by the march kernels when a ray's appearance entries fit no sub-list (budgeted lists only)
+constexpr int kFailEntriesWord = 36;   // appearance entries of the rays that fit no sub-list (finished by k_finish_rays): the next budget counts them
 constexpr unsigned kKeptMagic = 0x4b455054u;   // "KEPT"
 int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev, unsigned list_cap, unsigned tile_hi, float4* app_rgb,
                   unsigned* range_flag, hipStream_t s);
@@ -237,6 +241,11 @@ void* mlp_bwd_ss_absmax_words(void* packbuf);
 struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, feat, total; unsigned list_cap, feat_rows; };
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat = true, unsigned budget = 0);   // budget: appearance entries per ray (0: worst case)   // ctx: also room for sigma [rays,N] and rgb_raw [rays]; feat: feature rows (last region: the other offsets do not depend on it; KEEP_CTX calls carve without)
 int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s, int img_w = 0, int img_h = 0);
+// Tile-marcher launches: the rays whose appearance entries fitted no sub-list (budgeted lists) are shaded and composited straight from
+// their staging slices / spill rows by one more kernel behind k_composite (t2n_shade.hip); a launch without such rays costs one
+// empty kernel. Heads the finisher does not evaluate (the general view-dependent MLPs) keep the host-side retry.
+inline bool finish_supported(const t2n_field* f) { return !head_is_generic(f->desc.shading); }
+int launch_finish_rays(t2n_field* f, const RenderLaunch& L, const float* spill, const float4* scratch, hipStream_t s);
 int ctx_counts_post(const void* ws, const unsigned* counters_dev, hipStream_t s);   // KEEP_CTX forward: counts -> pinned host copy + event (t2n_backward.hip)
 // Activation rows the forward keeps for the backward when the KEEP_CTX workspace is larger than the context itself (the
 // caller's guess of the appearance-row count; 1728 B per row): x144 [rows,144], feat32 [rows,32], h0 / h1 [rows,128] behind

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void k_composite(const CompositeArgs a) {
     }
     if (r >= a.n_rays) return;
     const int4 ra = a.ray_app[r];
+    if (ra.x < 0) return;   // a ray whose entries fitted no sub-list (budgeted lists): k_finish_rays, behind this kernel, writes its colour
     float cr = 0.f, cg = 0.f, cb = 0.f;
     // (r, g, b, w) entries: the shading kernels copy the entry's weight next to its colour. Eight loads in flight per trip (a wave
     // runs as long as its longest slice: one dependent round trip per entry was most of the kernel's 57 us); the sum keeps the

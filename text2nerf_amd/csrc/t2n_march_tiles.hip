@@ -182,6 +182,18 @@ __device__ __forceinline__ float pair_dot_global(const FactorSet& S, const Axes3
     return part;
 }
 
+// A reservation that did not fit leaves its sub-list counter raised over entries nobody writes (the readers clamp the counter to
+// list_cap, so the part of the region inside the list IS walked by the shading kernels): those entries get a defined content — the
+// volume centre, weight 0, ray 0 — whatever the scratch held before (the SH head reads the entry's ray for its view direction).
+__device__ __forceinline__ void void_entries(float4* __restrict__ app_pos, int* __restrict__ app_ray, unsigned list, unsigned list_cap,
+                                             unsigned lo, unsigned hi, int lane) {
+    if (hi > list_cap) hi = list_cap;
+    for (unsigned e = lo + (unsigned)lane; e < hi; e += 64u) {
+        app_pos[(size_t)list * list_cap + e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        app_ray[(size_t)list * list_cap + e] = 0;
+    }
+}
+
 constexpr int kDenseLd = 20;                          // floats per ray row of the transpose tile (16 steps + pad, 16-B aligned)
 constexpr int kDenseFloats = 64 * kDenseLd;           // per wave: the weights tile
 struct __attribute__((aligned(4))) F4U { float x, y, z, w; };   // row segments of an [n_rays, N] tensor are only 4-B aligned for odd N
@@ -395,6 +407,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N
     // a region that does not fit its sub-list (small or ragged frames put many tiles on one list): the wave's rays take the
     // per-ray route below, which tries every sub-list; the inflated counter is clamped to list_cap by its readers
     const bool fits = base + total <= a.list_cap;
+    if (!fits && total) void_entries(a.app_pos, a.app_ray, list, a.list_cap, base, base + total, lane);
     const unsigned slot0 = list * a.list_cap + base + (incl - n);
     if (have) {
         if (over || !fits) {
@@ -428,26 +441,40 @@ struct CompactArgs {
     int4* ray_app; float4* app_pos; int* app_ray; unsigned* counters; unsigned list_cap;
     unsigned long long* stats;
     const float4* scratch; int cap;   // the marcher's per-ray staging slices
+    int finisher;                     // a ray that fits no sub-list is left to k_finish_rays (t2n_shade.hip) instead of losing its samples
 };
 // lane 0 reserves `napp` slots on the first sub-list with room; returns (slot0, napp or 0 when nothing fits) to all lanes
+// A ray that fits nowhere (budgeted lists, t2n_render_forward): with a finisher behind this kernel the ray keeps its hand-over record
+// in ray_app — x = -(first spilled sample) - 1 < 0 tells k_composite that the ray owns no list entries, y stays its appearance
+// count (k_ray_stats) — its slot of the overflow list is tagged (sign bit) and its entries are added to word kFailEntriesWord (the
+// next frame's budget); k_finish_rays shades and composites such rays from their staging slice and spill row, no list needed.
 __device__ __forceinline__ void reserve_slots(const CompactArgs& a, long long r, unsigned list, int lane, const int4 ra, unsigned& slot0,
-                                              unsigned& napp) {
+                                              unsigned& napp, int* ovf_slot) {
     slot0 = 0;
+    unsigned void_l = 0, void_lo = 0, void_hi = 0;   // a failed try's region inside its list (at most one per ray: tries stop there)
     if (lane == 0) {
         bool fits = napp == 0;
-        for (unsigned att = 0; att < (unsigned)kLists && !fits; ++att) {     // first sub-list with room (failed tries leave the
-            const unsigned l = (list + att) & (unsigned)(kLists - 1);          // counter above list_cap: readers clamp it)
+        for (unsigned att = 0; att < (unsigned)kLists && !fits && void_hi == 0u; ++att) {   // first sub-list with room (a failed try leaves
+            const unsigned l = (list + att) & (unsigned)(kLists - 1);                        // the counter above list_cap: readers clamp it)
             if (a.counters[l * kCounterStride] + napp > a.list_cap) continue;
             const unsigned s0 = atomicAdd(&a.counters[l * kCounterStride], napp);
             if (s0 + napp <= a.list_cap) { slot0 = l * a.list_cap + s0; fits = true; }
+            else if (s0 < a.list_cap) { void_l = l; void_lo = s0; void_hi = s0 + napp; }
         }
-        a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, ra.z, ra.w);
-        if (!fits && a.stats) a.stats[T2N_STAT_OVERFLOW] = 1ull;
-        if (!fits) a.counters[kOverflowWord] = 1u;   // budgeted lists: t2n_render_forward redoes the launch with worst-case lists
+        if (fits || !a.finisher) a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, ra.z, ra.w);
+        else {
+            a.ray_app[r] = make_int4(-ra.x - 1, (int)napp, ra.z, ra.w);
+            *ovf_slot = (int)((unsigned)r | 0x80000000u);
+            atomicAdd(&a.counters[kFailEntriesWord], napp);
+        }
+        if (!fits && !a.finisher && a.stats) a.stats[T2N_STAT_OVERFLOW] = 1ull;
+        if (!fits) a.counters[kOverflowWord] = 1u;   // budgeted lists: read back by the host (the next frames' budget, list_retries)
         if (!fits) napp = 0;
     }
     slot0 = __shfl(slot0, 0);
     napp = __shfl(napp, 0);
+    void_hi = __shfl(void_hi, 0);
+    if (void_hi) void_entries(a.app_pos, a.app_ray, __shfl(void_l, 0), a.list_cap, __shfl(void_lo, 0), void_hi, lane);
 }
 // append the entries of wbuf[r][from, end) above the threshold at slot0 + run.. (sample order)
 __device__ __forceinline__ void compact_span(const CompactArgs& a, long long r, const Ray& ray, int from, int end, unsigned slot0, unsigned run,
@@ -473,11 +500,11 @@ __device__ __forceinline__ void compact_span(const CompactArgs& a, long long r, 
 }
 // a ray the tile marcher handed over (staging slice full, or its wave's region did not fit the sub-list): the first
 // min(napp, cap) entries sit in the staging slice, the rest in wbuf[r][from..]
-__device__ __forceinline__ void compact_ray_staged(const CompactArgs& a, long long r, unsigned list, int lane) {
+__device__ __forceinline__ void compact_ray_staged(const CompactArgs& a, long long r, unsigned list, int lane, int* ovf_slot) {
     const int4 ra = a.ray_app[r];
     const int first = ra.w & 2047, Lw = ra.w >> 11, from = ra.x;
     unsigned napp = (unsigned)ra.y, slot0;
-    reserve_slots(a, r, list, lane, ra, slot0, napp);
+    reserve_slots(a, r, list, lane, ra, slot0, napp, ovf_slot);
     const unsigned staged = napp < (unsigned)a.cap ? napp : (unsigned)a.cap;
     for (unsigned k = (unsigned)lane; k < staged; k += 64u) {
         a.app_pos[slot0 + k] = a.scratch[(size_t)r * a.cap + k];
@@ -489,10 +516,11 @@ __device__ __forceinline__ void compact_ray_staged(const CompactArgs& a, long lo
     }
 }
 // the rays the tile marcher could not stage (more than cap appearance samples): a small persistent grid walks the list
-__global__ __launch_bounds__(256) void k_compact_list(const CompactArgs a, const unsigned* ovf_count, const int* ovf_list) {
+__global__ __launch_bounds__(256) void k_compact_list(const CompactArgs a, const unsigned* ovf_count, int* ovf_list) {
     const int lane = threadIdx.x & 63;
     const unsigned n = *ovf_count;
-    for (unsigned k = blockIdx.x * 4u + (threadIdx.x >> 6); k < n; k += gridDim.x * 4u) compact_ray_staged(a, ovf_list[k], blockIdx.x & 7u, lane);
+    for (unsigned k = blockIdx.x * 4u + (threadIdx.x >> 6); k < n; k += gridDim.x * 4u)
+        compact_ray_staged(a, ovf_list[k], blockIdx.x & 7u, lane, ovf_list + k);
 }
 
 // z_vals rows (z_i of every sample index, models/tensorBase.py:313-318) and zeroed weights rows of a launch's rays: one wave per
@@ -542,7 +570,8 @@ int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h
     c.ray_app = L.ray_app; c.app_pos = L.app_pos; c.app_ray = L.app_ray; c.counters = L.counters; c.list_cap = L.list_cap;
     c.stats = (unsigned long long*)L.stats;
     c.scratch = scratch; c.cap = cap;
-    hipLaunchKernelGGL(k_compact_list, dim3(64), dim3(256), 0, s, c, (const unsigned*)ovf_count, (const int*)ovf_list);
+    c.finisher = finish_supported(f) ? 1 : 0;
+    hipLaunchKernelGGL(k_compact_list, dim3(64), dim3(256), 0, s, c, (const unsigned*)ovf_count, ovf_list);
     timing_end(f, T2N_K_MARCH, s);
     T2N_HIP(hipGetLastError());
     return launch_ray_stats(L, s);

@@ -647,6 +647,191 @@ __global__ __launch_bounds__(256, 2) void k_shade(const ShadeArgs a) {
     if (SPLIT && a.range_flag && __any(!(amax <= 60000.f)) && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
+// ---- finisher of tile-marcher launches (budgeted appearance lists) --------------------------------------------------------------
+// The rays k_compact_list tagged in the overflow list own no list entries: their appearance samples sit in the marcher's per-ray
+// staging slice (the first `cap`) and, past it, in the ray's spill row of weights. One wave per such ray walks them in sample
+// order through a 32-entry LDS queue and evaluates gather -> basis_mat -> head on the exact fp32 matrix path (the arithmetic of
+// k_shade<false>, the reference's own: models/tensoRF.py:223-239, models/tensorBase.py:88-109), sums w * rgb in the entries' order
+// like k_composite and writes the ray's colour (models/tensorBase.py:494-501). No list memory is needed whatever the number of such
+// rays, so t2n_render_forward never has to wait for the march's counters: a launch without tagged rays costs this kernel's
+// empty dispatch (every workgroup reads one word).
+struct FinishArgs {
+    FieldDev F;
+    const float* rays; int ray_stride; int n_samples;
+    const int4* ray_app; const float* acc; float* rgb; int add_bg;
+    const float* wbuf; const float4* scratch; int cap;
+    const unsigned* ovf_count; const int* ovf_list;
+    unsigned long long* stats;
+};
+constexpr int kFinQueue = 96;                                  // float4 entries: 31 left over + 64 new candidates
+constexpr int kFinFloats = kTileFloats + kFinQueue * 4;        // per wave: the shade tile + the entry queue
+
+__global__ __launch_bounds__(256) void k_finish_rays(const FinishArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned n_ovf = *a.ovf_count;
+    if (n_ovf == 0u) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int s = lane & 31, h = lane >> 5;
+    float* __restrict__ X = smem + (size_t)wid * kFinFloats;
+    float* __restrict__ Fe = X;
+    float4* __restrict__ Q = reinterpret_cast<float4*>(X + kTileFloats);
+    const FieldDev& F = a.F;
+    const int N = a.n_samples;
+    bool any = false;
+    for (unsigned k = blockIdx.x * 4u + wid; k < n_ovf; k += gridDim.x * 4u) {
+        const int tag = a.ovf_list[k];
+        if (tag >= 0) continue;                    // found room in a sub-list: an ordinary ray
+        any = true;
+        const long long r = (long long)(tag & 0x7fffffff);
+        const int4 ra = a.ray_app[r];
+        const int from = -ra.x - 1, napp = ra.y, first = ra.w & 2047, Lw = ra.w >> 11;
+        const int staged = napp < a.cap ? napp : a.cap;
+        const float* __restrict__ rp = a.rays + r * a.ray_stride;
+        float cr = 0.f, cg = 0.f, cb = 0.f;
+        int q = 0;                                 // queued entries (wave-uniform)
+        // shade the first `cnt` queued entries, add w * rgb in their order, drop them from the queue
+        auto flush = [&](int cnt) {
+            gather_all<false>(F.app, X, lane, Q, nullptr, 0u, (unsigned)cnt, nullptr, 0u);
+            const float wq = s < cnt ? Q[s].w : 0.f;
+            wave_lds_sync();
+            f32x16 accb1[1] = {{0}};
+            {
+                LdsBNoBias bf{X + (size_t)h * kXld + s, kBasisReal};
+                mfma_stream<1, kKS1>(accb1, F.basisA + lane, kBasisStages, bf);
+            }
+            const f32x16 accb = accb1[0];
+            wave_lds_sync();
+#pragma unroll
+            for (int v = 0; v < 16; ++v) Fe[unit_of(v, h) * kXld + s] = accb[v];
+            wave_lds_sync();
+            float tr = 0.f, tg = 0.f, tb = 0.f;
+            if (F.shading == T2N_SHADE_MLP_FEA_NOVIEW) {
+                f32x16 acc0[4] = {{0}, {0}, {0}, {0}};
+                {
+                    PeB bf{Fe + (size_t)h * kXld + s, h, 0.f, 0.f, 1.f};
+                    mfma_stream<4, kKS4>(acc0, F.w0A + lane, kL0Stages, bf);
+                }
+                float* __restrict__ Hs = X;
+                wave_lds_sync();
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) Hs[(ms * 32 + unit_of(v, h)) * kXld + s] = fmaxf(acc0[ms][v], 0.f);
+                wave_lds_sync();
+                f32x16 acc1[4] = {{0}, {0}, {0}, {0}};
+                {
+                    LdsB bf{Hs + (size_t)h * kXld + s, 64, h};
+                    mfma_stream<4, kKS4>(acc1, F.w1A + lane, kL1Stages, bf);
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) Hs[(ms * 32 + unit_of(v, h)) * kXld + s] = fmaxf(acc1[ms][v], 0.f);
+                wave_lds_sync();
+                f32x16 acc2a[1] = {{0}};
+                {
+                    LdsB bf{Hs + (size_t)h * kXld + s, 64, h};
+                    mfma_stream<1, kKS1>(acc2a, F.w2A + lane, kL2Stages, bf);
+                }
+                tr = sigmoidf_(acc2a[0][0]); tg = sigmoidf_(acc2a[0][1]); tb = sigmoidf_(acc2a[0][2]);   // rows 0..2 live on h == 0
+            } else if (F.shading == T2N_SHADE_SH) {
+                if (h == 0) {   // models/sh.py:4-14,87-112 (degree 2), the ray's own direction
+                    const float dx = rp[3], dy = rp[4], dz = rp[5];
+                    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+                    const float C20 = 1.0925484305920792f, C21 = -1.0925484305920792f, C22 = 0.31539156525252005f,
+                                C23 = -1.0925484305920792f, C24 = 0.5462742152960396f;
+                    const float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
+                    float sh[9];
+                    sh[0] = C0; sh[1] = -C1 * dy; sh[2] = C1 * dz; sh[3] = -C1 * dx;
+                    sh[4] = C20 * xy; sh[5] = C21 * yz; sh[6] = C22 * (2.0f * zz - xx - yy); sh[7] = C23 * xz; sh[8] = C24 * (xx - yy);
+                    float o[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int b = 0; b < 9; ++b) acc = fmaf(sh[b], Fe[(c * 9 + b) * kXld + s], acc);
+                        o[c] = fmaxf(acc + 0.5f, 0.f);
+                    }
+                    tr = o[0]; tg = o[1]; tb = o[2];
+                }
+            } else if (h == 0) { tr = Fe[0 * kXld + s]; tg = Fe[1 * kXld + s]; tb = Fe[2 * kXld + s]; }   // T2N_SHADE_RGB
+            // the entries' own order, one fused multiply-add per entry and channel: k_composite's sum
+            for (int j = 0; j < cnt; ++j) {
+                const float wj = __shfl(wq, j), rj = __shfl(tr, j), gj = __shfl(tg, j), bj = __shfl(tb, j);
+                cr = fmaf(wj, rj, cr); cg = fmaf(wj, gj, cg); cb = fmaf(wj, bj, cb);
+            }
+            wave_lds_sync();   // Fe / Hs reads done
+            // queue: entries [cnt, q) move to the front
+            const int rest = q - cnt;
+            float4 mv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) mv[t] = (lane + 64 * t < rest) ? Q[cnt + lane + 64 * t] : make_float4(0.f, 0.f, 0.f, 0.f);
+            wave_lds_sync();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) if (lane + 64 * t < rest) Q[lane + 64 * t] = mv[t];
+            wave_lds_sync();
+            q = rest;
+        };
+        for (int k0 = 0; k0 < staged; k0 += 32) {
+            const int cnt = staged - k0 < 32 ? staged - k0 : 32;
+            if (lane < cnt) Q[q + lane] = a.scratch[(size_t)r * a.cap + k0 + lane];
+            q += cnt;
+            wave_lds_sync();
+            if (q >= 32) flush(32);
+        }
+        if (napp > staged) {
+            const Ray ray = load_ray(F, rp, a.ray_stride);
+            const int end = first + Lw;
+            for (int base = from; base < end; base += 64) {
+                const int i = base + lane;
+                const float w = i < end ? a.wbuf[r * N + i] : 0.f;
+                const bool m = (i < end) & (w > F.thres);
+                const unsigned long long bal = __ballot(m);
+                if (m) {
+                    const int pre = (int)__popcll(bal & ((1ull << lane) - 1ull));
+                    const float z = sample_z<false>(F, ray, i, 0.f);
+                    float xn, yn, zn;
+                    sample_point<false>(F, ray, z, xn, yn, zn);
+                    Q[q + pre] = make_float4(xn, yn, zn, w);
+                }
+                q += (int)__popcll(bal);
+                wave_lds_sync();
+                while (q >= 32) flush(32);
+            }
+        }
+        if (q > 0) flush(q);
+        if (lane == 0) {
+            if (a.add_bg) { const float bg = 1.f - a.acc[r]; cr += bg; cg += bg; cb += bg; }
+            a.rgb[r * 3 + 0] = fminf(fmaxf(cr, 0.f), 1.f);
+            a.rgb[r * 3 + 1] = fminf(fmaxf(cg, 0.f), 1.f);
+            a.rgb[r * 3 + 2] = fminf(fmaxf(cb, 0.f), 1.f);
+        }
+    }
+    if (any && lane == 0 && a.stats) a.stats[T2N_STAT_LIST_RETRY] = 1ull;
+}
+
+int launch_finish_rays(t2n_field* f, const RenderLaunch& L, const float* spill, const float4* scratch, hipStream_t s) {
+    const int cap = L.n_samples / 4 > 0 ? L.n_samples / 4 : 1;     // (launch_march_tiles' staging geometry)
+    const unsigned* ovf_count = (const unsigned*)((const char*)scratch + (size_t)L.n_rays * cap * 16);
+    FinishArgs a;
+    a.F = f->dev;
+    a.rays = L.rays; a.ray_stride = L.ray_stride; a.n_samples = L.n_samples;
+    a.ray_app = L.ray_app; a.acc = L.acc; a.rgb = L.rgb; a.add_bg = (L.flags & T2N_FLAG_ADD_BG) ? 1 : 0;
+    a.wbuf = L.weights ? L.weights : spill; a.scratch = scratch; a.cap = cap;
+    a.ovf_count = ovf_count; a.ovf_list = (const int*)((const char*)ovf_count + 256);
+    a.stats = (unsigned long long*)L.stats;
+    const size_t lds = (size_t)4 * kFinFloats * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        T2N_HIP(hipFuncSetAttribute((const void*)k_finish_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_finish_rays, dim3(512), dim3(256), lds, s, a);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
 // ---- features only (K2a of the default render path): gather + basis_mat -> fp32 feature rows [tile * 32 + sample][32] for the
 // sample-stationary head (t2n_mlp_ss.hip), one factor pair at a time. (The first form of this stage, a 144-row X tile per wave
 // with two waves per SIMD, ran 0.64 ms per C2 frame against 0.58: DESIGN.md, v23 / v25; it lives in the history, not here.)

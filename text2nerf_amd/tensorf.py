@@ -337,12 +337,13 @@ class TensorBase(nn.Module):
         # 'fp32' (default) or 'bf16' (BASELINE configs[4]): the forward gathers read bf16 copies of the 12 factor tensors;
         # the render equals the fp32 render of the bf16-rounded tensors bit for bit, the parameters stay fp32 masters
         self.factor_storage = os.environ.get("T2N_FACTOR_STORAGE", "fp32")
-        # Early ray termination of eval renders that return neither weights nor z_vals (evaluation(), render_views, ...): a ray whose
-        # transmittance fell below this evaluates no further sample. The reference never terminates (models/tensorBase.py:19-26,
-        # 494-505), so this is a bounded deviation (< eps on acc and colour, < eps * z range on depth), not its arithmetic: set 0.0
-        # for the reference's sample-for-sample behaviour (exact evaluated-sample counts). OctreeRender_trilinear_fast (weights
-        # returned) and training are never terminated.
-        self.early_termination = float(os.environ.get("T2N_EARLY_TERMINATION", "1e-6"))
+        # Early ray termination of eval renders that return neither weights nor z_vals (evaluation(), render_views, ...): OPT-IN. The
+        # reference never terminates (models/tensorBase.py:19-26,494-505: every in-box sample is evaluated), so the default 0.0 is its
+        # sample-for-sample arithmetic (exact evaluated-sample counts). A threshold eps > 0 stops a ray whose transmittance fell below it:
+        # a bounded deviation (< eps on acc and colour, < eps * z range on depth). Values above rayMarch_weight_thres are clamped to it
+        # (a skipped sample could otherwise have been an appearance sample). OctreeRender_trilinear_fast (weights returned) and
+        # training are never terminated. T2N_EARLY_TERMINATION sets the default of new fields.
+        self.early_termination = float(os.environ.get("T2N_EARLY_TERMINATION", "0"))
         self._handle = None
         self._uploaded_key = None
         self._gbuf = None
@@ -768,7 +769,8 @@ class TensorBase(nn.Module):
             _lib.check(lib.t2n_field_set_mlp_precision(self._handle, 1 if self.mlp_exact_fp32 else 0),
                        "t2n_field_set_mlp_precision")
             self._precision_set = bool(self.mlp_exact_fp32)
-        et = float(self.early_termination or 0.0)
+        # (rayMarch_weight_thres = 0 — `weight > thres`, models/tensorBase.py:477 — is a legitimate setting: 0 then means off)
+        et = max(0.0, min(float(self.early_termination or 0.0), float(self.rayMarch_weight_thres)))
         if getattr(self, "_term_set", None) != et:
             _lib.check(lib.t2n_field_set_early_termination(self._handle, et), "t2n_field_set_early_termination")
             self._term_set = et
