@@ -64,9 +64,10 @@ __device__ __forceinline__ Ray load_ray(const FieldDev& F, const float* __restri
 }
 
 // models/tensorBase.py:313-318: z_i = t_min + stepSize * (i [+ u])
-template <bool TRAIN>
+// NOTAB: the caller's launches never carry an NDC depth table (the tile marcher): no run-time test in the step loop
+template <bool TRAIN, bool NOTAB = false>
 __device__ __forceinline__ float sample_z(const FieldDev& F, const Ray& r, int i, float u) {
-    if (F.ztab) return F.ztab[i];          // NDC: torch.linspace(near, far, N) [+ shared jitter], built by the host mirror
+    if (!NOTAB && F.ztab) return F.ztab[i];          // NDC: torch.linspace(near, far, N) [+ shared jitter], built by the host mirror
     float rng = (float)i;
     if (TRAIN) rng = rng + u;
     const float st = F.step * rng;
@@ -323,19 +324,48 @@ __device__ __forceinline__ void ray_interval(const FieldDev& F, const Ray& ray, 
     }
 }
 
+// expf / logf as the device library evaluates them (extended-precision product with log2 e around v_exp_f32; v_log_f32 times ln 2
+// in two pieces), WITHOUT its guards for arguments no caller here has: exp_finite(x) for finite x <= 88 (the library adds the overflow
+// branch, a flush below -103.3 that v_ldexp_f32 performs by itself — the argument is clamped at -200, so -inf gives 0 as well —, and
+// denormal-input scaling the reduced argument never needs),
+// log_ge1(u) for finite u >= 1 (no denormal pre-scaling, no infinity test). Same operations in the same order on the values that
+// remain: the results are the library's bit for bit, at 10 + 5 instead of 13 + 13 instructions per evaluation — the tile marcher runs
+// three of them per sample (softplus = log1p(exp(.)), then 1 - exp(-sigma dist): models/tensorBase.py:19-26,406-410).
+__device__ __forceinline__ float exp_finite(float x0) {
+    float x;                                                        // max(x0, -200): -inf would turn ph - n into NaN; below -103.3 the result is 0
+    asm("v_max_f32 %0, 0xc3480000, %1" : "=v"(x) : "v"(x0));        // either way (one instruction: fmaxf adds a canonicalising v_max in front)
+    const float l2e = __uint_as_float(0x3fb8aa3bu);
+    const float ph = x * l2e;
+    const float n = __builtin_rintf(ph);
+    float pl = fmaf(x, l2e, -ph);
+    pl = fmaf(x, __uint_as_float(0x32a5705fu), pl);                 // + x * (log2 e - l2e)
+    const float a = (ph - n) + pl;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)n);
+}
+__device__ __forceinline__ float log_ge1(float u) {
+    const float ln2 = __uint_as_float(0x3f317217u);                 // (the library's high piece: NOT the float nearest to ln 2)
+    const float y = __builtin_amdgcn_logf(u);
+    const float r0 = y * ln2;
+    float r1 = fmaf(y, ln2, -r0);
+    r1 = fmaf(y, __uint_as_float(0x3377d1cfu), r1);                 // + y * (ln 2 - ln2)
+    return r0 + r1;
+}
+
 // log1p(t) for t >= 0 as log(u) + (t - (u - 1)) / u with u = fl(1 + t): the second term restores what the rounding of 1 + t
 // dropped (first order; the neglected term is below 2^-48 relative), so the result is within ~1 ulp of the accurate logf —
 // at ~35 instructions instead of the ~130 of the library's double-float log1pf (a quarter of the tile marcher's step).
 __device__ __forceinline__ float log1p_pos(float t) {
     const float u = 1.f + t;
-    return fmaf(t - (u - 1.f), __builtin_amdgcn_rcpf(u), logf(u));
+    return fmaf(t - (u - 1.f), __builtin_amdgcn_rcpf(u), log_ge1(u));
 }
 
 // feature2density (models/tensorBase.py:406-410): softplus(beta=1, threshold=20) of feat+shift, or relu(feat).
+// ACT: the activation as a compile-time constant (-1: F.act at run time)
+template <int ACT = -1>
 __device__ __forceinline__ float feature2density(const FieldDev& F, float feat) {
-    if (F.act == T2N_ACT_RELU) return fmaxf(feat, 0.f);
+    if (ACT == T2N_ACT_RELU || (ACT < 0 && F.act == T2N_ACT_RELU)) return fmaxf(feat, 0.f);
     const float x = feat + F.shift;
-    return x > 20.f ? x : log1p_pos(expf(x));
+    return x > 20.f ? x : log1p_pos(exp_finite(x));
 }
 
 // XCD-aware block -> logical tile map: the dispatcher places block b on XCD b % 8; give every XCD a contiguous run of

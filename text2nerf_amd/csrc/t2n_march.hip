@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_march(const MarchArgs a) {
             }
             const float d = scaled_dist(F, ray, dist);
             const float nsd = (-sg) * d;
-            const float alpha = 1.f - expf(nsd);
+            const float alpha = 1.f - exp_finite(nsd);   // (nsd <= 0)
             const float f = (1.f - alpha) + 1e-10f;
             const float incl = wave_scan_mul(f, lane);
             float excl = __shfl_up(incl, 1);

@@ -208,7 +208,10 @@ struct __attribute__((aligned(4))) F4U { float x, y, z, w; };   // row segments 
 #ifndef T2N_MTD_WAVES
 #define T2N_MTD_WAVES 4
 #endif
-template <bool DENSE>
+// ALPHA: the field carries an AlphaGridMask; RELU: fea2denseAct = relu. Compile-time, like the absent NDC depth table (the host never
+// sends NDC renders here): the step loop of the driver's configuration (no mask, softplus) carries neither the mask's eight-tap
+// gather with its 64-bit address arithmetic nor a run-time test per sample and option.
+template <bool DENSE, bool ALPHA = false, bool RELU = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N_MTD_WAVES : T2N_MT_WAVES, DENSE ? T2N_MTD_WAVES : T2N_MT_WAVES))) void k_march_tiles(const TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -277,9 +280,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N
             xn[q] = yn[q] = zn[q] = z[q] = w_out[q] = 0.f;
             ok[q] = false;
             if (have && idx >= lo && idx <= hi && idx <= i_end && !dead) {
-                z[q] = sample_z<false>(F, ray, idx, 0.f);
+                z[q] = sample_z<false, true>(F, ray, idx, 0.f);
                 ok[q] = sample_point<false>(F, ray, z[q], xn[q], yn[q], zn[q]);
-                if (F.alpha && ok[q]) ok[q] = alpha_pass(F, ray, z[q]);      // models/tensorBase.py:451-456
+                if constexpr (ALPHA) { if (ok[q]) ok[q] = alpha_pass(F, ray, z[q]); }      // models/tensorBase.py:451-456
             }
             any_ok |= ok[q];
         }
@@ -339,9 +342,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N
             const int idx = i + q;
             const bool spill = have && idx <= i_end && napp >= (unsigned)a.cap && !DENSE;
             if (ok[q]) {
-                const float sg = feature2density(F, part[q]);
-                const float dist = idx < N - 1 ? sample_z<false>(F, ray, idx + 1, 0.f) - z[q] : 0.f;     // :448
-                const float alpha = 1.f - expf((-sg) * (dist * F.dscale));                            // raw2alpha :19-26
+                const float sg = feature2density<RELU ? T2N_ACT_RELU : T2N_ACT_SOFTPLUS>(F, part[q]);
+                const float dist = idx < N - 1 ? sample_z<false, true>(F, ray, idx + 1, 0.f) - z[q] : 0.f;     // :448
+                const float alpha = 1.f - exp_finite((-sg) * (dist * F.dscale));                      // raw2alpha :19-26 (argument <= 0)
                 const float w = alpha * T;
                 T = T * ((1.f - alpha) + 1e-10f);
                 acc += w;
@@ -560,8 +563,14 @@ int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h
     if (L.weights || L.z_vals)
         hipLaunchKernelGGL(k_dense_fill, dim3((unsigned)((L.n_rays + 3) / 4)), dim3(256), 0, s, f->dev, L.rays, (long long)L.n_rays, L.ray_stride,
                            L.n_samples, L.weights, L.z_vals);
-    if (dense) hipLaunchKernelGGL(k_march_tiles<true>, grid, dim3(256), (size_t)4 * (kStageFloats + kDenseFloats) * sizeof(float), s, a);
-    else hipLaunchKernelGGL(k_march_tiles<false>, grid, dim3(256), (size_t)4 * kStageFloats * sizeof(float), s, a);
+    const size_t lds = (size_t)4 * (kStageFloats + (dense ? kDenseFloats : 0)) * sizeof(float);
+    const bool mask = f->dev.alpha != nullptr, relu = f->dev.act == T2N_ACT_RELU;
+#define T2N_MT_LAUNCH(D, A, R) hipLaunchKernelGGL((k_march_tiles<D, A, R>), grid, dim3(256), lds, s, a)
+    if (dense) { if (mask) { if (relu) T2N_MT_LAUNCH(true, true, true); else T2N_MT_LAUNCH(true, true, false); }
+                 else { if (relu) T2N_MT_LAUNCH(true, false, true); else T2N_MT_LAUNCH(true, false, false); } }
+    else { if (mask) { if (relu) T2N_MT_LAUNCH(false, true, true); else T2N_MT_LAUNCH(false, true, false); }
+           else { if (relu) T2N_MT_LAUNCH(false, false, true); else T2N_MT_LAUNCH(false, false, false); } }
+#undef T2N_MT_LAUNCH
     T2N_HIP(hipGetLastError());
     CompactArgs c;
     c.F = f->dev;

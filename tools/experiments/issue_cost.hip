@@ -13,13 +13,14 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
     "a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47", \
     "a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71"
 
-enum { FMA, FMA_DEP, CVT_PKRTZ, FMA_MIX, PK_MAX, ACC_READ, SIN, EXP, DS_READ128, NOP0, NOP1, MAX, PK_FMA, MOV, FRACT, PAIR_DEP, ACC_READ_DEP, DS_READ64, MIX_CVT, CVT_PK_RNE, CVT_F16, SPLIT1, SPLIT2, SPLIT2_RNE, FMA_DIST2, PERM, PK_MUL, ACC_READ_SPACED, NKIND };
+enum { FMA, FMA_DEP, CVT_PKRTZ, FMA_MIX, PK_MAX, ACC_READ, SIN, EXP, DS_READ128, NOP0, NOP1, MAX, PK_FMA, MOV, FRACT, PAIR_DEP, ACC_READ_DEP, DS_READ64, MIX_CVT, CVT_PK_RNE, CVT_F16, SPLIT1, SPLIT2, SPLIT2_RNE, FMA_DIST2, PERM, PK_MUL, ACC_READ_SPACED, MIXLO, MIXLOHI, SPLIT3, SPLIT3_ONE, NKIND };
 static const char* kNames[NKIND] = {"v_fma_f32 (independent)", "v_fma_f32 (one dependent chain)", "v_cvt_pkrtz_f16_f32", "v_fma_mix_f32", "v_pk_max_i16",
     "v_accvgpr_read_b32 (idle AccVGPRs)", "v_sin_f32", "v_exp_f32", "ds_read_b128 (wait once per 4 MFMAs)", "s_nop 0", "s_nop 1", "v_max_f32", "v_pk_fma_f32",
     "v_mov_b32", "v_fract_f32", "v_fma -> v_max dependent pairs (counted as 2)", "v_accvgpr_read -> v_fma dependent pairs (counted as 2)",
     "ds_read_b64 (wait once per 4 MFMAs)", "2 v_fma_mix -> v_cvt_pkrtz triples (counted as 3)", "v_cvt_pk_f16_f32 (gfx950, RNE)", "v_cvt_f16_f32",
     "hi/lo split, ONE chain: cvt_pkrtz, 2 mix, nop, cvt_pkrtz (N/4 splits, counted as 4)", "hi/lo split, TWO chains interleaved (N/8 double splits, counted as 8)",
-    "the same with v_cvt_pk_f16_f32", "v_fma_f32, two chains alternating (dependent at distance 2)", "v_perm_b32", "v_pk_mul_f32", "v_accvgpr_read, v_fma alternating (independent)"};
+    "the same with v_cvt_pk_f16_f32", "v_fma_f32, two chains alternating (dependent at distance 2)", "v_perm_b32", "v_pk_mul_f32", "v_accvgpr_read, v_fma alternating (independent)", "v_fma_mixlo_f16 (independent)", "v_fma_mixlo_f16 -> v_fma_mixhi_f16 pairs into one register (counted as 2)",
+    "hi/lo split with mixlo/mixhi, TWO chains interleaved: 2 cvt_pkrtz, 2 mixlo, 2 mixhi (N/6 double splits, counted as 6)", "hi/lo split with mixlo/mixhi, ONE chain: cvt_pkrtz, mixlo, mixhi (counted as 3)"};
 
 static float* g_out; static unsigned long long* g_ticks;
 template <int KIND, int E>
@@ -65,6 +66,24 @@ __device__ __forceinline__ void filler(float (&x)[8], unsigned (&u)[8], u4v (&q)
         if constexpr (E % 8 == 5) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(x[3]) : "v"(u[2]), "v"(s), "v"(x[7]));
         if constexpr (E % 8 == 6) { if constexpr (KIND == SPLIT2) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[1]) : "v"(x[0]), "v"(x[1])); else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u[1]) : "v"(x[0]), "v"(x[1])); }
         if constexpr (E % 8 == 7) { if constexpr (KIND == SPLIT2) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[3]) : "v"(x[2]), "v"(x[3])); else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u[3]) : "v"(x[2]), "v"(x[3])); }
+    }
+    if constexpr (KIND == MIXLO) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(u[i]) : "v"(u[j]), "v"(x[i]));
+    if constexpr (KIND == MIXLOHI) {
+        if constexpr (E % 2 == 0) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(u[i]) : "v"(u[j]), "v"(x[i]));
+        else asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(u[(E - 1) % 8]) : "v"(u[(E + 2) % 8]), "v"(x[i]));
+    }
+    if constexpr (KIND == SPLIT3) {
+        if constexpr (E % 6 == 0) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[0]) : "v"(x[4]), "v"(x[5]));
+        if constexpr (E % 6 == 1) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[2]) : "v"(x[6]), "v"(x[7]));
+        if constexpr (E % 6 == 2) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(u[1]) : "v"(u[0]), "v"(x[4]));
+        if constexpr (E % 6 == 3) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(u[3]) : "v"(u[2]), "v"(x[6]));
+        if constexpr (E % 6 == 4) asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(u[1]) : "v"(u[0]), "v"(x[5]));
+        if constexpr (E % 6 == 5) asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(u[3]) : "v"(u[2]), "v"(x[7]));
+    }
+    if constexpr (KIND == SPLIT3_ONE) {
+        if constexpr (E % 3 == 0) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[0]) : "v"(x[4]), "v"(x[5]));
+        if constexpr (E % 3 == 1) asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "+v"(u[1]) : "v"(u[0]), "v"(x[4]));
+        if constexpr (E % 3 == 2) asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(u[1]) : "v"(u[0]), "v"(x[5]));
     }
     if constexpr (KIND == FMA_DIST2) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[E % 2]) : "v"(s));
     if constexpr (KIND == PERM) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(u[i]) : "v"(u[j]), "v"(u[(E + 1) % 8]), "v"(u[(E + 5) % 8]));
@@ -206,9 +225,13 @@ void kind(int iters) {
            kNames[KIND], c0, c2, c4, c6, c8, c12, c16, (c16 - c8) / 8);
     fflush(stdout);
 }
-int main() {
+int main(int argc, char** argv) {
     (void)hipMalloc(&g_out, 4096); (void)hipMalloc(&g_ticks, 1024 * 8);
     const int it = 4000;
+    if (argc > 1) {   // round 5: the lo halves straight from v_fma_mixlo_f16 / v_fma_mixhi_f16 (three instructions per pair instead of four)
+        kind<CVT_PKRTZ>(it); kind<FMA_MIX>(it); kind<MIXLO>(it); kind<MIXLOHI>(it); kind<SPLIT1>(it); kind<SPLIT3_ONE>(it); kind<SPLIT2>(it); kind<SPLIT3>(it);
+        return 0;
+    }
     kind<FMA>(it); kind<FMA_DEP>(it); kind<PAIR_DEP>(it); kind<MAX>(it); kind<MOV>(it); kind<PK_FMA>(it); kind<CVT_PKRTZ>(it); kind<FMA_MIX>(it); kind<MIX_CVT>(it); kind<PK_MAX>(it);
     kind<ACC_READ>(it); kind<ACC_READ_DEP>(it); kind<SIN>(it); kind<EXP>(it); kind<FRACT>(it); kind<DS_READ128>(it); kind<DS_READ64>(it); kind<NOP0>(it); kind<NOP1>(it);
     kind<CVT_PK_RNE>(it); kind<CVT_F16>(it); kind<SPLIT1>(it); kind<SPLIT2>(it); kind<SPLIT2_RNE>(it); kind<FMA_DIST2>(it); kind<PERM>(it); kind<PK_MUL>(it); kind<ACC_READ_SPACED>(it);
