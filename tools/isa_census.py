@@ -48,6 +48,27 @@ def main():
                 if t in labels and labels[t] < i and i - labels[t] > best[0]:
                     best = (i - labels[t], labels[t], i + 1)
         a, b = best[1], best[2]
+    if "--blocks" in sys.argv:      # basic blocks of the range: size, classes, closing branch
+        blocks, cur, nm = [], [], "entry"
+        for l in L[a:b]:
+            if re.match(r"^\.LBB\d+_\d+:", l):
+                if cur:
+                    blocks.append((nm, cur))
+                nm, cur = l.split(":")[0], []
+                continue
+            if not l or l.startswith((".", ";", "//")):
+                continue
+            cur.append(l)
+            if l.startswith(("s_cbranch", "s_branch")):
+                blocks.append((nm, cur))
+                nm, cur = nm + "'", []
+        if cur:
+            blocks.append((nm, cur))
+        for nm, ins in blocks:
+            c = collections.Counter(klass(x.split()[0]) for x in ins)
+            br = ins[-1] if ins and ins[-1].startswith(("s_cbranch", "s_branch")) else ""
+            print(f"{nm:14s} {len(ins):4d}  valu {c['valu'] + c['valu-slow'] + c['valu-trans']:4d} salu {c['salu']:3d} vmem {c['vmem']:2d} "
+                  f"lds {c['lds']:2d} mfma {c['mfma']:2d}  {br}")
     ins = [l for l in L[a:b] if l and not l.startswith((".", ";", "//")) and not re.match(r"^\S+:", l)]
     by_class, by_m = collections.Counter(), collections.Counter()
     for l in ins:
