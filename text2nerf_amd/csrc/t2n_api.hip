@@ -816,13 +816,15 @@ retry_worst_case:
 }
 
 // Workspace for one budgeted launch of a frame, from what the field's last such launch needed: twice the entries per ray it
-// used + 16, at least kBudgetMin; a quarter of the samples when nothing is known yet. Never more than the worst case.
+// used + 16, at least kBudgetMin; 32 entries per ray when nothing is known yet. Never more than the worst case.
 extern "C" size_t t2n_render_workspace_bytes_hint(const t2n_field* f, int64_t n_rays, int n_samples) {
     if (!f || n_rays <= 0 || n_samples <= 0) return 0;
     counts_poll(const_cast<t2n_field*>(f), false);
     const size_t worst = carve(n_rays, n_samples).total;
     if (n_rays < kBudgetMinRays) return worst;
-    unsigned b = f->list_hint ? 2u * f->list_hint + 16u : (unsigned)(n_samples / 4 > 64 ? n_samples / 4 : 64);
+    // nothing known yet: 32 entries per ray (the driver's scenes need ~7; a scene that needs more has its surplus rays finished on the
+    // device by k_finish_rays for the frame or two until the counters of the first launches have landed)
+    unsigned b = f->list_hint ? 2u * f->list_hint + 16u : 32u;
     if (b < kBudgetMin) b = kBudgetMin;
     if (b >= (unsigned)n_samples) return worst;
     const size_t want = carve_workspace(n_rays, n_samples, true, true, b).total;

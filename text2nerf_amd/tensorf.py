@@ -39,15 +39,45 @@ def _ws_key(device):
     return (str(device), int(torch.cuda.current_stream(device).cuda_stream))
 
 
+_WS_IDLE = {}            # (device, stream) -> consecutive requests that used less than a quarter of the buffer
+_WS_SHRINK_AFTER = 64    # ... after which the buffer is given back (a training run whose appearance lists tripled once and shrank again)
+
+
 def workspace(device, nbytes: int) -> torch.Tensor:
-    """Grow-only scratch buffer handed to the C-ABI calls, one per (device, stream): calls queued on one stream execute in order
-    and may share it (every call is done with it when it returns control to the stream); fields driven on DIFFERENT streams get
-    different buffers, so a render on one stream never aliases the backward scratch of another."""
+    """Scratch buffer handed to the C-ABI calls, one per (device, stream): calls queued on one stream execute in order and may
+    share it (every call is done with it when it returns control to the stream); fields driven on DIFFERENT streams get different
+    buffers, so a render on one stream never aliases the backward scratch of another. It grows when a call needs more and is given
+    back when _WS_SHRINK_AFTER consecutive requests used less than a quarter of it. Either way the old buffer is dropped BEFORE the
+    new one is allocated and torch's cached blocks go back to the driver: a buffer that grew in steps would otherwise leave every
+    earlier size reserved in the caching allocator (54 GiB reserved for 9.5 GiB in use, profiles/round4_train_soak.txt)."""
     key = _ws_key(device)
     buf = _WORKSPACE.get(key)
-    if buf is None or buf.numel() < nbytes:
-        _WORKSPACE[key] = buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    nbytes = int(nbytes)
+    if buf is not None and buf.numel() >= nbytes:
+        if nbytes * 4 < buf.numel() and buf.numel() > (256 << 20):
+            _WS_IDLE[key] = _WS_IDLE.get(key, 0) + 1
+            if _WS_IDLE[key] < _WS_SHRINK_AFTER:
+                return buf
+        else:
+            _WS_IDLE[key] = 0
+            return buf
+    _WS_IDLE[key] = 0
+    had = buf is not None
+    _WORKSPACE.pop(key, None)
+    del buf
+    if had and torch.device(device).type == "cuda":
+        torch.cuda.empty_cache()      # (rare: sizes move geometrically)
+    _WORKSPACE[key] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
     return buf
+
+
+def _ladder(n: int, step: float = 1.25, floor: int = 1024) -> int:
+    """n rounded up to the next rung of a geometric ladder: sizes derived from running counts change rarely, and a caching allocator
+    sees the same few block sizes again and again."""
+    v = floor
+    while v < n:
+        v = int(v * step) + 1
+    return v
 
 
 def release_workspaces(device=None, keep_current=True) -> int:
@@ -1031,7 +1061,7 @@ class TensorBase(nn.Module):
             z = z[:1]          # sample_ray_ndc returns ONE [1,N] depth row (models/tensorBase.py:296-302)
         return rgb, depth, z, w
 
-    def _render_raw(self, rays, N, flags, jitter, want_wz, keep_ctx=False, frame_width=None):
+    def _render_raw(self, rays, N, flags, jitter, want_wz, keep_ctx=False, frame_width=None, reuse_ctx=False):
         lib = _lib.load()
         h = self.sync_params(frame_width=frame_width)
         dev = rays.device
@@ -1047,8 +1077,21 @@ class TensorBase(nn.Module):
             # row count: the forward then keeps them and the backward skips its appearance recompute (too small a guess
             # only costs that recompute)
             rows_hint = int(getattr(self, "_ctx_rows_hint", 0))
-            ws = torch.empty(int(lib.t2n_render_workspace_bytes_ctx(R, N)) + (256 + rows_hint * 1728 if rows_hint else 0),
-                             dtype=torch.uint8, device=dev)
+            rows_hint = _ladder(rows_hint) // 32 * 32 if rows_hint else 0     # (a few distinct sizes over a run: the allocator reuses its blocks)
+            need = int(lib.t2n_render_workspace_bytes_ctx(R, N)) + (256 + rows_hint * 1728 if rows_hint else 0)
+            if reuse_ctx:
+                # train_step: the step's backward is queued before the next step's forward, so ONE retained buffer serves every step
+                # (stream order); it grows like workspace() does — old buffer dropped first, cached blocks returned to the driver
+                ws = getattr(self, "_ctx_buf", None)
+                if ws is None or ws.numel() < need or ws.device != dev:
+                    had = ws is not None
+                    self._ctx_buf = ws = None
+                    if had:
+                        torch.cuda.empty_cache()
+                    self._ctx_buf = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                ws = ws[:need]
+            else:
+                ws = torch.empty(need, dtype=torch.uint8, device=dev)
             flags |= FLAG_KEEP_CTX
         else:
             need = int(lib.t2n_render_workspace_bytes(max(R, 1), N))
@@ -1111,7 +1154,7 @@ class TensorBase(nn.Module):
             self._ctx_rows_hint = (int(rows.value * 1.25) + 95) // 32 * 32 if self.keep_activation_rows else 0
             need = int(lib.t2n_backward_workspace_bytes(self._handle, rows.value, R, N))
             have = _WORKSPACE.get(_ws_key(dev))
-            bws = workspace(dev, need) if have is not None and have.numel() >= need else workspace(dev, int(need * 1.5))
+            bws = workspace(dev, need) if have is not None and have.numel() >= need else workspace(dev, int(need * 1.25))
             _lib.check(lib.t2n_render_backward(self._handle, _lib.ptr(rays), R, rays.shape[1], N, flags | FLAG_KEEP_CTX,
                                                _lib.ptr(jitter), _lib.ptr(d_rgb), _lib.ptr(d_depth), _lib.ptr(d_w),
                                                C.byref(gs), _lib.ptr(ws), ws.numel(), _lib.ptr(bws), bws.numel(),
@@ -1156,7 +1199,7 @@ class TensorBase(nn.Module):
         if getattr(self, "_head_flat", None) is None or self._head_flat.numel() != sum(p.numel() for p in head):
             self._head_flat = torch.zeros(sum(p.numel() for p in head), device=dev)
         with torch.no_grad():
-            rgb, depth, z, w, ws = self._render_raw(rays, N, flags, jitter, True, keep_ctx=True)
+            rgb, depth, z, w, ws = self._render_raw(rays, N, flags, jitter, True, keep_ctx=True, reuse_ctx=True)
             d_rgb, d_depth, d_w = torch.empty_like(rgb), torch.empty_like(depth), torch.empty_like(w)
             losses = torch.empty(4, device=dev)
             lws = torch.empty(int(lib.t2n_train_loss_workspace_bytes(R)), dtype=torch.uint8, device=dev)
