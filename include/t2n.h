@@ -114,8 +114,9 @@ enum { T2N_STAT_EVALUATED = 0,   /* V: in-box (and z-gated) samples that read th
        T2N_STAT_OVERFLOW = 3,    /* must stay 0 */
        T2N_STAT_F16_REDO = 4,    /* sub-launches whose split-f16 appearance stage met a value outside the f16 range and were
                                     redone on the exact fp32 path (results are the exact path's) */
-       T2N_STAT_LIST_RETRY = 5,  /* 1: the call's budgeted appearance lists overflowed and the whole call was rendered again with
-                                    worst-case lists (results are the worst-case path's) */
+       T2N_STAT_LIST_RETRY = 5,  /* 1: some rays of the call found no room in its budgeted appearance lists and were shaded and
+                                    composited by the per-ray finisher (k_finish_rays: exact-fp32 head, no list memory); with the
+                                    general view-dependent heads: the whole call was rendered again with worst-case lists */
        T2N_STAT_COUNT = 8 };
 
 const char* t2n_last_error(void);
@@ -209,15 +210,17 @@ int t2n_raw2alpha(const float* sigma, const float* dist, int64_t n_rays, int n_s
  *             t2n_render_workspace_bytes sizes the appearance lists for the worst case (every sample of every ray an appearance
  *             sample: 16 GiB for an 800x800 x 518 frame that uses ~0.2 GB of it). An image-ordered eval frame (T2N_FLAG_COHERENT
  *             with t2n_field_set_frame_width) of >= 65536 rays given LESS than that runs as ONE launch with lists budgeted to
- *             what the workspace holds; the call waits for the march kernels' counters (pinned host copy + event, the shading
- *             kernels already queued) and, should the lists have overflowed, renders the whole call again in worst-case
- *             sub-launches (stats[T2N_STAT_LIST_RETRY] = 1, same results). t2n_render_workspace_bytes_hint returns a workspace
- *             size for that mode from what the field's previous budgeted launch needed (~4.7 GB for the frame above).
+ *             what the workspace holds. The call never waits for the device: rays whose entries find no room are finished on the
+ *             device (stats[T2N_STAT_LIST_RETRY] = 1; their colours come from the exact-fp32 head, within ~1e-6 of the split-f16
+ *             one; depth and every other ray are unaffected); the sub-list counters travel to pinned host memory behind an event
+ *             and a LATER call (or t2n_render_workspace_bytes_hint / t2n_field_list_retries) turns them into the next budget.
+ *             t2n_render_workspace_bytes_hint returns a workspace size for that mode: lists for 32 entries per ray while nothing is
+ *             known, then twice what the field's last completed budgeted launch needed + 16 (~4.3 GB for the frame above).
  */
 size_t t2n_render_workspace_bytes(int64_t rays_per_launch, int n_samples);
 size_t t2n_render_workspace_bytes_hint(const t2n_field* f, int64_t n_rays, int n_samples);
 size_t t2n_render_workspace_bytes_budget(int64_t n_rays, int n_samples, int entries_per_ray);   /* one launch, lists for this many entries per ray */
-uint64_t t2n_field_list_retries(const t2n_field* f);   /* calls redone with worst-case lists since the field was created */
+uint64_t t2n_field_list_retries(const t2n_field* f);   /* budgeted calls that overflowed their lists since the field was created (waits for counters still in flight) */
 int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
                        const float* jitter, float* rgb, float* depth, float* weights, float* z_vals, uint64_t* stats,
                        void* workspace, size_t workspace_bytes, t2n_stream stream);
