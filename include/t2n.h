@@ -225,6 +225,29 @@ int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_rays, int ray_
                        const float* jitter, float* rgb, float* depth, float* weights, float* z_vals, uint64_t* stats,
                        void* workspace, size_t workspace_bytes, t2n_stream stream);
 
+/* ---- general-shape path (csrc/t2n_generic.hip): field / head shapes beyond the tuned kernels' — more than 16 density or 48 appearance
+ * components per plane (different counts per plane allowed), app_dim up to 64, any fea_pe / view_pe up to 16, featureC up to 256 — the
+ * shapes the reference accepts through n_lamb_sigma / n_lamb_sh / data_dim_color / fea_pe / featureC (models/tensoRF.py:144-160,
+ * models/tensorBase.py:62-159, e_opt.py:83-107). No field handle: the parameters are read in place in the reference's layouts and the
+ * gradients are ACCUMULATED (atomics) into tensors of the same layouts. One thread per ray / per appearance sample, no MFMA: a slow
+ * path. Heads: MLP_Fea_noview, MLP_Fea, MLP, SH, RGB. No NDC sampling, no AlphaGridMask. `weights` / `z_vals` may be NULL in the forward
+ * (kept in the workspace then); the backward takes the forward's workspace (and the same weights / z_vals pointers) unchanged. */
+typedef struct t2n_generic_desc {
+    float aabb_min[3], aabb_max[3], inv_aabb_size[3];
+    int32_t grid[3];
+    int32_t density_n_comp[3], app_n_comp[3];
+    int32_t app_dim, shading, fea_pe, view_pe, feature_c, act;
+    float density_shift, distance_scale, weight_thres, step_size, near, far, z_gate;
+} t2n_generic_desc;
+size_t t2n_generic_workspace_bytes(int64_t n_rays, int n_samples);
+int t2n_generic_forward(const t2n_generic_desc* desc, const t2n_field_params* params, const float* rays, int64_t n_rays, int ray_stride,
+                        int n_samples, uint32_t flags, const float* jitter, float* rgb, float* depth, float* weights, float* z_vals,
+                        uint64_t* stats, void* workspace, size_t workspace_bytes, t2n_stream stream);
+int t2n_generic_backward(const t2n_generic_desc* desc, const t2n_field_params* params, const float* rays, int64_t n_rays, int ray_stride,
+                         int n_samples, uint32_t flags, const float* jitter, const float* weights, const float* z_vals,
+                         const float* d_rgb, const float* d_depth, const float* d_weights, const t2n_field_grads* grads,
+                         void* workspace, size_t workspace_bytes, t2n_stream stream);
+
 /* ndc_rays_blender (blender = 1) / ndc_rays (0) (dataLoader/ray_utils.py:88-124): [n,3] origins + directions -> NDC. */
 int t2n_ndc_rays(int H, int W, float focal, float near, int blender, const float* rays_o, const float* rays_d, int64_t n,
                  float* o_out, float* d_out, t2n_stream stream);

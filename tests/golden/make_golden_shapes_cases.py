@@ -19,4 +19,13 @@ SHAPES = {
                  view_pe=6, pos_pe=6),
     "sh": dict(density_n_comp=[4, 4, 4], appearance_n_comp=[12, 12, 12], app_dim=27, shadingMode="SH", fea_pe=6, featureC=128,
                view_pe=6, pos_pe=6),
+    # LARGER than the tuned kernels hold (round 5: the general-shape path, csrc/t2n_generic.hip): twice the components (different per
+    # plane), 256 hidden units; a view-dependent head with 40 features and 192 units; the SH head on 72 components
+    "wide": dict(density_n_comp=[32, 20, 24], appearance_n_comp=[96, 64, 72], app_dim=27, shadingMode="MLP_Fea_noview", fea_pe=6,
+                 featureC=256, view_pe=6, pos_pe=6),
+    "wide_fea": dict(density_n_comp=[24, 24, 24], appearance_n_comp=[64, 64, 64], app_dim=40, shadingMode="MLP_Fea", fea_pe=3,
+                     featureC=192, view_pe=2, pos_pe=6),
+    "wide_sh": dict(density_n_comp=[40, 8, 8], appearance_n_comp=[72, 72, 72], app_dim=27, shadingMode="SH", fea_pe=6, featureC=128,
+                    view_pe=6, pos_pe=6),
 }
+WIDE = ("wide", "wide_fea", "wide_sh")    # shapes of the general-shape path (no embedding onto the tuned kernels)

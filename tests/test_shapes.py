@@ -17,7 +17,7 @@ from tests.conftest import GOLDEN, TINY
 from text2nerf_amd import synth
 
 sys.path.insert(0, GOLDEN)
-from make_golden_shapes_cases import SHAPES  # noqa: E402
+from make_golden_shapes_cases import SHAPES, WIDE  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -64,6 +64,10 @@ def test_embedding_is_exact_on_the_oracle(tiny, gs, tag):
     tensors equals the oracle on the real ones, and gradients taken through the embedding equal the reference's autograd goldens."""
     kw = SHAPES[tag]
     m = _field(kw, "cpu", gs[f"{tag}_seed"])
+    if tag in WIDE:      # larger than the tuned kernels: no embedding, the general-shape path (GPU test below)
+        assert m._is_general() and not m._needs_embed() and not m.supports_deferred_factor_grads()
+        return
+    assert not m._is_general()
     if tag in ("rgb", "sh16"):
         assert not m._needs_embed()
         return
@@ -98,18 +102,26 @@ def test_embedding_is_exact_on_the_oracle(tiny, gs, tag):
     assert m._embedded_params()[12] is not emb[12]                              # a parameter changed: rebuilt
 
 
-def test_shapes_beyond_the_kernels_are_rejected_on_construction():
-    from text2nerf_amd import TensorVMSplit
+def test_shapes_beyond_the_kernels_take_the_general_path_and_its_limits_fail_on_construction():
+    """Round 5: more components / a wider head than the tuned kernels hold construct (general-shape path, csrc/t2n_generic.hip); what
+    even that path does not hold, and the stage entry points of a field without a native handle, fail loudly."""
+    from text2nerf_amd import TensorCP, TensorVMSplit
     from text2nerf_amd._lib import T2NError
     aabb = torch.tensor([[-1.0] * 3, [1.0] * 3])
+    base = dict(density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, shadingMode="MLP_Fea_noview", fea_pe=6, step_ratio=1.0)
     for kw in (dict(density_n_comp=[32, 16, 16]), dict(appearance_n_comp=[48, 48, 96]), dict(featureC=256), dict(fea_pe=7), dict(app_dim=28)):
-        base = dict(density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, shadingMode="MLP_Fea_noview", fea_pe=6, step_ratio=1.0)
-        base.update(kw)
+        m = TensorVMSplit(aabb, [8, 8, 8], "cpu", **dict(base, **kw))
+        assert m._is_general() and not m._needs_embed()
         with pytest.raises(T2NError):
-            TensorVMSplit(aabb, [8, 8, 8], "cpu", **base)
+            m._kernel_shape()                      # no native field: no stage entry points, mask operators, train_step
+    for kw in (dict(featureC=512), dict(app_dim=65), dict(fea_pe=17)):
+        with pytest.raises(T2NError):
+            TensorVMSplit(aabb, [8, 8, 8], "cpu", **dict(base, **kw))
+    with pytest.raises(T2NError):
+        TensorCP(aabb, [8, 8, 8], "cpu", density_n_comp=[32] * 3, appearance_n_comp=[48] * 3, shadingMode="MLP_Fea_noview", fea_pe=6)
     ok = TensorVMSplit(aabb, [8, 8, 8], "cpu", density_n_comp=[16, 4, 4], appearance_n_comp=[48, 12, 12], shadingMode="MLP_Fea_noview",
                        fea_pe=2, featureC=64, app_dim=12, step_ratio=1.0)
-    assert ok._needs_embed() and not ok.supports_deferred_factor_grads()
+    assert ok._needs_embed() and not ok._is_general() and not ok.supports_deferred_factor_grads()
 
 
 @pytest.mark.gpu

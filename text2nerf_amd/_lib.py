@@ -41,6 +41,14 @@ class FieldParams(C.Structure):
 
 FieldGrads = FieldParams  # same shape: pointers in reference layouts
 
+
+class GenericDesc(C.Structure):   # t2n_generic_desc: the general-shape path (csrc/t2n_generic.hip)
+    _fields_ = [("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3), ("inv_aabb_size", C.c_float * 3), ("grid", C.c_int32 * 3),
+                ("density_n_comp", C.c_int32 * 3), ("app_n_comp", C.c_int32 * 3), ("app_dim", C.c_int32), ("shading", C.c_int32),
+                ("fea_pe", C.c_int32), ("view_pe", C.c_int32), ("feature_c", C.c_int32), ("act", C.c_int32),
+                ("density_shift", C.c_float), ("distance_scale", C.c_float), ("weight_thres", C.c_float), ("step_size", C.c_float),
+                ("near", C.c_float), ("far", C.c_float), ("z_gate", C.c_float)]
+
 _lib = None
 _lock = threading.Lock()
 
@@ -129,6 +137,13 @@ SIGNATURES = {
     "t2n_alpha_volume": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2n_upsample_bilinear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "t2n_filter_rays_alpha": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "t2n_generic_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "t2n_generic_forward": (C.c_int, [C.POINTER(GenericDesc), C.POINTER(FieldParams), C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_void_p]),
+    "t2n_generic_backward": (C.c_int, [C.POINTER(GenericDesc), C.POINTER(FieldParams), C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FieldGrads),
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "t2n_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "t2n_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
 }

@@ -1,0 +1,457 @@
+// General-shape render path: field / head shapes beyond what the tuned kernels hold (more than 16 density or 48 appearance
+// components per plane, app_dim > 27 / fea_pe > 6 / featureC > 128 on the MLP heads). The reference is generic in all of them
+// (models/tensoRF.py:144-160, models/tensorBase.py:62-159, e_opt.py:83-107); here they run as a plain restatement — one thread per
+// ray for the march, one thread per appearance sample for the head, loops over the component / unit counts, parameters read in place
+// in the reference's own layouts ([1,C,H,W] planes, [1,C,L,1] lines), gradients accumulated with atomics into those layouts. No MFMA,
+// no LDS staging: a path that removes the shape limit, not a fast one (the driver's configuration never comes here).
+//
+// Replaces: models/tensorBase.py:304-323 (sample_ray), :436-507 (forward), :19-26 (raw2alpha), :406-410 (feature2density), :11-17 +
+// :62-159 (the heads), :29-39 (SH / RGB), models/tensoRF.py:205-239 (compute_densityfeature / compute_appfeature), and their autograd.
+#include "t2n_device.h"
+
+namespace t2n {
+
+constexpr int kGenDimMax = 64, kGenHidMax = 256, kGenInMax = 4096;
+
+struct GenArgs {
+    FieldDev F;                       // scalars only (aabb, step, thresholds, activation); the factor sets of F are unused here
+    int grid[3], Cd[3], Ca[3], app_dim, shading, fea_pe, view_pe, fC, in0;
+    const float* dp[3]; const float* dl[3]; const float* ap[3]; const float* al[3];
+    const float* basis; const float* w0; const float* b0; const float* w1; const float* b1; const float* w2; const float* b2;
+    float* g_dp[3]; float* g_dl[3]; float* g_ap[3]; float* g_al[3];
+    float* g_basis; float* g_w0; float* g_b0; float* g_w1; float* g_b1; float* g_w2; float* g_b2;
+    const float* rays; long long n_rays; int ray_stride; int N; int train; int add_bg;
+    const float* jitter;
+    float* rgb; float* depth;         // outputs
+    float* w; float* z;               // [R, N] rows (the caller's tensors or workspace)
+    float* sigma; float* T;           // [R, N] context: density and transmittance in front of every sample
+    float* rgb_s;                     // [R, N, 3] colours of the appearance samples (context)
+    float* acc; float* raw;           // [R] opacity, [R, 3] colour before the clamp
+    const float* d_rgb; const float* d_depth; const float* d_w;   // upstream gradients
+    float* go;                        // [R, N, 3] dL/d colour of the appearance samples (backward scratch)
+    unsigned long long* stats;
+};
+
+struct Tap3 { Axis a[3]; };
+__device__ __forceinline__ Tap3 gen_taps(const GenArgs& a, float xn, float yn, float zn) {
+    Tap3 t;
+    t.a[0] = axis_taps(xn, a.grid[0]); t.a[1] = axis_taps(yn, a.grid[1]); t.a[2] = axis_taps(zn, a.grid[2]);
+    return t;
+}
+// plane k of a factor set in the reference layout: value(c, y, x) = P[(c * H + y) * W + x], H = grid[mat1(k)], W = grid[mat0(k)]
+__device__ __forceinline__ float gen_plane(const float* __restrict__ P, int c, int H, int W, const Axis& ax, const Axis& ay) {
+    const float* __restrict__ p = P + (size_t)c * H * W;
+    float v = p[(size_t)ay.i0 * W + ax.i0] * (ay.w0 * ax.w0);
+    v = fmaf(p[(size_t)ay.i0 * W + ax.i1], ay.w0 * ax.w1, v);
+    v = fmaf(p[(size_t)ay.i1 * W + ax.i0], ay.w1 * ax.w0, v);
+    v = fmaf(p[(size_t)ay.i1 * W + ax.i1], ay.w1 * ax.w1, v);
+    return v;
+}
+__device__ __forceinline__ float gen_line(const float* __restrict__ Ln, int c, int Lsz, const Axis& al) {
+    const float* __restrict__ p = Ln + (size_t)c * Lsz;
+    return fmaf(p[al.i1], al.w1, p[al.i0] * al.w0);
+}
+__device__ __forceinline__ void gen_plane_add(float* __restrict__ G, int c, int H, int W, const Axis& ax, const Axis& ay, float g) {
+    float* __restrict__ p = G + (size_t)c * H * W;
+    atomicAdd(p + (size_t)ay.i0 * W + ax.i0, g * (ay.w0 * ax.w0));
+    atomicAdd(p + (size_t)ay.i0 * W + ax.i1, g * (ay.w0 * ax.w1));
+    atomicAdd(p + (size_t)ay.i1 * W + ax.i0, g * (ay.w1 * ax.w0));
+    atomicAdd(p + (size_t)ay.i1 * W + ax.i1, g * (ay.w1 * ax.w1));
+}
+__device__ __forceinline__ void gen_line_add(float* __restrict__ G, int c, int Lsz, const Axis& al, float g) {
+    float* __restrict__ p = G + (size_t)c * Lsz;
+    atomicAdd(p + al.i0, g * al.w0);
+    atomicAdd(p + al.i1, g * al.w1);
+}
+
+__device__ __forceinline__ float gen_density_feature(const GenArgs& a, const Tap3& t) {
+    float feat = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        const int W = a.grid[mat0(k)], H = a.grid[mat1(k)], Lz = a.grid[vecm(k)];
+        const Axis& ax = t.a[mat0(k)]; const Axis& ay = t.a[mat1(k)]; const Axis& al = t.a[vecm(k)];
+        for (int c = 0; c < a.Cd[k]; ++c) feat = fmaf(gen_plane(a.dp[k], c, H, W, ax, ay), gen_line(a.dl[k], c, Lz, al), feat);
+    }
+    return feat;
+}
+
+__device__ __forceinline__ bool gen_point(const GenArgs& a, const Ray& ray, float z, float& xn, float& yn, float& zn) {
+    return a.train ? sample_point<true>(a.F, ray, z, xn, yn, zn) : sample_point<false>(a.F, ray, z, xn, yn, zn);
+}
+__device__ __forceinline__ float gen_z(const GenArgs& a, const Ray& ray, int i, float u) {
+    return a.train ? sample_z<true, true>(a.F, ray, i, u) : sample_z<false, true>(a.F, ray, i, 0.f);
+}
+
+// ---- march: one thread per ray --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_gen_march(const GenArgs a) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_rays) return;
+    const Ray ray = load_ray(a.F, a.rays + r * a.ray_stride, a.ray_stride);
+    const float u = a.train ? a.jitter[r] : 0.f;
+    const int N = a.N;
+    float T = 1.f, acc = 0.f, dep = 0.f;
+    unsigned long long nev = 0, napp = 0;
+    for (int i = 0; i < N; ++i) {
+        const float z = gen_z(a, ray, i, u);
+        float xn, yn, zn;
+        const bool ok = gen_point(a, ray, z, xn, yn, zn);
+        float sg = 0.f;
+        if (ok) { sg = feature2density(a.F, gen_density_feature(a, gen_taps(a, xn, yn, zn))); ++nev; }
+        const float dist = i < N - 1 ? gen_z(a, ray, i + 1, u) - z : 0.f;                 // :448
+        const float alpha = 1.f - expf((-sg) * (dist * a.F.dscale));                      // :19-26
+        const float w = alpha * T;
+        a.z[r * N + i] = z; a.sigma[r * N + i] = sg; a.T[r * N + i] = T; a.w[r * N + i] = w;
+        T = T * ((1.f - alpha) + 1e-10f);
+        acc += w;
+        dep = fmaf(w, z, dep);
+        napp += (w > a.F.thres) ? 1u : 0u;
+    }
+    a.acc[r] = acc;
+    a.depth[r] = dep + (1.f - acc) * ray.last;                                             // :504-505
+    if (a.stats) { atomicAdd(&a.stats[T2N_STAT_EVALUATED], nev); atomicAdd(&a.stats[T2N_STAT_APPEARANCE], napp); }
+}
+
+// ---- head: one thread per appearance sample ---------------------------------------------------------------------------------------
+// X[col] = plane x line of appearance component col (planes concatenated: models/tensoRF.py:223-239), feat = basis_mat X
+__device__ __forceinline__ void gen_features(const GenArgs& a, const Tap3& t, float* __restrict__ feat) {
+    for (int f = 0; f < a.app_dim; ++f) feat[f] = 0.f;
+    int col = 0;
+    const int ncol = a.Ca[0] + a.Ca[1] + a.Ca[2];
+    for (int k = 0; k < 3; ++k) {
+        const int W = a.grid[mat0(k)], H = a.grid[mat1(k)], Lz = a.grid[vecm(k)];
+        const Axis& ax = t.a[mat0(k)]; const Axis& ay = t.a[mat1(k)]; const Axis& al = t.a[vecm(k)];
+        for (int c = 0; c < a.Ca[k]; ++c, ++col) {
+            const float x = gen_plane(a.ap[k], c, H, W, ax, ay) * gen_line(a.al[k], c, Lz, al);
+            for (int f = 0; f < a.app_dim; ++f) feat[f] = fmaf(a.basis[(size_t)f * ncol + col], x, feat[f]);
+        }
+    }
+}
+// The MLP heads' input row in the reference's column order (models/tensorBase.py:11-17, :75-84, :101-107, :148-155), enumerated
+// instead of stored (a 1 024-float row per thread would be scratch memory): fn(j, x_j, f, d) with f >= 0 for a column that depends on
+// feature f (d = its derivative with respect to that feature), f = -1 for the view-direction columns.
+template <class FN>
+__device__ __forceinline__ int gen_inputs(const GenArgs& a, const float* __restrict__ feat, const float* __restrict__ dir, FN&& fn) {
+    int n = 0;
+    const bool view = a.shading != T2N_SHADE_MLP_FEA_NOVIEW;
+    for (int f = 0; f < a.app_dim; ++f) fn(n++, feat[f], f, 1.f);
+    if (view) for (int d = 0; d < 3; ++d) fn(n++, dir[d], -1, 0.f);
+    const int fpe = a.shading == T2N_SHADE_MLP ? 0 : a.fea_pe;
+    if (fpe > 0) {
+        for (int f = 0; f < a.app_dim; ++f) for (int o = 0; o < fpe; ++o) { const float sc = (float)(1 << o), t = feat[f] * sc; fn(n++, sinf(t), f, cosf(t) * sc); }
+        for (int f = 0; f < a.app_dim; ++f) for (int o = 0; o < fpe; ++o) { const float sc = (float)(1 << o), t = feat[f] * sc; fn(n++, cosf(t), f, -sinf(t) * sc); }
+    }
+    if (view && a.view_pe > 0) {
+        for (int d = 0; d < 3; ++d) for (int o = 0; o < a.view_pe; ++o) fn(n++, sinf(dir[d] * (float)(1 << o)), -1, 0.f);
+        for (int d = 0; d < 3; ++d) for (int o = 0; o < a.view_pe; ++o) fn(n++, cosf(dir[d] * (float)(1 << o)), -1, 0.f);
+    }
+    return n;
+}
+__device__ __forceinline__ void gen_sh9(const float* dir, float* sh) {   // models/sh.py:4-14,87-112 (degree 2)
+    const float dx = dir[0], dy = dir[1], dz = dir[2];
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
+    sh[0] = C0; sh[1] = -C1 * dy; sh[2] = C1 * dz; sh[3] = -C1 * dx;
+    sh[4] = 1.0925484305920792f * xy; sh[5] = -1.0925484305920792f * yz; sh[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+    sh[7] = -1.0925484305920792f * xz; sh[8] = 0.5462742152960396f * (xx - yy);
+}
+// hidden layers: h = b + W x (row-major [out, in] like nn.Linear), pre-activation values kept (the backward needs the ReLU masks)
+__device__ __forceinline__ void gen_linear(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ x, int nin, int nout,
+                                           bool relu_in, float* __restrict__ h) {
+    for (int o = 0; o < nout; ++o) {
+        float s = b[o];
+        const float* __restrict__ wr = W + (size_t)o * nin;
+        for (int j = 0; j < nin; ++j) s = fmaf(wr[j], relu_in ? fmaxf(x[j], 0.f) : x[j], s);
+        h[o] = s;
+    }
+}
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(64) void k_gen_shade(const GenArgs a) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a.N;
+    if (t >= a.n_rays * N) return;
+    const float w = a.w[t];
+    if (!(w > a.F.thres)) return;                                                            // :477
+    const long long r = t / N;
+    const int i = (int)(t - r * N);
+    const float* __restrict__ rp = a.rays + r * a.ray_stride;
+    const Ray ray = load_ray(a.F, rp, a.ray_stride);
+    const float u = a.train ? a.jitter[r] : 0.f;
+    float xn, yn, zn;
+    gen_point(a, ray, gen_z(a, ray, i, u), xn, yn, zn);
+    const Tap3 tp = gen_taps(a, xn, yn, zn);
+    float feat[kGenDimMax];
+    gen_features(a, tp, feat);
+    const float dir[3] = {rp[3], rp[4], rp[5]};
+    float gfeat[kGenDimMax];
+    if (BACKWARD) for (int f = 0; f < a.app_dim; ++f) gfeat[f] = 0.f;
+    const float* __restrict__ go = BACKWARD ? a.go + t * 3 : nullptr;
+    if (a.shading == T2N_SHADE_RGB) {
+        if (!BACKWARD) { a.rgb_s[t * 3] = feat[0]; a.rgb_s[t * 3 + 1] = feat[1]; a.rgb_s[t * 3 + 2] = feat[2]; }
+        else { gfeat[0] = go[0]; gfeat[1] = go[1]; gfeat[2] = go[2]; }
+    } else if (a.shading == T2N_SHADE_SH) {
+        float sh[9];
+        gen_sh9(dir, sh);
+        for (int c = 0; c < 3; ++c) {
+            float s = 0.f;
+            for (int b = 0; b < 9; ++b) s = fmaf(sh[b], feat[c * 9 + b], s);
+            if (!BACKWARD) a.rgb_s[t * 3 + c] = fmaxf(s + 0.5f, 0.f);                        // :29-33
+            else if (s + 0.5f > 0.f) for (int b = 0; b < 9; ++b) gfeat[c * 9 + b] = go[c] * sh[b];
+        }
+    } else {
+        float h0[kGenHidMax], h1[kGenHidMax];
+        const int fC = a.fC, nin = a.in0;
+        for (int v = 0; v < fC; ++v) h0[v] = a.b0[v];
+        gen_inputs(a, feat, dir, [&](int j, float xj, int, float) {
+            for (int v = 0; v < fC; ++v) h0[v] = fmaf(a.w0[(size_t)v * nin + j], xj, h0[v]);
+        });
+        gen_linear(a.w1, a.b1, h0, fC, fC, true, h1);
+        float o[3];
+        gen_linear(a.w2, a.b2, h1, fC, 3, true, o);
+        float c3[3];
+        for (int c = 0; c < 3; ++c) c3[c] = 1.f / (1.f + expf(-o[c]));
+        if (!BACKWARD) { a.rgb_s[t * 3] = c3[0]; a.rgb_s[t * 3 + 1] = c3[1]; a.rgb_s[t * 3 + 2] = c3[2]; }
+        else {
+            float d2[3];
+            for (int c = 0; c < 3; ++c) d2[c] = go[c] * c3[c] * (1.f - c3[c]);
+            // layer 2: dW2, db2, d h1 (h1 is overwritten by its gradient, masked by its own sign)
+            for (int c = 0; c < 3; ++c) if (a.g_b2) atomicAdd(a.g_b2 + c, d2[c]);
+            for (int v = 0; v < fC; ++v) {
+                const float hv = fmaxf(h1[v], 0.f);
+                float g = 0.f;
+                for (int c = 0; c < 3; ++c) {
+                    if (a.g_w2 && hv != 0.f) atomicAdd(a.g_w2 + (size_t)c * fC + v, d2[c] * hv);
+                    g = fmaf(a.w2[(size_t)c * fC + v], d2[c], g);
+                }
+                h1[v] = h1[v] > 0.f ? g : 0.f;
+            }
+            // layer 1: dW1, db1, d h0
+            float g0[kGenHidMax];
+            for (int v = 0; v < fC; ++v) g0[v] = 0.f;
+            for (int uu = 0; uu < fC; ++uu) {
+                const float g = h1[uu];
+                if (g == 0.f) continue;
+                if (a.g_b1) atomicAdd(a.g_b1 + uu, g);
+                const float* __restrict__ wr = a.w1 + (size_t)uu * fC;
+                for (int v = 0; v < fC; ++v) {
+                    const float hv = fmaxf(h0[v], 0.f);
+                    if (a.g_w1 && hv != 0.f) atomicAdd(a.g_w1 + (size_t)uu * fC + v, g * hv);
+                    g0[v] = fmaf(wr[v], g, g0[v]);
+                }
+            }
+            for (int v = 0; v < fC; ++v) g0[v] = h0[v] > 0.f ? g0[v] : 0.f;
+            // layer 0: dW0, db0, and d features through the raw columns and the encoding's derivative (the view directions carry
+            // no gradient)
+            for (int v = 0; v < fC; ++v) if (a.g_b0 && g0[v] != 0.f) atomicAdd(a.g_b0 + v, g0[v]);
+            gen_inputs(a, feat, dir, [&](int j, float xj, int f, float dxdf) {
+                float g = 0.f;
+                for (int v = 0; v < fC; ++v) {
+                    const float gv = g0[v];
+                    if (gv == 0.f) continue;
+                    if (a.g_w0) atomicAdd(a.g_w0 + (size_t)v * nin + j, gv * xj);
+                    g = fmaf(a.w0[(size_t)v * nin + j], gv, g);
+                }
+                if (f >= 0) gfeat[f] = fmaf(g, dxdf, gfeat[f]);
+            });
+        }
+    }
+    if (BACKWARD) {
+        // basis_mat and the appearance factors: X[col] recomputed, dB[f][col] += gfeat[f] X[col], dX[col] = sum_f B[f][col] gfeat[f]
+        int col = 0;
+        const int ncol = a.Ca[0] + a.Ca[1] + a.Ca[2];
+        for (int k = 0; k < 3; ++k) {
+            const int W = a.grid[mat0(k)], H = a.grid[mat1(k)], Lz = a.grid[vecm(k)];
+            const Axis& ax = tp.a[mat0(k)]; const Axis& ay = tp.a[mat1(k)]; const Axis& al = tp.a[vecm(k)];
+            for (int c = 0; c < a.Ca[k]; ++c, ++col) {
+                const float pv = gen_plane(a.ap[k], c, H, W, ax, ay), lv = gen_line(a.al[k], c, Lz, al);
+                const float xv = pv * lv;
+                float gx = 0.f;
+                for (int f = 0; f < a.app_dim; ++f) {
+                    if (a.g_basis) atomicAdd(a.g_basis + (size_t)f * ncol + col, gfeat[f] * xv);
+                    gx = fmaf(a.basis[(size_t)f * ncol + col], gfeat[f], gx);
+                }
+                if (a.g_ap[k]) gen_plane_add(a.g_ap[k], c, H, W, ax, ay, gx * lv);
+                if (a.g_al[k]) gen_line_add(a.g_al[k], c, Lz, al, gx * pv);
+            }
+        }
+    }
+}
+
+// ---- composite: one thread per ray (models/tensorBase.py:494-501) ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gen_composite(const GenArgs a) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_rays) return;
+    const int N = a.N;
+    float c[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < N; ++i) {
+        const float w = a.w[r * N + i];
+        if (w > a.F.thres) for (int k = 0; k < 3; ++k) c[k] = fmaf(w, a.rgb_s[(r * N + i) * 3 + k], c[k]);
+    }
+    if (a.add_bg) { const float bg = 1.f - a.acc[r]; c[0] += bg; c[1] += bg; c[2] += bg; }
+    for (int k = 0; k < 3; ++k) { a.raw[r * 3 + k] = c[k]; a.rgb[r * 3 + k] = fminf(fmaxf(c[k], 0.f), 1.f); }
+}
+
+// ---- backward of composite + raw2alpha + the density factors: one thread per ray -------------------------------------------------
+__global__ __launch_bounds__(64) void k_gen_bwd_march(const GenArgs a) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_rays) return;
+    const int N = a.N;
+    const Ray ray = load_ray(a.F, a.rays + r * a.ray_stride, a.ray_stride);
+    float dc[3];
+    float dbg = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        const float raw = a.raw[r * 3 + k];
+        dc[k] = (raw > 0.f && raw < 1.f) ? a.d_rgb[r * 3 + k] : 0.f;          // clamp(0, 1): gradient inside the open interval
+        dbg += dc[k];
+    }
+    const float dd = a.d_depth[r];
+    // dL/dw_i of the direct terms; rgb_map += 1 - acc and depth_map += (1 - acc) * last put -dbg and -dd * last on every weight
+    const float common = (a.add_bg ? -dbg : 0.f) - dd * ray.last;
+    float S = 0.f;   // sum over j > i of G_j w_j
+    for (int i = N - 1; i >= 0; --i) {
+        const long long t = r * N + i;
+        const float w = a.w[t], z = a.z[t], sg = a.sigma[t], T = a.T[t];
+        float G = common + dd * z + (a.d_w ? a.d_w[t] : 0.f);
+        if (w > a.F.thres) {
+            for (int k = 0; k < 3; ++k) {
+                G = fmaf(dc[k], a.rgb_s[t * 3 + k], G);
+                a.go[t * 3 + k] = dc[k] * w;
+            }
+        }
+        const float dist = i < N - 1 ? a.z[t + 1] - z : 0.f;
+        const float sd = dist * a.F.dscale;
+        const float e = expf((-sg) * sd);                     // 1 - alpha
+        const float fct = e + 1e-10f;                          // T_{i+1} = T_i * fct (fct = (1 - alpha) + 1e-10, alpha = 1 - e)
+        const float dalpha = G * T - S / fct;
+        S = fmaf(G, w, S);
+        const float dsg = dalpha * sd * e;                     // d alpha / d sigma = dist * scale * exp(-sigma dist scale)
+        if (dsg == 0.f || (sg == 0.f && a.F.act == T2N_ACT_RELU)) continue;
+        float xn, yn, zn;
+        if (!gen_point(a, ray, z, xn, yn, zn)) continue;       // (sigma is 0 and constant outside the box)
+        const Tap3 tp = gen_taps(a, xn, yn, zn);
+        // relu: sg > 0 here. softplus (threshold 20: identity above; softplus(x) <= 20 exactly for x <= 20 in fp32): 1 - exp(-softplus)
+        const float dfeat = (a.F.act == T2N_ACT_RELU || sg > 20.f) ? dsg : dsg * (-expm1f(-sg));
+        for (int k = 0; k < 3; ++k) {
+            const int W = a.grid[mat0(k)], H = a.grid[mat1(k)], Lz = a.grid[vecm(k)];
+            const Axis& ax = tp.a[mat0(k)]; const Axis& ay = tp.a[mat1(k)]; const Axis& al = tp.a[vecm(k)];
+            for (int c = 0; c < a.Cd[k]; ++c) {
+                const float pv = gen_plane(a.dp[k], c, H, W, ax, ay), lv = gen_line(a.dl[k], c, Lz, al);
+                if (a.g_dp[k]) gen_plane_add(a.g_dp[k], c, H, W, ax, ay, dfeat * lv);
+                if (a.g_dl[k]) gen_line_add(a.g_dl[k], c, Lz, al, dfeat * pv);
+            }
+        }
+    }
+}
+
+static int gen_fill(GenArgs& a, const t2n_generic_desc* d, const t2n_field_params* p, const char* who) {
+    if (!d || !p) { set_error("%s: NULL argument", who); return T2N_ERR_INVALID; }
+    memset(&a, 0, sizeof(a));
+    FieldDev& F = a.F;
+    for (int k = 0; k < 3; ++k) {
+        F.aabb0[k] = d->aabb_min[k]; F.aabb1[k] = d->aabb_max[k]; F.inv[k] = d->inv_aabb_size[k];
+        a.grid[k] = d->grid[k]; a.Cd[k] = d->density_n_comp[k]; a.Ca[k] = d->app_n_comp[k];
+        if (d->grid[k] < 2 || a.Cd[k] < 1 || a.Ca[k] < 1) { set_error("%s: bad grid / component counts", who); return T2N_ERR_INVALID; }
+        a.dp[k] = p->density_plane[k]; a.dl[k] = p->density_line[k]; a.ap[k] = p->app_plane[k]; a.al[k] = p->app_line[k];
+        if (!a.dp[k] || !a.dl[k] || !a.ap[k] || !a.al[k]) { set_error("%s: NULL factor tensor", who); return T2N_ERR_INVALID; }
+    }
+    F.shift = d->density_shift; F.dscale = d->distance_scale; F.thres = d->weight_thres; F.step = d->step_size;
+    F.near = d->near; F.far = d->far; F.zgate = d->z_gate; F.act = d->act; F.shading = d->shading; F.app_dim = d->app_dim;
+    a.app_dim = d->app_dim; a.shading = d->shading; a.fea_pe = d->fea_pe; a.view_pe = d->view_pe; a.fC = d->feature_c;
+    a.basis = p->basis_weight; a.w0 = p->mlp_w0; a.b0 = p->mlp_b0; a.w1 = p->mlp_w1; a.b1 = p->mlp_b1; a.w2 = p->mlp_w2; a.b2 = p->mlp_b2;
+    if (!a.basis) { set_error("%s: NULL basis_weight", who); return T2N_ERR_INVALID; }
+    if (a.app_dim < 1 || a.app_dim > kGenDimMax) { set_error("%s: app_dim %d outside [1, %d]", who, a.app_dim, kGenDimMax); return T2N_ERR_UNSUPPORTED; }
+    const bool mlp = d->shading == T2N_SHADE_MLP_FEA_NOVIEW || d->shading == T2N_SHADE_MLP_FEA || d->shading == T2N_SHADE_MLP;
+    if (d->shading == T2N_SHADE_SH && a.app_dim != 27) { set_error("%s: SH head needs app_dim 27", who); return T2N_ERR_UNSUPPORTED; }
+    if (d->shading == T2N_SHADE_RGB && a.app_dim != 3) { set_error("%s: RGB head needs app_dim 3", who); return T2N_ERR_UNSUPPORTED; }
+    if (!mlp && d->shading != T2N_SHADE_SH && d->shading != T2N_SHADE_RGB) { set_error("%s: shading head %d", who, d->shading); return T2N_ERR_UNSUPPORTED; }
+    if (mlp) {
+        if (!a.w0 || !a.b0 || !a.w1 || !a.b1 || !a.w2 || !a.b2) { set_error("%s: MLP head needs all six renderModule tensors", who); return T2N_ERR_INVALID; }
+        const bool view = d->shading != T2N_SHADE_MLP_FEA_NOVIEW;
+        const int fpe = d->shading == T2N_SHADE_MLP ? 0 : d->fea_pe;
+        a.in0 = a.app_dim * (1 + 2 * fpe) + (view ? 3 + 6 * d->view_pe : 0);
+        if (a.fC < 1 || a.fC > kGenHidMax || a.in0 > kGenInMax || fpe < 0 || fpe > 16 || d->view_pe < 0 || d->view_pe > 16) {
+            set_error("%s: head shape featureC %d / %d inputs beyond %d / %d", who, a.fC, a.in0, kGenHidMax, kGenInMax);
+            return T2N_ERR_UNSUPPORTED;
+        }
+    }
+    return T2N_OK;
+}
+
+struct GenCarve { size_t w, z, sigma, T, rgb_s, acc, raw, go, total; };
+static GenCarve gen_carve(int64_t R, int N, bool own_wz) {
+    GenCarve c;
+    size_t o = 0;
+    const size_t rn = (size_t)R * N * 4;
+    auto take = [&](size_t b) { const size_t at = o; o = (o + b + 255) / 256 * 256; return at; };
+    c.w = own_wz ? take(rn) : 0; c.z = own_wz ? take(rn) : 0;
+    c.sigma = take(rn); c.T = take(rn); c.rgb_s = take(rn * 3); c.acc = take((size_t)R * 4); c.raw = take((size_t)R * 12); c.go = take(rn * 3);
+    c.total = o;
+    return c;
+}
+
+}  // namespace t2n
+
+using namespace t2n;
+
+extern "C" size_t t2n_generic_workspace_bytes(int64_t n_rays, int n_samples) {
+    if (n_rays <= 0 || n_samples <= 0) return 0;
+    return gen_carve(n_rays, n_samples, true).total;
+}
+
+static int gen_bind(GenArgs& a, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags, const float* jitter,
+                    float* weights, float* z_vals, void* workspace, size_t workspace_bytes, const char* who) {
+    if (!rays || !workspace || n_rays <= 0 || ray_stride < 6 || n_samples < 1) { set_error("%s: bad argument", who); return T2N_ERR_INVALID; }
+    if (flags & T2N_FLAG_NDC) { set_error("%s: NDC sampling is not available on the general-shape path", who); return T2N_ERR_UNSUPPORTED; }
+    if ((flags & T2N_FLAG_TRAIN) && !jitter) { set_error("%s: train mode needs the jitter draws", who); return T2N_ERR_INVALID; }
+    if ((uint64_t)n_rays * (uint64_t)n_samples > 0x7fffffffull) { set_error("%s: more than 2^31 samples per call (chunk the rays)", who); return T2N_ERR_UNSUPPORTED; }
+    const GenCarve c = gen_carve(n_rays, n_samples, true);
+    if (c.total > workspace_bytes) { set_error("%s: workspace %zu B < %zu B", who, workspace_bytes, c.total); return T2N_ERR_WORKSPACE; }
+    char* ws = (char*)workspace;
+    a.rays = rays; a.n_rays = n_rays; a.ray_stride = ray_stride; a.N = n_samples;
+    a.train = (flags & T2N_FLAG_TRAIN) ? 1 : 0; a.add_bg = (flags & T2N_FLAG_ADD_BG) ? 1 : 0; a.jitter = jitter;
+    a.w = weights ? weights : (float*)(ws + c.w); a.z = z_vals ? z_vals : (float*)(ws + c.z);
+    a.sigma = (float*)(ws + c.sigma); a.T = (float*)(ws + c.T); a.rgb_s = (float*)(ws + c.rgb_s); a.acc = (float*)(ws + c.acc);
+    a.raw = (float*)(ws + c.raw); a.go = (float*)(ws + c.go);
+    return T2N_OK;
+}
+
+extern "C" int t2n_generic_forward(const t2n_generic_desc* desc, const t2n_field_params* params, const float* rays, int64_t n_rays,
+                                   int ray_stride, int n_samples, uint32_t flags, const float* jitter, float* rgb, float* depth,
+                                   float* weights, float* z_vals, uint64_t* stats, void* workspace, size_t workspace_bytes, t2n_stream stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (n_rays == 0) { if (stats) T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s)); return T2N_OK; }
+    GenArgs a;
+    int rc = gen_fill(a, desc, params, "t2n_generic_forward");
+    if (rc) return rc;
+    if (!rgb || !depth) { set_error("t2n_generic_forward: NULL output"); return T2N_ERR_INVALID; }
+    if ((rc = gen_bind(a, rays, n_rays, ray_stride, n_samples, flags, jitter, weights, z_vals, workspace, workspace_bytes, "t2n_generic_forward"))) return rc;
+    a.rgb = rgb; a.depth = depth; a.stats = (unsigned long long*)stats;
+    if (stats) T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s));
+    hipLaunchKernelGGL(k_gen_march, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, s, a);
+    const long long tot = (long long)n_rays * n_samples;
+    hipLaunchKernelGGL(k_gen_shade<false>, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_gen_composite, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, s, a);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_generic_backward(const t2n_generic_desc* desc, const t2n_field_params* params, const float* rays, int64_t n_rays,
+                                    int ray_stride, int n_samples, uint32_t flags, const float* jitter, const float* weights,
+                                    const float* z_vals, const float* d_rgb, const float* d_depth, const float* d_weights,
+                                    const t2n_field_grads* g, void* workspace, size_t workspace_bytes, t2n_stream stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (n_rays == 0) return T2N_OK;
+    GenArgs a;
+    int rc = gen_fill(a, desc, params, "t2n_generic_backward");
+    if (rc) return rc;
+    if (!g || !d_rgb || !d_depth) { set_error("t2n_generic_backward: NULL argument"); return T2N_ERR_INVALID; }
+    if ((rc = gen_bind(a, rays, n_rays, ray_stride, n_samples, flags, jitter, const_cast<float*>(weights), const_cast<float*>(z_vals), workspace,
+                       workspace_bytes, "t2n_generic_backward"))) return rc;
+    for (int k = 0; k < 3; ++k) { a.g_dp[k] = g->density_plane[k]; a.g_dl[k] = g->density_line[k]; a.g_ap[k] = g->app_plane[k]; a.g_al[k] = g->app_line[k]; }
+    a.g_basis = g->basis_weight; a.g_w0 = g->mlp_w0; a.g_b0 = g->mlp_b0; a.g_w1 = g->mlp_w1; a.g_b1 = g->mlp_b1; a.g_w2 = g->mlp_w2; a.g_b2 = g->mlp_b2;
+    a.d_rgb = d_rgb; a.d_depth = d_depth; a.d_w = d_weights;
+    hipLaunchKernelGGL(k_gen_bwd_march, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, s, a);
+    const long long tot = (long long)n_rays * n_samples;
+    hipLaunchKernelGGL(k_gen_shade<true>, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, s, a);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}

@@ -387,7 +387,7 @@ class TensorBase(nn.Module):
         self.update_stepSize(gridSize)
         self.init_svd_volume(gridSize[0], device)
         self.init_render_func(shadingMode, pos_pe, view_pe, fea_pe, featureC, device)
-        self._kernel_shape()      # shapes beyond the kernels' capacity fail here, loudly
+        self._is_general()        # shapes beyond the general path's capacity fail here, loudly
 
     def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):
         """models/tensorBase.py:200-217: the head's parameter container (its arithmetic runs in the shade kernels)."""
@@ -533,25 +533,52 @@ class TensorBase(nn.Module):
     # zero weights (sin 0 = 0, cos 0 = 1 meet a zero weight), missing octaves are zero weight columns, missing hidden units have zero
     # weights and biases (relu(0) = 0). The embedded tensors are built with differentiable torch ops (cached per parameter version), so
     # autograd carries the kernels' gradients back to the real parameters: a slow path (one padded copy per parameter change), not an
-    # error. Larger shapes have no embedding and are rejected.
+    # error. Larger shapes have no embedding: they run on the general-shape path (_is_general, csrc/t2n_generic.hip).
     KERNEL_DEN, KERNEL_APP, KERNEL_DIM, KERNEL_PE, KERNEL_FC = 16, 48, 27, 6, 128
+
+    GENERAL_DIM, GENERAL_FC, GENERAL_PE = 64, 256, 16     # limits of the general-shape path (csrc/t2n_generic.hip)
+
+    def _is_general(self):
+        """Shapes BEYOND the tuned kernels' (more components per plane, a wider head): rendered and differentiated by the general-shape
+        kernels (csrc/t2n_generic.hip: loops over the counts, reference layouts read in place) — slow, but not an error. Fixed at
+        construction."""
+        flag = self.__dict__.get("_general_flag")
+        if flag is None:
+            wide_head = False
+            if isinstance(self.renderModule, nn.Module):
+                wide_head = self.featureC > self.KERNEL_FC
+                if self.shadingMode == "MLP_Fea_noview":
+                    wide_head = wide_head or self.app_dim > self.KERNEL_DIM or self.fea_pe > self.KERNEL_PE
+                else:      # view-dependent heads: the tuned general-head path holds app_dim <= 32 and 512 inputs
+                    n_in = self.renderModule.mlp[0].weight.shape[1]
+                    wide_head = wide_head or self.app_dim > 32 or n_in > 512
+            flag = max(self.density_n_comp) > self.KERNEL_DEN or max(self.app_n_comp) > self.KERNEL_APP or wide_head
+            if flag:
+                if type(self) is not TensorVMSplit:
+                    raise T2NError(f"{type(self).__name__} with n_comp {self.density_n_comp} / {self.app_n_comp}: the general-shape path serves "
+                                   "TensorVMSplit only")
+                if self.app_dim > self.GENERAL_DIM or (isinstance(self.renderModule, nn.Module) and self.featureC > self.GENERAL_FC) or \
+                        max(self.fea_pe, self.view_pe) > self.GENERAL_PE or self.fea_pe < 0:
+                    raise T2NError(f"app_dim {self.app_dim} / featureC {self.featureC} / fea_pe {self.fea_pe} / view_pe {self.view_pe}: beyond the "
+                                   f"general-shape path ({self.GENERAL_DIM} / {self.GENERAL_FC} / {self.GENERAL_PE})")
+            self.__dict__["_general_flag"] = flag
+        return flag
 
     def _kernel_shape(self):
         """(density comps, appearance comps, app_dim, fea_pe, featureC) the native field is created with."""
-        if max(self.density_n_comp) > self.KERNEL_DEN or max(self.app_n_comp) > self.KERNEL_APP:
-            raise T2NError(f"n_comp {self.density_n_comp} / {self.app_n_comp}: the HIP kernels hold at most {self.KERNEL_DEN} density and "
-                           f"{self.KERNEL_APP} appearance components per plane (smaller counts run zero-padded)")
-        if isinstance(self.renderModule, nn.Module) and self.featureC > self.KERNEL_FC:
-            raise T2NError(f"featureC {self.featureC}: the HIP heads hold at most {self.KERNEL_FC} hidden units (smaller run zero-padded)")
+        if self._is_general():
+            raise T2NError("this field's shape runs on the general-shape path (forward / backward through the render call only: no native "
+                           "field handle, hence no stage entry points, occupancy-mask operators or train_step)")
         if self.shadingMode == "MLP_Fea_noview":
-            if self.app_dim > self.KERNEL_DIM or self.fea_pe > self.KERNEL_PE or self.fea_pe < 0:
-                raise T2NError(f"MLP_Fea_noview with app_dim {self.app_dim} / fea_pe {self.fea_pe}: at most {self.KERNEL_DIM} / "
-                               f"{self.KERNEL_PE} (smaller run zero-padded)")
+            if self.fea_pe < 0:
+                raise T2NError(f"fea_pe {self.fea_pe}")
             return self.KERNEL_DEN, self.KERNEL_APP, self.KERNEL_DIM, self.KERNEL_PE, self.KERNEL_FC
         return self.KERNEL_DEN, self.KERNEL_APP, self.app_dim, self.fea_pe, self.KERNEL_FC if isinstance(self.renderModule, nn.Module) else self.featureC
 
     def _needs_embed(self):
         flag = self.__dict__.get("_embed_flag")
+        if flag is None and self._is_general():
+            flag = self.__dict__["_embed_flag"] = False
         if flag is None:     # (component counts and head sizes are fixed at construction)
             kd, ka, kdim, kpe, kfc = self._kernel_shape()
             flag = (any(c != kd for c in self.density_n_comp) or any(c != ka for c in self.app_n_comp) or kdim != self.app_dim
@@ -654,7 +681,7 @@ class TensorBase(nn.Module):
         embedded TensorCP) and the device keeps fp32 master copies: then ``defer_factor_grads`` lets the backward leave the
         plane / line gradients in the library's channel-last buffers for ``optim.TVAdam(field=...)`` to consume in place."""
         return type(self)._kernel_views is TensorVMSplit._kernel_views and type(self)._autograd_params is TensorVMSplit._autograd_params \
-            and self.factor_storage == "fp32" and not self._needs_embed()
+            and self.factor_storage == "fp32" and not self._needs_embed() and not self._is_general()
 
     def factor_grad_buffer(self, _raw=False):
         """The channel-last gradients of the 12 plane / line tensors as ONE flat fp32 tensor owned here and handed to the native
@@ -1048,6 +1075,15 @@ class TensorBase(nn.Module):
         fw = int(self.frame_width if frame_width is None else frame_width)
         if not is_train and not ndc_ray and fw and R % fw == 0:
             flags |= FLAG_COHERENT
+        if self._is_general():
+            if ndc_ray or self.alphaMask is not None:
+                raise T2NError("the general-shape path has no NDC sampling and no AlphaGridMask")
+            flags &= ~FLAG_COHERENT
+            ps = self._real_params()
+            if torch.is_grad_enabled() and any(p.requires_grad for p in ps):
+                return _GeneralFn.apply(self, rays, N, flags, jitter, *ps)
+            rgb, depth, z, w, _ = self._general_forward(rays, N, flags, jitter)
+            return (rgb, depth, z, w) if self.materialize_weights or is_train else (rgb, depth, None, None)
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._autograd_params())
         if needs_grad and self._needs_embed():
             # every differentiable forward gets its own embedding graph: a second forward + backward at an unchanged parameter version
@@ -1160,6 +1196,64 @@ class TensorBase(nn.Module):
                                                C.byref(gs), _lib.ptr(ws), ws.numel(), _lib.ptr(bws), bws.numel(),
                                                st), "t2n_render_backward")
         self._deferred_grad_key = self._uploaded_key if defer else None   # which parameters the device-side gradients belong to
+        return grads
+
+    # ---- general-shape path (csrc/t2n_generic.hip) --------------------------------------------------------------------------------
+    def _general_desc(self):
+        d = _lib.GenericDesc()
+        a = self.aabb.detach().float().cpu()
+        inv = self.invaabbSize.detach().float().cpu()
+        for k in range(3):
+            d.aabb_min[k], d.aabb_max[k], d.inv_aabb_size[k] = float(a[0, k]), float(a[1, k]), float(inv[k])
+            d.grid[k] = int(self.gridSize[k])
+            d.density_n_comp[k], d.app_n_comp[k] = int(self.density_n_comp[k]), int(self.app_n_comp[k])
+        d.app_dim, d.shading = int(self.app_dim), _lib.SHADE_IDS[self.shadingMode]
+        d.fea_pe, d.view_pe, d.feature_c = int(self.fea_pe), int(self.view_pe), int(self.featureC)
+        d.act = _lib.ACT_IDS[self.fea2denseAct]
+        d.density_shift, d.distance_scale = float(self.density_shift), float(self.distance_scale)
+        d.weight_thres, d.step_size = float(self.rayMarch_weight_thres), float(self.stepSize)
+        d.near, d.far, d.z_gate = float(self.near_far[0]), float(self.near_far[1]), float(self.z_gate)
+        return d
+
+    def _general_forward(self, rays, N, flags, jitter):
+        """t2n_generic_forward: (rgb, depth, z_vals, weights, workspace). The workspace holds the context the backward needs."""
+        lib = _lib.load()
+        ps = self._real_params()
+        dev = rays.device
+        if dev.type != "cuda" or any(p.device != dev for p in ps):
+            raise T2NError("the renderer runs on an MI355X (cuda/HIP) only: rays and parameters must live there")
+        R = rays.shape[0]
+        if R * N > 0x7fffffff:
+            raise T2NError("general-shape path: more than 2^31 samples in one call (render in chunks: OctreeRender_trilinear_fast does)")
+        rgb, depth = torch.empty(R, 3, device=dev), torch.empty(R, device=dev)
+        w, z = torch.empty(R, N, device=dev), torch.empty(R, N, device=dev)
+        stats = torch.empty(_lib.T2N_STAT_COUNT, device=dev, dtype=torch.int64)
+        ws = torch.empty(int(lib.t2n_generic_workspace_bytes(R, N)), dtype=torch.uint8, device=dev)
+        d = self._general_desc()
+        st = self._param_struct([p.detach() for p in ps])
+        with torch.cuda.device(dev):
+            _lib.check(lib.t2n_generic_forward(C.byref(d), C.byref(st), _lib.ptr(rays), R, rays.shape[1], N, flags, _lib.ptr(jitter),
+                                               _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(w), _lib.ptr(z), _lib.ptr(stats), _lib.ptr(ws),
+                                               ws.numel(), _lib.current_stream_ptr(dev)), "t2n_generic_forward")
+        self.last_stats = stats
+        return rgb, depth, z, w, ws
+
+    def _general_backward(self, rays, jitter, N, flags, ws, w, z, d_rgb, d_depth, d_w):
+        lib = _lib.load()
+        ps = self._real_params()
+        dev = rays.device
+        R = rays.shape[0]
+        grads = [torch.zeros_like(p) for p in ps]
+        d_rgb = torch.zeros(R, 3, device=dev) if d_rgb is None else d_rgb.contiguous().float()
+        d_depth = torch.zeros(R, device=dev) if d_depth is None else d_depth.contiguous().float()
+        d_w = None if d_w is None else d_w.contiguous().float()
+        d = self._general_desc()
+        st = self._param_struct([p.detach() for p in ps])
+        gs = self._param_struct(grads, _lib.FieldGrads)
+        with torch.cuda.device(dev):
+            _lib.check(lib.t2n_generic_backward(C.byref(d), C.byref(st), _lib.ptr(rays), R, rays.shape[1], N, flags, _lib.ptr(jitter),
+                                                _lib.ptr(w), _lib.ptr(z), _lib.ptr(d_rgb), _lib.ptr(d_depth), _lib.ptr(d_w), C.byref(gs),
+                                                _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr(dev)), "t2n_generic_backward")
         return grads
 
     def train_step(self, rays, rgb_target, depth_target, optimizer, N_samples=-1, white_bg=True, w_depth=0.005, w_trans=1e3, delta=0.1,
@@ -1605,6 +1699,30 @@ class TensorCP(TensorVMSplit):
                 lines[i] = nn.Parameter(lines[i].data[:, :, int(lo[a]):int(hi[a]), :].contiguous())
         self._virt = None
         self._adopt_window(lo, hi, box)
+
+
+class _GeneralFn(torch.autograd.Function):
+    """Autograd bridge of the general-shape path: t2n_generic_forward / t2n_generic_backward; the parameters are the module's own
+    leaf tensors (reference layouts), the gradients come back in those layouts."""
+
+    @staticmethod
+    def forward(ctx, field, rays, N, flags, jitter, *params):
+        rgb, depth, z, w, ws = field._general_forward(rays, N, flags, jitter)
+        ctx.field, ctx.N, ctx.flags, ctx.ws = field, N, flags, ws
+        ctx.key = tuple((p.data_ptr(), p._version) for p in params)
+        ctx.save_for_backward(rays, jitter, w, z)
+        ctx.mark_non_differentiable(z)
+        return rgb, depth, z, w
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d_z, d_w):
+        field = ctx.field
+        rays, jitter, w, z = ctx.saved_tensors
+        if tuple((p.data_ptr(), p._version) for p in field._real_params()) != ctx.key:
+            raise T2NError("parameters changed between forward and backward")
+        grads = field._general_backward(rays, jitter, ctx.N, ctx.flags, ctx.ws, w, z, d_rgb, d_depth, d_w)
+        ctx.ws = None
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class _RenderFn(torch.autograd.Function):
