@@ -434,8 +434,11 @@ def scaling_prediction(field, dev, fused_ms, G=8):
 
 
 def count_gpus_sysfs():
-    """GPUs of this node WITHOUT touching the HIP runtime: KFD topology nodes with SIMDs (CPU nodes have simd_count 0), narrowed by
-    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set. 0 without a KFD topology, None when it cannot be parsed."""
+    """GPUs this process can USE, without touching the HIP runtime: KFD topology nodes with SIMDs (CPU nodes have simd_count 0) whose
+    render node (/dev/dri/renderD<drm_render_minor>) is readable and writable here — a container's device cgroup may expose fewer
+    render nodes than the host topology lists —, then narrowed the way the runtime composes the visibility variables:
+    ROCR_VISIBLE_DEVICES filters first, HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES index into what is left. 0 without a KFD topology,
+    None (unknown: the child ranks decide) when it cannot be parsed."""
     import glob
     nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
     if not nodes:
@@ -444,13 +447,26 @@ def count_gpus_sysfs():
     for f in nodes:
         try:
             props = dict(l.split()[:2] for l in open(f).read().splitlines() if len(l.split()) >= 2)
-            n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+            node = f"/dev/dri/renderD{minor}"
+            if minor >= 0 and os.path.exists("/dev/dri") and not os.access(node, os.R_OK | os.W_OK):
+                continue   # listed by the host's topology, not usable from here
+            n += 1
         except Exception:
             return None
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+
+    def listed(var):
         v = os.environ.get(var)
-        if v is not None and v.strip() != "":
-            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+        return None if v is None or v.strip() == "" else len([x for x in v.split(",") if x.strip() != ""])
+    rocr = listed("ROCR_VISIBLE_DEVICES")
+    if rocr is not None:
+        n = min(n, rocr)
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):     # (indices into the ROCR-filtered list: never more than it holds)
+        k = listed(var)
+        if k is not None:
+            n = min(n, k)
     return n
 
 
@@ -565,6 +581,9 @@ def main():
 
     def gpu_up():
         assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        if torch.cuda.device_count() <= local_rank:      # (a rank without a device of its own leaves at once instead of hanging its peers)
+            print(f"[bench] rank {rank}: local rank {local_rank} but {torch.cuda.device_count()} visible device(s)", file=sys.stderr, flush=True)
+            os._exit(3)
         torch.cuda.set_device(local_rank)
         torch.zeros(1, device=dev).add_(1)
         torch.cuda.synchronize()

@@ -271,11 +271,18 @@ def test_unsupported_configs_fail_loudly():
     aabb = torch.tensor([[-1.0] * 3, [1.0] * 3])
     with pytest.raises(T2NError):
         TensorVMSplit(aabb, [8, 8, 8], dev(), shadingMode="MLP_PE")
+    base = dict(density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, shadingMode="MLP_Fea_noview", fea_pe=6, step_ratio=1.0)
+    for kw in (dict(featureC=512), dict(fea_pe=17), dict(app_dim=65)):
+        with pytest.raises(T2NError):       # beyond even the general-shape path: rejected at construction
+            TensorVMSplit(aabb, [8, 8, 8], dev(), **dict(base, **kw))
     for kw in (dict(density_n_comp=[32, 16, 16]), dict(appearance_n_comp=[96, 48, 48]), dict(featureC=256), dict(fea_pe=8), dict(app_dim=30)):
-        base = dict(density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, shadingMode="MLP_Fea_noview", fea_pe=6, step_ratio=1.0)
-        base.update(kw)
-        with pytest.raises(T2NError):       # beyond the kernels' capacity: rejected at construction (smaller shapes run zero-padded)
-            TensorVMSplit(aabb, [8, 8, 8], dev(), **base)
+        wide = TensorVMSplit(aabb, [8, 8, 8], dev(), **dict(base, **kw))     # beyond the tuned kernels: the general-shape path renders it
+        with torch.no_grad():
+            rgb, depth, _, _ = wide(torch.tensor([[0.0, 0.0, -3.0, 0.0, 0.0, 1.0]] * 4))
+        assert rgb.shape == (4, 3) and bool(torch.isfinite(rgb).all())
+        for call in (lambda: wide.sync_params(), lambda: wide.compute_alpha(torch.zeros(4, 3, device=dev()))):
+            with pytest.raises(T2NError):   # ... but it has no native field: the stage entry points say so
+                call()
     ok = TensorVMSplit(aabb, [8, 8, 8], dev(), density_n_comp=[16] * 3, appearance_n_comp=[48] * 3,
                        shadingMode="MLP_Fea_noview", fea_pe=6, step_ratio=1.0)
     with pytest.raises(T2NError):

@@ -53,6 +53,34 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in sources() + _headers())
 
 
+def check_ss3_isa(hipcc, verbose=False):
+    """k_mlp_ss3 keeps live accumulators in literally named AccVGPRs across separate asm statements; nothing reserves them in
+    between, so the build is refused should the compiler ever put values of its own there or spill: the kernel's assembly must hold no
+    v_accvgpr_write / v_accvgpr_mov (hipcc staging a value in an AccVGPR), no scratch, no spilled registers. Runs when t2n_mlp_ss.hip
+    was recompiled (one more -S pass of that file)."""
+    import re
+    src = os.path.join(CSRC, "t2n_mlp_ss.hip")
+    asm = os.path.join(OBJ, "t2n_mlp_ss.s")
+    subprocess.run([hipcc] + CFLAGS + ["-S", "--cuda-device-only", src, "-o", asm], check=True, stderr=subprocess.DEVNULL)
+    text = open(asm).read()
+    found = 0
+    for m in re.finditer(r"^(_ZN3t2n2ss9k_mlp_ss3\w*):[^\n]*\n(.*?)\n\.Lfunc_end\d+:", text, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        found += 1
+        bad = [l.strip() for l in body.split("\n") if re.match(r"\s*v_accvgpr_(write|mov)", l)]
+        meta = re.search(r"\.name:\s+" + name + r"\n.*?\.vgpr_spill_count:\s+(\d+)", text, re.S)
+        priv = re.search(r"\.name:\s+" + name + r"\n.*?\.private_segment_fixed_size:\s+(\d+)", text, re.S)
+        spills = int(meta.group(1)) if meta else -1
+        scratch = int(priv.group(1)) if priv else -1
+        if bad or spills != 0 or scratch != 0:
+            raise RuntimeError(f"{name}: the compiler touched the AccVGPRs or spilled ({len(bad)} v_accvgpr_write/mov, {spills} spilled "
+                               f"registers, {scratch} B of scratch): the hand-allocated accumulators are not safe with this build")
+        if verbose:
+            print(f"check_ss3_isa: {name} ok ({body.count('v_accvgpr_read_b32')} accumulator reads, no writes, no spills)", flush=True)
+    if found != 2:
+        raise RuntimeError(f"check_ss3_isa: expected the two instantiations of k_mlp_ss3 in the assembly, found {found}")
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
@@ -68,6 +96,8 @@ def build(force=False, verbose=False):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:
         list(ex.map(compile_one, todo))
+    if any(os.path.basename(s) == "t2n_mlp_ss.hip" for s in todo):
+        check_ss3_isa(hipcc, verbose)
     keep = {_obj(s) for s in sources()}
     for o in glob.glob(os.path.join(OBJ, "*.o")):       # objects of sources that no longer exist must not be linked
         if o not in keep:

@@ -62,6 +62,7 @@ constexpr float kRange = 59968.f;             // |activation| from here on (an f
 
 struct Args {
     const uint4* w0; const uint4* w1; const uint4* w2; const float* bias; const float* inv_scale;   // packed by k_pack_ss
+    const float* bounds;          // [0..3] row-norm bounds of the hidden activations, [4] (as unsigned) 1: the untracked kernel may run (k_ss_scales)
     const float* feat;            // [rows][32] fp32 feature rows (row = tile * 32 + sample): 27 features, the entry's compositing weight, zeros
     const unsigned* counters; unsigned list_cap; int nlists;
     unsigned tile_hi;             // 32-sample tiles [0, min(ntiles, tile_hi)) are this kernel's
@@ -288,7 +289,7 @@ __device__ __forceinline__ void conv_bias(Conv3& V, const float* __restrict__ LB
 // instruction sits next to its producer. (One wave per SIMD: an instruction issued right behind the one it depends on costs 8 cycles
 // instead of 4, and v_fma_mix -> v_cvt_pkrtz needs a wait state on top: tools/experiments/issue_cost.hip, 8.0 against 5.6 cycles per
 // instruction for the split sequence alone.)
-template <int S, int BASE, int BOFF>
+template <int S, int BASE, int BOFF, bool TRACK = true>
 struct ConvFill3 {
     u4v (&Hh)[8]; u4v (&Hl)[8]; Conv3& V; float inv, neg1; s2v& amax; const float* __restrict__ LBh; const f32x16* src;
     template <int IDX> __device__ __forceinline__ void run() {
@@ -323,7 +324,7 @@ struct ConvFill3 {
             const h2v ph = __builtin_bit_cast(h2v, V.ph[j]);
             V.x[j][0] = fmaf((float)ph[0], neg1, V.x[j][0]);
             V.x[j][1] = fmaf((float)ph[1], neg1, V.x[j][1]);
-            amax = __builtin_elementwise_max(amax, __builtin_bit_cast(s2v, V.ph[j]));   // bit patterns of non-negative halves order like their values
+            if constexpr (TRACK) amax = __builtin_elementwise_max(amax, __builtin_bit_cast(s2v, V.ph[j]));   // bit patterns of non-negative halves order like their values
         } else if constexpr (m == 5) {
             V.pl[j] = __builtin_bit_cast(unsigned, (hh2)__builtin_amdgcn_cvt_pkrtz(V.x[j][0], V.x[j][1]));
         }
@@ -334,7 +335,7 @@ struct ConvFill3 {
 #endif
         Hh[S] = u4v{V.ph[0], V.ph[1], V.ph[2], V.ph[3]};
         Hl[S] = u4v{V.pl[0], V.pl[1], V.pl[2], V.pl[3]};
-        asm volatile("" : "+v"(amax));   // pinned to its K-step: left alone, hipcc defers the maxima to the next round and spills the halves for it
+        if constexpr (TRACK) asm volatile("" : "+v"(amax));   // pinned to its K-step: left alone, hipcc defers the maxima to the next round and spills the halves for it
     }
 };
 
@@ -434,7 +435,7 @@ struct TileCtx {   // what the stages share (references: everything is inlined i
     const LdsA& L; u4v (&H0h)[8]; u4v (&H0l)[8]; u4v (&H1h)[8]; u4v (&H1l)[8];
 };
 constexpr int acc1_of(int t) { return t == 1 ? 192 : -1; }   // where tile t's layer-1 accumulators live (see above)
-template <int T_, int St>
+template <int T_, int St, bool TRACK>
 __device__ __forceinline__ void stage_step(TileCtx& c) {
     constexpr int K0 = kE0 + kEL * T_ + 4 * St;
     if constexpr (T_ > 0) fetch2<St>(c.A2, c.L);   // consumed by the layer-2 step riding in the NEXT layer-1 step (step 7: the stage's epilogue)
@@ -444,7 +445,7 @@ __device__ __forceinline__ void stage_step(TileCtx& c) {
         if constexpr (T_ == 0) { NoFill fa; run(fa, fb, l2); return; }
 #endif
         if constexpr (St < 7) {
-            ConvFill3<St + 1, 64 * T_, 0> fa{c.H0h, c.H0l, c.V0, c.inv0, c.neg1, c.amax, c.LBh, nullptr};
+            ConvFill3<St + 1, 64 * T_, 0, TRACK> fa{c.H0h, c.H0l, c.V0, c.inv0, c.neg1, c.amax, c.LBh, nullptr};
             run(fa, fb, l2);
         } else {
             NoFill fa;
@@ -455,20 +456,20 @@ __device__ __forceinline__ void stage_step(TileCtx& c) {
         NoFill fb;
         with_a(fb, NoL2());
     } else {
-        ConvFill3<St, acc1_of(T_ - 1), 128> fb{c.H1h, c.H1l, c.V1, c.inv1, c.neg1, c.amax, c.LBh, c.accv};
+        ConvFill3<St, acc1_of(T_ - 1), 128, TRACK> fb{c.H1h, c.H1l, c.V1, c.inv1, c.neg1, c.amax, c.LBh, c.accv};
         if constexpr (St == 0) with_a(fb, NoL2());
         else with_a(fb, L2Ops<64 * (T_ - 1), St == 1>{c.A2[(St - 1) % 2], c.H1h[St - 1], c.H1l[St - 1]});
     }
 }
-template <int T_>
+template <int T_, bool TRACK>
 __device__ __forceinline__ void stage(TileCtx& c) {
     if constexpr (T_ > 0) conv_bias<0, 128>(c.V1, c.LBh);   // the previous tile's first layer-1 conversion step (in flight under the block below)
     {
-        ConvFill3<0, 64 * T_, 0> f{c.H0h, c.H0l, c.V0, c.inv0, c.neg1, c.amax, c.LBh, nullptr};
+        ConvFill3<0, 64 * T_, 0, TRACK> f{c.H0h, c.H0l, c.V0, c.inv0, c.neg1, c.amax, c.LBh, nullptr};
         f.all();
     }
-    stage_step<T_, 0>(c); stage_step<T_, 1>(c); stage_step<T_, 2>(c); stage_step<T_, 3>(c);
-    stage_step<T_, 4>(c); stage_step<T_, 5>(c); stage_step<T_, 6>(c); stage_step<T_, 7>(c);
+    stage_step<T_, 0, TRACK>(c); stage_step<T_, 1, TRACK>(c); stage_step<T_, 2, TRACK>(c); stage_step<T_, 3, TRACK>(c);
+    stage_step<T_, 4, TRACK>(c); stage_step<T_, 5, TRACK>(c); stage_step<T_, 6, TRACK>(c); stage_step<T_, 7, TRACK>(c);
     if constexpr (T_ + 1 < kT3) conv_bias<0, 0>(c.V0, c.LBh);   // the next tile's first layer-0 conversion step
     if constexpr (T_ > 0) {   // the previous tile's last layer-2 step
         L2Ops<64 * (T_ - 1), false> l2{c.A2[1], c.H1h[7], c.H1l[7]};
@@ -522,8 +523,15 @@ __device__ __forceinline__ void l2_last(AEl (&A2)[2], const u4v& Hh, const u4v& 
     SS_FENCE();
 }
 
+// TRACK: the hidden activations' f16 range is tracked value by value (one packed maximum per pair: 1.7 % of a round's issue cycles);
+// !TRACK: it is bounded from the weights instead — |h0| <= max_j (sum_c |W0[j][pe c]| + |b0[j]|) + max|feature| * max_j sum_c |W0[j][raw c]|,
+// |h1| <= max_j sum_k |W1[j][k]| * that + max |b1| (row norms by k_ss_scales at upload; the features' own maximum is tracked per round
+// in both forms) — and the launch raises the range flag when the bound passes the f16 range. Both instantiations are launched; the word
+// bounds[4] (written at upload: bound fine for features up to 64) makes one of them return at once.
+template <bool TRACK>
 __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    if ((__float_as_uint(a.bounds[4]) != 0u) == TRACK) return;
     // LDS map: ring [0, 64 KB) | W1 [64 KB, 128 KB) | W2 [128 KB, 144 KB) | biases (unscaled) | sub-list table. A DS instruction carries a
     // 16-bit byte offset: with the lane's operand addresses written as THREE opaque bases (lane * 16 + 0 / 64 KB / 128 KB) plus constants
     // every fetch is base + immediate; left to itself hipcc materialises one base register per 64-KB-crossing constant and spills them.
@@ -682,7 +690,7 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
         }
 #define SS3_L2(St)                                                                                                                \
         {                                                                                                                         \
-            ConvFill3<St + 1, -1, 128> f{H1h, H1l, V1, inv1, neg1, amax, LBh, accv};                                              \
+            ConvFill3<St + 1, -1, 128, TRACK> f{H1h, H1l, V1, inv1, neg1, amax, LBh, accv};                                       \
             l2_step<St, 128>(A2, H1h[St], H1l[St], f, L);                                                                         \
         }
         {
@@ -693,18 +701,18 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
             // (hipcc cannot tell the bias reads from the LDS-DMA's destination and drains vmcnt in front of the first one behind a DMA issue:
             // none is issued between here and the round's last bias read — the next round's chunk 2 goes out at the end of the round)
             conv_bias<0, 0>(V, LBh);   // tile 0's first conversion step
-            stage<0>(ctx);
+            stage<0, TRACK>(ctx);
             SS3_T(p_tile[0]);
             asm volatile("; SS3_MARK stage1");
             // the next round's features (needed from the round's last step on): 42 registers in flight through two stages — loaded at the
             // tail instead, their HBM / MALL latency (~2 us behind the gather kernel's 548 MB of rows) stalled every round for ~2.5 k cycles
 #pragma unroll
             for (int t = 0; t < kT3; ++t) load_feat(rn, t, E[t].in.f);
-            stage<1>(ctx);
+            stage<1, TRACK>(ctx);
             SS3_FINAL(0)
             SS3_T(p_tile[1]);
             asm volatile("; SS3_MARK stage2");
-            stage<2>(ctx);
+            stage<2, TRACK>(ctx);
             SS3_FINAL(1)
             SS3_T(p_tile[2]);
             asm volatile("; SS3_MARK tail");
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
             fetch2<0>(A2, L); fetch2<1>(A2, L);
             conv_bias<0, 128>(V1, LBh);
             {
-                ConvFill3<0, -1, 128> f{H1h, H1l, V1, inv1, neg1, amax, LBh, accv};
+                ConvFill3<0, -1, 128, TRACK> f{H1h, H1l, V1, inv1, neg1, amax, LBh, accv};
                 f.all();
             }
             SS3_L2(0) SS3_L2(1) SS3_L2(2) SS3_L2(3) SS3_L2(4) SS3_L2(5) SS3_L2(6)
@@ -748,7 +756,13 @@ __global__ __launch_bounds__(256) void k_mlp_ss3(const Args a) {
 #if defined(SS3_ABL_NO_DMA) || defined(SS3_ABL_NO_ENC) || defined(SS3_ABL_NO_CONV) || defined(SS3_ABL_S0_NOCONV) || defined(SS3_TIMING_ONLY)
     if (am[0] == (_Float16)12345.f) atomicOr(a.range_flag, 1u);   // timing-only build: garbage values must not trigger the exact redo
 #else
-    if (__any(!((float)am[0] < kRange) || !((float)am[1] < kRange) || amax_u > __float_as_uint(kRange)) && lane == 0) atomicOr(a.range_flag, 1u);
+    bool out_of_range = !((float)am[0] < kRange) || !((float)am[1] < kRange) || amax_u > __float_as_uint(kRange);
+    if constexpr (!TRACK) {
+        const float fmx = __uint_as_float(amax_u);                                    // largest |feature| this wave saw
+        const float b0 = fmaf(fmx, a.bounds[1], a.bounds[0]), b1 = fmaf(a.bounds[2], b0, a.bounds[3]);
+        out_of_range = out_of_range || !(b0 < kRange) || !(b1 < kRange);
+    }
+    if (__any(out_of_range) && lane == 0) atomicOr(a.range_flag, 1u);
 #endif
 }
 
@@ -774,6 +788,23 @@ __global__ __launch_bounds__(256) void k_ss_scales(const PackArgs a) {
         if (lane == 0) red[l][wv] = m[l];
     }
     __syncthreads();
+    // row-norm bounds for the untracked head (see k_mlp_ss3): thread j < 128 owns hidden unit j of both layers
+    __shared__ float nb[4][128];
+    if (tid < 128) {
+        float pe = 0.f, raw = 0.f, r1 = 0.f;
+        for (int c = 0; c < 351; ++c) { const float v = fabsf(a.w0[tid * 351 + c]); if (c < 27) raw += v; else pe += v; }
+        for (int c = 0; c < 128; ++c) r1 += fabsf(a.w1[tid * 128 + c]);
+        nb[0][tid] = pe + fabsf(a.b0[tid]); nb[1][tid] = raw; nb[2][tid] = r1; nb[3][tid] = fabsf(a.b1[tid]);
+    }
+    __syncthreads();
+    if (tid == 8) {
+        float m4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q) for (int j = 0; j < 128; ++j) m4[q] = fmaxf(m4[q], nb[q][j]);
+        for (int q = 0; q < 4; ++q) a.scales[8 + q] = m4[q] * 1.0001f;        // (the sums above round: a margin)
+        const float b0 = m4[0] + 64.f * m4[1], b1 = m4[2] * b0 + m4[3];
+        const bool ok = b0 < 0.5f * kRange && b1 < 0.5f * kRange;             // NaN / inf weights compare false: the tracked kernel runs
+        reinterpret_cast<unsigned*>(a.scales)[12] = ok ? 1u : 0u;
+    }
     if (tid < 3) {
         const float mx = fmaxf(fmaxf(red[tid][0], red[tid][1]), fmaxf(red[tid][2], red[tid][3]));
         float s = 1.f;
@@ -852,7 +883,7 @@ int ss_pack(t2n_field* f, hipStream_t s) {
     using namespace ss;
     const size_t nw = (size_t)kW0 + kW1 + kW2;
     if (!f->buf_ss) {
-        T2N_HIP(hipMalloc((void**)&f->buf_ss, nw * 16 + (kBias + 8) * 4));
+        T2N_HIP(hipMalloc((void**)&f->buf_ss, nw * 16 + (kBias + 16) * 4));   // + scales [0..7], activation bounds [8..11], untracked-ok word [12]
     }
     uint4* base = (uint4*)f->buf_ss;
     PackArgs a;
@@ -881,14 +912,15 @@ int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev,
     else if (f->ss_event && f->ss_stream != (void*)s) T2N_HIP(hipStreamWaitEvent(s, (hipEvent_t)f->ss_event, 0));
     static bool attr_set = false;
     if (!attr_set) {
-        T2N_HIP(hipFuncSetAttribute((const void*)k_mlp_ss3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        T2N_HIP(hipFuncSetAttribute((const void*)k_mlp_ss3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+        T2N_HIP(hipFuncSetAttribute((const void*)k_mlp_ss3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
         attr_set = true;
     }
     const size_t nw = (size_t)kW0 + kW1 + kW2;
     uint4* base = (uint4*)f->buf_ss;
     Args a;
     a.w0 = base; a.w1 = base + kW0; a.w2 = base + kW0 + kW1;
-    a.bias = (const float*)(base + nw); a.inv_scale = a.bias + kBias + 4;
+    a.bias = (const float*)(base + nw); a.inv_scale = a.bias + kBias + 4; a.bounds = a.bias + kBias + 8;
     a.feat = feat; a.counters = counters_dev; a.list_cap = list_cap; a.nlists = kLists; a.tile_hi = tile_hi; a.app_rgb = app_rgb;
     a.range_flag = range_flag; a.neg1 = -1.f;
 #ifdef SS3_PROF
@@ -898,7 +930,8 @@ int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev,
     T2N_HIP(hipMemsetAsync(prof, 0, 1024 * 10 * 8, s));
     a.prof = prof;
 #endif
-    hipLaunchKernelGGL(k_mlp_ss3, dim3(256), dim3(256), kLds, s, a);
+    hipLaunchKernelGGL(k_mlp_ss3<false>, dim3(256), dim3(256), kLds, s, a);   // (one of the two returns at once: bounds[4])
+    hipLaunchKernelGGL(k_mlp_ss3<true>, dim3(256), dim3(256), kLds, s, a);
 #ifdef SS3_PROF
     if (++prof_calls == 20) {   // one report per process: per-wave cycle sums, averaged over the waves
         static unsigned long long h[1024 * 10];

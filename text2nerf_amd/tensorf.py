@@ -805,6 +805,7 @@ class TensorBase(nn.Module):
         mkey = None if mask is None else (mask.alpha_volume.data_ptr(), mask.alpha_volume._version, tuple(mask.alpha_volume.shape))
         if getattr(self, "_alpha_key", "unset") != mkey:
             queued = True
+            self._wait_readers(dev)
             with torch.cuda.device(dev):
                 if mask is None:
                     _lib.check(lib.t2n_field_set_alpha_mask(self._handle, None, 0, 0, 0, None, None, _lib.current_stream_ptr(dev)),
@@ -840,6 +841,7 @@ class TensorBase(nn.Module):
             force = True
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if force or key != self._uploaded_key:
+            self._wait_readers(dev)
             with torch.cuda.device(dev):
                 st = self._param_struct([p.detach() for p in ps])
                 if not force and self._uploaded_key is not None and key[:12] == getattr(self, "_device_factor_key", None):
@@ -859,11 +861,34 @@ class TensorBase(nn.Module):
         if queued:
             ev = torch.cuda.Event()
             ev.record(cur)
-            self._upload_event, self._upload_seen = ev, {int(cur.cuda_stream)}
+            self._upload_event, self._upload_seen, self._upload_stream = ev, {int(cur.cuda_stream)}, int(cur.cuda_stream)
         elif getattr(self, "_upload_event", None) is not None and int(cur.cuda_stream) not in self._upload_seen:
             cur.wait_event(self._upload_event)
             self._upload_seen.add(int(cur.cuda_stream))
         return self._handle
+
+    def _wait_readers(self, dev):
+        """ADVICE r4 (write-after-read): an upload rewrites the factor / head / mask copies in place; frames of this field still in flight
+        on OTHER streams (renderer._FramePipe) read them. Every render on a stream other than the last upload's leaves an event
+        (_note_reader); the uploading stream waits for those before it overwrites anything. (One _FramePipe per device at a time: the
+        pipes share their side streams and scratch.)"""
+        readers = self.__dict__.get("_reader_events")
+        if readers:
+            cur = torch.cuda.current_stream(dev)
+            for sid, ev in readers.items():
+                if sid != int(cur.cuda_stream):
+                    cur.wait_event(ev)
+            readers.clear()
+
+    def _note_reader(self, dev):
+        seen = getattr(self, "_upload_seen", None)
+        cur = torch.cuda.current_stream(dev)
+        sid = int(cur.cuda_stream)
+        if seen is None or sid == getattr(self, "_upload_stream", sid):
+            return                      # same stream as the uploads: ordered by the stream itself
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.__dict__.setdefault("_reader_events", {})[sid] = ev
 
     def __del__(self):
         try:
@@ -1145,6 +1170,7 @@ class TensorBase(nn.Module):
                                               _lib.ptr(ws), ws.numel(), _lib.current_stream_ptr(dev)),
                        "t2n_render_forward")
         self.last_stats = stats
+        self._note_reader(dev)
         if keep_ctx:
             return rgb, depth, z, w, ws
         return rgb, depth, z, w
