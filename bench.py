@@ -53,7 +53,7 @@ BYTES_PER_APP = 3456
 BYTES_PER_RAY = 40
 FLOP_PER_APP = 131168    # 2*(144*27 + 351*128 + 128*128 + 128*3)
 FLOP_HEAD = 123392       # 2*(351*128 + 128*128 + 128*3): the MLP head without basis_mat
-PMC_FILES = ("round4_pmc.json", "round3_pmc.json")   # the newest committed counter record is used (profiles/)
+PMC_FILES = ("round5_pmc.json", "round4_pmc.json", "round3_pmc.json")   # the newest committed counter record is used (profiles/)
 MFMA_F32_PEAK_TF = 157.3
 MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 
@@ -313,8 +313,39 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
                                              "batch is gathered on the device, only the jitter draws (CPU generator, like the reference) "
                                              "cross PCIe"}
     if fused_step:
+        # kernel groups of one fused iteration (HIP events on the launch streams, a short pass of its own: the brackets cost the
+        # streams a few us each) and what bounds the largest of them
+        kt, roofs = {}, {}
+        try:
+            field.timing(True)
+            field.read_timing(reset=True)
+            n_t = 10
+            for k in range(n_t):
+                it(warmup + iters + k)
+            torch.cuda.synchronize()
+            kt = {k: v[0] / n_t for k, v in field.read_timing(reset=True).items()}
+            field.timing(False)
+            A = field.stats()["appearance"]
+            if kt.get("bwd_scatter"):
+                # appearance scatter (k_app_bin + scan + k_bwd_tile_accum<48>): per appearance row and plane 48 channels x (4 plane + 2 line
+                # taps) double-precision LDS atomics; a CU retires one wave-wide ds_add_f64 per ~9 clocks (tools/experiments/lds_atomic_bench.hip)
+                atom = A * 3 * 48 * 6
+                peak = 256 * 64 / 9.0 * 2.1e9
+                roofs["bwd_scatter"] = {"bound": "lds-f64-atomics", "kernel": "k_bwd_tile_accum<48> (+ binning)", "unit": "G lane-atomics/s",
+                                        "achieved": atom / (kt["bwd_scatter"] * 1e-3) / 1e9, "peak": peak / 1e9,
+                                        "frac": atom / (kt["bwd_scatter"] * 1e-3) / peak, "ms_per_iter": kt["bwd_scatter"]}
+            if kt.get("bwd_mlp"):
+                # MLP backward: input-gradient chain (3 f16 products per fp32 product) + weight-gradient GEMMs (6 bf16 products): the
+                # reference's 2 x 2 x MACs per row, against the dense f16 peak
+                flop = 2.0 * 2.0 * (351 * 128 + 128 * 128 + 128 * 3 + 144 * 27) * A
+                roofs["bwd_mlp"] = {"bound": "mfma", "kernel": "k_mlp_bwd_ss + k_gemm_tn_b + k_bwd_l2", "unit": "TFLOP/s",
+                                    "achieved": flop / (kt["bwd_mlp"] * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TF,
+                                    "frac": flop / (kt["bwd_mlp"] * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, "ms_per_iter": kt["bwd_mlp"]}
+        except Exception as e:  # noqa: BLE001  (reporting only)
+            kt = {"error": repr(e)[:200]}
         return {"train_iters_per_s_fused_step": iters / dt, "train_ms_per_iter_fused_step": dt / iters * 1e3,
                 "train_ms_per_iter_fused_step_blocks": blocks_ms,
+                "train_kernel_ms_per_iter": kt, "train_kernel_rooflines": roofs,
                 "train_step_fused": "TensorVMSplit.train_step: no autograd graph, loss + its gradients in one kernel, event-based row "
                                     f"count, TV + Adam on the device copies; loss {float(loss.detach()):.4f}"}
     if fused_optim:
@@ -1049,11 +1080,22 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["config"]["dropin_eval_call_ms"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_train:
+            # the fused step first, from a clean allocator: its peak reserved memory is the train figure (the render legs above
+            # leave 2.65-GB weight tensors and worst-case workspaces in torch's cache)
+            try:
+                from text2nerf_amd import tensorf as _tf2
+                _tf2.release_workspaces(keep_current=False)
+                torch.cuda.empty_cache()
+                torch.cuda.reset_peak_memory_stats(dev)
+                base_res = torch.cuda.memory_reserved(dev)
+            except Exception:  # noqa: BLE001
+                base_res = 0
+            out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True))
+            # (what the fused train leg added on top of the resident render state: the 300^3 field, its ray tensor, outputs)
+            out["config"]["memory_reserved_GiB_train"] = round((torch.cuda.max_memory_reserved(dev) - base_res) / 2 ** 30, 3)
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True))
-            out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True, resident=True))
-            out["config"]["memory_reserved_GiB_train"] = round(torch.cuda.memory_reserved(dev) / 2 ** 30, 3)
         if world == 1 and not c4 and not args.quick:
             out["scaling_prediction"] = sp = scaling_prediction(field, dev, out["config"].get("train_ms_per_iter_fused_step"))
             out["config"]["train_ms_per_iter_fused_step_2048_rays"] = sp.get("train_dp", {}).get("fused_step_ms_by_rays_per_gpu", {}).get("2048")

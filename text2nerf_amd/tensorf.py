@@ -28,7 +28,7 @@ VEC_MODE = [2, 1, 0]
 
 # train_step seeds the TV terms on a side stream (two more library calls and two stream hand-overs per step) only for batches whose step is
 # GPU-bound; below, the TV pass stays inside the optimiser step
-_SEED_MIN_RAYS = int(os.environ.get("T2N_SEED_MIN_RAYS", "8192"))
+_SEED_MIN_RAYS = 8192
 _WORKSPACE = {}
 
 
@@ -363,17 +363,17 @@ class TensorBase(nn.Module):
         self.z_gate = 2.0                 # models/tensorBase.py:460
         self.frame_width = 0              # set to the image width when eval rays are whole row-major frames: enables the
                                           # 8x8-tile marcher (shared dot-product tables); 0 = unknown -> per-ray marcher
-        self.mlp_exact_fp32 = os.environ.get("T2N_MLP_EXACT", "0") == "1"   # False: f16 two-way-split MFMA products
+        self.mlp_exact_fp32 = False       # False: f16 two-way-split MFMA products; True: exact fp32 MFMA (forward and backward)
         # 'fp32' (default) or 'bf16' (BASELINE configs[4]): the forward gathers read bf16 copies of the 12 factor tensors;
         # the render equals the fp32 render of the bf16-rounded tensors bit for bit, the parameters stay fp32 masters
-        self.factor_storage = os.environ.get("T2N_FACTOR_STORAGE", "fp32")
+        self.factor_storage = "fp32"
         # Early ray termination of eval renders that return neither weights nor z_vals (evaluation(), render_views, ...): OPT-IN. The
         # reference never terminates (models/tensorBase.py:19-26,494-505: every in-box sample is evaluated), so the default 0.0 is its
         # sample-for-sample arithmetic (exact evaluated-sample counts). A threshold eps > 0 stops a ray whose transmittance fell below it:
         # a bounded deviation (< eps on acc and colour, < eps * z range on depth). Values above rayMarch_weight_thres are clamped to it
         # (a skipped sample could otherwise have been an appearance sample). OctreeRender_trilinear_fast (weights returned) and
-        # training are never terminated. T2N_EARLY_TERMINATION sets the default of new fields.
-        self.early_termination = float(os.environ.get("T2N_EARLY_TERMINATION", "0"))
+        # training are never terminated.
+        self.early_termination = 0.0
         self._handle = None
         self._uploaded_key = None
         self._gbuf = None

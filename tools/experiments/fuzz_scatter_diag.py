@@ -2,7 +2,6 @@
 (T2N_BWD_ATOMIC_SCATTER=1, an independent implementation of the same sums), against the oracle's autograd in float32 and against the
 oracle in FLOAT64 (what tells fp32 summation noise in a nearly empty batch from a wrong sum), per tensor."""
 import os, sys, subprocess
-os.environ.setdefault("T2N_EARLY_TERMINATION", "0")
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

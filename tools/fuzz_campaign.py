@@ -6,7 +6,6 @@ import traceback
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("T2N_EARLY_TERMINATION", "0")   # sample-for-sample comparisons (evaluated counts): as tests/conftest.py does for the suite
 from tests import test_hip_fuzz as F  # noqa: E402
 
 

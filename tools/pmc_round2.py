@@ -14,7 +14,10 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("t2n::", "").replace("ss::", "").split("<")[0]
+            full = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("t2n::", "").replace("ss::", "")
+            k = full.split("<")[0]
+            if full.startswith("k_mlp_ss3<true>"):
+                k = "k_mlp_ss3_tracked"      # round 5: the instantiation that returns at once on the bench weights must not dilute the head's means
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 import hashlib
 
