@@ -450,6 +450,8 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->buf_mlp_h) (void)hipFree(f->buf_mlp_h);
     if (f->buf_ss) (void)hipFree(f->buf_ss);
     if (f->ss_event) (void)hipEventDestroy((hipEvent_t)f->ss_event);
+    if (f->ss_ok_event) (void)hipEventDestroy((hipEvent_t)f->ss_ok_event);
+    if (f->ss_ok_host) (void)hipHostFree(f->ss_ok_host);
     for (auto& c : f->count_slots) {
         if (c.host) (void)hipHostFree(c.host);
         if (c.ev) (void)hipEventDestroy((hipEvent_t)c.ev);

@@ -85,6 +85,7 @@ struct t2n_field {
     void* buf_ss = nullptr;    // sample-stationary head operands (t2n_mlp_ss.hip), packed lazily from params_ref
     bool ss_dirty = true;
     void* ss_event = nullptr; void* ss_stream = nullptr;   // the pack's stream + an event behind it: a render on ANOTHER stream waits for it
+    unsigned* ss_ok_host = nullptr; void* ss_ok_event = nullptr; int ss_variant = -2;   // head instantiation the packed weights allow: -1 copy in flight, -2 unknown (both launched), 0 untracked, 1 tracked
     float* buf_alpha = nullptr; // alpha-mask volume copy
     int mlp_split = 1;         // 1: f16 two-way split products (default), 0: exact fp32 MFMA
     // channel-last gradient accumulators (backward), allocated on first use

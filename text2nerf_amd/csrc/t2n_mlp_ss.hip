@@ -900,6 +900,19 @@ int ss_pack(t2n_field* f, hipStream_t s) {
     T2N_HIP(hipEventRecord((hipEvent_t)f->ss_event, s));
     f->ss_stream = (void*)s;
     f->ss_dirty = false;
+    // which instantiation of the head these weights allow (bounds[4]) also travels to pinned host memory behind an event: launches
+    // that find the copy landed start only that one; until then both are started and the word on the device makes one return at once
+    f->ss_variant = -1;
+    if (!f->ss_ok_host) {
+        if (hipHostMalloc((void**)&f->ss_ok_host, 4, hipHostMallocDefault) != hipSuccess) { f->ss_ok_host = nullptr; (void)hipGetLastError(); }
+        hipEvent_t e;
+        if (f->ss_ok_host && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) f->ss_ok_event = (void*)e;
+    }
+    if (f->ss_ok_host && f->ss_ok_event) {
+        *f->ss_ok_host = 0xffffffffu;
+        if (hipMemcpyAsync(f->ss_ok_host, a.scales + 12, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipEventRecord((hipEvent_t)f->ss_ok_event, s) != hipSuccess) { (void)hipGetLastError(); f->ss_variant = -2; }
+    } else f->ss_variant = -2;   // no read-back: always both launches
     return T2N_OK;
 }
 
@@ -930,8 +943,12 @@ int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev,
     T2N_HIP(hipMemsetAsync(prof, 0, 1024 * 10 * 8, s));
     a.prof = prof;
 #endif
-    hipLaunchKernelGGL(k_mlp_ss3<false>, dim3(256), dim3(256), kLds, s, a);   // (one of the two returns at once: bounds[4])
-    hipLaunchKernelGGL(k_mlp_ss3<true>, dim3(256), dim3(256), kLds, s, a);
+    if (f->ss_variant == -1 && hipEventQuery((hipEvent_t)f->ss_ok_event) == hipSuccess && *f->ss_ok_host != 0xffffffffu)
+        f->ss_variant = *f->ss_ok_host ? 0 : 1;   // 0: untracked (bounds hold), 1: tracked
+    else if (f->ss_variant == -1) (void)hipGetLastError();   // (hipErrorNotReady)
+    // (a kernel started for the wrong word returns at once: bounds[4] on the device decides, the host copy only saves the empty launch)
+    if (f->ss_variant != 1) hipLaunchKernelGGL(k_mlp_ss3<false>, dim3(256), dim3(256), kLds, s, a);
+    if (f->ss_variant != 0) hipLaunchKernelGGL(k_mlp_ss3<true>, dim3(256), dim3(256), kLds, s, a);
 #ifdef SS3_PROF
     if (++prof_calls == 20) {   // one report per process: per-wave cycle sums, averaged over the waves
         static unsigned long long h[1024 * 10];

@@ -827,7 +827,7 @@ int launch_finish_rays(t2n_field* f, const RenderLaunch& L, const float* spill, 
         T2N_HIP(hipFuncSetAttribute((const void*)k_finish_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_finish_rays, dim3(512), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k_finish_rays, dim3(128), dim3(256), lds, s, a);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }
@@ -1618,8 +1618,11 @@ int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, c
         if (rc) return rc;
         ShadeArgs oa = a;
         oa.tile_lo = ws_tiles; oa.range_flag = flag; oa.split_unsafe = f->split_unsafe;
-        if (half) hipLaunchKernelGGL(k_shade_coop<true>, grid, dim3(256), kCoopLds, s, oa);
-        else hipLaunchKernelGGL(k_shade_coop<false>, grid, dim3(256), kCoopLds, s, oa);
+        // tiles past the feature-row capacity (none in steady state: the rows are sized from the list budget): a small persistent
+        // grid — 512 workgroups that find nothing cost the frame 8 us, 64 cost it the launch
+        const dim3 grid_o(grid.x < 64u ? grid.x : 64u);
+        if (half) hipLaunchKernelGGL(k_shade_coop<true>, grid_o, dim3(256), kCoopLds, s, oa);
+        else hipLaunchKernelGGL(k_shade_coop<false>, grid_o, dim3(256), kCoopLds, s, oa);
         ShadeArgs ra = a;   // every tile of the launch, the one-kernel path's included
         ra.run_if_nonzero = counters_dev + kRangeFlagWord; ra.stats = (unsigned long long*)stats;
         hipLaunchKernelGGL(k_shade<false>, grid, dim3(256), lds, s, ra);
