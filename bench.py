@@ -620,7 +620,11 @@ def main():
         torch.cuda.synchronize()
 
     dist = None
-    if world > 1:
+    # T2N_BENCH_FORCE_GROUP=1: initialise the process group even for ONE rank, so that the N > 1 code of this file (RCCL group with
+    # device_id, object gather of the rank evidence, tile all-gather inside the timed region, max-over-ranks all-reduce, the
+    # data-parallel train step) executes on a 1-GPU box (tests/test_rccl_single.py)
+    grouped = world > 1 or bool(os.environ.get("T2N_BENCH_FORCE_GROUP"))
+    if grouped:
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -691,13 +695,13 @@ def main():
     def step():
         with torch.no_grad():
             rgb, depth, z, w = field(rays, white_bg=True, is_train=False, N_samples=-1)
-            if c4 and world > 1:   # strong scaling: the frame is complete only when every tile has arrived
+            if c4 and grouped:   # strong scaling: the frame is complete only when every tile has arrived
                 tile = torch.zeros((cap, 4), dtype=rgb.dtype, device=rgb.device)
                 tile[:R, :3], tile[:R, 3] = rgb, depth
                 out = torch.empty((world * cap, 4), dtype=tile.dtype, device=tile.device)
                 dist.all_gather_into_tensor(out, tile)
                 return out
-            if world > 1:
+            if grouped:
                 tile = torch.cat([rgb, depth[:, None]], 1)
                 out = torch.empty((world * tile.shape[0], 4), dtype=tile.dtype, device=tile.device)
                 work = dist.all_gather_into_tensor(out, tile, async_op=True)
@@ -766,7 +770,7 @@ def main():
         if rank == 0:
             with torch.no_grad():
                 s_rgb, s_depth, _, _ = field(frame_rays, white_bg=True, is_train=False, N_samples=-1)
-            if world > 1:
+            if grouped:
                 if bands:
                     g = band_unshard(g, W, world)
                 else:
@@ -898,7 +902,7 @@ def main():
             "inregion_timing": "none" if args.no_inregion_timing else "head only",
             "parallelism": f"ray-tile x{world}" + ((" + RCCL all-gather of rgb+depth tiles inside every step" if c4 else
                                                     " + RCCL all-gather of rgb+depth tiles (async, overlapped with the "
-                                                    "next frame's render)") if world > 1 else ""),
+                                                    "next frame's render)") if grouped else ""),
             "kernel_ms_per_frame": frame_ms,
             "issue_model_ms_by_kernel": issue,
             "kernel_rooflines": roofs,
@@ -958,7 +962,7 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n * 1e3
 
-        if world == 1 and not c4 and not args.quick:
+        if not grouped and not c4 and not args.quick:
             # sustained clocks: the same frame for >= 2 s
             n_sus = max(int(2200.0 / max(ms_step, 0.1)), args.steps)
             out["config"]["sustained_ms_per_step"] = timed_frames(n_sus)
@@ -1041,7 +1045,7 @@ def main():
                 out["config"]["exact_fp32_ms_per_step"] = ms_exact
                 out["config"]["exact_fp32_value_ray_samples_per_s"] = R * N / (ms_exact * 1e-3)
                 out["config"]["exact_fp32_shade_frac_of_f32_mfma_peak"] = ex.get("frac")
-        if world == 1 and not c4 and not args.quick:
+        if not grouped and not c4 and not args.quick:
             # early ray termination (eval renders without weights / z_vals; the mirror's default eps 1e-6): frame time and evaluated
             # samples with it on and off, on the bench scene (soft walls: T ~ 4e-4 behind them, nothing to skip), on fog (S2) and on
             # opaque walls (S1-sharp)
@@ -1079,7 +1083,7 @@ def main():
                 out["config"]["dropin_eval_call_ms"] = dropin_eval_ms(field, dev, H, W)
             except Exception as e:  # noqa: BLE001
                 out["config"]["dropin_eval_call_ms"] = {"error": repr(e)[:300]}
-        if world == 1 and not args.no_train:
+        if not grouped and not args.no_train:
             # the fused step first, from a clean allocator: its peak reserved memory is the train figure (the render legs above
             # leave 2.65-GB weight tensors and worst-case workspaces in torch's cache)
             try:
@@ -1096,7 +1100,7 @@ def main():
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True, resident=True))
-        if world == 1 and not c4 and not args.quick:
+        if not grouped and not c4 and not args.quick:
             out["scaling_prediction"] = sp = scaling_prediction(field, dev, out["config"].get("train_ms_per_iter_fused_step"))
             out["config"]["train_ms_per_iter_fused_step_2048_rays"] = sp.get("train_dp", {}).get("fused_step_ms_by_rays_per_gpu", {}).get("2048")
             out["config"]["scaling_prediction_headline"] = {
@@ -1106,7 +1110,7 @@ def main():
                 "train_dp_step_ms_at_2048_rays": sp.get("train_dp", {}).get("fused_step_ms_by_rays_per_gpu", {}).get("2048"),
                 "train_dp_all_reduce_estimate_ms": sp.get("train_dp", {}).get("all_reduce_estimate_ms"),
                 "note": "one-GPU predictions (tile times, link-rate estimates), not measurements: see scaling_prediction"}
-        if world == 1 and not args.no_cpu_baseline:
+        if not grouped and not args.no_cpu_baseline:
             def hip_render(r):
                 with torch.no_grad():
                     a, b, _, _ = field(r.to(dev), white_bg=True, is_train=False, N_samples=-1)

@@ -623,6 +623,17 @@ int launch_setup(const SetupOps& o, hipStream_t s) {
 }  // namespace t2n
 
 namespace t2n {
+// The counter block (2 KB) to pinned, device-visible host memory by ONE wave's stores: hipMemcpyAsync device -> host runs a blit kernel
+// that costs the stream 11 us (+ ~6 us of dispatch gap) per frame / train step; this kernel costs its launch
+__global__ __launch_bounds__(64) void k_post_counts(const unsigned* __restrict__ src, unsigned* __restrict__ host_dst, int words) {
+    for (int i = threadIdx.x; i < words; i += 64) host_dst[i] = src[i];
+    __threadfence_system();
+}
+int post_counts(const unsigned* counters_dev, unsigned* host_dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(64), 0, s, counters_dev, host_dst, kLists * kCounterStride);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
 // Budgeted launches post their counter block (sub-list fills, overflow word, entries of the rays the finisher took) to pinned host
 // memory behind the march kernels, with an event; nobody waits for it. A later call that finds the event complete turns the
 // counters into the next budget (list_hint) and the retry count. kCountSlots launches may be in flight; one more skips its post.
@@ -656,8 +667,7 @@ static void counts_post(t2n_field* f, const unsigned* counters_dev, int64_t n_ra
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
         c.ev = (void*)ev;
     }
-    if (hipMemcpyAsync(c.host, counters_dev, sizeof(unsigned) * kLists * kCounterStride, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipEventRecord((hipEvent_t)c.ev, s) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (post_counts(counters_dev, c.host, s) != T2N_OK || hipEventRecord((hipEvent_t)c.ev, s) != hipSuccess) { (void)hipGetLastError(); return; }
     c.pending = true; c.n_rays = n_rays; c.n_samples = n_samples; c.budget = budget;
     f->count_next = (f->count_next + 1) % t2n_field::kCountSlots;
 }
@@ -797,8 +807,10 @@ retry_worst_case:
                                                0xffffffffu, keep ? nullptr : L.feat, L.feat_rows, stats))) return rc;
         }
         if ((rc = tiles ? launch_composite(f, L, s, f->frame_w, (int)(cnt / f->frame_w)) : launch_composite(f, L, s))) return rc;
-        // budgeted lists: the rays that found no room are shaded and composited from their staging slices, on the device
-        if (budget && finish_supported(f) && (rc = launch_finish_rays(f, L, (const float*)(ws + c.sigma), (const float4*)(ws + c.scratch), s))) return rc;
+        // the rays that found no room in the lists (budgeted lists; with worst-case lists a ray cannot be left over, but the
+        // compaction kernel tags by the same rule and a tagged ray is only ever coloured here) are shaded and composited from their
+        // staging slices, on the device
+        if (tiles && finish_supported(f) && (rc = launch_finish_rays(f, L, (const float*)(ws + c.sigma), (const float4*)(ws + c.scratch), s))) return rc;
     }
     if (budget && generic_overflow) {
         // the general view-dependent heads (no device-side finisher; their path synchronises per sub-launch anyway): some rays

@@ -1043,7 +1043,7 @@ int t2n::ctx_counts_post(const void* ws, const unsigned* counters_dev, hipStream
         c.dev = dev;
     }
     c.ws = ws;
-    T2N_HIP(hipMemcpyAsync(c.host, counters_dev, sizeof(unsigned) * kLists * kCounterStride, hipMemcpyDeviceToHost, s));
+    { const int rc = post_counts(counters_dev, c.host, s); if (rc) return rc; }   // (a device store into the pinned buffer: no blit kernel)
     T2N_HIP(hipEventRecord(c.ev, s));
     c.valid = true;
     return T2N_OK;

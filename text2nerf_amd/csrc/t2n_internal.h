@@ -247,6 +247,7 @@ int launch_composite(t2n_field* f, const RenderLaunch& L, hipStream_t s, int img
 // empty kernel. Heads the finisher does not evaluate (the general view-dependent MLPs) keep the host-side retry.
 inline bool finish_supported(const t2n_field* f) { return !head_is_generic(f->desc.shading); }
 int launch_finish_rays(t2n_field* f, const RenderLaunch& L, const float* spill, const float4* scratch, hipStream_t s);
+int post_counts(const unsigned* counters_dev, unsigned* host_dst, hipStream_t s);   // counter block -> pinned host memory, by a device store (t2n_api.hip)
 int ctx_counts_post(const void* ws, const unsigned* counters_dev, hipStream_t s);   // KEEP_CTX forward: counts -> pinned host copy + event (t2n_backward.hip)
 // Activation rows the forward keeps for the backward when the KEEP_CTX workspace is larger than the context itself (the
 // caller's guess of the appearance-row count; 1728 B per row): x144 [rows,144], feat32 [rows,32], h0 / h1 [rows,128] behind

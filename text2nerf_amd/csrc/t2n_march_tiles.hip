@@ -454,15 +454,18 @@ struct CompactArgs {
 __device__ __forceinline__ void reserve_slots(const CompactArgs& a, long long r, unsigned list, int lane, const int4 ra, unsigned& slot0,
                                               unsigned& napp, int* ovf_slot) {
     slot0 = 0;
-    unsigned void_l = 0, void_lo = 0, void_hi = 0;   // a failed try's region inside its list (at most one per ray: tries stop there)
     if (lane == 0) {
         bool fits = napp == 0;
-        for (unsigned att = 0; att < (unsigned)kLists && !fits && void_hi == 0u; ++att) {   // first sub-list with room (a failed try leaves
-            const unsigned l = (list + att) & (unsigned)(kLists - 1);                        // the counter above list_cap: readers clamp it)
+        for (unsigned att = 0; att < (unsigned)kLists && !fits; ++att) {     // first sub-list with room (a failed try leaves the
+            const unsigned l = (list + att) & (unsigned)(kLists - 1);          // counter above list_cap: readers clamp it)
             if (a.counters[l * kCounterStride] + napp > a.list_cap) continue;
             const unsigned s0 = atomicAdd(&a.counters[l * kCounterStride], napp);
             if (s0 + napp <= a.list_cap) { slot0 = l * a.list_cap + s0; fits = true; }
-            else if (s0 < a.list_cap) { void_l = l; void_lo = s0; void_hi = s0 + napp; }
+            else                                                              // lost a race for the list's tail: its part of the
+                for (unsigned e = s0; e < a.list_cap; ++e) {                  // list gets defined entries (void_entries), by this lane
+                    a.app_pos[(size_t)l * a.list_cap + e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    a.app_ray[(size_t)l * a.list_cap + e] = 0;
+                }
         }
         if (fits || !a.finisher) a.ray_app[r] = make_int4((int)slot0, fits ? (int)napp : 0, ra.z, ra.w);
         else {
@@ -476,8 +479,6 @@ __device__ __forceinline__ void reserve_slots(const CompactArgs& a, long long r,
     }
     slot0 = __shfl(slot0, 0);
     napp = __shfl(napp, 0);
-    void_hi = __shfl(void_hi, 0);
-    if (void_hi) void_entries(a.app_pos, a.app_ray, __shfl(void_l, 0), a.list_cap, __shfl(void_lo, 0), void_hi, lane);
 }
 // append the entries of wbuf[r][from, end) above the threshold at slot0 + run.. (sample order)
 __device__ __forceinline__ void compact_span(const CompactArgs& a, long long r, const Ray& ray, int from, int end, unsigned slot0, unsigned run,
