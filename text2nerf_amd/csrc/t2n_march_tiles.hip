@@ -46,6 +46,9 @@ struct TileArgs {
     // the marcher writes the weights of the 16-step blocks its wave's window touches, through a per-wave LDS transpose: 16 steps x
     // 64 rays, then 64-B row segments per store
     float* dense_w;
+#ifdef MT_PROF
+    unsigned long long* prof;   // [waves][8] per-region cycle sums (instrumented build, tools/r5_march_accounting.sh)
+#endif
 };
 
 __device__ __forceinline__ void lds_fence_w() {
@@ -208,6 +211,14 @@ struct __attribute__((aligned(4))) F4U { float x, y, z, w; };   // row segments 
 #ifndef T2N_MTD_WAVES
 #define T2N_MTD_WAVES 4
 #endif
+// -DMT_PROF (timing-only build): s_memtime at the region boundaries of a step pair, summed per wave. With five waves per SIMD a
+// region's cycles include what the SIMD gave to the other four meanwhile: the sums say where a wave's time goes, not what the
+// instructions cost alone.
+#ifdef MT_PROF
+#define MT_T(var) do { const unsigned long long tn = __builtin_readcyclecounter(); var += tn - p_t; p_t = tn; } while (0)
+#else
+#define MT_T(var) do {} while (0)
+#endif
 // ALPHA: the field carries an AlphaGridMask; RELU: fea2denseAct = relu. Compile-time, like the absent NDC depth table (the host never
 // sends NDC renders here): the step loop of the driver's configuration (no mask, softplus) carries neither the mask's eight-tap
 // gather with its 64-bit address arithmetic nor a run-time test per sample and option.
@@ -262,6 +273,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N
     // the wave leaves the loop when none of its rays has anything left to evaluate
     const float eps = DENSE ? 0.f : F.term_eps;
     bool dead = false;   // this ray is below term_eps (as of the last look)
+#ifdef MT_PROF
+    unsigned long long p_coord = 0, p_axes = 0, p_build = 0, p_read = 0, p_act = 0, p_pairs = 0;
+    const unsigned long long p_start = __builtin_readcyclecounter();
+    unsigned long long p_t = p_start;
+#endif
     for (int i = i_begin; i <= i_end; i += kSteps) {
         // looked at every eighth step pair, and the rays' own gate is refreshed only there: a test of the CURRENT transmittance in front of
         // every step pair chains each iteration to the one before (the step pair's gathers cannot start before the previous pair's
@@ -287,6 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N
             any_ok |= ok[q];
         }
         const unsigned long long okm = __ballot(any_ok);
+        MT_T(p_coord);
         // (a lane whose staging slice is full keeps its spill row gap-free: masked-out samples inside its window get zeros)
         if (!DENSE && !okm && !__any(have && napp >= (unsigned)a.cap)) continue;
         float part[kSteps];
@@ -320,13 +337,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N
             const int span = max(max(32 - __builtin_clz(f0) - __builtin_ctz(f0), 32 - __builtin_clz(f1) - __builtin_ctz(f1)),
                                  32 - __builtin_clz(f2) - __builtin_ctz(f2)) + 1;
             const bool ranged = !(bits & 0x40000000u);
+            MT_T(p_axes);
             if (ranged && span <= 4) {
                 table_build<2>(F.den, amn, stD, l15, lq);
                 lds_fence_w();
+                MT_T(p_build);
 #pragma unroll
                 for (int q = 0; q < kSteps; ++q)
                     if (ok[q]) part[q] = table_read<2>(A[q], amn, stD);
                 lds_fence_w();
+                MT_T(p_read);
             } else {
 #pragma unroll   // (a rolled loop would index A[] dynamically and push the per-sample arrays to scratch)
                 for (int q = 0; q < kSteps; ++q)
@@ -387,7 +407,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DENSE ? T2N
                 }
             }
         }
+#ifdef MT_PROF
+        MT_T(p_act); ++p_pairs;
+#endif
     }
+#ifdef MT_PROF
+    if (lane == 0 && a.prof) {
+        unsigned long long* o = a.prof + (size_t)(blockIdx.x * 4 + wid) * 8;
+        o[0] = p_coord; o[1] = p_axes; o[2] = p_build; o[3] = p_read; o[4] = p_act; o[5] = p_pairs; o[6] = __builtin_readcyclecounter() - p_start;
+    }
+#endif
     const int Lw = last >= first && first >= 0 ? last - first + 1 : 0;
     if (have) {
         a.acc[r] = acc;
@@ -557,6 +586,14 @@ int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h
     a.app_pos = L.app_pos; a.app_ray = L.app_ray; a.counters = L.counters; a.list_cap = L.list_cap; a.stats = (unsigned long long*)L.stats;
     a.dense_w = L.weights;
     a.F.term_eps = (!L.weights && !L.z_vals && !L.sigma_ctx) ? f->term_eps : 0.f;   // (eval only: this marcher has no train form)
+#ifdef MT_PROF
+    static unsigned long long* prof = nullptr;
+    static int prof_calls = 0;
+    const long long prof_waves = ((long long)((img_w + 7) / 8) * ((img_h + 7) / 8) + 3) / 4 * 4;
+    if (!prof) T2N_HIP(hipMalloc((void**)&prof, (size_t)65536 * 8 * 8));
+    T2N_HIP(hipMemsetAsync(prof, 0, (size_t)65536 * 8 * 8, s));
+    a.prof = prof_waves <= 65536 ? prof : nullptr;
+#endif
     // (*ovf_count was zeroed by the launch's setup kernel, t2n_render_forward)
     const long long tiles = (long long)((img_w + 7) / 8) * ((img_h + 7) / 8);
     const dim3 grid((unsigned)((tiles + 3) / 4));
@@ -573,6 +610,20 @@ int launch_march_tiles(t2n_field* f, const RenderLaunch& L, int img_w, int img_h
            else { if (relu) T2N_MT_LAUNCH(false, false, true); else T2N_MT_LAUNCH(false, false, false); } }
 #undef T2N_MT_LAUNCH
     T2N_HIP(hipGetLastError());
+#ifdef MT_PROF
+    if (a.prof && ++prof_calls == 20) {   // one report per process: per-wave cycle sums, averaged over the waves that ran steps
+        static unsigned long long h[65536 * 8];
+        T2N_HIP(hipStreamSynchronize(s));
+        T2N_HIP(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long long n = 0;
+        for (long long i = 0; i < prof_waves; ++i) if (h[i * 8 + 5]) { ++n; for (int k = 0; k < 8; ++k) sum[k] += (double)h[i * 8 + k]; }
+        if (n) fprintf(stderr, "[mt prof] %lld waves, per wave: step pairs %.1f, cycles in the step loop %.0f = coordinates + validity %.0f, axis taps + union bit set %.0f, "
+                               "table build (loads -> MFMA -> LDS) %.0f, table reads %.0f, activation + compositing + staging %.0f; per step pair %.0f\n",
+                       n, sum[5] / n, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4]) / n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n,
+                       (sum[0] + sum[1] + sum[2] + sum[3] + sum[4]) / (sum[5] > 0 ? sum[5] : 1));
+    }
+#endif
     CompactArgs c;
     c.F = f->dev;
     c.rays = L.rays; c.n_rays = L.n_rays; c.ray_stride = L.ray_stride; c.n_samples = L.n_samples;
