@@ -1076,7 +1076,7 @@ static int read_counts(const void* fwd_ws, int64_t n_rays, int n_samples, hipStr
     if (kept_rows_stated) *kept_rows_stated = raw[kKeptMagicWord] == kKeptMagic ? raw[kKeptRowsWord] : 0u;
     if (consume) {   // the backward overwrites the kept rows in place: a second backward on this workspace must recompute
         if (slot) { std::lock_guard<std::mutex> lock(g_ctx_mutex); if (slot->valid && slot->ws == fwd_ws) slot->host[kKeptMagicWord] = 0u; }
-        T2N_HIP(hipMemsetAsync((char*)const_cast<void*>(fwd_ws) + c.counters + kKeptMagicWord * 4, 0, 4, s));
+        // (the device word is cleared by the caller's setup kernel: a 4-byte hipMemsetAsync is a 6-us fill kernel of its own on the stream)
     }
     unsigned t = 0;
     for (int l = 0; l < kLists; ++l) {
@@ -1164,6 +1164,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     if (!f->gbuf_external) T2N_HIP(hipMemsetAsync(f->gbuf_all, 0, f->gbuf_bytes, s));
     SetupOps so;   // go, the two bin histograms: zeroed by one kernel once the scatter paths are known (below)
     so.zero(go, (size_t)rows_alloc * 16);
+    so.zero(fw + c.counters + kKeptMagicWord * 4, 4);   // the kept rows are consumed by this call (read_counts cleared the host copy)
 
     // 1. appearance forward recompute with activations kept
     timing_begin(f, T2N_K_BWD_MLP, s);
