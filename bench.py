@@ -166,15 +166,15 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0, check=None):
     return out
 
 
-def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_step=False, batch=16384, resident=False):
+def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_step=False, batch=16384, resident=False, speculative=False):
     keep_threads = torch.get_num_threads()
     try:
-        return _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resident)
+        return _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resident, speculative)
     finally:
         torch.set_num_threads(keep_threads)     # the loop below runs on half the cores; callers (CPU baseline, other legs) get theirs back
 
 
-def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resident=False):
+def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resident=False, speculative=False):
     """C3-shaped optimisation step (text2nerf_main.py:547-601): 16 384 random rays of 9 small-baseline 512x512 views,
     N=259, is_train, MSE(rgb)+0.005 MSE(depth)+1e3 transmittance+TV(density 0.1, app 0.01), Adam(0.02/1e-3).
     With `dist` (world > 1): data-parallel — the SAME 16 384-ray batch is split into equal shards (strong scaling), local
@@ -229,14 +229,15 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
     def it(k):
         if resident:
             idx = perm_d[(k * batch) % (perm.numel() - batch):][:batch]
-            return field.train_step(allrays_d[idx], allrgb_d[idx], alldepth_d[idx], opt, N_samples=n_samples, white_bg=True, tv=tv_terms)[3]
+            return field.train_step(allrays_d[idx], allrgb_d[idx], alldepth_d[idx], opt, N_samples=n_samples, white_bg=True, tv=tv_terms,
+                                    speculative=speculative)[3]
         idx = perm[(k * batch) % (perm.numel() - batch):][:batch]
         if dist is not None:
             idx = idx[lo:hi]
         if fused_step:   # autograd-free: render -> loss kernel (emits d_rgb / d_depth / d_weights) -> backward -> TV + Adam
             ar = (lambda: allreduce_gradients(all_params, average=True, field=field)) if dist is not None else None
             return field.train_step(allrays[idx], allrgb[idx], alldepth[idx], opt, N_samples=n_samples, white_bg=True, tv=tv_terms,
-                                    all_reduce=ar)[3]
+                                    all_reduce=ar, speculative=speculative)[3]
         # targets go host -> device like text2nerf_main.py:550-553, through the pinned staging ring (a pageable .to(device)
         # drains the stream first and idles the GPU for the rest of the host-side batch preparation)
         rays, rgb_t, dep_t = allrays[idx], to_device_async(allrgb[idx], dev), to_device_async(alldepth[idx], dev)
@@ -304,6 +305,10 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
                 "train_dp_step": f"data-parallel x{world}: {batch} rays split into {hi - lo}/GPU (strong scaling), in-place all-reduce of the "
                                  f"{field.factor_grad_buffer().numel() * 4 / 1e6:.1f} MB channel-last factor-gradient buffer + one small flat "
                                  f"message for the head, fused loss + TV + Adam on the device copies, loss {float(loss.detach()):.4f}"}
+    if speculative:
+        return {"ms_per_iter": dt / iters * 1e3, "blocks_ms": blocks_ms, "rays": batch, "resident": bool(resident),
+                "device_rows_steps": int(getattr(field, "device_rows_steps", 0)), "overflows": int(getattr(field, "device_rows_overflows", 0)),
+                "unanswered_polls": int(getattr(field, "device_rows_unanswered", 0)), "loss": float(loss.detach())}
     if fused_step and batch != 16384:
         return {"ms_per_iter": dt / iters * 1e3, "rays": batch}
     if resident:

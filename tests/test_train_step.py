@@ -106,6 +106,57 @@ def test_train_step_equals_the_autograd_step(tiny_params, seeded, monkeypatch):
     assert_same_trajectory(fa, fb, steps=3)
 
 
+def test_speculative_step_equals_the_counted_step(tiny_params):
+    """train_step(speculative=True): the backward reads no row count on the host (T2N_FLAG_DEVICE_ROWS: capacity from the previous
+    step, kernels clip on the device) — same trajectory as the counted step, and the route really was taken."""
+    from text2nerf_amd.optim import TVAdam
+    rays, rgb_t, dep_t = batch()
+    fa = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    fb = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    oa = TVAdam(fa.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fa)
+    ob = TVAdam(fb.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fb)
+    for it in range(6):
+        torch.manual_seed(300 + it)
+        la = fa.train_step(rays, rgb_t, dep_t, oa, N_samples=-1, white_bg=True, tv=[(fa.density_plane, 0.1), (fa.app_plane, 0.01)])
+        torch.manual_seed(300 + it)
+        lb = fb.train_step(rays, rgb_t, dep_t, ob, N_samples=-1, white_bg=True, tv=[(fb.density_plane, 0.1), (fb.app_plane, 0.01)],
+                           speculative=True)
+        assert torch.allclose(la, lb, rtol=1e-5, atol=1e-9), (it, la, lb)
+    assert getattr(fb, "device_rows_steps", 0) == 5 and getattr(fb, "device_rows_overflows", 0) == 0     # (step 0 learns the capacity)
+    assert getattr(fa, "device_rows_steps", 0) == 0
+    assert_same_trajectory(fa, fb, steps=6)
+
+
+def test_speculative_step_survives_a_capacity_overflow(tiny_params, monkeypatch):
+    """A step whose appearance rows exceed the capacity: the rows past it lose their appearance gradient (nothing else), the host
+    learns it one step later, counts it, and the next step takes the counted route with the re-learned capacity."""
+    from text2nerf_amd import tensorf as tf
+    from text2nerf_amd.optim import TVAdam
+    monkeypatch.setattr(tf, "_ladder", lambda n, *a, **k: n)       # (the ladder's floor of 1024 rows would hide the small capacity)
+    rays, rgb_t, dep_t = batch()
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    o = TVAdam(f.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=f)
+    step = lambda: f.train_step(rays, rgb_t, dep_t, o, N_samples=-1, white_bg=True, speculative=True)
+    torch.manual_seed(1)
+    step()
+    full = int(f._ctx_rows_hint)
+    assert full > 256
+    f._ctx_rows_hint = 64                      # far below what the batch needs
+    torch.manual_seed(2)
+    l1 = step()
+    assert f.device_rows_steps == 1
+    torch.manual_seed(3)
+    l2 = step()                                # polls step 1's count: overflow -> counted route
+    assert f.device_rows_overflows == 1 and f.device_rows_steps == 1
+    assert int(f._ctx_rows_hint) > 256
+    torch.manual_seed(4)
+    step()
+    assert f.device_rows_steps == 2
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(l1).all()) and bool(torch.isfinite(l2).all())
+    assert all(bool(torch.isfinite(p).all()) for p in f.parameters())
+
+
 def test_deferred_factor_gradients_add_up_over_chunks(tiny_params):
     """with TVAdam(field=...) a batch larger than `chunk` makes several backward nodes; every one of them must land in
     the factor gradients (round 1 zeroed the buffer per backward call and kept only the last chunk's). Reference: the same chunked

@@ -15,6 +15,7 @@ KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_mlp",
 STAT_EVALUATED, STAT_APPEARANCE, STAT_RAYS, STAT_OVERFLOW, STAT_F16_REDO, STAT_LIST_RETRY = 0, 1, 2, 3, 4, 5
 
 FLAG_TRAIN, FLAG_ADD_BG, FLAG_KEEP_CTX, FLAG_COHERENT, FLAG_NDC = 1, 2, 4, 8, 16
+FLAG_DEVICE_ROWS = 32
 SHADE_IDS = {"MLP_Fea_noview": 0, "SH": 1, "RGB": 2, "MLP_Fea": 3, "MLP_PE": 4, "MLP": 5}   # MLP_PE: rejected in tensorf.py (broken upstream)
 ACT_IDS = {"softplus": 0, "relu": 1}
 
@@ -118,6 +119,7 @@ SIGNATURES = {
     "t2n_ndc_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                      C.c_void_p, C.c_void_p]),
     "t2n_render_ctx_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
+    "t2n_render_ctx_rows_try": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
     "t2n_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int64, C.c_int]),
     "t2n_render_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FieldGrads), C.c_void_p, C.c_size_t,

@@ -39,6 +39,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 struct TilePrefix { unsigned t[kLists + 1]; };   // tiles before each sub-list (host-computed from the counters)
 struct GradSet { float* plane[3]; float* line[3]; };
+// The same in device memory, for a backward that never reads the counters on the host (T2N_FLAG_DEVICE_ROWS): tile prefix and row
+// count from the forward's counters (k_bwd_plan), clipped to the row CAPACITY the caller's buffers hold; overflow = the count
+// exceeded it (the rows beyond take no part in this backward: the caller learns it from the forward's posted counters)
+struct BwdPlan { TilePrefix tp; unsigned rows; unsigned overflow; };
 
 __device__ __forceinline__ unsigned slot_to_row(unsigned slot, unsigned list_cap, const TilePrefix& tp) {
     const unsigned l = slot / list_cap;
@@ -245,6 +249,7 @@ struct BwdMarchArgs {
     const float* d_rgb; const float* d_depth; const float* d_w;
     float4* go;   // [rows] dL/d(pre-sigmoid rgb) per appearance row
     unsigned list_cap; TilePrefix tp; int add_bg;
+    const BwdPlan* plan;   // when set: the tile prefix comes from device memory (T2N_FLAG_DEVICE_ROWS)
     // BIN: dL/dfeature per sample goes to gfeat [n_rays, N] (aliases sigma) and the (plane, tile) histogram is counted
     float* gfeat; unsigned* hist; BlockGeom geom;
 };
@@ -305,7 +310,8 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
             // MLP heads: rgb = sigmoid(o): dL/do = dL/drgb * rgb (1 - rgb), dL/drgb_sample = g_c * w. SH / RGB heads end without a
             // sigmoid: their backward (k_simple_head_bwd) takes dL/drgb itself
             const bool sig = F.shading != T2N_SHADE_SH && F.shading != T2N_SHADE_RGB;
-            a.go[slot_to_row(slot, a.list_cap, a.tp)] =
+            const unsigned row = a.plan ? slot_to_row(slot, a.list_cap, a.plan->tp) : slot_to_row(slot, a.list_cap, a.tp);
+            if (!a.plan || row < a.plan->rows) a.go[row] =
                 make_float4(gr * w * (sig ? cr * (1.f - cr) : 1.f), gg * w * (sig ? cg * (1.f - cg) : 1.f),
                             gb * w * (sig ? cb * (1.f - cb) : 1.f), 0.f);
         }
@@ -813,21 +819,24 @@ __global__ __launch_bounds__(kAccThreads) void k_bwd_tile_accum(const TileAccumA
 struct AppBinArgs {
     FactorSet S; BinGeom geom; const float4* app_pos; const unsigned* counters; unsigned list_cap; TilePrefix tp; long long rows;
     unsigned* hist; const unsigned* tile_start; float4* recs;
+    const BwdPlan* plan;   // when set: tile prefix and row count from device memory (rows = the capacity the grid was sized for)
 };
 template <int PASS>
 __global__ __launch_bounds__(256) void k_app_bin(const AppBinArgs a) {
     const int lane = threadIdx.x & 63;
     const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long row = wv * 64 + lane;
-    if (wv * 64 >= a.rows) return;
+    const long long rows = a.plan ? (long long)a.plan->rows : a.rows;
+    if (wv * 64 >= rows) return;
+    const TilePrefix& tp = a.plan ? a.plan->tp : a.tp;
     int key[3] = {-1, -1, -1};
     float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < a.rows) {
+    if (row < rows) {
         const unsigned tile = (unsigned)(row >> 5);
         int l = 0;
 #pragma unroll
-        for (int q = 1; q < kLists; ++q) l += (a.tp.t[q] <= tile) ? 1 : 0;
-        const unsigned slot = (unsigned)(row - (long long)a.tp.t[l] * 32);
+        for (int q = 1; q < kLists; ++q) l += (tp.t[q] <= tile) ? 1 : 0;
+        const unsigned slot = (unsigned)(row - (long long)tp.t[l] * 32);
         unsigned cnt = a.counters[l * kCounterStride];
         if (cnt > a.list_cap) cnt = a.list_cap;
         if (slot < cnt) {
@@ -938,7 +947,7 @@ __global__ __launch_bounds__(256) void k_relayout_add(const RelayoutAddMulti a) 
 
 // Activation / gradient rows of the backward pass. Buffers whose lifetimes do not overlap (or that are rewritten
 // element-in-place by the same thread) share storage: g1 over h1, g0 over h0, gx over xpe, gf over feat32, gX over x144.
-struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, gpack, hist, bin_total, tile_start, nseg, segs, recs, a_hist, a_bin_total, a_tile_start, a_nseg, a_segs, a_recs, total; unsigned seg_cap, a_seg_cap; };
+struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, gpack, hist, bin_total, tile_start, nseg, segs, recs, a_hist, a_bin_total, a_tile_start, a_nseg, a_segs, a_recs, plan, total; unsigned seg_cap, a_seg_cap; };
 static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_tiles, int n_blocks, int k0 = 351) {   // k0: inputs of MLP layer 0; n_blocks: density bins x copies
     BwdCarve c;
@@ -969,6 +978,7 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
     c.a_nseg = o; o = al256(o + 4);
     c.a_segs = o; o = al256(o + (size_t)c.a_seg_cap * 16);
     c.a_recs = o; o = al256(o + 3 * R * 16);
+    c.plan = o; o = al256(o + sizeof(BwdPlan));
     c.total = o;
     return c;
 }
@@ -1007,6 +1017,32 @@ static int ensure_grad_buffers(t2n_field* f) {
     f->gbuf_external = false;
     grad_slices(f, off);
     return T2N_OK;
+}
+
+// The plan of a backward that reads no count on the host: one wave turns the forward's sub-list counters into the tile prefix and the
+// row count, clipped to the capacity; the forward's statement that it kept the activation rows with exactly this capacity is checked here
+// too (a mismatch leaves rows = 0: nothing of the appearance branch runs, overflow says why)
+__global__ __launch_bounds__(64) void k_bwd_plan(const unsigned* __restrict__ counters, unsigned list_cap, unsigned rows_cap, unsigned kept_rows,
+                                                 BwdPlan* __restrict__ plan) {
+    const int lane = threadIdx.x;
+    unsigned cnt = lane < kLists ? counters[lane * kCounterStride] : 0u;
+    if (cnt > list_cap) cnt = list_cap;
+    unsigned incl = (cnt + 31u) / 32u;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const unsigned excl = incl - (cnt + 31u) / 32u;
+    if (lane < kLists) plan->tp.t[lane] = excl;
+    const unsigned total = __shfl(incl, kLists - 1);
+    if (lane == 0) {
+        plan->tp.t[kLists] = total;
+        const bool stated = counters[kKeptMagicWord] == kKeptMagic && counters[kKeptRowsWord] == kept_rows;
+        const unsigned rows = total * 32u;
+        plan->overflow = (!stated || rows > rows_cap) ? 1u : 0u;
+        plan->rows = !stated ? 0u : (rows < rows_cap ? rows : rows_cap);
+    }
 }
 
 }  // namespace t2n
@@ -1095,6 +1131,25 @@ extern "C" int t2n_render_ctx_rows(const void* fwd_workspace, int64_t n_rays, in
     return read_counts(fwd_workspace, n_rays, n_samples, (hipStream_t)stream, counts, nullptr, rows);
 }
 
+// The same without waiting: *rows = -1 while the forward's counters have not reached the host yet (or their slot was evicted)
+extern "C" int t2n_render_ctx_rows_try(const void* fwd_workspace, int64_t n_rays, int n_samples, int64_t* rows) {
+    if (!fwd_workspace || !rows || n_rays <= 0 || n_samples <= 0) { set_error("t2n_render_ctx_rows_try: bad argument"); return T2N_ERR_INVALID; }
+    *rows = -1;
+    int dev = 0;
+    T2N_HIP(hipGetDevice(&dev));
+    const Carve c = carve_workspace(n_rays, n_samples, true, false);
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    for (auto& q : g_ctx)
+        if (q.valid && q.ws == fwd_workspace && q.dev == dev) {
+            if (hipEventQuery(q.ev) != hipSuccess) { (void)hipGetLastError(); return T2N_OK; }
+            unsigned t = 0;
+            for (int l = 0; l < kLists; ++l) { unsigned n = q.host[l * kCounterStride]; if (n > c.list_cap) n = c.list_cap; t += (n + 31u) / 32u; }
+            *rows = (int64_t)t * 32;
+            return T2N_OK;
+        }
+    return T2N_OK;
+}
+
 extern "C" size_t t2n_backward_workspace_bytes(const t2n_field* f, int64_t rows, int64_t n_rays, int n_samples) {
     if (!f || n_rays <= 0 || n_samples <= 0) return 0;
     const int k0 = head_is_generic(f->desc.shading) ? head_dims(f->desc).K0 : 351;
@@ -1126,13 +1181,34 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     hipStream_t s = (hipStream_t)stream;
     unsigned counts[kLists];
     TilePrefix tp;
+    memset(&tp, 0, sizeof(tp));
     int64_t rows = 0;
     unsigned kept_stated = 0;
-    int rc = read_counts(fwd_workspace, n_rays, n_samples, s, counts, &tp, &rows, &kept_stated, true);
-    if (rc) return rc;
-    const int64_t rows_alloc = rows < 32 ? 32 : rows;
+    int rc = T2N_OK;
     const BinGeom geom = bin_geom(f->dev.den);
     const BlockGeom bgeom = block_geom(f->dev.den);
+    // T2N_FLAG_DEVICE_ROWS: nothing is read back. The row CAPACITY is what both workspaces hold (the forward's kept activation rows, the
+    // backward's row buffers); k_bwd_plan derives tile prefix and row count on the device and every row-streaming kernel clips to it.
+    const bool dev_rows = (flags & T2N_FLAG_DEVICE_ROWS) != 0;
+    if (dev_rows) {
+        const KeptRows kc = kept_rows(c.total, fwd_workspace_bytes);
+        if (generic || simple || gemm_fp32_mode(f) || f->desc.app_dim != 27 || K0 != 351 || kc.rows < 32 || f->dev.app.C != 48) {
+            set_error("t2n_render_backward: T2N_FLAG_DEVICE_ROWS needs the fused MLP_Fea_noview head in split-f16 mode and a forward workspace with kept activation rows");
+            return T2N_ERR_UNSUPPORTED;
+        }
+        int64_t lo = 0, hi = (int64_t)kc.rows / 32;     // largest capacity (in tiles) whose backward buffers fit
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) / 2;
+            if (bwd_carve(mid * 32, n_rays, n_samples, geom.total, bgeom.total * bgeom.copies, K0).total <= bwd_workspace_bytes) lo = mid; else hi = mid - 1;
+        }
+        if (lo < 1) { set_error("t2n_render_backward: backward workspace %zu B holds no row", bwd_workspace_bytes); return T2N_ERR_WORKSPACE; }
+        rows = lo * 32;
+        kept_stated = kc.rows;       // (checked on the device by k_bwd_plan)
+    } else {
+        rc = read_counts(fwd_workspace, n_rays, n_samples, s, counts, &tp, &rows, &kept_stated, true);
+        if (rc) return rc;
+    }
+    const int64_t rows_alloc = rows < 32 ? 32 : rows;
     const BwdCarve b = bwd_carve(rows_alloc, n_rays, n_samples, geom.total, bgeom.total * bgeom.copies, K0);
     if (b.total > bwd_workspace_bytes) { set_error("t2n_render_backward: backward workspace %zu B < %zu B", bwd_workspace_bytes, b.total); return T2N_ERR_WORKSPACE; }
     if ((rc = ensure_grad_buffers(f))) return rc;
@@ -1157,6 +1233,12 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     const int* app_ray = (const int*)(fw + c.app_ray);
     float4* app_rgb = (float4*)(fw + c.app_rgb);
     const unsigned* counters = (const unsigned*)(fw + c.counters);
+    BwdPlan* plan = dev_rows ? (BwdPlan*)(bw + b.plan) : nullptr;
+    const unsigned* rows_dev = plan ? &plan->rows : nullptr;
+    if (plan) {
+        hipLaunchKernelGGL(k_bwd_plan, dim3(1), dim3(64), 0, s, counters, c.list_cap, (unsigned)rows, kept_stated, plan);
+        T2N_HIP(hipGetLastError());
+    }
 
     const int* gr = f->desc.grid;
     // a library-owned gradient buffer holds the gradients of THIS call; a caller-owned one (t2n_field_set_grad_buffer) accumulates
@@ -1192,7 +1274,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         a.rays = rays; a.n_rays = n_rays; a.ray_stride = ray_stride; a.n_samples = n_samples; a.npad = (n_samples + 63) & ~63;
         a.jitter = jitter; a.sigma = (const float*)(fw + c.sigma); a.ray_app = (const int4*)(fw + c.ray_app);
         a.app_rgb = app_rgb; a.rgb_raw = (const float4*)(fw + c.rgb_raw);
-        a.d_rgb = d_rgb; a.d_depth = d_depth; a.d_w = d_weights; a.go = go; a.list_cap = c.list_cap; a.tp = tp;
+        a.d_rgb = d_rgb; a.d_depth = d_depth; a.d_w = d_weights; a.go = go; a.list_cap = c.list_cap; a.tp = tp; a.plan = plan;
         a.add_bg = (flags & T2N_FLAG_ADD_BG) ? 1 : 0;
         const size_t lds = (size_t)4 * 4 * a.npad * sizeof(float);
         const unsigned nb = (unsigned)((n_rays + 3) / 4);
@@ -1204,6 +1286,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         static const bool force_atomic = getenv("T2N_BWD_ATOMIC_SCATTER") && atoi(getenv("T2N_BWD_ATOMIC_SCATTER")) != 0;
         bin = !force_atomic && lds_acc <= 160 * 1024 && block_geom_ok(f->dev.den) && (uint64_t)n_rays * n_samples * 3 < 0x7fffffffull;
         lds_bin = lds_acc;
+        if (plan && !bin) { set_error("t2n_render_backward: T2N_FLAG_DEVICE_ROWS needs the binned scatters (grid lines within the LDS budget)"); return T2N_ERR_UNSUPPORTED; }
         a.gfeat = (float*)(fw + c.sigma); a.hist = (unsigned*)(bw + b.hist); a.geom = bgeom;
         if (bin) {
             so.zero(a.hist, (size_t)bgeom.total * bgeom.copies * 4);
@@ -1276,8 +1359,8 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             // the input-gradient chain as ONE kernel (t2n_mlp_bwd_ss.hip): k_bwd_l2 only accumulates dW2 / db2 (h1 stays intact for it),
             // the chain writes g1 over h1 and g0 / gf / gX into the (otherwise unused) encoding buffer
             float* G0 = xpe; float* GF = xpe + (size_t)rows * 128; float* GX = xpe + (size_t)rows * 160;
-            launch_bwd_l2((const float4*)go, (const float*)h1, rows, P->mlp_w2, nullptr, g->mlp_w2, g->mlp_b2, part, s);
-            if ((rc = launch_mlp_bwd_ss(f, gpack, (const float4*)go, h1, h0, feat32, G0, GF, GX, rows, s, packed_early))) return rc;
+            launch_bwd_l2((const float4*)go, (const float*)h1, rows, P->mlp_w2, nullptr, g->mlp_w2, g->mlp_b2, part, s, rows_dev);
+            if ((rc = launch_mlp_bwd_ss(f, gpack, (const float4*)go, h1, h0, feat32, G0, GF, GX, rows, s, packed_early, rows_dev))) return rc;
             // From here two chains share nothing but read-only rows: the weight-gradient GEMMs (g1 / G0 / GF with h0 / features / x144
             // -> the MLP gradients, through `part`) and the appearance scatter (GX -> the factor gradient buffers). The GEMMs wait on
             // memory latency and workgroup barriers, the scatter on LDS atomics: they run side by side, the GEMMs on a third stream
@@ -1296,11 +1379,12 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
                 T2N_HIP(hipStreamWaitEvent(sg, (hipEvent_t)f->ev_fork2, 0));
                 side_gemm = true;
             }
-            if (g->mlp_w1) launch_gemm_tn(4, gemm_fp32, g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, sg, nullptr, g->mlp_b1);
+            if (plan && (!g->mlp_w1 || !g->mlp_w0)) { set_error("t2n_render_backward: T2N_FLAG_DEVICE_ROWS needs the weight-gradient tensors of both hidden layers"); return T2N_ERR_INVALID; }
+            if (g->mlp_w1) launch_gemm_tn(4, gemm_fp32, g1, 128, h0, 128, rows, 128, 128, g->mlp_w1, 128, part, sg, nullptr, g->mlp_b1, rows_dev);
             else if (g->mlp_b1) launch_colsum((const float*)g1, 128, (long long)rows, 128, g->mlp_b1, sg);
-            if (g->mlp_w0) launch_gemm_tn(4, gemm_fp32, G0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, sg, feat32, g->mlp_b0);
+            if (g->mlp_w0) launch_gemm_tn(4, gemm_fp32, G0, 128, xpe, K0pad, rows, 128, K0, g->mlp_w0, K0, part, sg, feat32, g->mlp_b0, rows_dev);
             else if (g->mlp_b0) launch_colsum((const float*)G0, 128, (long long)rows, 128, g->mlp_b0, sg);
-            if (g->basis_weight) launch_gemm_tn(1, gemm_fp32, GF, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, sg);
+            if (g->basis_weight) launch_gemm_tn(1, gemm_fp32, GF, 32, x144, 144, rows, f->desc.app_dim, 144, g->basis_weight, 144, part, sg, nullptr, nullptr, rows_dev);
             if (side_gemm) T2N_HIP(hipEventRecord((hipEvent_t)f->ev_join2, sg));
             gxapp = GX;
         } else {
@@ -1339,7 +1423,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             // tile-binned: count -> scan -> write records -> LDS accumulate, 16 channels per workgroup
             AppBinArgs ab;
             ab.S = f->dev.app; ab.geom = bin_geom(f->dev.app); ab.app_pos = app_pos; ab.counters = counters; ab.list_cap = c.list_cap;
-            ab.tp = tp; ab.rows = rows; ab.hist = (unsigned*)(bw + b.a_hist); ab.tile_start = (const unsigned*)(bw + b.a_tile_start); ab.recs = (float4*)(bw + b.a_recs);
+            ab.plan = plan; ab.tp = tp; ab.rows = rows; ab.hist = (unsigned*)(bw + b.a_hist); ab.tile_start = (const unsigned*)(bw + b.a_tile_start); ab.recs = (float4*)(bw + b.a_recs);
             const unsigned nbk = (unsigned)((rows + 255) / 256);
             hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, s, ab);
             launch_bin_scan(ab.hist, ab.geom.total, kBinCopies, (unsigned*)(bw + b.a_bin_total), (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),

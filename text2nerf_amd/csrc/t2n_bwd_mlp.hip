@@ -13,8 +13,12 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __bu
 
 // ---- layer 2 (3 outputs): VALU ------------------------------------------------------------------------------------------
 // go [rows,4], h1 [rows,128] -> g1 [rows,128] = (go W2) * [h1>0]; dW2[3,128] += go^T h1; db2[3] += colsum(go)
+// rows_dev (all row-streaming kernels of the backward, optional): the row count in DEVICE memory — the backward of a speculative
+// train step (T2N_FLAG_DEVICE_ROWS) sizes its grids and buffers from a row CAPACITY and never reads the count on the host; `rows` is
+// then the capacity and the kernels clip it (k_bwd_plan, t2n_backward.hip)
 __global__ __launch_bounds__(256) void k_bwd_l2(const float4* __restrict__ go, const float* __restrict__ h1, long long rows,
-                                                const float* __restrict__ w2, float* g1, float* __restrict__ part) {
+                                                const float* __restrict__ w2, float* g1, float* __restrict__ part, const unsigned* __restrict__ rows_dev) {
+    if (rows_dev) rows = rows < (long long)*rows_dev ? rows : (long long)*rows_dev;
     // The kernel is a [rows, 128] stream with 3 x 128 running sums: memory-latency bound unless enough of it is in flight. Thread
     // (c, q) = (tid & 31, tid >> 5) owns units 4c .. 4c+3 (one 16-byte load per row) of rows base + 8k + q, k = 0..7: eight rows per
     // thread and 64 rows per workgroup in flight, 1024 workgroups (grid-stride). The one-dword-per-thread, four-rows-in-flight,
@@ -91,7 +95,12 @@ __global__ __launch_bounds__(256) void k_bwd_l2_reduce(const float* __restrict__
 // is stored to `part` [chunks][MB*32][ldp] and k_gemm_tn_reduce sums the chunks into C (deterministic, no atomics).
 template <int MB>
 __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                 long long rows, int N, float* __restrict__ part, int ldp, int chunk_rows) {
+                                                 long long rows, int N, float* __restrict__ part, int ldp, int chunk_rows, const unsigned* __restrict__ rows_dev) {
+    if (rows_dev) {   // (see k_bwd_l2; chunks re-cut for the actual row count)
+        rows = rows < (long long)*rows_dev ? rows : (long long)*rows_dev;
+        const long long c = ((rows + gridDim.y - 1) / gridDim.y + 31) / 32 * 32;
+        chunk_rows = c < 64 ? 64 : (int)c;
+    }
     constexpr int MA = MB * 32;            // staged A columns
     constexpr int A4 = MA / 4;             // float4 per staged A row
     constexpr int NA = (32 * A4) / 256;    // float4 loads per thread for the A tile (MB=4: 4, MB=1: 1)
@@ -338,10 +347,10 @@ size_t tn_part_bytes(int64_t rows, int k0) {
 // layer 2 of the backward: up to kL2Blocks workgroups of 64 rows in flight each, their partial weight / bias sums through `scratch`
 // (>= kL2Blocks x 388 floats: the weight-gradient GEMMs' partial buffer, not in use yet)
 void launch_bwd_l2(const float4* go, const float* h1, long long rows, const float* w2, float* g1, float* dw2, float* db2,
-                          float* scratch, hipStream_t s) {
+                          float* scratch, hipStream_t s, const unsigned* rows_dev) {
     const long long tiles = (rows + 63) / 64;
     const unsigned nb = (unsigned)(tiles < kL2Blocks ? tiles : kL2Blocks);
-    hipLaunchKernelGGL(k_bwd_l2, dim3(nb), dim3(256), 0, s, go, h1, rows, w2, g1, scratch);
+    hipLaunchKernelGGL(k_bwd_l2, dim3(nb), dim3(256), 0, s, go, h1, rows, w2, g1, scratch, rows_dev);
     if (dw2 || db2) hipLaunchKernelGGL(k_bwd_l2_reduce, dim3(387), dim3(256), 0, s, (const float*)scratch, (int)nb, dw2, db2);
 }
 // the fp32-MFMA GEMMs instead of the f16 / bf16 split ones (t2n_gemm_h.hip, t2n_mlp_bwd_ss.hip): when the field runs its MLP in exact
@@ -351,14 +360,14 @@ bool gemm_fp32_mode(const t2n_field* f) { return !f->mlp_split; }
 // GEMM and `B` is never read. db (may be NULL): += column sums of A (the layer's bias gradient).
 template <int MB>
 static void launch_gemm_tn_t(bool fp32, const float* A, int lda, const float* B, int ldb, long long rows, int M, int N, float* C, int ldc,
-                           float* part, hipStream_t s, const float* pe_feat, float* db) {
+                           float* part, hipStream_t s, const float* pe_feat, float* db, const unsigned* rows_dev) {
     const TnPlan p = tn_plan(rows, N);
     if (!fp32 && MB == 4) {   // (the 27-row basis gradient is latency-bound either way: 31 us fp32, 44 us bf16x3)
         (void)launch_gemm_tn_b(A, lda, pe_feat ? pe_feat : B, pe_feat ? 32 : ldb, rows, N, part, p.ldp, p.chunk_rows, p.ng, p.chunks,
-                               pe_feat != nullptr, db, s);
+                               pe_feat != nullptr, db, s, rows_dev);
     } else {
         hipLaunchKernelGGL((k_gemm_tn<MB>), dim3((unsigned)p.ng, (unsigned)p.chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part,
-                           p.ldp, p.chunk_rows);
+                           p.ldp, p.chunk_rows, rows_dev);
         if (db) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, A, lda, rows, M, db, 128);
     }
     hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((MB * 32 * p.ldp + 31) / 32)), dim3(256), 0, s, (const float*)part,
@@ -379,9 +388,9 @@ void launch_gemm_nn(const float* IN, int ldin, const float* W, int ldw, long lon
 
 // MB = 4: M <= 128 rows of A per workgroup tile; MB = 1: M <= 32 (the 27-row basis gradient)
 void launch_gemm_tn(int MB, bool fp32, const float* A, int lda, const float* B, int ldb, long long rows, int M, int N, float* C, int ldc,
-                    float* part, hipStream_t s, const float* pe_feat, float* db) {
-    if (MB == 4) launch_gemm_tn_t<4>(fp32, A, lda, B, ldb, rows, M, N, C, ldc, part, s, pe_feat, db);
-    else launch_gemm_tn_t<1>(fp32, A, lda, B, ldb, rows, M, N, C, ldc, part, s, pe_feat, db);
+                    float* part, hipStream_t s, const float* pe_feat, float* db, const unsigned* rows_dev) {
+    if (MB == 4) launch_gemm_tn_t<4>(fp32, A, lda, B, ldb, rows, M, N, C, ldc, part, s, pe_feat, db, rows_dev);
+    else launch_gemm_tn_t<1>(fp32, A, lda, B, ldb, rows, M, N, C, ldc, part, s, pe_feat, db, rows_dev);
 }
 static unsigned colsum_grid(long long rows) { return (unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512); }
 void launch_colsum(const float* G, int ld, long long rows, int N, float* db, hipStream_t s) {

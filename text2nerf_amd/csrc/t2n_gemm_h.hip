@@ -213,7 +213,12 @@ __device__ __forceinline__ Op3 split_unit(const float (&x)[8]) {
 template <int MB, bool PE>
 __global__ __launch_bounds__(256) void k_gemm_tn_b(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                    long long rows, int N, float* __restrict__ part, int ldp, int chunk_rows,
-                                                   float* __restrict__ bsum) {
+                                                   float* __restrict__ bsum, const unsigned* __restrict__ rows_dev) {
+    if (rows_dev) {   // (see k_bwd_l2) the chunks are re-cut for the actual row count: every workgroup of the capacity-sized grid gets its share
+        rows = rows < (long long)*rows_dev ? rows : (long long)*rows_dev;
+        const long long c = ((rows + gridDim.y - 1) / gridDim.y + 31) / 32 * 32;
+        chunk_rows = c < 64 ? 64 : (int)c;
+    }
     __shared__ __attribute__((aligned(16))) uint4 sA[2][MB][3][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 31, kh = lane >> 5;
     const int ng = blockIdx.x;
@@ -369,10 +374,10 @@ int launch_gemm_nn_h(void* packbuf, int which, int K0, const float* IN, int ldin
 // part[chunks][128][ldp] = per-chunk A^T B for the 128-column gradients (the caller reduces the chunks). pe: B = feat [rows, 32] and the
 // product is with its positional encoding (N = 351). db (may be NULL): += column sums of A.
 int launch_gemm_tn_b(const float* A, int lda, const float* B, int ldb, long long rows, int N, float* part, int ldp, int chunk_rows,
-                     int ng, int chunks, bool pe, float* db, hipStream_t s) {
+                     int ng, int chunks, bool pe, float* db, hipStream_t s, const unsigned* rows_dev) {
     using namespace gh;
-    if (pe) hipLaunchKernelGGL((k_gemm_tn_b<4, true>), dim3((unsigned)ng, (unsigned)chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part, ldp, chunk_rows, db);
-    else hipLaunchKernelGGL((k_gemm_tn_b<4, false>), dim3((unsigned)ng, (unsigned)chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part, ldp, chunk_rows, db);
+    if (pe) hipLaunchKernelGGL((k_gemm_tn_b<4, true>), dim3((unsigned)ng, (unsigned)chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part, ldp, chunk_rows, db, rows_dev);
+    else hipLaunchKernelGGL((k_gemm_tn_b<4, false>), dim3((unsigned)ng, (unsigned)chunks), dim3(256), 0, s, A, lda, B, ldb, rows, N, part, ldp, chunk_rows, db, rows_dev);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

@@ -219,14 +219,14 @@ int gemm_h_pack(t2n_field* f, void* buf, int K0, hipStream_t s);
 int launch_gemm_nn_h(void* packbuf, int which, int K0, const float* IN, int ldin, long long rows, const float* ACT, int ldact, float* OUT,
                      int ldo, hipStream_t s);
 int launch_gemm_tn_b(const float* A, int lda, const float* B, int ldb, long long rows, int N, float* part, int ldp, int chunk_rows,
-                     int ng, int chunks, bool pe, float* db, hipStream_t s);
+                     int ng, int chunks, bool pe, float* db, hipStream_t s, const unsigned* rows_dev = nullptr);
 // MLP part of the render backward: fp32-MFMA GEMMs, layer 2, bias sums, positional encoding (t2n_bwd_mlp.hip)
 size_t tn_part_bytes(int64_t rows, int k0);   // partial-sum scratch of the weight-gradient GEMMs (and of layer 2) for `rows` rows
 bool gemm_fp32_mode(const t2n_field* f);
 void launch_bwd_l2(const float4* go, const float* h1, long long rows, const float* w2, float* g1, float* dw2, float* db2, float* scratch,
-                   hipStream_t s);
+                   hipStream_t s, const unsigned* rows_dev = nullptr);   // rows_dev: the row count in device memory (rows = capacity then)
 void launch_gemm_tn(int MB, bool fp32, const float* A, int lda, const float* B, int ldb, long long rows, int M, int N, float* C, int ldc,
-                    float* part, hipStream_t s, const float* pe_feat = nullptr, float* db = nullptr);
+                    float* part, hipStream_t s, const float* pe_feat = nullptr, float* db = nullptr, const unsigned* rows_dev = nullptr);
 void launch_gemm_nn(const float* IN, int ldin, const float* W, int ldw, long long rows, int K, int N, const float* ACT, int ldact, float* OUT,
                     int ldo, hipStream_t s);
 void launch_colsum(const float* G, int ld, long long rows, int N, float* db, hipStream_t s);
@@ -235,7 +235,7 @@ void launch_pe_bwd(const float* gx, const float* feat, long long rows, float* gf
 // fused input-gradient chain of the MLP_Fea_noview head's backward (t2n_mlp_bwd_ss.hip)
 size_t mlp_bwd_ss_pack_bytes();
 int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, const float* h0, const float* feat, float* g0, float* gf,
-                      float* gx, long long rows, hipStream_t s, bool packed = false);
+                      float* gx, long long rows, hipStream_t s, bool packed = false, const unsigned* rows_dev = nullptr);
 int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed);
 void* mlp_bwd_ss_absmax_words(void* packbuf);
 // forward-workspace carve shared by forward and backward (t2n_api.hip)

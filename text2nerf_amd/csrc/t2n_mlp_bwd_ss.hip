@@ -43,6 +43,7 @@ struct Args {
     const float4* go; float* h1; const float* h0; const float* feat;   // h1 is overwritten with g1
     float* g0; float* gf; float* gx;                                   // [rows,128], [rows,32], [rows,144]
     long long rows;                                                    // a multiple of 32
+    const unsigned* rows_dev;                                          // optional: the row count in device memory (rows = capacity; see k_bwd_l2)
     float neg1;
 };
 
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_ss(const Args a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const long long ntiles = a.rows / 32;
+    const long long ntiles = (a.rows_dev && (long long)*a.rows_dev < a.rows ? (long long)*a.rows_dev : a.rows) / 32;
     const long long nrounds = (ntiles + 7) / 8;
     if ((long long)blockIdx.x >= nrounds) return;
     unsigned ob0 = (unsigned)lane * 16u, ob1 = (unsigned)lane * 16u + 65536u, ob2 = (unsigned)lane * 16u + 131072u;
@@ -476,7 +477,7 @@ int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed) {
 }
 
 int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, const float* h0, const float* feat, float* g0, float* gf,
-                      float* gx, long long rows, hipStream_t s, bool packed) {
+                      float* gx, long long rows, hipStream_t s, bool packed, const unsigned* rows_dev) {
     using namespace bss;
     if (!packed) { const int rc = mlp_bwd_ss_pack(f, packbuf, s, false); if (rc) return rc; }
     uint4* base = (uint4*)packbuf;
@@ -490,7 +491,7 @@ int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, 
     }
     Args a;
     a.a2 = pa.a2; a.a1 = pa.a1; a.a0 = pa.a0; a.ab = pa.ab; a.inv_scale = pa.scales + 4;
-    a.go = go; a.h1 = h1; a.h0 = h0; a.feat = feat; a.g0 = g0; a.gf = gf; a.gx = gx; a.rows = rows; a.neg1 = -1.f;
+    a.go = go; a.h1 = h1; a.h0 = h0; a.feat = feat; a.g0 = g0; a.gf = gf; a.gx = gx; a.rows = rows; a.rows_dev = rows_dev; a.neg1 = -1.f;
     const long long nrounds = (rows / 32 + 7) / 8;
     hipLaunchKernelGGL(k_mlp_bwd_ss, dim3((unsigned)(nrounds < 256 ? nrounds : 256)), dim3(512), kLds, s, a);
     T2N_HIP(hipGetLastError());

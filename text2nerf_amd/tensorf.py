@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import FLAG_ADD_BG, FLAG_COHERENT, FLAG_KEEP_CTX, FLAG_NDC, FLAG_TRAIN, T2NError
+from ._lib import FLAG_ADD_BG, FLAG_COHERENT, FLAG_DEVICE_ROWS, FLAG_KEEP_CTX, FLAG_NDC, FLAG_TRAIN, T2NError
 
 MAT_MODE = [[0, 1], [0, 2], [1, 2]]
 VEC_MODE = [2, 1, 0]
@@ -1140,6 +1140,7 @@ class TensorBase(nn.Module):
             rows_hint = int(getattr(self, "_ctx_rows_hint", 0))
             rows_hint = _ladder(rows_hint) // 32 * 32 if rows_hint else 0     # (a few distinct sizes over a run: the allocator reuses its blocks)
             need = int(lib.t2n_render_workspace_bytes_ctx(R, N)) + (256 + rows_hint * 1728 if rows_hint else 0)
+            self._ctx_rows_cap = rows_hint
             if reuse_ctx:
                 # train_step: the step's backward is queued before the next step's forward, so ONE retained buffer serves every step
                 # (stream order); it grows like workspace() does — old buffer dropped first, cached blocks returned to the driver
@@ -1175,7 +1176,7 @@ class TensorBase(nn.Module):
             return rgb, depth, z, w, ws
         return rgb, depth, z, w
 
-    def _backward_raw(self, rays, jitter, N, flags, ws, d_rgb, d_depth, d_w, head_grads=None):
+    def _backward_raw(self, rays, jitter, N, flags, ws, d_rgb, d_depth, d_w, head_grads=None, device_rows=False):
         """t2n_render_backward for a KEEP_CTX forward (workspace `ws`): returns the 19 gradient tensors in autograd order (None for the
         12 factor tensors in deferred mode: those accumulate in factor_grad_buffer()). `head_grads`: optional preallocated, zeroed
         gradient tensors of the 7 head tensors (train_step reuses one flat buffer)."""
@@ -1206,6 +1207,19 @@ class TensorBase(nn.Module):
         d_depth = torch.zeros(R, device=dev) if d_depth is None else d_depth.contiguous().float()
         d_w = None if d_w is None else d_w.contiguous().float()
         st = _lib.current_stream_ptr(dev)
+        if device_rows:
+            # nothing is read back: the capacity is the hint the forward kept its activation rows with; the kernels clip to the
+            # row count on the device (T2N_FLAG_DEVICE_ROWS). train_step polls the count afterwards, without waiting.
+            with torch.cuda.device(dev):
+                need = int(lib.t2n_backward_workspace_bytes(self._handle, int(self._ctx_rows_cap), R, N))
+                have = _WORKSPACE.get(_ws_key(dev))
+                bws = workspace(dev, need) if have is not None and have.numel() >= need else workspace(dev, int(need * 1.25))
+                _lib.check(lib.t2n_render_backward(self._handle, _lib.ptr(rays), R, rays.shape[1], N, flags | FLAG_KEEP_CTX | FLAG_DEVICE_ROWS,
+                                                   _lib.ptr(jitter), _lib.ptr(d_rgb), _lib.ptr(d_depth), _lib.ptr(d_w),
+                                                   C.byref(gs), _lib.ptr(ws), ws.numel(), _lib.ptr(bws), bws.numel(),
+                                                   st), "t2n_render_backward")
+            self._deferred_grad_key = self._uploaded_key if defer else None
+            return grads
         with torch.cuda.device(dev):
             rows = C.c_int64(0)
             # the counts reached pinned host memory behind the forward's march kernel: this waits for that copy's event, not
@@ -1283,7 +1297,7 @@ class TensorBase(nn.Module):
         return grads
 
     def train_step(self, rays, rgb_target, depth_target, optimizer, N_samples=-1, white_bg=True, w_depth=0.005, w_trans=1e3, delta=0.1,
-                   tv=(), all_reduce=None, all_reduce_averages=True):
+                   tv=(), all_reduce=None, all_reduce_averages=True, speculative=False):
         """One optimisation step of text2nerf_main.py:547-590 without the autograd graph: render (train mode, CPU-generator jitter
         like models/tensorBase.py:313-317) -> the driver's loss as ONE kernel that emits d_rgb / d_depth / d_weights
         (t2n_train_loss) -> t2n_render_backward -> optimizer.step(). `optimizer`: optim.TVAdam(field=self) (TV terms via `tv`, as
@@ -1291,7 +1305,12 @@ class TensorBase(nn.Module):
         lambda: parallel.allreduce_gradients(params, field=self)); it must AVERAGE over the ranks (the TV terms, identical on every
         rank, may already sit in the gradient buffer when it runs: a mean leaves them as they are, a sum would multiply them by the
         world size) — pass all_reduce_averages=False for any other reduction and the TV terms are added after it. Returns the device tensor [mse, depth loss, transmittance loss,
-        total] of this batch (no host synchronisation). Same arithmetic as the autograd path: tests/test_train_step.py."""
+        total] of this batch (no host synchronisation). Same arithmetic as the autograd path: tests/test_train_step.py.
+        `speculative=True`: the backward does not wait for the forward's appearance row count either (T2N_FLAG_DEVICE_ROWS): its
+        row capacity is 1.25x what the previous step needed, the kernels clip to the actual count on the device, and the host learns
+        the count one step later without waiting. A step whose count exceeds the capacity drops the appearance gradients of the
+        rows past it — counted in `self.device_rows_overflows`, and the next step runs with the larger capacity. The first step (and
+        any step after an overflow) takes the counted route."""
         lib = _lib.load()
         params = self._autograd_params()
         if any(not p.is_leaf for p in params):
@@ -1315,6 +1334,10 @@ class TensorBase(nn.Module):
                 and self.supports_deferred_factor_grads() and (all_reduce is None or all_reduce_averages):
             seed_ev = self.seed_factor_grads_with_tv(tv)
             seed_terms, tv = list(tv), ()
+        device_rows = False
+        if speculative:
+            device_rows = self._poll_device_rows() and bool(self.keep_activation_rows) and int(getattr(self, "_ctx_rows_hint", 0)) > 0 \
+                and self.shadingMode == "MLP_Fea_noview" and not self.mlp_exact_fp32
         head = params[12:]
         if getattr(self, "_head_flat", None) is None or self._head_flat.numel() != sum(p.numel() for p in head):
             self._head_flat = torch.zeros(sum(p.numel() for p in head), device=dev)
@@ -1335,7 +1358,10 @@ class TensorBase(nn.Module):
                 off += p.numel()
             if seed_ev is not None:
                 torch.cuda.current_stream(dev).wait_event(seed_ev)
-            grads = self._backward_raw(rays, jitter, N, flags, ws, d_rgb, d_depth, d_w, head_grads=views)
+            grads = self._backward_raw(rays, jitter, N, flags, ws, d_rgb, d_depth, d_w, head_grads=views, device_rows=device_rows)
+            if device_rows:
+                self._device_rows_pending = (ws.data_ptr(), R, N, int(self._ctx_rows_cap))
+                self.device_rows_steps = getattr(self, "device_rows_steps", 0) + 1
             for p, g in zip(params, grads):
                 p.grad = g
             if all_reduce is not None:
@@ -1344,6 +1370,26 @@ class TensorBase(nn.Module):
             if seed_terms is not None:
                 self.seed_factor_grads_with_tv(seed_terms, ahead=True)
         return losses
+
+    def _poll_device_rows(self):
+        """The row count of the previous speculative step, read without waiting (its forward finished long ago in any loop that is not
+        already GPU-bound). Updates the capacity hint; False = that step overflowed its capacity (the next one takes the counted route,
+        which re-learns the hint) . An unanswered poll keeps the hint."""
+        pend, self._device_rows_pending = getattr(self, "_device_rows_pending", None), None
+        if pend is None:
+            return True
+        lib = _lib.load()
+        ptr, R, N, cap = pend
+        rows = C.c_int64(-1)
+        _lib.check(lib.t2n_render_ctx_rows_try(C.c_void_p(ptr), R, N, C.byref(rows)), "t2n_render_ctx_rows_try")
+        if rows.value < 0:
+            self.device_rows_unanswered = getattr(self, "device_rows_unanswered", 0) + 1
+            return True
+        self._ctx_rows_hint = (int(rows.value * 1.25) + 95) // 32 * 32
+        if rows.value > cap:
+            self.device_rows_overflows = getattr(self, "device_rows_overflows", 0) + 1
+            return False
+        return True
 
     def stats(self):
         """Counters of the last render call (one device->host copy): evaluated / appearance samples, overflow."""
