@@ -1265,6 +1265,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     hipStream_t den_stream = s;   // the stream the density gradients are finished on
     bool side_gemm = false;   // the weight-gradient GEMMs were put on the third stream: joined before step 6
     bool packed_early = false;   // k_mlp_bwd_ss's operands were packed in front of k_bwd_march
+    bool pack_side = false;      // ... on the third stream: joined in front of k_mlp_bwd_ss
     bool bin = false;
     size_t lds_bin = 0;
     {
@@ -1296,7 +1297,31 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
         const bool pack_now = rows > 0 && !generic && !simple && !gemm_fp32_mode(f) && f->desc.app_dim == 27 && K0 == 351;
         if (pack_now) so.zero(mlp_bwd_ss_absmax_words((void*)(bw + b.gpack)), 16);
         if ((rc = launch_setup(so, s))) return rc;
-        if (pack_now && (rc = mlp_bwd_ss_pack(f, (void*)(bw + b.gpack), s, true))) return rc;
+        static const bool serial = getenv("T2N_BWD_SERIAL") != nullptr;
+        if (pack_now) {
+            // ... on the third stream (idle until the weight-gradient GEMMs): two 6-us kernels off the caller's stream, joined in front
+            // of k_mlp_bwd_ss, behind k_bwd_march and layer 2
+            hipStream_t sp = s;
+#ifndef T2N_PACK_ON_CALLER_STREAM
+#define T2N_PACK_ON_CALLER_STREAM 0
+#endif
+            if (!serial && bin && !T2N_PACK_ON_CALLER_STREAM) {
+                if (!f->gemm_stream) {
+                    hipStream_t st; hipEvent_t e0, e1;
+                    T2N_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                    T2N_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+                    T2N_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+                    f->gemm_stream = (void*)st; f->ev_fork2 = (void*)e0; f->ev_join2 = (void*)e1;
+                }
+                if (!f->ev_pack) { hipEvent_t e; T2N_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); f->ev_pack = (void*)e; }
+                sp = (hipStream_t)f->gemm_stream;
+                T2N_HIP(hipEventRecord((hipEvent_t)f->ev_fork2, s));
+                T2N_HIP(hipStreamWaitEvent(sp, (hipEvent_t)f->ev_fork2, 0));
+                pack_side = true;
+            }
+            if ((rc = mlp_bwd_ss_pack(f, (void*)(bw + b.gpack), sp, true))) return rc;
+            if (pack_side) T2N_HIP(hipEventRecord((hipEvent_t)f->ev_pack, sp));
+        }
         packed_early = pack_now;
         timing_begin(f, T2N_K_BWD_MARCH, s);
         if (!bin) {
@@ -1308,7 +1333,6 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             // The density scatter (scan -> records -> LDS accumulate: atomic-latency- and LDS-bound, little VALU, no MFMA) shares
             // nothing with the MLP backward and the appearance scatter below but the finished k_bwd_march: it runs on a side stream
             // beside them and is joined before the gradients leave this call (T2N_BWD_SERIAL=1: one stream).
-            static const bool serial = getenv("T2N_BWD_SERIAL") != nullptr;
             hipStream_t sd = s;
             if (!serial && rows > 0) {
                 if (!f->side_stream) {
@@ -1360,6 +1384,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             // the chain writes g1 over h1 and g0 / gf / gX into the (otherwise unused) encoding buffer
             float* G0 = xpe; float* GF = xpe + (size_t)rows * 128; float* GX = xpe + (size_t)rows * 160;
             launch_bwd_l2((const float4*)go, (const float*)h1, rows, P->mlp_w2, nullptr, g->mlp_w2, g->mlp_b2, part, s, rows_dev);
+            if (pack_side) T2N_HIP(hipStreamWaitEvent(s, (hipEvent_t)f->ev_pack, 0));
             if ((rc = launch_mlp_bwd_ss(f, gpack, (const float4*)go, h1, h0, feat32, G0, GF, GX, rows, s, packed_early, rows_dev))) return rc;
             // From here two chains share nothing but read-only rows: the weight-gradient GEMMs (g1 / G0 / GF with h0 / features / x144
             // -> the MLP gradients, through `part`) and the appearance scatter (GX -> the factor gradient buffers). The GEMMs wait on

@@ -258,6 +258,35 @@ __device__ __forceinline__ void issue_taps_ax(const FactorSet& S, int CQ, int q,
     t.wl0 = al.w0; t.wl1 = al.w1;
 }
 
+// The second sample of a pair on the taps of the first: consecutive entries of an appearance list are consecutive steps of one ray
+// (half a voxel apart on the C2 grid), so the four texels of a plane - or the two of a line - are very often THE SAME as the previous
+// entry's. The loads run only in the lanes whose cell changed (the others keep the registers the first sample loaded: a masked load
+// leaves inactive lanes untouched); the weights are always this sample's. Same values, same arithmetic: bit-identical rows.
+template <int K>
+__device__ __forceinline__ void issue_taps_ax_changed(const FactorSet& S, int CQ, int q, const Axes3& A, bool plane_changed, bool line_changed,
+                                                      QuadTaps& t) {
+    const Axis& ax = A.a[mat0(K)];
+    const Axis& ay = A.a[mat1(K)];
+    const Axis& al = A.a[vecm(K)];
+    const unsigned W = (unsigned)S.W[K];
+    const unsigned tb = (unsigned)CQ * 16u, qb = (unsigned)q * 16u;
+    const char* __restrict__ P = reinterpret_cast<const char*>(S.plane[K]);
+    const char* __restrict__ Ln = reinterpret_cast<const char*>(S.line[K]);
+    if (plane_changed) {
+        const unsigned r0 = __umul24((unsigned)ay.i0, W), r1 = __umul24((unsigned)ay.i1, W);
+        t.nw = *reinterpret_cast<const float4*>(P + ((r0 + (unsigned)ax.i0) * tb + qb));
+        t.ne = *reinterpret_cast<const float4*>(P + ((r0 + (unsigned)ax.i1) * tb + qb));
+        t.sw = *reinterpret_cast<const float4*>(P + ((r1 + (unsigned)ax.i0) * tb + qb));
+        t.se = *reinterpret_cast<const float4*>(P + ((r1 + (unsigned)ax.i1) * tb + qb));
+    }
+    if (line_changed) {
+        t.l0 = *reinterpret_cast<const float4*>(Ln + ((unsigned)al.i0 * tb + qb));
+        t.l1 = *reinterpret_cast<const float4*>(Ln + ((unsigned)al.i1 * tb + qb));
+    }
+    t.wnw = ay.w0 * ax.w0; t.wne = ay.w0 * ax.w1; t.wsw = ay.w1 * ax.w0; t.wse = ay.w1 * ax.w1;
+    t.wl0 = al.w0; t.wl1 = al.w1;
+}
+
 __device__ __forceinline__ float4 taps_plane(const QuadTaps& t) {
     float4 v = f4_mul(t.nw, t.wnw);
     v = f4_fma(t.ne, t.wne, v);

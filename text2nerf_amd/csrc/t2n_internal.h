@@ -108,6 +108,7 @@ struct t2n_field {
     CountSlot count_slots[kCountSlots]; int count_next = 0;
     void* side_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;   // backward: the density scatter runs beside the MLP backward
     void* ev_den = nullptr;      // recorded behind the density scatter of the last backward (t2n_field_wait_density_grads)
+    void* ev_pack = nullptr;   // backward: k_mlp_bwd_ss's operand packing (on gemm_stream) is done
     void* gemm_stream = nullptr; void* ev_fork2 = nullptr; void* ev_join2 = nullptr;  // backward: the weight-gradient GEMMs run beside the appearance scatter
     unsigned list_hint = 0;          // appearance entries per ray of the last budgeted launch (0: unknown)
     unsigned long long list_retries = 0;

@@ -857,6 +857,10 @@ __device__ __forceinline__ Axes3 parked_axes(const FactorSet& S, const float4* _
     return A;
 }
 
+#ifndef T2N_SHARE_TAPS
+#define T2N_SHARE_TAPS 1
+#endif
+constexpr bool kShareTaps = T2N_SHARE_TAPS != 0;
 template <int K, bool HALF>
 __device__ __forceinline__ void gather_pair(const FactorSet& S, float* __restrict__ X, const float4* __restrict__ P, int lane, unsigned nlive) {
     // the item -> (sample, quad) maps and their LDS addresses are loop-invariant per lane: left visible, hipcc hoists ~40 of them
@@ -898,6 +902,43 @@ __device__ __forceinline__ void gather_pair(const FactorSet& S, float* __restric
         __builtin_amdgcn_sched_barrier(0);
         consume(t1, s1, o1);
         consume(t0, s0, o0);
+    } else if constexpr (kShareTaps) {
+        // items in PAIRS: lane -> (entries 2j and 2j+1, quad q), three pairs per lane; the second entry loads only what changed
+        int ca, cb, cl;     // the first entry's cell (plane column, plane row, line row)
+        auto first = [&](int p, QuadTaps& t, int& s_, int& q_, int& ca_, int& cb_, int& cl_) {
+            const int item = p * 64 + lane;
+            const int j = item / 12;
+            q_ = item - j * 12; s_ = 2 * j;
+            const Axes3 A = parked_axes(S, P, s_);
+            ca_ = A.a[mat0(K)].i0; cb_ = A.a[mat1(K)].i0; cl_ = A.a[vecm(K)].i0;
+            issue_taps_ax<K, false>(S, 12, q_, A, t);
+        };
+        auto second = [&](QuadTaps& t, int& s_, int q_, int ca_, int cb_, int cl_) {
+            s_ += 1;
+            const Axes3 A = parked_axes(S, P, s_);
+            const bool pc = (A.a[mat0(K)].i0 != ca_) || (A.a[mat1(K)].i0 != cb_), lc = A.a[vecm(K)].i0 != cl_;
+            issue_taps_ax_changed<K>(S, 12, q_, A, pc, lc, t);
+        };
+        auto consume = [&](const QuadTaps& t, int s_, int q_) {
+            const float4 pv = taps_plane(t), l = taps_line(t);
+            float4 v = make_float4(pv.x * l.x, pv.y * l.y, pv.z * l.z, pv.w * l.w);
+            if (!((unsigned)s_ < nlive)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float* dst = X + (size_t)(q_ * 4) * kXld + s_;
+            dst[0] = v.x; dst[kXld] = v.y; dst[2 * kXld] = v.z; dst[3 * kXld] = v.w;
+        };
+        QuadTaps t0, t1;
+        int s0, q0, s1, q1, ca1, cb1, cl1;
+#define T2N_FENCE __builtin_amdgcn_sched_barrier(0)
+        first(0, t0, s0, q0, ca, cb, cl);
+        first(1, t1, s1, q1, ca1, cb1, cl1);
+        T2N_FENCE;
+        consume(t0, s0, q0); T2N_FENCE; second(t0, s0, q0, ca, cb, cl); T2N_FENCE;
+        consume(t1, s1, q1); T2N_FENCE; second(t1, s1, q1, ca1, cb1, cl1); T2N_FENCE;
+        consume(t0, s0, q0); T2N_FENCE; first(2, t0, s0, q0, ca, cb, cl); T2N_FENCE;
+        consume(t1, s1, q1); T2N_FENCE;
+        consume(t0, s0, q0); T2N_FENCE; second(t0, s0, q0, ca, cb, cl); T2N_FENCE;
+        consume(t0, s0, q0);
+#undef T2N_FENCE
     } else {
         auto issue = [&](int it, QuadTaps& t, int& s_, int& q_) {
             const int item = it * 64 + lane;
