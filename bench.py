@@ -166,6 +166,9 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0, check=None):
     return out
 
 
+TRAIN_THREADS = None   # (experiments: host threads of the train loop)
+
+
 def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_step=False, batch=16384, resident=False, speculative=False):
     keep_threads = torch.get_num_threads()
     try:
@@ -184,7 +187,9 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
     # the loop's CPU work is row gathers of 16 384 rays / targets: half the usable cores leaves the quota headroom for the HIP runtime's
     # own threads (a process that outruns its cgroup CPU quota is throttled for the rest of a 100-ms period: one such stall inside a
     # 40-ms timed region turned 1.87 ms per iteration into 2.4)
-    torch.set_num_threads(max(1, min(8, torch.get_num_threads() // 2)))
+    # (the fused step's own host work is launches and one staging copy; its gathers run on the prefetch thread: two threads, the rest of
+    # the quota stays with the HIP runtime — 0.97-0.98 ms at 1 or 2 threads against 0.97-1.07 at 4 or 8, tools/experiments/train_threads_ab.py)
+    torch.set_num_threads(TRAIN_THREADS or (2 if fused_step else max(1, min(8, torch.get_num_threads() // 2))))
     from text2nerf_amd import OctreeRender_trilinear_fast, synth, to_device_async
     from text2nerf_amd.losses import TVLoss, TransMittanceLoss_mask
     field, params, aabb = build_field(dev)
@@ -226,6 +231,26 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
     if resident:   # the whole training set (9 views: 94 MB) and the permutation live in HBM: the batch is three device gathers
         allrays_d, allrgb_d, alldepth_d, perm_d = allrays.to(dev), allrgb.to(dev), alldepth.to(dev), perm.to(dev)
 
+    def idx_of(k):
+        idx = perm[(k * batch) % (perm.numel() - batch):][:batch]
+        return idx[lo:hi] if dist is not None else idx
+
+    # fused step with the training set on the host: the row gathers of batch k+1 run on a worker thread while step k is enqueued
+    # (text2nerf_amd.BatchPrefetcher; what a data loader does). The reference-form legs keep the driver's synchronous gather.
+    from text2nerf_amd import BatchPrefetcher
+    pf = BatchPrefetcher([allrays, allrgb, alldepth]) if (fused_step and not resident) else None
+    pf_next = [None]
+
+    def batch_of(k):
+        if pf_next[0] != k:
+            if pf_next[0] is not None:
+                pf.get()            # (a block restarted the sequence: drop the batch gathered ahead)
+            pf.submit(idx_of(k))
+        b = pf.get()
+        pf.submit(idx_of(k + 1))
+        pf_next[0] = k + 1
+        return b
+
     def it(k):
         if resident:
             idx = perm_d[(k * batch) % (perm.numel() - batch):][:batch]
@@ -236,11 +261,12 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
             idx = idx[lo:hi]
         if fused_step:   # autograd-free: render -> loss kernel (emits d_rgb / d_depth / d_weights) -> backward -> TV + Adam
             ar = (lambda: allreduce_gradients(all_params, average=True, field=field)) if dist is not None else None
-            return field.train_step(allrays[idx], allrgb[idx], alldepth[idx], opt, N_samples=n_samples, white_bg=True, tv=tv_terms,
-                                    all_reduce=ar, speculative=speculative)[3]
+            b_rays, b_rgb, b_dep = batch_of(k)      # the rows allrays[idx] / allrgb[idx] / alldepth[idx] (text2nerf_main.py:550-553)
+            return field.train_step(b_rays, b_rgb, b_dep, opt, N_samples=n_samples, white_bg=True, tv=tv_terms, all_reduce=ar,
+                                    speculative=speculative)[3]
         # targets go host -> device like text2nerf_main.py:550-553, through the pinned staging ring (a pageable .to(device)
         # drains the stream first and idles the GPU for the rest of the host-side batch preparation)
-        rays, rgb_t, dep_t = allrays[idx], to_device_async(allrgb[idx], dev), to_device_async(alldepth[idx], dev)
+        rays, rgb_t, dep_t = allrays.index_select(0, idx), to_device_async(allrgb.index_select(0, idx), dev), to_device_async(alldepth.index_select(0, idx), dev)
         rgb, _, depth, w, z = OctreeRender_trilinear_fast(rays, field, chunk=max(int(rays.shape[0]), 1), N_samples=n_samples, white_bg=True,
                                                           ndc_ray=False, device=dev, is_train=True)
         loss = torch.mean((rgb - rgb_t) ** 2) + 0.005 * torch.mean((depth - dep_t) ** 2)
@@ -1105,6 +1131,12 @@ def main():
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True, resident=True))
+            try:   # the same step without the host read of the row count (T2N_FLAG_DEVICE_ROWS): immune to a slow host, not faster on a fast one
+                sp_ = train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True, resident=True, speculative=True)
+                out["config"]["train_ms_per_iter_fused_step_resident_speculative"] = sp_["ms_per_iter"]
+                out["config"]["train_speculative"] = {k: sp_[k] for k in ("blocks_ms", "device_rows_steps", "overflows", "unanswered_polls")}
+            except Exception as e:  # noqa: BLE001  (reporting only)
+                out["config"]["train_speculative"] = {"error": repr(e)[:200]}
         if not grouped and not c4 and not args.quick:
             out["scaling_prediction"] = sp = scaling_prediction(field, dev, out["config"].get("train_ms_per_iter_fused_step"))
             out["config"]["train_ms_per_iter_fused_step_2048_rays"] = sp.get("train_dp", {}).get("fused_step_ms_by_rays_per_gpu", {}).get("2048")

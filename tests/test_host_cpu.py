@@ -114,6 +114,28 @@ def test_simple_sampler_and_shards():
         assert max(h - l for l, h in b) == tile_capacity(R, W) if R else True
 
 
+def test_batch_prefetcher_returns_the_rows_in_submission_order():
+    """The training loop's gathers one batch ahead on a worker thread: same rows as `tensor[ids]` (text2nerf_main.py:550-553), FIFO,
+    errors of the worker surface at get()."""
+    from text2nerf_amd import BatchPrefetcher, SimpleSampler
+    g = torch.Generator().manual_seed(3)
+    rays, rgb, dep = torch.randn(1000, 6, generator=g), torch.rand(1000, 3, generator=g), torch.rand(1000, generator=g)
+    pf = BatchPrefetcher([rays, rgb, dep])
+    np.random.seed(7)
+    s = SimpleSampler(1000, 64)
+    ids = [s.nextids() for _ in range(5)]
+    pf.submit(ids[0])
+    for k in range(5):
+        if k + 1 < 5:
+            pf.submit(ids[k + 1])
+        b = pf.get()
+        assert torch.equal(b[0], rays[ids[k]]) and torch.equal(b[1], rgb[ids[k]]) and torch.equal(b[2], dep[ids[k]])
+    pf.submit(torch.tensor([1000]))
+    with pytest.raises(IndexError):
+        pf.get()
+    pf.close()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

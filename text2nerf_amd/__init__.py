@@ -2,7 +2,7 @@
 
 Host-side mirror of the reference interface for this path; the arithmetic runs in libt2n_hip.so (include/t2n.h).
 """
-from .renderer import (OctreeRender_trilinear_fast, SimpleSampler, render_views, postprocess_frame,  # noqa: F401
+from .renderer import (OctreeRender_trilinear_fast, SimpleSampler, BatchPrefetcher, render_views, postprocess_frame,  # noqa: F401
                        evaluation_frames, evaluation, evaluation_path)
 from .tensorf import (AlphaGridMask, MLPRender, MLPRender_Fea, MLPRender_Fea_noview, MLPRender_PE, RGBRender, SHRender, TensorBase,  # noqa: F401
                       TensorCP, TensorVM, TensorVMSplit, positional_encoding, raw2alpha, release_workspaces, to_device_async,

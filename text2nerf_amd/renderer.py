@@ -23,6 +23,43 @@ class SimpleSampler:
         return self.ids[self.curr:self.curr + self.batch]
 
 
+class BatchPrefetcher:
+    """The training loop's row gathers (text2nerf_main.py:550-553: `allrays[ray_idx]`, `allrgbs[ray_idx]`, depths) one batch ahead on a
+    worker thread: `submit(ids)` starts gathering rows `ids` of every tensor, `get()` returns the oldest submitted batch. The gathers
+    are `index_select` (per-row copies; the advanced-indexing kernel costs 3x the host time and collapses when its threads are
+    oversubscribed) and release the GIL, so they run beside the main thread's kernel launches."""
+
+    def __init__(self, tensors):
+        import queue
+        import threading
+        self.tensors = list(tensors)
+        self._in, self._out = queue.Queue(), queue.Queue()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        while True:
+            ids = self._in.get()
+            if ids is None:
+                return
+            try:
+                self._out.put([t.index_select(0, ids) for t in self.tensors])
+            except Exception as e:  # noqa: BLE001  (handed to the consumer)
+                self._out.put(e)
+
+    def submit(self, ids):
+        self._in.put(ids)
+
+    def get(self):
+        b = self._out.get()
+        if isinstance(b, Exception):
+            raise b
+        return b
+
+    def close(self):
+        self._in.put(None)
+
+
 _FW_CACHE = {}     # (data_ptr, shape, version, device) -> detected width: a loop that re-renders the same ray tensor probes it once
 
 

@@ -1369,6 +1369,15 @@ class TensorBase(nn.Module):
             optimizer.step(tv=tv) if tv else optimizer.step()
             if seed_terms is not None:
                 self.seed_factor_grads_with_tv(seed_terms, ahead=True)
+            if speculative:
+                # nothing in the step waits for the GPU any more: the host is held to two steps of run-ahead (a queue that grows
+                # without bound stalls in the HIP runtime for milliseconds at a time: 7-ms pauses every ~11 steps measured)
+                evs = self.__dict__.setdefault("_spec_events", [])
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                evs.append(ev)
+                if len(evs) > 2:
+                    evs.pop(0).synchronize()
         return losses
 
     def _poll_device_rows(self):
