@@ -57,7 +57,9 @@ enum {
     T2N_FLAG_DEVICE_ROWS = 32u, /* t2n_render_backward only: read NO count on the host. The appearance row capacity is what the two
                                * workspaces hold (the forward's kept activation rows; the backward's row buffers); the actual row count
                                * and tile prefix are derived on the device and every row kernel clips to them. Rows past the capacity
-                               * lose their appearance gradient (t2n_render_ctx_rows_try tells the caller afterwards). Needs the fused
+                               * lose their appearance gradient (t2n_render_ctx_rows_try tells the caller afterwards). ONE backward per
+                               * forward in this mode: the kept rows are consumed in place, a second call on the same context finds the
+                               * forward's statement cleared and computes no appearance gradients. Needs the fused
                                * MLP_Fea_noview head (27/6/128, 48 comps), the binned scatters and all head gradient tensors. */
     T2N_FLAG_COHERENT = 8u    /* hint (eval): rays are a row-major image whose width was given by t2n_field_set_frame_width:
                                  march 8x8-pixel tiles whose rays share one texel x line-row dot-product table per step

@@ -185,7 +185,10 @@ __device__ __forceinline__ void scatter_win(const FactorSet& S, const GradSet& G
 constexpr int kBinTile = 16;      // texels per tile edge (footprints reach one texel further: 17 staged)
 constexpr int kBinCopies = 32;    // privatised histogram / cursor copies (every ray starts in the camera's tile)
 constexpr int kBinSegApp = 512;   // smallest segment (sizes the segment list); the scan picks the actual size per call
-constexpr unsigned kAccTargetSegsApp = 512;   // accumulate work items aimed at: whole rounds over 256 CUs
+#ifndef T2N_ACC_TARGET_SEGS_APP
+#define T2N_ACC_TARGET_SEGS_APP 512
+#endif
+constexpr unsigned kAccTargetSegsApp = T2N_ACC_TARGET_SEGS_APP;   // accumulate work items aimed at: whole rounds over 256 CUs
 constexpr unsigned kAccGrid = 2048;   // accumulate workgroups launched (grid-stride over the segment list)
 
 struct BinGeom { int tw[3], before[3], total; };
