@@ -157,6 +157,31 @@ def test_speculative_step_survives_a_capacity_overflow(tiny_params, monkeypatch)
     assert all(bool(torch.isfinite(p).all()) for p in f.parameters())
 
 
+def test_speculative_takes_the_counted_route_where_the_device_plan_does_not_apply(tiny_params):
+    """The device-side row plan serves the fused split-f16 head only: with the strict-fp32 head `speculative=True` is the counted step
+    (no error, no device-rows call), and the C-ABI refuses the flag outright."""
+    import ctypes as C
+    from text2nerf_amd import _lib
+    from text2nerf_amd.optim import TVAdam
+    rays, rgb_t, dep_t = batch()
+    f = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    f.mlp_exact_fp32 = True
+    o = TVAdam(f.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=f)
+    for it in range(3):
+        torch.manual_seed(it)
+        l = f.train_step(rays, rgb_t, dep_t, o, N_samples=-1, white_bg=True, speculative=True)
+    assert getattr(f, "device_rows_steps", 0) == 0 and bool(torch.isfinite(l).all())
+    # the flag itself on that field: T2N_ERR_UNSUPPORTED, nothing launched
+    d = dev()
+    r = rays.to(d)
+    N = f.nSamples
+    jit = torch.rand(r.shape[0], device=d)
+    with torch.no_grad():
+        rgb, depth, z, w, ws = f._render_raw(r, N, _lib.FLAG_TRAIN | _lib.FLAG_ADD_BG, jit, True, keep_ctx=True)
+    with pytest.raises(_lib.T2NError, match="DEVICE_ROWS"):
+        f._backward_raw(r, jit, N, _lib.FLAG_TRAIN | _lib.FLAG_ADD_BG, ws, torch.ones_like(rgb), torch.zeros_like(depth), None, device_rows=True)
+
+
 def test_deferred_factor_gradients_add_up_over_chunks(tiny_params):
     """with TVAdam(field=...) a batch larger than `chunk` makes several backward nodes; every one of them must land in
     the factor gradients (round 1 zeroed the buffer per backward call and kept only the last chunk's). Reference: the same chunked
