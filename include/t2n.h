@@ -57,7 +57,7 @@ enum {
     T2N_FLAG_DEVICE_ROWS = 32u, /* t2n_render_backward only: read NO count on the host. The appearance row capacity is what the two
                                * workspaces hold (the forward's kept activation rows; the backward's row buffers); the actual row count
                                * and tile prefix are derived on the device and every row kernel clips to them. Rows past the capacity
-                               * lose their appearance gradient (t2n_render_ctx_rows_try tells the caller afterwards). ONE backward per
+                               * lose their appearance gradient (t2n_field_device_rows_record tells the caller afterwards). ONE backward per
                                * forward in this mode: the kept rows are consumed in place, a second call on the same context finds the
                                * forward's statement cleared and computes no appearance gradients. Needs the fused
                                * MLP_Fea_noview head (27/6/128, 48 comps), the binned scatters and all head gradient tensors. */
@@ -330,9 +330,10 @@ int t2n_dibr_filter_mask(float* image, int32_t* known, int H, int W, t2n_stream 
  * writes end (so both workspaces must stay alive until `stream` has passed the call, as for any asynchronous call). */
 size_t t2n_render_workspace_bytes_ctx(int64_t n_rays, int n_samples);
 int t2n_render_ctx_rows(const void* fwd_workspace, int64_t n_rays, int n_samples, t2n_stream stream, int64_t* rows);
-/* The same without waiting: *rows = -1 while the forward's counters have not reached the host (or were evicted from the ring of
- * 32 posted forwards). Never blocks, never touches the stream: legal while a stream capture is open elsewhere. */
-int t2n_render_ctx_rows_try(const void* fwd_workspace, int64_t n_rays, int n_samples, int64_t* rows);
+/* What the T2N_FLAG_DEVICE_ROWS backwards of this field recorded, read from pinned host memory (never waits, never touches a
+ * stream): out[0..7] = appearance rows the last eight such calls NEEDED (before clipping to their capacity; slot = sequence & 7),
+ * out[8] = how many calls overflowed their capacity so far, out[9] = records written. A caller sizes its next capacity from it. */
+int t2n_field_device_rows_record(const t2n_field* f, uint32_t out[10]);
 size_t t2n_backward_workspace_bytes(const t2n_field* f, int64_t rows, int64_t n_rays, int n_samples);
 int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_rays, int ray_stride, int n_samples, uint32_t flags,
                         const float* jitter, const float* d_rgb, const float* d_depth, const float* d_weights,

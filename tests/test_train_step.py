@@ -129,7 +129,8 @@ def test_speculative_step_equals_the_counted_step(tiny_params):
 
 def test_speculative_step_survives_a_capacity_overflow(tiny_params, monkeypatch):
     """A step whose appearance rows exceed the capacity: the rows past it lose their appearance gradient (nothing else), the host
-    learns it one step later, counts it, and the next step takes the counted route with the re-learned capacity."""
+    reads it from the pinned record (late at worst), counts it, and the next step takes the counted route; the capacity follows the
+    recorded need."""
     from text2nerf_amd import tensorf as tf
     from text2nerf_amd.optim import TVAdam
     monkeypatch.setattr(tf, "_ladder", lambda n, *a, **k: n)       # (the ladder's floor of 1024 rows would hide the small capacity)
@@ -145,8 +146,9 @@ def test_speculative_step_survives_a_capacity_overflow(tiny_params, monkeypatch)
     torch.manual_seed(2)
     l1 = step()
     assert f.device_rows_steps == 1
+    torch.cuda.synchronize()                   # (the record of that step has arrived: the test must not depend on the host's lead)
     torch.manual_seed(3)
-    l2 = step()                                # polls step 1's count: overflow -> counted route
+    l2 = step()                                # reads the record: overflow -> counted route, capacity from the recorded need
     assert f.device_rows_overflows == 1 and f.device_rows_steps == 1
     assert int(f._ctx_rows_hint) > 256
     torch.manual_seed(4)

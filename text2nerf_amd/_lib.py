@@ -119,7 +119,7 @@ SIGNATURES = {
     "t2n_ndc_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                      C.c_void_p, C.c_void_p]),
     "t2n_render_ctx_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
-    "t2n_render_ctx_rows_try": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
+    "t2n_field_device_rows_record": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "t2n_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int64, C.c_int]),
     "t2n_render_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FieldGrads), C.c_void_p, C.c_size_t,

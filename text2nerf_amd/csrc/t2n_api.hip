@@ -460,6 +460,7 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->ev_join) (void)hipEventDestroy((hipEvent_t)f->ev_join);
     if (f->ev_den) (void)hipEventDestroy((hipEvent_t)f->ev_den);
     if (f->side_stream) (void)hipStreamDestroy((hipStream_t)f->side_stream);
+    if (f->plan_host) (void)hipHostFree(f->plan_host);
     if (f->ev_pack) (void)hipEventDestroy((hipEvent_t)f->ev_pack);
     if (f->ev_fork2) (void)hipEventDestroy((hipEvent_t)f->ev_fork2);
     if (f->ev_join2) (void)hipEventDestroy((hipEvent_t)f->ev_join2);

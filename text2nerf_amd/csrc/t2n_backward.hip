@@ -1025,8 +1025,11 @@ static int ensure_grad_buffers(t2n_field* f) {
 // The plan of a backward that reads no count on the host: one wave turns the forward's sub-list counters into the tile prefix and the
 // row count, clipped to the capacity; the forward's statement that it kept the activation rows with exactly this capacity is checked here
 // too (a mismatch leaves rows = 0: nothing of the appearance branch runs, overflow says why)
+// host_rec (pinned host memory of the field, may be NULL): words 0..7 = the rows the last eight such backwards NEEDED (before clipping),
+// word 8 = how many of them overflowed their capacity so far, word 9 = sequence number of the newest record + 1. A caller sizes its
+// next capacity from it without ever waiting: every record arrives, late at worst.
 __global__ __launch_bounds__(64) void k_bwd_plan(const unsigned* __restrict__ counters, unsigned list_cap, unsigned rows_cap, unsigned kept_rows,
-                                                 BwdPlan* __restrict__ plan) {
+                                                 BwdPlan* __restrict__ plan, unsigned* host_rec, unsigned seq) {
     const int lane = threadIdx.x;
     unsigned cnt = lane < kLists ? counters[lane * kCounterStride] : 0u;
     if (cnt > list_cap) cnt = list_cap;
@@ -1043,8 +1046,16 @@ __global__ __launch_bounds__(64) void k_bwd_plan(const unsigned* __restrict__ co
         plan->tp.t[kLists] = total;
         const bool stated = counters[kKeptMagicWord] == kKeptMagic && counters[kKeptRowsWord] == kept_rows;
         const unsigned rows = total * 32u;
-        plan->overflow = (!stated || rows > rows_cap) ? 1u : 0u;
+        const unsigned ovf = (!stated || rows > rows_cap) ? 1u : 0u;
+        plan->overflow = ovf;
         plan->rows = !stated ? 0u : (rows < rows_cap ? rows : rows_cap);
+        if (host_rec) {
+            volatile unsigned* h = host_rec;
+            h[seq & 7u] = rows;
+            if (ovf) h[8] = h[8] + 1u;      // (plan kernels of one field run one after the other)
+            __threadfence_system();
+            h[9] = seq + 1u;
+        }
     }
 }
 
@@ -1134,22 +1145,12 @@ extern "C" int t2n_render_ctx_rows(const void* fwd_workspace, int64_t n_rays, in
     return read_counts(fwd_workspace, n_rays, n_samples, (hipStream_t)stream, counts, nullptr, rows);
 }
 
-// The same without waiting: *rows = -1 while the forward's counters have not reached the host yet (or their slot was evicted)
-extern "C" int t2n_render_ctx_rows_try(const void* fwd_workspace, int64_t n_rays, int n_samples, int64_t* rows) {
-    if (!fwd_workspace || !rows || n_rays <= 0 || n_samples <= 0) { set_error("t2n_render_ctx_rows_try: bad argument"); return T2N_ERR_INVALID; }
-    *rows = -1;
-    int dev = 0;
-    T2N_HIP(hipGetDevice(&dev));
-    const Carve c = carve_workspace(n_rays, n_samples, true, false);
-    std::lock_guard<std::mutex> lock(g_ctx_mutex);
-    for (auto& q : g_ctx)
-        if (q.valid && q.ws == fwd_workspace && q.dev == dev) {
-            if (hipEventQuery(q.ev) != hipSuccess) { (void)hipGetLastError(); return T2N_OK; }
-            unsigned t = 0;
-            for (int l = 0; l < kLists; ++l) { unsigned n = q.host[l * kCounterStride]; if (n > c.list_cap) n = c.list_cap; t += (n + 31u) / 32u; }
-            *rows = (int64_t)t * 32;
-            return T2N_OK;
-        }
+// What the T2N_FLAG_DEVICE_ROWS backwards of this field recorded (k_bwd_plan): a plain read of pinned host memory, never waits.
+extern "C" int t2n_field_device_rows_record(const t2n_field* f, uint32_t out[10]) {
+    if (!f || !out) { set_error("t2n_field_device_rows_record: NULL argument"); return T2N_ERR_INVALID; }
+    if (!f->plan_host) { for (int i = 0; i < 10; ++i) out[i] = 0u; return T2N_OK; }
+    const volatile unsigned* h = f->plan_host;
+    for (int i = 0; i < 10; ++i) out[i] = h[i];
     return T2N_OK;
 }
 
@@ -1239,7 +1240,11 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
     BwdPlan* plan = dev_rows ? (BwdPlan*)(bw + b.plan) : nullptr;
     const unsigned* rows_dev = plan ? &plan->rows : nullptr;
     if (plan) {
-        hipLaunchKernelGGL(k_bwd_plan, dim3(1), dim3(64), 0, s, counters, c.list_cap, (unsigned)rows, kept_stated, plan);
+        if (!f->plan_host) {
+            T2N_HIP(hipHostMalloc((void**)&f->plan_host, 16 * sizeof(unsigned), hipHostMallocDefault));
+            for (int i = 0; i < 16; ++i) f->plan_host[i] = 0u;
+        }
+        hipLaunchKernelGGL(k_bwd_plan, dim3(1), dim3(64), 0, s, counters, c.list_cap, (unsigned)rows, kept_stated, plan, f->plan_host, f->plan_seq++);
         T2N_HIP(hipGetLastError());
     }
 

@@ -108,6 +108,7 @@ struct t2n_field {
     CountSlot count_slots[kCountSlots]; int count_next = 0;
     void* side_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;   // backward: the density scatter runs beside the MLP backward
     void* ev_den = nullptr;      // recorded behind the density scatter of the last backward (t2n_field_wait_density_grads)
+    unsigned* plan_host = nullptr; unsigned plan_seq = 0;   // T2N_FLAG_DEVICE_ROWS: k_bwd_plan's record in pinned host memory (t2n_field_device_rows_record)
     void* ev_pack = nullptr;   // backward: k_mlp_bwd_ss's operand packing (on gemm_stream) is done
     void* gemm_stream = nullptr; void* ev_fork2 = nullptr; void* ev_join2 = nullptr;  // backward: the weight-gradient GEMMs run beside the appearance scatter
     unsigned list_hint = 0;          // appearance entries per ray of the last budgeted launch (0: unknown)

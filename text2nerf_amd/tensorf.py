@@ -895,6 +895,7 @@ class TensorBase(nn.Module):
             if getattr(self, "_handle", None) is not None:
                 _lib.load().t2n_field_destroy(self._handle)
                 self._handle = None
+                self._device_rows_ovf_seen = self._device_rows_issued = 0   # (the new handle's record starts from zero)
         except Exception:
             pass
 
@@ -1000,6 +1001,7 @@ class TensorBase(nn.Module):
         if self._handle is not None:
             _lib.load().t2n_field_destroy(self._handle)
             self._handle = None
+            self._device_rows_ovf_seen = self._device_rows_issued = 0
         self._uploaded_key = None
         self._gbuf = None            # channel-last factor gradients: sized by the grid
         self._gbuf_dirty = False
@@ -1307,10 +1309,10 @@ class TensorBase(nn.Module):
         world size) — pass all_reduce_averages=False for any other reduction and the TV terms are added after it. Returns the device tensor [mse, depth loss, transmittance loss,
         total] of this batch (no host synchronisation). Same arithmetic as the autograd path: tests/test_train_step.py.
         `speculative=True`: the backward does not wait for the forward's appearance row count either (T2N_FLAG_DEVICE_ROWS): its
-        row capacity is 1.25x what the previous step needed, the kernels clip to the actual count on the device, and the host learns
-        the count one step later without waiting. A step whose count exceeds the capacity drops the appearance gradients of the
-        rows past it — counted in `self.device_rows_overflows`, and the next step runs with the larger capacity. The first step (and
-        any step after an overflow) takes the counted route."""
+        row capacity is 1.25x the largest need of the last eight steps, the kernels clip to the actual count on the device, and the
+        host learns every step's need from a record in pinned memory, without waiting (late at worst, never lost). A step whose count
+        exceeds the capacity drops the appearance gradients of the rows past it — counted in `self.device_rows_overflows`. The first
+        step (and the step after a recorded overflow) takes the counted route."""
         lib = _lib.load()
         params = self._autograd_params()
         if any(not p.is_leaf for p in params):
@@ -1360,8 +1362,8 @@ class TensorBase(nn.Module):
                 torch.cuda.current_stream(dev).wait_event(seed_ev)
             grads = self._backward_raw(rays, jitter, N, flags, ws, d_rgb, d_depth, d_w, head_grads=views, device_rows=device_rows)
             if device_rows:
-                self._device_rows_pending = (ws.data_ptr(), R, N, int(self._ctx_rows_cap))
                 self.device_rows_steps = getattr(self, "device_rows_steps", 0) + 1
+                self._device_rows_issued = getattr(self, "_device_rows_issued", 0) + 1
             for p, g in zip(params, grads):
                 p.grad = g
             if all_reduce is not None:
@@ -1381,24 +1383,35 @@ class TensorBase(nn.Module):
         return losses
 
     def _poll_device_rows(self):
-        """The row count of the previous speculative step, read without waiting (its forward finished long ago in any loop that is not
-        already GPU-bound). Updates the capacity hint; False = that step overflowed its capacity (the next one takes the counted route,
-        which re-learns the hint) . An unanswered poll keeps the hint."""
-        pend, self._device_rows_pending = getattr(self, "_device_rows_pending", None), None
-        if pend is None:
+        """What the speculative steps have recorded so far (k_bwd_plan writes every step's row NEED and an overflow count into pinned
+        host memory: t2n_field_device_rows_record — a plain host read, never waits, and no record is ever lost, it is late at worst).
+        The capacity hint becomes 1.25 x the largest need of the last eight records. Returns False when an overflow has been recorded
+        since the last poll: the next step takes the counted route."""
+        if not getattr(self, "device_rows_steps", 0) or self._handle is None:
             return True
-        lib = _lib.load()
-        ptr, R, N, cap = pend
-        rows = C.c_int64(-1)
-        _lib.check(lib.t2n_render_ctx_rows_try(C.c_void_p(ptr), R, N, C.byref(rows)), "t2n_render_ctx_rows_try")
-        if rows.value < 0:
-            self.device_rows_unanswered = getattr(self, "device_rows_unanswered", 0) + 1
-            return True
-        self._ctx_rows_hint = (int(rows.value * 1.25) + 95) // 32 * 32
-        if rows.value > cap:
-            self.device_rows_overflows = getattr(self, "device_rows_overflows", 0) + 1
-            return False
-        return True
+        rec = (C.c_uint32 * 10)()
+        _lib.check(_lib.load().t2n_field_device_rows_record(self._handle, rec), "t2n_field_device_rows_record")
+        if rec[9] < getattr(self, "_device_rows_issued", 0):
+            self.device_rows_unanswered = getattr(self, "device_rows_unanswered", 0) + 1     # (records still on their way)
+        # margin over the recorded need: 1.25, widened by a quarter with every recorded overflow (a row count growing faster than the
+        # record travels), narrowed again over 64 clean polls
+        margin = getattr(self, "_device_rows_margin", 1.25)
+        seen = getattr(self, "_device_rows_ovf_seen", 0)
+        overflowed = rec[8] > seen
+        if overflowed:
+            self.device_rows_overflows = getattr(self, "device_rows_overflows", 0) + int(rec[8] - seen)
+            self._device_rows_ovf_seen = int(rec[8])
+            margin = min(2.0, margin * 1.25)
+            self._device_rows_clean = 0
+        else:
+            self._device_rows_clean = getattr(self, "_device_rows_clean", 0) + 1
+            if self._device_rows_clean >= 64:
+                margin, self._device_rows_clean = max(1.25, margin / 1.1), 0
+        self._device_rows_margin = margin
+        need = max(rec[0:8])
+        if need:
+            self._ctx_rows_hint = (int(need * margin) + 95) // 32 * 32
+        return not overflowed
 
     def stats(self):
         """Counters of the last render call (one device->host copy): evaluated / appearance samples, overflow."""
