@@ -53,15 +53,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in sources() + _headers())
 
 
-def check_ss3_isa(hipcc, verbose=False):
+def check_ss3_isa(hipcc, verbose=False, extra=(), obj_dir=None):
     """k_mlp_ss3 keeps live accumulators in literally named AccVGPRs across separate asm statements; nothing reserves them in
     between, so the build is refused should the compiler ever put values of its own there or spill: the kernel's assembly must hold no
-    v_accvgpr_write / v_accvgpr_mov (hipcc staging a value in an AccVGPR), no scratch, no spilled registers. Runs when t2n_mlp_ss.hip
-    was recompiled (one more -S pass of that file)."""
+    v_accvgpr_write / v_accvgpr_mov (hipcc staging a value in an AccVGPR), no scratch, no spilled registers. One more -S pass of that
+    file. ADVICE r5: the verdict is remembered by a stamp file next to the object (`t2n_mlp_ss.checked`, newer than the object = passed);
+    build() re-runs the check whenever the stamp is missing or older, and removes a refused object so that no later build links it."""
     import re
+    obj_dir = obj_dir or OBJ
     src = os.path.join(CSRC, "t2n_mlp_ss.hip")
-    asm = os.path.join(OBJ, "t2n_mlp_ss.s")
-    subprocess.run([hipcc] + CFLAGS + ["-S", "--cuda-device-only", src, "-o", asm], check=True, stderr=subprocess.DEVNULL)
+    asm = os.path.join(obj_dir, "t2n_mlp_ss.s")
+    subprocess.run([hipcc] + CFLAGS + list(extra) + ["-S", "--cuda-device-only", src, "-o", asm], check=True,
+                   stderr=subprocess.DEVNULL)
     text = open(asm).read()
     found = 0
     for m in re.finditer(r"^(_ZN3t2n2ss9k_mlp_ss3\w*):[^\n]*\n(.*?)\n\.Lfunc_end\d+:", text, re.S | re.M):
@@ -96,8 +99,17 @@ def build(force=False, verbose=False):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:
         list(ex.map(compile_one, todo))
-    if any(os.path.basename(s) == "t2n_mlp_ss.hip" for s in todo):
-        check_ss3_isa(hipcc, verbose)
+    ss_obj = _obj(os.path.join(CSRC, "t2n_mlp_ss.hip"))
+    stamp = ss_obj[:-2] + ".checked"
+    if not os.path.exists(stamp) or os.path.getmtime(stamp) < os.path.getmtime(ss_obj):
+        try:
+            check_ss3_isa(hipcc, verbose)
+        except Exception:
+            for f in (ss_obj, stamp):         # a refused object must not survive into the next build()'s link
+                if os.path.exists(f):
+                    os.remove(f)
+            raise
+        open(stamp, "w").close()
     keep = {_obj(s) for s in sources()}
     for o in glob.glob(os.path.join(OBJ, "*.o")):       # objects of sources that no longer exist must not be linked
         if o not in keep:
@@ -111,4 +123,8 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
+    if "--check-ss3" in sys.argv:          # tools/build_variant.sh: python -m text2nerf_amd.build --check-ss3 OBJ_DIR [extra flags]
+        i = sys.argv.index("--check-ss3")
+        check_ss3_isa(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), True, extra=sys.argv[i + 2:], obj_dir=sys.argv[i + 1])
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

@@ -20,6 +20,11 @@ for f in $src/*.hip; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
+# the AccVGPR / spill guard of text2nerf_amd/build.py, on this variant's flags; a refused object is removed so that it is never linked
+if [ ! -f $obj/t2n_mlp_ss.checked ] || [ $obj/t2n_mlp_ss.o -nt $obj/t2n_mlp_ss.checked ]; then
+  (cd $root && python3 -m text2nerf_amd.build --check-ss3 $obj $extra) || { rm -f $obj/t2n_mlp_ss.o $obj/t2n_mlp_ss.checked; exit 1; }
+  touch $obj/t2n_mlp_ss.checked
+fi
 out=$root/text2nerf_amd/libt2n_hip_$name.so
 [ "$name" = main ] && out=$root/text2nerf_amd/libt2n_hip.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined $obj/*.o -o $out.tmp
