@@ -169,15 +169,15 @@ def cpu_baseline(params, aabb, grid, n_samples, budget_s=12.0, check=None):
 TRAIN_THREADS = None   # (experiments: host threads of the train loop)
 
 
-def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_step=False, batch=16384, resident=False, speculative=False):
+def train_bench(dev, iters=20, warmup=3, fused_optim=False, dist=None, fused_step=False, batch=16384, resident=False, speculative=False, step_kw=None):
     keep_threads = torch.get_num_threads()
     try:
-        return _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resident, speculative)
+        return _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resident, speculative, step_kw or {})
     finally:
         torch.set_num_threads(keep_threads)     # the loop below runs on half the cores; callers (CPU baseline, other legs) get theirs back
 
 
-def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resident=False, speculative=False):
+def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resident=False, speculative=False, step_kw={}):
     """C3-shaped optimisation step (text2nerf_main.py:547-601): 16 384 random rays of 9 small-baseline 512x512 views,
     N=259, is_train, MSE(rgb)+0.005 MSE(depth)+1e3 transmittance+TV(density 0.1, app 0.01), Adam(0.02/1e-3).
     With `dist` (world > 1): data-parallel — the SAME 16 384-ray batch is split into equal shards (strong scaling), local
@@ -255,7 +255,7 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
         if resident:
             idx = perm_d[(k * batch) % (perm.numel() - batch):][:batch]
             return field.train_step(allrays_d[idx], allrgb_d[idx], alldepth_d[idx], opt, N_samples=n_samples, white_bg=True, tv=tv_terms,
-                                    speculative=speculative)[3]
+                                    speculative=speculative, **step_kw)[3]
         idx = perm[(k * batch) % (perm.numel() - batch):][:batch]
         if dist is not None:
             idx = idx[lo:hi]
@@ -263,7 +263,7 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
             ar = (lambda: allreduce_gradients(all_params, average=True, field=field)) if dist is not None else None
             b_rays, b_rgb, b_dep = batch_of(k)      # the rows allrays[idx] / allrgb[idx] / alldepth[idx] (text2nerf_main.py:550-553)
             return field.train_step(b_rays, b_rgb, b_dep, opt, N_samples=n_samples, white_bg=True, tv=tv_terms, all_reduce=ar,
-                                    speculative=speculative)[3]
+                                    speculative=speculative, **step_kw)[3]
         # targets go host -> device like text2nerf_main.py:550-553, through the pinned staging ring (a pageable .to(device)
         # drains the stream first and idles the GPU for the rest of the host-side batch preparation)
         rays, rgb_t, dep_t = allrays.index_select(0, idx), to_device_async(allrgb.index_select(0, idx), dev), to_device_async(alldepth.index_select(0, idx), dev)

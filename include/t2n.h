@@ -13,7 +13,8 @@
  *     no CPU fallback in this library.
  *   - work is enqueued on the caller's HIP stream (pass torch.cuda.current_stream().cuda_stream); calls do not
  *     synchronise unless documented. The library allocates device memory only inside t2n_field_create/_upload (the
- *     channel-last copy of the factor tensors); per-call scratch comes from the caller's workspace.
+ *     channel-last copy of the factor tensors) and, once, in the first t2n_train_step of a field (its training state: a few hundred
+ *     KB); per-call scratch comes from the caller's workspace.
  *   - a handle may be used from one host thread at a time.
  */
 #ifndef T2N_H_
@@ -440,6 +441,66 @@ int t2n_filter_rays_alpha(const t2n_field* f, const float* rays, int64_t n_rays,
  * samples kept}. Double precision, deterministic. */
 int t2n_depth_align_global(const float* depth_rendered, const float* depth_est, int H, int W, const int32_t* pixel_sample_yx,
                            int n_samples, double push_depth, float* depth_shift, double* scale_shift, t2n_stream stream);
+
+/* ---- One optimisation step of the reference's loop (text2nerf_main.py:547-601) as ONE submission: TV gradient -> train-mode render
+ * (KEEP_CTX) -> t2n_train_loss -> t2n_render_backward (device-side row plan, as T2N_FLAG_DEVICE_ROWS) -> Adam on all 19 tensors ->
+ * re-packed head operands, on the caller's stream and three library-owned side streams (forked from / joined into `stream` by events, so
+ * the whole call can be captured into a hipGraph: t2n_train_graph_*). Nothing in it is read on the host and no kernel argument changes
+ * from step to step: the batch comes through the caller's fixed device buffers, the per-step scalars (learning rates, TV weights) through
+ * `hyper` in device memory, Adam's step count lives in the field (device memory; bias corrections are derived from it on the device).
+ * Fused MLP_Fea_noview head (27 / 6 / 128), 16 + 48 components, fp32 factor storage, split-f16 head arithmetic, no NDC, no alpha mask:
+ * anything else is T2N_ERR_UNSUPPORTED (use the separate calls).
+ *   hyper          device float[T2N_TRAIN_HYPER_FLOATS]: [0..18] learning rates of the 19 tensors in t2n_field_params order, [19] / [20]
+ *                  TV weights of the density / appearance planes (already x 1e-2: models/tensoRF.py:193-203), rest reserved
+ *   params         the caller's reference-layout tensors: updated in place (like t2n_field_tv_adam_step / t2n_adam_step_multi)
+ *   exp_avg(_sq)   Adam moments: [0..11] CHANNEL-LAST buffers of the factor tensors, [12..18] reference layout
+ *   head_grads     device float[T2N_TRAIN_HEAD_GRAD_FLOATS]: the gradients of basis_mat and the six MLP tensors, contiguous, in
+ *                  parameter order, followed by ONE vote word (a data-parallel caller all-reduces the whole buffer with the gradients;
+ *                  the factor gradients are in the field's gradient buffer: t2n_field_set_grad_buffer)
+ *   rows_capacity  appearance rows (multiple of 32) the workspace is sized for. A step that needs MORE applies NO update at all (every
+ *                  optimiser kernel reads the verdict from device memory and returns; Adam's step count does not advance): the caller
+ *                  learns it from t2n_field_train_record — without waiting — and submits the same batch again with a capacity >= the
+ *                  recorded need.
+ *   phases         1: render + loss + backward only (gradients left in the field's buffer and head_grads), 2: optimiser only (after a
+ *                  data-parallel all-reduce of both; a non-zero vote word withholds the update on every rank), 3: both.
+ *   losses         device float[4] = {mse, depth loss, transmittance loss, total} of the batch
+ * Replaces (reference): text2nerf_main.py:553-590 (renderer call, losses, TV terms, zero_grad / backward / step). */
+#define T2N_TRAIN_HYPER_FLOATS 32
+#define T2N_TRAIN_HEAD_GRAD_FLOATS (27 * 144 + 128 * 351 + 128 + 128 * 128 + 128 + 3 * 128 + 3 + 1)
+typedef struct t2n_train_step_args {
+    const float* rays; int64_t n_rays; int32_t ray_stride; int32_t n_samples;
+    uint32_t flags;            /* T2N_FLAG_ADD_BG or 0 (T2N_FLAG_TRAIN is implied) */
+    uint32_t phases;           /* 1 | 2 */
+    const float* jitter; const float* rgb_target; const float* depth_target;
+    float w_depth, w_trans, delta;
+    float beta1, beta2, eps;
+    const float* hyper;
+    t2n_field_params params;
+    float* exp_avg[19]; float* exp_avg_sq[19];
+    float* head_grads;
+    int64_t rows_capacity;
+    void* workspace; size_t workspace_bytes;
+    float* losses;
+} t2n_train_step_args;
+size_t t2n_train_step_workspace_bytes(const t2n_field* f, int64_t n_rays, int n_samples, int64_t rows_capacity);
+int t2n_train_step(t2n_field* f, const t2n_train_step_args* a, t2n_stream stream);
+/* Adam's step count of the field's fused steps (device memory): set when an optimiser state is loaded / reset. Asynchronous on `stream`. */
+int t2n_field_train_set_step(t2n_field* f, uint32_t step, t2n_stream stream);
+/* What the fused steps recorded, from pinned host memory (never waits, never touches a stream): out[0] = newest sequence number + 1 in
+ * the ring (steps of the field are numbered from 0), out[1] = Adam steps applied, out[2] = steps withheld (both informational: written
+ * without ordering); out[4 + 2 k], out[5 + 2 k], k = 0..15: the record of the step with (sequence number & 15) == k — the appearance rows
+ * it NEEDED and its tag = (sequence number + 1) << 1 | withheld. A record is ONE 8-byte store: a slot whose tag carries another sequence
+ * number has not been written for this step yet. */
+int t2n_field_train_record(const t2n_field* f, uint32_t out[36]);
+/* The same call captured ONCE into a hipGraph (stream capture of t2n_train_step on `stream`, the side streams included) and replayed:
+ * every pointer and size in `a` is frozen — the caller refills the buffers behind them (batch, hyper) before each launch and
+ * re-captures when a size (n_rays, n_samples, rows_capacity, workspace) or a pointer changes. t2n_train_step must have run eagerly once
+ * with the same field (lazy stream / event / buffer creation cannot be captured). */
+typedef struct t2n_train_graph t2n_train_graph;
+int t2n_train_graph_capture(t2n_field* f, const t2n_train_step_args* a, t2n_stream stream, t2n_train_graph** out);
+int t2n_train_graph_launch(t2n_train_graph* g, t2n_stream stream);
+int t2n_train_graph_nodes(const t2n_train_graph* g);   /* kernel nodes of the captured step */
+int t2n_train_graph_destroy(t2n_train_graph* g);
 
 /* ---- measurement hooks (bench.py): when enabled, each kernel launch of the render call is bracketed by HIP events on
  * the launch stream. t2n_timing_read synchronises those events and returns accumulated milliseconds and launch counts

@@ -83,27 +83,124 @@ def step_autograd(f, opt, rays, rgb_t, dep_t, chunk=None):
     return torch.stack([mse, dl, tl, tot]).detach()
 
 
-@pytest.mark.parametrize("seeded", [True, False])
-def test_train_step_equals_the_autograd_step(tiny_params, seeded, monkeypatch):
-    """`seeded`: the TV terms written into the gradient buffer on a side stream in front of the backward (t2n_field_tv_seed; what train_step
-    does for batches of 8 192 rays and more, forced here for the small test batch) against the TV pass inside the optimiser step."""
+@pytest.mark.parametrize("form", ["composed-seeded", "composed", "fused", "fused-graph"])
+def test_train_step_equals_the_autograd_step(tiny_params, form, monkeypatch):
+    """Every form of train_step against the autograd form of the reference's step (text2nerf_main.py:547-601), with the learning rates
+    and the TV weights decaying from step to step like the driver's (lr_factor, :577-583,597-598).
+    composed(-seeded): render -> loss kernel -> backward -> TVAdam as separate calls (`seeded`: the TV terms written into the gradient
+    buffer on a side stream in front of the backward — what that form does for batches of 8 192 rays and more, forced here);
+    fused: ONE C call (t2n_train_step: nothing read on the host, every per-step scalar from device memory); fused-graph: that call
+    captured once per input buffer and replayed (4 captures, then hipGraphLaunch) — the changed learning rates / TV weights reach the
+    replayed kernels through device memory."""
     from text2nerf_amd import tensorf as tf
     from text2nerf_amd.optim import TVAdam
-    monkeypatch.setattr(tf, "_SEED_MIN_RAYS", 0 if seeded else 1 << 30)
+    monkeypatch.setattr(tf, "_SEED_MIN_RAYS", 0 if form == "composed-seeded" else 1 << 30)
+    kw = {"composed-seeded": dict(fused=False), "composed": dict(fused=False), "fused": dict(fused=True, graph=False),
+          "fused-graph": dict(fused=True, graph=True)}[form]
     rays, rgb_t, dep_t = batch()
     fa = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
     fb = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
     oa = TVAdam(fa.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fa)
     ob = TVAdam(fb.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fb)
-    for it in range(3):
-        tv = [(fa.density_plane, 0.1), (fa.app_plane, 0.01)]
+    steps = 7
+    for it in range(steps):
+        w_d, w_a = 0.1 * 0.9 ** it, 0.01 * 0.8 ** it
+        for o in (oa, ob):
+            for g in o.param_groups:
+                g["lr"] = g["lr"] * 0.97
         torch.manual_seed(100 + it)            # the jitter comes from the CPU default generator in both forms
         la = step_autograd(fa, oa, rays, rgb_t, dep_t)
-        oa.step(tv=tv)
+        oa.step(tv=[(fa.density_plane, w_d), (fa.app_plane, w_a)])
         torch.manual_seed(100 + it)
-        lb = fb.train_step(rays, rgb_t, dep_t, ob, N_samples=-1, white_bg=True, tv=[(fb.density_plane, 0.1), (fb.app_plane, 0.01)])
+        lb = fb.train_step(rays, rgb_t, dep_t, ob, N_samples=-1, white_bg=True, tv=[(fb.density_plane, w_d), (fb.app_plane, w_a)], **kw).clone()
         assert torch.allclose(la, lb, rtol=1e-5, atol=1e-9), (it, la, lb)
-    assert_same_trajectory(fa, fb, steps=3)
+    fs = fb.__dict__.get("_fused_step")
+    if form.startswith("fused"):
+        fs.sync()
+        assert fs.replays == 0 and fs.issued == steps
+        assert (fs.graph_launches, fs.graph_captures) == ((steps - 1, 4) if form == "fused-graph" else (0, 0))
+        if form == "fused-graph":
+            assert fs.graph_nodes <= 40        # the captured step: kernels of one iteration (43 launches + torch fills in round 5's composed form)
+        assert all(int(ob.state[p]["step"]) == steps for p in fb.parameters())
+    else:
+        assert fs is None
+    assert_same_trajectory(fa, fb, steps=steps)
+
+
+def test_fused_step_withholds_an_update_whose_rows_do_not_fit(tiny_params):
+    """never apply a truncated gradient. A fused step whose appearance rows exceed its capacity applies NOTHING — the 19
+    tensors, their Adam moments and the step count stay bit-identical — the host learns it from the pinned record (without waiting),
+    counts it and submits the same batch again with a capacity that holds it; the trajectory is the one of the steps without the
+    incident."""
+    from text2nerf_amd.optim import TVAdam
+    rays, rgb_t, dep_t = batch()
+    fa = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    fb = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    oa = TVAdam(fa.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fa)
+    ob = TVAdam(fb.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fb)
+    tv = lambda f: [(f.density_plane, 0.1), (f.app_plane, 0.01)]   # noqa: E731
+    for it in range(2):
+        torch.manual_seed(40 + it)
+        fa.train_step(rays, rgb_t, dep_t, oa, white_bg=True, tv=tv(fa), fused=True, graph=False)
+        torch.manual_seed(40 + it)
+        fb.train_step(rays, rgb_t, dep_t, ob, white_bg=True, tv=tv(fb), fused=True, graph=False)
+    fs = fb._fused_step
+    fs.sync()
+    assert max(fs.needs) > 1024
+    before = {k: v.detach().clone() for k, v in fb.state_dict().items()}
+    moments = [t.clone() for p in fb.parameters() for t in (ob.state[p].get("exp_avg_cl", ob.state[p].get("exp_avg")),)]
+    fs.cap_once = 256                          # far below what the batch needs
+    torch.manual_seed(42)
+    l = fb.train_step(rays, rgb_t, dep_t, ob, white_bg=True, tv=tv(fb), fused=True, graph=False).clone()
+    torch.cuda.synchronize()
+    # the withheld step: nothing moved (bit for bit), the loss of the batch is still reported
+    assert bool(torch.isfinite(l).all())
+    for k, v in fb.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    for t0, p in zip(moments, fb.parameters()):
+        assert torch.equal(t0, ob.state[p].get("exp_avg_cl", ob.state[p].get("exp_avg")))
+    import ctypes as C
+    from text2nerf_amd import _lib
+    rec = (C.c_uint32 * 36)()
+    _lib.check(_lib.load().t2n_field_train_record(fb._handle, rec), "t2n_field_train_record")
+    assert (rec[1], rec[2]) == (2, 1)          # Adam steps applied / withheld, on the device
+    torch.manual_seed(42)
+    fa.train_step(rays, rgb_t, dep_t, oa, white_bg=True, tv=tv(fa), fused=True, graph=False)
+    # the next call reads the record, replays the withheld batch with room for it, then runs its own
+    torch.manual_seed(43)
+    fa.train_step(rays, rgb_t, dep_t, oa, white_bg=True, tv=tv(fa), fused=True, graph=False)
+    torch.manual_seed(43)
+    fb.train_step(rays, rgb_t, dep_t, ob, white_bg=True, tv=tv(fb), fused=True, graph=False)
+    fs.sync()
+    assert fs.replays == 1 and fb.device_rows_overflows == 1 and fs.rows_cap > 1024
+    assert all(int(ob.state[p]["step"]) == 4 for p in fb.parameters())
+    _lib.check(_lib.load().t2n_field_train_record(fb._handle, rec), "t2n_field_train_record")
+    assert (rec[1], rec[2]) == (4, 1)
+    assert_same_trajectory(fa, fb, steps=4)
+
+
+def test_fused_step_in_two_phases_equals_the_single_call(tiny_params):
+    """Data-parallel form: render + loss + backward (phase 1), the caller's all-reduce of the factor gradient buffer and the head gradients
+    (+ the vote word behind them), the optimiser (phase 2). With an identity all-reduce: the single call's trajectory."""
+    from text2nerf_amd.optim import TVAdam
+    rays, rgb_t, dep_t = batch()
+    fa = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    fb = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    oa = TVAdam(fa.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fa)
+    ob = TVAdam(fb.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fb)
+    seen = []
+    def all_reduce():
+        g = fb.factor_grad_buffer()
+        seen.append((float(g.abs().max()), float(fb.basis_mat.weight.grad.abs().max()), float(fb._fused_step.head_grads[-1])))
+    for it in range(4):
+        torch.manual_seed(7 + it)
+        la = fa.train_step(rays, rgb_t, dep_t, oa, white_bg=True, tv=[(fa.density_plane, 0.1), (fa.app_plane, 0.01)], fused=True, graph=False).clone()
+        torch.manual_seed(7 + it)
+        lb = fb.train_step(rays, rgb_t, dep_t, ob, white_bg=True, tv=[(fb.density_plane, 0.1), (fb.app_plane, 0.01)], fused=True, all_reduce=all_reduce).clone()
+        assert torch.allclose(la, lb, rtol=1e-6, atol=1e-9)
+    assert len(seen) == 4 and all(a > 0 and b > 0 and v == 0.0 for a, b, v in seen)   # gradients were there, nobody voted to withhold
+    fb._fused_step.sync()
+    assert_same_trajectory(fa, fb, steps=4)
 
 
 def test_speculative_step_equals_the_counted_step(tiny_params):
@@ -117,7 +214,7 @@ def test_speculative_step_equals_the_counted_step(tiny_params):
     ob = TVAdam(fb.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fb)
     for it in range(6):
         torch.manual_seed(300 + it)
-        la = fa.train_step(rays, rgb_t, dep_t, oa, N_samples=-1, white_bg=True, tv=[(fa.density_plane, 0.1), (fa.app_plane, 0.01)])
+        la = fa.train_step(rays, rgb_t, dep_t, oa, N_samples=-1, white_bg=True, tv=[(fa.density_plane, 0.1), (fa.app_plane, 0.01)], fused=False)
         torch.manual_seed(300 + it)
         lb = fb.train_step(rays, rgb_t, dep_t, ob, N_samples=-1, white_bg=True, tv=[(fb.density_plane, 0.1), (fb.app_plane, 0.01)],
                            speculative=True)

@@ -50,6 +50,23 @@ class GenericDesc(C.Structure):   # t2n_generic_desc: the general-shape path (cs
                 ("density_shift", C.c_float), ("distance_scale", C.c_float), ("weight_thres", C.c_float), ("step_size", C.c_float),
                 ("near", C.c_float), ("far", C.c_float), ("z_gate", C.c_float)]
 
+TRAIN_HYPER_FLOATS = 32
+TRAIN_HEAD_GRAD_FLOATS = 27 * 144 + 128 * 351 + 128 + 128 * 128 + 128 + 3 * 128 + 3 + 1   # + the vote word
+TRAIN_HEAD_SIZES = (27 * 144, 128 * 351, 128, 128 * 128, 128, 3 * 128, 3)
+
+
+class TrainStepArgs(C.Structure):   # t2n_train_step_args
+    _fields_ = [("rays", C.c_void_p), ("n_rays", C.c_int64), ("ray_stride", C.c_int32), ("n_samples", C.c_int32),
+                ("flags", C.c_uint32), ("phases", C.c_uint32),
+                ("jitter", C.c_void_p), ("rgb_target", C.c_void_p), ("depth_target", C.c_void_p),
+                ("w_depth", C.c_float), ("w_trans", C.c_float), ("delta", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("hyper", C.c_void_p), ("params", FieldParams),
+                ("exp_avg", C.c_void_p * 19), ("exp_avg_sq", C.c_void_p * 19),
+                ("head_grads", C.c_void_p), ("rows_capacity", C.c_int64),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("losses", C.c_void_p)]
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -146,6 +163,14 @@ SIGNATURES = {
     "t2n_generic_backward": (C.c_int, [C.POINTER(GenericDesc), C.POINTER(FieldParams), C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FieldGrads),
                                        C.c_void_p, C.c_size_t, C.c_void_p]),
+    "t2n_train_step_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int, C.c_int64]),
+    "t2n_train_step": (C.c_int, [C.c_void_p, C.POINTER(TrainStepArgs), C.c_void_p]),
+    "t2n_field_train_set_step": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "t2n_field_train_record": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "t2n_train_graph_capture": (C.c_int, [C.c_void_p, C.POINTER(TrainStepArgs), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "t2n_train_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "t2n_train_graph_nodes": (C.c_int, [C.c_void_p]),
+    "t2n_train_graph_destroy": (C.c_int, [C.c_void_p]),
     "t2n_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "t2n_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
 }

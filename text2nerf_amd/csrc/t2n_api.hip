@@ -466,6 +466,10 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->ev_join2) (void)hipEventDestroy((hipEvent_t)f->ev_join2);
     if (f->gemm_stream) (void)hipStreamDestroy((hipStream_t)f->gemm_stream);
     if (f->buf_alpha) (void)hipFree(f->buf_alpha);
+    if (f->train_dev) (void)hipFree(f->train_dev);
+    if (f->train_host) (void)hipHostFree(f->train_host);
+    for (auto& e : f->train_ev) if (e) (void)hipEventDestroy((hipEvent_t)e);
+    if (f->bin_stream) (void)hipStreamDestroy((hipStream_t)f->bin_stream);
     for (int k = 0; k < T2N_K_COUNT; ++k)
         for (int i = 0; i < kTimingEvents; ++i) {
             if (f->slots[k].start[i]) (void)hipEventDestroy(f->slots[k].start[i]);
@@ -490,6 +494,7 @@ extern "C" int t2n_field_upload(t2n_field* f, const t2n_field_params* p, t2n_str
     if (rc) return rc;
     f->params_ref = *p;
     f->ss_dirty = true;
+    f->train_packed = false;
     f->uploaded = true;
     return T2N_OK;
 }
@@ -511,6 +516,7 @@ extern "C" int t2n_field_upload_head(t2n_field* f, const t2n_field_params* p, t2
     f->params_ref.mlp_w0 = p->mlp_w0; f->params_ref.mlp_b0 = p->mlp_b0; f->params_ref.mlp_w1 = p->mlp_w1; f->params_ref.mlp_b1 = p->mlp_b1;
     f->params_ref.mlp_w2 = p->mlp_w2; f->params_ref.mlp_b2 = p->mlp_b2;
     f->ss_dirty = true;
+    f->train_packed = false;
     return T2N_OK;
 }
 

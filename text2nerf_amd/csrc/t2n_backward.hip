@@ -952,14 +952,15 @@ __global__ __launch_bounds__(256) void k_relayout_add(const RelayoutAddMulti a) 
 // element-in-place by the same thread) share storage: g1 over h1, g0 over h0, gx over xpe, gf over feat32, gX over x144.
 struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, gpack, hist, bin_total, tile_start, nseg, segs, recs, a_hist, a_bin_total, a_tile_start, a_nseg, a_segs, a_recs, plan, total; unsigned seg_cap, a_seg_cap; };
 static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
-static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_tiles, int n_blocks, int k0 = 351) {   // k0: inputs of MLP layer 0; n_blocks: density bins x copies
+static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_tiles, int n_blocks, int k0 = 351, bool rows_kept = false) {   // k0: inputs of MLP layer 0; n_blocks: density bins x copies; rows_kept: the activation rows live in the forward's workspace (fused step): none here
     BwdCarve c;
     size_t o = 0;
     const size_t R = (size_t)rows;
-    c.x144 = o; o = al256(o + R * 144 * 4);
-    c.feat32 = o; o = al256(o + R * 32 * 4);
-    c.h0 = o; o = al256(o + R * 128 * 4);
-    c.h1 = o; o = al256(o + R * 128 * 4);
+    const size_t RA = rows_kept ? 0 : R;
+    c.x144 = o; o = al256(o + RA * 144 * 4);
+    c.feat32 = o; o = al256(o + RA * 32 * 4);
+    c.h0 = o; o = al256(o + RA * 128 * 4);
+    c.h1 = o; o = al256(o + RA * 128 * 4);
     c.go = o; o = al256(o + R * 16);
     c.xpe = o; o = al256(o + R * (size_t)((k0 + 3) & ~3) * 4);
     c.part = o; o = al256(o + tn_part_bytes(rows, k0));
@@ -1536,5 +1537,457 @@ extern "C" size_t t2n_field_grad_buffer_density_bytes(const t2n_field* f) {
 extern "C" int t2n_field_wait_density_grads(const t2n_field* f, t2n_stream waiter) {
     if (!f) { set_error("t2n_field_wait_density_grads: NULL field"); return T2N_ERR_INVALID; }
     if (f->ev_den) T2N_HIP(hipStreamWaitEvent((hipStream_t)waiter, (hipEvent_t)f->ev_den, 0));
+    return T2N_OK;
+}
+
+// =====================================================================================================================================
+// t2n_train_step: one optimisation step of text2nerf_main.py:547-601 as ONE submission (include/t2n.h). The kernels are those of
+// t2n_render_forward (KEEP_CTX, train), t2n_train_loss, t2n_render_backward (T2N_FLAG_DEVICE_ROWS) and the optimiser entry points; what is
+// new is the ORDER: every launch that does not lie on the step's dependency chain runs on a side stream beside it, and nothing about a
+// step is decided on the host.
+//   s  (caller)  setup -> march -> shade (kept rows) -> composite -> loss -> bwd_march -> mlp_bwd_ss -> tile_accum -> Adam (factors)
+//   sa (side)    TV seed of the gradient buffer (beside the march) ........ density binning + scatter (behind bwd_march)
+//   sb (bin)     plan (rows, tile prefix, verdict, Adam scalars, host record) -> appearance binning (needs the forward's lists only)
+//   sg (gemm)    layer-2 gradients (behind bwd_march) -> weight-gradient GEMMs (behind mlp_bwd_ss) -> Adam (head) -> operand re-packs
+// =====================================================================================================================================
+#ifndef T2N_SEED_AFTER_MARCH
+#define T2N_SEED_AFTER_MARCH 1
+#endif
+namespace t2n {
+
+// zero fills of one step as ONE launch: region r = blockIdx.y (a uniform index into the kernel arguments)
+constexpr int kZeroRegions = 12;
+struct ZeroOps { unsigned* ptr[kZeroRegions]; unsigned long long words[kZeroRegions]; int n = 0;
+    bool add(void* p, size_t bytes) { if (!p || !bytes) return true; if (n >= kZeroRegions) return false; ptr[n] = (unsigned*)p; words[n] = (bytes + 3) / 4; ++n; return true; } };
+__global__ __launch_bounds__(256) void k_zero_regions(const ZeroOps o) {
+    const int r = blockIdx.y;
+    unsigned* __restrict__ p = o.ptr[r];
+    const unsigned long long n = o.words[r];
+    if ((((uintptr_t)p) & 15u) == 0) {
+        uint4* __restrict__ p4 = reinterpret_cast<uint4*>(p);
+        const unsigned long long n4 = n / 4;
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (unsigned long long i = n4 * 4 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) p[i] = 0u;
+    } else {
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) p[i] = 0u;
+    }
+}
+
+// The plan of a fused step (one wave, right behind the forward's march): k_bwd_plan's tile prefix / row count / overflow from the
+// sub-list counters, and with them the step's VERDICT — a step whose rows exceed the capacity applies no update — Adam's step count and
+// this step's bias-corrected scalars (torch.optim.Adam: step_size = lr / (1 - beta1^t), denom = sqrt(v) / sqrt(1 - beta2^t) + eps, in
+// double like the host entry points), the vote word behind the head gradients and the record in pinned host memory.
+__global__ __launch_bounds__(64) void k_train_plan(const unsigned* __restrict__ counters, unsigned list_cap, unsigned rows_cap, BwdPlan* __restrict__ plan,
+                                                   TrainState* __restrict__ st, const float* __restrict__ hyper, float beta1, float beta2, float* vote,
+                                                   unsigned* host_rec) {
+    const int lane = threadIdx.x;
+    unsigned cnt = lane < kLists ? counters[lane * kCounterStride] : 0u;
+    if (cnt > list_cap) cnt = list_cap;
+    unsigned incl = (cnt + 31u) / 32u;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const unsigned excl = incl - (cnt + 31u) / 32u;
+    if (lane < kLists) plan->tp.t[lane] = excl;
+    const unsigned total = __shfl(incl, kLists - 1);
+    const unsigned rows = total * 32u;
+    const unsigned ovf = rows > rows_cap ? 1u : 0u;
+    const unsigned step = st->step + (ovf ? 0u : 1u);     // (every lane reads the old value; lane 0 writes below)
+    if (lane < 19 && !ovf) {
+        const double bc1 = 1.0 - pow((double)beta1, (double)step);
+        st->lr_over_bc1[lane] = (float)((double)hyper[lane] / bc1);
+        if (lane == 0) st->inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        plan->tp.t[kLists] = total;
+        plan->overflow = ovf;
+        plan->rows = rows < rows_cap ? rows : rows_cap;
+        const unsigned seq = st->seq;
+        st->seq = seq + 1u;
+        st->skip = ovf;
+        st->step = step;
+        if (ovf) st->skipped = st->skipped + 1u;
+        if (vote) *vote = ovf ? 1.f : 0.f;
+        if (host_rec) {
+            // ONE 8-byte store per record into fine-grained pinned memory: {rows needed, (sequence + 1) << 1 | withheld}. No fence: a
+            // system-scope release writes the L2 back (60 us behind the march's 50 MB of output), and the host needs no ordering between
+            // records — an entry whose sequence number is not the one it waits for has simply not arrived yet
+            volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(host_rec);
+            h[2 + (seq & 15u)] = ((unsigned long long)(((seq + 1u) << 1) | ovf) << 32) | rows;
+            host_rec[1] = step; host_rec[2] = st->skipped;
+        }
+    }
+}
+// Data-parallel steps (phases 1 | all-reduce | 2): the vote word came back from the all-reduce of the head gradients. A rank whose own
+// rows fitted but whose peers' did not withholds its update too: the optimistic count of k_train_plan is taken back.
+__global__ __launch_bounds__(64) void k_train_commit(TrainState* __restrict__ st, const float* __restrict__ vote, unsigned* host_rec) {
+    if (threadIdx.x != 0) return;
+    if (*vote != 0.f && !st->skip) {
+        st->skip = 1u; st->step = st->step - 1u; st->skipped = st->skipped + 1u;
+        if (host_rec) {
+            volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(host_rec);
+            const unsigned seq = st->seq - 1u;
+            h[2 + (seq & 15u)] = h[2 + (seq & 15u)] | (1ull << 32);
+            host_rec[1] = st->step; host_rec[2] = st->skipped;
+        }
+    }
+}
+__global__ __launch_bounds__(64) void k_train_set_step(TrainState* st, unsigned step, unsigned* host_rec) {
+    if (threadIdx.x == 0) { st->step = step; if (host_rec) ((volatile unsigned*)host_rec)[1] = step; }
+}
+
+struct TrainCarve { size_t fwd, fwd_bytes, bwd, bwd_bytes, g1, rgb, depth, w, z, d_rgb, d_depth, d_w, part, total; };
+static TrainCarve train_carve(const t2n_field* f, int64_t R, int N, int64_t rows) {
+    TrainCarve t;
+    const BinGeom geom = bin_geom(f->dev.den);
+    const BlockGeom bg = block_geom(f->dev.den);
+    size_t o = 0;
+    const Carve c = carve_workspace(R, N, true, false);
+    t.fwd = o; t.fwd_bytes = al256(c.total) + (size_t)rows * (144 + 32 + 128 + 128) * 4; o = al256(o + t.fwd_bytes);
+    t.bwd = o; t.bwd_bytes = bwd_carve(rows, R, N, geom.total, bg.total * bg.copies, 351, true).total; o = al256(o + t.bwd_bytes);
+    t.g1 = o; o = al256(o + (size_t)rows * 128 * 4);
+    t.rgb = o; o = al256(o + (size_t)R * 12);
+    t.depth = o; o = al256(o + (size_t)R * 4);
+    t.w = o; o = al256(o + (size_t)R * N * 4);
+    t.z = o; o = al256(o + (size_t)R * N * 4);
+    t.d_rgb = o; o = al256(o + (size_t)R * 12);
+    t.d_depth = o; o = al256(o + (size_t)R * 4);
+    t.d_w = o; o = al256(o + (size_t)R * N * 4);
+    t.part = o; o = al256(o + (size_t)((R + 3) / 4) * 12);
+    t.total = o;
+    return t;
+}
+static size_t train_dev_bytes() { return 256 + al256(mlp_bwd_ss_pack_bytes()); }
+static bool train_supported(const t2n_field* f) {
+    return f->desc.shading == T2N_SHADE_MLP_FEA_NOVIEW && f->desc.app_dim == 27 && f->dev.app.C == 48 && f->dev.den.C == 16 && f->mlp_split &&
+           !f->factor_bf16 && !f->dev.alpha && block_geom_ok(f->dev.den);
+}
+static int train_ensure(t2n_field* f, hipStream_t s) {
+    if (!f->train_dev) {
+        T2N_HIP(hipMalloc(&f->train_dev, train_dev_bytes()));
+        T2N_HIP(hipMemsetAsync(f->train_dev, 0, 256, s));
+        T2N_HIP(hipHostMalloc((void**)&f->train_host, 64 * sizeof(unsigned), hipHostMallocDefault));
+        for (int i = 0; i < 64; ++i) f->train_host[i] = 0u;
+        f->train_packed = false;
+    }
+    auto mk_stream = [](void** st) -> int { if (!*st) { hipStream_t x; T2N_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking)); *st = (void*)x; } return T2N_OK; };
+    int rc;
+    if ((rc = mk_stream(&f->side_stream)) || (rc = mk_stream(&f->gemm_stream)) || (rc = mk_stream(&f->bin_stream))) return rc;
+    for (auto& e : f->train_ev) if (!e) { hipEvent_t x; T2N_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming)); e = (void*)x; }
+    if (!f->ev_den) { hipEvent_t e; T2N_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); f->ev_den = (void*)e; }
+    return T2N_OK;
+}
+// the backward chain's transposed split-f16 operands + the forward's packed head operands from the CURRENT head weights
+static int train_repack(t2n_field* f, const t2n_field_params* p, bool forward_too, hipStream_t s) {
+    int rc;
+    if (forward_too && (rc = launch_pack_mlp(f, p, s))) return rc;
+    void* gpack = (char*)f->train_dev + 256;
+    if ((rc = mlp_bwd_ss_pack(f, gpack, s, false))) return rc;
+    f->train_packed = true;
+    return T2N_OK;
+}
+
+}  // namespace t2n
+
+extern "C" size_t t2n_train_step_workspace_bytes(const t2n_field* f, int64_t n_rays, int n_samples, int64_t rows_capacity) {
+    if (!f || n_rays <= 0 || n_samples <= 0 || rows_capacity < 32) return 0;
+    return train_carve(f, n_rays, n_samples, rows_capacity / 32 * 32).total;
+}
+
+extern "C" int t2n_field_train_set_step(t2n_field* f, uint32_t step, t2n_stream stream) {
+    if (!f) { set_error("t2n_field_train_set_step: NULL field"); return T2N_ERR_INVALID; }
+    int rc;
+    if ((rc = train_ensure(f, (hipStream_t)stream))) return rc;
+    hipLaunchKernelGGL(k_train_set_step, dim3(1), dim3(64), 0, (hipStream_t)stream, (TrainState*)f->train_dev, (unsigned)step, f->train_host);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+extern "C" int t2n_field_train_record(const t2n_field* f, uint32_t out[36]) {
+    if (!f || !out) { set_error("t2n_field_train_record: NULL argument"); return T2N_ERR_INVALID; }
+    if (!f->train_host) { for (int i = 0; i < 36; ++i) out[i] = 0u; return T2N_OK; }
+    // pinned layout: words 1, 2 = steps applied / withheld (informational: written without ordering), then 16 eight-byte records
+    // {rows needed, (sequence + 1) << 1 | withheld} at sequence & 15. out[0] = number of consecutive records present from the field's
+    // first step on, i.e. records of sequence numbers < out[0] have all landed (the host keeps its own count of what it consumed).
+    const volatile unsigned long long* h = reinterpret_cast<const volatile unsigned long long*>(f->train_host);
+    out[1] = f->train_host[1]; out[2] = f->train_host[2]; out[3] = 0u;
+    unsigned newest = 0u;
+    for (int k = 0; k < 16; ++k) {
+        const unsigned long long e = h[2 + k];
+        const unsigned tag = (unsigned)(e >> 32);
+        out[4 + 2 * k] = (unsigned)e;           // rows needed
+        out[5 + 2 * k] = tag;                   // (sequence + 1) << 1 | withheld; 0 = never written
+        if ((tag >> 1) > newest) newest = tag >> 1;
+    }
+    out[0] = newest;   // newest sequence number + 1 seen in the ring (records arrive in order: one plan kernel after the other)
+    return T2N_OK;
+}
+
+extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_stream stream) {
+    if (!f || !A || !A->rays || !A->jitter || !A->rgb_target || !A->depth_target || !A->hyper || !A->head_grads || !A->workspace || !A->losses ||
+        A->n_rays <= 0 || A->ray_stride < 6 || A->n_samples <= 0 || !(A->phases & 3u)) {
+        set_error("t2n_train_step: bad argument");
+        return T2N_ERR_INVALID;
+    }
+    if (!f->uploaded) { set_error("t2n_train_step: field has no uploaded parameters"); return T2N_ERR_STATE; }
+    if (!train_supported(f)) {
+        set_error("t2n_train_step: needs the fused MLP_Fea_noview head (27 / 6 / 128) in split-f16 mode, 16 + 48 components, fp32 factor storage, no alpha mask");
+        return T2N_ERR_UNSUPPORTED;
+    }
+    const int64_t R = A->n_rays;
+    const int N = A->n_samples;
+    const int64_t rows = A->rows_capacity / 32 * 32;
+    if (N > 1024 || rows < 32 || (uint64_t)R * N * 3 >= 0x7fffffffull || (uint64_t)list_capacity(R, N) * kLists > 0x7fffffffull) {
+        set_error("t2n_train_step: n_samples %d (<= 1024), rows_capacity %lld (>= 32) or n_rays x n_samples out of range", N, (long long)A->rows_capacity);
+        return T2N_ERR_UNSUPPORTED;
+    }
+    int Lmax = 0;
+    for (int k = 0; k < 3; ++k) Lmax = f->dev.den.L[k] > Lmax ? f->dev.den.L[k] : Lmax;
+    const size_t lds_acc = tile_accum_lds(16, Lmax);
+    if (lds_acc > 160 * 1024) { set_error("t2n_train_step: grid lines beyond the LDS budget of the binned scatter"); return T2N_ERR_UNSUPPORTED; }
+    const TrainCarve T = train_carve(f, R, N, rows);
+    if (T.total > A->workspace_bytes) { set_error("t2n_train_step: workspace %zu B < %zu B", A->workspace_bytes, T.total); return T2N_ERR_WORKSPACE; }
+    if (!f->gbuf_all) { set_error("t2n_train_step: the field has no gradient buffer (t2n_field_set_grad_buffer)"); return T2N_ERR_STATE; }
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = train_ensure(f, s))) return rc;
+    hipStream_t sa = (hipStream_t)f->side_stream, sg = (hipStream_t)f->gemm_stream, sb = (hipStream_t)f->bin_stream;
+    hipEvent_t* ev = (hipEvent_t*)f->train_ev;   // 0 begin, 1 seed, 2 march, 3 plan, 4 appbin, 5 bwd_march, 6 chain, 7 gemm-stream join, 8 loss
+    TrainState* st = (TrainState*)f->train_dev;
+    void* gpack = (char*)f->train_dev + 256;
+    float* vote = A->head_grads + (T2N_TRAIN_HEAD_GRAD_FLOATS - 1);
+    const bool do_grad = (A->phases & 1u) != 0, do_opt = (A->phases & 2u) != 0;
+    // the caller's tensors are the parameters from here on (the optimiser writes them; the packs read them)
+    const t2n_field_params* P = &A->params;
+    if (do_opt && (!P->basis_weight || !P->mlp_w0 || !P->mlp_b0 || !P->mlp_w1 || !P->mlp_b1 || !P->mlp_w2 || !P->mlp_b2)) { set_error("t2n_train_step: NULL head tensor"); return T2N_ERR_INVALID; }
+
+    char* ws = (char*)A->workspace;
+    char* fw = ws + T.fwd;
+    char* bw = ws + T.bwd;
+    const Carve c = carve_workspace(R, N, true, false);
+    const KeptRows kr = kept_rows(c.total, T.fwd_bytes);
+    if ((int64_t)kr.rows < rows) { set_error("t2n_train_step: internal carve mismatch (%u kept rows < %lld)", kr.rows, (long long)rows); return T2N_ERR_WORKSPACE; }
+    const BinGeom ageom = bin_geom(f->dev.app);
+    const BinGeom dgeom_t = bin_geom(f->dev.den);
+    const BlockGeom bgeom = block_geom(f->dev.den);
+    const BwdCarve b = bwd_carve(rows, R, N, dgeom_t.total, bgeom.total * bgeom.copies, 351, true);
+    float* rgb = (float*)(ws + T.rgb); float* depth = (float*)(ws + T.depth); float* w = (float*)(ws + T.w); float* z = (float*)(ws + T.z);
+    float* d_rgb = (float*)(ws + T.d_rgb); float* d_depth = (float*)(ws + T.d_depth); float* d_w = (float*)(ws + T.d_w);
+    const uint32_t flags = (A->flags & T2N_FLAG_ADD_BG) | T2N_FLAG_TRAIN | T2N_FLAG_KEEP_CTX;
+
+    if (do_grad) {
+        if (!f->train_packed) {   // first step / after an upload: the operands an optimiser phase leaves packed behind every later step
+            if ((rc = mlp_bwd_ss_pack(f, gpack, s, false))) return rc;
+            f->train_packed = true;
+        }
+        T2N_HIP(hipEventRecord(ev[0], s));
+        // ---- every zero fill of the step in one launch
+        RenderLaunch L;
+        L.rays = A->rays; L.n_rays = R; L.ray_stride = A->ray_stride; L.n_samples = N; L.flags = flags; L.jitter = A->jitter;
+        L.rgb = rgb; L.depth = depth; L.weights = w; L.z_vals = z; L.stats = nullptr;
+        L.counters = (unsigned*)(fw + c.counters); L.acc = (float*)(fw + c.acc); L.ray_app = (int4*)(fw + c.ray_app);
+        L.app_pos = (float4*)(fw + c.app_pos); L.app_rgb = (float4*)(fw + c.app_rgb); L.app_ray = (int*)(fw + c.app_ray);
+        L.list_cap = c.list_cap; L.feat = nullptr; L.feat_rows = 0;
+        L.sigma_ctx = (float*)(fw + c.sigma); L.rgb_raw = (float4*)(fw + c.rgb_raw);
+        float4* go = (float4*)(bw + b.go);
+        {
+            ZeroOps zo;
+            bool ok = zo.add(L.counters, (size_t)kLists * kCounterStride * 4);
+            ok = ok && zo.add(go, (size_t)rows * 16);
+            ok = ok && zo.add(bw + b.hist, (size_t)bgeom.total * bgeom.copies * 4);
+            ok = ok && zo.add(bw + b.a_hist, (size_t)ageom.total * kBinCopies * 4);
+            ok = ok && zo.add(A->head_grads, (size_t)T2N_TRAIN_HEAD_GRAD_FLOATS * 4);
+            if (!ok) { set_error("t2n_train_step: zero-fill table overflow"); return T2N_ERR_INVALID; }
+            unsigned long long mx = 1;
+            for (int r = 0; r < zo.n; ++r) mx = zo.words[r] > mx ? zo.words[r] : mx;
+            unsigned bx = (unsigned)((mx + 4095) / 4096);
+            bx = bx > 256 ? 256 : (bx < 1 ? 1 : bx);
+            hipLaunchKernelGGL(k_zero_regions, dim3(bx, (unsigned)zo.n), dim3(256), 0, s, zo);
+        }
+        // ---- forward: march
+        if ((rc = launch_march(f, L, s))) return rc;
+        T2N_HIP(hipEventRecord(ev[2], s));
+        // ---- forward: shade with the activation rows kept, composite; the driver's loss
+        {
+            ShadeCtx ctx{(float*)(fw + kr.x144), (float*)(fw + kr.feat32), (float*)(fw + kr.h0), (float*)(fw + kr.h1)};
+            if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, A->ray_stride, L.counters, L.list_cap, L.app_rgb, &ctx, s, false, kr.rows))) return rc;
+        }
+        if ((rc = launch_composite(f, L, s))) return rc;
+        // (the sum of the per-workgroup partials only feeds the reported losses: off the chain, on sg — folded into the loss kernel's last
+        // workgroup it needs an agent-scope release per workgroup, i.e. an L2 write-back each: 357 us instead of 22)
+        if ((rc = launch_train_loss(rgb, depth, w, z, A->rgb_target, A->depth_target, R, N, A->w_depth, A->w_trans, A->delta, d_rgb, d_depth, d_w,
+                                    A->losses, (float*)(ws + T.part), nullptr, s, sg, ev[8]))) return rc;
+        // ---- sb: plan, then the appearance binning (needs the forward's lists and the plan, not a single gradient)
+        T2N_HIP(hipStreamWaitEvent(sb, ev[2], 0));
+        BwdPlan* plan = (BwdPlan*)(bw + b.plan);
+        hipLaunchKernelGGL(k_train_plan, dim3(1), dim3(64), 0, sb, (const unsigned*)L.counters, c.list_cap, (unsigned)rows, plan, st, A->hyper,
+                           A->beta1, A->beta2, vote, f->train_host);
+        T2N_HIP(hipEventRecord(ev[3], sb));
+        GradSet gapp;
+        for (int k = 0; k < 3; ++k) { gapp.plane[k] = f->gbuf_app_plane[k]; gapp.line[k] = f->gbuf_app_line[k]; }
+        float* GX = (float*)(bw + b.xpe) + (size_t)rows * 160;
+        {
+            AppBinArgs ab;
+            ab.S = f->dev.app; ab.geom = ageom; ab.app_pos = L.app_pos; ab.counters = L.counters; ab.list_cap = c.list_cap;
+            ab.plan = plan; memset(&ab.tp, 0, sizeof(ab.tp)); ab.rows = rows; ab.hist = (unsigned*)(bw + b.a_hist); ab.tile_start = (const unsigned*)(bw + b.a_tile_start); ab.recs = (float4*)(bw + b.a_recs);
+            const unsigned nbk = (unsigned)((rows + 255) / 256);
+            hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, sb, ab);
+            launch_bin_scan(ab.hist, ab.geom.total, kBinCopies, (unsigned*)(bw + b.a_bin_total), (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),
+                            b.a_seg_cap, 0u, kAccTargetSegsApp, 512u, sb);
+            hipLaunchKernelGGL((k_app_bin<1>), dim3(nbk), dim3(256), 0, sb, ab);
+            T2N_HIP(hipEventRecord(ev[4], sb));
+        }
+        // ---- sa: the gradient buffer starts as the TV gradient of the current factors (zero where no weight is set): 140 MB of streaming
+        // beside the shade kernel (matrix cores + LDS) rather than beside the march (gathers: the two slow each other by a third)
+        T2N_HIP(hipStreamWaitEvent(sa, ev[T2N_SEED_AFTER_MARCH ? 2 : 0], 0));
+        if ((rc = launch_tv_seed_dev(f, A->hyper + 19, sa))) return rc;
+        T2N_HIP(hipEventRecord(ev[1], sa));
+        // ---- backward: per-ray pass
+        float* x144 = (float*)(fw + kr.x144); float* feat32 = (float*)(fw + kr.feat32); float* h0 = (float*)(fw + kr.h0); float* h1 = (float*)(fw + kr.h1);
+        float* part = (float*)(bw + b.part);
+        float* xpe = (float*)(bw + b.xpe);
+        float* G0 = xpe; float* GF = xpe + (size_t)rows * 128;
+        float* G1 = (float*)(ws + T.g1);
+        const unsigned* rows_dev = &plan->rows;
+        T2N_HIP(hipStreamWaitEvent(s, ev[3], 0));
+        {
+            BwdMarchArgs a;
+            a.F = f->dev; a.F.ztab = nullptr;
+            for (int k = 0; k < 3; ++k) { a.gden.plane[k] = f->gbuf_den_plane[k]; a.gden.line[k] = f->gbuf_den_line[k]; }
+            a.rays = A->rays; a.n_rays = R; a.ray_stride = A->ray_stride; a.n_samples = N; a.npad = (N + 63) & ~63;
+            a.jitter = A->jitter; a.sigma = (const float*)(fw + c.sigma); a.ray_app = (const int4*)(fw + c.ray_app);
+            a.app_rgb = L.app_rgb; a.rgb_raw = (const float4*)(fw + c.rgb_raw);
+            a.d_rgb = d_rgb; a.d_depth = d_depth; a.d_w = d_w; a.go = go; a.list_cap = c.list_cap; memset(&a.tp, 0, sizeof(a.tp)); a.plan = plan;
+            a.add_bg = (flags & T2N_FLAG_ADD_BG) ? 1 : 0;
+            a.gfeat = (float*)(fw + c.sigma); a.hist = (unsigned*)(bw + b.hist); a.geom = bgeom;
+            const size_t lds = (size_t)4 * 4 * a.npad * sizeof(float);
+            const unsigned nb = (unsigned)((R + 3) / 4);
+            hipLaunchKernelGGL((k_bwd_march<true, true>), dim3(nb), dim3(256), lds, s, a);
+            T2N_HIP(hipEventRecord(ev[5], s));
+        }
+        float* hg = A->head_grads;   // basis | w0 | b0 | w1 | b1 | w2 | b2
+        float* g_basis = hg; float* g_w0 = g_basis + 27 * 144; float* g_b0 = g_w0 + 128 * 351; float* g_w1 = g_b0 + 128; float* g_b1 = g_w1 + 128 * 128;
+        float* g_w2 = g_b1 + 128; float* g_b2 = g_w2 + 3 * 128;
+        // ---- the input-gradient chain
+        if ((rc = launch_mlp_bwd_ss(f, gpack, (const float4*)go, h1, h0, feat32, G0, GF, GX, rows, s, true, rows_dev, G1))) return rc;
+        T2N_HIP(hipEventRecord(ev[6], s));
+        {
+            const unsigned nb = (unsigned)((R + 3) / 4);
+            // ---- sa: density scatter (behind the TV seed on the same stream)
+            T2N_HIP(hipStreamWaitEvent(sa, ev[5], 0));
+            launch_bin_scan((unsigned*)(bw + b.hist), bgeom.total, bgeom.copies, (unsigned*)(bw + b.bin_total), (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, kDenSeg,
+                            0u, kDenSeg, sa);
+            BinArgs ba;
+            ba.F = f->dev; ba.F.ztab = nullptr; ba.geom = bgeom; ba.rays = A->rays; ba.n_rays = R; ba.ray_stride = A->ray_stride; ba.n_samples = N;
+            ba.jitter = A->jitter; ba.gfeat = (float*)(fw + c.sigma); ba.ray_app = (const int4*)(fw + c.ray_app); ba.cursor = (unsigned*)(bw + b.hist); ba.tile_start = (const unsigned*)(bw + b.tile_start); ba.recs = (float4*)(bw + b.recs);
+            hipLaunchKernelGGL((k_bwd_bin<true>), dim3(nb), dim3(256), 0, sa, ba);
+            DenBlockArgs da;
+            da.S = f->dev.den; for (int k = 0; k < 3; ++k) { da.G.plane[k] = f->gbuf_den_plane[k]; da.G.line[k] = f->gbuf_den_line[k]; } da.geom = bgeom; da.segs = (const int4*)(bw + b.segs);
+            da.nseg = (const unsigned*)(bw + b.nseg); da.recs = (const float4*)(bw + b.recs);
+            hipLaunchKernelGGL(k_bwd_den_block, dim3(b.seg_cap < kAccGrid ? b.seg_cap : kAccGrid), dim3(kDenThreads), 0, sa, da);
+            T2N_HIP(hipEventRecord((hipEvent_t)f->ev_den, sa));
+                }
+        // ---- sg: layer 2's weight gradient needs go and the kept h1 only (the chain writes g1 elsewhere in this form)
+        T2N_HIP(hipStreamWaitEvent(sg, ev[5], 0));
+        launch_bwd_l2((const float4*)go, (const float*)h1, rows, f->params_ref.mlp_w2, nullptr, g_w2, g_b2, part, sg, rows_dev);
+        T2N_HIP(hipStreamWaitEvent(sg, ev[6], 0));
+        launch_gemm_tn(4, false, G1, 128, h0, 128, rows, 128, 128, g_w1, 128, part, sg, nullptr, g_b1, rows_dev);
+        launch_gemm_tn(4, false, G0, 128, xpe, 352, rows, 128, 351, g_w0, 351, part, sg, feat32, g_b0, rows_dev);
+        launch_gemm_tn(1, false, GF, 32, x144, 144, rows, 27, 144, g_basis, 144, part, sg, nullptr, nullptr, rows_dev);
+        // ---- appearance scatter: records binned on sb, gradient buffer seeded on sa
+        T2N_HIP(hipStreamWaitEvent(s, ev[4], 0));
+        T2N_HIP(hipStreamWaitEvent(s, ev[1], 0));
+        {
+            TileAccumArgs ta;
+            ta.S = f->dev.app; ta.G = gapp; ta.geom = ageom; ta.segs = (const int4*)(bw + b.a_segs);
+            ta.nseg = (const unsigned*)(bw + b.a_nseg); ta.recs = (const float4*)(bw + b.a_recs);
+            ta.gx = GX; ta.gx_ld = 144;
+            static bool attr_set = false;
+            if (!attr_set) { T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+            hipLaunchKernelGGL((k_bwd_tile_accum<48>), dim3(b.a_seg_cap < kAccGrid ? b.a_seg_cap : kAccGrid, 3), dim3(kAccThreads), lds_acc, s, ta);
+        }
+        T2N_HIP(hipGetLastError());
+        if (!do_opt) {   // gradients final on `s`: join both side chains
+            T2N_HIP(hipEventRecord(ev[7], sg));
+            T2N_HIP(hipStreamWaitEvent(s, ev[7], 0));
+            T2N_HIP(hipStreamWaitEvent(s, (hipEvent_t)f->ev_den, 0));
+            return T2N_OK;
+        }
+    } else {
+        // optimiser-only phase (data-parallel): the vote word has been all-reduced with the head gradients
+        hipLaunchKernelGGL(k_train_commit, dim3(1), dim3(64), 0, s, st, (const float*)vote, f->train_host);
+        T2N_HIP(hipEventRecord(ev[6], s));
+        T2N_HIP(hipStreamWaitEvent(sg, ev[6], 0));
+    }
+    // ---- optimiser. sg: Adam on the seven head tensors, then every packed form of the new head weights (the forward's fp32 and
+    // split-f16 operands, the backward chain's transposed ones) beside the factor tensors' Adam on `s`
+    if ((rc = launch_head_adam_dev(P, A->head_grads, A->exp_avg + 12, A->exp_avg_sq + 12, A->beta1, A->beta2, A->eps, st, sg))) return rc;
+    f->params_ref.basis_weight = P->basis_weight;
+    f->params_ref.mlp_w0 = P->mlp_w0; f->params_ref.mlp_b0 = P->mlp_b0; f->params_ref.mlp_w1 = P->mlp_w1; f->params_ref.mlp_b1 = P->mlp_b1;
+    f->params_ref.mlp_w2 = P->mlp_w2; f->params_ref.mlp_b2 = P->mlp_b2;
+    for (int k = 0; k < 3; ++k) {
+        f->params_ref.density_plane[k] = P->density_plane[k]; f->params_ref.density_line[k] = P->density_line[k];
+        f->params_ref.app_plane[k] = P->app_plane[k]; f->params_ref.app_line[k] = P->app_line[k];
+    }
+    if ((rc = train_repack(f, P, true, sg))) return rc;
+    f->ss_dirty = true;
+    T2N_HIP(hipEventRecord(ev[7], sg));
+    if (do_grad) T2N_HIP(hipStreamWaitEvent(s, (hipEvent_t)f->ev_den, 0));
+    if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, st, 0, 12, s))) return rc;
+    T2N_HIP(hipStreamWaitEvent(s, ev[7], 0));
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+// ---- the step as a hipGraph: stream capture of the call above (relaxed mode: the library's side streams join the capture through
+// their event waits), instantiated once, replayed per step
+struct t2n_train_graph { hipGraph_t graph; hipGraphExec_t exec; int nodes; t2n_field* f; };
+
+extern "C" int t2n_train_graph_capture(t2n_field* f, const t2n_train_step_args* a, t2n_stream stream, t2n_train_graph** out) {
+    if (!f || !a || !out) { set_error("t2n_train_graph_capture: NULL argument"); return T2N_ERR_INVALID; }
+    if (!f->train_dev || !f->train_packed) { set_error("t2n_train_graph_capture: run t2n_train_step eagerly once first (lazy state cannot be captured)"); return T2N_ERR_STATE; }
+    // captured on a stream of its own: the caller's may be the legacy default stream, which cannot capture (hipErrorStreamCaptureUnsupported);
+    // the instantiated graph is launched on whatever stream the caller passes to t2n_train_graph_launch
+    (void)stream;
+    hipStream_t s = nullptr;
+    T2N_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    const hipError_t e0 = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+    if (e0 != hipSuccess) { (void)hipStreamDestroy(s); return hip_fail(e0, "hipStreamBeginCapture"); }
+    const int rc = t2n_train_step(f, a, (t2n_stream)s);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    (void)hipStreamDestroy(s);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess || !g) return hip_fail(e, "hipStreamEndCapture");
+    hipGraphExec_t ex = nullptr;
+    const hipError_t e2 = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e2 != hipSuccess) { (void)hipGraphDestroy(g); return hip_fail(e2, "hipGraphInstantiate"); }
+    size_t n = 0;
+    (void)hipGraphGetNodes(g, nullptr, &n);
+    t2n_train_graph* tg = new t2n_train_graph{g, ex, (int)n, f};
+    *out = tg;
+    return T2N_OK;
+}
+extern "C" int t2n_train_graph_launch(t2n_train_graph* g, t2n_stream stream) {
+    if (!g) { set_error("t2n_train_graph_launch: NULL graph"); return T2N_ERR_INVALID; }
+    t2n_field* f = g->f;
+    if (!f->train_packed) {   // the head was uploaded since the last step (load_state_dict, a step of another optimiser): the captured step
+        // expects the backward chain's operands of the CURRENT weights, which an optimiser phase leaves behind and an upload does not
+        const int rc = mlp_bwd_ss_pack(f, (char*)f->train_dev + 256, (hipStream_t)stream, false);
+        if (rc) return rc;
+        f->train_packed = true;
+    }
+    T2N_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return T2N_OK;
+}
+extern "C" int t2n_train_graph_nodes(const t2n_train_graph* g) { return g ? g->nodes : 0; }
+extern "C" int t2n_train_graph_destroy(t2n_train_graph* g) {
+    if (!g) return T2N_OK;
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
     return T2N_OK;
 }

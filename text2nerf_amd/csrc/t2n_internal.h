@@ -54,6 +54,20 @@ struct FieldDev {
     float term_eps;
 };
 
+// Device-side state of the fused training step (t2n_train_step): one 256-B block per field. k_train_plan advances it once per step;
+// every optimiser kernel of the step reads its verdict and its scalars from here (nothing about a step is a by-value kernel argument,
+// so a captured step can be replayed).
+struct TrainState {
+    unsigned step;         // Adam steps applied so far
+    unsigned seq;          // fused steps issued (plan kernels run)
+    unsigned skipped;      // steps whose update was withheld (appearance rows beyond the capacity)
+    unsigned skip;         // verdict of the step in flight: 1 = the optimiser kernels return at once
+    unsigned loss_ticket;  // k_train_loss: workgroups finished (the last one adds up the partial sums and resets it)
+    unsigned pad[3];
+    float lr_over_bc1[19]; // lr / (1 - beta1^step) per tensor, step = the step being applied
+    float inv_bc2_sqrt;    // 1 / sqrt(1 - beta2^step)
+};
+
 constexpr int kTimingEvents = 1024;   // timed launches per kernel between two reads; launches beyond are counted and priced at the timed average
 struct TimingSlot {
     hipEvent_t start[kTimingEvents], stop[kTimingEvents];
@@ -111,6 +125,10 @@ struct t2n_field {
     unsigned* plan_host = nullptr; unsigned plan_seq = 0;   // T2N_FLAG_DEVICE_ROWS: k_bwd_plan's record in pinned host memory (t2n_field_device_rows_record)
     void* ev_pack = nullptr;   // backward: k_mlp_bwd_ss's operand packing (on gemm_stream) is done
     void* gemm_stream = nullptr; void* ev_fork2 = nullptr; void* ev_join2 = nullptr;  // backward: the weight-gradient GEMMs run beside the appearance scatter
+    // fused training step (t2n_train_step): device state + the backward chain's packed operands (one allocation), the pinned host record,
+    // a third side stream for the plan + appearance binning and the events of the call's fork / join graph
+    void* train_dev = nullptr; unsigned* train_host = nullptr; void* bin_stream = nullptr; void* train_ev[12] = {};
+    bool train_packed = false;   // the backward chain's operands in train_dev are those of the current head weights
     unsigned list_hint = 0;          // appearance entries per ray of the last budgeted launch (0: unknown)
     unsigned long long list_retries = 0;
 };
@@ -237,9 +255,20 @@ void launch_pe_bwd(const float* gx, const float* feat, long long rows, float* gf
 // fused input-gradient chain of the MLP_Fea_noview head's backward (t2n_mlp_bwd_ss.hip)
 size_t mlp_bwd_ss_pack_bytes();
 int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, const float* h0, const float* feat, float* g0, float* gf,
-                      float* gx, long long rows, hipStream_t s, bool packed = false, const unsigned* rows_dev = nullptr);
+                      float* gx, long long rows, hipStream_t s, bool packed = false, const unsigned* rows_dev = nullptr,
+                      float* g1_out = nullptr);   // g1_out: g1 written there instead of over h1 (h1 stays intact for a concurrent k_bwd_l2)
 int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed);
 void* mlp_bwd_ss_absmax_words(void* packbuf);
+// the fused training step's optimiser launches (t2n_optim.hip): scalars / TV weights / verdict from device memory
+int launch_tv_seed_dev(t2n_field* f, const float* tvw_dev, hipStream_t s);
+int launch_factor_adam_dev(t2n_field* f, const t2n_field_params* params, float* const* m, float* const* v, float beta1, float beta2, float eps,
+                           const TrainState* st, int first, int count, hipStream_t s);
+int launch_head_adam_dev(const t2n_field_params* params, const float* grads_flat, float* const* m, float* const* v, float beta1, float beta2,
+                         float eps, const TrainState* st, hipStream_t s);
+// the driver's loss with the reduction folded into the last workgroup (ticket: a zero-initialised device word the kernel resets)
+int launch_train_loss(const float* rgb, const float* depth, const float* weights, const float* z_vals, const float* rgb_t, const float* depth_t,
+                      int64_t n_rays, int n_samples, float w_depth, float w_trans, float delta, float* d_rgb, float* d_depth, float* d_weights,
+                      float* losses, float* part, unsigned* ticket, hipStream_t s, hipStream_t reduce_stream = nullptr, hipEvent_t ev = nullptr);
 // forward-workspace carve shared by forward and backward (t2n_api.hip)
 struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, feat, total; unsigned list_cap, feat_rows; };
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat = true, unsigned budget = 0);   // budget: appearance entries per ray (0: worst case)   // ctx: also room for sigma [rays,N] and rgb_raw [rays]; feat: feature rows (last region: the other offsets do not depend on it; KEEP_CTX calls carve without)

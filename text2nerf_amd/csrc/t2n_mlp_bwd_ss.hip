@@ -40,7 +40,8 @@ static_assert(oAb + kAb * 16 == (int)kLds && kLds <= 160 * 1024, "LDS map");
 
 struct Args {
     const uint4* a2; const uint4* a1; const uint4* a0; const uint4* ab; const float* inv_scale;   // [0] W2, [1] W1, [2] W0, [3] basis
-    const float4* go; float* h1; const float* h0; const float* feat;   // h1 is overwritten with g1
+    const float4* go; float* h1; const float* h0; const float* feat;   // h1 is overwritten with g1 unless g1 points elsewhere
+    float* g1;
     float* g0; float* gf; float* gx;                                   // [rows,128], [rows,32], [rows,144]
     long long rows;                                                    // a multiple of 32
     const unsigned* rows_dev;                                          // optional: the row count in device memory (rows = capacity; see k_bwd_l2)
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(512) void k_mlp_bwd_ss(const Args a) {
         kstep<4>(acc, at(oA2), Bh, Bl);
         {
             const float us = pow2i(-E);
-            float* __restrict__ gr = a.h1 + row * 128 + 4 * h;
+            float* __restrict__ gr = a.g1 + row * 128 + 4 * h;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -477,7 +478,7 @@ int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed) {
 }
 
 int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, const float* h0, const float* feat, float* g0, float* gf,
-                      float* gx, long long rows, hipStream_t s, bool packed, const unsigned* rows_dev) {
+                      float* gx, long long rows, hipStream_t s, bool packed, const unsigned* rows_dev, float* g1_out) {
     using namespace bss;
     if (!packed) { const int rc = mlp_bwd_ss_pack(f, packbuf, s, false); if (rc) return rc; }
     uint4* base = (uint4*)packbuf;
@@ -491,7 +492,7 @@ int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, 
     }
     Args a;
     a.a2 = pa.a2; a.a1 = pa.a1; a.a0 = pa.a0; a.ab = pa.ab; a.inv_scale = pa.scales + 4;
-    a.go = go; a.h1 = h1; a.h0 = h0; a.feat = feat; a.g0 = g0; a.gf = gf; a.gx = gx; a.rows = rows; a.rows_dev = rows_dev; a.neg1 = -1.f;
+    a.go = go; a.h1 = h1; a.g1 = g1_out ? g1_out : h1; a.h0 = h0; a.feat = feat; a.g0 = g0; a.gf = gf; a.gx = gx; a.rows = rows; a.rows_dev = rows_dev; a.neg1 = -1.f;
     const long long nrounds = (rows / 32 + 7) / 8;
     hipLaunchKernelGGL(k_mlp_bwd_ss, dim3((unsigned)(nrounds < 256 ? nrounds : 256)), dim3(512), kLds, s, a);
     T2N_HIP(hipGetLastError());

@@ -81,6 +81,8 @@ struct AdamMulti {
     long long n[kAdamMaxTensors]; unsigned block0[kAdamMaxTensors + 1];
     float lr_over_bc1[kAdamMaxTensors], inv_bc2_sqrt[kAdamMaxTensors];
     int count; float beta1, beta2, eps;
+    // fused training step: scalars and the step's verdict from device memory (tensor t <-> st->lr_over_bc1[st_first + t]); NULL: by value
+    const TrainState* st; int st_first;
 };
 __global__ __launch_bounds__(256) void k_adam_multi(const AdamMulti a) {
     int t = 0;
@@ -90,13 +92,18 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamMulti a) {
     //  through s_load from the kernarg segment)
     const long long i = (long long)(blockIdx.x - a.block0[t]) * 256 + threadIdx.x;
     if (i >= a.n[t]) return;
+    float lr = a.lr_over_bc1[t], ib = a.inv_bc2_sqrt[t];
+    if (a.st) {
+        if (a.st->skip) return;      // the step's appearance rows did not fit: no tensor moves, no moment decays
+        lr = a.st->lr_over_bc1[a.st_first + t]; ib = a.st->inv_bc2_sqrt;
+    }
     float* __restrict__ p = a.p[t]; const float* __restrict__ g = a.g[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
     const float gi = g[i];
     const float mi = m[i] + (gi - m[i]) * (1.f - a.beta1);
     const float vi = v[i] * a.beta2 + (1.f - a.beta2) * gi * gi;
     m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) * a.inv_bc2_sqrt[t] + a.eps;
-    p[i] = p[i] - a.lr_over_bc1[t] * (mi / denom);
+    const float denom = sqrtf(vi) * ib + a.eps;
+    p[i] = p[i] - lr * (mi / denom);
 }
 
 // ---- the same step on the field's channel-last master copies -------------------------------------------------------------
@@ -176,6 +183,8 @@ struct FactorStep {
     float sh[12], sw[12], lr_over_bc1[12], inv_bc2_sqrt[12];
     unsigned ablock0[13], tblock0[13];   // first workgroup of tensor t in the Adam / TV launch (TV: zero-width for lines and weight 0)
     float beta1, beta2, eps;
+    // fused training step (NULL: by value): Adam scalars + verdict; the two TV weights (x 1e-2) of this step in device memory
+    const TrainState* st; const float* tvw_dev;
 };
 __global__ __launch_bounds__(256) void k_tv_grad_cl_multi(const FactorStep a) {
     int t = 0;
@@ -190,7 +199,14 @@ __global__ __launch_bounds__(256) void k_tv_seed_cl_multi(const FactorStep a) {
 #pragma unroll 1
     for (int q = 1; q < 12; ++q) t += (a.tblock0[q] <= blockIdx.x) ? 1 : 0;
     const long long i = (long long)(blockIdx.x - a.tblock0[t]) * 256 + threadIdx.x;
-    if (a.sh[t] != 0.f || a.sw[t] != 0.f) tv_grad_cl_body<true>(a.p[t], a.g[t], i, a.C[t] / 4, a.H[t], a.W[t], a.sh[t], a.sw[t]);
+    float sh = a.sh[t], sw = a.sw[t];
+    if (a.tvw_dev) {   // the host's expressions (t2n_field_tv_seed), on this step's weights; planes only (t = 0..2 density, 6..8 appearance)
+        const float tvw = t < 3 ? a.tvw_dev[0] : ((t >= 6 && t < 9) ? a.tvw_dev[1] : 0.f);
+        const int C = a.C[t], H = a.H[t], W = a.W[t];
+        sh = tvw != 0.f ? tvw * 2.f / ((float)C * (float)(H - 1) * (float)W) : 0.f;
+        sw = tvw != 0.f ? tvw * 2.f / ((float)C * (float)H * (float)(W - 1)) : 0.f;
+    }
+    if (sh != 0.f || sw != 0.f) tv_grad_cl_body<true>(a.p[t], a.g[t], i, a.C[t] / 4, a.H[t], a.W[t], sh, sw);
     else if (i < a.npos[t] * (a.C[t] / 4)) reinterpret_cast<float4*>(a.g[t])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __global__ __launch_bounds__(256) void k_adam_cl_multi(const FactorStep a) {
@@ -199,8 +215,13 @@ __global__ __launch_bounds__(256) void k_adam_cl_multi(const FactorStep a) {
 #pragma unroll 1
     for (int q = 1; q < 12; ++q) t += (a.ablock0[q] <= blockIdx.x) ? 1 : 0;
     const unsigned blk = blockIdx.x - a.ablock0[t];
-    if (a.C[t] == 16) adam_cl_tile<16>(tile, blk, a.p[t], a.g[t], a.m[t], a.v[t], a.ref[t], a.npos[t], a.lr_over_bc1[t], a.beta1, a.beta2, a.eps, a.inv_bc2_sqrt[t]);
-    else adam_cl_tile<48>(tile, blk, a.p[t], a.g[t], a.m[t], a.v[t], a.ref[t], a.npos[t], a.lr_over_bc1[t], a.beta1, a.beta2, a.eps, a.inv_bc2_sqrt[t]);
+    float lr = a.lr_over_bc1[t], ib = a.inv_bc2_sqrt[t];
+    if (a.st) {
+        if (a.st->skip) return;      // (uniform over the launch)
+        lr = a.st->lr_over_bc1[t]; ib = a.st->inv_bc2_sqrt;
+    }
+    if (a.C[t] == 16) adam_cl_tile<16>(tile, blk, a.p[t], a.g[t], a.m[t], a.v[t], a.ref[t], a.npos[t], lr, a.beta1, a.beta2, a.eps, ib);
+    else adam_cl_tile<48>(tile, blk, a.p[t], a.g[t], a.m[t], a.v[t], a.ref[t], a.npos[t], lr, a.beta1, a.beta2, a.eps, ib);
 }
 
 }  // namespace t2n
@@ -294,6 +315,92 @@ extern "C" int t2n_field_tv_seed(t2n_field* f, float tv_weight_density, float tv
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }
+
+
+// ---- the fused training step's optimiser launches (t2n_train_step, t2n_backward.hip): the same kernels, with the step's scalars,
+// TV weights and verdict read from device memory ----------------------------------------------------------------------------------
+namespace t2n {
+static void factor_step_geometry(t2n_field* f, FactorStep& A, unsigned& ab, unsigned& tb_all) {
+    const int* gr = f->desc.grid;
+    ab = 0; tb_all = 0;
+    for (int q = 0; q < 4; ++q)
+        for (int k = 0; k < 3; ++k) {
+            const int idx = q * 3 + k;
+            const int H = gr[mat1(k)], W = gr[mat0(k)];
+            const long long HW = (long long)H * W, L = gr[vecm(k)];
+            float* pcl[4] = {f->buf_den_plane[k], f->buf_den_line[k], f->buf_app_plane[k], f->buf_app_line[k]};
+            float* gcl[4] = {f->gbuf_den_plane[k], f->gbuf_den_line[k], f->gbuf_app_plane[k], f->gbuf_app_line[k]};
+            const int C = q < 2 ? 16 : 48;
+            const bool plane = (q & 1) == 0;
+            A.p[idx] = pcl[q]; A.g[idx] = gcl[q];
+            A.npos[idx] = plane ? HW : L; A.C[idx] = C; A.H[idx] = plane ? H : (int)L; A.W[idx] = plane ? W : 1;
+            A.tblock0[idx] = tb_all;
+            tb_all += (unsigned)((A.npos[idx] * (C / 4) + 255) / 256);
+            A.ablock0[idx] = ab;
+            ab += (unsigned)((A.npos[idx] + 63) / 64);
+        }
+    A.tblock0[12] = tb_all; A.ablock0[12] = ab;
+}
+int launch_tv_seed_dev(t2n_field* f, const float* tvw_dev, hipStream_t s) {
+    if (f->desc.grid[0] < 2 || f->desc.grid[1] < 2 || f->desc.grid[2] < 2) { set_error("t2n_train_step: TV needs planes of at least 2x2"); return T2N_ERR_INVALID; }
+    FactorStep A;
+    memset(&A, 0, sizeof(A));
+    unsigned ab, tb;
+    factor_step_geometry(f, A, ab, tb);
+    A.tvw_dev = tvw_dev;
+    hipLaunchKernelGGL(k_tv_seed_cl_multi, dim3(tb), dim3(256), 0, s, A);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+// Adam on the channel-last copies of the factor tensors first .. first + count - 1 (order: density planes, density lines, appearance
+// planes, appearance lines), new values also written to the caller's reference-layout tensors
+int launch_factor_adam_dev(t2n_field* f, const t2n_field_params* params, float* const* m, float* const* v, float beta1, float beta2, float eps,
+                           const TrainState* st, int first, int count, hipStream_t s) {
+    FactorStep A;
+    memset(&A, 0, sizeof(A));
+    unsigned ab, tb;
+    factor_step_geometry(f, A, ab, tb);
+    for (int k = 0; k < 3; ++k) {
+        A.ref[k] = (float*)params->density_plane[k]; A.ref[3 + k] = (float*)params->density_line[k];
+        A.ref[6 + k] = (float*)params->app_plane[k]; A.ref[9 + k] = (float*)params->app_line[k];
+    }
+    for (int i = 0; i < 12; ++i) { A.m[i] = m[i]; A.v[i] = v[i]; if (!A.ref[i] || !m[i] || !v[i]) { set_error("t2n_train_step: NULL factor tensor / moment %d", i); return T2N_ERR_INVALID; } }
+    A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.st = st;
+    // a sub-range of the tensors: the launch covers their workgroups only (block index rebased by shifting the table)
+    const unsigned b0 = A.ablock0[first], b1 = A.ablock0[first + count];
+    if (first > 0 || count < 12) {
+        for (int i = 0; i <= 12; ++i) A.ablock0[i] = A.ablock0[i] >= b0 ? A.ablock0[i] - b0 : 0u;
+        // tensors before `first` get zero-width ranges at 0 (the kernel's search lands on the last tensor whose start is <= the block)
+        for (int i = first + count + 1; i <= 12; ++i) A.ablock0[i] = 0xffffffffu;
+    }
+    if (b1 > b0) hipLaunchKernelGGL(k_adam_cl_multi, dim3(b1 - b0), dim3(256), 0, s, A);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+// Adam on the seven head tensors (reference layout; gradients contiguous in `grads_flat`, parameter order)
+int launch_head_adam_dev(const t2n_field_params* params, const float* grads_flat, float* const* m, float* const* v, float beta1, float beta2,
+                         float eps, const TrainState* st, hipStream_t s) {
+    AdamMulti a;
+    memset(&a, 0, sizeof(a));
+    float* ps[7] = {(float*)params->basis_weight, (float*)params->mlp_w0, (float*)params->mlp_b0, (float*)params->mlp_w1, (float*)params->mlp_b1,
+                    (float*)params->mlp_w2, (float*)params->mlp_b2};
+    const long long n[7] = {27 * 144, 128 * 351, 128, 128 * 128, 128, 3 * 128, 3};
+    unsigned blocks = 0;
+    long long off = 0;
+    for (int i = 0; i < 7; ++i) {
+        if (!ps[i] || !m[i] || !v[i]) { set_error("t2n_train_step: NULL head tensor / moment %d", i); return T2N_ERR_INVALID; }
+        a.p[i] = ps[i]; a.g[i] = grads_flat + off; a.m[i] = m[i]; a.v[i] = v[i]; a.n[i] = n[i];
+        a.block0[i] = blocks;
+        blocks += (unsigned)((n[i] + 255) / 256);
+        off += n[i];
+    }
+    a.block0[7] = blocks;
+    a.count = 7; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.st = st; a.st_first = 12;
+    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, s, a);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+}  // namespace t2n
 
 extern "C" int t2n_adam_step_multi(int count, float* const* params, const float* const* grads, float* const* exp_avg,
                                    float* const* exp_avg_sq, const int64_t* sizes, const float* lrs, float beta1, float beta2, float eps,

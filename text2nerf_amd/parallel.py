@@ -164,6 +164,15 @@ def allreduce_gradients(params, group=None, average=True, field=None, overlap=Tr
     params = [p for p in params if p.requires_grad]
     if not params:
         return
+    fs = field.__dict__.get("_fused_step") if field is not None else None
+    if fs is not None and fs.owns_head_grads(params):
+        # the fused step (text2nerf_amd/trainer.py) keeps the head gradients in ONE flat buffer with a vote word behind them (non-zero:
+        # some rank's appearance rows did not fit its capacity — the optimiser phase then withholds the update on EVERY rank): reduced in
+        # place, no concatenation, no copy back
+        dist.all_reduce(fs.head_grads, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            fs.head_grads.div_(world)
+        return
     for p in params:
         if p.grad is None:
             p.grad = torch.zeros_like(p)

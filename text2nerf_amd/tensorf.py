@@ -1299,7 +1299,7 @@ class TensorBase(nn.Module):
         return grads
 
     def train_step(self, rays, rgb_target, depth_target, optimizer, N_samples=-1, white_bg=True, w_depth=0.005, w_trans=1e3, delta=0.1,
-                   tv=(), all_reduce=None, all_reduce_averages=True, speculative=False):
+                   tv=(), all_reduce=None, all_reduce_averages=True, speculative=False, fused=None, graph=None):
         """One optimisation step of text2nerf_main.py:547-590 without the autograd graph: render (train mode, CPU-generator jitter
         like models/tensorBase.py:313-317) -> the driver's loss as ONE kernel that emits d_rgb / d_depth / d_weights
         (t2n_train_loss) -> t2n_render_backward -> optimizer.step(). `optimizer`: optim.TVAdam(field=self) (TV terms via `tv`, as
@@ -1312,9 +1312,27 @@ class TensorBase(nn.Module):
         row capacity is 1.25x the largest need of the last eight steps, the kernels clip to the actual count on the device, and the
         host learns every step's need from a record in pinned memory, without waiting (late at worst, never lost). A step whose count
         exceeds the capacity drops the appearance gradients of the rows past it — counted in `self.device_rows_overflows`. The first
-        step (and the step after a recorded overflow) takes the counted route."""
+        step (and the step after a recorded overflow) takes the counted route.
+        `fused` (default: whenever it applies — this field shape, fused MLP_Fea_noview head in split-f16 mode, no alpha mask, optimizer =
+        optim.TVAdam(field=self), an averaging all_reduce): the whole step is ONE C call (t2n_train_step, text2nerf_amd/trainer.py) that
+        reads nothing on the host; a step whose appearance rows exceed its capacity applies NO update and is submitted again (never a
+        truncated gradient). `graph` (default True with `fused`, single process): that call captured once into a hipGraph and replayed.
+        The returned loss tensor is then a fixed buffer the next step overwrites."""
         lib = _lib.load()
         params = self._autograd_params()
+        can_fuse = self._can_fuse_train_step(optimizer) and (all_reduce is None or all_reduce_averages) and not speculative
+        if fused and not can_fuse:
+            raise T2NError("train_step(fused=True): needs the tuned field shape with the MLP_Fea_noview head (split-f16 arithmetic), fp32 factor "
+                           "storage, no alpha mask, optim.TVAdam(field=tensorf) and an averaging all_reduce")
+        if can_fuse and fused is not False:
+            from .trainer import FusedStep
+            fs = self.__dict__.get("_fused_step")
+            if fs is None or fs.opt is not optimizer:
+                fs = self.__dict__["_fused_step"] = FusedStep(self, optimizer)
+            N = int(N_samples) if N_samples > 0 else self.nSamples
+            flags = FLAG_ADD_BG if (white_bg or bool(torch.rand((1,)) < 0.5)) else 0
+            use_graph = (all_reduce is None) if graph is None else bool(graph)
+            return fs.step(rays, rgb_target, depth_target, N, flags, w_depth, w_trans, delta, tv, use_graph, all_reduce)
         if any(not p.is_leaf for p in params):
             raise T2NError("train_step needs the kernels' own field shape (the parameters ARE the kernel tensors); embedded shapes, "
                            "TensorVM and TensorCP train through the autograd form (OctreeRender_trilinear_fast + loss.backward())")
@@ -1381,6 +1399,12 @@ class TensorBase(nn.Module):
                 if len(evs) > 2:
                     evs.pop(0).synchronize()
         return losses
+
+    def _can_fuse_train_step(self, optimizer):
+        return (getattr(optimizer, "field", None) is self and self.supports_deferred_factor_grads() and self.shadingMode == "MLP_Fea_noview"
+                and not self.mlp_exact_fp32 and self.alphaMask is None and int(self.app_dim) == 27 and int(self.fea_pe) == 6
+                and int(self.featureC) == 128 and list(self.density_n_comp) == [16] * 3 and list(self.app_n_comp) == [48] * 3
+                and (int(self.nSamples) <= 1024))
 
     def _poll_device_rows(self):
         """What the speculative steps have recorded so far (k_bwd_plan writes every step's row NEED and an overflow count into pinned

@@ -9,5 +9,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "0"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
 spec = len(sys.argv) > 4 and sys.argv[4] == "spec"
+# round 6: argv[4] = legacy | fused_eager | fused_graph selects the train_step form (default: the product default)
+kw = {"legacy": dict(fused=False), "fused_eager": dict(fused=True, graph=False), "fused_graph": dict(fused=True, graph=True)}.get(sys.argv[4] if len(sys.argv) > 4 else "", None)
 print(json.dumps(bench.train_bench(torch.device("cuda:0"), iters=iters, warmup=3, fused_optim=mode == "1", fused_step=mode in ("2", "3"), resident=mode == "3",
-                                   batch=batch, speculative=spec)))
+                                   batch=batch, speculative=spec, step_kw=kw)))
