@@ -464,6 +464,14 @@ int t2n_depth_align_global(const float* depth_rendered, const float* depth_est, 
  *   phases         1: render + loss + backward only (gradients left in the field's buffer and head_grads), 2: optimiser only (after a
  *                  data-parallel all-reduce of both; a non-zero vote word withholds the update on every rank), 3: both.
  *   losses         device float[4] = {mse, depth loss, transmittance loss, total} of the batch
+ * Pipelined form (eager calls with phases = 3): when `input_stream` names the stream on which the batch buffers (rays, jitter, targets,
+ * hyper) were written and the workspace holds TWICE t2n_train_step_workspace_bytes, the step's early part — zero fills, the march (it
+ * reads the density factors only), the plan and the appearance binning — does not wait for `stream`: it starts as soon as the PREVIOUS
+ * t2n_train_step of this field has stepped its density factors and `input_stream` has passed the call, beside the previous step's
+ * appearance scatter / weight-gradient GEMMs / Adam. The two halves of the workspace and two slots of per-step scalars alternate. The
+ * caller must not have touched the field (uploads, other optimiser steps) between the two calls; everything else about the call
+ * (ordering of its results on `stream`, the record) is unchanged. head_grads is left ZEROED by the optimiser phase (and must be zero
+ * when a phases = 1 | 3 call starts).
  * Replaces (reference): text2nerf_main.py:553-590 (renderer call, losses, TV terms, zero_grad / backward / step). */
 #define T2N_TRAIN_HYPER_FLOATS 32
 #define T2N_TRAIN_HEAD_GRAD_FLOATS (27 * 144 + 128 * 351 + 128 + 128 * 128 + 128 + 3 * 128 + 3 + 1)
@@ -481,6 +489,7 @@ typedef struct t2n_train_step_args {
     int64_t rows_capacity;
     void* workspace; size_t workspace_bytes;
     float* losses;
+    t2n_stream input_stream;   /* optional (NULL = none), see "pipelined form" */
 } t2n_train_step_args;
 size_t t2n_train_step_workspace_bytes(const t2n_field* f, int64_t n_rays, int n_samples, int64_t rows_capacity);
 int t2n_train_step(t2n_field* f, const t2n_train_step_args* a, t2n_stream stream);

@@ -64,7 +64,7 @@ class TrainStepArgs(C.Structure):   # t2n_train_step_args
                 ("hyper", C.c_void_p), ("params", FieldParams),
                 ("exp_avg", C.c_void_p * 19), ("exp_avg_sq", C.c_void_p * 19),
                 ("head_grads", C.c_void_p), ("rows_capacity", C.c_int64),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("losses", C.c_void_p)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("losses", C.c_void_p), ("input_stream", C.c_void_p)]
 
 
 _lib = None

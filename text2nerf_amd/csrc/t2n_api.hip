@@ -470,6 +470,7 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->train_host) (void)hipHostFree(f->train_host);
     for (auto& e : f->train_ev) if (e) (void)hipEventDestroy((hipEvent_t)e);
     if (f->bin_stream) (void)hipStreamDestroy((hipStream_t)f->bin_stream);
+    if (f->early_stream) (void)hipStreamDestroy((hipStream_t)f->early_stream);
     for (int k = 0; k < T2N_K_COUNT; ++k)
         for (int i = 0; i < kTimingEvents; ++i) {
             if (f->slots[k].start[i]) (void)hipEventDestroy(f->slots[k].start[i]);
@@ -495,6 +496,7 @@ extern "C" int t2n_field_upload(t2n_field* f, const t2n_field_params* p, t2n_str
     f->params_ref = *p;
     f->ss_dirty = true;
     f->train_packed = false;
+    f->train_chain = false;
     f->uploaded = true;
     return T2N_OK;
 }
@@ -517,6 +519,7 @@ extern "C" int t2n_field_upload_head(t2n_field* f, const t2n_field_params* p, t2
     f->params_ref.mlp_w2 = p->mlp_w2; f->params_ref.mlp_b2 = p->mlp_b2;
     f->ss_dirty = true;
     f->train_packed = false;
+    f->train_chain = false;
     return T2N_OK;
 }
 

@@ -255,10 +255,15 @@ struct BwdMarchArgs {
     const BwdPlan* plan;   // when set: the tile prefix comes from device memory (T2N_FLAG_DEVICE_ROWS)
     // BIN: dL/dfeature per sample goes to gfeat [n_rays, N] (aliases sigma) and the (plane, tile) histogram is counted
     float* gfeat; unsigned* hist; BlockGeom geom;
+    // LOSS (fused training step): the driver's loss (t2n_loss.hip, text2nerf_main.py:559-575) evaluated here instead of by a kernel of its
+    // own between forward and backward — the weights and sample depths it needs are recomputed by this kernel anyway, so the forward
+    // materialises neither, and d_rgb / d_depth / d_weights never exist in memory. rgb / depth: the composite's outputs; part: the
+    // per-workgroup partial sums [ceil(n_rays / 4)][3] of k_train_loss (same grouping, same order: the reported losses are bit-identical)
+    const float* rgb; const float* depth; const float* rgb_t; const float* depth_t; float w_depth, w_trans, delta; float* loss_part;
 };
 
 // BIN = false: scatter with sliding windows + global atomics (any grid). BIN = true: first pass of the tile-binned scatter.
-template <bool TRAIN, bool BIN>
+template <bool TRAIN, bool BIN, bool LOSS = false>
 __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -268,20 +273,42 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
     float* __restrict__ Gw = Tw + a.npad;                       // dL/dw, later dL/dfeature
     const FieldDev& F = a.F;
     const long long r = (long long)blockIdx.x * 4 + wid;
-    if (r >= a.n_rays) return;
-    const int4 ra = a.ray_app[r];
-    const int first = ra.w & 2047, Lw = ra.w >> 11;
-    if (Lw <= 0) return;
+    if (!LOSS && r >= a.n_rays) return;
+    const bool live_ray = r < a.n_rays;
+    const long long rs = live_ray ? r : 0;
+    const int4 ra = a.ray_app[rs];
+    const int first = ra.w & 2047, Lw = live_ray ? (ra.w >> 11) : 0;
+    if (!LOSS && Lw <= 0) return;
     const int N = a.n_samples;
-    const Ray ray = load_ray(F, a.rays + r * a.ray_stride, a.ray_stride);
-    const float u = (TRAIN && !F.ztab) ? a.jitter[r] : 0.f;   // NDC: `jitter` is the depth table
+    const Ray ray = load_ray(F, a.rays + rs * a.ray_stride, a.ray_stride);
+    const float u = (TRAIN && !F.ztab) ? a.jitter[rs] : 0.f;   // NDC: `jitter` is the depth table
     // upstream gradients of this ray; clamp(0,1) passes gradient on the closed interval
-    const float4 rr = a.rgb_raw[r];
-    const float gr = (rr.x >= 0.f && rr.x <= 1.f) ? a.d_rgb[r * 3 + 0] : 0.f;
-    const float gg = (rr.y >= 0.f && rr.y <= 1.f) ? a.d_rgb[r * 3 + 1] : 0.f;
-    const float gb = (rr.z >= 0.f && rr.z <= 1.f) ? a.d_rgb[r * 3 + 2] : 0.f;
-    const float gd = a.d_depth[r];
+    const float4 rr = a.rgb_raw[rs];
+    float d_r, d_g, d_b, gd;
+    float e_rgb = 0.f, e_dep = 0.f, dt = 0.f;
+    if constexpr (LOSS) {
+        // k_train_loss's per-ray arithmetic (same expressions, same order)
+        const float R = (float)a.n_rays;
+        const float x0 = a.rgb[rs * 3 + 0] - a.rgb_t[rs * 3 + 0], x1 = a.rgb[rs * 3 + 1] - a.rgb_t[rs * 3 + 1], x2 = a.rgb[rs * 3 + 2] - a.rgb_t[rs * 3 + 2];
+        d_r = 2.f * x0 / (3.f * R); d_g = 2.f * x1 / (3.f * R); d_b = 2.f * x2 / (3.f * R);
+        const float q = lane == 0 ? x0 * x0 : (lane == 1 ? x1 * x1 : (lane == 2 ? x2 * x2 : 0.f));
+        e_rgb = wave_sum(q);
+        dt = a.depth_t[rs];
+        float dep = a.depth[rs];
+        const bool bad = dep != dep;
+        if (bad) dep = 0.f;
+        const float dd = dep - dt;
+        gd = bad ? 0.f : 2.f * a.w_depth * dd / R;
+        e_dep = dd * dd;
+    } else {
+        d_r = a.d_rgb[r * 3 + 0]; d_g = a.d_rgb[r * 3 + 1]; d_b = a.d_rgb[r * 3 + 2];
+        gd = a.d_depth[r];
+    }
+    const float gr = (rr.x >= 0.f && rr.x <= 1.f) ? d_r : 0.f;
+    const float gg = (rr.y >= 0.f && rr.y <= 1.f) ? d_g : 0.f;
+    const float gb = (rr.z >= 0.f && rr.z <= 1.f) ? d_b : 0.f;
     const float bg = a.add_bg ? 1.f : 0.f;
+    float m_lane = 0.f;   // LOSS: sum of the masked weights of the samples this lane saw (sample index = first + lane mod 64)
 
     // ---- forward recompute (same arithmetic as k_march pass C) + dL/dw ---------------------------------------------------
     float carry = 1.f;
@@ -321,9 +348,24 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
         run += (unsigned)__popcll(bal);
         if (j < Lw) {
             float G = gr * (cr - bg) + gg * (cg - bg) + gb * (cb - bg) + gd * (z - ray.last);
-            if (a.d_w) G += a.d_w[r * N + i];
+            if constexpr (LOSS) m_lane += ((z - dt) + a.delta < 0.f) ? w : 0.f;
+            else if (a.d_w) G += a.d_w[r * N + i];
             Sg[j] = sg; Al[j] = alpha; Tw[j] = T; Gw[j] = G;
         }
+    }
+    float gw = 0.f;
+    if constexpr (LOSS) {
+        // m_r = mean_n(w [z - depth_t + delta < 0]): k_train_loss's lane n mod 64 summed the samples this kernel's lane (n - first) mod 64
+        // saw, in the same (ascending) order — moved to that lane, the wave sum is k_train_loss's bit for bit
+        float m = __shfl(m_lane, (lane - first) & 63);
+        if (!live_ray) m = 0.f;
+        m = wave_sum(m) / (float)N;
+        gw = (2.f * a.w_trans * m / (float)a.n_rays) / (float)N;
+        __shared__ float red[4][3];
+        if (lane == 0) { red[wid][0] = live_ray ? e_rgb : 0.f; red[wid][1] = live_ray ? e_dep : 0.f; red[wid][2] = live_ray ? m * m : 0.f; }
+        __syncthreads();
+        if (threadIdx.x < 3) a.loss_part[(size_t)blockIdx.x * 3 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (Lw <= 0) return;
     }
     wave_lds_sync();
 
@@ -337,6 +379,7 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
             sg = Sg[j]; al = Al[j]; T = Tw[j]; G = Gw[j];
             const float z = sample_z<TRAIN>(F, ray, i, u);
             if (i < N - 1) dist = sample_z<TRAIN>(F, ray, i + 1, u) - z;
+            if constexpr (LOSS) G += ((z - dt) + a.delta < 0.f) ? gw : 0.f;   // d_weights of TransMittanceLoss_mask, never materialised
         }
         const float val = G * (al * T);
         float s = val;
@@ -465,14 +508,28 @@ __global__ __launch_bounds__(256) void k_bin_reduce(unsigned* __restrict__ hist,
 }
 // (2b) single workgroup: exclusive scan of the bin totals -> bin starts (+ sentinel) and the segment list of the accumulate pass. A record's
 // position is start[bin] + the running within-bin cursor of its copy.
+// copies > 0 (few bins: the appearance tiles): step (2a) runs here too — thread j walks bin j's privatised counters `hist_copies`
+// [copy][bin] (offsets in place) — instead of as a launch of its own in front of this one
 template <bool LDS>
 __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, unsigned* tile_start, int4* segs, unsigned* nseg_out,
-                                                   unsigned seg_cap, unsigned seg_size_in, unsigned target_segs, unsigned seg_min) {
+                                                   unsigned seg_cap, unsigned seg_size_in, unsigned target_segs, unsigned seg_min,
+                                                   unsigned* hist_copies, int copies) {
     extern __shared__ unsigned sh_hist[];
     __shared__ unsigned sh[17];
     const int t = threadIdx.x;
     const int n = n_tiles;
-    if (LDS) {
+    if (copies > 0) {
+        for (int j = t; j < n; j += 1024) {
+            unsigned run = 0;
+            for (int c = 0; c < copies; ++c) {
+                const unsigned v = hist_copies[(size_t)c * n + j];
+                hist_copies[(size_t)c * n + j] = run;
+                run += v;
+            }
+            if (LDS) sh_hist[j] = run; else hist[j] = run;
+        }
+        __syncthreads();
+    } else if (LDS) {
         for (int j = t; j < n; j += 1024) sh_hist[j] = hist[j];
         __syncthreads();
     }
@@ -527,15 +584,18 @@ __global__ __launch_bounds__(1024) void k_bin_scan(unsigned* hist, int n_tiles, 
     if (t == 0) *nseg_out = min(nsegs, seg_cap);
 }
 static void launch_bin_scan(unsigned* hist, int n_tiles, int copies, unsigned* bin_total, unsigned* tile_start, int4* segs, unsigned* nseg, unsigned seg_cap,
-                            unsigned seg_size, unsigned target_segs, unsigned seg_min, hipStream_t s) {
-    hipLaunchKernelGGL(k_bin_reduce, dim3((unsigned)(copies == 32 ? (n_tiles + 7) / 8 : (n_tiles + 255) / 256)), dim3(256), 0, s, hist, n_tiles, copies, bin_total);
+                            unsigned seg_size, unsigned target_segs, unsigned seg_min, hipStream_t s, bool one_launch = false) {
+    const bool merged = one_launch && (long long)n_tiles * copies <= 65536;   // (a single workgroup walks every counter: small tables only)
+    if (!merged) hipLaunchKernelGGL(k_bin_reduce, dim3((unsigned)(copies == 32 ? (n_tiles + 7) / 8 : (n_tiles + 255) / 256)), dim3(256), 0, s, hist, n_tiles, copies, bin_total);
     const size_t lds = (size_t)n_tiles * 4;
     if (lds <= 150 * 1024) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_bin_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-        hipLaunchKernelGGL((k_bin_scan<true>), dim3(1), dim3(1024), lds, s, bin_total, n_tiles, tile_start, segs, nseg, seg_cap, seg_size, target_segs, seg_min);
+        hipLaunchKernelGGL((k_bin_scan<true>), dim3(1), dim3(1024), lds, s, bin_total, n_tiles, tile_start, segs, nseg, seg_cap, seg_size, target_segs, seg_min,
+                           hist, merged ? copies : 0);
     } else {
-        hipLaunchKernelGGL((k_bin_scan<false>), dim3(1), dim3(1024), 0, s, bin_total, n_tiles, tile_start, segs, nseg, seg_cap, seg_size, target_segs, seg_min);
+        hipLaunchKernelGGL((k_bin_scan<false>), dim3(1), dim3(1024), 0, s, bin_total, n_tiles, tile_start, segs, nseg, seg_cap, seg_size, target_segs, seg_min,
+                           hist, merged ? copies : 0);
     }
 }
 
@@ -1328,7 +1388,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
                 T2N_HIP(hipStreamWaitEvent(sp, (hipEvent_t)f->ev_fork2, 0));
                 pack_side = true;
             }
-            if ((rc = mlp_bwd_ss_pack(f, (void*)(bw + b.gpack), sp, true))) return rc;
+            if ((rc = mlp_bwd_ss_pack(f, (void*)(bw + b.gpack), sp, true, true))) return rc;
             if (pack_side) T2N_HIP(hipEventRecord((hipEvent_t)f->ev_pack, sp));
         }
         packed_early = pack_now;
@@ -1579,7 +1639,8 @@ __global__ __launch_bounds__(256) void k_zero_regions(const ZeroOps o) {
 // double like the host entry points), the vote word behind the head gradients and the record in pinned host memory.
 __global__ __launch_bounds__(64) void k_train_plan(const unsigned* __restrict__ counters, unsigned list_cap, unsigned rows_cap, BwdPlan* __restrict__ plan,
                                                    TrainState* __restrict__ st, const float* __restrict__ hyper, float beta1, float beta2, float* vote,
-                                                   unsigned* host_rec) {
+                                                   unsigned* host_rec, unsigned slot) {
+    TrainScalars* __restrict__ sc = &st->sc[slot];
     const int lane = threadIdx.x;
     unsigned cnt = lane < kLists ? counters[lane * kCounterStride] : 0u;
     if (cnt > list_cap) cnt = list_cap;
@@ -1597,8 +1658,8 @@ __global__ __launch_bounds__(64) void k_train_plan(const unsigned* __restrict__ 
     const unsigned step = st->step + (ovf ? 0u : 1u);     // (every lane reads the old value; lane 0 writes below)
     if (lane < 19 && !ovf) {
         const double bc1 = 1.0 - pow((double)beta1, (double)step);
-        st->lr_over_bc1[lane] = (float)((double)hyper[lane] / bc1);
-        if (lane == 0) st->inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+        sc->lr_over_bc1[lane] = (float)((double)hyper[lane] / bc1);
+        if (lane == 0) sc->inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
     }
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
@@ -1607,7 +1668,7 @@ __global__ __launch_bounds__(64) void k_train_plan(const unsigned* __restrict__ 
         plan->rows = rows < rows_cap ? rows : rows_cap;
         const unsigned seq = st->seq;
         st->seq = seq + 1u;
-        st->skip = ovf;
+        sc->skip = ovf;
         st->step = step;
         if (ovf) st->skipped = st->skipped + 1u;
         if (vote) *vote = ovf ? 1.f : 0.f;
@@ -1623,10 +1684,10 @@ __global__ __launch_bounds__(64) void k_train_plan(const unsigned* __restrict__ 
 }
 // Data-parallel steps (phases 1 | all-reduce | 2): the vote word came back from the all-reduce of the head gradients. A rank whose own
 // rows fitted but whose peers' did not withholds its update too: the optimistic count of k_train_plan is taken back.
-__global__ __launch_bounds__(64) void k_train_commit(TrainState* __restrict__ st, const float* __restrict__ vote, unsigned* host_rec) {
+__global__ __launch_bounds__(64) void k_train_commit(TrainState* __restrict__ st, const float* __restrict__ vote, unsigned* host_rec, unsigned slot) {
     if (threadIdx.x != 0) return;
-    if (*vote != 0.f && !st->skip) {
-        st->skip = 1u; st->step = st->step - 1u; st->skipped = st->skipped + 1u;
+    if (*vote != 0.f && !st->sc[slot].skip) {
+        st->sc[slot].skip = 1u; st->step = st->step - 1u; st->skipped = st->skipped + 1u;
         if (host_rec) {
             volatile unsigned long long* h = reinterpret_cast<volatile unsigned long long*>(host_rec);
             const unsigned seq = st->seq - 1u;
@@ -1639,7 +1700,7 @@ __global__ __launch_bounds__(64) void k_train_set_step(TrainState* st, unsigned 
     if (threadIdx.x == 0) { st->step = step; if (host_rec) ((volatile unsigned*)host_rec)[1] = step; }
 }
 
-struct TrainCarve { size_t fwd, fwd_bytes, bwd, bwd_bytes, g1, rgb, depth, w, z, d_rgb, d_depth, d_w, part, total; };
+struct TrainCarve { size_t fwd, fwd_bytes, bwd, bwd_bytes, g1, rgb, depth, part, total; };
 static TrainCarve train_carve(const t2n_field* f, int64_t R, int N, int64_t rows) {
     TrainCarve t;
     const BinGeom geom = bin_geom(f->dev.den);
@@ -1651,11 +1712,6 @@ static TrainCarve train_carve(const t2n_field* f, int64_t R, int N, int64_t rows
     t.g1 = o; o = al256(o + (size_t)rows * 128 * 4);
     t.rgb = o; o = al256(o + (size_t)R * 12);
     t.depth = o; o = al256(o + (size_t)R * 4);
-    t.w = o; o = al256(o + (size_t)R * N * 4);
-    t.z = o; o = al256(o + (size_t)R * N * 4);
-    t.d_rgb = o; o = al256(o + (size_t)R * 12);
-    t.d_depth = o; o = al256(o + (size_t)R * 4);
-    t.d_w = o; o = al256(o + (size_t)R * N * 4);
     t.part = o; o = al256(o + (size_t)((R + 3) / 4) * 12);
     t.total = o;
     return t;
@@ -1675,7 +1731,7 @@ static int train_ensure(t2n_field* f, hipStream_t s) {
     }
     auto mk_stream = [](void** st) -> int { if (!*st) { hipStream_t x; T2N_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking)); *st = (void*)x; } return T2N_OK; };
     int rc;
-    if ((rc = mk_stream(&f->side_stream)) || (rc = mk_stream(&f->gemm_stream)) || (rc = mk_stream(&f->bin_stream))) return rc;
+    if ((rc = mk_stream(&f->side_stream)) || (rc = mk_stream(&f->gemm_stream)) || (rc = mk_stream(&f->bin_stream)) || (rc = mk_stream(&f->early_stream))) return rc;
     for (auto& e : f->train_ev) if (!e) { hipEvent_t x; T2N_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming)); e = (void*)x; }
     if (!f->ev_den) { hipEvent_t e; T2N_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); f->ev_den = (void*)e; }
     return T2N_OK;
@@ -1685,7 +1741,7 @@ static int train_repack(t2n_field* f, const t2n_field_params* p, bool forward_to
     int rc;
     if (forward_too && (rc = launch_pack_mlp(f, p, s))) return rc;
     void* gpack = (char*)f->train_dev + 256;
-    if ((rc = mlp_bwd_ss_pack(f, gpack, s, false))) return rc;
+    if ((rc = mlp_bwd_ss_pack(f, gpack, s, false, true))) return rc;
     f->train_packed = true;
     return T2N_OK;
 }
@@ -1760,11 +1816,22 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
     void* gpack = (char*)f->train_dev + 256;
     float* vote = A->head_grads + (T2N_TRAIN_HEAD_GRAD_FLOATS - 1);
     const bool do_grad = (A->phases & 1u) != 0, do_opt = (A->phases & 2u) != 0;
+    // pipelined form: the early part of this step on `se`, beside the previous step's tail (see include/t2n.h)
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap_status);
+    const bool pipe = A->input_stream && do_grad && do_opt && A->workspace_bytes >= 2 * T.total && cap_status == hipStreamCaptureStatusNone;
+    const bool chain_prev = f->train_chain;               // the previous call was a full step of this form and left its density-Adam event
+    f->train_chain = false;
+    const unsigned par = f->train_calls & 1u;            // scalar slot (always alternates) and, pipelined, workspace half
+    if (do_grad) f->train_calls++;
+    const unsigned slot = do_grad ? par : ((f->train_calls - 1u) & 1u);   // an optimiser-only call takes the slot its gradient call wrote
+    TrainScalars* sc = &st->sc[slot];
+    hipStream_t se = pipe ? (hipStream_t)f->early_stream : s;
     // the caller's tensors are the parameters from here on (the optimiser writes them; the packs read them)
     const t2n_field_params* P = &A->params;
     if (do_opt && (!P->basis_weight || !P->mlp_w0 || !P->mlp_b0 || !P->mlp_w1 || !P->mlp_b1 || !P->mlp_w2 || !P->mlp_b2)) { set_error("t2n_train_step: NULL head tensor"); return T2N_ERR_INVALID; }
 
-    char* ws = (char*)A->workspace;
+    char* ws = (char*)A->workspace + (pipe ? (size_t)par * T.total : 0);
     char* fw = ws + T.fwd;
     char* bw = ws + T.bwd;
     const Carve c = carve_workspace(R, N, true, false);
@@ -1774,20 +1841,26 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
     const BinGeom dgeom_t = bin_geom(f->dev.den);
     const BlockGeom bgeom = block_geom(f->dev.den);
     const BwdCarve b = bwd_carve(rows, R, N, dgeom_t.total, bgeom.total * bgeom.copies, 351, true);
-    float* rgb = (float*)(ws + T.rgb); float* depth = (float*)(ws + T.depth); float* w = (float*)(ws + T.w); float* z = (float*)(ws + T.z);
-    float* d_rgb = (float*)(ws + T.d_rgb); float* d_depth = (float*)(ws + T.d_depth); float* d_w = (float*)(ws + T.d_w);
+    float* rgb = (float*)(ws + T.rgb); float* depth = (float*)(ws + T.depth);
     const uint32_t flags = (A->flags & T2N_FLAG_ADD_BG) | T2N_FLAG_TRAIN | T2N_FLAG_KEEP_CTX;
 
     if (do_grad) {
         if (!f->train_packed) {   // first step / after an upload: the operands an optimiser phase leaves packed behind every later step
-            if ((rc = mlp_bwd_ss_pack(f, gpack, s, false))) return rc;
+            if ((rc = mlp_bwd_ss_pack(f, gpack, s, false, true))) return rc;
             f->train_packed = true;
         }
         T2N_HIP(hipEventRecord(ev[0], s));
+        if (A->input_stream && cap_status == hipStreamCaptureStatusNone) {
+            // the early part waits for the batch buffers and for the previous step's density Adam (first pipelined call: for `stream`);
+            // a call that cannot take the pipelined form (se == s) is simply ordered behind the batch copy
+            T2N_HIP(hipEventRecord(ev[10], (hipStream_t)A->input_stream));
+            T2N_HIP(hipStreamWaitEvent(se, ev[10], 0));
+            if (pipe) T2N_HIP(hipStreamWaitEvent(se, chain_prev ? ev[9] : ev[0], 0));
+        }
         // ---- every zero fill of the step in one launch
         RenderLaunch L;
         L.rays = A->rays; L.n_rays = R; L.ray_stride = A->ray_stride; L.n_samples = N; L.flags = flags; L.jitter = A->jitter;
-        L.rgb = rgb; L.depth = depth; L.weights = w; L.z_vals = z; L.stats = nullptr;
+        L.rgb = rgb; L.depth = depth; L.weights = nullptr; L.z_vals = nullptr; L.stats = nullptr;   // (weights / sample depths: recomputed where they are needed)
         L.counters = (unsigned*)(fw + c.counters); L.acc = (float*)(fw + c.acc); L.ray_app = (int4*)(fw + c.ray_app);
         L.app_pos = (float4*)(fw + c.app_pos); L.app_rgb = (float4*)(fw + c.app_rgb); L.app_ray = (int*)(fw + c.app_ray);
         L.list_cap = c.list_cap; L.feat = nullptr; L.feat_rows = 0;
@@ -1799,32 +1872,31 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
             ok = ok && zo.add(go, (size_t)rows * 16);
             ok = ok && zo.add(bw + b.hist, (size_t)bgeom.total * bgeom.copies * 4);
             ok = ok && zo.add(bw + b.a_hist, (size_t)ageom.total * kBinCopies * 4);
-            ok = ok && zo.add(A->head_grads, (size_t)T2N_TRAIN_HEAD_GRAD_FLOATS * 4);
+            // (head_grads: left zeroed by the previous optimiser phase — its Adam kernel clears what it consumed; a pipelined early part
+            // must not clear a buffer the previous step's head Adam has yet to read)
             if (!ok) { set_error("t2n_train_step: zero-fill table overflow"); return T2N_ERR_INVALID; }
             unsigned long long mx = 1;
             for (int r = 0; r < zo.n; ++r) mx = zo.words[r] > mx ? zo.words[r] : mx;
             unsigned bx = (unsigned)((mx + 4095) / 4096);
             bx = bx > 256 ? 256 : (bx < 1 ? 1 : bx);
-            hipLaunchKernelGGL(k_zero_regions, dim3(bx, (unsigned)zo.n), dim3(256), 0, s, zo);
+            hipLaunchKernelGGL(k_zero_regions, dim3(bx, (unsigned)zo.n), dim3(256), 0, se, zo);
         }
         // ---- forward: march
-        if ((rc = launch_march(f, L, s))) return rc;
-        T2N_HIP(hipEventRecord(ev[2], s));
+        if ((rc = launch_march(f, L, se))) return rc;
+        T2N_HIP(hipEventRecord(ev[2], se));
+        if (pipe) T2N_HIP(hipStreamWaitEvent(s, ev[2], 0));
         // ---- forward: shade with the activation rows kept, composite; the driver's loss
         {
             ShadeCtx ctx{(float*)(fw + kr.x144), (float*)(fw + kr.feat32), (float*)(fw + kr.h0), (float*)(fw + kr.h1)};
             if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, A->ray_stride, L.counters, L.list_cap, L.app_rgb, &ctx, s, false, kr.rows))) return rc;
         }
         if ((rc = launch_composite(f, L, s))) return rc;
-        // (the sum of the per-workgroup partials only feeds the reported losses: off the chain, on sg — folded into the loss kernel's last
-        // workgroup it needs an agent-scope release per workgroup, i.e. an L2 write-back each: 357 us instead of 22)
-        if ((rc = launch_train_loss(rgb, depth, w, z, A->rgb_target, A->depth_target, R, N, A->w_depth, A->w_trans, A->delta, d_rgb, d_depth, d_w,
-                                    A->losses, (float*)(ws + T.part), nullptr, s, sg, ev[8]))) return rc;
+        // (the driver's loss is evaluated by k_bwd_march<.., LOSS>; its partial sums are added up by the step's one reduce launch)
         // ---- sb: plan, then the appearance binning (needs the forward's lists and the plan, not a single gradient)
         T2N_HIP(hipStreamWaitEvent(sb, ev[2], 0));
         BwdPlan* plan = (BwdPlan*)(bw + b.plan);
         hipLaunchKernelGGL(k_train_plan, dim3(1), dim3(64), 0, sb, (const unsigned*)L.counters, c.list_cap, (unsigned)rows, plan, st, A->hyper,
-                           A->beta1, A->beta2, vote, f->train_host);
+                           A->beta1, A->beta2, vote, f->train_host, slot);
         T2N_HIP(hipEventRecord(ev[3], sb));
         GradSet gapp;
         for (int k = 0; k < 3; ++k) { gapp.plane[k] = f->gbuf_app_plane[k]; gapp.line[k] = f->gbuf_app_line[k]; }
@@ -1836,13 +1908,14 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
             const unsigned nbk = (unsigned)((rows + 255) / 256);
             hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, sb, ab);
             launch_bin_scan(ab.hist, ab.geom.total, kBinCopies, (unsigned*)(bw + b.a_bin_total), (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),
-                            b.a_seg_cap, 0u, kAccTargetSegsApp, 512u, sb);
+                            b.a_seg_cap, 0u, kAccTargetSegsApp, 512u, sb, true);
             hipLaunchKernelGGL((k_app_bin<1>), dim3(nbk), dim3(256), 0, sb, ab);
             T2N_HIP(hipEventRecord(ev[4], sb));
         }
         // ---- sa: the gradient buffer starts as the TV gradient of the current factors (zero where no weight is set): 140 MB of streaming
         // beside the shade kernel (matrix cores + LDS) rather than beside the march (gathers: the two slow each other by a third)
-        T2N_HIP(hipStreamWaitEvent(sa, ev[T2N_SEED_AFTER_MARCH ? 2 : 0], 0));
+        T2N_HIP(hipStreamWaitEvent(sa, ev[0], 0));     // (behind the previous step's Adam: it read this buffer and wrote the factors)
+        if (T2N_SEED_AFTER_MARCH) T2N_HIP(hipStreamWaitEvent(sa, ev[2], 0));
         if ((rc = launch_tv_seed_dev(f, A->hyper + 19, sa))) return rc;
         T2N_HIP(hipEventRecord(ev[1], sa));
         // ---- backward: per-ray pass
@@ -1860,12 +1933,14 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
             a.rays = A->rays; a.n_rays = R; a.ray_stride = A->ray_stride; a.n_samples = N; a.npad = (N + 63) & ~63;
             a.jitter = A->jitter; a.sigma = (const float*)(fw + c.sigma); a.ray_app = (const int4*)(fw + c.ray_app);
             a.app_rgb = L.app_rgb; a.rgb_raw = (const float4*)(fw + c.rgb_raw);
-            a.d_rgb = d_rgb; a.d_depth = d_depth; a.d_w = d_w; a.go = go; a.list_cap = c.list_cap; memset(&a.tp, 0, sizeof(a.tp)); a.plan = plan;
+            a.d_rgb = nullptr; a.d_depth = nullptr; a.d_w = nullptr; a.go = go; a.list_cap = c.list_cap; memset(&a.tp, 0, sizeof(a.tp)); a.plan = plan;
+            a.rgb = rgb; a.depth = depth; a.rgb_t = A->rgb_target; a.depth_t = A->depth_target; a.w_depth = A->w_depth; a.w_trans = A->w_trans; a.delta = A->delta;
+            a.loss_part = (float*)(ws + T.part);
             a.add_bg = (flags & T2N_FLAG_ADD_BG) ? 1 : 0;
             a.gfeat = (float*)(fw + c.sigma); a.hist = (unsigned*)(bw + b.hist); a.geom = bgeom;
             const size_t lds = (size_t)4 * 4 * a.npad * sizeof(float);
             const unsigned nb = (unsigned)((R + 3) / 4);
-            hipLaunchKernelGGL((k_bwd_march<true, true>), dim3(nb), dim3(256), lds, s, a);
+            hipLaunchKernelGGL((k_bwd_march<true, true, true>), dim3(nb), dim3(256), lds, s, a);
             T2N_HIP(hipEventRecord(ev[5], s));
         }
         float* hg = A->head_grads;   // basis | w0 | b0 | w1 | b1 | w2 | b2
@@ -1892,11 +1967,13 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
                 }
         // ---- sg: layer 2's weight gradient needs go and the kept h1 only (the chain writes g1 elsewhere in this form)
         T2N_HIP(hipStreamWaitEvent(sg, ev[5], 0));
-        launch_bwd_l2((const float4*)go, (const float*)h1, rows, f->params_ref.mlp_w2, nullptr, g_w2, g_b2, part, sg, rows_dev);
+        const WgradRegions WR = wgrad_regions(rows, 351);
+        launch_bwd_l2((const float4*)go, (const float*)h1, rows, f->params_ref.mlp_w2, nullptr, nullptr, nullptr, (float*)((char*)part + WR.l2), sg, rows_dev);
         T2N_HIP(hipStreamWaitEvent(sg, ev[6], 0));
-        launch_gemm_tn(4, false, G1, 128, h0, 128, rows, 128, 128, g_w1, 128, part, sg, nullptr, g_b1, rows_dev);
-        launch_gemm_tn(4, false, G0, 128, xpe, 352, rows, 128, 351, g_w0, 351, part, sg, feat32, g_b0, rows_dev);
-        launch_gemm_tn(1, false, GF, 32, x144, 144, rows, 27, 144, g_basis, 144, part, sg, nullptr, nullptr, rows_dev);
+        launch_gemm_tn(4, false, G1, 128, h0, 128, rows, 128, 128, g_w1, 128, (float*)((char*)part + WR.tn[0]), sg, nullptr, g_b1, rows_dev, false);
+        launch_gemm_tn(4, false, G0, 128, xpe, 352, rows, 128, 351, g_w0, 351, (float*)((char*)part + WR.tn[1]), sg, feat32, g_b0, rows_dev, false);
+        launch_gemm_tn(1, false, GF, 32, x144, 144, rows, 27, 144, g_basis, 144, (float*)((char*)part + WR.tn[2]), sg, nullptr, nullptr, rows_dev, false);
+        launch_wgrad_reduce((const char*)part, rows, g_w2, g_b2, g_w1, g_w0, g_basis, sg, (const float*)(ws + T.part), R, A->w_depth, A->w_trans, A->losses);
         // ---- appearance scatter: records binned on sb, gradient buffer seeded on sa
         T2N_HIP(hipStreamWaitEvent(s, ev[4], 0));
         T2N_HIP(hipStreamWaitEvent(s, ev[1], 0));
@@ -1918,13 +1995,13 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
         }
     } else {
         // optimiser-only phase (data-parallel): the vote word has been all-reduced with the head gradients
-        hipLaunchKernelGGL(k_train_commit, dim3(1), dim3(64), 0, s, st, (const float*)vote, f->train_host);
+        hipLaunchKernelGGL(k_train_commit, dim3(1), dim3(64), 0, s, st, (const float*)vote, f->train_host, slot);
         T2N_HIP(hipEventRecord(ev[6], s));
         T2N_HIP(hipStreamWaitEvent(sg, ev[6], 0));
     }
     // ---- optimiser. sg: Adam on the seven head tensors, then every packed form of the new head weights (the forward's fp32 and
     // split-f16 operands, the backward chain's transposed ones) beside the factor tensors' Adam on `s`
-    if ((rc = launch_head_adam_dev(P, A->head_grads, A->exp_avg + 12, A->exp_avg_sq + 12, A->beta1, A->beta2, A->eps, st, sg))) return rc;
+    if ((rc = launch_head_adam_dev(P, A->head_grads, A->exp_avg + 12, A->exp_avg_sq + 12, A->beta1, A->beta2, A->eps, sc, sg, true))) return rc;
     f->params_ref.basis_weight = P->basis_weight;
     f->params_ref.mlp_w0 = P->mlp_w0; f->params_ref.mlp_b0 = P->mlp_b0; f->params_ref.mlp_w1 = P->mlp_w1; f->params_ref.mlp_b1 = P->mlp_b1;
     f->params_ref.mlp_w2 = P->mlp_w2; f->params_ref.mlp_b2 = P->mlp_b2;
@@ -1935,8 +2012,14 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
     if ((rc = train_repack(f, P, true, sg))) return rc;
     f->ss_dirty = true;
     T2N_HIP(hipEventRecord(ev[7], sg));
-    if (do_grad) T2N_HIP(hipStreamWaitEvent(s, (hipEvent_t)f->ev_den, 0));
-    if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, st, 0, 12, s))) return rc;
+    if (do_grad) {
+        // the density factors (a quarter of the bytes) step on sa right behind their scatter, beside the appearance scatter on `s`
+        if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, sc, 0, 6, sa))) return rc;
+        T2N_HIP(hipEventRecord(ev[9], sa));
+        f->train_chain = true;      // (the next call's early part may start behind this event)
+        if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, sc, 6, 6, s))) return rc;
+        T2N_HIP(hipStreamWaitEvent(s, ev[9], 0));
+    } else if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, sc, 0, 12, s))) return rc;
     T2N_HIP(hipStreamWaitEvent(s, ev[7], 0));
     T2N_HIP(hipGetLastError());
     return T2N_OK;
@@ -1976,7 +2059,7 @@ extern "C" int t2n_train_graph_launch(t2n_train_graph* g, t2n_stream stream) {
     t2n_field* f = g->f;
     if (!f->train_packed) {   // the head was uploaded since the last step (load_state_dict, a step of another optimiser): the captured step
         // expects the backward chain's operands of the CURRENT weights, which an optimiser phase leaves behind and an upload does not
-        const int rc = mlp_bwd_ss_pack(f, (char*)f->train_dev + 256, (hipStream_t)stream, false);
+        const int rc = mlp_bwd_ss_pack(f, (char*)f->train_dev + 256, (hipStream_t)stream, false, true);
         if (rc) return rc;
         f->train_packed = true;
     }

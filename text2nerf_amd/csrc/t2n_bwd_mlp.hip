@@ -71,9 +71,8 @@ __global__ __launch_bounds__(256) void k_bwd_l2(const float4* __restrict__ go, c
 }
 // dw2 [3,128] += sum of the workgroups' partials, db2 [3] likewise: one workgroup per output, thread b sums partials b, b + 256, ...
 // in order, then a fixed-order tree (deterministic)
-__global__ __launch_bounds__(256) void k_bwd_l2_reduce(const float* __restrict__ part, int nblocks, float* dw2, float* db2) {
-    __shared__ float red[4];
-    const int i = blockIdx.x, b = threadIdx.x;
+__device__ __forceinline__ void bwd_l2_reduce_body(const float* __restrict__ part, int nblocks, float* dw2, float* db2, int i, float* red) {
+    const int b = threadIdx.x;
     float v = 0.f;
     for (int k = b; k < nblocks; k += 256) v += part[(size_t)k * 388 + i];
 #pragma unroll
@@ -85,6 +84,10 @@ __global__ __launch_bounds__(256) void k_bwd_l2_reduce(const float* __restrict__
         if (i < 384) { if (dw2) dw2[i] += s; }
         else if (db2) db2[i - 384] += s;
     }
+}
+__global__ __launch_bounds__(256) void k_bwd_l2_reduce(const float* __restrict__ part, int nblocks, float* dw2, float* db2) {
+    __shared__ float red[4];
+    bwd_l2_reduce_body(part, nblocks, dw2, db2, blockIdx.x, red);
 }
 
 // ---- fp32 MFMA GEMMs -----------------------------------------------------------------------------------------------------
@@ -156,11 +159,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, in
 // C[M,N] (row-major, ldc) += sum over chunks of part[chunk][MA][ldp]. A workgroup owns 32 consecutive outputs; its 8
 // thread groups of 32 each sum every 8th chunk and the partial sums meet in LDS in a fixed order (deterministic, no atomics): a
 // 128 x 128 gradient is 512 workgroups instead of 64 (one thread per output left most of the chip idle behind ~500 dependent loads)
-__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict__ part, int chunks, int MA, int ldp, int M, int N,
-                                                        float* __restrict__ C, int ldc) {
-    __shared__ float red[8][32];
+__device__ __forceinline__ void gemm_tn_reduce_body(const float* __restrict__ part, int chunks, int MA, int ldp, int M, int N,
+                                                    float* __restrict__ C, int ldc, unsigned blk, float (*red)[32]) {
     const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int t = blockIdx.x * 32 + o;
+    const int t = (int)blk * 32 + o;
     const int row = t / ldp, col = t - row * ldp;
     const bool live = row < M && col < N;
     float s0 = 0.f, s1 = 0.f;
@@ -175,6 +177,27 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict_
     __syncthreads();
     if (sl == 0 && live)
         C[(size_t)row * ldc + col] += ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) + ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]));
+}
+__global__ __launch_bounds__(256) void k_gemm_tn_reduce(const float* __restrict__ part, int chunks, int MA, int ldp, int M, int N,
+                                                        float* __restrict__ C, int ldc) {
+    __shared__ float red[8][32];
+    gemm_tn_reduce_body(part, chunks, MA, ldp, M, N, C, ldc, blockIdx.x, red);
+}
+// The fused training step: the partial sums of layer 2 and of the three weight-gradient GEMMs (each in a region of its own) reduced by
+// ONE launch behind the last GEMM instead of four launches between them (same per-output order of additions)
+struct WgradReduce {
+    const float* l2_part; int l2_blocks; float* dw2; float* db2;
+    const float* part[3]; int chunks[3], MA[3], ldp[3], M[3], N[3], ldc[3]; float* C[3];
+    unsigned block0[5];
+    LossReduceArgs loss;   // losses == NULL: none; else the LAST workgroup adds up the loss kernel's partial sums
+};
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradReduce a) {
+    __shared__ float red[8][32];
+    const unsigned b = blockIdx.x;
+    if (b >= a.block0[4]) { __shared__ float lred[256][3]; loss_reduce_rows(a.loss, lred); return; }
+    if (b < a.block0[1]) { bwd_l2_reduce_body(a.l2_part, a.l2_blocks, a.dw2, a.db2, (int)b, &red[0][0]); return; }
+    const int t = b < a.block0[2] ? 0 : (b < a.block0[3] ? 1 : 2);
+    gemm_tn_reduce_body(a.part[t], a.chunks[t], a.MA[t], a.ldp[t], a.M[t], a.N[t], a.C[t], a.ldc[t], b - a.block0[1 + t], red);
 }
 
 // OUT[rows, N] = (IN[rows, K] W[K, N]) (* [ACT > 0] if ACT). A workgroup owns one 128-column group of N: its K x 128 slab
@@ -334,16 +357,21 @@ TnPlan tn_plan(int64_t rows, int N) {
     if (p.chunks < 1) p.chunks = 1;
     return p;
 }
-size_t tn_part_bytes(int64_t rows, int k0) {
-    size_t m = (size_t)kL2Blocks * 388 * 4;   // layer 2's per-workgroup partial sums (launch_bwd_l2) come first
+// one region per producer (layer 2's per-workgroup sums, then the three GEMMs' chunk partials): the fused training step reduces all four
+// with one launch at the end; the composed backward reuses the first region's start for every GEMM in turn
+WgradRegions wgrad_regions(int64_t rows, int k0) {
+    WgradRegions r;
+    size_t o = 0;
+    r.l2 = o; o += ((size_t)kL2Blocks * 388 * 4 + 255) / 256 * 256;
     const int shapes[3][2] = {{128, 128}, {128, k0}, {32, 144}};
-    for (auto& sh : shapes) {
-        const TnPlan p = tn_plan(rows, sh[1]);
-        const size_t b = (size_t)p.chunks * sh[0] * p.ldp * 4;
-        if (b > m) m = b;
+    for (int i = 0; i < 3; ++i) {
+        const TnPlan p = tn_plan(rows, shapes[i][1]);
+        r.tn[i] = o; o += ((size_t)p.chunks * shapes[i][0] * p.ldp * 4 + 255) / 256 * 256;
     }
-    return m;
+    r.total = o;
+    return r;
 }
+size_t tn_part_bytes(int64_t rows, int k0) { return wgrad_regions(rows, k0).total; }
 // layer 2 of the backward: up to kL2Blocks workgroups of 64 rows in flight each, their partial weight / bias sums through `scratch`
 // (>= kL2Blocks x 388 floats: the weight-gradient GEMMs' partial buffer, not in use yet)
 void launch_bwd_l2(const float4* go, const float* h1, long long rows, const float* w2, float* g1, float* dw2, float* db2,
@@ -360,7 +388,7 @@ bool gemm_fp32_mode(const t2n_field* f) { return !f->mlp_split; }
 // GEMM and `B` is never read. db (may be NULL): += column sums of A (the layer's bias gradient).
 template <int MB>
 static void launch_gemm_tn_t(bool fp32, const float* A, int lda, const float* B, int ldb, long long rows, int M, int N, float* C, int ldc,
-                           float* part, hipStream_t s, const float* pe_feat, float* db, const unsigned* rows_dev) {
+                           float* part, hipStream_t s, const float* pe_feat, float* db, const unsigned* rows_dev, bool reduce) {
     const TnPlan p = tn_plan(rows, N);
     if (!fp32 && MB == 4) {   // (the 27-row basis gradient is latency-bound either way: 31 us fp32, 44 us bf16x3)
         (void)launch_gemm_tn_b(A, lda, pe_feat ? pe_feat : B, pe_feat ? 32 : ldb, rows, N, part, p.ldp, p.chunk_rows, p.ng, p.chunks,
@@ -370,7 +398,7 @@ static void launch_gemm_tn_t(bool fp32, const float* A, int lda, const float* B,
                            p.ldp, p.chunk_rows, rows_dev);
         if (db) hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512)), dim3(256), 0, s, A, lda, rows, M, db, 128);
     }
-    hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((MB * 32 * p.ldp + 31) / 32)), dim3(256), 0, s, (const float*)part,
+    if (reduce) hipLaunchKernelGGL(k_gemm_tn_reduce, dim3((unsigned)((MB * 32 * p.ldp + 31) / 32)), dim3(256), 0, s, (const float*)part,
                        p.chunks, MB * 32, p.ldp, M, N, C, ldc);
 }
 void launch_gemm_nn(const float* IN, int ldin, const float* W, int ldw, long long rows, int K, int N, const float* ACT,
@@ -388,9 +416,30 @@ void launch_gemm_nn(const float* IN, int ldin, const float* W, int ldw, long lon
 
 // MB = 4: M <= 128 rows of A per workgroup tile; MB = 1: M <= 32 (the 27-row basis gradient)
 void launch_gemm_tn(int MB, bool fp32, const float* A, int lda, const float* B, int ldb, long long rows, int M, int N, float* C, int ldc,
-                    float* part, hipStream_t s, const float* pe_feat, float* db, const unsigned* rows_dev) {
-    if (MB == 4) launch_gemm_tn_t<4>(fp32, A, lda, B, ldb, rows, M, N, C, ldc, part, s, pe_feat, db, rows_dev);
-    else launch_gemm_tn_t<1>(fp32, A, lda, B, ldb, rows, M, N, C, ldc, part, s, pe_feat, db, rows_dev);
+                    float* part, hipStream_t s, const float* pe_feat, float* db, const unsigned* rows_dev, bool reduce) {
+    if (MB == 4) launch_gemm_tn_t<4>(fp32, A, lda, B, ldb, rows, M, N, C, ldc, part, s, pe_feat, db, rows_dev, reduce);
+    else launch_gemm_tn_t<1>(fp32, A, lda, B, ldb, rows, M, N, C, ldc, part, s, pe_feat, db, rows_dev, reduce);
+}
+// (fused training step) layer 2 + the three GEMMs of the MLP_Fea_noview head, partials at `base` + wgrad_regions(rows, 351): one reduce
+void launch_wgrad_reduce(const char* base, long long rows, float* dw2, float* db2, float* dw1, float* dw0, float* dwb, hipStream_t s,
+                         const float* loss_part, long long n_rays, float w_depth, float w_trans, float* losses) {
+    const WgradRegions R = wgrad_regions(rows, 351);
+    WgradReduce a;
+    const long long tiles = (rows + 63) / 64;
+    a.l2_part = (const float*)(base + R.l2); a.l2_blocks = (int)(tiles < kL2Blocks ? tiles : kL2Blocks); a.dw2 = dw2; a.db2 = db2;
+    const int shapes[3][3] = {{128, 128, 128}, {128, 351, 128}, {27, 144, 32}};   // M, N, MA
+    float* Cs[3] = {dw1, dw0, dwb};
+    unsigned b = 387;
+    a.block0[0] = 0; a.block0[1] = b;
+    for (int i = 0; i < 3; ++i) {
+        const TnPlan p = tn_plan(rows, shapes[i][1]);
+        a.part[i] = (const float*)(base + R.tn[i]); a.chunks[i] = p.chunks; a.MA[i] = shapes[i][2]; a.ldp[i] = p.ldp; a.M[i] = shapes[i][0];
+        a.N[i] = shapes[i][1]; a.ldc[i] = shapes[i][1]; a.C[i] = Cs[i];
+        b += (unsigned)((shapes[i][2] * p.ldp + 31) / 32);
+        a.block0[2 + i] = b;
+    }
+    a.loss = LossReduceArgs{loss_part, (unsigned)((n_rays + 3) / 4), losses, n_rays, w_depth, w_trans};
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(b + (losses ? 1u : 0u)), dim3(256), 0, s, a);
 }
 static unsigned colsum_grid(long long rows) { return (unsigned)((rows + 127) / 128 < 512 ? (rows + 127) / 128 : 512); }
 void launch_colsum(const float* G, int ld, long long rows, int N, float* db, hipStream_t s) {

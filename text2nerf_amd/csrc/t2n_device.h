@@ -406,4 +406,23 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned nblocks) {
     return start + j;
 }
 
+
+// the sum of k_train_loss's per-workgroup partials -> losses[4] (one workgroup of 256 threads, fixed order: deterministic). Shared by
+// k_train_loss_reduce (t2n_loss.hip) and the fused training step's one reduce launch (k_wgrad_reduce, t2n_bwd_mlp.hip).
+struct LossReduceArgs { const float* part; unsigned nblocks; float* losses; long long R; float w_depth, w_trans; };
+__device__ __forceinline__ void loss_reduce_rows(const LossReduceArgs& a, float (*red)[3]) {
+    const float* __restrict__ part = a.part;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (unsigned b = threadIdx.x; b < a.nblocks; b += 256) { s0 += part[(size_t)b * 3]; s1 += part[(size_t)b * 3 + 1]; s2 += part[(size_t)b * 3 + 2]; }
+    red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1; red[threadIdx.x][2] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[threadIdx.x][0] += red[threadIdx.x + o][0]; red[threadIdx.x][1] += red[threadIdx.x + o][1]; red[threadIdx.x][2] += red[threadIdx.x + o][2]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mse = red[0][0] / (3.f * (float)a.R), dl = red[0][1] / (float)a.R, tl = red[0][2] / (float)a.R;
+        a.losses[0] = mse; a.losses[1] = dl; a.losses[2] = tl; a.losses[3] = mse + a.w_depth * dl + a.w_trans * tl;
+    }
+}
 }  // namespace t2n

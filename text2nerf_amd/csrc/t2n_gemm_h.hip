@@ -292,9 +292,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn_b(const float* __restrict__ A, 
             acc[m] = mfma_b(ah, ob.h, acc[m]);
             acc[m] = mfma_b(ah, ob.m, acc[m]);
             acc[m] = mfma_b(am, ob.h, acc[m]);
+#if !defined(T2N_EXP_GEMM_3MFMA)   // (experiment: what the kernel costs with half the matrix work — results are then wrong)
             acc[m] = mfma_b(ah, ob.l, acc[m]);
             acc[m] = mfma_b(al, ob.h, acc[m]);
             acc[m] = mfma_b(am, ob.m, acc[m]);
+#endif
         }
         buf ^= 1;
     };

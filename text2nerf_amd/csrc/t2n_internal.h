@@ -57,15 +57,20 @@ struct FieldDev {
 // Device-side state of the fused training step (t2n_train_step): one 256-B block per field. k_train_plan advances it once per step;
 // every optimiser kernel of the step reads its verdict and its scalars from here (nothing about a step is a by-value kernel argument,
 // so a captured step can be replayed).
+// what the optimiser kernels of ONE step read: two slots, used alternately — the plan of step k + 1 may run (beside step k's tail: the
+// pipelined form of the call) while step k's Adam kernels still read theirs
+struct TrainScalars {
+    float lr_over_bc1[19]; // lr / (1 - beta1^step) per tensor, step = the step being applied
+    float inv_bc2_sqrt;    // 1 / sqrt(1 - beta2^step)
+    unsigned skip;         // verdict: 1 = the optimiser kernels apply nothing
+    unsigned pad[3];
+};
 struct TrainState {
     unsigned step;         // Adam steps applied so far
     unsigned seq;          // fused steps issued (plan kernels run)
     unsigned skipped;      // steps whose update was withheld (appearance rows beyond the capacity)
-    unsigned skip;         // verdict of the step in flight: 1 = the optimiser kernels return at once
-    unsigned loss_ticket;  // k_train_loss: workgroups finished (the last one adds up the partial sums and resets it)
-    unsigned pad[3];
-    float lr_over_bc1[19]; // lr / (1 - beta1^step) per tensor, step = the step being applied
-    float inv_bc2_sqrt;    // 1 / sqrt(1 - beta2^step)
+    unsigned pad[5];
+    TrainScalars sc[2];
 };
 
 constexpr int kTimingEvents = 1024;   // timed launches per kernel between two reads; launches beyond are counted and priced at the timed average
@@ -128,6 +133,7 @@ struct t2n_field {
     // fused training step (t2n_train_step): device state + the backward chain's packed operands (one allocation), the pinned host record,
     // a third side stream for the plan + appearance binning and the events of the call's fork / join graph
     void* train_dev = nullptr; unsigned* train_host = nullptr; void* bin_stream = nullptr; void* train_ev[12] = {};
+    void* early_stream = nullptr; unsigned train_calls = 0; bool train_chain = false;   // pipelined steps: stream of a step's early part; calls so far (workspace / scalar slot parity); the previous call left its density-Adam event
     bool train_packed = false;   // the backward chain's operands in train_dev are those of the current head weights
     unsigned list_hint = 0;          // appearance entries per ray of the last budgeted launch (0: unknown)
     unsigned long long list_retries = 0;
@@ -246,7 +252,12 @@ bool gemm_fp32_mode(const t2n_field* f);
 void launch_bwd_l2(const float4* go, const float* h1, long long rows, const float* w2, float* g1, float* dw2, float* db2, float* scratch,
                    hipStream_t s, const unsigned* rows_dev = nullptr);   // rows_dev: the row count in device memory (rows = capacity then)
 void launch_gemm_tn(int MB, bool fp32, const float* A, int lda, const float* B, int ldb, long long rows, int M, int N, float* C, int ldc,
-                    float* part, hipStream_t s, const float* pe_feat = nullptr, float* db = nullptr, const unsigned* rows_dev = nullptr);
+                    float* part, hipStream_t s, const float* pe_feat = nullptr, float* db = nullptr, const unsigned* rows_dev = nullptr,
+                    bool reduce = true);   // reduce = false: the chunk partials stay in `part` (launch_wgrad_reduce adds them up later)
+struct WgradRegions { size_t l2, tn[3], total; };   // byte offsets of the partial-sum regions in the backward's `part` buffer
+WgradRegions wgrad_regions(int64_t rows, int k0);
+void launch_wgrad_reduce(const char* base, long long rows, float* dw2, float* db2, float* dw1, float* dw0, float* dwb, hipStream_t s,
+                         const float* loss_part = nullptr, long long n_rays = 0, float w_depth = 0.f, float w_trans = 0.f, float* losses = nullptr);
 void launch_gemm_nn(const float* IN, int ldin, const float* W, int ldw, long long rows, int K, int N, const float* ACT, int ldact, float* OUT,
                     int ldo, hipStream_t s);
 void launch_colsum(const float* G, int ld, long long rows, int N, float* db, hipStream_t s);
@@ -257,18 +268,18 @@ size_t mlp_bwd_ss_pack_bytes();
 int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, const float* h0, const float* feat, float* g0, float* gf,
                       float* gx, long long rows, hipStream_t s, bool packed = false, const unsigned* rows_dev = nullptr,
                       float* g1_out = nullptr);   // g1_out: g1 written there instead of over h1 (h1 stays intact for a concurrent k_bwd_l2)
-int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed);
+int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed, bool one_launch = false);   // one_launch: the pack kernel finds the matrices' largest magnitudes itself
 void* mlp_bwd_ss_absmax_words(void* packbuf);
 // the fused training step's optimiser launches (t2n_optim.hip): scalars / TV weights / verdict from device memory
 int launch_tv_seed_dev(t2n_field* f, const float* tvw_dev, hipStream_t s);
 int launch_factor_adam_dev(t2n_field* f, const t2n_field_params* params, float* const* m, float* const* v, float beta1, float beta2, float eps,
-                           const TrainState* st, int first, int count, hipStream_t s);
+                           const TrainScalars* st, int first, int count, hipStream_t s);
 int launch_head_adam_dev(const t2n_field_params* params, const float* grads_flat, float* const* m, float* const* v, float beta1, float beta2,
-                         float eps, const TrainState* st, hipStream_t s);
-// the driver's loss with the reduction folded into the last workgroup (ticket: a zero-initialised device word the kernel resets)
+                         float eps, const TrainScalars* st, hipStream_t s, bool zero_grads = false);
+// the driver's loss (t2n_loss.hip); reduce = false leaves the per-workgroup partial sums [ceil(n_rays / 4)][3] in `part`
 int launch_train_loss(const float* rgb, const float* depth, const float* weights, const float* z_vals, const float* rgb_t, const float* depth_t,
                       int64_t n_rays, int n_samples, float w_depth, float w_trans, float delta, float* d_rgb, float* d_depth, float* d_weights,
-                      float* losses, float* part, unsigned* ticket, hipStream_t s, hipStream_t reduce_stream = nullptr, hipEvent_t ev = nullptr);
+                      float* losses, float* part, bool reduce, hipStream_t s);
 // forward-workspace carve shared by forward and backward (t2n_api.hip)
 struct Carve { size_t acc, ray_app, counters, app_pos, app_ray, app_rgb, sigma, rgb_raw, scratch, feat, total; unsigned list_cap, feat_rows; };
 Carve carve_workspace(int64_t rays, int n_samples, bool ctx, bool feat = true, unsigned budget = 0);   // budget: appearance entries per ray (0: worst case)   // ctx: also room for sigma [rays,N] and rgb_raw [rays]; feat: feature rows (last region: the other offsets do not depend on it; KEEP_CTX calls carve without)

@@ -10,22 +10,10 @@ struct LossArgs {
     const float* rgb; const float* depth; const float* w; const float* z; const float* rgb_t; const float* depth_t;
     long long R; int N; float w_depth, w_trans, delta;
     float* d_rgb; float* d_depth; float* d_w; float* part; float* losses; unsigned nblocks;
-    unsigned* ticket;   // fused training step: the workgroup that finishes last adds the partial sums up (k_train_loss_reduce's order)
 };
 __device__ __forceinline__ void loss_reduce_body(const LossArgs& a, float (*red)[3]) {
-    const volatile float* part = a.part;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (unsigned b = threadIdx.x; b < a.nblocks; b += 256) { s0 += part[(size_t)b * 3]; s1 += part[(size_t)b * 3 + 1]; s2 += part[(size_t)b * 3 + 2]; }
-    red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1; red[threadIdx.x][2] = s2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { red[threadIdx.x][0] += red[threadIdx.x + o][0]; red[threadIdx.x][1] += red[threadIdx.x + o][1]; red[threadIdx.x][2] += red[threadIdx.x + o][2]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const float mse = red[0][0] / (3.f * (float)a.R), dl = red[0][1] / (float)a.R, tl = red[0][2] / (float)a.R;
-        a.losses[0] = mse; a.losses[1] = dl; a.losses[2] = tl; a.losses[3] = mse + a.w_depth * dl + a.w_trans * tl;
-    }
+    const LossReduceArgs r{a.part, a.nblocks, a.losses, a.R, a.w_depth, a.w_trans};
+    loss_reduce_rows(r, red);
 }
 __global__ __launch_bounds__(256) void k_train_loss(const LossArgs a) {
     __shared__ float red[4][3];
@@ -59,18 +47,6 @@ __global__ __launch_bounds__(256) void k_train_loss(const LossArgs a) {
     if (lane == 0) { red[wid][0] = e_rgb; red[wid][1] = e_dep; red[wid][2] = e_tr; }
     __syncthreads();
     if (threadIdx.x < 3) a.part[(size_t)blockIdx.x * 3 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (!a.ticket) return;
-    // one launch instead of two: every workgroup publishes its sums and takes a ticket; the holder of the last one reduces
-    __shared__ unsigned last;
-    __shared__ float red2[256][3];
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(a.ticket, 1u) == a.nblocks - 1u ? 1u : 0u;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    loss_reduce_body(a, red2);
-    if (threadIdx.x == 0) *a.ticket = 0u;
 }
 __global__ __launch_bounds__(256) void k_train_loss_reduce(const LossArgs a) {
     __shared__ float red[256][3];
@@ -78,21 +54,16 @@ __global__ __launch_bounds__(256) void k_train_loss_reduce(const LossArgs a) {
 }
 int launch_train_loss(const float* rgb, const float* depth, const float* weights, const float* z_vals, const float* rgb_t, const float* depth_t,
                       int64_t n_rays, int n_samples, float w_depth, float w_trans, float delta, float* d_rgb, float* d_depth, float* d_weights,
-                      float* losses, float* part, unsigned* ticket, hipStream_t s, hipStream_t reduce_stream, hipEvent_t ev) {
+                      float* losses, float* part, bool reduce, hipStream_t s) {
     LossArgs a;
     a.rgb = rgb; a.depth = depth; a.w = weights; a.z = z_vals; a.rgb_t = rgb_t; a.depth_t = depth_t; a.R = n_rays; a.N = n_samples;
     a.w_depth = w_depth; a.w_trans = w_trans; a.delta = delta; a.d_rgb = d_rgb; a.d_depth = d_depth; a.d_w = d_weights;
-    a.part = part; a.losses = losses; a.nblocks = (unsigned)((n_rays + 3) / 4); a.ticket = ticket;
+    a.part = part; a.losses = losses; a.nblocks = (unsigned)((n_rays + 3) / 4);
     hipLaunchKernelGGL(k_train_loss, dim3(a.nblocks), dim3(256), 0, s, a);
-    if (!ticket) {
-        hipStream_t sr = s;
-        if (reduce_stream && ev) {   // the reduction beside whatever `s` does next (its result is only ever read by the host)
-            T2N_HIP(hipEventRecord(ev, s));
-            T2N_HIP(hipStreamWaitEvent(reduce_stream, ev, 0));
-            sr = reduce_stream;
-        }
-        hipLaunchKernelGGL(k_train_loss_reduce, dim3(1), dim3(256), 0, sr, a);
-    }
+    // reduce = false (fused training step): the partial sums are added up by the step's one reduce launch (k_wgrad_reduce) — the sum only
+    // feeds the reported losses. (Folded into this kernel's last workgroup it needs an agent-scope release per workgroup, an L2 write-back
+    // each: 357 us instead of 22 measured.)
+    if (reduce) hipLaunchKernelGGL(k_train_loss_reduce, dim3(1), dim3(256), 0, s, a);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }
@@ -111,6 +82,6 @@ extern "C" int t2n_train_loss(const float* rgb, const float* depth, const float*
     }
     if (workspace_bytes < t2n_train_loss_workspace_bytes(n_rays)) { set_error("t2n_train_loss: workspace too small"); return T2N_ERR_WORKSPACE; }
     return launch_train_loss(rgb, depth, weights, z_vals, rgb_t, depth_t, n_rays, n_samples, w_depth, w_trans, delta, d_rgb, d_depth, d_weights,
-                             losses, (float*)workspace, nullptr, (hipStream_t)stream, nullptr, nullptr);
+                             losses, (float*)workspace, true, (hipStream_t)stream);
 }
 

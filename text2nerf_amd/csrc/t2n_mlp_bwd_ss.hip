@@ -387,8 +387,28 @@ __host__ __device__ inline int enc_col(int U, int i) {
     const int F = 14 * hh + v / 12, o = (v % 12) >> 1, sc = v & 1;
     return F < 27 ? (sc ? 189 : 27) + F * 6 + o : -1;
 }
+__device__ __forceinline__ unsigned block_absmax(const float* __restrict__ p, int n, unsigned* sh) {
+    unsigned m = 0u;
+    for (int i = threadIdx.x; i < n; i += 256) m = max(m, __float_as_uint(p[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+}
+// SELF: every workgroup derives the four matrices' largest magnitudes itself (66 000 values from L2) instead of reading them from a
+// k_bss_absmax launch in front of this one: one launch per re-pack (the fused training step re-packs behind every optimiser step)
+template <bool SELF>
 __global__ __launch_bounds__(256) void k_pack_bwd_ss(const PackArgs a) {
-    const float s2 = scale_of(a.absmax[0]), s1 = scale_of(a.absmax[1]), s0 = scale_of(a.absmax[2]), sb = scale_of(a.absmax[3]);
+    float s2, s1, s0, sb;
+    if (SELF) {
+        __shared__ unsigned sh[4];
+        s2 = scale_of(block_absmax(a.w2, 3 * 128, sh)); s1 = scale_of(block_absmax(a.w1, 128 * 128, sh));
+        s0 = scale_of(block_absmax(a.w0, 128 * 351, sh)); sb = scale_of(block_absmax(a.wb, 27 * 144, sh));
+    } else {
+        s2 = scale_of(a.absmax[0]); s1 = scale_of(a.absmax[1]); s0 = scale_of(a.absmax[2]); sb = scale_of(a.absmax[3]);
+    }
     if (blockIdx.x == 0 && threadIdx.x < 4) {
         const float s = threadIdx.x == 0 ? s2 : (threadIdx.x == 1 ? s1 : (threadIdx.x == 2 ? s0 : sb));
         a.scales[threadIdx.x] = s; a.scales[4 + threadIdx.x] = 1.f / s;
@@ -458,7 +478,7 @@ void* mlp_bwd_ss_absmax_words(void* packbuf) {
 // The transposed split-f16 operands of the chain from the CURRENT weights: two small launches that depend on nothing but the parameters —
 // the backward runs them before it forks its side streams (queued behind the density scatter's workgroups, the 6-us pack kernel sat
 // 50 us on the critical path in front of k_mlp_bwd_ss).
-int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed) {
+int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed, bool one_launch) {
     using namespace bss;
     const t2n_field_params& p = f->params_ref;
     uint4* base = (uint4*)packbuf;
@@ -467,12 +487,17 @@ int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed) {
     pa.a2 = base; pa.a1 = base + kA2; pa.a0 = base + kA2 + kA1; pa.ab = base + kA2 + kA1 + kA0;
     unsigned* am = (unsigned*)(base + kA2 + kA1 + kA0 + kAb);
     pa.absmax = am; pa.scales = (float*)(am + 4);
+    if (one_launch) {
+        hipLaunchKernelGGL(k_pack_bwd_ss<true>, dim3(64), dim3(256), 0, s, pa);
+        T2N_HIP(hipGetLastError());
+        return T2N_OK;
+    }
     if (!zeroed) T2N_HIP(hipMemsetAsync(am, 0, 16, s));
     AbsMaxArgs m;
     m.p[0] = p.mlp_w2; m.n[0] = 3 * 128; m.p[1] = p.mlp_w1; m.n[1] = 128 * 128; m.p[2] = p.mlp_w0; m.n[2] = 128 * 351; m.p[3] = p.basis_weight; m.n[3] = 27 * 144;
     m.out = am;
     hipLaunchKernelGGL(k_bss_absmax, dim3(16, 4), dim3(256), 0, s, m);
-    hipLaunchKernelGGL(k_pack_bwd_ss, dim3(64), dim3(256), 0, s, pa);
+    hipLaunchKernelGGL(k_pack_bwd_ss<false>, dim3(64), dim3(256), 0, s, pa);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

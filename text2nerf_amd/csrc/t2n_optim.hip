@@ -82,7 +82,7 @@ struct AdamMulti {
     float lr_over_bc1[kAdamMaxTensors], inv_bc2_sqrt[kAdamMaxTensors];
     int count; float beta1, beta2, eps;
     // fused training step: scalars and the step's verdict from device memory (tensor t <-> st->lr_over_bc1[st_first + t]); NULL: by value
-    const TrainState* st; int st_first;
+    const TrainScalars* st; int st_first; int zero_grads;   // zero_grads: the consumed gradient is set to zero (the next step accumulates into it)
 };
 __global__ __launch_bounds__(256) void k_adam_multi(const AdamMulti a) {
     int t = 0;
@@ -94,11 +94,12 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamMulti a) {
     if (i >= a.n[t]) return;
     float lr = a.lr_over_bc1[t], ib = a.inv_bc2_sqrt[t];
     if (a.st) {
-        if (a.st->skip) return;      // the step's appearance rows did not fit: no tensor moves, no moment decays
+        if (a.st->skip) { if (a.zero_grads) const_cast<float*>(a.g[t])[i] = 0.f; return; }   // the step's appearance rows did not fit: no tensor moves, no moment decays
         lr = a.st->lr_over_bc1[a.st_first + t]; ib = a.st->inv_bc2_sqrt;
     }
     float* __restrict__ p = a.p[t]; const float* __restrict__ g = a.g[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
     const float gi = g[i];
+    if (a.zero_grads) const_cast<float*>(g)[i] = 0.f;
     const float mi = m[i] + (gi - m[i]) * (1.f - a.beta1);
     const float vi = v[i] * a.beta2 + (1.f - a.beta2) * gi * gi;
     m[i] = mi; v[i] = vi;
@@ -184,7 +185,7 @@ struct FactorStep {
     unsigned ablock0[13], tblock0[13];   // first workgroup of tensor t in the Adam / TV launch (TV: zero-width for lines and weight 0)
     float beta1, beta2, eps;
     // fused training step (NULL: by value): Adam scalars + verdict; the two TV weights (x 1e-2) of this step in device memory
-    const TrainState* st; const float* tvw_dev;
+    const TrainScalars* st; const float* tvw_dev;
 };
 __global__ __launch_bounds__(256) void k_tv_grad_cl_multi(const FactorStep a) {
     int t = 0;
@@ -355,7 +356,7 @@ int launch_tv_seed_dev(t2n_field* f, const float* tvw_dev, hipStream_t s) {
 // Adam on the channel-last copies of the factor tensors first .. first + count - 1 (order: density planes, density lines, appearance
 // planes, appearance lines), new values also written to the caller's reference-layout tensors
 int launch_factor_adam_dev(t2n_field* f, const t2n_field_params* params, float* const* m, float* const* v, float beta1, float beta2, float eps,
-                           const TrainState* st, int first, int count, hipStream_t s) {
+                           const TrainScalars* st, int first, int count, hipStream_t s) {
     FactorStep A;
     memset(&A, 0, sizeof(A));
     unsigned ab, tb;
@@ -379,7 +380,7 @@ int launch_factor_adam_dev(t2n_field* f, const t2n_field_params* params, float* 
 }
 // Adam on the seven head tensors (reference layout; gradients contiguous in `grads_flat`, parameter order)
 int launch_head_adam_dev(const t2n_field_params* params, const float* grads_flat, float* const* m, float* const* v, float beta1, float beta2,
-                         float eps, const TrainState* st, hipStream_t s) {
+                         float eps, const TrainScalars* st, hipStream_t s, bool zero_grads) {
     AdamMulti a;
     memset(&a, 0, sizeof(a));
     float* ps[7] = {(float*)params->basis_weight, (float*)params->mlp_w0, (float*)params->mlp_b0, (float*)params->mlp_w1, (float*)params->mlp_b1,
@@ -395,7 +396,7 @@ int launch_head_adam_dev(const t2n_field_params* params, const float* grads_flat
         off += n[i];
     }
     a.block0[7] = blocks;
-    a.count = 7; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.st = st; a.st_first = 12;
+    a.count = 7; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.st = st; a.st_first = 12; a.zero_grads = zero_grads ? 1 : 0;
     hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, s, a);
     T2N_HIP(hipGetLastError());
     return T2N_OK;

@@ -25,6 +25,7 @@ from ._lib import T2NError
 
 _RING = 4          # input buffers (and graphs); the host runs at most two steps ahead of the device, so a slot's verdict is known before reuse
 _RUN_AHEAD = 2
+PIPELINE_MAX_BYTES = 3 << 30
 
 
 def _ladder(n: int, step: float = 1.25, floor: int = 1024) -> int:
@@ -56,6 +57,11 @@ class FusedStep:
         self.replays = 0
         self.copy_stream = None
         self.cap_once = 0
+        self.pipe_input = None          # stream the current batch was copied on, when this call may take the pipelined form
+        self.pipe_ws = False
+        self.pipelined_launches = 0
+        self.pipeline = True            # (False: always the serial form)
+        self._key_after = None
         self.slot_done = [None] * _RING
         self.queue = []            # withheld batches waiting for their replay: (input buffer copy, meta, rows needed)
         self.graph_launches = 0
@@ -145,6 +151,11 @@ class FusedStep:
         need = int(lib.t2n_train_step_workspace_bytes(self.field._handle, R, N, cap))
         if need == 0:
             raise T2NError("t2n_train_step_workspace_bytes: bad shape")
+        # pipelined steps alternate between two halves of the workspace (include/t2n.h); a step that needs more than PIPELINE_MAX_BYTES
+        # (the fog phase of a run: millions of appearance rows) runs in the serial form on one
+        self.pipe_ws = need <= PIPELINE_MAX_BYTES
+        if self.pipe_ws:
+            need *= 2
         if self.ws is None or self.ws.numel() < need:
             had = self.ws is not None
             self.ws = None
@@ -190,6 +201,7 @@ class FusedStep:
         ws = self._workspace(R, N, cap)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         a.losses = self.losses.data_ptr()
+        a.input_stream = None
         key = (R, stride, N, flags, phases, cap, betas, eps, w_depth, w_trans, delta, ws.data_ptr(), buf.data_ptr(),
                tuple(p.data_ptr() for p in ps), tuple(t.data_ptr() for t in ms), tuple(t.data_ptr() for t in vs))
         return a, key
@@ -219,6 +231,9 @@ class FusedStep:
                 _lib.check(lib.t2n_train_graph_launch(g, st), "t2n_train_graph_launch")
                 self.graph_launches += 1
             else:
+                if self.pipe_input is not None and self.pipe_ws and int(a.phases) == 3:
+                    a.input_stream = self.pipe_input       # (eager, full step: the early part may run beside the previous step's tail)
+                    self.pipelined_launches += 1
                 _lib.check(lib.t2n_train_step(f._handle, C.byref(a), st), "t2n_train_step")
                 self.eager_launches += 1
 
@@ -290,6 +305,8 @@ class FusedStep:
     def step(self, rays, rgb_t, dep_t, N, flags, w_depth, w_trans, delta, tv, graph, all_reduce=None):
         f = self.field
         lib = _lib.load()
+        untouched = self._key_after is not None and f._uploaded_key == self._key_after and \
+            tuple((p.data_ptr(), p._version) for p in f._all_params()) == self._key_after
         h = f.sync_params()
         if self._handle_seen is not h:
             # a new native field (first step, or the handle was re-created): its step count is the optimiser's
@@ -345,9 +362,17 @@ class FusedStep:
                 cs.wait_event(self.slot_done[i])       # the step that read this buffer last
             with torch.cuda.stream(cs):
                 buf.copy_(pin, non_blocking=True)
-            cur.wait_event(cs.record_event())
+            # nobody touched the field since this driver's last step: the C call may start the step's early part (march, plan, binning)
+            # on its own stream behind the copy — beside the previous step's tail — instead of behind the whole previous step
+            self.pipe_input = C.c_void_p(cs.cuda_stream) if (self.pipeline and untouched and not graph and all_reduce is None) else None
+            if self.pipe_input is None:
+                cur.wait_event(cs.record_event())
+        else:
+            self.pipe_input = None
         meta = dict(R=R, stride=stride, N=N, flags=flags, betas=betas, eps=eps, w_depth=float(w_depth), w_trans=float(w_trans), delta=float(delta))
         self._submit(i, meta, graph, all_reduce)
+        self.pipe_input = None
+        self._key_after = f._uploaded_key
         f.device_rows_steps = getattr(f, "device_rows_steps", 0) + 1
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
