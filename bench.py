@@ -309,7 +309,7 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
         # ~45 steps — 114 000 appearance samples until step 40, 674 000 at 60, tools/experiments/train_sample_growth.py — so later
         # steps of one trajectory would be another workload), warm-up included; the MEDIAN is reported and all three are in the line
         blocks = [dt]
-        for _ in range(2):
+        for _ in range(max(2, int(os.environ.get("T2N_TRAIN_BLOCKS", "3")) - 1)):
             field.load_state_dict(init_state)
             opt = make_opt()
             for k in range(warmup):
@@ -320,9 +320,16 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
                 loss = it(warmup + k)
             torch.cuda.synchronize()
             blocks.append(time.perf_counter() - t0)
+            if os.environ.get("T2N_TRAIN_DEBUG") and field.__dict__.get("_fused_step") is not None:
+                fs_ = field._fused_step
+                print("[bench] fused step driver:", dict(issued=fs_.issued, eager=fs_.eager_launches, graph=fs_.graph_launches, pipelined=fs_.pipelined_launches,
+                                                          replays=fs_.replays, cap=fs_.rows_cap, needs=fs_.needs[-3:], ws=hex(fs_.ws.data_ptr()), ws_bytes=fs_.ws.numel(),
+                                                          m=[hex(t.data_ptr()) for t in fs_._moments()[1][:12:3]], v=[hex(t.data_ptr()) for t in fs_._moments()[2][:12:3]],
+                                                          gbuf=hex(field._gbuf.data_ptr()), inbuf=[hex(b.data_ptr()) for b in fs_.inbuf if b is not None], hg=hex(fs_.head_grads.data_ptr())),
+                      file=sys.stderr, flush=True)
         blocks_ms = [round(b / iters * 1e3, 4) for b in blocks]
         print("[bench] train blocks of %d iterations (ms/iter): %s" % (iters, blocks_ms), file=sys.stderr, flush=True)
-        dt = sorted(blocks)[1]
+        dt = sorted(blocks)[len(blocks) // 2]
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -62,6 +62,8 @@ enum {
                                * forward in this mode: the kept rows are consumed in place, a second call on the same context finds the
                                * forward's statement cleared and computes no appearance gradients. Needs the fused
                                * MLP_Fea_noview head (27/6/128, 48 comps), the binned scatters and all head gradient tensors. */
+    T2N_FLAG_PIPELINE = 64u,  /* t2n_train_step only: the pipelined form is allowed (the caller has not touched the field since its previous
+                               * t2n_train_step) */
     T2N_FLAG_COHERENT = 8u    /* hint (eval): rays are a row-major image whose width was given by t2n_field_set_frame_width:
                                  march 8x8-pixel tiles whose rays share one texel x line-row dot-product table per step
                                  (f32 matrix cores). Same samples; the density feature is summed in table order and the
@@ -464,20 +466,22 @@ int t2n_depth_align_global(const float* depth_rendered, const float* depth_est, 
  *   phases         1: render + loss + backward only (gradients left in the field's buffer and head_grads), 2: optimiser only (after a
  *                  data-parallel all-reduce of both; a non-zero vote word withholds the update on every rank), 3: both.
  *   losses         device float[4] = {mse, depth loss, transmittance loss, total} of the batch
- * Pipelined form (eager calls with phases = 3): when `input_stream` names the stream on which the batch buffers (rays, jitter, targets,
- * hyper) were written and the workspace holds TWICE t2n_train_step_workspace_bytes, the step's early part — zero fills, the march (it
- * reads the density factors only), the plan and the appearance binning — does not wait for `stream`: it starts as soon as the PREVIOUS
- * t2n_train_step of this field has stepped its density factors and `input_stream` has passed the call, beside the previous step's
- * appearance scatter / weight-gradient GEMMs / Adam. The two halves of the workspace and two slots of per-step scalars alternate. The
- * caller must not have touched the field (uploads, other optimiser steps) between the two calls; everything else about the call
- * (ordering of its results on `stream`, the record) is unchanged. head_grads is left ZEROED by the optimiser phase (and must be zero
- * when a phases = 1 | 3 call starts).
+ * host_batch: the call itself copies host_batch_bytes from pinned host memory to batch_buffer (asynchronously, ahead of everything that
+ * reads the batch). Pipelined form — an eager call with T2N_FLAG_PIPELINE, phases = 3, host_batch set and a workspace of TWICE
+ * t2n_train_step_workspace_bytes: the copy and the step's early part (zero fills, the march — it reads the density factors only —, the
+ * plan, the appearance binning) are enqueued on the library's side stream right behind the PREVIOUS step's density Adam instead of
+ * behind `stream`, i.e. they run beside the previous step's appearance scatter / weight-gradient GEMMs / Adam. The two halves of the
+ * workspace and two slots of per-step scalars alternate. The caller must not have touched the field (uploads, other optimiser steps)
+ * between the two calls and must not reuse host_batch / batch_buffer before the call after next has been submitted; everything else
+ * about the call (ordering of its results on `stream`, the record) is unchanged. head_grads is left ZEROED by the optimiser phase (and
+ * must be zero when a phases = 1 | 3 call starts). The whole call uses three side streams (early part + TV seed + density scatter; layer
+ * 2 + weight-gradient GEMMs + head step; none for the rest): with the caller's, one per hardware queue.
  * Replaces (reference): text2nerf_main.py:553-590 (renderer call, losses, TV terms, zero_grad / backward / step). */
 #define T2N_TRAIN_HYPER_FLOATS 32
 #define T2N_TRAIN_HEAD_GRAD_FLOATS (27 * 144 + 128 * 351 + 128 + 128 * 128 + 128 + 3 * 128 + 3 + 1)
 typedef struct t2n_train_step_args {
     const float* rays; int64_t n_rays; int32_t ray_stride; int32_t n_samples;
-    uint32_t flags;            /* T2N_FLAG_ADD_BG or 0 (T2N_FLAG_TRAIN is implied) */
+    uint32_t flags;            /* T2N_FLAG_ADD_BG, T2N_FLAG_PIPELINE or 0 (T2N_FLAG_TRAIN is implied) */
     uint32_t phases;           /* 1 | 2 */
     const float* jitter; const float* rgb_target; const float* depth_target;
     float w_depth, w_trans, delta;
@@ -489,7 +493,9 @@ typedef struct t2n_train_step_args {
     int64_t rows_capacity;
     void* workspace; size_t workspace_bytes;
     float* losses;
-    t2n_stream input_stream;   /* optional (NULL = none), see "pipelined form" */
+    const void* host_batch;    /* optional: the batch in PINNED host memory (NULL: the device buffers are already filled), see below */
+    size_t host_batch_bytes;
+    void* batch_buffer;        /* device destination of host_batch: the start of the ONE allocation rays / jitter / targets / hyper point into */
 } t2n_train_step_args;
 size_t t2n_train_step_workspace_bytes(const t2n_field* f, int64_t n_rays, int n_samples, int64_t rows_capacity);
 int t2n_train_step(t2n_field* f, const t2n_train_step_args* a, t2n_stream stream);
@@ -516,7 +522,10 @@ int t2n_train_graph_destroy(t2n_train_graph* g);
  * per kernel since the last reset (up to 1024 launches per kernel are timed between two reads; launches beyond that are counted and
  * priced at the timed average). Kernel ids: */
 enum { T2N_K_MARCH = 0, T2N_K_SHADE = 1, T2N_K_COMPOSITE = 2, T2N_K_UPLOAD = 3, T2N_K_BWD_MARCH = 4, T2N_K_BWD_MLP = 5,
-       T2N_K_BWD_SCATTER = 6, T2N_K_DENSITY = 7, T2N_K_APPFEAT = 8 /* appearance gather + basis_mat */, T2N_K_COUNT = 9 };
+       T2N_K_BWD_SCATTER = 6, T2N_K_DENSITY = 7, T2N_K_APPFEAT = 8 /* appearance gather + basis_mat */,
+       /* t2n_train_step only (its groups run side by side on four streams: each figure is the group's own start-to-end time under that
+        * concurrency): weight-gradient GEMMs + their reduce; density binning + scatter; TV seed; Adam on the factors; head Adam + re-packs */
+       T2N_K_BWD_WGRAD = 9, T2N_K_BWD_DENSITY = 10, T2N_K_TV_SEED = 11, T2N_K_ADAM = 12, T2N_K_HEAD_STEP = 13, T2N_K_COUNT = 14 };
 int t2n_timing_enable(t2n_field* f, int on);   /* on: 0 off, 1 every kernel, else a mask: bit (k + 1) brackets kernel id k only */
 int t2n_timing_read(t2n_field* f, double* ms /*[T2N_K_COUNT]*/, int64_t* launches /*[T2N_K_COUNT]*/, int reset);
 

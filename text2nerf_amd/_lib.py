@@ -10,12 +10,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2N_LIB") or os.path.join(_HERE, "libt2n_hip.so")
 
 T2N_STAT_COUNT = 8
-T2N_K_COUNT = 9
-KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_mlp", "bwd_scatter", "density", "app_features")
+T2N_K_COUNT = 14
+KERNEL_NAMES = ("march", "shade", "composite", "upload", "bwd_march", "bwd_mlp", "bwd_scatter", "density", "app_features",
+                "bwd_wgrad", "bwd_density", "tv_seed", "adam", "head_step")
 STAT_EVALUATED, STAT_APPEARANCE, STAT_RAYS, STAT_OVERFLOW, STAT_F16_REDO, STAT_LIST_RETRY = 0, 1, 2, 3, 4, 5
 
 FLAG_TRAIN, FLAG_ADD_BG, FLAG_KEEP_CTX, FLAG_COHERENT, FLAG_NDC = 1, 2, 4, 8, 16
 FLAG_DEVICE_ROWS = 32
+FLAG_PIPELINE = 64
 SHADE_IDS = {"MLP_Fea_noview": 0, "SH": 1, "RGB": 2, "MLP_Fea": 3, "MLP_PE": 4, "MLP": 5}   # MLP_PE: rejected in tensorf.py (broken upstream)
 ACT_IDS = {"softplus": 0, "relu": 1}
 
@@ -64,7 +66,7 @@ class TrainStepArgs(C.Structure):   # t2n_train_step_args
                 ("hyper", C.c_void_p), ("params", FieldParams),
                 ("exp_avg", C.c_void_p * 19), ("exp_avg_sq", C.c_void_p * 19),
                 ("head_grads", C.c_void_p), ("rows_capacity", C.c_int64),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("losses", C.c_void_p), ("input_stream", C.c_void_p)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("losses", C.c_void_p), ("host_batch", C.c_void_p), ("host_batch_bytes", C.c_size_t), ("batch_buffer", C.c_void_p)]
 
 
 _lib = None

@@ -769,12 +769,14 @@ struct TileAccumArgs {
     const float* gx; int gx_ld;
 };
 // CT = channels of the factor set (texel stride); a workgroup covers the 16 channels [coff, coff + 16).
-template <int CT, int K>
+// CG = channels per workgroup (16: one workgroup per CU with 138 KB of LDS at 300^3; 8 with NT = 256 threads: 69 KB — two workgroups per CU,
+// one accumulates while the other stages / zeroes / flushes)
+template <int CT, int K, int CG, int NT>
 __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const int4 sg, int x0, int y0, int coff, const float* Pv,
                                                    double* Pa, const float* Lv, double* La, float4* tab) {
-    constexpr int C = 16;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, ch = lane & 15, sub = lane >> 4;
-    constexpr int NW = kAccThreads / 64;
+    constexpr int C = CG;   // 64 / CG records per instruction, CG instructions per batch of 64 records
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, ch = lane & (CG - 1), sub = lane / CG;
+    constexpr int NW = NT / 64;
     const int W = a.S.W[K], H = a.S.H[K], L = a.S.L[K];
     const int per = ((sg.z - sg.y + NW * 64 - 1) / (NW * 64)) * 64;     // records per wave, whole batches
     const int rb = sg.y + wid * per, re = min(sg.z, rb + per);
@@ -794,19 +796,19 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
         wave_lds_sync();
         // appearance: the 16 per-channel gradients this lane needs for the batch, all in flight before the accumulate loop
         // (a dependent global load per record inside the loop serialised ~1 us round trips)
-        float gpre[16];
+        float gpre[CG];
         if (a.gx) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float4 t0 = T[(sub * 16 + q) * 3];
+            for (int q = 0; q < CG; ++q) {
+                const float4 t0 = T[(sub * CG + q) * 3];
                 gpre[q] = t0.w != 0.f ? a.gx[(size_t)__float_as_int(t0.z) * a.gx_ld + K * CT + coff + ch] : 0.f;
             }
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            // the four records an instruction handles are 16 apart in the batch: neighbours in the list are neighbouring
+        for (int q = 0; q < CG; ++q) {
+            // the RPI records an instruction handles are CG apart in the batch: neighbours in the list are neighbouring
             // samples of ONE ray and would hit the same accumulator words (same-address LDS atomics serialise)
-            const int ri = sub * 16 + q;
+            const int ri = sub * CG + q;
             const float4 t0 = T[ri * 3], wp = T[ri * 3 + 1], wl = T[ri * 3 + 2];
             const int c00 = __float_as_int(t0.x) + ch, c01 = c00 + C, c10 = c00 + (kBinTile + 1) * C, c11 = c10 + C;
             const int r0 = __float_as_int(t0.y) + ch, r1 = r0 + C;
@@ -825,11 +827,11 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
     }
 }
 // grid: (segments, CT / 16)
-template <int CT>
-__global__ __launch_bounds__(kAccThreads) void k_bwd_tile_accum(const TileAccumArgs a) {
+template <int CT, int CG = 16, int NT = kAccThreads>
+__global__ __launch_bounds__(NT) void k_bwd_tile_accum(const TileAccumArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned nseg = *a.nseg;
-    const int coff = blockIdx.y * 16;
+    const int coff = blockIdx.y * CG;
     for (unsigned seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     if (seg != blockIdx.x) __syncthreads();   // the previous segment's flush has finished reading the accumulators
     const int4 sg = a.segs[seg];
@@ -841,36 +843,36 @@ __global__ __launch_bounds__(kAccThreads) void k_bwd_tile_accum(const TileAccumA
     else if (k == 1) { W = a.S.W[1]; H = a.S.H[1]; L = a.S.L[1]; tw = a.geom.tw[1]; P = a.S.plane[1]; Ln = a.S.line[1]; gP = a.G.plane[1]; gL = a.G.line[1]; }
     else { W = a.S.W[2]; H = a.S.H[2]; L = a.S.L[2]; tw = a.geom.tw[2]; P = a.S.plane[2]; Ln = a.S.line[2]; gP = a.G.plane[2]; gL = a.G.line[2]; }
     const int x0 = (tile % tw) * kBinTile - 1, y0 = (tile / tw) * kBinTile - 1;   // texel of local (0, 0)
-    constexpr int C = 16, T1 = kBinTile + 1, TP = T1 * T1 * C, C4 = C / 4;
+    constexpr int C = CG, T1 = kBinTile + 1, TP = T1 * T1 * C, C4 = C / 4;
     double* Pa = reinterpret_cast<double*>(smem);
     double* La = Pa + TP;
     float* Pv = reinterpret_cast<float*>(La + (size_t)(L + 2) * C);
     float* Lv = Pv + TP;
     float4* tab = reinterpret_cast<float4*>(Lv + (size_t)(L + 2) * C);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int idx = threadIdx.x; idx < TP / 4; idx += kAccThreads) {
+    for (int idx = threadIdx.x; idx < TP / 4; idx += NT) {
         const int cell = idx / C4, q = idx - cell * C4, ly = cell / T1, lx = cell - ly * T1, y = y0 + ly, x = x0 + lx;
         reinterpret_cast<float4*>(Pv)[idx] = (x >= 0 && x < W && y >= 0 && y < H)
             ? *reinterpret_cast<const float4*>(P + ((size_t)y * W + x) * CT + coff + q * 4) : zero4;
     }
-    for (int idx = threadIdx.x; idx < (L + 2) * C4; idx += kAccThreads) {
+    for (int idx = threadIdx.x; idx < (L + 2) * C4; idx += NT) {
         const int row = idx / C4 - 1, q = idx % C4;
         reinterpret_cast<float4*>(Lv)[idx] = (row >= 0 && row < L) ? *reinterpret_cast<const float4*>(Ln + (size_t)row * CT + coff + q * 4) : zero4;
     }
-    for (int idx = threadIdx.x; idx < (TP + (L + 2) * C) / 2; idx += kAccThreads) reinterpret_cast<float4*>(Pa)[idx] = zero4;
+    for (int idx = threadIdx.x; idx < (TP + (L + 2) * C) / 2; idx += NT) reinterpret_cast<float4*>(Pa)[idx] = zero4;
     __syncthreads();
-    if (k == 0) tile_accum_records<CT, 0>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
-    else if (k == 1) tile_accum_records<CT, 1>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
-    else tile_accum_records<CT, 2>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
+    if (k == 0) tile_accum_records<CT, 0, CG, NT>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
+    else if (k == 1) tile_accum_records<CT, 1, CG, NT>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
+    else tile_accum_records<CT, 2, CG, NT>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
     __syncthreads();
-    for (int idx = threadIdx.x; idx < TP; idx += kAccThreads) {
+    for (int idx = threadIdx.x; idx < TP; idx += NT) {
         const float v = (float)Pa[idx];
         if (v != 0.f) {
             const int cell = idx / C, c = idx - cell * C, ly = cell / T1, lx = cell - ly * T1, y = y0 + ly, x = x0 + lx;
             if (x >= 0 && x < W && y >= 0 && y < H) atomicAdd(gP + ((size_t)y * W + x) * CT + coff + c, v);
         }
     }
-    for (int idx = threadIdx.x; idx < L * C; idx += kAccThreads) {
+    for (int idx = threadIdx.x; idx < L * C; idx += NT) {
         const float v = (float)La[C + idx];
         if (v != 0.f) atomicAdd(gL + (size_t)(idx / C) * CT + coff + (idx % C), v);
     }
@@ -924,9 +926,9 @@ __global__ __launch_bounds__(256) void k_app_bin(const AppBinArgs a) {
     }
 }
 // doubles: tile + line accumulators; floats: staged values; per-wave tap tables (64 records x 3 float4)
-static size_t tile_accum_lds(int C, int Lmax) {
+static size_t tile_accum_lds(int C, int Lmax, int threads = kAccThreads) {
     const size_t cells = (size_t)(kBinTile + 1) * (kBinTile + 1) * C + (size_t)(Lmax + 2) * C;
-    return cells * 8 + cells * 4 + (size_t)(kAccThreads / 64) * 64 * 3 * 16;
+    return cells * 8 + cells * 4 + (size_t)(threads / 64) * 64 * 3 * 16;
 }
 
 // appearance taps: re-gather and scatter-add with gX [rows,144]
@@ -1610,6 +1612,9 @@ extern "C" int t2n_field_wait_density_grads(const t2n_field* f, t2n_stream waite
 //   sb (bin)     plan (rows, tile prefix, verdict, Adam scalars, host record) -> appearance binning (needs the forward's lists only)
 //   sg (gemm)    layer-2 gradients (behind bwd_march) -> weight-gradient GEMMs (behind mlp_bwd_ss) -> Adam (head) -> operand re-packs
 // =====================================================================================================================================
+#ifndef T2N_ACC_CG8
+#define T2N_ACC_CG8 1
+#endif
 #ifndef T2N_SEED_AFTER_MARCH
 #define T2N_SEED_AFTER_MARCH 1
 #endif
@@ -1731,17 +1736,20 @@ static int train_ensure(t2n_field* f, hipStream_t s) {
     }
     auto mk_stream = [](void** st) -> int { if (!*st) { hipStream_t x; T2N_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking)); *st = (void*)x; } return T2N_OK; };
     int rc;
-    if ((rc = mk_stream(&f->side_stream)) || (rc = mk_stream(&f->gemm_stream)) || (rc = mk_stream(&f->bin_stream)) || (rc = mk_stream(&f->early_stream))) return rc;
+    if ((rc = mk_stream(&f->side_stream)) || (rc = mk_stream(&f->gemm_stream))) return rc;
     for (auto& e : f->train_ev) if (!e) { hipEvent_t x; T2N_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming)); e = (void*)x; }
     if (!f->ev_den) { hipEvent_t e; T2N_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); f->ev_den = (void*)e; }
     return T2N_OK;
 }
 // the backward chain's transposed split-f16 operands + the forward's packed head operands from the CURRENT head weights
-static int train_repack(t2n_field* f, const t2n_field_params* p, bool forward_too, hipStream_t s) {
+// (the forward pack reads every weight anyway: it leaves the four matrices' largest magnitudes in the chain pack's absmax words — zeroed
+// by the head Adam launch in front of it — so the chain pack is one short launch; a pack kernel that scanned the matrices itself took
+// 60-105 us at the end of the step's longest chain)
+static int train_repack(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
     int rc;
-    if (forward_too && (rc = launch_pack_mlp(f, p, s))) return rc;
     void* gpack = (char*)f->train_dev + 256;
-    if ((rc = mlp_bwd_ss_pack(f, gpack, s, false, true))) return rc;
+    if ((rc = launch_pack_mlp(f, p, s, (unsigned*)mlp_bwd_ss_absmax_words(gpack)))) return rc;
+    if ((rc = mlp_bwd_ss_pack(f, gpack, s, true, false, true))) return rc;
     f->train_packed = true;
     return T2N_OK;
 }
@@ -1810,7 +1818,11 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if ((rc = train_ensure(f, s))) return rc;
-    hipStream_t sa = (hipStream_t)f->side_stream, sg = (hipStream_t)f->gemm_stream, sb = (hipStream_t)f->bin_stream;
+    // three streams beside the caller's (one per hardware queue): sa = early part + TV seed + density scatter / Adam, sg = layer 2 +
+    // weight-gradient GEMMs + head step. (With separate streams for the plan / binning, the early part and the caller's batch copy, seven
+    // streams shared four queues: whichever chain landed behind the GEMM chain's queue waited for it — 0.86 or 0.99 ms per step depending
+    // on the order the streams had been created in.)
+    hipStream_t sa = (hipStream_t)f->side_stream, sg = (hipStream_t)f->gemm_stream, sb = sa;
     hipEvent_t* ev = (hipEvent_t*)f->train_ev;   // 0 begin, 1 seed, 2 march, 3 plan, 4 appbin, 5 bwd_march, 6 chain, 7 gemm-stream join, 8 loss
     TrainState* st = (TrainState*)f->train_dev;
     void* gpack = (char*)f->train_dev + 256;
@@ -1819,14 +1831,14 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
     // pipelined form: the early part of this step on `se`, beside the previous step's tail (see include/t2n.h)
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap_status);
-    const bool pipe = A->input_stream && do_grad && do_opt && A->workspace_bytes >= 2 * T.total && cap_status == hipStreamCaptureStatusNone;
+    const bool pipe = (A->flags & T2N_FLAG_PIPELINE) && A->host_batch && do_grad && do_opt && A->workspace_bytes >= 2 * T.total && cap_status == hipStreamCaptureStatusNone;
     const bool chain_prev = f->train_chain;               // the previous call was a full step of this form and left its density-Adam event
     f->train_chain = false;
     const unsigned par = f->train_calls & 1u;            // scalar slot (always alternates) and, pipelined, workspace half
     if (do_grad) f->train_calls++;
     const unsigned slot = do_grad ? par : ((f->train_calls - 1u) & 1u);   // an optimiser-only call takes the slot its gradient call wrote
     TrainScalars* sc = &st->sc[slot];
-    hipStream_t se = pipe ? (hipStream_t)f->early_stream : s;
+    hipStream_t se = pipe ? sa : s;     // (on sa the early part is ordered behind the previous step's density Adam by the stream itself)
     // the caller's tensors are the parameters from here on (the optimiser writes them; the packs read them)
     const t2n_field_params* P = &A->params;
     if (do_opt && (!P->basis_weight || !P->mlp_w0 || !P->mlp_b0 || !P->mlp_w1 || !P->mlp_b1 || !P->mlp_w2 || !P->mlp_b2)) { set_error("t2n_train_step: NULL head tensor"); return T2N_ERR_INVALID; }
@@ -1850,12 +1862,10 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
             f->train_packed = true;
         }
         T2N_HIP(hipEventRecord(ev[0], s));
-        if (A->input_stream && cap_status == hipStreamCaptureStatusNone) {
-            // the early part waits for the batch buffers and for the previous step's density Adam (first pipelined call: for `stream`);
-            // a call that cannot take the pipelined form (se == s) is simply ordered behind the batch copy
-            T2N_HIP(hipEventRecord(ev[10], (hipStream_t)A->input_stream));
-            T2N_HIP(hipStreamWaitEvent(se, ev[10], 0));
-            if (pipe) T2N_HIP(hipStreamWaitEvent(se, chain_prev ? ev[9] : ev[0], 0));
+        if (pipe && !chain_prev) T2N_HIP(hipStreamWaitEvent(se, ev[0], 0));   // (the previous call left no density-Adam event on sa: behind `stream`)
+        if (A->host_batch) {
+            if (!A->batch_buffer || !A->host_batch_bytes) { set_error("t2n_train_step: host_batch without batch_buffer / host_batch_bytes"); return T2N_ERR_INVALID; }
+            T2N_HIP(hipMemcpyAsync(A->batch_buffer, A->host_batch, A->host_batch_bytes, hipMemcpyHostToDevice, se));
         }
         // ---- every zero fill of the step in one launch
         RenderLaunch L;
@@ -1916,7 +1926,9 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
         // beside the shade kernel (matrix cores + LDS) rather than beside the march (gathers: the two slow each other by a third)
         T2N_HIP(hipStreamWaitEvent(sa, ev[0], 0));     // (behind the previous step's Adam: it read this buffer and wrote the factors)
         if (T2N_SEED_AFTER_MARCH) T2N_HIP(hipStreamWaitEvent(sa, ev[2], 0));
+        timing_begin(f, T2N_K_TV_SEED, sa);
         if ((rc = launch_tv_seed_dev(f, A->hyper + 19, sa))) return rc;
+        timing_end(f, T2N_K_TV_SEED, sa);
         T2N_HIP(hipEventRecord(ev[1], sa));
         // ---- backward: per-ray pass
         float* x144 = (float*)(fw + kr.x144); float* feat32 = (float*)(fw + kr.feat32); float* h0 = (float*)(fw + kr.h0); float* h1 = (float*)(fw + kr.h1);
@@ -1940,19 +1952,24 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
             a.gfeat = (float*)(fw + c.sigma); a.hist = (unsigned*)(bw + b.hist); a.geom = bgeom;
             const size_t lds = (size_t)4 * 4 * a.npad * sizeof(float);
             const unsigned nb = (unsigned)((R + 3) / 4);
+            timing_begin(f, T2N_K_BWD_MARCH, s);
             hipLaunchKernelGGL((k_bwd_march<true, true, true>), dim3(nb), dim3(256), lds, s, a);
+            timing_end(f, T2N_K_BWD_MARCH, s);
             T2N_HIP(hipEventRecord(ev[5], s));
         }
         float* hg = A->head_grads;   // basis | w0 | b0 | w1 | b1 | w2 | b2
         float* g_basis = hg; float* g_w0 = g_basis + 27 * 144; float* g_b0 = g_w0 + 128 * 351; float* g_w1 = g_b0 + 128; float* g_b1 = g_w1 + 128 * 128;
         float* g_w2 = g_b1 + 128; float* g_b2 = g_w2 + 3 * 128;
         // ---- the input-gradient chain
+        timing_begin(f, T2N_K_BWD_MLP, s);
         if ((rc = launch_mlp_bwd_ss(f, gpack, (const float4*)go, h1, h0, feat32, G0, GF, GX, rows, s, true, rows_dev, G1))) return rc;
+        timing_end(f, T2N_K_BWD_MLP, s);
         T2N_HIP(hipEventRecord(ev[6], s));
         {
             const unsigned nb = (unsigned)((R + 3) / 4);
             // ---- sa: density scatter (behind the TV seed on the same stream)
             T2N_HIP(hipStreamWaitEvent(sa, ev[5], 0));
+            timing_begin(f, T2N_K_BWD_DENSITY, sa);
             launch_bin_scan((unsigned*)(bw + b.hist), bgeom.total, bgeom.copies, (unsigned*)(bw + b.bin_total), (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, kDenSeg,
                             0u, kDenSeg, sa);
             BinArgs ba;
@@ -1963,17 +1980,20 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
             da.S = f->dev.den; for (int k = 0; k < 3; ++k) { da.G.plane[k] = f->gbuf_den_plane[k]; da.G.line[k] = f->gbuf_den_line[k]; } da.geom = bgeom; da.segs = (const int4*)(bw + b.segs);
             da.nseg = (const unsigned*)(bw + b.nseg); da.recs = (const float4*)(bw + b.recs);
             hipLaunchKernelGGL(k_bwd_den_block, dim3(b.seg_cap < kAccGrid ? b.seg_cap : kAccGrid), dim3(kDenThreads), 0, sa, da);
+            timing_end(f, T2N_K_BWD_DENSITY, sa);
             T2N_HIP(hipEventRecord((hipEvent_t)f->ev_den, sa));
-                }
+        }
         // ---- sg: layer 2's weight gradient needs go and the kept h1 only (the chain writes g1 elsewhere in this form)
         T2N_HIP(hipStreamWaitEvent(sg, ev[5], 0));
         const WgradRegions WR = wgrad_regions(rows, 351);
         launch_bwd_l2((const float4*)go, (const float*)h1, rows, f->params_ref.mlp_w2, nullptr, nullptr, nullptr, (float*)((char*)part + WR.l2), sg, rows_dev);
         T2N_HIP(hipStreamWaitEvent(sg, ev[6], 0));
+        timing_begin(f, T2N_K_BWD_WGRAD, sg);
         launch_gemm_tn(4, false, G1, 128, h0, 128, rows, 128, 128, g_w1, 128, (float*)((char*)part + WR.tn[0]), sg, nullptr, g_b1, rows_dev, false);
         launch_gemm_tn(4, false, G0, 128, xpe, 352, rows, 128, 351, g_w0, 351, (float*)((char*)part + WR.tn[1]), sg, feat32, g_b0, rows_dev, false);
         launch_gemm_tn(1, false, GF, 32, x144, 144, rows, 27, 144, g_basis, 144, (float*)((char*)part + WR.tn[2]), sg, nullptr, nullptr, rows_dev, false);
         launch_wgrad_reduce((const char*)part, rows, g_w2, g_b2, g_w1, g_w0, g_basis, sg, (const float*)(ws + T.part), R, A->w_depth, A->w_trans, A->losses);
+        timing_end(f, T2N_K_BWD_WGRAD, sg);
         // ---- appearance scatter: records binned on sb, gradient buffer seeded on sa
         T2N_HIP(hipStreamWaitEvent(s, ev[4], 0));
         T2N_HIP(hipStreamWaitEvent(s, ev[1], 0));
@@ -1983,8 +2003,18 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
             ta.nseg = (const unsigned*)(bw + b.a_nseg); ta.recs = (const float4*)(bw + b.a_recs);
             ta.gx = GX; ta.gx_ld = 144;
             static bool attr_set = false;
-            if (!attr_set) { T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
-            hipLaunchKernelGGL((k_bwd_tile_accum<48>), dim3(b.a_seg_cap < kAccGrid ? b.a_seg_cap : kAccGrid, 3), dim3(kAccThreads), lds_acc, s, ta);
+            if (!attr_set) {
+                T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                T2N_HIP(hipFuncSetAttribute((const void*)k_bwd_tile_accum<48, 8, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                attr_set = true;
+            }
+            const size_t lds8 = tile_accum_lds(8, Lmax, 256);
+            timing_begin(f, T2N_K_BWD_SCATTER, s);
+            if (T2N_ACC_CG8 && lds8 <= 80 * 1024)   // two workgroups per CU: one accumulates while the other stages / zeroes / flushes
+                hipLaunchKernelGGL((k_bwd_tile_accum<48, 8, 256>), dim3(b.a_seg_cap < kAccGrid ? b.a_seg_cap : kAccGrid, 6), dim3(256), lds8, s, ta);
+            else
+                hipLaunchKernelGGL((k_bwd_tile_accum<48>), dim3(b.a_seg_cap < kAccGrid ? b.a_seg_cap : kAccGrid, 3), dim3(kAccThreads), lds_acc, s, ta);
+            timing_end(f, T2N_K_BWD_SCATTER, s);
         }
         T2N_HIP(hipGetLastError());
         if (!do_opt) {   // gradients final on `s`: join both side chains
@@ -2001,7 +2031,8 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
     }
     // ---- optimiser. sg: Adam on the seven head tensors, then every packed form of the new head weights (the forward's fp32 and
     // split-f16 operands, the backward chain's transposed ones) beside the factor tensors' Adam on `s`
-    if ((rc = launch_head_adam_dev(P, A->head_grads, A->exp_avg + 12, A->exp_avg_sq + 12, A->beta1, A->beta2, A->eps, sc, sg, true))) return rc;
+    timing_begin(f, T2N_K_HEAD_STEP, sg);
+    if ((rc = launch_head_adam_dev(P, A->head_grads, A->exp_avg + 12, A->exp_avg_sq + 12, A->beta1, A->beta2, A->eps, sc, sg, true, (unsigned*)mlp_bwd_ss_absmax_words(gpack)))) return rc;
     f->params_ref.basis_weight = P->basis_weight;
     f->params_ref.mlp_w0 = P->mlp_w0; f->params_ref.mlp_b0 = P->mlp_b0; f->params_ref.mlp_w1 = P->mlp_w1; f->params_ref.mlp_b1 = P->mlp_b1;
     f->params_ref.mlp_w2 = P->mlp_w2; f->params_ref.mlp_b2 = P->mlp_b2;
@@ -2009,15 +2040,18 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
         f->params_ref.density_plane[k] = P->density_plane[k]; f->params_ref.density_line[k] = P->density_line[k];
         f->params_ref.app_plane[k] = P->app_plane[k]; f->params_ref.app_line[k] = P->app_line[k];
     }
-    if ((rc = train_repack(f, P, true, sg))) return rc;
+    if ((rc = train_repack(f, P, sg))) return rc;
     f->ss_dirty = true;
+    timing_end(f, T2N_K_HEAD_STEP, sg);
     T2N_HIP(hipEventRecord(ev[7], sg));
     if (do_grad) {
         // the density factors (a quarter of the bytes) step on sa right behind their scatter, beside the appearance scatter on `s`
         if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, sc, 0, 6, sa))) return rc;
         T2N_HIP(hipEventRecord(ev[9], sa));
         f->train_chain = true;      // (the next call's early part may start behind this event)
+        timing_begin(f, T2N_K_ADAM, s);
         if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, sc, 6, 6, s))) return rc;
+        timing_end(f, T2N_K_ADAM, s);
         T2N_HIP(hipStreamWaitEvent(s, ev[9], 0));
     } else if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, sc, 0, 12, s))) return rc;
     T2N_HIP(hipStreamWaitEvent(s, ev[7], 0));

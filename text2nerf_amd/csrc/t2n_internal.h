@@ -157,7 +157,7 @@ void timing_end(t2n_field* f, int k, hipStream_t s);
 
 // launchers implemented per translation unit
 int launch_relayout(t2n_field* f, const t2n_field_params* p, hipStream_t s);
-int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s);
+int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s, unsigned* absmax_out = nullptr);   // absmax_out: 4 zeroed words, see PackArgs
 
 struct RenderLaunch {
     const float* rays; int64_t n_rays; int ray_stride; int n_samples; uint32_t flags;
@@ -268,14 +268,14 @@ size_t mlp_bwd_ss_pack_bytes();
 int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, const float* h0, const float* feat, float* g0, float* gf,
                       float* gx, long long rows, hipStream_t s, bool packed = false, const unsigned* rows_dev = nullptr,
                       float* g1_out = nullptr);   // g1_out: g1 written there instead of over h1 (h1 stays intact for a concurrent k_bwd_l2)
-int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed, bool one_launch = false);   // one_launch: the pack kernel finds the matrices' largest magnitudes itself
+int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed, bool one_launch = false, bool absmax_done = false);   // one_launch: the pack kernel finds the matrices' largest magnitudes itself
 void* mlp_bwd_ss_absmax_words(void* packbuf);
 // the fused training step's optimiser launches (t2n_optim.hip): scalars / TV weights / verdict from device memory
 int launch_tv_seed_dev(t2n_field* f, const float* tvw_dev, hipStream_t s);
 int launch_factor_adam_dev(t2n_field* f, const t2n_field_params* params, float* const* m, float* const* v, float beta1, float beta2, float eps,
                            const TrainScalars* st, int first, int count, hipStream_t s);
 int launch_head_adam_dev(const t2n_field_params* params, const float* grads_flat, float* const* m, float* const* v, float beta1, float beta2,
-                         float eps, const TrainScalars* st, hipStream_t s, bool zero_grads = false);
+                         float eps, const TrainScalars* st, hipStream_t s, bool zero_grads = false, unsigned* zero_words4 = nullptr);
 // the driver's loss (t2n_loss.hip); reduce = false leaves the per-workgroup partial sums [ceil(n_rays / 4)][3] in `part`
 int launch_train_loss(const float* rgb, const float* depth, const float* weights, const float* z_vals, const float* rgb_t, const float* depth_t,
                       int64_t n_rays, int n_samples, float w_depth, float w_trans, float delta, float* d_rgb, float* d_depth, float* d_weights,

@@ -478,7 +478,7 @@ void* mlp_bwd_ss_absmax_words(void* packbuf) {
 // The transposed split-f16 operands of the chain from the CURRENT weights: two small launches that depend on nothing but the parameters —
 // the backward runs them before it forks its side streams (queued behind the density scatter's workgroups, the 6-us pack kernel sat
 // 50 us on the critical path in front of k_mlp_bwd_ss).
-int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed, bool one_launch) {
+int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed, bool one_launch, bool absmax_done) {
     using namespace bss;
     const t2n_field_params& p = f->params_ref;
     uint4* base = (uint4*)packbuf;
@@ -489,6 +489,11 @@ int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed, boo
     pa.absmax = am; pa.scales = (float*)(am + 4);
     if (one_launch) {
         hipLaunchKernelGGL(k_pack_bwd_ss<true>, dim3(64), dim3(256), 0, s, pa);
+        T2N_HIP(hipGetLastError());
+        return T2N_OK;
+    }
+    if (absmax_done) {   // the caller's previous launch left the absmax words (launch_pack_mlp)
+        hipLaunchKernelGGL(k_pack_bwd_ss<false>, dim3(64), dim3(256), 0, s, pa);
         T2N_HIP(hipGetLastError());
         return T2N_OK;
     }

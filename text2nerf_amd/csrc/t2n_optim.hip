@@ -82,9 +82,10 @@ struct AdamMulti {
     float lr_over_bc1[kAdamMaxTensors], inv_bc2_sqrt[kAdamMaxTensors];
     int count; float beta1, beta2, eps;
     // fused training step: scalars and the step's verdict from device memory (tensor t <-> st->lr_over_bc1[st_first + t]); NULL: by value
-    const TrainScalars* st; int st_first; int zero_grads;   // zero_grads: the consumed gradient is set to zero (the next step accumulates into it)
+    const TrainScalars* st; int st_first; int zero_grads; unsigned* zero_words4;   // zero_words4: four words cleared by the launch (the next launch's absmax accumulators)   // zero_grads: the consumed gradient is set to zero (the next step accumulates into it)
 };
 __global__ __launch_bounds__(256) void k_adam_multi(const AdamMulti a) {
+    if (a.zero_words4 && blockIdx.x == 0 && threadIdx.x < 4) a.zero_words4[threadIdx.x] = 0u;
     int t = 0;
 #pragma unroll 1
     for (int q = 1; q < a.count; ++q) t += (a.block0[q] <= blockIdx.x) ? 1 : 0;
@@ -134,6 +135,25 @@ __device__ __forceinline__ void tv_grad_cl_body(const float* __restrict__ x, flo
     float4 gv = G[t];
     gv.x += acc.x; gv.y += acc.y; gv.z += acc.z; gv.w += acc.w;
     G[t] = gv;
+}
+
+// the same stencil with 32-bit index arithmetic (a factor tensor has < 2^31 float4 elements; checked by the launcher): the 64-bit
+// divisions of the form above are ~150 of the seed kernel's instructions per thread, on a kernel that moves 32 bytes per thread
+__device__ __forceinline__ void tv_seed_cl_body32(const float* __restrict__ x, float* __restrict__ g, unsigned t, unsigned C4, unsigned H, unsigned W, float sh,
+                                                  float sw) {
+    const unsigned n = H * W * C4;
+    if (t >= n) return;
+    const unsigned pos = C4 == 4u ? (t >> 2) : (C4 == 12u ? t / 12u : t / C4);
+    const unsigned h = pos / W, w = pos - h * W;
+    const float4* __restrict__ X = reinterpret_cast<const float4*>(x);
+    const float4 v = X[t];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned row = W * C4;
+    if (h > 0) { const float4 u = X[t - row]; acc.x += sh * (2.f * (v.x - u.x)); acc.y += sh * (2.f * (v.y - u.y)); acc.z += sh * (2.f * (v.z - u.z)); acc.w += sh * (2.f * (v.w - u.w)); }
+    if (h < H - 1) { const float4 d = X[t + row]; acc.x -= sh * (2.f * (d.x - v.x)); acc.y -= sh * (2.f * (d.y - v.y)); acc.z -= sh * (2.f * (d.z - v.z)); acc.w -= sh * (2.f * (d.w - v.w)); }
+    if (w > 0) { const float4 l = X[t - C4]; acc.x += sw * (2.f * (v.x - l.x)); acc.y += sw * (2.f * (v.y - l.y)); acc.z += sw * (2.f * (v.z - l.z)); acc.w += sw * (2.f * (v.w - l.w)); }
+    if (w < W - 1) { const float4 r = X[t + C4]; acc.x -= sw * (2.f * (r.x - v.x)); acc.y -= sw * (2.f * (r.y - v.y)); acc.z -= sw * (2.f * (r.z - v.z)); acc.w -= sw * (2.f * (r.w - v.w)); }
+    reinterpret_cast<float4*>(g)[t] = acc;
 }
 
 __device__ __forceinline__ float adam_one(float p, float gi, float& m, float& v, float lr_over_bc1, float beta1, float beta2, float eps,
@@ -199,7 +219,8 @@ __global__ __launch_bounds__(256) void k_tv_seed_cl_multi(const FactorStep a) {
     int t = 0;
 #pragma unroll 1
     for (int q = 1; q < 12; ++q) t += (a.tblock0[q] <= blockIdx.x) ? 1 : 0;
-    const long long i = (long long)(blockIdx.x - a.tblock0[t]) * 256 + threadIdx.x;
+    const unsigned i32 = (blockIdx.x - a.tblock0[t]) * 256u + threadIdx.x;
+    const long long i = (long long)i32;
     float sh = a.sh[t], sw = a.sw[t];
     if (a.tvw_dev) {   // the host's expressions (t2n_field_tv_seed), on this step's weights; planes only (t = 0..2 density, 6..8 appearance)
         const float tvw = t < 3 ? a.tvw_dev[0] : ((t >= 6 && t < 9) ? a.tvw_dev[1] : 0.f);
@@ -207,7 +228,7 @@ __global__ __launch_bounds__(256) void k_tv_seed_cl_multi(const FactorStep a) {
         sh = tvw != 0.f ? tvw * 2.f / ((float)C * (float)(H - 1) * (float)W) : 0.f;
         sw = tvw != 0.f ? tvw * 2.f / ((float)C * (float)H * (float)(W - 1)) : 0.f;
     }
-    if (sh != 0.f || sw != 0.f) tv_grad_cl_body<true>(a.p[t], a.g[t], i, a.C[t] / 4, a.H[t], a.W[t], sh, sw);
+    if (sh != 0.f || sw != 0.f) tv_seed_cl_body32(a.p[t], a.g[t], i32, (unsigned)a.C[t] / 4u, (unsigned)a.H[t], (unsigned)a.W[t], sh, sw);
     else if (i < a.npos[t] * (a.C[t] / 4)) reinterpret_cast<float4*>(a.g[t])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __global__ __launch_bounds__(256) void k_adam_cl_multi(const FactorStep a) {
@@ -380,7 +401,7 @@ int launch_factor_adam_dev(t2n_field* f, const t2n_field_params* params, float* 
 }
 // Adam on the seven head tensors (reference layout; gradients contiguous in `grads_flat`, parameter order)
 int launch_head_adam_dev(const t2n_field_params* params, const float* grads_flat, float* const* m, float* const* v, float beta1, float beta2,
-                         float eps, const TrainScalars* st, hipStream_t s, bool zero_grads) {
+                         float eps, const TrainScalars* st, hipStream_t s, bool zero_grads, unsigned* zero_words4) {
     AdamMulti a;
     memset(&a, 0, sizeof(a));
     float* ps[7] = {(float*)params->basis_weight, (float*)params->mlp_w0, (float*)params->mlp_b0, (float*)params->mlp_w1, (float*)params->mlp_b1,
@@ -396,7 +417,7 @@ int launch_head_adam_dev(const t2n_field_params* params, const float* grads_flat
         off += n[i];
     }
     a.block0[7] = blocks;
-    a.count = 7; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.st = st; a.st_first = 12; a.zero_grads = zero_grads ? 1 : 0;
+    a.count = 7; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.st = st; a.st_first = 12; a.zero_grads = zero_grads ? 1 : 0; a.zero_words4 = zero_words4;
     hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, s, a);
     T2N_HIP(hipGetLastError());
     return T2N_OK;

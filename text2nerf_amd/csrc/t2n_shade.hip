@@ -1418,7 +1418,17 @@ struct PackArgs {
     float* basisA; float* w0A; float* w1A; float* w2A;
     int app_dim, has_mlp;
     unsigned* clear_word;   // the split packing's range flag, cleared here (k_pack_mlp_h, the next launch, ORs into it)
+    // optional (fused training step): max |w| of w2 / w1 / w0 / basis_mat as float bit patterns, atomicMax'ed into absmax[0..3] (zeroed
+    // by the launch in front of this one): what the backward chain's operand pack scales by — this kernel reads every weight anyway
+    unsigned* absmax;
 };
+__device__ __forceinline__ void pack_absmax(const PackArgs& a, int idx, float v) {
+    if (!a.absmax) return;
+    unsigned m = __float_as_uint(v) & 0x7fffffffu;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&a.absmax[idx], m);
+}
 
 __global__ __launch_bounds__(256) void k_pack_mlp(const PackArgs a) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1426,7 +1436,9 @@ __global__ __launch_bounds__(256) void k_pack_mlp(const PackArgs a) {
     const int nb = kBasisSteps * 64, n0 = kL0Steps * 256, n1 = kL1Steps * 256, n2 = kL2Steps * 64;
     if (gid < nb) {
         const int t = gid / 64, l = gid % 64, i = l & 31, h = l >> 5;
-        a.basisA[gid] = (t < kBasisReal && i < a.app_dim) ? a.basis[i * kAppK + 2 * t + h] : 0.f;
+        const float v = (t < kBasisReal && i < a.app_dim) ? a.basis[i * kAppK + 2 * t + h] : 0.f;
+        a.basisA[gid] = v;
+        pack_absmax(a, 3, v);
         return;
     }
     if (!a.has_mlp) return;
@@ -1446,6 +1458,7 @@ __global__ __launch_bounds__(256) void k_pack_mlp(const PackArgs a) {
             v = h == 0 ? a.b0[out] : 0.f;
         }
         a.w0A[g] = v;
+        pack_absmax(a, 2, t == kL0Real - 1 ? 0.f : v);    // (the bias step is not part of the matrix)
         return;
     }
     g -= n0;
@@ -1456,6 +1469,7 @@ __global__ __launch_bounds__(256) void k_pack_mlp(const PackArgs a) {
         if (t < 64) v = a.w1[out * 128 + 2 * t + h];
         else if (t == 64) v = h == 0 ? a.b1[out] : 0.f;
         a.w1A[g] = v;
+        pack_absmax(a, 1, t == 64 ? 0.f : v);
         return;
     }
     g -= n1;
@@ -1467,6 +1481,7 @@ __global__ __launch_bounds__(256) void k_pack_mlp(const PackArgs a) {
             else if (t == 64) v = h == 0 ? a.b2[i] : 0.f;
         }
         a.w2A[g] = v;
+        pack_absmax(a, 0, t == 64 ? 0.f : v);
     }
 }
 
@@ -1546,7 +1561,7 @@ __global__ __launch_bounds__(256) void k_pack_mlp_h(const PackHArgs a) {
     }
 }
 
-int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
+int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s, unsigned* absmax_out) {
     const size_t nb = (size_t)kBasisSteps * 64, n0 = (size_t)kL0Steps * 256, n1 = (size_t)kL1Steps * 256, n2 = (size_t)kL2Steps * 64;
     if (!f->buf_mlp) {
         T2N_HIP(hipMalloc((void**)&f->buf_mlp, (nb + n0 + n1 + n2) * sizeof(float)));
@@ -1569,6 +1584,7 @@ int launch_pack_mlp(t2n_field* f, const t2n_field_params* p, hipStream_t s) {
     }
     _Float16* hbase = (_Float16*)f->buf_mlp_h;
     a.clear_word = (unsigned*)((float*)(hbase + hb + h0 + h1 + h2) + 288);
+    a.absmax = (a.has_mlp && f->desc.app_dim == 27) ? absmax_out : nullptr;
     hipLaunchKernelGGL(k_pack_mlp, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     T2N_HIP(hipGetLastError());
     PackHArgs ha;

@@ -57,7 +57,8 @@ class FusedStep:
         self.replays = 0
         self.copy_stream = None
         self.cap_once = 0
-        self.pipe_input = None          # stream the current batch was copied on, when this call may take the pipelined form
+        self.host_batch = None          # (pinned pointer, bytes) of the staged batch when the C call is to copy it
+        self.pipe_ok = False
         self.pipe_ws = False
         self.pipelined_launches = 0
         self.pipeline = True            # (False: always the serial form)
@@ -68,40 +69,79 @@ class FusedStep:
         self.graph_captures = 0
         self.eager_launches = 0
         self._handle_seen = None
+        self._mom_cache = None
+        self._arg_cache = {}
+        self._group_of = None
+        self._pin_np = [None] * _RING
+        self._ws_for = None
 
     # ---- optimiser state ------------------------------------------------------------------------------------------------------------
     def _moments(self):
         f, opt = self.field, self.opt
+        c = self._mom_cache
+        if c is not None:
+            # the host side of a 2 048-ray step is as long as its device side: the moment tensors are looked up once; a replaced optimiser
+            # state (load_state_dict) shows in the first / last entries
+            ps, ms, vs = c
+            st0, st18 = opt.state[ps[0]], opt.state[ps[18]]
+            if st0.get("exp_avg_cl") is ms[0] and st18.get("exp_avg") is ms[18] and st0["step"] == st18["step"]:
+                return ps, ms, vs, int(st0["step"])
         ps = f._all_params()
         ms, vs, steps = [], [], []
+        fresh = [i for i, p in enumerate(ps[:12]) if "exp_avg_cl" not in opt.state[p]]
+        pool = None
+        if len(fresh) == 12:
+            # a new optimiser: the 24 channel-last moment buffers of the factor tensors are slices of ONE allocation the field keeps across
+            # optimisers (zeroed here). Fresh allocations per optimiser land wherever the caching allocator has room, and the step time
+            # follows the placement: 0.86 against 0.99 ms per 16 384-ray step, alternating from one optimiser to the next (measured)
+            n = sum(p.numel() for p in ps[:12])
+            pool = f.__dict__.get("_fused_moments")
+            if pool is None or pool.numel() != 2 * n or pool.device != ps[0].device:
+                pool = f.__dict__["_fused_moments"] = torch.empty(2 * n, device=ps[0].device, dtype=torch.float32)
+            pool.zero_()
+        off = 0
         for i, p in enumerate(ps):
             st = opt.state[p]
             a, b = ("exp_avg_cl", "exp_avg_sq_cl") if i < 12 else ("exp_avg", "exp_avg_sq")
             if a not in st:
                 st.setdefault("step", 0)
-                st[a] = torch.zeros(p.numel(), device=p.device, dtype=torch.float32) if i < 12 else torch.zeros_like(p)
-                st[b] = torch.zeros(p.numel(), device=p.device, dtype=torch.float32) if i < 12 else torch.zeros_like(p)
+                if pool is not None and i < 12:
+                    st[a] = pool[off:off + p.numel()]
+                    st[b] = pool[pool.numel() // 2 + off:pool.numel() // 2 + off + p.numel()]
+                else:
+                    st[a] = torch.zeros(p.numel(), device=p.device, dtype=torch.float32) if i < 12 else torch.zeros_like(p)
+                    st[b] = torch.zeros(p.numel(), device=p.device, dtype=torch.float32) if i < 12 else torch.zeros_like(p)
+            if i < 12:
+                off += p.numel()
             ms.append(st[a]); vs.append(st[b]); steps.append(int(st["step"]))
         if len(set(steps)) != 1:
             raise T2NError("fused train step: the 19 tensors must share one Adam step count")
+        self._mom_cache = (ps, ms, vs)
+        self._arg_cache = {}
         return ps, ms, vs, steps[0]
 
     def _hyper(self, tv):
+        """The step's scalars as a list of TRAIN_HYPER_FLOATS floats (19 learning rates, the two TV weights x 1e-2), betas, eps."""
         f, opt = self.field, self.opt
-        lr_of = {id(p): float(g["lr"]) for g in opt.param_groups for p in g["params"]}
-        ps = f._all_params()
-        h = torch.zeros(_lib.TRAIN_HYPER_FLOATS)
-        for i, p in enumerate(ps):
-            if id(p) not in lr_of:
+        groups = opt.param_groups
+        gi = self._group_of
+        if gi is None or len(gi[1]) != len(groups):
+            where = {id(p): k for k, g in enumerate(groups) for p in g["params"]}
+            ps = f._all_params()
+            if any(id(p) not in where for p in ps):
                 raise T2NError("fused train step: every tensor of the field must be in a parameter group")
-            h[i] = lr_of[id(p)]
+            gi = self._group_of = ([where[id(p)] for p in ps], list(groups))
+        lrs = [float(g["lr"]) for g in groups]
+        h = [lrs[k] for k in gi[0]]
         tv_d, tv_a = f._tv_weights(tv)
-        h[19], h[20] = tv_d, tv_a
-        g0 = opt.param_groups[0]
-        for g in opt.param_groups:
-            if tuple(g["betas"]) != tuple(g0["betas"]) or float(g["eps"]) != float(g0["eps"]):
-                raise T2NError("fused train step: all parameter groups must share betas and eps")
-        return h, tuple(float(b) for b in g0["betas"]), float(g0["eps"])
+        h += [tv_d, tv_a] + [0.0] * (_lib.TRAIN_HYPER_FLOATS - 21)
+        g0 = groups[0]
+        b0, e0 = g0["betas"], g0["eps"]
+        for g in groups:
+            if g["betas"] != b0 or g["eps"] != e0:
+                if tuple(g["betas"]) != tuple(b0) or float(g["eps"]) != float(e0):
+                    raise T2NError("fused train step: all parameter groups must share betas and eps")
+        return h, (float(b0[0]), float(b0[1])), float(e0)
 
     # ---- the device's record ----------------------------------------------------------------------------------------------------------
     def _poll(self):
@@ -132,7 +172,7 @@ class FusedStep:
             self.seen += 1
         if self.needs:
             want = _ladder(int(max(self.needs) * self.margin) + 64)
-            if want > self.rows_cap or want < self.rows_cap // 2:
+            if want > self.rows_cap or want < int(self.rows_cap * 0.8):     # (grids and zero fills scale with the capacity: follow it down too)
                 self.rows_cap = want
 
     def sync(self):
@@ -147,7 +187,10 @@ class FusedStep:
 
     # ---- submission -------------------------------------------------------------------------------------------------------------------
     def _workspace(self, R, N, cap):
+        if self.ws is not None and self._ws_for == (R, N, cap, self.field._handle.value):
+            return self.ws
         lib = _lib.load()
+        self._ws_for = (R, N, cap, self.field._handle.value)
         need = int(lib.t2n_train_step_workspace_bytes(self.field._handle, R, N, cap))
         if need == 0:
             raise T2NError("t2n_train_step_workspace_bytes: bad shape")
@@ -156,13 +199,17 @@ class FusedStep:
         self.pipe_ws = need <= PIPELINE_MAX_BYTES
         if self.pipe_ws:
             need *= 2
+        if self.ws is None:
+            self.ws = self.field.__dict__.get("_fused_ws")     # (the field keeps ONE such buffer: a new optimiser / driver takes it over)
+            if self.ws is not None and self.ws.device != self.dev:
+                self.ws = None
         if self.ws is None or self.ws.numel() < need:
             had = self.ws is not None
-            self.ws = None
+            self.ws = self.field.__dict__["_fused_ws"] = None
             self._drop_graphs()
             if had:
                 torch.cuda.empty_cache()
-            self.ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            self.ws = self.field.__dict__["_fused_ws"] = torch.empty(need, dtype=torch.uint8, device=self.dev)
         return self.ws
 
     def _drop_graphs(self):
@@ -181,6 +228,14 @@ class FusedStep:
         f = self.field
         ps, ms, vs, _ = self._moments()
         buf = self.inbuf[slot_i]
+        ws = self._workspace(R, N, cap)
+        ck = (slot_i, R, stride, N, flags, phases, cap, betas, eps, w_depth, w_trans, delta, ws.data_ptr(), buf.data_ptr(), ps[0].data_ptr())
+        hit = self._arg_cache.get(ck)
+        if hit is not None:
+            hit[0].host_batch, hit[0].host_batch_bytes = None, 0
+            return hit
+        if len(self._arg_cache) > 64:
+            self._arg_cache.clear()
         a = _lib.TrainStepArgs()
         o = 0
         base = buf.data_ptr()
@@ -198,12 +253,12 @@ class FusedStep:
             a.exp_avg_sq[i] = vs[i].data_ptr()
         a.head_grads = self.head_grads.data_ptr()
         a.rows_capacity = cap
-        ws = self._workspace(R, N, cap)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         a.losses = self.losses.data_ptr()
-        a.input_stream = None
+        a.host_batch, a.host_batch_bytes, a.batch_buffer = None, 0, buf.data_ptr()
         key = (R, stride, N, flags, phases, cap, betas, eps, w_depth, w_trans, delta, ws.data_ptr(), buf.data_ptr(),
                tuple(p.data_ptr() for p in ps), tuple(t.data_ptr() for t in ms), tuple(t.data_ptr() for t in vs))
+        self._arg_cache[ck] = (a, key)
         return a, key
 
     def _launch(self, slot_i, a, key, graph, m=None):
@@ -231,20 +286,26 @@ class FusedStep:
                 _lib.check(lib.t2n_train_graph_launch(g, st), "t2n_train_graph_launch")
                 self.graph_launches += 1
             else:
-                if self.pipe_input is not None and self.pipe_ws and int(a.phases) == 3:
-                    a.input_stream = self.pipe_input       # (eager, full step: the early part may run beside the previous step's tail)
-                    self.pipelined_launches += 1
+                if self.host_batch is not None:
+                    a.host_batch, a.host_batch_bytes = self.host_batch     # (the C call copies the batch; pipelined form when it may)
+                    a.flags = int(a.flags) & ~_lib.FLAG_PIPELINE
+                    if self.pipe_ok and self.pipe_ws and int(a.phases) == 3:
+                        a.flags = int(a.flags) | _lib.FLAG_PIPELINE
+                        self.pipelined_launches += 1
                 _lib.check(lib.t2n_train_step(f._handle, C.byref(a), st), "t2n_train_step")
                 self.eager_launches += 1
 
     def _after_update(self):
         """The C call changed all 19 tensors in place (and left the device copies / packed operands current)."""
-        from .optim import _bump_version
         f = self.field
-        ps = f._all_params()
-        for p in ps:
-            _bump_version(p)
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        ps = self._mom_cache[0] if self._mom_cache is not None else f._all_params()
+        try:
+            torch._C._increment_version(ps)
+        except Exception:
+            from .optim import _bump_version
+            for p in ps:
+                _bump_version(p)
+        key = tuple([(p.data_ptr(), p._version) for p in ps])
         f._uploaded_key = key
         f._device_factor_key = key[:12]
         f._gbuf_dirty = True
@@ -335,12 +396,19 @@ class FusedStep:
             self._drain_queue()
         hyper, betas, eps = self._hyper(tv)
         n_in = R * stride + R + 3 * R + R + _lib.TRAIN_HYPER_FLOATS
-        self._ensure_inbuf(i, n_in)
+        for j in range(_RING):          # (all four slots at once: a pinned allocation inside somebody's timed loop costs a millisecond)
+            self._ensure_inbuf(j, n_in)
         buf, pin = self.inbuf[i], self.pinned[i]
         jitter = torch.rand(R, 1)      # CPU default generator, one draw per ray: models/tensorBase.py:313-317
-        pieces = [(rays, R * stride), (jitter, R), (rgb_t, 3 * R), (dep_t, R), (hyper, _lib.TRAIN_HYPER_FLOATS)]
+        if self._pin_np[i] is None or self._pin_np[i].shape[0] != n_in:
+            self._pin_np[i] = pin.numpy()
+        o_h = n_in - _lib.TRAIN_HYPER_FLOATS
+        self._pin_np[i][o_h:] = hyper
+        pieces = [(rays, R * stride), (jitter, R), (rgb_t, 3 * R), (dep_t, R)]
         o = 0
         on_host = all(t.device.type == "cpu" for t, _ in pieces)
+        if not on_host:
+            buf[o_h:].copy_(pin[o_h:], non_blocking=True)
         for t, n in pieces:
             if t.numel() != n:
                 raise T2NError(f"fused train step: batch tensor of {t.numel()} elements where {n} are expected")
@@ -351,27 +419,16 @@ class FusedStep:
             else:
                 buf[o:o + n].copy_(t.reshape(-1).float(), non_blocking=True)
             o += n
-        if on_host:
-            # the one host -> device copy of the step, on a stream of its own: it runs while the previous step is still executing (the input
-            # buffers form a ring) instead of between two steps
-            cur = torch.cuda.current_stream(self.dev)
-            cs = self.copy_stream
-            if cs is None:
-                cs = self.copy_stream = torch.cuda.Stream(device=self.dev)
-            if self.slot_done[i] is not None:
-                cs.wait_event(self.slot_done[i])       # the step that read this buffer last
-            with torch.cuda.stream(cs):
-                buf.copy_(pin, non_blocking=True)
-            # nobody touched the field since this driver's last step: the C call may start the step's early part (march, plan, binning)
-            # on its own stream behind the copy — beside the previous step's tail — instead of behind the whole previous step
-            self.pipe_input = C.c_void_p(cs.cuda_stream) if (self.pipeline and untouched and not graph and all_reduce is None) else None
-            if self.pipe_input is None:
-                cur.wait_event(cs.record_event())
-        else:
-            self.pipe_input = None
+        # all on the host: the C call copies the staged batch itself — on its side stream, beside the previous step's tail, when nobody has
+        # touched the field since this driver's last step (pipelined form, include/t2n.h); else in front of the step on the current stream
+        self.host_batch = (C.c_void_p(pin.data_ptr()), n_in * 4) if on_host else None
+        self.pipe_ok = bool(on_host and self.pipeline and untouched and not graph and all_reduce is None)
+        if on_host and (graph or all_reduce is not None or not self.pipeline):
+            buf.copy_(pin, non_blocking=True)
+            self.host_batch = None
         meta = dict(R=R, stride=stride, N=N, flags=flags, betas=betas, eps=eps, w_depth=float(w_depth), w_trans=float(w_trans), delta=float(delta))
         self._submit(i, meta, graph, all_reduce)
-        self.pipe_input = None
+        self.host_batch = None
         self._key_after = f._uploaded_key
         f.device_rows_steps = getattr(f, "device_rows_steps", 0) + 1
         ev = torch.cuda.Event()
