@@ -352,8 +352,10 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
                                              "cross PCIe"}
     if fused_step:
         # kernel groups of one fused iteration (HIP events on the launch streams, a short pass of its own: the brackets cost the
-        # streams a few us each) and what bounds the largest of them
+        # streams a few us each) and what bounds the largest of them. In the one-call form (t2n_train_step) the groups run side by side on
+        # four streams: each figure is the group's own start-to-end time UNDER that concurrency, their sum exceeds the step
         kt, roofs = {}, {}
+        fs = field.__dict__.get("_fused_step") if step_kw.get("fused", True) is not False else None
         try:
             field.timing(True)
             field.read_timing(reset=True)
@@ -361,31 +363,69 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
             for k in range(n_t):
                 it(warmup + iters + k)
             torch.cuda.synchronize()
-            kt = {k: v[0] / n_t for k, v in field.read_timing(reset=True).items()}
+            kt = {k: round(v[0] / n_t, 5) for k, v in field.read_timing(reset=True).items()}
             field.timing(False)
-            A = field.stats()["appearance"]
+            # sample counts of one such batch (a train-mode render of its own: the one-call step keeps no statistics)
+            with torch.no_grad():
+                b_rays = allrays[idx_of(warmup + iters)]
+                torch.manual_seed(7)
+                field(b_rays.to(dev), white_bg=True, is_train=True, N_samples=n_samples)
+            st_ = field.stats()
+            A, V = st_["appearance"], st_["evaluated"]
+            lds_peak = 256 * 64 / 9.0 * 2.1e9     # a CU retires one wave-wide ds_add_f64 per ~9 clocks (tools/experiments/lds_atomic_bench.hip)
             if kt.get("bwd_scatter"):
-                # appearance scatter (k_app_bin + scan + k_bwd_tile_accum<48>): per appearance row and plane 48 channels x (4 plane + 2 line
-                # taps) double-precision LDS atomics; a CU retires one wave-wide ds_add_f64 per ~9 clocks (tools/experiments/lds_atomic_bench.hip)
+                # appearance scatter (k_bwd_tile_accum<48> [+ its binning in the composed form]): per appearance row and plane 48 channels x
+                # (4 plane + 2 line taps) double-precision LDS atomics
                 atom = A * 3 * 48 * 6
-                peak = 256 * 64 / 9.0 * 2.1e9
-                roofs["bwd_scatter"] = {"bound": "lds-f64-atomics", "kernel": "k_bwd_tile_accum<48> (+ binning)", "unit": "G lane-atomics/s",
-                                        "achieved": atom / (kt["bwd_scatter"] * 1e-3) / 1e9, "peak": peak / 1e9,
-                                        "frac": atom / (kt["bwd_scatter"] * 1e-3) / peak, "ms_per_iter": kt["bwd_scatter"]}
+                roofs["bwd_scatter"] = {"bound": "lds-f64-atomics", "kernel": "k_bwd_tile_accum<48>", "unit": "G lane-atomics/s",
+                                        "achieved": atom / (kt["bwd_scatter"] * 1e-3) / 1e9, "peak": lds_peak / 1e9,
+                                        "frac": atom / (kt["bwd_scatter"] * 1e-3) / lds_peak, "ms_per_iter": kt["bwd_scatter"]}
+            if kt.get("bwd_density"):
+                # density scatter (k_bin_reduce + k_bin_scan + k_bwd_bin + k_bwd_den_block): per evaluated sample ONE record, eight ds_add_f64
+                # (trilinear splat into the block's 16^3 corner field); the six contractions per block segment run on fp32 MFMA and are
+                # flushed with 13 824 global fp32 atomics per segment — the group is bound by that flush and by the binning passes, not by
+                # the LDS atomics this fraction prices
+                atom = V * 8
+                roofs["bwd_density"] = {"bound": "lds-f64-atomics", "kernel": "k_bwd_bin + k_bwd_den_block (+ scans)", "unit": "G lane-atomics/s",
+                                        "achieved": atom / (kt["bwd_density"] * 1e-3) / 1e9, "peak": lds_peak / 1e9,
+                                        "frac": atom / (kt["bwd_density"] * 1e-3) / lds_peak, "ms_per_iter": kt["bwd_density"],
+                                        "records_per_iter": V}
             if kt.get("bwd_mlp"):
-                # MLP backward: input-gradient chain (3 f16 products per fp32 product) + weight-gradient GEMMs (6 bf16 products): the
-                # reference's 2 x 2 x MACs per row, against the dense f16 peak
-                flop = 2.0 * 2.0 * (351 * 128 + 128 * 128 + 128 * 3 + 144 * 27) * A
-                roofs["bwd_mlp"] = {"bound": "mfma", "kernel": "k_mlp_bwd_ss + k_gemm_tn_b + k_bwd_l2", "unit": "TFLOP/s",
+                # input-gradient chain (k_mlp_bwd_ss; 3 f16 products per fp32 product) [+ the weight-gradient GEMMs in the composed form]:
+                # the reference's MACs per row against the dense f16 peak
+                both = "bwd_wgrad" not in kt
+                flop = (2.0 if both else 1.0) * 2.0 * (351 * 128 + 128 * 128 + 128 * 3 + 144 * 27) * A
+                roofs["bwd_mlp"] = {"bound": "mfma", "kernel": "k_mlp_bwd_ss" + (" + k_gemm_tn_b + k_bwd_l2" if both else ""), "unit": "TFLOP/s",
                                     "achieved": flop / (kt["bwd_mlp"] * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TF,
                                     "frac": flop / (kt["bwd_mlp"] * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, "ms_per_iter": kt["bwd_mlp"]}
+            if kt.get("bwd_wgrad"):
+                # weight-gradient GEMMs (k_gemm_tn_b x 2: six bf16 products per fp32 product; k_gemm_tn fp32; one reduce): VALU-bound on the
+                # operand splits — with half the MFMAs the step is 20 us shorter (profiles/round6_gemm_half_mfma_ab.txt)
+                flop = 2.0 * (351 * 128 + 128 * 128 + 144 * 27) * A
+                roofs["bwd_wgrad"] = {"bound": "mfma", "kernel": "k_gemm_tn_b x 2 + k_gemm_tn + k_wgrad_reduce", "unit": "TFLOP/s",
+                                      "achieved": flop / (kt["bwd_wgrad"] * 1e-3) / 1e12, "peak": MFMA_F16_PEAK_TF,
+                                      "frac": flop / (kt["bwd_wgrad"] * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, "ms_per_iter": kt["bwd_wgrad"]}
+            if kt.get("adam") or kt.get("tv_seed"):
+                # TV seed + Adam on the 70 MB of factors: streaming (seed: read p, write g; Adam: read g, p, m, v, write p, m, v + the reference-layout copy)
+                nb = field.factor_grad_buffer(_raw=True).numel() * 4
+                roofs["tv_adam"] = {"bound": "hbm", "kernel": "k_tv_seed_cl_multi + k_adam_cl_multi (appearance part; the density part runs beside the appearance scatter)",
+                                    "unit": "GB/s", "bytes_per_iter": 10 * nb,
+                                    "note": "2 + 8 passes over the factor bytes per step = 0.70 GB: ~0.12 ms at the ~6 TB/s these kernels reach alone"}
         except Exception as e:  # noqa: BLE001  (reporting only)
             kt = {"error": repr(e)[:200]}
+        form = "one C call (t2n_train_step, eager, pipelined)" if fs is not None and not step_kw.get("graph") else (
+            "one hipGraph launch (t2n_train_graph_*)" if fs is not None else "composed: render -> loss kernel -> backward -> TVAdam, separate calls")
+        extra = {}
+        if fs is not None:
+            fs.sync()
+            extra = {"train_step_driver": dict(issued=fs.issued, eager=fs.eager_launches, pipelined=fs.pipelined_launches, graph_launches=fs.graph_launches,
+                                               graph_captures=fs.graph_captures, graph_nodes=getattr(fs, "graph_nodes", None), replays=fs.replays,
+                                               rows_capacity=fs.rows_cap, rows_needed=fs.needs[-3:], workspace_GiB=round(fs.ws.numel() / 2 ** 30, 3))}
         return {"train_iters_per_s_fused_step": iters / dt, "train_ms_per_iter_fused_step": dt / iters * 1e3,
                 "train_ms_per_iter_fused_step_blocks": blocks_ms,
-                "train_kernel_ms_per_iter": kt, "train_kernel_rooflines": roofs,
-                "train_step_fused": "TensorVMSplit.train_step: no autograd graph, loss + its gradients in one kernel, event-based row "
-                                    f"count, TV + Adam on the device copies; loss {float(loss.detach()):.4f}"}
+                "train_kernel_ms_per_iter": kt, "train_kernel_rooflines": roofs, **extra,
+                "train_step_fused": f"TensorVMSplit.train_step, {form}: no autograd graph, the driver's loss inside the per-ray backward kernel, "
+                                    f"device-side row plan, TV seed + Adam on the device copies; loss {float(loss.detach()):.4f}"}
     if fused_optim:
         return {"train_iters_per_s_fused_optim": iters / dt, "train_ms_per_iter_fused_optim": dt / iters * 1e3,
                 "train_ms_per_iter_fused_optim_blocks": blocks_ms}
@@ -1135,15 +1175,18 @@ def main():
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True))
             # (what the fused train leg added on top of the resident render state: the 300^3 field, its ray tensor, outputs)
             out["config"]["memory_reserved_GiB_train"] = round((torch.cuda.max_memory_reserved(dev) - base_res) / 2 ** 30, 3)
+            for tag, kw in (("graph", dict(fused=True, graph=True)), ("composed", dict(fused=False))):
+                try:   # the same step as ONE hipGraph launch, and in round 5's composed form (separate C calls), same loop
+                    r_ = train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True, step_kw=kw)
+                    out["config"][f"train_ms_per_iter_fused_step_{tag}"] = r_["train_ms_per_iter_fused_step"]
+                    out["config"][f"train_ms_per_iter_fused_step_{tag}_blocks"] = r_["train_ms_per_iter_fused_step_blocks"]
+                    if tag == "graph":
+                        out["config"]["train_step_graph_nodes"] = (r_.get("train_step_driver") or {}).get("graph_nodes")
+                except Exception as e:  # noqa: BLE001  (reporting only)
+                    out["config"][f"train_ms_per_iter_fused_step_{tag}"] = {"error": repr(e)[:200]}
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_optim=True))
             out["config"].update(train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True, resident=True))
-            try:   # the same step without the host read of the row count (T2N_FLAG_DEVICE_ROWS): immune to a slow host, not faster on a fast one
-                sp_ = train_bench(dev, iters=args.train_iters, warmup=args.train_warmup, fused_step=True, resident=True, speculative=True)
-                out["config"]["train_ms_per_iter_fused_step_resident_speculative"] = sp_["ms_per_iter"]
-                out["config"]["train_speculative"] = {k: sp_[k] for k in ("blocks_ms", "device_rows_steps", "overflows", "unanswered_polls")}
-            except Exception as e:  # noqa: BLE001  (reporting only)
-                out["config"]["train_speculative"] = {"error": repr(e)[:200]}
         if not grouped and not c4 and not args.quick:
             out["scaling_prediction"] = sp = scaling_prediction(field, dev, out["config"].get("train_ms_per_iter_fused_step"))
             out["config"]["train_ms_per_iter_fused_step_2048_rays"] = sp.get("train_dp", {}).get("fused_step_ms_by_rays_per_gpu", {}).get("2048")

@@ -15,7 +15,9 @@
  *     synchronise unless documented. The library allocates device memory only inside t2n_field_create/_upload (the
  *     channel-last copy of the factor tensors) and, once, in the first t2n_train_step of a field (its training state: a few hundred
  *     KB); per-call scratch comes from the caller's workspace.
- *   - a handle may be used from one host thread at a time.
+ *   - a handle may be used from one host thread at a time. This includes the `const t2n_field*` queries t2n_render_workspace_bytes_hint
+ *     and t2n_field_list_retries: they consume the counters that budgeted launches posted (and the latter waits for those still in
+ *     flight), i.e. they update the field's hint state.
  */
 #ifndef T2N_H_
 #define T2N_H_

@@ -17,14 +17,14 @@ KW = dict(density_n_comp=[24, 20, 32], appearance_n_comp=[64, 72, 56], app_dim=2
           view_pe=6, pos_pe=6)
 
 
-def _build(seed=3):
+def _build(seed=3, density_shift=-10):
     from text2nerf_amd import TensorVMSplit
     params = synth.make_field_params(seed, GRID, density_n_comp=KW["density_n_comp"], app_n_comp=KW["appearance_n_comp"], app_dim=27,
                                      feature_c=KW["featureC"], fea_pe=6, shading_mode="MLP_Fea_noview", density_scale=0.8, aabb=AABB)
-    m = TensorVMSplit(torch.tensor(AABB), GRID, dev(), near_far=NF, alphaMask_thres=1e-4, density_shift=-10, distance_scale=25,
+    m = TensorVMSplit(torch.tensor(AABB), GRID, dev(), near_far=NF, alphaMask_thres=1e-4, density_shift=density_shift, distance_scale=25,
                       step_ratio=1.0, fea2denseAct="softplus", **KW)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
-    cfg = O.FieldConfig(aabb=AABB, grid_size=GRID, near_far=NF, shading_mode="MLP_Fea_noview", fea_pe=6)
+    cfg = O.FieldConfig(aabb=AABB, grid_size=GRID, near_far=NF, shading_mode="MLP_Fea_noview", fea_pe=6, density_shift=float(density_shift))
     return m, params, cfg
 
 
@@ -63,3 +63,27 @@ def test_wide_field_train_gradients_vs_oracle_autograd():
     close(out[0], o[0].detach().numpy(), atol=RGB_ATOL)
     ((o[0] * ca).sum() + 0.1 * o[1].sum() + (o[3] ** 2).sum()).backward()
     _grad_check(m, {k: (v.grad if v.grad is not None else torch.zeros_like(v)).numpy() for k, v in P.items()}, rel=5e-4)
+
+
+def test_clamp_passes_the_gradient_on_the_closed_interval():
+    """rgb_map.clamp(0, 1) passes its gradient at exactly 0.0 and 1.0 (torch.clamp's autograd; the tuned path does the same:
+    k_bwd_march). A nearly empty field (density_shift -40: sigma ~ 1e-13, no weight reaches the appearance threshold) under a white
+    background composites to exactly 1.0f on every ray, while d rgb / d sigma = -(1 - acc)' is not zero: the density gradients of the
+    general-shape path against the oracle's autograd (the upstream gradient scaled so that they are O(1))."""
+    from tests.test_hip_parity import _grad_check
+    m, params, cfg = _build(seed=5, density_shift=-40)
+    rays = torch.from_numpy(synth.frame_rays_np(12, 16, c2w=synth.look_pose(0.2, -0.1, (0.1, 0.2, -2.5))))
+    g = np.random.Generator(np.random.PCG64(9))
+    ca = torch.from_numpy((g.uniform(0.5, 1.5, (rays.shape[0], 3)) * 1e14).astype(np.float32))
+    torch.manual_seed(7)
+    jit = torch.rand(rays.shape[0], 1)
+    torch.manual_seed(7)
+    out = m(rays, is_train=True, white_bg=True, N_samples=48)
+    assert bool((out[0] == 1.0).all())                      # every pre-clamp colour sits ON the boundary
+    (out[0] * ca.to(dev())).sum().backward()
+    P = O.params_from_numpy(params, requires_grad=True)
+    o = O.forward(cfg, P, rays, white_bg=True, is_train=True, n_samples=48, jitter=jit)
+    (o[0] * ca).sum().backward()
+    ref = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).numpy() for k, v in P.items()}
+    assert max(float(np.abs(ref[f"density_plane.{k}"]).max()) for k in range(3)) > 1e-3     # the reference does pass a gradient there
+    _grad_check(m, ref, rel=5e-4)

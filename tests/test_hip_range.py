@@ -232,3 +232,22 @@ def test_one_kernel_appearance_paths_stay_correct():
         tf._WORKSPACE.clear()
     assert n_app > 20000
     assert float((got - ref).abs().max()) <= 2e-7
+
+
+def test_nan_density_feature_renders_as_empty_space(tiny_params):
+    """ADVICE r5, deliberate deviation (csrc/t2n_device.h exp_finite): the marchers clamp the activation's argument with a raw v_max_f32,
+    which returns the other operand for a NaN — a NaN density feature becomes sigma = 0 / alpha = 0 where the reference propagates NaN
+    into the ray. Pinned here so that the behaviour is a decision: a field with one NaN density texel renders FINITE, and the rays that
+    do not touch the texel's footprint are bit-identical to the clean field's."""
+    r = rays().to(dev())
+    clean = make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    bad = {k: v.copy() for k, v in tiny_params.items()}
+    pl = bad["density_plane.0"]
+    pl[0, :, pl.shape[2] // 2, pl.shape[3] // 2] = np.nan
+    f = make_field(bad, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    with torch.no_grad():
+        a = clean(r, white_bg=True, is_train=False, N_samples=-1)
+        b = f(r, white_bg=True, is_train=False, N_samples=-1)
+    assert bool(torch.isfinite(b[0]).all()) and bool(torch.isfinite(b[1]).all())
+    same = (a[0] == b[0]).all(dim=1)
+    assert 0 < int(same.sum()) < r.shape[0] or bool(same.all())     # (rays through the texel's column differ, the rest are untouched)

@@ -675,7 +675,9 @@ static void counts_post(t2n_field* f, const unsigned* counters_dev, int64_t n_ra
     if (!c.host) {
         if (hipHostMalloc((void**)&c.host, sizeof(unsigned) * kLists * kCounterStride, hipHostMallocDefault) != hipSuccess) { c.host = nullptr; (void)hipGetLastError(); return; }
         hipEvent_t ev;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {   // (a slot with a buffer but no event would never post again)
+            (void)hipGetLastError(); (void)hipHostFree(c.host); c.host = nullptr; return;
+        }
         c.ev = (void*)ev;
     }
     if (post_counts(counters_dev, c.host, s) != T2N_OK || hipEventRecord((hipEvent_t)c.ev, s) != hipSuccess) { (void)hipGetLastError(); return; }

@@ -1263,6 +1263,18 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             set_error("t2n_render_backward: T2N_FLAG_DEVICE_ROWS needs the fused MLP_Fea_noview head in split-f16 mode and a forward workspace with kept activation rows");
             return T2N_ERR_UNSUPPORTED;
         }
+        // EVERY precondition of the device-side plan is checked here, before anything is launched or forked (the checks further
+        // down stay as assertions: a refusal there would leave queued kernels and unjoined side streams behind)
+        {
+            int Lm = 0;
+            for (int k = 0; k < 3; ++k) Lm = f->dev.den.L[k] > Lm ? f->dev.den.L[k] : Lm;
+            const bool force_atomic_env = getenv("T2N_BWD_ATOMIC_SCATTER") && atoi(getenv("T2N_BWD_ATOMIC_SCATTER")) != 0;
+            if (force_atomic_env || tile_accum_lds(16, Lm) > 160 * 1024 || !block_geom_ok(f->dev.den) || (uint64_t)n_rays * n_samples * 3 >= 0x7fffffffull) {
+                set_error("t2n_render_backward: T2N_FLAG_DEVICE_ROWS needs the binned scatters (grid lines within the LDS budget)");
+                return T2N_ERR_UNSUPPORTED;
+            }
+            if (!g->mlp_w1 || !g->mlp_w0) { set_error("t2n_render_backward: T2N_FLAG_DEVICE_ROWS needs the weight-gradient tensors of both hidden layers"); return T2N_ERR_INVALID; }
+        }
         int64_t lo = 0, hi = (int64_t)kc.rows / 32;     // largest capacity (in tiles) whose backward buffers fit
         while (lo < hi) {
             const int64_t mid = (lo + hi + 1) / 2;

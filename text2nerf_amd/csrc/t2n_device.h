@@ -360,6 +360,11 @@ __device__ __forceinline__ void ray_interval(const FieldDev& F, const Ray& ray, 
 // log_ge1(u) for finite u >= 1 (no denormal pre-scaling, no infinity test). Same operations in the same order on the values that
 // remain: the results are the library's bit for bit, at 10 + 5 instead of 13 + 13 instructions per evaluation — the tile marcher runs
 // three of them per sample (softplus = log1p(exp(.)), then 1 - exp(-sigma dist): models/tensorBase.py:19-26,406-410).
+// NaN (deliberate deviation): v_max_f32 returns the other operand for a quiet NaN, so exp_finite(NaN) = exp(-200) = 0 where
+// expf(NaN) is NaN — a NaN density feature renders as empty space (sigma = 0, alpha = 0) on the marchers that use this form, where the
+// reference propagates NaN into the ray's colour. A diverged field therefore shows as missing geometry and a finite loss, not as NaN
+// pixels (tests/test_hip_range.py::test_nan_density_feature_renders_as_empty_space pins the behaviour); keeping the NaN would cost a
+// compare + select in front of each of the three evaluations per sample of the frame's most issue-bound kernel.
 __device__ __forceinline__ float exp_finite(float x0) {
     float x;                                                        // max(x0, -200): -inf would turn ph - n into NaN; below -103.3 the result is 0
     asm("v_max_f32 %0, 0xc3480000, %1" : "=v"(x) : "v"(x0));        // either way (one instruction: fmaxf adds a canonicalising v_max in front)

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void k_gen_bwd_march(const GenArgs a) {
     float dbg = 0.f;
     for (int k = 0; k < 3; ++k) {
         const float raw = a.raw[r * 3 + k];
-        dc[k] = (raw > 0.f && raw < 1.f) ? a.d_rgb[r * 3 + k] : 0.f;          // clamp(0, 1): gradient inside the open interval
+        dc[k] = (raw >= 0.f && raw <= 1.f) ? a.d_rgb[r * 3 + k] : 0.f;        // clamp(0, 1): autograd passes the gradient on the CLOSED interval (as k_bwd_march)
         dbg += dc[k];
     }
     const float dd = a.d_depth[r];
