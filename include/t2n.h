@@ -127,8 +127,8 @@ enum { T2N_STAT_EVALUATED = 0,   /* V: in-box (and z-gated) samples that read th
        T2N_STAT_F16_REDO = 4,    /* sub-launches whose split-f16 appearance stage met a value outside the f16 range and were
                                     redone on the exact fp32 path (results are the exact path's) */
        T2N_STAT_LIST_RETRY = 5,  /* 1: some rays of the call found no room in its budgeted appearance lists and were shaded and
-                                    composited by the per-ray finisher (k_finish_rays: exact-fp32 head, no list memory); with the
-                                    general view-dependent heads: the whole call was rendered again with worst-case lists */
+                                    composited by the per-ray finisher (k_finish_rays: exact-fp32 head, no list memory). (The general
+                                    view-dependent heads always render with worst-case lists.) */
        T2N_STAT_COUNT = 8 };
 
 const char* t2n_last_error(void);
@@ -230,6 +230,14 @@ int t2n_raw2alpha(const float* sigma, const float* dist, int64_t n_rays, int n_s
  *             known, then twice what the field's last completed budgeted launch needed + 16 (~4.3 GB for the frame above).
  */
 size_t t2n_render_workspace_bytes(int64_t rays_per_launch, int n_samples);
+/* The general view-dependent heads (T2N_SHADE_MLP_FEA / _MLP_PE / _MLP; models/tensorBase.py:62-86,111-159) evaluate their unfused MLP
+ * through activation scratch behind the sizes above: add this many bytes (0 for the other heads) and one pass covers 32 appearance rows
+ * per ray; rows beyond that are taken in further passes over the same scratch. The call reads no count on the host and allocates
+ * nothing: tile prefix and row count are derived on the device, every kernel clips to them, and the host issues the passes the worst
+ * case needs (a pass past the count costs its empty launches). */
+size_t t2n_render_head_scratch_bytes(const t2n_field* f, int64_t n_rays);
+/* rows per ray that sizing reserves (default 32; the driver's scenes need ~7): fewer rows = less memory per ray, more passes */
+int t2n_field_set_head_scratch_rows(t2n_field* f, int rows_per_ray);
 size_t t2n_render_workspace_bytes_hint(const t2n_field* f, int64_t n_rays, int n_samples);
 size_t t2n_render_workspace_bytes_budget(int64_t n_rays, int n_samples, int entries_per_ray);   /* one launch, lists for this many entries per ray */
 uint64_t t2n_field_list_retries(const t2n_field* f);   /* budgeted calls that overflowed their lists since the field was created (waits for counters still in flight) */

@@ -76,3 +76,33 @@ def test_mlp_pe_head_is_rejected():
     from text2nerf_amd._lib import T2NError
     with pytest.raises(T2NError):
         TensorVMSplit(torch.tensor([[-1.0] * 3, [1.0] * 3]), [8, 8, 8], dev(), shadingMode="MLP_PE")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(HEADS))
+def test_hip_heads_in_several_passes_equal_one_pass(tiny, tag):
+    """the general heads' forward reads no count on the host and allocates nothing — the activation scratch is part of
+    the caller's workspace and the rows are taken in passes of its capacity, every kernel clipping to a device-side plan. With ONE
+    scratch row per ray (instead of 32) a frame's ~7 appearance rows per ray need several passes: bit-identical colours, and the
+    sub-launch form of the reference call (chunked rays) agrees as well."""
+    from tests.test_hip_parity import dev
+    from text2nerf_amd import TensorVMSplit, OctreeRender_trilinear_fast
+    kw = HEADS[tag]
+    def make():
+        m = TensorVMSplit(torch.tensor(TINY["aabb"]), TINY["grid"], dev(), density_n_comp=[16] * 3, appearance_n_comp=[48] * 3, app_dim=27,
+                          near_far=TINY["near_far"], alphaMask_thres=1e-4, density_shift=-10, distance_scale=25, featureC=128,
+                          step_ratio=1.0, fea2denseAct="softplus", **kw)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in _params(kw).items()}, strict=True)
+        return m
+    rays = torch.from_numpy(synth.frame_rays_np(40, 48, c2w=synth.look_pose(0.3, -0.1, (0.2, 0.1, -1.0))))     # 1 920 rays
+    a, b = make(), make()
+    b.head_scratch_rows_per_ray = 1
+    with torch.no_grad():
+        ra = a(rays.to(dev()))
+        rb = b(rays.to(dev()))
+        rc = OctreeRender_trilinear_fast(rays, b, chunk=512, N_samples=-1, white_bg=True, is_train=False, device=dev())
+    rows = a.stats()["appearance"]
+    assert rows > 3 * (rays.shape[0] + 256), rows        # more rows than one pass of the small scratch holds, several times over
+    assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1])
+    # (the chunked call marches per ray where the whole frame may take the tile marcher: same samples, weights to ~2e-6)
+    assert float((ra[0] - rc[0]).abs().max()) <= 2e-5 and float((ra[1] - rc[2]).abs().max()) <= 2e-4

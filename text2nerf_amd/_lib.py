@@ -102,6 +102,8 @@ SIGNATURES = {
     "t2n_raw2alpha": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
     "t2n_render_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "t2n_render_head_scratch_bytes": (C.c_size_t, [C.c_void_p, C.c_int64]),
+    "t2n_field_set_head_scratch_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "t2n_render_workspace_bytes_hint": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int]),
     "t2n_field_list_retries": (C.c_uint64, [C.c_void_p]),
     "t2n_render_workspace_bytes_budget": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),

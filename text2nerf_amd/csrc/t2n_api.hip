@@ -600,6 +600,15 @@ extern "C" size_t t2n_render_workspace_bytes(int64_t rays_per_launch, int n_samp
     return carve(rays_per_launch, n_samples).total;
 }
 
+// The general view-dependent heads (MLP_Fea / MLP_PE / MLP) evaluate their unfused MLP through activation scratch BEHIND the workspace
+// sizes the functions above return: this many bytes more let one pass cover 32 rows per ray (rows beyond that are taken in further
+// passes over the same scratch; any amount >= one 32-row tile works). 0 for the other heads.
+extern "C" size_t t2n_render_head_scratch_bytes(const t2n_field* f, int64_t n_rays) {
+    if (!f || n_rays <= 0 || !head_is_generic(f->desc.shading)) return 0;
+    const size_t row = (size_t)(32 + head_dims(f->desc).K0pad + 128 + 128) * sizeof(float);
+    return ((size_t)n_rays * (size_t)f->head_rows_per_ray + 32 * kLists) / 32 * 32 * row + 512;
+}
+
 extern "C" size_t t2n_render_workspace_bytes_ctx(int64_t n_rays, int n_samples) {
     if (n_rays <= 0 || n_samples <= 0) return 0;
     return carve_workspace(n_rays, n_samples, true, false).total;
@@ -715,12 +724,12 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
     // largest sub-launch whose worst case (every sample an appearance sample) fits the workspace
     int64_t per = n_rays;
     unsigned budget = 0;   // appearance entries per ray the lists are sized for (0: worst case)
-    bool generic_overflow = false;
     counts_poll(f, false);   // counters of earlier budgeted launches that have landed meanwhile: the hint, list_retries (never waits)
     // A frame for the tile marcher whose worst case does not fit is first tried as ONE launch with budgeted lists (the largest
     // budget the workspace holds): a C2 frame needs ~7 entries per ray where the worst case reserves 518. The counters reach
     // pinned host memory behind the march kernels; a launch that overflowed is redone below in worst-case sub-launches.
-    if (tiles && carve(n_rays, n_samples).total > workspace_bytes && n_rays >= kBudgetMinRays && !getenv("T2N_NO_BUDGET")) {
+    const bool generic_head = head_is_generic(f->desc.shading);
+    if (tiles && !generic_head && carve(n_rays, n_samples).total > workspace_bytes && n_rays >= kBudgetMinRays && !getenv("T2N_NO_BUDGET")) {
         unsigned lo = 0, hi = (unsigned)n_samples;   // largest budget in [kBudgetFloor, n_samples) that fits
         if (carve_workspace(n_rays, n_samples, true, true, kBudgetFloor).total <= workspace_bytes) {
             lo = kBudgetFloor;
@@ -731,10 +740,14 @@ extern "C" int t2n_render_forward(t2n_field* f, const float* rays, int64_t n_ray
         }
         if (lo >= kBudgetFloor && (uint64_t)list_capacity_budget(n_rays, n_samples, lo) * kLists <= 0x7fffffffull) budget = lo;
     }
-retry_worst_case:
+
+    // general view-dependent heads: activation scratch of the unfused MLP for kHeadRowsPerRay rows per ray behind the sub-launch's carve
+    // (feat32 | X0 | h0 | h1 per row); rows beyond it are taken in further passes over the same scratch (see the loop below)
+    const size_t head_row_bytes = generic_head ? (size_t)(32 + head_dims(f->desc).K0pad + 128 + 128) * sizeof(float) : 0;
+    auto head_bytes = [&](int64_t rays) { return generic_head ? ((size_t)rays * (size_t)f->head_rows_per_ray + 32 * kLists) / 32 * 32 * head_row_bytes + 256 : (size_t)0; };
     if (!budget) {
-        while (!keep && per > 1 && carve(per, n_samples).total > workspace_bytes) per = (per + 1) / 2;
-        if (!keep && carve(per, n_samples).total > workspace_bytes) { set_error("t2n_render_forward: workspace %zu B too small", workspace_bytes); return T2N_ERR_WORKSPACE; }
+        while (!keep && per > 1 && carve(per, n_samples).total + head_bytes(per) > workspace_bytes) per = (per + 1) / 2;
+        if (!keep && carve(per, n_samples).total + head_bytes(per) > workspace_bytes) { set_error("t2n_render_forward: workspace %zu B too small", workspace_bytes); return T2N_ERR_WORKSPACE; }
         while ((uint64_t)list_capacity(per, n_samples) * kLists > 0x7fffffffull) per = (per + 1) / 2;   // int slots
         if (tiles && per < n_rays) {   // sub-launches must cover whole 8-row bands of the image
             const int64_t band = (int64_t)8 * f->frame_w;
@@ -786,29 +799,35 @@ retry_worst_case:
         } else if ((rc = launch_march(f, L, s))) return rc;
         if (budget) counts_post(f, L.counters, n_rays, n_samples, budget, s);   // -> pinned host memory behind the march; read by a LATER call
         if (keep && (rc = ctx_counts_post(workspace, L.counters, s))) return rc;   // the backward sizes itself from these without draining the stream
-        if (head_is_generic(f->desc.shading)) {
-            // general head path: the appearance-row count is needed on the host to size the activation scratch (one stream
-            // sync per sub-launch; the fused MLP_Fea_noview head needs none)
-            unsigned raw[kLists * kCounterStride], tb[kLists + 1];
-            T2N_HIP(hipMemcpyAsync(raw, L.counters, sizeof(raw), hipMemcpyDeviceToHost, s));
-            T2N_HIP(hipStreamSynchronize(s));
-            if (budget && raw[kOverflowWord]) generic_overflow = true;
-            unsigned t = 0;
-            for (int l = 0; l < kLists; ++l) { unsigned cnt = raw[l * kCounterStride]; if (cnt > L.list_cap) cnt = L.list_cap; tb[l] = t; t += (cnt + 31u) / 32u; }
-            tb[kLists] = t;
-            const long long rows = (long long)t * 32;
-            if (rows > 0) {
-                const HeadDims H = head_dims(f->desc);
-                float* scratch = nullptr;
-                const size_t per_row = (size_t)(32 + H.K0pad + 128 + 128) * sizeof(float);
-                T2N_HIP(hipMallocAsync((void**)&scratch, (size_t)rows * per_row, s));
-                float* feat32 = scratch; float* x0 = feat32 + rows * 32; float* h0 = x0 + rows * H.K0pad; float* h1 = h0 + rows * 128;
-                ShadeCtx ctx{nullptr, feat32, nullptr, nullptr};
-                rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, &ctx, s, true);
-                if (!rc) rc = launch_head_forward(f, tb, rows, feat32, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, x0, h0,
-                                                  h1, L.app_rgb, s);
-                (void)hipFreeAsync(scratch, s);
-                if (rc) return rc;
+        if (generic_head) {
+            // general head path, no host read and no allocation: one wave derives tile prefix + row count from the
+            // counters (k_head_plan, in the counter block's spare words), the activation scratch is the workspace behind the carve, and
+            // the rows are taken in PASSES of the scratch's capacity — gather + basis (feat32) -> head input rows -> two dense layers ->
+            // layer 2 + sigmoid into the list — every kernel clipping to the device-side count. The host issues the passes the WORST
+            // case needs (every sample an appearance sample); a pass past the count is six empty launches.
+            const HeadDims H = head_dims(f->desc);
+            HeadPlanDev* plan = (HeadPlanDev*)(L.counters + kHeadPlanWord);
+            if ((rc = launch_head_plan(L.counters, L.list_cap, plan, s))) return rc;
+            const size_t off = align_up(c.total, 256);
+            size_t avail = workspace_bytes > off ? workspace_bytes - off : 0;
+            long long cap = (long long)(avail / head_row_bytes) / 32 * 32;
+            if (cap > 0x7fffffe0ll) cap = 0x7fffffe0ll;
+            if (cap < 32) {
+                set_error("t2n_render_forward: the workspace holds no activation row of the general head (add t2n_render_head_scratch_bytes)");
+                return T2N_ERR_WORKSPACE;
+            }
+            {
+                float* feat32 = (float*)(ws + off); float* x0 = feat32 + cap * 32; float* h0 = x0 + cap * H.K0pad; float* h1 = h0 + cap * 128;
+                const long long worst = ((long long)L.list_cap + 31) / 32 * 32 * kLists;    // padded rows if every slot of every sub-list were used
+                const long long worst_rows = worst < (cnt * (long long)n_samples + 32ll * kLists) ? worst : (cnt * (long long)n_samples + 32ll * kLists);
+                for (long long row0 = 0; row0 < worst_rows; row0 += cap) {
+                    // the kernels index activation rows by their number in the call: base pointers shifted so that row row0 is scratch row 0
+                    ShadeCtx ctx{nullptr, feat32 - row0 * 32, nullptr, nullptr};
+                    if ((rc = launch_shade_list(f, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, L.app_rgb, &ctx, s, true,
+                                                (unsigned)(row0 + cap), nullptr, 0, nullptr, (unsigned)(row0 / 32), (unsigned)((row0 + cap) / 32)))) return rc;
+                    if ((rc = launch_head_forward(f, nullptr, cap, feat32, L.app_pos, L.app_ray, L.rays, ray_stride, L.counters, L.list_cap, x0, h0,
+                                                  h1, L.app_rgb, s, plan, row0))) return rc;
+                }
             }
         } else {
             // training forward with spare workspace: run the activation-keeping kernel now, so the backward need not re-run
@@ -824,20 +843,6 @@ retry_worst_case:
         // compaction kernel tags by the same rule and a tagged ray is only ever coloured here) are shaded and composited from their
         // staging slices, on the device
         if (tiles && finish_supported(f) && (rc = launch_finish_rays(f, L, (const float*)(ws + c.sigma), (const float4*)(ws + c.scratch), s))) return rc;
-    }
-    if (budget && generic_overflow) {
-        // the general view-dependent heads (no device-side finisher; their path synchronises per sub-launch anyway): some rays
-        // found no room, everything is rendered again with worst-case lists (sub-launches sized to the workspace)
-        f->list_retries++;
-        f->list_hint = 2u * budget < (unsigned)n_samples ? 2u * budget : (unsigned)n_samples;   // the next hint asks for > 4x the room
-        if (stats) {
-            T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s));
-            T2N_HIP(hipMemsetD32Async((hipDeviceptr_t)(stats + T2N_STAT_LIST_RETRY), 1, 1, s));
-        }
-        generic_overflow = false;
-        budget = 0;
-        per = n_rays;
-        goto retry_worst_case;
     }
     return T2N_OK;
 }
@@ -879,6 +884,12 @@ extern "C" int t2n_field_set_alpha_mask(t2n_field* f, const float* volume, int D
     T2N_HIP(hipMemcpyAsync(f->buf_alpha, volume, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     f->dev.alpha = f->buf_alpha; f->dev.aD = D; f->dev.aH = H; f->dev.aW = W;
     for (int k = 0; k < 3; ++k) { f->dev.a_min[k] = aabb_min_host[k]; f->dev.a_inv[k] = inv_size_host[k]; }
+    return T2N_OK;
+}
+
+extern "C" int t2n_field_set_head_scratch_rows(t2n_field* f, int rows_per_ray) {
+    if (!f || rows_per_ray < 1 || rows_per_ray > 4096) { set_error("t2n_field_set_head_scratch_rows: rows_per_ray must lie in [1, 4096]"); return T2N_ERR_INVALID; }
+    f->head_rows_per_ray = rows_per_ray;
     return T2N_OK;
 }
 

@@ -32,6 +32,23 @@ HeadDims head_dims(const t2n_field_desc& d) {
 }
 
 struct TilePrefixH { unsigned t[kLists + 1]; };
+// The forward's device-side plan (t2n_render_forward reads no count on the host): tile prefix of the sub-lists and the row count, derived
+// from the march kernel's counters by one wave; the head kernels below take their rows in PASSES of a fixed capacity — pass p covers rows
+// [row0, row0 + cap) of the call, activation row r lives at scratch row r - row0 — and clip to the count on the device. The host issues
+// the passes for the worst case (every sample an appearance sample); a pass beyond the count costs its empty launches.
+__global__ __launch_bounds__(64) void k_head_plan(const unsigned* __restrict__ counters, unsigned list_cap, HeadPlanDev* __restrict__ plan) {
+    const int lane = threadIdx.x;
+    unsigned cnt = lane < kLists ? counters[lane * kCounterStride] : 0u;
+    if (cnt > list_cap) cnt = list_cap;
+    unsigned incl = (cnt + 31u) / 32u;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane < kLists) plan->t[lane] = incl - (cnt + 31u) / 32u;
+    if (lane == kLists - 1) { plan->t[kLists] = incl; plan->rows = incl * 32u; }
+}
 
 // row -> appearance-list entry (rows are 32-entry tiles, sub-list by sub-list); returns false for padding rows
 __device__ __forceinline__ bool row_entry(long long row, const TilePrefixH& tp, const unsigned* counters, unsigned list_cap, unsigned& idx) {
@@ -49,16 +66,19 @@ __device__ __forceinline__ bool row_entry(long long row, const TilePrefixH& tp, 
 struct HeadInArgs {
     HeadDims H; const float* feat32; const float4* app_pos; const int* app_ray; const float* rays; int ray_stride; int ndc;
     const unsigned* counters; unsigned list_cap; TilePrefixH tp; long long rows; float* x0;
+    const HeadPlanDev* plan; long long row0;   // plan != NULL: tile prefix / row count from device memory, rows = the pass's capacity (see k_head_plan)
 };
 // one thread per (row, column): column c of the reference's torch.cat
 __global__ __launch_bounds__(256) void k_head_in(const HeadInArgs a) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int Kp = a.H.K0pad;
-    const long long row = t / Kp;
-    const int c = (int)(t - row * Kp);
-    if (row >= a.rows) return;
+    const long long lrow = t / Kp;
+    const int c = (int)(t - lrow * Kp);
+    const long long row = a.row0 + lrow;
+    if (lrow >= a.rows || (a.plan && row >= (long long)a.plan->rows)) return;
     unsigned idx;
-    const bool live = row_entry(row, a.tp, a.counters, a.list_cap, idx);
+    const bool live = a.plan ? row_entry(row, *reinterpret_cast<const TilePrefixH*>(a.plan->t), a.counters, a.list_cap, idx)
+                             : row_entry(row, a.tp, a.counters, a.list_cap, idx);
     float v = 0.f;
     if (live && c < a.H.K0) {
         const HeadDims& H = a.H;
@@ -69,11 +89,11 @@ __global__ __launch_bounds__(256) void k_head_in(const HeadInArgs a) {
             return d;
         };
         auto base_a = [&](int k) {   // the tensor PE block A encodes: features (MLP_Fea) or normalised points (MLP_PE)
-            if (H.shading == T2N_SHADE_MLP_FEA) return a.feat32[row * 32 + k];
+            if (H.shading == T2N_SHADE_MLP_FEA) return a.feat32[lrow * 32 + k];
             const float4 p = a.app_pos[idx];
             return k == 0 ? p.x : (k == 1 ? p.y : p.z);
         };
-        if (c < H.o_view) v = a.feat32[row * 32 + c];
+        if (c < H.o_view) v = a.feat32[lrow * 32 + c];
         else if (c < H.o_view + 3) v = view(c - H.o_view);
         else if (c < H.o_pe_v) {            // PE block A: [sin (k-major, octave-minor) | cos]
             const int freqs = H.shading == T2N_SHADE_MLP_FEA ? H.fea_pe : H.pos_pe;
@@ -90,7 +110,7 @@ __global__ __launch_bounds__(256) void k_head_in(const HeadInArgs a) {
             v = cs ? cosf(arg) : sinf(arg);
         }
     }
-    a.x0[row * Kp + c] = v;
+    a.x0[lrow * Kp + c] = v;
 }
 
 // gf [rows,32] = dL/dfeatures from gx [rows,K0pad] = dL/d(input row): the direct feature columns, plus (MLP_Fea) the chain
@@ -184,7 +204,13 @@ int launch_simple_head_bwd(t2n_field* f, const unsigned tiles_before[kLists + 1]
 // staged once (row stride 65: conflict-free both ways), 4 waves walk 32-row tiles, rows on the MFMA N axis, columns on M.
 // K <= 512 (LDS), ldin % 4 == 0 with finite padding columns, ldo % 4 == 0.
 __global__ __launch_bounds__(256) void k_dense(const float* __restrict__ IN, int ldin, const float* __restrict__ Wt, int K, int N,
-                                               const float* __restrict__ bias, int relu, long long rows, float* OUT, int ldo) {
+                                               const float* __restrict__ bias, int relu, long long rows, float* OUT, int ldo,
+                                               const HeadPlanDev* __restrict__ plan, long long row0) {
+    if (plan) {   // rows = the pass's capacity: clip to what the call really has
+        const long long left = (long long)plan->rows - row0;
+        rows = left < rows ? left : rows;
+        if (rows <= 0) return;
+    }
     extern __shared__ __attribute__((aligned(16))) float sW[];   // [K4][65]
     const int lane = threadIdx.x & 63, s = lane & 31, h = lane >> 5, w = threadIdx.x >> 6;
     const int ng = blockIdx.x;
@@ -243,14 +269,17 @@ __global__ __launch_bounds__(256) void k_dense(const float* __restrict__ IN, int
 struct Dense3Args {
     const float* h1; const float* w2; const float* b2; const unsigned* counters; unsigned list_cap; TilePrefixH tp; long long rows; float4* app_rgb;
     const float4* app_pos;   // the entry's compositing weight (.w) rides along in app_rgb.w: k_composite reads one array
+    const HeadPlanDev* plan; long long row0;
 };
 __global__ __launch_bounds__(256) void k_dense3_sigmoid(const Dense3Args a) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long row = t >> 2;
+    const long long lrow = t >> 2;
+    const long long row = a.row0 + lrow;
     const int p = (int)(t & 3);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    if (row < a.rows) {
-        const float* hr = a.h1 + row * 128 + p * 32;
+    const bool in = lrow < a.rows && (!a.plan || row < (long long)a.plan->rows);
+    if (in) {
+        const float* hr = a.h1 + lrow * 128 + p * 32;
         for (int j = 0; j < 32; ++j) {
             const float x = hr[j];
             s0 = fmaf(x, a.w2[p * 32 + j], s0); s1 = fmaf(x, a.w2[128 + p * 32 + j], s1); s2 = fmaf(x, a.w2[256 + p * 32 + j], s2);
@@ -259,9 +288,9 @@ __global__ __launch_bounds__(256) void k_dense3_sigmoid(const Dense3Args a) {
     s0 += dpp_quad_xor1(s0); s0 += dpp_quad_xor2(s0);
     s1 += dpp_quad_xor1(s1); s1 += dpp_quad_xor2(s1);
     s2 += dpp_quad_xor1(s2); s2 += dpp_quad_xor2(s2);
-    if (row < a.rows && p == 0) {
+    if (in && p == 0) {
         unsigned idx;
-        if (row_entry(row, a.tp, a.counters, a.list_cap, idx)) {
+        if (a.plan ? row_entry(row, *reinterpret_cast<const TilePrefixH*>(a.plan->t), a.counters, a.list_cap, idx) : row_entry(row, a.tp, a.counters, a.list_cap, idx)) {
             const float r = 1.f / (1.f + expf(-(s0 + a.b2[0]))), g = 1.f / (1.f + expf(-(s1 + a.b2[1]))), b = 1.f / (1.f + expf(-(s2 + a.b2[2])));
             a.app_rgb[idx] = make_float4(r, g, b, a.app_pos[idx].w);
         }
@@ -269,7 +298,7 @@ __global__ __launch_bounds__(256) void k_dense3_sigmoid(const Dense3Args a) {
 }
 
 static int launch_dense(const float* IN, int ldin, const float* Wt, int K, int N, const float* bias, int relu, long long rows, float* OUT,
-                        int ldo, hipStream_t s) {
+                        int ldo, hipStream_t s, const HeadPlanDev* plan = nullptr, long long row0 = 0) {
     if (K > 512) { set_error("generic head: %d MLP inputs > 512", K); return T2N_ERR_UNSUPPORTED; }
     const int ng = (N + 63) / 64;
     const long long tiles4 = ((rows + 31) / 32 + 3) / 4;
@@ -279,29 +308,35 @@ static int launch_dense(const float* IN, int ldin, const float* Wt, int K, int N
     const size_t lds = (size_t)((K + 3) & ~3) * 65 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_dense, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 65 * 4); attr_set = true; }
-    hipLaunchKernelGGL(k_dense, dim3((unsigned)ng, (unsigned)by), dim3(256), lds, s, IN, ldin, Wt, K, N, bias, relu, rows, OUT, ldo);
+    hipLaunchKernelGGL(k_dense, dim3((unsigned)ng, (unsigned)by), dim3(256), lds, s, IN, ldin, Wt, K, N, bias, relu, rows, OUT, ldo, plan, row0);
     return T2N_OK;
 }
 
 // features (already in feat32) -> X0 -> h0 -> h1 -> app_rgb. tiles_before[l] = 32-row tiles before sub-list l.
 int launch_head_forward(t2n_field* f, const unsigned tiles_before[kLists + 1], long long rows, const float* feat32, const float4* app_pos,
                         const int* app_ray, const float* rays, int ray_stride, const unsigned* counters, unsigned list_cap, float* x0,
-                        float* h0, float* h1, float4* app_rgb, hipStream_t s) {
+                        float* h0, float* h1, float4* app_rgb, hipStream_t s, const HeadPlanDev* plan, long long row0) {
     if (rows <= 0) return T2N_OK;
     const HeadDims H = head_dims(f->desc);
     const t2n_field_params* P = &f->params_ref;
     HeadInArgs a;
     a.H = H; a.feat32 = feat32; a.app_pos = app_pos; a.app_ray = app_ray; a.rays = rays; a.ray_stride = ray_stride;
-    a.ndc = f->dev.ztab ? 1 : 0; a.counters = counters; a.list_cap = list_cap; a.rows = rows; a.x0 = x0;
-    for (int l = 0; l <= kLists; ++l) a.tp.t[l] = tiles_before[l];
+    a.ndc = f->dev.ztab ? 1 : 0; a.counters = counters; a.list_cap = list_cap; a.rows = rows; a.x0 = x0; a.plan = plan; a.row0 = row0;
+    for (int l = 0; l <= kLists; ++l) a.tp.t[l] = tiles_before ? tiles_before[l] : 0u;
     const long long n = rows * H.K0pad;
     hipLaunchKernelGGL(k_head_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     int rc;
-    if ((rc = launch_dense(x0, H.K0pad, P->mlp_w0, H.K0, 128, P->mlp_b0, 1, rows, h0, 128, s))) return rc;
-    if ((rc = launch_dense(h0, 128, P->mlp_w1, 128, 128, P->mlp_b1, 1, rows, h1, 128, s))) return rc;
+    if ((rc = launch_dense(x0, H.K0pad, P->mlp_w0, H.K0, 128, P->mlp_b0, 1, rows, h0, 128, s, plan, row0))) return rc;
+    if ((rc = launch_dense(h0, 128, P->mlp_w1, 128, 128, P->mlp_b1, 1, rows, h1, 128, s, plan, row0))) return rc;
     Dense3Args d;
-    d.h1 = h1; d.w2 = P->mlp_w2; d.b2 = P->mlp_b2; d.counters = counters; d.list_cap = list_cap; d.tp = a.tp; d.rows = rows; d.app_rgb = app_rgb; d.app_pos = app_pos;
+    d.h1 = h1; d.w2 = P->mlp_w2; d.b2 = P->mlp_b2; d.counters = counters; d.list_cap = list_cap; d.tp = a.tp; d.rows = rows; d.app_rgb = app_rgb; d.app_pos = app_pos; d.plan = plan; d.row0 = row0;
     hipLaunchKernelGGL(k_dense3_sigmoid, dim3((unsigned)((rows * 4 + 255) / 256)), dim3(256), 0, s, d);
+    T2N_HIP(hipGetLastError());
+    return T2N_OK;
+}
+
+int launch_head_plan(const unsigned* counters, unsigned list_cap, HeadPlanDev* plan, hipStream_t s) {
+    hipLaunchKernelGGL(k_head_plan, dim3(1), dim3(64), 0, s, counters, list_cap, plan);
     T2N_HIP(hipGetLastError());
     return T2N_OK;
 }

@@ -118,6 +118,7 @@ struct t2n_field {
     bool uploaded = false;
     int timing = 0;
     int frame_w = 0;           // image width hint for the tile marcher (0: unknown)
+    int head_rows_per_ray = 32;   // general view-dependent heads: activation-scratch rows per ray a sub-launch reserves (t2n_field_set_head_scratch_rows)
     float term_eps = 0.f;      // early ray termination threshold of eval launches (t2n_field_set_early_termination; 0 = off)
     t2n::TimingSlot slots[T2N_K_COUNT];
     // optimistic (budgeted) render launches: the counters travel to pinned host memory behind the march kernels; the entries a
@@ -194,7 +195,7 @@ struct ShadeCtx { float* x144; float* feat32; float* h0; float* h1; };
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
                       const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s,
                       bool features_only = false, unsigned ctx_rows = 0xffffffffu, float* feat = nullptr, unsigned feat_rows = 0,
-                      uint64_t* stats = nullptr);
+                      uint64_t* stats = nullptr, unsigned tile_lo = 0, unsigned tile_hi = 0xffffffffu);   // tile_lo / tile_hi: the one-kernel paths cover these tiles only
 // feat / feat_rows: scratch rows for the two-kernel default path (features -> sample-stationary head, t2n_mlp_ss.hip); tiles
 // past the capacity take the one-kernel path. Word kRangeFlagWord of the counter block is the head's f16-range flag.
 constexpr int kRangeFlagWord = 32;
@@ -203,6 +204,7 @@ constexpr int kRangeFlagWord = 32;
 // the statement once it has consumed the rows (h0 / h1 are overwritten in place).
 constexpr int kKeptMagicWord = 33, kKeptRowsWord = 34;
 constexpr int kOverflowWord = 35;   // raised by the march kernels when a ray's appearance entries fit no sub-list (budgeted lists only)
+constexpr int kHeadPlanWord = 40;      // general view-dependent heads: the forward's device-side plan (HeadPlanDev, 10 words) lives here
 constexpr int kFailEntriesWord = 36;   // appearance entries of the rays that fit no sub-list (finished by k_finish_rays): the next budget counts them
 constexpr unsigned kKeptMagic = 0x4b455054u;   // "KEPT"
 int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev, unsigned list_cap, unsigned tile_hi, float4* app_rgb,
@@ -213,9 +215,13 @@ int launch_mlp_ss(t2n_field* f, const float* feat, const unsigned* counters_dev,
 struct HeadDims { int shading, C, fea_pe, view_pe, pos_pe, o_feat, o_view, o_pe_a, n_pe_a, o_pe_v, n_pe_v, K0, K0pad; };
 HeadDims head_dims(const t2n_field_desc& d);
 inline bool head_is_generic(int shading) { return shading == T2N_SHADE_MLP_FEA || shading == T2N_SHADE_MLP_PE || shading == T2N_SHADE_MLP; }
+struct HeadPlanDev { unsigned t[kLists + 1]; unsigned rows; };   // device-side plan of a general-head forward: tile prefix, row count
+int launch_head_plan(const unsigned* counters, unsigned list_cap, HeadPlanDev* plan, hipStream_t s);
+// plan == NULL: rows / tiles_before from the host (the backward's recompute). plan != NULL: one PASS over rows [row0, row0 + rows) of the
+// call, scratch row = row - row0, clipped to the plan's count on the device (tiles_before may be NULL)
 int launch_head_forward(t2n_field* f, const unsigned tiles_before[kLists + 1], long long rows, const float* feat32, const float4* app_pos,
                         const int* app_ray, const float* rays, int ray_stride, const unsigned* counters, unsigned list_cap, float* x0,
-                        float* h0, float* h1, float4* app_rgb, hipStream_t s);
+                        float* h0, float* h1, float4* app_rgb, hipStream_t s, const HeadPlanDev* plan = nullptr, long long row0 = 0);
 int launch_head_in_bwd(t2n_field* f, const float* gx, const float* feat32, long long rows, float* gf, hipStream_t s);
 // backward of the parameter-free SH / RGB heads: dL/dfeatures rows from the per-sample colour gradients (t2n_heads.hip)
 // Several small device-side initialisations as ONE launch (every hipMemsetAsync / hipMemsetD32Async is a 5-us kernel of its own on the

@@ -1625,12 +1625,12 @@ static bool use_ws(const t2n_field* f) {
 
 int launch_shade_list(t2n_field* f, const float4* app_pos, const int* app_ray, const float* rays, int ray_stride,
                       const unsigned* counters_dev, unsigned list_cap, float4* app_rgb, const ShadeCtx* ctx, hipStream_t s,
-                      bool features_only, unsigned ctx_rows, float* feat, unsigned feat_rows, uint64_t* stats) {
+                      bool features_only, unsigned ctx_rows, float* feat, unsigned feat_rows, uint64_t* stats, unsigned tile_lo, unsigned tile_hi) {
     ShadeArgs a;
     memset(&a, 0, sizeof(a));
     if (ctx) a.ctx = *ctx;
     a.ctx_rows = ctx_rows;
-    a.tile_lo = 0; a.tile_hi = 0xffffffffu;
+    a.tile_lo = tile_lo; a.tile_hi = tile_hi;
     a.F = f->dev;
     if (features_only) a.F.shading = T2N_SHADE_RGB;   // gather + basis only; the rgb slots get placeholder values the head overwrites
     a.app_pos = app_pos; a.app_ray = app_ray; a.rays = rays; a.ray_stride = ray_stride;

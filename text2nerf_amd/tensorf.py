@@ -799,6 +799,7 @@ class TensorBase(nn.Module):
             self._term_set = None
             self._storage_set = None
             self._frame_w_set = None
+            self._head_rows_set = 32
             self._alpha_key = "unset"
         queued = False     # device work queued by this call (mask / parameter uploads)
         mask = self.alphaMask
@@ -819,6 +820,10 @@ class TensorBase(nn.Module):
                                                             _lib.current_stream_ptr(dev)), "t2n_field_set_alpha_mask")
                     object.__setattr__(mask, "_field", self)   # plain attribute: a Module attribute would register a cycle
             self._alpha_key = mkey
+        hr = int(getattr(self, "head_scratch_rows_per_ray", 32))
+        if getattr(self, "_head_rows_set", 32) != hr:
+            _lib.check(lib.t2n_field_set_head_scratch_rows(self._handle, hr), "t2n_field_set_head_scratch_rows")
+            self._head_rows_set = hr
         fw = int(self.frame_width if frame_width is None else frame_width)
         if getattr(self, "_frame_w_set", None) != fw:
             _lib.check(lib.t2n_field_set_frame_width(self._handle, fw), "t2n_field_set_frame_width")
@@ -1141,7 +1146,8 @@ class TensorBase(nn.Module):
             # only costs that recompute)
             rows_hint = int(getattr(self, "_ctx_rows_hint", 0))
             rows_hint = _ladder(rows_hint) // 32 * 32 if rows_hint else 0     # (a few distinct sizes over a run: the allocator reuses its blocks)
-            need = int(lib.t2n_render_workspace_bytes_ctx(R, N)) + (256 + rows_hint * 1728 if rows_hint else 0)
+            need = int(lib.t2n_render_workspace_bytes_ctx(R, N)) + (256 + rows_hint * 1728 if rows_hint else 0) \
+                + int(lib.t2n_render_head_scratch_bytes(h, R))       # (general view-dependent heads: activation scratch behind the context)
             self._ctx_rows_cap = rows_hint
             if reuse_ctx:
                 # train_step: the step's backward is queued before the next step's forward, so ONE retained buffer serves every step
@@ -1158,12 +1164,12 @@ class TensorBase(nn.Module):
                 ws = torch.empty(need, dtype=torch.uint8, device=dev)
             flags |= FLAG_KEEP_CTX
         else:
-            need = int(lib.t2n_render_workspace_bytes(max(R, 1), N))
+            need = int(lib.t2n_render_workspace_bytes(max(R, 1), N)) + int(lib.t2n_render_head_scratch_bytes(h, max(R, 1)))
             if flags & FLAG_COHERENT:
                 # image-ordered frames: lists budgeted from what the previous frame needed instead of the worst case (the library
                 # checks the march kernels' counters and redoes an overflowed frame with worst-case lists)
                 need = min(need, int(lib.t2n_render_workspace_bytes_hint(h, max(R, 1), N)))
-            ws = workspace(dev, min(need, max(workspace_budget(dev), int(lib.t2n_render_workspace_bytes(1024, N)))))
+            ws = workspace(dev, min(need, max(workspace_budget(dev), int(lib.t2n_render_workspace_bytes(1024, N)) + int(lib.t2n_render_head_scratch_bytes(h, 1024)))))
             if getattr(self, "workspace_bytes_override", None):    # tests: hand the call exactly this much of the buffer
                 ws = workspace(dev, int(self.workspace_bytes_override))[:int(self.workspace_bytes_override)]
         with torch.cuda.device(dev):
