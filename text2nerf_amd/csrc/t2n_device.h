@@ -221,6 +221,12 @@ __device__ __forceinline__ float4 bf16x4_to_f4(uint2 u) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
                        __uint_as_float(u.y & 0xffff0000u));
 }
+// a[23:0] * b[23:0] + c as ONE full-rate instruction (the compiler turns the plain expression into v_mul_lo_u32 / v_mad_u64_u32, quarter rate)
+__device__ __forceinline__ unsigned umad24(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 // HALF: the factor set is read from its bf16 copy (8-B quads, half the bytes through the texture addresser / L1).
 template <int K, bool HALF = false>
 __device__ __forceinline__ void issue_taps_ax(const FactorSet& S, int CQ, int q, const Axes3& A, QuadTaps& t) {
@@ -232,8 +238,8 @@ __device__ __forceinline__ void issue_taps_ax(const FactorSet& S, int CQ, int q,
     constexpr unsigned QB = HALF ? 8u : 16u;
     const unsigned tb = (unsigned)CQ * QB, qb = (unsigned)q * QB;
     // 24-bit multiplies: full-rate VALU ops (v_mul_lo_u32 is quarter rate); tap indices and widths are < 2^24
-    const unsigned r0 = __umul24((unsigned)ay.i0, W), r1 = __umul24((unsigned)ay.i1, W);
     if constexpr (HALF) {
+        const unsigned r0 = __umul24((unsigned)ay.i0, W), r1 = __umul24((unsigned)ay.i1, W);
         const char* __restrict__ P = reinterpret_cast<const char*>(S.plane_h[K]);
         const char* __restrict__ Ln = reinterpret_cast<const char*>(S.line_h[K]);
         const uint2 nw = *reinterpret_cast<const uint2*>(P + ((r0 + (unsigned)ax.i0) * tb + qb));
@@ -247,12 +253,14 @@ __device__ __forceinline__ void issue_taps_ax(const FactorSet& S, int CQ, int q,
     } else {
         const char* __restrict__ P = reinterpret_cast<const char*>(S.plane[K]);
         const char* __restrict__ Ln = reinterpret_cast<const char*>(S.line[K]);
-        t.nw = *reinterpret_cast<const float4*>(P + ((r0 + (unsigned)ax.i0) * tb + qb));
-        t.ne = *reinterpret_cast<const float4*>(P + ((r0 + (unsigned)ax.i1) * tb + qb));
-        t.sw = *reinterpret_cast<const float4*>(P + ((r1 + (unsigned)ax.i0) * tb + qb));
-        t.se = *reinterpret_cast<const float4*>(P + ((r1 + (unsigned)ax.i1) * tb + qb));
-        t.l0 = *reinterpret_cast<const float4*>(Ln + ((unsigned)al.i0 * tb + qb));
-        t.l1 = *reinterpret_cast<const float4*>(Ln + ((unsigned)al.i1 * tb + qb));
+        // (texel index < 2^24 — grids up to 4096^2 — and texel bytes < 2^24: v_mad_u32_u24, a full-rate op; the plain 32-bit multiply-add
+        // compiles to v_mad_u64_u32)
+        t.nw = *reinterpret_cast<const float4*>(P + umad24(umad24((unsigned)ay.i0, W, (unsigned)ax.i0), tb, qb));
+        t.ne = *reinterpret_cast<const float4*>(P + umad24(umad24((unsigned)ay.i0, W, (unsigned)ax.i1), tb, qb));
+        t.sw = *reinterpret_cast<const float4*>(P + umad24(umad24((unsigned)ay.i1, W, (unsigned)ax.i0), tb, qb));
+        t.se = *reinterpret_cast<const float4*>(P + umad24(umad24((unsigned)ay.i1, W, (unsigned)ax.i1), tb, qb));
+        t.l0 = *reinterpret_cast<const float4*>(Ln + umad24((unsigned)al.i0, tb, qb));
+        t.l1 = *reinterpret_cast<const float4*>(Ln + umad24((unsigned)al.i1, tb, qb));
     }
     t.wnw = ay.w0 * ax.w0; t.wne = ay.w0 * ax.w1; t.wsw = ay.w1 * ax.w0; t.wse = ay.w1 * ax.w1;
     t.wl0 = al.w0; t.wl1 = al.w1;
@@ -273,15 +281,14 @@ __device__ __forceinline__ void issue_taps_ax_changed(const FactorSet& S, int CQ
     const char* __restrict__ P = reinterpret_cast<const char*>(S.plane[K]);
     const char* __restrict__ Ln = reinterpret_cast<const char*>(S.line[K]);
     if (plane_changed) {
-        const unsigned r0 = __umul24((unsigned)ay.i0, W), r1 = __umul24((unsigned)ay.i1, W);
-        t.nw = *reinterpret_cast<const float4*>(P + ((r0 + (unsigned)ax.i0) * tb + qb));
-        t.ne = *reinterpret_cast<const float4*>(P + ((r0 + (unsigned)ax.i1) * tb + qb));
-        t.sw = *reinterpret_cast<const float4*>(P + ((r1 + (unsigned)ax.i0) * tb + qb));
-        t.se = *reinterpret_cast<const float4*>(P + ((r1 + (unsigned)ax.i1) * tb + qb));
+        t.nw = *reinterpret_cast<const float4*>(P + umad24(umad24((unsigned)ay.i0, W, (unsigned)ax.i0), tb, qb));
+        t.ne = *reinterpret_cast<const float4*>(P + umad24(umad24((unsigned)ay.i0, W, (unsigned)ax.i1), tb, qb));
+        t.sw = *reinterpret_cast<const float4*>(P + umad24(umad24((unsigned)ay.i1, W, (unsigned)ax.i0), tb, qb));
+        t.se = *reinterpret_cast<const float4*>(P + umad24(umad24((unsigned)ay.i1, W, (unsigned)ax.i1), tb, qb));
     }
     if (line_changed) {
-        t.l0 = *reinterpret_cast<const float4*>(Ln + ((unsigned)al.i0 * tb + qb));
-        t.l1 = *reinterpret_cast<const float4*>(Ln + ((unsigned)al.i1 * tb + qb));
+        t.l0 = *reinterpret_cast<const float4*>(Ln + umad24((unsigned)al.i0, tb, qb));
+        t.l1 = *reinterpret_cast<const float4*>(Ln + umad24((unsigned)al.i1, tb, qb));
     }
     t.wnw = ay.w0 * ax.w0; t.wne = ay.w0 * ax.w1; t.wsw = ay.w1 * ax.w0; t.wse = ay.w1 * ax.w1;
     t.wl0 = al.w0; t.wl1 = al.w1;

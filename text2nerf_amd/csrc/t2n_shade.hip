@@ -908,7 +908,7 @@ __device__ __forceinline__ void gather_pair(const FactorSet& S, float* __restric
         auto first = [&](int p, QuadTaps& t, int& s_, int& q_, int& ca_, int& cb_, int& cl_) {
             const int item = p * 64 + lane;
             const int j = item / 12;
-            q_ = item - j * 12; s_ = 2 * j;
+            q_ = item - (int)__umul24((unsigned)j, 12u); s_ = 2 * j;
             const Axes3 A = parked_axes(S, P, s_);
             ca_ = A.a[mat0(K)].i0; cb_ = A.a[mat1(K)].i0; cl_ = A.a[vecm(K)].i0;
             issue_taps_ax<K, false>(S, 12, q_, A, t);
@@ -920,6 +920,10 @@ __device__ __forceinline__ void gather_pair(const FactorSet& S, float* __restric
             issue_taps_ax_changed<K>(S, 12, q_, A, pc, lc, t);
         };
         auto consume = [&](const QuadTaps& t, int s_, int q_) {
+            // (round 6: the same 28 multiply / fma per item as 14 packed-fp32 operations — v_pk_mul_f32 / v_pk_fma_f32 — took 15.6 % of the
+            // tile loop's VALU instructions away and NOTHING off the kernel's time: 0.572 against 0.574 ms, it waits for the texture
+            // addresser; that build's rows also differed from run to run at the 1e-6 level for a reason not found, so it is not kept:
+            // profiles/round6_features_count_table.txt)
             const float4 pv = taps_plane(t), l = taps_line(t);
             float4 v = make_float4(pv.x * l.x, pv.y * l.y, pv.z * l.z, pv.w * l.w);
             if (!((unsigned)s_ < nlive)) v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1043,6 +1047,7 @@ __global__ __launch_bounds__(64 * kPairWaves) __attribute__((amdgpu_waves_per_eu
     float4 mine, nmine;
     locate(blockIdx.x * (unsigned)kPairWaves + wid, base, nlive, mine);
     for (unsigned tile = blockIdx.x * (unsigned)kPairWaves + wid; tile < ntiles; tile += wave_stride, base = nbase, nlive = nnlive, mine = nmine) {
+        asm volatile("; FEATP_MARK tile_begin");   // (tools/featp_count_table.py: the tile loop's instructions by mnemonic)
         if (lane < 32) {   // (dead entries sit at the volume centre: in the box like every list entry)
             const Axes3 A = sample_axes_inbox(F.app, mine.x, mine.y, mine.z);
             // list slots that were reserved but never written (a budgeted launch that overflowed: this kernel is already queued when
@@ -1076,6 +1081,7 @@ __global__ __launch_bounds__(64 * kPairWaves) __attribute__((amdgpu_waves_per_eu
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(row + 8 * g) = make_float4(accb[4 * g], accb[4 * g + 1], accb[4 * g + 2], (g == 3 && h == 0) ? wgt : accb[4 * g + 3]);
         wave_lds_sync();   // X and P reads done before the next tile overwrites them
+        asm volatile("; FEATP_MARK tile_end");
     }
     if (a.range_flag && __any(!(amax <= 60000.f)) && lane == 0) atomicOr(a.range_flag, 1u);
 }
