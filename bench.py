@@ -438,6 +438,37 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
             "train_appearance_samples": field.stats()["appearance"]}
 
 
+def general_shape_ms(dev, G=128, H=400):
+    """One eval frame of a WIDE field on the general-shape path (csrc/t2n_generic.hip: [32,20,24] density / [96,64,72] appearance
+    components, featureC 256 — beyond the tuned kernels' 16 / 48 / 128) through the reference's call, next to the tuned shape on the
+    same 128^3 grid and 400 x 400 camera: what leaving the tuned shape costs."""
+    from text2nerf_amd import TensorVMSplit, OctreeRender_trilinear_fast, synth
+    aabb, nf = [[-8.0, -6.0, -7.0], [8.0, 7.0, 6.5]], [0.5, 8.0]
+    rays = torch.from_numpy(synth.frame_rays_np(H, H, c2w=synth.look_pose(0.3, -0.1, (0.2, 0.1, -1.0)))).to(dev)
+    out = {}
+    for tag, dn, an, fc in (("tuned_16_48_128", [16] * 3, [48] * 3, 128), ("wide_32.20.24_96.64.72_256", [32, 20, 24], [96, 64, 72], 256)):
+        params = synth.make_field_params(11, [G] * 3, density_n_comp=dn, app_n_comp=an, app_dim=27, feature_c=fc, fea_pe=6,
+                                         shading_mode="MLP_Fea_noview", density_scale=0.9, aabb=aabb)
+        m = TensorVMSplit(torch.tensor(aabb), [G] * 3, dev, density_n_comp=dn, appearance_n_comp=an, app_dim=27, near_far=nf,
+                          shadingMode="MLP_Fea_noview", density_shift=-10, distance_scale=25, pos_pe=0, view_pe=0, fea_pe=6, featureC=fc,
+                          step_ratio=1.0, fea2denseAct="softplus")
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+        with torch.no_grad():
+            for _ in range(2):
+                OctreeRender_trilinear_fast(rays, m, chunk=65536, N_samples=-1, white_bg=True, is_train=False, device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                OctreeRender_trilinear_fast(rays, m, chunk=65536, N_samples=-1, white_bg=True, is_train=False, device=dev)
+            torch.cuda.synchronize()
+        out[tag] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        out["n_samples"] = int(m.nSamples)
+        del m
+    out["ratio"] = round(out["wide_32.20.24_96.64.72_256"] / max(out["tuned_16_48_128"], 1e-9), 1)
+    out["frame"] = f"{G}^3 grid, {H} x {H} rays, ms per frame; round 5's plain form of the general path: 3 396 ms (profiles/round6_general_path.txt)"
+    return out
+
+
 def dropin_eval_ms(field, dev, H, W, n=12):
     """The reference's own evaluation call, unchanged (renderer.py:85-89): ALL rays of one image as a HOST tensor into
     OctreeRender_trilinear_fast(rays, tensorf, chunk=..., N_samples=-1, ...) — H2D through the pinned ring, raster width detected
@@ -1161,6 +1192,10 @@ def main():
                 out["config"]["dropin_eval_call_ms"] = dropin_eval_ms(field, dev, H, W)
             except Exception as e:  # noqa: BLE001
                 out["config"]["dropin_eval_call_ms"] = {"error": repr(e)[:300]}
+            try:
+                out["config"]["general_shape_ms"] = general_shape_ms(dev)
+            except Exception as e:  # noqa: BLE001
+                out["config"]["general_shape_ms"] = {"error": repr(e)[:300]}
         if not grouped and not args.no_train:
             # the fused step first, from a clean allocator: its peak reserved memory is the train figure (the render legs above
             # leave 2.65-GB weight tensors and worst-case workspaces in torch's cache)

@@ -260,6 +260,10 @@ typedef struct t2n_generic_desc {
     float density_shift, distance_scale, weight_thres, step_size, near, far, z_gate;
 } t2n_generic_desc;
 size_t t2n_generic_workspace_bytes(int64_t n_rays, int n_samples);
+/* the same + room for channel-last staging copies of the factor tensors and the appearance-sample list: with this much workspace the
+ * FORWARD runs as cooperative kernels (thread per sample for the density, a workgroup per 64 appearance samples for features + head)
+ * instead of the plain form — 1 500 x per sample apart on a wide 128^3 field. Same outputs and context; the backward is unchanged. */
+size_t t2n_generic_workspace_bytes_desc(const t2n_generic_desc* desc, int64_t n_rays, int n_samples);
 int t2n_generic_forward(const t2n_generic_desc* desc, const t2n_field_params* params, const float* rays, int64_t n_rays, int ray_stride,
                         int n_samples, uint32_t flags, const float* jitter, float* rgb, float* depth, float* weights, float* z_vals,
                         uint64_t* stats, void* workspace, size_t workspace_bytes, t2n_stream stream);

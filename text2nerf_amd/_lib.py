@@ -161,6 +161,7 @@ SIGNATURES = {
     "t2n_upsample_bilinear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "t2n_filter_rays_alpha": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "t2n_generic_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "t2n_generic_workspace_bytes_desc": (C.c_size_t, [C.POINTER(GenericDesc), C.c_int64, C.c_int]),
     "t2n_generic_forward": (C.c_int, [C.POINTER(GenericDesc), C.POINTER(FieldParams), C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_uint32,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_void_p]),

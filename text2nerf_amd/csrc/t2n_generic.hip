@@ -7,6 +7,8 @@
 //
 // Replaces: models/tensorBase.py:304-323 (sample_ray), :436-507 (forward), :19-26 (raw2alpha), :406-410 (feature2density), :11-17 +
 // :62-159 (the heads), :29-39 (SH / RGB), models/tensoRF.py:205-239 (compute_densityfeature / compute_appfeature), and their autograd.
+#include <stdlib.h>
+
 #include "t2n_device.h"
 
 namespace t2n {
@@ -342,6 +344,292 @@ __global__ __launch_bounds__(64) void k_gen_bwd_march(const GenArgs a) {
     }
 }
 
+// =====================================================================================================================================
+// The forward as kernels (round 6; the backward above stays the plain restatement): what made the first form 1 500 x slower than the tuned
+// path per sample was its shape, not its arithmetic — one THREAD walked a whole ray (2 500 waves for a 400 x 400 frame) reading
+// [1, C, H, W] factors one component per cache line, and one thread ran a whole MLP out of scratch memory. Here:
+//   k_gen_stage      the twelve factor tensors -> channel-last copies in the workspace ([pos][C]: a tap's components are contiguous)
+//   k_gen_sigma      one thread per (ray, sample): depth, box test, density feature (components in the reference's order: the same
+//                    sums as the plain form), sigma
+//   k_gen_scan       one thread per ray: transmittance / weights / opacity / depth from the sigmas
+//   k_gen_compact    the appearance samples (weight > threshold) -> an index list (wave-aggregated append)
+//   k_gen_head       one workgroup per 64 list entries: appearance features (each wave a quarter of the components, basis_mat from LDS),
+//                    then the head — MLP layers as [units of this wave] x [64 samples] outer products on the VALU with the weights as
+//                    wave-uniform (scalar) operands and the activations in LDS; SH / RGB per sample
+// Taken when the workspace has room for the staged copies and the list (t2n_generic_workspace_bytes_desc); same outputs and context as
+// the plain form (the backward reads them), values equal to rounding (the density sums are bit-identical).
+struct GenFast {
+    const float* dp[3]; const float* dl[3]; const float* ap[3]; const float* al[3];   // channel-last copies
+    int* list; unsigned* count; unsigned cap;
+    int ncol;
+    const float* w0p; const float* w1p; int ld0, ld1;   // MLP weights with rows padded to multiples of 16 floats (64-byte aligned rows: s_load_dwordx16)
+};
+__global__ __launch_bounds__(256) void k_gen_padrows(const float* __restrict__ src, float* __restrict__ dst, int rows, int n, int ld) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)rows * ld) return;
+    const int r = (int)(t / ld), j = (int)(t - (long long)r * ld);
+    dst[t] = j < n ? src[(size_t)r * n + j] : 0.f;
+}
+struct GenStageArgs { const float* src[12]; float* dst[12]; int C[12]; long long HW[12]; unsigned block0[13]; };
+__global__ __launch_bounds__(256) void k_gen_stage(const GenStageArgs a) {
+    __shared__ float tile[64][65];
+    int t = 0;
+#pragma unroll 1
+    for (int q = 1; q < 12; ++q) t += (a.block0[q] <= blockIdx.x) ? 1 : 0;
+    const int C = a.C[t];
+    const long long HW = a.HW[t];
+    const int cb = (C + 63) / 64;                       // channel blocks of 64
+    const unsigned b = blockIdx.x - a.block0[t];
+    const long long p0 = (long long)(b / cb) * 64;
+    const int c0 = (int)(b % cb) * 64;
+    const int lp = threadIdx.x & 63, q4 = threadIdx.x >> 6;
+    for (int c = q4; c < 64; c += 4)
+        tile[c][lp] = (c0 + c < C && p0 + lp < HW) ? a.src[t][(long long)(c0 + c) * HW + p0 + lp] : 0.f;
+    __syncthreads();
+    for (int pp = q4; pp < 64; pp += 4)
+        if (c0 + lp < C && p0 + pp < HW) a.dst[t][(p0 + pp) * C + c0 + lp] = tile[lp][pp];
+}
+// plane / line value of component c from the channel-last copies (same expressions as gen_plane / gen_line)
+__device__ __forceinline__ float gen_density_feature_cl(const GenArgs& a, const GenFast& fa, const Tap3& t) {
+    float feat = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        const int W = a.grid[mat0(k)], C = a.Cd[k];
+        const Axis& ax = t.a[mat0(k)]; const Axis& ay = t.a[mat1(k)]; const Axis& al = t.a[vecm(k)];
+        const float* __restrict__ p00 = fa.dp[k] + ((size_t)ay.i0 * W + ax.i0) * C;
+        const float* __restrict__ p01 = fa.dp[k] + ((size_t)ay.i0 * W + ax.i1) * C;
+        const float* __restrict__ p10 = fa.dp[k] + ((size_t)ay.i1 * W + ax.i0) * C;
+        const float* __restrict__ p11 = fa.dp[k] + ((size_t)ay.i1 * W + ax.i1) * C;
+        const float* __restrict__ l0 = fa.dl[k] + (size_t)al.i0 * C;
+        const float* __restrict__ l1 = fa.dl[k] + (size_t)al.i1 * C;
+        const float w00 = ay.w0 * ax.w0, w01 = ay.w0 * ax.w1, w10 = ay.w1 * ax.w0, w11 = ay.w1 * ax.w1;
+        for (int c = 0; c < C; ++c) {
+            float v = p00[c] * w00;
+            v = fmaf(p01[c], w01, v); v = fmaf(p10[c], w10, v); v = fmaf(p11[c], w11, v);
+            feat = fmaf(v, fmaf(l1[c], al.w1, l0[c] * al.w0), feat);
+        }
+    }
+    return feat;
+}
+__global__ __launch_bounds__(256) void k_gen_sigma(const GenArgs a, const GenFast fa) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a.N;
+    if (t >= a.n_rays * N) return;
+    const long long r = t / N;
+    const int i = (int)(t - r * N);
+    const Ray ray = load_ray(a.F, a.rays + r * a.ray_stride, a.ray_stride);
+    const float u = a.train ? a.jitter[r] : 0.f;
+    const float z = gen_z(a, ray, i, u);
+    float xn, yn, zn;
+    float sg = 0.f;
+    const bool ok = gen_point(a, ray, z, xn, yn, zn);
+    if (ok) sg = feature2density(a.F, gen_density_feature_cl(a, fa, gen_taps(a, xn, yn, zn)));
+    a.z[t] = z; a.sigma[t] = sg;
+    a.T[t] = ok ? 1.f : 0.f;      // (in-box flag for the scan's statistics; overwritten there)
+}
+__global__ __launch_bounds__(64) void k_gen_scan(const GenArgs a) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_rays) return;
+    const Ray ray = load_ray(a.F, a.rays + r * a.ray_stride, a.ray_stride);
+    const int N = a.N;
+    float T = 1.f, acc = 0.f, dep = 0.f;
+    unsigned long long nev = 0, napp = 0;
+    float z = a.z[r * N];
+    for (int i = 0; i < N; ++i) {
+        const float zn = i < N - 1 ? a.z[r * N + i + 1] : z;
+        const float sg = a.sigma[r * N + i];
+        nev += a.T[r * N + i] != 0.f ? 1u : 0u;
+        const float dist = i < N - 1 ? zn - z : 0.f;
+        const float alpha = 1.f - expf((-sg) * (dist * a.F.dscale));
+        const float w = alpha * T;
+        a.T[r * N + i] = T; a.w[r * N + i] = w;
+        T = T * ((1.f - alpha) + 1e-10f);
+        acc += w;
+        dep = fmaf(w, z, dep);
+        napp += (w > a.F.thres) ? 1u : 0u;
+        z = zn;
+    }
+    a.acc[r] = acc;
+    a.depth[r] = dep + (1.f - acc) * ray.last;
+    if (a.stats) { atomicAdd(&a.stats[T2N_STAT_EVALUATED], nev); atomicAdd(&a.stats[T2N_STAT_APPEARANCE], napp); }
+}
+__global__ __launch_bounds__(256) void k_gen_compact(const GenArgs a, const GenFast fa) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool app = t < a.n_rays * a.N && a.w[t] > a.F.thres;
+    const unsigned long long bal = __ballot(app);
+    if (!bal) return;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(fa.count, (unsigned)__popcll(bal));
+    base = __shfl(base, 0);
+    if (app) fa.list[base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (int)t;
+}
+// column j of the MLP input row (gen_inputs' order) for features `feat` (LDS column of sample s: stride 64) and direction dir
+__device__ __forceinline__ float gen_input_col(const GenArgs& a, const float* __restrict__ feat_s, const float* dir, int j) {
+    const int D = a.app_dim;
+    const bool view = a.shading != T2N_SHADE_MLP_FEA_NOVIEW;
+    if (j < D) return feat_s[j * 64];
+    j -= D;
+    if (view) { if (j < 3) return dir[j]; j -= 3; }
+    const int fpe = a.shading == T2N_SHADE_MLP ? 0 : a.fea_pe;
+    if (j < 2 * fpe * D) {
+        const bool cs = j >= fpe * D;
+        if (cs) j -= fpe * D;
+        const int f = j / fpe, o = j - f * fpe;
+        const float tt = feat_s[f * 64] * (float)(1 << o);
+        return cs ? cosf(tt) : sinf(tt);
+    }
+    j -= 2 * fpe * D;
+    const bool cs = j >= 3 * a.view_pe;
+    if (cs) j -= 3 * a.view_pe;
+    const int d = j / a.view_pe, o = j - d * a.view_pe;
+    const float tt = dir[d] * (float)(1 << o);
+    return cs ? cosf(tt) : sinf(tt);
+}
+constexpr int kGenUnitsPerWave = kGenHidMax / 4;   // 64
+// wave-uniform weight reads through the CONSTANT address space: the backend then issues scalar loads (s_load_dwordx16 into SGPRs, the FMAs
+// take them as scalar operands); through a plain global pointer every weight was a 64-lane vector load of one address — 2 216 of them in
+// the head kernel, which made it load-issue-bound
+typedef const float __attribute__((address_space(4))) * cfp_t;
+__device__ __forceinline__ cfp_t as_const(const float* p) { return (cfp_t)(uintptr_t)p; }
+// one dense layer for the workgroup's 64 samples: out unit v = 4 u + g (wave g) of `nout`, inputs X[j][s] (LDS, relu'd if relu_in) for
+// j < nin, weights row-major [nout][nin] read wave-uniformly. acc[u] holds unit 4 u + g of sample s.
+// W: rows padded to `ld` floats (a multiple of 16, zero beyond nin), 64-byte aligned
+template <class XF>
+__device__ __forceinline__ void gen_layer(float (&acc)[kGenUnitsPerWave], const float* __restrict__ W, const float* __restrict__ b, int nin, int ld, int nout,
+                                          int g, XF&& xchunk) {
+#pragma unroll
+    for (int u = 0; u < kGenUnitsPerWave; ++u) { const int v = 4 * u + g; acc[u] = v < nout ? b[v] : 0.f; }
+    for (int j0 = 0; j0 < nin; j0 += 16) {
+        float x[16];
+        xchunk(j0, x);                                   // x[e] = input j0 + e of this lane's sample (0 beyond nin)
+#pragma unroll
+        for (int u = 0; u < kGenUnitsPerWave; ++u) {
+            const int v = 4 * u + g;
+            if (v < nout) {                              // (wave-uniform)
+                const cfp_t wr = as_const((const float*)__builtin_assume_aligned(W + (size_t)v * ld + j0, 64));
+                float s_ = acc[u];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s_ = fmaf(wr[e], x[e], s_);
+                acc[u] = s_;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast fa) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int D = a.app_dim, ncol = fa.ncol, fC = a.fC;
+    float* __restrict__ basisT = sm;                                  // [ncol][D]
+    float* __restrict__ feat = basisT + (size_t)ncol * D;             // [D][64]
+    float* __restrict__ Xc = feat + D * 64;                           // [16][64] input chunk
+    float* __restrict__ Hb = Xc + 16 * 64;                            // [max(4 D, fC)][64]: feature partials, then activations
+    const int tid = threadIdx.x, s = tid & 63, g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < ncol * D; i += 256) { const int col = i / D, f = i - col * D; basisT[i] = a.basis[(size_t)f * ncol + col]; }
+    __syncthreads();
+    const unsigned count = *fa.count;
+    const unsigned ntiles = (count + 63u) / 64u;
+    const bool mlp = a.shading == T2N_SHADE_MLP_FEA_NOVIEW || a.shading == T2N_SHADE_MLP_FEA || a.shading == T2N_SHADE_MLP;
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const unsigned e = tile * 64u + (unsigned)s;
+        const bool live = e < count;
+        const long long t = fa.list[live ? e : tile * 64u];
+        const long long r = t / a.N;
+        const int i = (int)(t - r * a.N);
+        const float* __restrict__ rp = a.rays + r * a.ray_stride;
+        const Ray ray = load_ray(a.F, rp, a.ray_stride);
+        const float u = a.train ? a.jitter[r] : 0.f;
+        float xn, yn, zn;
+        gen_point(a, ray, gen_z(a, ray, i, u), xn, yn, zn);
+        const Tap3 tp = gen_taps(a, xn, yn, zn);
+        const float dir[3] = {rp[3], rp[4], rp[5]};
+        // ---- appearance features: wave g takes a quarter of every plane's components ---------------------------------------------------
+        {
+            float fp[kGenDimMax];
+#pragma unroll
+            for (int f = 0; f < kGenDimMax; ++f) fp[f] = 0.f;
+            int col0 = 0;
+            for (int k = 0; k < 3; ++k) {
+                const int W = a.grid[mat0(k)], C = a.Ca[k];
+                const Axis& ax = tp.a[mat0(k)]; const Axis& ay = tp.a[mat1(k)]; const Axis& al = tp.a[vecm(k)];
+                const float* __restrict__ p00 = fa.ap[k] + ((size_t)ay.i0 * W + ax.i0) * C;
+                const float* __restrict__ p01 = fa.ap[k] + ((size_t)ay.i0 * W + ax.i1) * C;
+                const float* __restrict__ p10 = fa.ap[k] + ((size_t)ay.i1 * W + ax.i0) * C;
+                const float* __restrict__ p11 = fa.ap[k] + ((size_t)ay.i1 * W + ax.i1) * C;
+                const float* __restrict__ l0 = fa.al[k] + (size_t)al.i0 * C;
+                const float* __restrict__ l1 = fa.al[k] + (size_t)al.i1 * C;
+                const float w00 = ay.w0 * ax.w0, w01 = ay.w0 * ax.w1, w10 = ay.w1 * ax.w0, w11 = ay.w1 * ax.w1;
+                const int per = (C + 3) / 4, cb = g * per, ce = min(C, cb + per);
+                for (int c = cb; c < ce; ++c) {
+                    float v = p00[c] * w00;
+                    v = fmaf(p01[c], w01, v); v = fmaf(p10[c], w10, v); v = fmaf(p11[c], w11, v);
+                    const float xv = v * fmaf(l1[c], al.w1, l0[c] * al.w0);
+                    const float* __restrict__ bt = basisT + (size_t)(col0 + c) * D;
+#pragma unroll
+                    for (int f = 0; f < kGenDimMax; ++f) if (f < D) fp[f] = fmaf(bt[f], xv, fp[f]);
+                }
+                col0 += C;
+            }
+#pragma unroll
+            for (int f = 0; f < kGenDimMax; ++f) if (f < D) Hb[(g * D + f) * 64 + s] = fp[f];
+        }
+        __syncthreads();
+        for (int f = g; f < D; f += 4) feat[f * 64 + s] = (Hb[f * 64 + s] + Hb[(D + f) * 64 + s]) + (Hb[(2 * D + f) * 64 + s] + Hb[(3 * D + f) * 64 + s]);
+        __syncthreads();
+        float c3[3] = {0.f, 0.f, 0.f};
+        if (!mlp) {
+            if (g == 0 && live) {
+                if (a.shading == T2N_SHADE_RGB) { c3[0] = feat[s]; c3[1] = feat[64 + s]; c3[2] = feat[128 + s]; }
+                else {
+                    float sh[9];
+                    gen_sh9(dir, sh);
+                    for (int c = 0; c < 3; ++c) {
+                        float q = 0.f;
+                        for (int b = 0; b < 9; ++b) q = fmaf(sh[b], feat[(c * 9 + b) * 64 + s], q);
+                        c3[c] = fmaxf(q + 0.5f, 0.f);
+                    }
+                }
+                a.rgb_s[t * 3] = c3[0]; a.rgb_s[t * 3 + 1] = c3[1]; a.rgb_s[t * 3 + 2] = c3[2];
+            }
+            __syncthreads();
+            continue;
+        }
+        // ---- layer 0: the input row in chunks of 16 columns (each wave makes 4 of them, LDS), all waves multiply -------------------------
+        float acc[kGenUnitsPerWave];
+        const int nin = a.in0;
+        gen_layer(acc, fa.w0p, a.b0, nin, fa.ld0, fC, g, [&](int j0, float (&x)[16]) {
+            __syncthreads();                                            // the previous chunk has been read
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int j = j0 + 4 * g + q; Xc[(4 * g + q) * 64 + s] = j < nin ? gen_input_col(a, feat + s, dir, j) : 0.f; }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = Xc[e * 64 + s];
+        });
+        __syncthreads();
+#pragma unroll
+        for (int uu = 0; uu < kGenUnitsPerWave; ++uu) { const int v = 4 * uu + g; if (v < fC) Hb[v * 64 + s] = fmaxf(acc[uu], 0.f); }
+        __syncthreads();
+        // ---- layer 1 ------------------------------------------------------------------------------------------------------------------
+        gen_layer(acc, fa.w1p, a.b1, fC, fa.ld1, fC, g, [&](int j0, float (&x)[16]) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = j0 + e < fC ? Hb[(j0 + e) * 64 + s] : 0.f;
+        });
+        __syncthreads();                                                // every wave has read h0
+#pragma unroll
+        for (int uu = 0; uu < kGenUnitsPerWave; ++uu) { const int v = 4 * uu + g; if (v < fC) Hb[v * 64 + s] = fmaxf(acc[uu], 0.f); }
+        __syncthreads();
+        // ---- layer 2 + sigmoid (wave 0) -----------------------------------------------------------------------------------------------
+        if (g == 0 && live) {
+            float o[3] = {a.b2[0], a.b2[1], a.b2[2]};
+            const cfp_t w2 = as_const(a.w2);
+            for (int v = 0; v < fC; ++v) {
+                const float hv = Hb[v * 64 + s];
+                o[0] = fmaf(w2[v], hv, o[0]); o[1] = fmaf(w2[fC + v], hv, o[1]); o[2] = fmaf(w2[2 * fC + v], hv, o[2]);
+            }
+            for (int c = 0; c < 3; ++c) a.rgb_s[t * 3 + c] = 1.f / (1.f + expf(-o[c]));
+        }
+        __syncthreads();
+    }
+}
+
 static int gen_fill(GenArgs& a, const t2n_generic_desc* d, const t2n_field_params* p, const char* who) {
     if (!d || !p) { set_error("%s: NULL argument", who); return T2N_ERR_INVALID; }
     memset(&a, 0, sizeof(a));
@@ -388,9 +676,45 @@ static GenCarve gen_carve(int64_t R, int N, bool own_wz) {
     return c;
 }
 
+// staged (channel-last) factor copies + the appearance list behind the plain carve
+struct GenStageCarve { size_t t[12], list, count, w0p, w1p, total; };
+static GenStageCarve gen_stage_carve(const t2n_generic_desc* d, int64_t R, int N, size_t base) {
+    GenStageCarve c;
+    size_t o = (base + 255) / 256 * 256;
+    for (int q = 0; q < 4; ++q)
+        for (int k = 0; k < 3; ++k) {
+            const size_t HW = (size_t)d->grid[mat1(k)] * d->grid[mat0(k)], L = (size_t)d->grid[vecm(k)];
+            const size_t C = q < 2 ? (size_t)d->density_n_comp[k] : (size_t)d->app_n_comp[k];
+            c.t[q * 3 + k] = o;
+            o = (o + ((q & 1) ? L : HW) * C * 4 + 255) / 256 * 256;
+        }
+    c.list = o; o = (o + (size_t)R * N * 4 + 255) / 256 * 256;
+    c.count = o; o += 256;
+    // MLP weights, rows padded to 16 floats (in0 <= kGenInMax inputs; sized for the worst case of the limits so that the carve needs no head shape)
+    const size_t fc = (size_t)(d->feature_c > 0 ? d->feature_c : 1);
+    const int fpe = d->shading == T2N_SHADE_MLP ? 0 : d->fea_pe;
+    const size_t in0 = (size_t)d->app_dim * (1 + 2 * (fpe > 0 ? fpe : 0)) + (d->shading != T2N_SHADE_MLP_FEA_NOVIEW ? 3 + 6 * (size_t)(d->view_pe > 0 ? d->view_pe : 0) : 0);
+    c.w0p = o; o = (o + fc * ((in0 + 15) / 16 * 16) * 4 + 255) / 256 * 256;
+    c.w1p = o; o = (o + fc * ((fc + 15) / 16 * 16) * 4 + 255) / 256 * 256;
+    c.total = o;
+    return c;
+}
+static size_t gen_head_lds(const t2n_generic_desc* d) {
+    const size_t ncol = (size_t)d->app_n_comp[0] + d->app_n_comp[1] + d->app_n_comp[2], D = (size_t)d->app_dim;
+    const size_t hb = 4 * D > (size_t)d->feature_c ? 4 * D : (size_t)d->feature_c;
+    return (ncol * D + D * 64 + 16 * 64 + hb * 64) * sizeof(float);
+}
+
 }  // namespace t2n
 
 using namespace t2n;
+
+// with room for the channel-last staging of the factors and the appearance list: the forward then runs as the kernels of round 6
+// (k_gen_stage ... k_gen_head) instead of the plain per-ray / per-sample restatement
+extern "C" size_t t2n_generic_workspace_bytes_desc(const t2n_generic_desc* desc, int64_t n_rays, int n_samples) {
+    if (!desc || n_rays <= 0 || n_samples <= 0) return 0;
+    return gen_stage_carve(desc, n_rays, n_samples, gen_carve(n_rays, n_samples, true).total).total;
+}
 
 extern "C" size_t t2n_generic_workspace_bytes(int64_t n_rays, int n_samples) {
     if (n_rays <= 0 || n_samples <= 0) return 0;
@@ -426,8 +750,48 @@ extern "C" int t2n_generic_forward(const t2n_generic_desc* desc, const t2n_field
     if ((rc = gen_bind(a, rays, n_rays, ray_stride, n_samples, flags, jitter, weights, z_vals, workspace, workspace_bytes, "t2n_generic_forward"))) return rc;
     a.rgb = rgb; a.depth = depth; a.stats = (unsigned long long*)stats;
     if (stats) T2N_HIP(hipMemsetAsync(stats, 0, sizeof(uint64_t) * T2N_STAT_COUNT, s));
-    hipLaunchKernelGGL(k_gen_march, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, s, a);
     const long long tot = (long long)n_rays * n_samples;
+    const GenStageCarve sc = gen_stage_carve(desc, n_rays, n_samples, gen_carve(n_rays, n_samples, true).total);
+    const size_t lds = gen_head_lds(desc);
+    static const bool plain = getenv("T2N_GENERIC_PLAIN") && atoi(getenv("T2N_GENERIC_PLAIN")) != 0;
+    if (!plain && sc.total <= workspace_bytes && lds <= 160 * 1024) {
+        char* ws = (char*)workspace;
+        GenFast fa;
+        GenStageArgs sa;
+        unsigned blocks = 0;
+        for (int q = 0; q < 4; ++q)
+            for (int k = 0; k < 3; ++k) {
+                const int idx = q * 3 + k;
+                const float* src[4] = {a.dp[k], a.dl[k], a.ap[k], a.al[k]};
+                const long long HW = (long long)desc->grid[mat1(k)] * desc->grid[mat0(k)], L = desc->grid[vecm(k)];
+                sa.src[idx] = src[q]; sa.dst[idx] = (float*)(ws + sc.t[idx]); sa.C[idx] = q < 2 ? a.Cd[k] : a.Ca[k]; sa.HW[idx] = (q & 1) ? L : HW;
+                sa.block0[idx] = blocks;
+                blocks += (unsigned)(((sa.HW[idx] + 63) / 64) * ((sa.C[idx] + 63) / 64));
+            }
+        sa.block0[12] = blocks;
+        for (int k = 0; k < 3; ++k) { fa.dp[k] = sa.dst[k]; fa.dl[k] = sa.dst[3 + k]; fa.ap[k] = sa.dst[6 + k]; fa.al[k] = sa.dst[9 + k]; }
+        fa.list = (int*)(ws + sc.list); fa.count = (unsigned*)(ws + sc.count); fa.cap = (unsigned)tot; fa.ncol = a.Ca[0] + a.Ca[1] + a.Ca[2];
+        T2N_HIP(hipMemsetAsync(fa.count, 0, 4, s));
+        hipLaunchKernelGGL(k_gen_stage, dim3(blocks), dim3(256), 0, s, sa);
+        fa.w0p = fa.w1p = nullptr; fa.ld0 = fa.ld1 = 0;
+        if (a.w0 && a.w1 && a.in0 > 0) {
+            fa.ld0 = (a.in0 + 15) / 16 * 16; fa.ld1 = (a.fC + 15) / 16 * 16;
+            fa.w0p = (const float*)(ws + sc.w0p); fa.w1p = (const float*)(ws + sc.w1p);
+            hipLaunchKernelGGL(k_gen_padrows, dim3((unsigned)(((long long)a.fC * fa.ld0 + 255) / 256)), dim3(256), 0, s, a.w0, (float*)(ws + sc.w0p), a.fC, a.in0, fa.ld0);
+            hipLaunchKernelGGL(k_gen_padrows, dim3((unsigned)(((long long)a.fC * fa.ld1 + 255) / 256)), dim3(256), 0, s, a.w1, (float*)(ws + sc.w1p), a.fC, a.fC, fa.ld1);
+        }
+        hipLaunchKernelGGL(k_gen_sigma, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a, fa);
+        hipLaunchKernelGGL(k_gen_scan, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_gen_compact, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a, fa);
+        static bool attr_set = false;
+        if (!attr_set) { T2N_HIP(hipFuncSetAttribute((const void*)k_gen_head, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+        const unsigned long long wt = ((unsigned long long)tot + 63) / 64;
+        hipLaunchKernelGGL(k_gen_head, dim3((unsigned)(wt < 1024 ? (wt ? wt : 1) : 1024)), dim3(256), lds, s, a, fa);
+        hipLaunchKernelGGL(k_gen_composite, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, s, a);
+        T2N_HIP(hipGetLastError());
+        return T2N_OK;
+    }
+    hipLaunchKernelGGL(k_gen_march, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_gen_shade<false>, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_gen_composite, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, s, a);
     T2N_HIP(hipGetLastError());

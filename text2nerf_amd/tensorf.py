@@ -1276,8 +1276,8 @@ class TensorBase(nn.Module):
         rgb, depth = torch.empty(R, 3, device=dev), torch.empty(R, device=dev)
         w, z = torch.empty(R, N, device=dev), torch.empty(R, N, device=dev)
         stats = torch.empty(_lib.T2N_STAT_COUNT, device=dev, dtype=torch.int64)
-        ws = torch.empty(int(lib.t2n_generic_workspace_bytes(R, N)), dtype=torch.uint8, device=dev)
         d = self._general_desc()
+        ws = torch.empty(int(lib.t2n_generic_workspace_bytes_desc(C.byref(d), R, N)), dtype=torch.uint8, device=dev)
         st = self._param_struct([p.detach() for p in ps])
         with torch.cuda.device(dev):
             _lib.check(lib.t2n_generic_forward(C.byref(d), C.byref(st), _lib.ptr(rays), R, rays.shape[1], N, flags, _lib.ptr(jitter),
