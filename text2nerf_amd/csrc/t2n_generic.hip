@@ -557,14 +557,26 @@ __global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast
                 const float* __restrict__ l0 = fa.al[k] + (size_t)al.i0 * C;
                 const float* __restrict__ l1 = fa.al[k] + (size_t)al.i1 * C;
                 const float w00 = ay.w0 * ax.w0, w01 = ay.w0 * ax.w1, w10 = ay.w1 * ax.w0, w11 = ay.w1 * ax.w1;
-                const int per = (C + 3) / 4, cb = g * per, ce = min(C, cb + per);
-                for (int c = cb; c < ce; ++c) {
-                    float v = p00[c] * w00;
-                    v = fmaf(p01[c], w01, v); v = fmaf(p10[c], w10, v); v = fmaf(p11[c], w11, v);
-                    const float xv = v * fmaf(l1[c], al.w1, l0[c] * al.w0);
+                auto one = [&](int c, float a00, float a01, float a10, float a11, float b0, float b1) {
+                    float v = a00 * w00;
+                    v = fmaf(a01, w01, v); v = fmaf(a10, w10, v); v = fmaf(a11, w11, v);
+                    const float xv = v * fmaf(b1, al.w1, b0 * al.w0);
                     const float* __restrict__ bt = basisT + (size_t)(col0 + c) * D;
 #pragma unroll
                     for (int f = 0; f < kGenDimMax; ++f) if (f < D) fp[f] = fmaf(bt[f], xv, fp[f]);
+                };
+                if ((C & 3) == 0) {      // four components per load (the staged rows are 16-byte aligned when C is a multiple of 4)
+                    const int ng4 = C / 4, per = (ng4 + 3) / 4, qb = g * per, qe = min(ng4, qb + per);
+                    for (int q = qb; q < qe; ++q) {
+                        const float4 a00 = reinterpret_cast<const float4*>(p00)[q], a01 = reinterpret_cast<const float4*>(p01)[q];
+                        const float4 a10 = reinterpret_cast<const float4*>(p10)[q], a11 = reinterpret_cast<const float4*>(p11)[q];
+                        const float4 b0 = reinterpret_cast<const float4*>(l0)[q], b1 = reinterpret_cast<const float4*>(l1)[q];
+                        one(4 * q, a00.x, a01.x, a10.x, a11.x, b0.x, b1.x); one(4 * q + 1, a00.y, a01.y, a10.y, a11.y, b0.y, b1.y);
+                        one(4 * q + 2, a00.z, a01.z, a10.z, a11.z, b0.z, b1.z); one(4 * q + 3, a00.w, a01.w, a10.w, a11.w, b0.w, b1.w);
+                    }
+                } else {
+                    const int per = (C + 3) / 4, cb = g * per, ce = min(C, cb + per);
+                    for (int c = cb; c < ce; ++c) one(c, p00[c], p01[c], p10[c], p11[c], l0[c], l1[c]);
                 }
                 col0 += C;
             }
