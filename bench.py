@@ -53,7 +53,7 @@ BYTES_PER_APP = 3456
 BYTES_PER_RAY = 40
 FLOP_PER_APP = 131168    # 2*(144*27 + 351*128 + 128*128 + 128*3)
 FLOP_HEAD = 123392       # 2*(351*128 + 128*128 + 128*3): the MLP head without basis_mat
-PMC_FILES = ("round5_pmc.json", "round4_pmc.json", "round3_pmc.json")   # the newest committed counter record is used (profiles/)
+PMC_FILES = ("round6_pmc.json", "round5_pmc.json", "round4_pmc.json", "round3_pmc.json")   # the newest committed counter record is used (profiles/)
 MFMA_F32_PEAK_TF = 157.3
 MFMA_F16_PEAK_TF = 2500.0  # dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 

@@ -459,18 +459,14 @@ extern "C" int t2n_field_destroy(t2n_field* f) {
     if (f->ev_fork) (void)hipEventDestroy((hipEvent_t)f->ev_fork);
     if (f->ev_join) (void)hipEventDestroy((hipEvent_t)f->ev_join);
     if (f->ev_den) (void)hipEventDestroy((hipEvent_t)f->ev_den);
-    if (f->side_stream) (void)hipStreamDestroy((hipStream_t)f->side_stream);
     if (f->plan_host) (void)hipHostFree(f->plan_host);
     if (f->ev_pack) (void)hipEventDestroy((hipEvent_t)f->ev_pack);
     if (f->ev_fork2) (void)hipEventDestroy((hipEvent_t)f->ev_fork2);
     if (f->ev_join2) (void)hipEventDestroy((hipEvent_t)f->ev_join2);
-    if (f->gemm_stream) (void)hipStreamDestroy((hipStream_t)f->gemm_stream);
     if (f->buf_alpha) (void)hipFree(f->buf_alpha);
     if (f->train_dev) (void)hipFree(f->train_dev);
     if (f->train_host) (void)hipHostFree(f->train_host);
     for (auto& e : f->train_ev) if (e) (void)hipEventDestroy((hipEvent_t)e);
-    if (f->bin_stream) (void)hipStreamDestroy((hipStream_t)f->bin_stream);
-    if (f->early_stream) (void)hipStreamDestroy((hipStream_t)f->early_stream);
     for (int k = 0; k < T2N_K_COUNT; ++k)
         for (int i = 0; i < kTimingEvents; ++i) {
             if (f->slots[k].start[i]) (void)hipEventDestroy(f->slots[k].start[i]);

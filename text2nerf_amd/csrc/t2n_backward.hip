@@ -1010,6 +1010,28 @@ __global__ __launch_bounds__(256) void k_relayout_add(const RelayoutAddMulti a) 
         for (int c = cs; c < C; c += 4) dst[(long long)c * HW + pix0 + lp] += tile[lp * ld + c];
 }
 
+// The library's two side streams are PROCESS-wide (per device), created together at first use: HIP maps streams onto a handful of
+// hardware queues in creation order, and chains that share a queue run one behind the other. With a pair of streams per field, a field
+// created late in a process (after other fields, the caller's copy streams, ...) could get both of its side streams — or one of them and
+// the caller's — on one queue: the same 8 192-ray step took 0.79 ms in a long-running bench process and 0.60 ms in a fresh one.
+static std::mutex g_stream_mutex;
+static hipStream_t g_side[16][2];
+int shared_side_streams(void** a, void** b) {
+    int dev = 0;
+    T2N_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) { set_error("device ordinal %d beyond the side-stream table", dev); return T2N_ERR_UNSUPPORTED; }
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    if (!g_side[dev][0]) {
+        hipStream_t x, y;
+        T2N_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+        T2N_HIP(hipStreamCreateWithFlags(&y, hipStreamNonBlocking));
+        g_side[dev][0] = x; g_side[dev][1] = y;
+    }
+    if (a && !*a) *a = (void*)g_side[dev][0];
+    if (b && !*b) *b = (void*)g_side[dev][1];
+    return T2N_OK;
+}
+
 // Activation / gradient rows of the backward pass. Buffers whose lifetimes do not overlap (or that are rewritten
 // element-in-place by the same thread) share storage: g1 over h1, g0 over h0, gx over xpe, gf over feat32, gX over x144.
 struct BwdCarve { size_t x144, feat32, h0, h1, go, xpe, part, gpack, hist, bin_total, tile_start, nseg, segs, recs, a_hist, a_bin_total, a_tile_start, a_nseg, a_segs, a_recs, plan, total; unsigned seg_cap, a_seg_cap; };
@@ -1389,12 +1411,12 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
 #define T2N_PACK_ON_CALLER_STREAM 0
 #endif
             if (!serial && bin && !T2N_PACK_ON_CALLER_STREAM) {
-                if (!f->gemm_stream) {
-                    hipStream_t st; hipEvent_t e0, e1;
-                    T2N_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                if (!f->gemm_stream || !f->ev_fork2) {
+                    hipEvent_t e0, e1;
+                    { const int rcs = shared_side_streams(&f->side_stream, &f->gemm_stream); if (rcs) return rcs; }
                     T2N_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
                     T2N_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-                    f->gemm_stream = (void*)st; f->ev_fork2 = (void*)e0; f->ev_join2 = (void*)e1;
+                    f->ev_fork2 = (void*)e0; f->ev_join2 = (void*)e1;
                 }
                 if (!f->ev_pack) { hipEvent_t e; T2N_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); f->ev_pack = (void*)e; }
                 sp = (hipStream_t)f->gemm_stream;
@@ -1418,12 +1440,12 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             // beside them and is joined before the gradients leave this call (T2N_BWD_SERIAL=1: one stream).
             hipStream_t sd = s;
             if (!serial && rows > 0) {
-                if (!f->side_stream) {
-                    hipStream_t st; hipEvent_t e0, e1;
-                    T2N_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                if (!f->side_stream || !f->ev_fork) {
+                    hipEvent_t e0, e1;
+                    { const int rcs = shared_side_streams(&f->side_stream, &f->gemm_stream); if (rcs) return rcs; }
                     T2N_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
                     T2N_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-                    f->side_stream = (void*)st; f->ev_fork = (void*)e0; f->ev_join = (void*)e1;
+                    f->ev_fork = (void*)e0; f->ev_join = (void*)e1;
                 }
                 sd = (hipStream_t)f->side_stream;
                 T2N_HIP(hipEventRecord((hipEvent_t)f->ev_fork, s));
@@ -1475,12 +1497,12 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             // that is joined before the gradients leave this call (T2N_BWD_SERIAL=1: one stream).
             hipStream_t sg = s;
             if (side) {
-                if (!f->gemm_stream) {
-                    hipStream_t st; hipEvent_t e0, e1;
-                    T2N_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                if (!f->gemm_stream || !f->ev_fork2) {
+                    hipEvent_t e0, e1;
+                    { const int rcs = shared_side_streams(&f->side_stream, &f->gemm_stream); if (rcs) return rcs; }
                     T2N_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
                     T2N_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-                    f->gemm_stream = (void*)st; f->ev_fork2 = (void*)e0; f->ev_join2 = (void*)e1;
+                    f->ev_fork2 = (void*)e0; f->ev_join2 = (void*)e1;
                 }
                 sg = (hipStream_t)f->gemm_stream;
                 T2N_HIP(hipEventRecord((hipEvent_t)f->ev_fork2, s));
@@ -1746,9 +1768,8 @@ static int train_ensure(t2n_field* f, hipStream_t s) {
         for (int i = 0; i < 64; ++i) f->train_host[i] = 0u;
         f->train_packed = false;
     }
-    auto mk_stream = [](void** st) -> int { if (!*st) { hipStream_t x; T2N_HIP(hipStreamCreateWithFlags(&x, hipStreamNonBlocking)); *st = (void*)x; } return T2N_OK; };
     int rc;
-    if ((rc = mk_stream(&f->side_stream)) || (rc = mk_stream(&f->gemm_stream))) return rc;
+    if ((rc = shared_side_streams(&f->side_stream, &f->gemm_stream))) return rc;
     for (auto& e : f->train_ev) if (!e) { hipEvent_t x; T2N_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming)); e = (void*)x; }
     if (!f->ev_den) { hipEvent_t e; T2N_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); f->ev_den = (void*)e; }
     return T2N_OK;

@@ -126,15 +126,15 @@ struct t2n_field {
     static constexpr int kCountSlots = 4;
     struct CountSlot { unsigned* host = nullptr; void* ev = nullptr; bool pending = false; int64_t n_rays = 0; int n_samples = 0; unsigned budget = 0; };
     CountSlot count_slots[kCountSlots]; int count_next = 0;
-    void* side_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;   // backward: the density scatter runs beside the MLP backward
+    void* side_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;   // (the streams are the process-wide pair of shared_side_streams: not owned)   // backward: the density scatter runs beside the MLP backward
     void* ev_den = nullptr;      // recorded behind the density scatter of the last backward (t2n_field_wait_density_grads)
     unsigned* plan_host = nullptr; unsigned plan_seq = 0;   // T2N_FLAG_DEVICE_ROWS: k_bwd_plan's record in pinned host memory (t2n_field_device_rows_record)
     void* ev_pack = nullptr;   // backward: k_mlp_bwd_ss's operand packing (on gemm_stream) is done
     void* gemm_stream = nullptr; void* ev_fork2 = nullptr; void* ev_join2 = nullptr;  // backward: the weight-gradient GEMMs run beside the appearance scatter
     // fused training step (t2n_train_step): device state + the backward chain's packed operands (one allocation), the pinned host record,
     // a third side stream for the plan + appearance binning and the events of the call's fork / join graph
-    void* train_dev = nullptr; unsigned* train_host = nullptr; void* bin_stream = nullptr; void* train_ev[12] = {};
-    void* early_stream = nullptr; unsigned train_calls = 0; bool train_chain = false;   // pipelined steps: stream of a step's early part; calls so far (workspace / scalar slot parity); the previous call left its density-Adam event
+    void* train_dev = nullptr; unsigned* train_host = nullptr; void* train_ev[12] = {};
+    unsigned train_calls = 0; bool train_chain = false;   // pipelined steps: stream of a step's early part; calls so far (workspace / scalar slot parity); the previous call left its density-Adam event
     bool train_packed = false;   // the backward chain's operands in train_dev are those of the current head weights
     unsigned list_hint = 0;          // appearance entries per ray of the last budgeted launch (0: unknown)
     unsigned long long list_retries = 0;
