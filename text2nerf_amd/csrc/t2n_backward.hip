@@ -1657,9 +1657,15 @@ namespace t2n {
 // zero fills of one step as ONE launch: region r = blockIdx.y (a uniform index into the kernel arguments)
 constexpr int kZeroRegions = 12;
 struct ZeroOps { unsigned* ptr[kZeroRegions]; unsigned long long words[kZeroRegions]; int n = 0;
+    const uint4* up_src = nullptr; uint4* up_dst = nullptr; unsigned long long up_n16 = 0;   // optional upload: 16-byte words from pinned host memory (grid row n)
     bool add(void* p, size_t bytes) { if (!p || !bytes) return true; if (n >= kZeroRegions) return false; ptr[n] = (unsigned*)p; words[n] = (bytes + 3) / 4; ++n; return true; } };
 __global__ __launch_bounds__(256) void k_zero_regions(const ZeroOps o) {
     const int r = blockIdx.y;
+    if (r == o.n) {   // the batch: read over the host link by the kernel itself (same steady-state time as an engine copy in front of the launch, which stalled the stream for ~5 ms once per process)
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < o.up_n16; i += (unsigned long long)gridDim.x * 256)
+            o.up_dst[i] = o.up_src[i];
+        return;
+    }
     unsigned* __restrict__ p = o.ptr[r];
     const unsigned long long n = o.words[r];
     if ((((uintptr_t)p) & 15u) == 0) {
@@ -1896,9 +1902,15 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
         }
         T2N_HIP(hipEventRecord(ev[0], s));
         if (pipe && !chain_prev) T2N_HIP(hipStreamWaitEvent(se, ev[0], 0));   // (the previous call left no density-Adam event on sa: behind `stream`)
+        const uint4* up_src = nullptr;
         if (A->host_batch) {
             if (!A->batch_buffer || !A->host_batch_bytes) { set_error("t2n_train_step: host_batch without batch_buffer / host_batch_bytes"); return T2N_ERR_INVALID; }
-            T2N_HIP(hipMemcpyAsync(A->batch_buffer, A->host_batch, A->host_batch_bytes, hipMemcpyHostToDevice, se));
+            // pinned, 16-byte-aligned batches are read by the zero-fill launch itself (below); anything else through the copy engine
+            static const bool engine_copy = getenv("T2N_COPY_ENGINE") != nullptr;
+            void* dp = nullptr;
+            if (!engine_copy && ((uintptr_t)A->host_batch & 15u) == 0 && ((uintptr_t)A->batch_buffer & 15u) == 0 && (A->host_batch_bytes & 15u) == 0 &&
+                hipHostGetDevicePointer(&dp, const_cast<void*>((const void*)A->host_batch), 0) == hipSuccess && dp) up_src = (const uint4*)dp;
+            else { (void)hipGetLastError(); T2N_HIP(hipMemcpyAsync(A->batch_buffer, A->host_batch, A->host_batch_bytes, hipMemcpyHostToDevice, se)); }
         }
         // ---- every zero fill of the step in one launch
         RenderLaunch L;
@@ -1920,9 +1932,10 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
             if (!ok) { set_error("t2n_train_step: zero-fill table overflow"); return T2N_ERR_INVALID; }
             unsigned long long mx = 1;
             for (int r = 0; r < zo.n; ++r) mx = zo.words[r] > mx ? zo.words[r] : mx;
+            if (up_src) { zo.up_src = up_src; zo.up_dst = (uint4*)A->batch_buffer; zo.up_n16 = A->host_batch_bytes / 16; mx = zo.up_n16 * 16 > mx ? zo.up_n16 * 16 : mx; }   // (one 16-byte word per thread up to 256 workgroups)
             unsigned bx = (unsigned)((mx + 4095) / 4096);
             bx = bx > 256 ? 256 : (bx < 1 ? 1 : bx);
-            hipLaunchKernelGGL(k_zero_regions, dim3(bx, (unsigned)zo.n), dim3(256), 0, se, zo);
+            hipLaunchKernelGGL(k_zero_regions, dim3(bx, (unsigned)zo.n + (up_src ? 1u : 0u)), dim3(256), 0, se, zo);
         }
         // ---- forward: march
         if ((rc = launch_march(f, L, se))) return rc;
