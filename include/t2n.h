@@ -477,6 +477,15 @@ int t2n_depth_align_global(const float* depth_rendered, const float* depth_est, 
  *                  optimiser kernel reads the verdict from device memory and returns; Adam's step count does not advance): the caller
  *                  learns it from t2n_field_train_record — without waiting — and submits the same batch again with a capacity >= the
  *                  recorded need.
+ *   shard_world    > 1 selects the SHARDED OPTIMISER of a data-parallel group: of every plane's n / 64 whole 64-position
+ *                  blocks, rank r owns blocks [r c, (r + 1) c), c = (n / 64) / world (the "body", world c blocks); the blocks behind the
+ *                  body and the six lines are replicated (t2n_field_shard_layout gives the offsets). phases = 1 then seeds the gradient
+ *                  buffer with world x the TV gradient on the blocks this rank owns, zero on the rest of the body and the plain TV
+ *                  gradient on the replicated part: AVERAGING the ranks' buffers — a reduce-scatter of each body, one small all-reduce of
+ *                  the replicated parts and head_grads — leaves every owner the full-batch gradient of its slice. phases = 2 steps the
+ *                  owned and the replicated blocks only (1 / world of the TV + Adam traffic); the caller then all-gathers each body of
+ *                  the channel-last parameter copies (t2n_field_factor_buffer) and a phases = 4 call writes the gathered blocks into its
+ *                  reference-layout tensors. Moments of blocks a rank does not own are never touched.
  *   phases         1: render + loss + backward only (gradients left in the field's buffer and head_grads), 2: optimiser only (after a
  *                  data-parallel all-reduce of both; a non-zero vote word withholds the update on every rank), 3: both.
  *   losses         device float[4] = {mse, depth loss, transmittance loss, total} of the batch
@@ -496,7 +505,7 @@ int t2n_depth_align_global(const float* depth_rendered, const float* depth_est, 
 typedef struct t2n_train_step_args {
     const float* rays; int64_t n_rays; int32_t ray_stride; int32_t n_samples;
     uint32_t flags;            /* T2N_FLAG_ADD_BG, T2N_FLAG_PIPELINE or 0 (T2N_FLAG_TRAIN is implied) */
-    uint32_t phases;           /* 1 | 2 */
+    uint32_t phases;           /* 1 | 2, or 4 alone (sharded optimiser: see shard_world) */
     const float* jitter; const float* rgb_target; const float* depth_target;
     float w_depth, w_trans, delta;
     float beta1, beta2, eps;
@@ -510,9 +519,16 @@ typedef struct t2n_train_step_args {
     const void* host_batch;    /* optional: the batch in PINNED host memory (NULL: the device buffers are already filled), see below */
     size_t host_batch_bytes;
     void* batch_buffer;        /* device destination of host_batch: the start of the ONE allocation rays / jitter / targets / hyper point into */
+    int32_t shard_world, shard_rank;   /* sharded optimiser (data-parallel): ranks and this rank; 0 / 1 = every rank steps every factor */
 } t2n_train_step_args;
 size_t t2n_train_step_workspace_bytes(const t2n_field* f, int64_t n_rays, int n_samples, int64_t rows_capacity);
 int t2n_train_step(t2n_field* f, const t2n_train_step_args* a, t2n_stream stream);
+/* The sharded optimiser's partition for `world` ranks: out[3 t + 0] = offset of factor tensor t in the field's gradient buffer (floats),
+ * out[3 t + 1] = floats of ONE rank's slice of its body (0 for the lines), out[3 t + 2] = its floats in all; t = 0..11 in the order density
+ * planes, density lines, appearance planes, appearance lines (channel-last: position-major, C = 16 / 48 floats per position). */
+int t2n_field_shard_layout(const t2n_field* f, int world, int64_t out[36]);
+/* Device pointer of the channel-last fp32 master copy of factor tensor t (the array the kernels read and the fused step's Adam updates). */
+int t2n_field_factor_buffer(const t2n_field* f, int t, void** ptr);
 /* Adam's step count of the field's fused steps (device memory): set when an optimiser state is loaded / reset. Asynchronous on `stream`. */
 int t2n_field_train_set_step(t2n_field* f, uint32_t step, t2n_stream stream);
 /* What the fused steps recorded, from pinned host memory (never waits, never touches a stream): out[0] = newest sequence number + 1 in

@@ -100,6 +100,41 @@ for overlap in (True, False):
     assert torch.equal(f.factor_grad_buffer(), snap), overlap
     assert all(torch.equal(p.grad, h) for p, h in zip(hp, head)), overlap
 print("allreduce_gradients(overlap=True / False) on one rank: identity, bitwise", flush=True)
+# 4. the sharded optimiser's exchange (parallel.ShardedExchange) through RCCL: on one rank a plane has no body (everything is
+#    "replicated"), so the step must equal the plain fused step; the three collectives are then driven directly on device tensors
+#    IN PLACE (output aliasing the input's own chunk: what reduce() / gather() do on larger groups)
+from text2nerf_amd.parallel import ShardedExchange  # noqa: E402
+fa, fb = make(), make()
+oa = TVAdam(fa.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fa)
+ob = TVAdam(fb.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fb)
+ex = None
+for it in range(3):
+    torch.manual_seed(100 + it)
+    fa.train_step(b_rays, rgb_t, dep_t, oa, N_samples=-1, white_bg=True, tv=[(fa.density_plane, 0.1), (fa.app_plane, 0.01)], fused=True, graph=False)
+    torch.manual_seed(100 + it)
+    if ex is None:
+        fb.train_step(b_rays, rgb_t, dep_t, ob, N_samples=-1, white_bg=True, tv=[(fb.density_plane, 0.1), (fb.app_plane, 0.01)], fused=True,
+                      graph=False, all_reduce=lambda: allreduce_gradients([p for p in fb.parameters() if p.requires_grad], average=True, field=fb))
+        ex = ShardedExchange.for_field(fb)
+        assert ex.world == 1 and all(l[1] == 0 for l in ex.layout)
+        # the channel-last parameter views wrap the library's own allocations: same values as the reference-layout tensors
+        pl = fb.density_plane[0].detach()
+        assert torch.equal(ex.params[0].view(pl.shape[2], pl.shape[3], pl.shape[1]).permute(2, 0, 1), pl[0])
+    else:
+        fb.train_step(b_rays, rgb_t, dep_t, ob, N_samples=-1, white_bg=True, tv=[(fb.density_plane, 0.1), (fb.app_plane, 0.01)], fused=True,
+                      graph=False, all_reduce=ex)
+for o in (fa, fb):
+    o.__dict__["_fused_step"].sync()
+for (ka, a), (kb, b) in zip(fa.state_dict().items(), fb.state_dict().items()):
+    assert ka == kb and torch.allclose(a, b, rtol=1e-3, atol=2e-5), (ka, float((a - b).abs().max()))
+x = torch.randn(4096, device=dev)
+snap = x.clone()
+ex._reduce_scatter_avg(x, x)          # reduce_scatter_tensor(AVG), output == the input's chunk of this rank
+ex._all_reduce_avg(x)
+ex._all_gather(x, x)                  # all_gather_into_tensor, input == the output's chunk of this rank
+torch.cuda.synchronize()
+assert torch.equal(x, snap)
+print("ShardedExchange: fused step through reduce() / gather() == plain fused step; in-place reduce_scatter / all_gather ok", flush=True)
 dist.barrier()
 torch.cuda.synchronize()
 dist.destroy_process_group()

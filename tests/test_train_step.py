@@ -329,3 +329,78 @@ def test_tv_terms_through_hip_kernels_match_torch_tvloss(tiny_params):
         assert float((got[k] - p.grad).abs().max()) <= 2e-6 * scale, k
     # a regulariser without TVLoss_weight (any callable) takes the plain route
     assert tv_planes(lambda x: x.sum(), list(f.density_plane), 1e-2) is None
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_optimizer_virtual_ranks(tiny_params, world):
+    """Sharded optimiser (t2n_train_step with shard_world / shard_rank, phases 1 / 2 / 4): `world` ranks — threads of this
+    process, each with its own field, optimiser state and fused step, exchanging through in-process collectives — against the single-rank
+    fused step on the same batches. Checks the kernels' side of the rule: who seeds which TV gradient, which blocks a rank's Adam
+    touches (moments of blocks it does not own stay zero), and that gathered blocks reach the reference-layout tensors."""
+    import ctypes as C
+    import threading
+    from text2nerf_amd import _lib
+    from text2nerf_amd.optim import TVAdam
+    from text2nerf_amd.parallel import shard_layout
+    from tests.helpers.virtual_ranks import VirtualExchange, VirtualGroup
+    rays, rgb_t, dep_t = batch()
+    steps = 3
+    mk = lambda: make_field(tiny_params, TINY["grid"], TINY["aabb"], TINY["near_far"])
+    ref = mk()
+    oref = TVAdam(ref.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=ref)
+    for it in range(steps):
+        torch.manual_seed(100 + it)
+        ref.train_step(rays, rgb_t, dep_t, oref, N_samples=-1, white_bg=True, tv=[(ref.density_plane, 0.1), (ref.app_plane, 0.01)], fused=True, graph=False)
+    ref.__dict__["_fused_step"].sync()
+    fields = [mk() for _ in range(world)]
+    opts = [TVAdam(f.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=f) for f in fields]
+    # the C layout == its Python mirror
+    lay = (C.c_int64 * 36)()
+    _lib.check(_lib.load().t2n_field_shard_layout(fields[0].sync_params(), world, lay), "t2n_field_shard_layout")
+    assert [[int(lay[3 * t + j]) for j in range(3)] for t in range(12)] == shard_layout(TINY["grid"], world)
+    vg = VirtualGroup(world)
+    exs = [VirtualExchange.make(f, vg, r) for r, f in enumerate(fields)]
+    errors = []
+
+    def run(r):
+        try:
+            torch.cuda.set_device(dev())
+            f = fields[r]
+            for it in range(steps):
+                vg.turn.acquire()
+                torch.manual_seed(100 + it)      # every rank the SAME batch and jitter: the average of the ranks' gradients is the batch gradient
+                f.train_step(rays, rgb_t, dep_t, opts[r], N_samples=-1, white_bg=True, tv=[(f.density_plane, 0.1), (f.app_plane, 0.01)],
+                             fused=True, graph=False, all_reduce=exs[r])
+            f.__dict__["_fused_step"].sync()
+        except BaseException as e:      # noqa: BLE001
+            errors.append((r, repr(e)))
+            vg.barrier.abort()
+            if vg.turn.locked():
+                try:
+                    vg.turn.release()
+                except RuntimeError:
+                    pass
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for r, f in enumerate(fields):
+        assert_same_trajectory(ref, f, steps)
+        # moments: zero exactly on the body blocks of the other ranks (channel-last pooled moments of the fused step)
+        fs = f.__dict__["_fused_step"]
+        _, ms, vs, _ = fs._moments()
+        for t in (0, 1, 2, 6, 7, 8):
+            off, sl, total = exs[r].layout[t]
+            m = ms[t].reshape(-1)
+            for rr in range(world):
+                seg = m[rr * sl:(rr + 1) * sl]
+                if rr == r:
+                    assert float(seg.abs().max()) > 0.0
+                else:
+                    assert float(seg.abs().max()) == 0.0, (r, t, rr)
+            if m[world * sl:].numel():
+                assert float(m[world * sl:].abs().max()) > 0.0

@@ -66,7 +66,8 @@ class TrainStepArgs(C.Structure):   # t2n_train_step_args
                 ("hyper", C.c_void_p), ("params", FieldParams),
                 ("exp_avg", C.c_void_p * 19), ("exp_avg_sq", C.c_void_p * 19),
                 ("head_grads", C.c_void_p), ("rows_capacity", C.c_int64),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("losses", C.c_void_p), ("host_batch", C.c_void_p), ("host_batch_bytes", C.c_size_t), ("batch_buffer", C.c_void_p)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("losses", C.c_void_p), ("host_batch", C.c_void_p), ("host_batch_bytes", C.c_size_t), ("batch_buffer", C.c_void_p),
+                ("shard_world", C.c_int32), ("shard_rank", C.c_int32)]
 
 
 _lib = None
@@ -172,6 +173,8 @@ SIGNATURES = {
     "t2n_train_step": (C.c_int, [C.c_void_p, C.POINTER(TrainStepArgs), C.c_void_p]),
     "t2n_field_train_set_step": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "t2n_field_train_record": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "t2n_field_shard_layout": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
+    "t2n_field_factor_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "t2n_train_graph_capture": (C.c_int, [C.c_void_p, C.POINTER(TrainStepArgs), C.c_void_p, C.POINTER(C.c_void_p)]),
     "t2n_train_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "t2n_train_graph_nodes": (C.c_int, [C.c_void_p]),

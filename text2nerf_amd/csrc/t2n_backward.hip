@@ -1636,6 +1636,30 @@ extern "C" int t2n_field_wait_density_grads(const t2n_field* f, t2n_stream waite
     return T2N_OK;
 }
 
+extern "C" int t2n_field_shard_layout(const t2n_field* f, int world, int64_t out[36]) {
+    if (!f || !out || world < 1) { set_error("t2n_field_shard_layout: bad argument"); return T2N_ERR_INVALID; }
+    size_t off[12];
+    (void)grad_layout(f, off);
+    unsigned lo[12], hi[12], body[12];
+    shard_partition(f, world, 0, lo, hi, body);
+    const int* gr = f->desc.grid;
+    for (int q = 0; q < 4; ++q)
+        for (int k = 0; k < 3; ++k) {
+            const int t = q * 3 + k, C = q < 2 ? f->desc.density_n_comp : f->desc.app_n_comp;
+            const int64_t n = (q & 1) == 0 ? (int64_t)gr[mat1(k)] * gr[mat0(k)] : (int64_t)gr[vecm(k)];
+            out[3 * t] = (int64_t)(off[t] / 4); out[3 * t + 1] = (int64_t)(hi[t] - lo[t]) * 64 * C; out[3 * t + 2] = n * C;
+        }
+    return T2N_OK;
+}
+
+extern "C" int t2n_field_factor_buffer(const t2n_field* f, int t, void** ptr) {
+    if (!f || !ptr || t < 0 || t >= 12) { set_error("t2n_field_factor_buffer: bad argument"); return T2N_ERR_INVALID; }
+    if (!f->uploaded || f->factor_bf16) { set_error("t2n_field_factor_buffer: needs an uploaded field with fp32 factor storage"); return T2N_ERR_STATE; }
+    float* const* tab[4] = {f->buf_den_plane, f->buf_den_line, f->buf_app_plane, f->buf_app_line};
+    *ptr = (void*)tab[t / 3][t % 3];
+    return T2N_OK;
+}
+
 // =====================================================================================================================================
 // t2n_train_step: one optimisation step of text2nerf_main.py:547-601 as ONE submission (include/t2n.h). The kernels are those of
 // t2n_render_forward (KEEP_CTX, train), t2n_train_loss, t2n_render_backward (T2N_FLAG_DEVICE_ROWS) and the optimiser entry points; what is
@@ -1831,9 +1855,19 @@ extern "C" int t2n_field_train_record(const t2n_field* f, uint32_t out[36]) {
 
 extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_stream stream) {
     if (!f || !A || !A->rays || !A->jitter || !A->rgb_target || !A->depth_target || !A->hyper || !A->head_grads || !A->workspace || !A->losses ||
-        A->n_rays <= 0 || A->ray_stride < 6 || A->n_samples <= 0 || !(A->phases & 3u)) {
+        A->n_rays <= 0 || A->ray_stride < 6 || A->n_samples <= 0 || !(A->phases & 7u) || ((A->phases & 4u) && A->phases != 4u)) {
         set_error("t2n_train_step: bad argument");
         return T2N_ERR_INVALID;
+    }
+    const int sworld = A->shard_world > 1 ? A->shard_world : 1, srank = A->shard_world > 1 ? A->shard_rank : 0;
+    if (srank < 0 || srank >= sworld || (sworld > 1 && (A->phases & 3u) == 3u)) {
+        set_error("t2n_train_step: shard_rank %d of %d, or a sharded step as one call (the gradient exchange lies between phases 1 and 2)", A->shard_rank, A->shard_world);
+        return T2N_ERR_INVALID;
+    }
+    if (A->phases == 4u) {   // sharded optimiser: the gathered body blocks of the other ranks -> the caller's reference-layout tensors
+        if (!f->uploaded || !train_supported(f)) { set_error("t2n_train_step: phases = 4 needs an uploaded field of the fused step's shape"); return T2N_ERR_STATE; }
+        if (sworld < 2) return T2N_OK;
+        return launch_factor_adam_dev(f, &A->params, nullptr, nullptr, 0.f, 0.f, 0.f, nullptr, 0, 12, (hipStream_t)stream, sworld, srank, true);
     }
     if (!f->uploaded) { set_error("t2n_train_step: field has no uploaded parameters"); return T2N_ERR_STATE; }
     if (!train_supported(f)) {
@@ -1973,7 +2007,7 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
         T2N_HIP(hipStreamWaitEvent(sa, ev[0], 0));     // (behind the previous step's Adam: it read this buffer and wrote the factors)
         if (T2N_SEED_AFTER_MARCH) T2N_HIP(hipStreamWaitEvent(sa, ev[2], 0));
         timing_begin(f, T2N_K_TV_SEED, sa);
-        if ((rc = launch_tv_seed_dev(f, A->hyper + 19, sa))) return rc;
+        if ((rc = launch_tv_seed_dev(f, A->hyper + 19, sa, sworld, srank))) return rc;
         timing_end(f, T2N_K_TV_SEED, sa);
         T2N_HIP(hipEventRecord(ev[1], sa));
         // ---- backward: per-ray pass
@@ -2092,14 +2126,14 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
     T2N_HIP(hipEventRecord(ev[7], sg));
     if (do_grad) {
         // the density factors (a quarter of the bytes) step on sa right behind their scatter, beside the appearance scatter on `s`
-        if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, sc, 0, 6, sa))) return rc;
+        if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, sc, 0, 6, sa, sworld, srank))) return rc;
         T2N_HIP(hipEventRecord(ev[9], sa));
         f->train_chain = true;      // (the next call's early part may start behind this event)
         timing_begin(f, T2N_K_ADAM, s);
-        if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, sc, 6, 6, s))) return rc;
+        if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, sc, 6, 6, s, sworld, srank))) return rc;
         timing_end(f, T2N_K_ADAM, s);
         T2N_HIP(hipStreamWaitEvent(s, ev[9], 0));
-    } else if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, sc, 0, 12, s))) return rc;
+    } else if ((rc = launch_factor_adam_dev(f, P, A->exp_avg, A->exp_avg_sq, A->beta1, A->beta2, A->eps, sc, 0, 12, s, sworld, srank))) return rc;
     T2N_HIP(hipStreamWaitEvent(s, ev[7], 0));
     T2N_HIP(hipGetLastError());
     return T2N_OK;

@@ -277,9 +277,10 @@ int launch_mlp_bwd_ss(t2n_field* f, void* packbuf, const float4* go, float* h1, 
 int mlp_bwd_ss_pack(t2n_field* f, void* packbuf, hipStream_t s, bool zeroed, bool one_launch = false, bool absmax_done = false);   // one_launch: the pack kernel finds the matrices' largest magnitudes itself
 void* mlp_bwd_ss_absmax_words(void* packbuf);
 // the fused training step's optimiser launches (t2n_optim.hip): scalars / TV weights / verdict from device memory
-int launch_tv_seed_dev(t2n_field* f, const float* tvw_dev, hipStream_t s);
+int launch_tv_seed_dev(t2n_field* f, const float* tvw_dev, hipStream_t s, int world = 1, int rank = 0);
 int launch_factor_adam_dev(t2n_field* f, const t2n_field_params* params, float* const* m, float* const* v, float beta1, float beta2, float eps,
-                           const TrainScalars* st, int first, int count, hipStream_t s);
+                           const TrainScalars* st, int first, int count, hipStream_t s, int world = 1, int rank = 0, bool relayout_only = false);
+void shard_partition(const t2n_field* f, int world, int rank, unsigned lo[12], unsigned hi[12], unsigned body[12]);
 int launch_head_adam_dev(const t2n_field_params* params, const float* grads_flat, float* const* m, float* const* v, float beta1, float beta2,
                          float eps, const TrainScalars* st, hipStream_t s, bool zero_grads = false, unsigned* zero_words4 = nullptr);
 // the driver's loss (t2n_loss.hip); reduce = false leaves the per-workgroup partial sums [ceil(n_rays / 4)][3] in `part`

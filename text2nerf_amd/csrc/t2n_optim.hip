@@ -168,7 +168,7 @@ __device__ __forceinline__ float adam_one(float p, float gi, float& m, float& v,
 template <int C>
 __device__ __forceinline__ void adam_cl_tile(float* __restrict__ tile, unsigned blk, float* __restrict__ p_cl, const float* __restrict__ g_cl,
                                              float* __restrict__ m, float* __restrict__ v, float* __restrict__ p_ref, long long npos_total,
-                                             float lr_over_bc1, float beta1, float beta2, float eps, float inv_bc2_sqrt) {
+                                             float lr_over_bc1, float beta1, float beta2, float eps, float inv_bc2_sqrt, bool relayout_only = false) {
     const long long pos0 = (long long)blk * 64;
     const int npos = (int)(npos_total - pos0 < 64 ? npos_total - pos0 : 64);
     const long long base4 = pos0 * (C / 4);
@@ -178,7 +178,13 @@ __device__ __forceinline__ void adam_cl_tile(float* __restrict__ tile, unsigned 
     float4* __restrict__ M = reinterpret_cast<float4*>(m) + base4;
     float4* __restrict__ V = reinterpret_cast<float4*>(v) + base4;
     for (int e = threadIdx.x; e < n4; e += 256) {
-        float4 pv = P[e], mv = M[e], vv = V[e];
+        float4 pv = P[e];
+        if (relayout_only) {
+            const int j = e / (C / 4), c = (e - j * (C / 4)) * 4;
+            tile[c * 65 + j] = pv.x; tile[(c + 1) * 65 + j] = pv.y; tile[(c + 2) * 65 + j] = pv.z; tile[(c + 3) * 65 + j] = pv.w;
+            continue;
+        }
+        float4 mv = M[e], vv = V[e];
         const float4 gv = G[e];
         pv.x = adam_one(pv.x, gv.x, mv.x, vv.x, lr_over_bc1, beta1, beta2, eps, inv_bc2_sqrt);
         pv.y = adam_one(pv.y, gv.y, mv.y, vv.y, lr_over_bc1, beta1, beta2, eps, inv_bc2_sqrt);
@@ -206,6 +212,12 @@ struct FactorStep {
     float beta1, beta2, eps;
     // fused training step (NULL: by value): Adam scalars + verdict; the two TV weights (x 1e-2) of this step in device memory
     const TrainScalars* st; const float* tvw_dev;
+    // sharded optimiser (data-parallel, world > 1; include/t2n.h "sharded optimiser"): the first body[t] 64-position blocks of plane t
+    // are split evenly over the ranks — this rank owns [own_lo[t], own_hi[t]) — everything behind them (a plane's last blocks, the
+    // lines) is replicated on every rank. world <= 1: body = 0, the whole tensor is "replicated" (the single-rank step).
+    unsigned own_lo[12], own_hi[12], body[12];
+    int world;
+    int relayout_only;   // Adam launch: no arithmetic — the blocks of the body this rank does NOT own, channel-last -> reference layout
 };
 __global__ __launch_bounds__(256) void k_tv_grad_cl_multi(const FactorStep a) {
     int t = 0;
@@ -228,6 +240,16 @@ __global__ __launch_bounds__(256) void k_tv_seed_cl_multi(const FactorStep a) {
         sh = tvw != 0.f ? tvw * 2.f / ((float)C * (float)(H - 1) * (float)W) : 0.f;
         sw = tvw != 0.f ? tvw * 2.f / ((float)C * (float)H * (float)(W - 1)) : 0.f;
     }
+    if (a.world > 1 && (sh != 0.f || sw != 0.f)) {
+        // sharded: the owner of a body block seeds `world` times the TV gradient (the ranks' buffers are then AVERAGED), the others zero;
+        // replicated blocks carry the TV gradient on every rank
+        const unsigned C4 = (unsigned)a.C[t] / 4u;
+        const unsigned blk = (C4 == 4u ? (i32 >> 2) : i32 / C4) >> 6;
+        if (blk < a.body[t]) {
+            if (blk >= a.own_lo[t] && blk < a.own_hi[t]) { sh *= (float)a.world; sw *= (float)a.world; }
+            else { sh = 0.f; sw = 0.f; }
+        }
+    }
     if (sh != 0.f || sw != 0.f) tv_seed_cl_body32(a.p[t], a.g[t], i32, (unsigned)a.C[t] / 4u, (unsigned)a.H[t], (unsigned)a.W[t], sh, sw);
     else if (i < a.npos[t] * (a.C[t] / 4)) reinterpret_cast<float4*>(a.g[t])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -236,14 +258,18 @@ __global__ __launch_bounds__(256) void k_adam_cl_multi(const FactorStep a) {
     int t = 0;
 #pragma unroll 1
     for (int q = 1; q < 12; ++q) t += (a.ablock0[q] <= blockIdx.x) ? 1 : 0;
-    const unsigned blk = blockIdx.x - a.ablock0[t];
+    unsigned blk = blockIdx.x - a.ablock0[t];
+    // the launch's blocks of tensor t: this rank's slice of the body, then the replicated blocks (relayout_only: the rest of the body)
+    if (a.relayout_only) blk = blk < a.own_lo[t] ? blk : blk + (a.own_hi[t] - a.own_lo[t]);
+    else { const unsigned own = a.own_hi[t] - a.own_lo[t]; blk = blk < own ? a.own_lo[t] + blk : a.body[t] + (blk - own); }
     float lr = a.lr_over_bc1[t], ib = a.inv_bc2_sqrt[t];
     if (a.st) {
         if (a.st->skip) return;      // (uniform over the launch)
         lr = a.st->lr_over_bc1[t]; ib = a.st->inv_bc2_sqrt;
     }
-    if (a.C[t] == 16) adam_cl_tile<16>(tile, blk, a.p[t], a.g[t], a.m[t], a.v[t], a.ref[t], a.npos[t], lr, a.beta1, a.beta2, a.eps, ib);
-    else adam_cl_tile<48>(tile, blk, a.p[t], a.g[t], a.m[t], a.v[t], a.ref[t], a.npos[t], lr, a.beta1, a.beta2, a.eps, ib);
+    const bool ro = a.relayout_only != 0;
+    if (a.C[t] == 16) adam_cl_tile<16>(tile, blk, a.p[t], a.g[t], a.m[t], a.v[t], a.ref[t], a.npos[t], lr, a.beta1, a.beta2, a.eps, ib, ro);
+    else adam_cl_tile<48>(tile, blk, a.p[t], a.g[t], a.m[t], a.v[t], a.ref[t], a.npos[t], lr, a.beta1, a.beta2, a.eps, ib, ro);
 }
 
 }  // namespace t2n
@@ -363,12 +389,39 @@ static void factor_step_geometry(t2n_field* f, FactorStep& A, unsigned& ab, unsi
         }
     A.tblock0[12] = tb_all; A.ablock0[12] = ab;
 }
-int launch_tv_seed_dev(t2n_field* f, const float* tvw_dev, hipStream_t s) {
+// the sharded optimiser's partition of the factor tensors (order: density planes, density lines, appearance planes, appearance lines):
+// a plane of n positions has n / 64 whole blocks; chunk = (n / 64) / world of them per rank, body = world * chunk; lines: body = 0
+void shard_partition(const t2n_field* f, int world, int rank, unsigned lo[12], unsigned hi[12], unsigned body[12]) {
+    const int* gr = f->desc.grid;
+    for (int q = 0; q < 4; ++q)
+        for (int k = 0; k < 3; ++k) {
+            const int idx = q * 3 + k;
+            const long long HW = (long long)gr[mat1(k)] * gr[mat0(k)];
+            const bool plane = (q & 1) == 0;
+            const unsigned chunk = (plane && world > 1) ? (unsigned)((HW / 64) / world) : 0u;
+            body[idx] = chunk * (unsigned)(world > 1 ? world : 1);
+            lo[idx] = chunk * (unsigned)(world > 1 ? rank : 0); hi[idx] = lo[idx] + chunk;
+        }
+}
+static void factor_step_shard(const t2n_field* f, FactorStep& A, int world, int rank, bool relayout_only, unsigned& ab) {
+    shard_partition(f, world, rank, A.own_lo, A.own_hi, A.body);
+    A.world = world > 1 ? world : 1;
+    A.relayout_only = relayout_only ? 1 : 0;
+    ab = 0;
+    for (int i = 0; i < 12; ++i) {
+        const unsigned total = (unsigned)((A.npos[i] + 63) / 64), own = A.own_hi[i] - A.own_lo[i];
+        A.ablock0[i] = ab;
+        ab += relayout_only ? A.body[i] - own : own + (total - A.body[i]);
+    }
+    A.ablock0[12] = ab;
+}
+int launch_tv_seed_dev(t2n_field* f, const float* tvw_dev, hipStream_t s, int world, int rank) {
     if (f->desc.grid[0] < 2 || f->desc.grid[1] < 2 || f->desc.grid[2] < 2) { set_error("t2n_train_step: TV needs planes of at least 2x2"); return T2N_ERR_INVALID; }
     FactorStep A;
     memset(&A, 0, sizeof(A));
     unsigned ab, tb;
     factor_step_geometry(f, A, ab, tb);
+    factor_step_shard(f, A, world, rank, false, ab);
     A.tvw_dev = tvw_dev;
     hipLaunchKernelGGL(k_tv_seed_cl_multi, dim3(tb), dim3(256), 0, s, A);
     T2N_HIP(hipGetLastError());
@@ -377,16 +430,17 @@ int launch_tv_seed_dev(t2n_field* f, const float* tvw_dev, hipStream_t s) {
 // Adam on the channel-last copies of the factor tensors first .. first + count - 1 (order: density planes, density lines, appearance
 // planes, appearance lines), new values also written to the caller's reference-layout tensors
 int launch_factor_adam_dev(t2n_field* f, const t2n_field_params* params, float* const* m, float* const* v, float beta1, float beta2, float eps,
-                           const TrainScalars* st, int first, int count, hipStream_t s) {
+                           const TrainScalars* st, int first, int count, hipStream_t s, int world, int rank, bool relayout_only) {
     FactorStep A;
     memset(&A, 0, sizeof(A));
     unsigned ab, tb;
     factor_step_geometry(f, A, ab, tb);
+    factor_step_shard(f, A, world, rank, relayout_only, ab);
     for (int k = 0; k < 3; ++k) {
         A.ref[k] = (float*)params->density_plane[k]; A.ref[3 + k] = (float*)params->density_line[k];
         A.ref[6 + k] = (float*)params->app_plane[k]; A.ref[9 + k] = (float*)params->app_line[k];
     }
-    for (int i = 0; i < 12; ++i) { A.m[i] = m[i]; A.v[i] = v[i]; if (!A.ref[i] || !m[i] || !v[i]) { set_error("t2n_train_step: NULL factor tensor / moment %d", i); return T2N_ERR_INVALID; } }
+    for (int i = 0; i < 12; ++i) { A.m[i] = m ? m[i] : nullptr; A.v[i] = v ? v[i] : nullptr; if (!A.ref[i] || (!relayout_only && (!A.m[i] || !A.v[i]))) { set_error("t2n_train_step: NULL factor tensor / moment %d", i); return T2N_ERR_INVALID; } }
     A.beta1 = beta1; A.beta2 = beta2; A.eps = eps; A.st = st;
     // a sub-range of the tensors: the launch covers their workgroups only (block index rebased by shifting the table)
     const unsigned b0 = A.ablock0[first], b1 = A.ablock0[first + count];

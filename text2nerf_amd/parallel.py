@@ -200,3 +200,149 @@ def broadcast_parameters(params, src=0, group=None):
             n = p.numel()
             p.copy_(flat[off:off + n].view_as(p))   # in-place on the parameter itself: bumps its version, so the native field
             off += n                                 # re-uploads (a write through .data would leave a stale device copy)
+
+
+# ---- sharded optimiser (SURVEY.md §8 e) -----------------------------------------------------------------------
+# With the flat all-reduce above every rank repeats TV + Adam over all 70 MB of factors (10 streams of HBM traffic per element) and
+# receives gradients it only needs 1 / world of. Here each plane's 64-position blocks are split evenly over the ranks (the "body"; the few
+# blocks behind it, the six lines and the head stay replicated):
+#   phase 1 (t2n_train_step, shard_world / shard_rank)   the owner seeds world x TV, everybody else zero, then the local backward
+#   reduce()    reduce-scatter(AVG) of each body IN PLACE (a rank receives only its slice: (world - 1) / world of the bytes of an
+#               all-reduce's reduce-scatter half, and no all-gather half), one small all-reduce(AVG) of replicated blocks + lines + head
+#   phase 2     TV-seeded Adam on the owned + replicated blocks: 1 / world of the optimiser traffic; moments of other blocks never touched
+#   gather()    all-gather of each body of the channel-last parameter copies IN PLACE
+#   phase 4     the gathered blocks -> the caller's reference-layout tensors
+# Bytes on the links per rank and step at world = 8, 300^3: reduce-scatter 7/8 x 69 MB + all-gather 7/8 x 69 MB — the same as the flat
+# all-reduce's — but TV + Adam drop from ~150 us to ~20 us per rank, and the all-gather of the parameters overlaps nothing it has to wait
+# for (the next step's march needs the density planes only: issued first).
+
+def shard_layout(grid, world, n_den=16, n_app=48):
+    """Python mirror of t2n_field_shard_layout (text2nerf_amd/csrc/t2n_optim.hip shard_partition): rows ``[offset, slice, total]`` in
+    floats for the 12 factor tensors (density planes, density lines, appearance planes, appearance lines) of the channel-last gradient
+    buffer; `slice` = floats of ONE rank's part of the body (0: wholly replicated)."""
+    MAT = ((0, 1), (0, 2), (1, 2))
+    VEC = (2, 1, 0)
+    out, off = [], 0
+    for q in range(4):
+        C = n_den if q < 2 else n_app
+        for k in range(3):
+            n = int(grid[MAT[k][1]]) * int(grid[MAT[k][0]]) if q % 2 == 0 else int(grid[VEC[k]])
+            chunk = ((n // 64) // world) if (q % 2 == 0 and world > 1) else 0
+            out.append([off // 4, chunk * 64 * C, n * C])
+            off += (n * C * 4 + 255) // 256 * 256
+    return out
+
+
+class _DeviceView:
+    """A device allocation of the native library as an object torch can wrap without a copy (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class ShardedExchange:
+    """The two exchanges of the sharded optimiser, as the ``all_reduce`` argument of ``train_step``::
+
+        ex = ShardedExchange.for_field(field, group)
+        field.train_step(rays, rgb, depth, optimizer, ..., all_reduce=ex)
+
+    `layout`: shard_layout rows; `grads`: the flat channel-last gradient buffer; `params`: the 12 channel-last parameter arrays (flat);
+    `extra`: callable returning further flat tensors averaged with the replicated parts (the fused step's head gradients + vote word)."""
+
+    def __init__(self, layout, grads, params, group=None, extra=None, world=None, rank=None):
+        self.group = group
+        if world is None:       # (world / rank given: a subclass brings its own collectives — tests/helpers/virtual_ranks.py)
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            self._nccl = dist.get_backend(group) == "nccl"
+        self.world, self.rank = int(world), int(rank)
+        self.layout, self.grads, self.params, self.extra = layout, grads, params, extra
+
+    @classmethod
+    def for_field(cls, field, group=None, world=None, rank=None):
+        from . import _lib
+        import ctypes as C
+        lib = _lib.load()
+        if world is None:
+            world = dist.get_world_size(group)
+        grads = field.factor_grad_buffer(_raw=True)
+        h = field.sync_params()
+        lay = (C.c_int64 * 36)()
+        _lib.check(lib.t2n_field_shard_layout(h, world, lay), "t2n_field_shard_layout")
+        layout = [[int(lay[3 * t]), int(lay[3 * t + 1]), int(lay[3 * t + 2])] for t in range(12)]
+        params = []
+        for t in range(12):
+            p = C.c_void_p()
+            _lib.check(lib.t2n_field_factor_buffer(h, t, C.byref(p)), "t2n_field_factor_buffer")
+            params.append(torch.as_tensor(_DeviceView(p.value, layout[t][2]), device=grads.device))
+        ex = cls(layout, grads, params, group, world=None if rank is None else world, rank=rank)
+        ex.field = field
+        return ex
+
+    def __call__(self):
+        raise RuntimeError("ShardedExchange drives the fused train step (TensorVMSplit.train_step with optim.TVAdam(field=...)); "
+                           "use parallel.allreduce_gradients for the composed step")
+
+    # -- collectives with an averaging reduction; gloo (CPU tests) has neither reduce_scatter nor AVG: all-reduce + divide there
+    def _reduce_scatter_avg(self, own, body):
+        if self._nccl:
+            dist.reduce_scatter_tensor(own, body, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(body, op=dist.ReduceOp.SUM, group=self.group)
+            own.div_(self.world)
+
+    def _all_reduce_avg(self, t):
+        if self._nccl:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            t.div_(self.world)
+
+    def _all_gather(self, body, own):
+        if self._nccl:
+            dist.all_gather_into_tensor(body, own, group=self.group)
+        else:
+            parts = [torch.empty_like(own) for _ in range(self.world)]
+            dist.all_gather(parts, own.clone(), group=self.group)
+            for r, part in enumerate(parts):
+                body[r * own.numel():(r + 1) * own.numel()].copy_(part)
+
+    def _slices(self, flat, t, base):
+        off = self.layout[t][0] if base else 0
+        sl, total = self.layout[t][1], self.layout[t][2]
+        body = flat[off:off + self.world * sl]
+        return body, body[self.rank * sl:(self.rank + 1) * sl], flat[off + self.world * sl:off + total]
+
+    def reduce(self, fused_step=None):
+        """Average the ranks' gradient buffers: every body by reduce-scatter (this rank's slice ends up averaged, the other slices
+        are garbage nobody reads), the replicated remainders + `extra` by ONE small all-reduce."""
+        g = self.grads
+        small = []
+        for t in range(12):
+            body, own, rest = self._slices(g, t, True)
+            if own.numel():
+                self._reduce_scatter_avg(own, body)
+            if rest.numel():
+                small.append(rest)
+        extra = []
+        if fused_step is not None:
+            extra = [fused_step.head_grads]
+        elif self.extra is not None:
+            extra = list(self.extra())
+        pieces = small + extra
+        flat = torch.cat([x.reshape(-1) for x in pieces])
+        self._all_reduce_avg(flat)
+        off = 0
+        for x in pieces:
+            n = x.numel()
+            x.copy_(flat[off:off + n].view_as(x))
+            off += n
+        f = getattr(self, "field", None)
+        if f is not None:
+            f._gbuf_dirty, f._gbuf_reduced = True, True
+
+    def gather(self, fused_step=None):
+        """All-gather every body of the channel-last parameter copies in place (density planes first: the next march reads them)."""
+        for t in range(12):
+            body, own, _ = self._slices(self.params[t], t, False)
+            if own.numel():
+                self._all_gather(body, own)

@@ -352,13 +352,26 @@ class FusedStep:
             self._launch(i, a, key, graph, m)
         else:
             a, key = self._args(i, m["R"], m["stride"], m["N"], m["flags"], 1, cap, m["betas"], m["eps"], m["w_depth"], m["w_trans"], m["delta"])
+            # parallel.ShardedExchange: the sharded optimiser — phase 1 seeds the TV gradient for the blocks this rank owns, the exchange
+            # averages (reduce-scatter of the plane bodies + one small all-reduce), phase 2 steps the owned and the replicated blocks,
+            # the exchange all-gathers the channel-last parameter bodies, phase 4 writes the gathered blocks to the caller's tensors
+            sharded = hasattr(all_reduce, "gather") and int(getattr(all_reduce, "world", 1)) > 1
+            a.shard_world, a.shard_rank = (int(all_reduce.world), int(all_reduce.rank)) if sharded else (0, 0)
             self._launch(i, a, key, False)
             f._gbuf_dirty, f._gbuf_stale, f._gbuf_reduced = True, False, False
             f._deferred_grad_key = f._uploaded_key
             self._install_head_grads()
-            all_reduce()
+            if hasattr(all_reduce, "reduce"):
+                all_reduce.reduce(self)
+            else:
+                all_reduce()
             a.phases = 2
             self._launch(i, a, key, False)
+            if sharded:
+                all_reduce.gather(self)
+                a.phases = 4
+                self._launch(i, a, key, False)
+            a.phases = 1
         self.slots[i] = dict(i=i, seq=self.issued, cap=cap, meta=m)
         self.issued += 1
         self._after_update()
