@@ -262,8 +262,11 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
         if fused_step:   # autograd-free: render -> loss kernel (emits d_rgb / d_depth / d_weights) -> backward -> TV + Adam
             ar = (lambda: allreduce_gradients(all_params, average=True, field=field)) if dist is not None else None
             b_rays, b_rgb, b_dep = batch_of(k)      # the rows allrays[idx] / allrgb[idx] / alldepth[idx] (text2nerf_main.py:550-553)
+            kw = step_kw
+            if "all_reduce" in step_kw:             # (scaling_prediction: a rank's compute with the exchange left out)
+                ar, kw = step_kw["all_reduce"], {a: b for a, b in step_kw.items() if a != "all_reduce"}
             return field.train_step(b_rays, b_rgb, b_dep, opt, N_samples=n_samples, white_bg=True, tv=tv_terms, all_reduce=ar,
-                                    speculative=speculative, **step_kw)[3]
+                                    speculative=speculative, **kw)[3]
         # targets go host -> device like text2nerf_main.py:550-553, through the pinned staging ring (a pageable .to(device)
         # drains the stream first and idles the GPU for the rest of the host-side batch preparation)
         rays, rgb_t, dep_t = allrays.index_select(0, idx), to_device_async(allrgb.index_select(0, idx), dev), to_device_async(alldepth.index_select(0, idx), dev)
@@ -556,16 +559,41 @@ def scaling_prediction(field, dev, fused_ms, G=8):
                 steps[b] = train_bench(dev, iters=20, warmup=3, fused_step=True, batch=b)["ms_per_iter"]
             # direct reduce-scatter + all-gather of the 69.6 MB buffer over 7 links per GPU: 2 x (bytes / 8) per link
             ar_ms = 2 * (69.6e6 / G) / (153e9 * 0.7) * 1e3 + 0.05
+
+            # the per-rank COMPUTE of a data-parallel step at 16 384 / G rays, with the exchanges left out (one GPU here): the two-call
+            # form every rank of the flat all-reduce runs (TV + Adam over all 70 MB on every rank), and rank 0 of the sharded optimiser
+            # (parallel.ShardedExchange: seeds / steps 1 / G of the planes, then writes the gathered 7 / 8 into the reference layout)
+            class _NoExchange:
+                def __init__(self, world, rank):
+                    self.world, self.rank = world, rank
+
+                def reduce(self, fs):
+                    pass
+
+                def gather(self, fs):
+                    pass
+            dp_flat = train_bench(dev, iters=20, warmup=3, fused_step=True, batch=16384 // G,
+                                  step_kw=dict(fused=True, graph=False, all_reduce=lambda: None))["ms_per_iter"]
+            dp_shard = train_bench(dev, iters=20, warmup=3, fused_step=True, batch=16384 // G,
+                                   step_kw=dict(fused=True, graph=False, all_reduce=_NoExchange(G, 0)))["ms_per_iter"]
             pred["train_dp"] = {"fused_step_ms_by_rays_per_gpu": {str(k): v for k, v in steps.items()},
                                 "all_reduce_estimate_ms": ar_ms,
-                                "predicted_8gpu_step_ms": steps[16384 // G] + ar_ms,
-                                "predicted_speedup": fused_ms / (steps[16384 // G] + ar_ms),
+                                "per_rank_compute_ms_flat_all_reduce": dp_flat,
+                                "per_rank_compute_ms_sharded_optimizer": dp_shard,
+                                "exchange_estimate_ms_sharded": ar_ms,     # reduce-scatter of the gradients + all-gather of the parameters: the same bytes per link
+                                "predicted_8gpu_step_ms_flat": dp_flat + ar_ms,
+                                "predicted_8gpu_step_ms": dp_shard + ar_ms,
+                                "predicted_speedup": fused_ms / (dp_shard + ar_ms),
+                                "predicted_speedup_flat": fused_ms / (dp_flat + ar_ms),
                                 # the other way to use 8 GPUs (the driver's --batch_size x 8): every GPU keeps its 16 384 rays
                                 "predicted_8gpu_weak_step_ms": fused_ms + ar_ms,
                                 "predicted_weak_rays_per_s_ratio": G * fused_ms / (fused_ms + ar_ms),
-                                "note": "strong scaling of ONE 16 384-ray batch: the step at 2 048 rays / GPU is a chain of ~40 launches whose "
-                                        "fixed cost does not shrink; the all-reduce is not overlapped with the backward (the scatter kernels "
-                                        "finish the factor gradients last). *_weak_*: 16 384 rays per GPU (8 x the batch), rays/s against one GPU"}
+                                "note": "strong scaling of ONE 16 384-ray batch: the step at 2 048 rays / GPU is a chain of 28 launches whose "
+                                        "fixed cost does not shrink. per_rank_compute_*: measured on this GPU with the exchange left out — "
+                                        "flat: every rank runs TV + Adam over all 70 MB; sharded (parallel.ShardedExchange, t2n_train_step "
+                                        "shard_world / shard_rank): 1 / 8 of the planes per rank + the write-back of the gathered 7 / 8. The "
+                                        "exchange (reduce-scatter of gradients + all-gather of parameters, priced from the link rate) is not "
+                                        "overlapped with compute in either form. *_weak_*: 16 384 rays per GPU (8 x the batch), rays/s against one GPU"}
         except Exception as e:  # noqa: BLE001
             pred["train_dp"] = {"error": repr(e)[:300]}
     pred["weak_c2"] = {"note": "default --gpus N mode: one independent 800x800 view per GPU, the 10 MB all-gather of frame k overlaps the "
