@@ -355,7 +355,10 @@ __global__ __launch_bounds__(64) void k_gen_bwd_march(const GenArgs a) {
 //   k_gen_compact    the appearance samples (weight > threshold) -> an index list (wave-aggregated append)
 //   k_gen_head       one workgroup per 64 list entries: appearance features (each wave a quarter of the components, basis_mat from LDS),
 //                    then the head — MLP layers as [units of this wave] x [64 samples] outer products on the VALU with the weights as
-//                    wave-uniform (scalar) operands and the activations in LDS; SH / RGB per sample
+//                    wave-uniform (scalar) operands and the activations in LDS; SH / RGB per sample.
+//                    MLP heads with <= 512 inputs: the kernel only writes the input rows of one PASS of the list (262 144 entries), layers
+//                    0 / 1 run on the matrix cores (k_dense of t2n_heads.hip, exact-fp32 MFMA), k_gen_out finishes (layer 2 + sigmoid);
+//                    passes are issued for the worst case and clipped to the device-side count (T2N_GENERIC_VALU_HEAD=1: the VALU form)
 // Taken when the workspace has room for the staged copies and the list (t2n_generic_workspace_bytes_desc); same outputs and context as
 // the plain form (the backward reads them), values equal to rounding (the density sums are bit-identical).
 struct GenFast {
@@ -363,6 +366,9 @@ struct GenFast {
     int* list; unsigned* count; unsigned cap;
     int ncol;
     const float* w0p; const float* w1p; int ld0, ld1;   // MLP weights with rows padded to multiples of 16 floats (64-byte aligned rows: s_load_dwordx16)
+    // MLP layers on the matrix cores (k_dense of t2n_heads.hip, exact-fp32 MFMA): the head kernel then only WRITES the input rows of
+    // one pass of the list — entries [row0, row0 + rows_cap) — to x0 [rows_cap][ldx]; k_gen_out finishes from h1
+    float* x0; int ldx; unsigned row0, rows_cap; HeadPlanDev* plan;
 };
 __global__ __launch_bounds__(256) void k_gen_padrows(const float* __restrict__ src, float* __restrict__ dst, int rows, int n, int ld) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -523,12 +529,18 @@ __global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast
     float* __restrict__ Xc = feat + D * 64;                           // [16][64] input chunk
     float* __restrict__ Hb = Xc + 16 * 64;                            // [max(4 D, fC)][64]: feature partials, then activations
     const int tid = threadIdx.x, s = tid & 63, g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned count = *fa.count;
+    unsigned ntiles = (count + 63u) / 64u, tile0 = 0;
+    if (fa.x0) {   // one pass of the list
+        tile0 = fa.row0 / 64u;
+        const unsigned te = (fa.row0 + fa.rows_cap) / 64u;
+        ntiles = ntiles < te ? ntiles : te;
+    }
+    if (tile0 + blockIdx.x >= ntiles) return;     // (a pass beyond the count: nothing staged)
     for (int i = tid; i < ncol * D; i += 256) { const int col = i / D, f = i - col * D; basisT[i] = a.basis[(size_t)f * ncol + col]; }
     __syncthreads();
-    const unsigned count = *fa.count;
-    const unsigned ntiles = (count + 63u) / 64u;
     const bool mlp = a.shading == T2N_SHADE_MLP_FEA_NOVIEW || a.shading == T2N_SHADE_MLP_FEA || a.shading == T2N_SHADE_MLP;
-    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (unsigned tile = tile0 + blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const unsigned e = tile * 64u + (unsigned)s;
         const bool live = e < count;
         const long long t = fa.list[live ? e : tile * 64u];
@@ -604,9 +616,23 @@ __global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast
             __syncthreads();
             continue;
         }
+        const int nin = a.in0;
+        if (fa.x0) {
+            // ---- the input rows of this tile to memory, 16 columns at a time: thread -> (row tid / 4, four columns): 64-byte runs per row
+            float* __restrict__ xr = fa.x0 + (size_t)(tile * 64u - fa.row0 + (unsigned)(tid >> 2)) * fa.ldx + (tid & 3) * 4;
+            for (int j0 = 0; j0 < fa.ldx; j0 += 16) {
+                __syncthreads();                                        // the previous chunk has been read
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int j = j0 + 4 * g + q; Xc[(4 * g + q) * 64 + s] = j < nin ? gen_input_col(a, feat + s, dir, j) : 0.f; }
+                __syncthreads();
+                const int rr = tid >> 2, cc = (tid & 3) * 4;
+                *reinterpret_cast<float4*>(xr + j0) = make_float4(Xc[cc * 64 + rr], Xc[(cc + 1) * 64 + rr], Xc[(cc + 2) * 64 + rr], Xc[(cc + 3) * 64 + rr]);
+            }
+            __syncthreads();
+            continue;
+        }
         // ---- layer 0: the input row in chunks of 16 columns (each wave makes 4 of them, LDS), all waves multiply -------------------------
         float acc[kGenUnitsPerWave];
-        const int nin = a.in0;
         gen_layer(acc, fa.w0p, a.b0, nin, fa.ld0, fC, g, [&](int j0, float (&x)[16]) {
             __syncthreads();                                            // the previous chunk has been read
 #pragma unroll
@@ -639,6 +665,38 @@ __global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast
             for (int c = 0; c < 3; ++c) a.rgb_s[t * 3 + c] = 1.f / (1.f + expf(-o[c]));
         }
         __syncthreads();
+    }
+}
+
+__global__ void k_gen_plan(const unsigned* __restrict__ count, HeadPlanDev* __restrict__ plan) { plan->rows = *count; }
+// layer 2 + sigmoid from h1 [rows_cap][ldh] of one pass: four lanes per row, a quarter of the units each
+__global__ __launch_bounds__(256) void k_gen_out(const GenArgs a, const GenFast fa, const float* __restrict__ h1, int ldh) {
+    const unsigned count = *fa.count;
+    if (fa.row0 >= count) return;
+    const int fC = a.fC, per = (fC + 3) / 4;
+    for (long long t4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; t4 < (long long)fa.rows_cap * 4; t4 += (long long)gridDim.x * blockDim.x) {
+    const unsigned lrow = (unsigned)(t4 >> 2);
+    const int p = (int)(t4 & 3);
+    const unsigned e = fa.row0 + lrow;
+    const bool in = e < count;
+    const int v0 = p * per, v1 = min(fC, v0 + per);
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (in) {
+        const float* __restrict__ hr = h1 + (size_t)lrow * ldh;
+        for (int v = v0; v < v1; ++v) {
+            const float hv = hr[v];
+            o0 = fmaf(a.w2[v], hv, o0); o1 = fmaf(a.w2[fC + v], hv, o1); o2 = fmaf(a.w2[2 * fC + v], hv, o2);
+        }
+    }
+    o0 += dpp_quad_xor1(o0); o0 += dpp_quad_xor2(o0);
+    o1 += dpp_quad_xor1(o1); o1 += dpp_quad_xor2(o1);
+    o2 += dpp_quad_xor1(o2); o2 += dpp_quad_xor2(o2);
+    if (in && p == 0) {
+        const long long t = fa.list[e];
+        a.rgb_s[t * 3] = 1.f / (1.f + expf(-(o0 + a.b2[0])));
+        a.rgb_s[t * 3 + 1] = 1.f / (1.f + expf(-(o1 + a.b2[1])));
+        a.rgb_s[t * 3 + 2] = 1.f / (1.f + expf(-(o2 + a.b2[2])));
+    }
     }
 }
 
@@ -689,7 +747,8 @@ static GenCarve gen_carve(int64_t R, int N, bool own_wz) {
 }
 
 // staged (channel-last) factor copies + the appearance list behind the plain carve
-struct GenStageCarve { size_t t[12], list, count, w0p, w1p, total; };
+struct GenStageCarve { size_t t[12], list, count, w0p, w1p, plan, x0, h0, h1, total; unsigned rows_cap; int ldx, ldh; };
+constexpr long long kGenPassRows = 262144;   // list entries per pass of the matrix-core head (x0 + h0 + h1: 3.4 KB per row at 351 / 256 / 256)
 static GenStageCarve gen_stage_carve(const t2n_generic_desc* d, int64_t R, int N, size_t base) {
     GenStageCarve c;
     size_t o = (base + 255) / 256 * 256;
@@ -708,6 +767,18 @@ static GenStageCarve gen_stage_carve(const t2n_generic_desc* d, int64_t R, int N
     const size_t in0 = (size_t)d->app_dim * (1 + 2 * (fpe > 0 ? fpe : 0)) + (d->shading != T2N_SHADE_MLP_FEA_NOVIEW ? 3 + 6 * (size_t)(d->view_pe > 0 ? d->view_pe : 0) : 0);
     c.w0p = o; o = (o + fc * ((in0 + 15) / 16 * 16) * 4 + 255) / 256 * 256;
     c.w1p = o; o = (o + fc * ((fc + 15) / 16 * 16) * 4 + 255) / 256 * 256;
+    // matrix-core head (MLP heads with <= 512 inputs): the device-side row count and one pass's activation rows
+    const long long tot = (long long)R * N;
+    c.rows_cap = (unsigned)(((tot < kGenPassRows ? tot : kGenPassRows) + 63) / 64 * 64);
+    c.ldx = (int)((in0 + 15) / 16 * 16); c.ldh = (int)((fc + 3) / 4 * 4);
+    const bool mlp = d->shading == T2N_SHADE_MLP_FEA_NOVIEW || d->shading == T2N_SHADE_MLP_FEA || d->shading == T2N_SHADE_MLP;
+    c.plan = o; o += 256;
+    c.x0 = c.h0 = c.h1 = 0;
+    if (mlp && in0 <= 512 && fc <= 512) {
+        c.x0 = o; o = (o + (size_t)c.rows_cap * c.ldx * 4 + 255) / 256 * 256;
+        c.h0 = o; o = (o + (size_t)c.rows_cap * c.ldh * 4 + 255) / 256 * 256;
+        c.h1 = o; o = (o + (size_t)c.rows_cap * c.ldh * 4 + 255) / 256 * 256;
+    }
     c.total = o;
     return c;
 }
@@ -798,7 +869,24 @@ extern "C" int t2n_generic_forward(const t2n_generic_desc* desc, const t2n_field
         static bool attr_set = false;
         if (!attr_set) { T2N_HIP(hipFuncSetAttribute((const void*)k_gen_head, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
         const unsigned long long wt = ((unsigned long long)tot + 63) / 64;
-        hipLaunchKernelGGL(k_gen_head, dim3((unsigned)(wt < 1024 ? (wt ? wt : 1) : 1024)), dim3(256), lds, s, a, fa);
+        fa.x0 = nullptr; fa.ldx = 0; fa.row0 = 0; fa.rows_cap = 0; fa.plan = nullptr;
+        static const bool valu_head = getenv("T2N_GENERIC_VALU_HEAD") && atoi(getenv("T2N_GENERIC_VALU_HEAD")) != 0;
+        if (sc.x0 && fa.w0p && !valu_head) {
+            // MLP layers 0 / 1 on the matrix cores: passes of rows_cap list entries, issued for the worst case (every sample an appearance
+            // sample) and clipped to the count on the device — a pass beyond the count costs its empty launches
+            fa.x0 = (float*)(ws + sc.x0); fa.ldx = sc.ldx; fa.rows_cap = sc.rows_cap; fa.plan = (HeadPlanDev*)(ws + sc.plan);
+            float* h0 = (float*)(ws + sc.h0); float* h1 = (float*)(ws + sc.h1);
+            hipLaunchKernelGGL(k_gen_plan, dim3(1), dim3(1), 0, s, (const unsigned*)fa.count, fa.plan);
+            const unsigned long long pt = ((unsigned long long)sc.rows_cap + 63) / 64;
+            for (long long row0 = 0; row0 < tot; row0 += sc.rows_cap) {
+                fa.row0 = (unsigned)row0;
+                hipLaunchKernelGGL(k_gen_head, dim3((unsigned)(pt < 1024 ? pt : 1024)), dim3(256), lds, s, a, fa);
+                if ((rc = launch_dense_rows(fa.x0, sc.ldx, a.w0, a.in0, a.fC, a.b0, 1, sc.rows_cap, h0, sc.ldh, s, fa.plan, row0))) return rc;
+                if ((rc = launch_dense_rows(h0, sc.ldh, a.w1, a.fC, a.fC, a.b1, 1, sc.rows_cap, h1, sc.ldh, s, fa.plan, row0))) return rc;
+                hipLaunchKernelGGL(k_gen_out, dim3((unsigned)min(((unsigned long long)sc.rows_cap * 4 + 255) / 256, 2048ull)), dim3(256), 0, s, a, fa, (const float*)h1, sc.ldh);
+            }
+        } else
+            hipLaunchKernelGGL(k_gen_head, dim3((unsigned)(wt < 1024 ? (wt ? wt : 1) : 1024)), dim3(256), lds, s, a, fa);
         hipLaunchKernelGGL(k_gen_composite, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, s, a);
         T2N_HIP(hipGetLastError());
         return T2N_OK;

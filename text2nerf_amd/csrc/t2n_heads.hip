@@ -312,6 +312,12 @@ static int launch_dense(const float* IN, int ldin, const float* Wt, int K, int N
     return T2N_OK;
 }
 
+// (the general-shape path's MLP layers, t2n_generic.hip)
+int launch_dense_rows(const float* IN, int ldin, const float* Wt, int K, int N, const float* bias, int relu, long long rows, float* OUT, int ldo,
+                      hipStream_t s, const HeadPlanDev* plan, long long row0) {
+    return launch_dense(IN, ldin, Wt, K, N, bias, relu, rows, OUT, ldo, s, plan, row0);
+}
+
 // features (already in feat32) -> X0 -> h0 -> h1 -> app_rgb. tiles_before[l] = 32-row tiles before sub-list l.
 int launch_head_forward(t2n_field* f, const unsigned tiles_before[kLists + 1], long long rows, const float* feat32, const float4* app_pos,
                         const int* app_ray, const float* rays, int ray_stride, const unsigned* counters, unsigned list_cap, float* x0,

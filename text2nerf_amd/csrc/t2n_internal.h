@@ -217,6 +217,9 @@ HeadDims head_dims(const t2n_field_desc& d);
 inline bool head_is_generic(int shading) { return shading == T2N_SHADE_MLP_FEA || shading == T2N_SHADE_MLP_PE || shading == T2N_SHADE_MLP; }
 struct HeadPlanDev { unsigned t[kLists + 1]; unsigned rows; };   // device-side plan of a general-head forward: tile prefix, row count
 int launch_head_plan(const unsigned* counters, unsigned list_cap, HeadPlanDev* plan, hipStream_t s);
+// OUT[rows, N] = act(IN[rows, K] Wt[N, K]^T + bias) on exact-fp32 MFMA (k_dense); rows clipped to plan->rows - row0 on the device
+int launch_dense_rows(const float* IN, int ldin, const float* Wt, int K, int N, const float* bias, int relu, long long rows, float* OUT, int ldo,
+                      hipStream_t s, const HeadPlanDev* plan, long long row0);
 // plan == NULL: rows / tiles_before from the host (the backward's recompute). plan != NULL: one PASS over rows [row0, row0 + rows) of the
 // call, scratch row = row - row0, clipped to the plan's count on the device (tiles_before may be NULL)
 int launch_head_forward(t2n_field* f, const unsigned tiles_before[kLists + 1], long long rows, const float* feat32, const float4* app_pos,
