@@ -369,6 +369,7 @@ struct GenFast {
     // MLP layers on the matrix cores (k_dense of t2n_heads.hip, exact-fp32 MFMA): the head kernel then only WRITES the input rows of
     // one pass of the list — entries [row0, row0 + rows_cap) — to x0 [rows_cap][ldx]; k_gen_out finishes from h1
     float* x0; int ldx; unsigned row0, rows_cap; HeadPlanDev* plan;
+    int hbc;   // columns of Hb (a multiple of 16): the head kernel's LDS staging of the input rows
 };
 __global__ __launch_bounds__(256) void k_gen_padrows(const float* __restrict__ src, float* __restrict__ dst, int rows, int n, int ld) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -521,7 +522,10 @@ __device__ __forceinline__ void gen_layer(float (&acc)[kGenUnitsPerWave], const 
         }
     }
 }
-__global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast fa) {
+// ROWS: the instantiation that only writes the MLP input rows (the layers run in k_dense): without the VALU layers' 64 accumulators it
+// needs a third of the registers (the one kernel for both took 256 VGPRs: one wave per SIMD, nothing to hide the gather's latency behind)
+template <bool ROWS, int DMAX>
+__device__ __forceinline__ void gen_head_body(const GenArgs& a, const GenFast& fa) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = a.app_dim, ncol = fa.ncol, fC = a.fC;
     float* __restrict__ basisT = sm;                                  // [ncol][D]
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast
     const int tid = threadIdx.x, s = tid & 63, g = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned count = *fa.count;
     unsigned ntiles = (count + 63u) / 64u, tile0 = 0;
-    if (fa.x0) {   // one pass of the list
+    if constexpr (ROWS) {   // one pass of the list
         tile0 = fa.row0 / 64u;
         const unsigned te = (fa.row0 + fa.rows_cap) / 64u;
         ntiles = ntiles < te ? ntiles : te;
@@ -555,9 +559,9 @@ __global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast
         const float dir[3] = {rp[3], rp[4], rp[5]};
         // ---- appearance features: wave g takes a quarter of every plane's components ---------------------------------------------------
         {
-            float fp[kGenDimMax];
+            float fp[DMAX];
 #pragma unroll
-            for (int f = 0; f < kGenDimMax; ++f) fp[f] = 0.f;
+            for (int f = 0; f < DMAX; ++f) fp[f] = 0.f;
             int col0 = 0;
             for (int k = 0; k < 3; ++k) {
                 const int W = a.grid[mat0(k)], C = a.Ca[k];
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast
                     const float xv = v * fmaf(b1, al.w1, b0 * al.w0);
                     const float* __restrict__ bt = basisT + (size_t)(col0 + c) * D;
 #pragma unroll
-                    for (int f = 0; f < kGenDimMax; ++f) if (f < D) fp[f] = fmaf(bt[f], xv, fp[f]);
+                    for (int f = 0; f < DMAX; ++f) if (f < D) fp[f] = fmaf(bt[f], xv, fp[f]);
                 };
                 if ((C & 3) == 0) {      // four components per load (the staged rows are 16-byte aligned when C is a multiple of 4)
                     const int ng4 = C / 4, per = (ng4 + 3) / 4, qb = g * per, qe = min(ng4, qb + per);
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast
                 col0 += C;
             }
 #pragma unroll
-            for (int f = 0; f < kGenDimMax; ++f) if (f < D) Hb[(g * D + f) * 64 + s] = fp[f];
+            for (int f = 0; f < DMAX; ++f) if (f < D) Hb[(g * D + f) * 64 + s] = fp[f];
         }
         __syncthreads();
         for (int f = g; f < D; f += 4) feat[f * 64 + s] = (Hb[f * 64 + s] + Hb[(D + f) * 64 + s]) + (Hb[(2 * D + f) * 64 + s] + Hb[(3 * D + f) * 64 + s]);
@@ -617,20 +621,42 @@ __global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast
             continue;
         }
         const int nin = a.in0;
-        if (fa.x0) {
-            // ---- the input rows of this tile to memory, 16 columns at a time: thread -> (row tid / 4, four columns): 64-byte runs per row
+        if constexpr (ROWS) {
+            // ---- the input rows of this tile to memory. Columns are built in rounds of `hbc` of them in Hb (free once the feature partials
+            // are reduced): the plain columns one by one; the features' encodings per FEATURE — one sincosf, then angle doubling per octave
+            // (sin 2x = 2 s c, cos 2x = c^2 - s^2: <= 5 steps, error ~3e-6) instead of a sinf or cosf per column, which was most of this
+            // kernel's time — then 16 columns at a time to memory: thread -> (row tid / 4, four columns), 64-byte runs per row
+            const int fpe = a.shading == T2N_SHADE_MLP ? 0 : a.fea_pe;
+            const int pe0 = D + (a.shading != T2N_SHADE_MLP_FEA_NOVIEW ? 3 : 0), pe1 = pe0 + 2 * fpe * D;
+            const int hbc = fa.hbc;
             float* __restrict__ xr = fa.x0 + (size_t)(tile * 64u - fa.row0 + (unsigned)(tid >> 2)) * fa.ldx + (tid & 3) * 4;
-            for (int j0 = 0; j0 < fa.ldx; j0 += 16) {
-                __syncthreads();                                        // the previous chunk has been read
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { const int j = j0 + 4 * g + q; Xc[(4 * g + q) * 64 + s] = j < nin ? gen_input_col(a, feat + s, dir, j) : 0.f; }
+            const int rr = tid >> 2, cc = (tid & 3) * 4;
+            for (int c0 = 0; c0 < fa.ldx; c0 += hbc) {
+                const int c1 = min(fa.ldx, c0 + hbc);
+                __syncthreads();                                        // the previous round has been written out
+                for (int j = c0 + g; j < c1; j += 4)
+                    if (j < pe0 || j >= pe1) Hb[(j - c0) * 64 + s] = j < nin ? gen_input_col(a, feat + s, dir, j) : 0.f;
+                for (int f = g; f < D; f += 4) {
+                    const int js = pe0 + f * fpe, jc = js + fpe * D;
+                    if ((js >= c1 || js + fpe <= c0) && (jc >= c1 || jc + fpe <= c0)) continue;
+                    float sv, cv;
+                    sincosf(feat[f * 64 + s], &sv, &cv);
+                    for (int o = 0; o < fpe; ++o) {
+                        if (js + o >= c0 && js + o < c1) Hb[(js + o - c0) * 64 + s] = sv;
+                        if (jc + o >= c0 && jc + o < c1) Hb[(jc + o - c0) * 64 + s] = cv;
+                        const float s2 = 2.f * sv * cv, c2 = cv * cv - sv * sv;
+                        sv = s2; cv = c2;
+                    }
+                }
                 __syncthreads();
-                const int rr = tid >> 2, cc = (tid & 3) * 4;
-                *reinterpret_cast<float4*>(xr + j0) = make_float4(Xc[cc * 64 + rr], Xc[(cc + 1) * 64 + rr], Xc[(cc + 2) * 64 + rr], Xc[(cc + 3) * 64 + rr]);
+                for (int j0 = c0; j0 < c1; j0 += 16) {
+                    const float* __restrict__ h = Hb + (size_t)(j0 - c0 + cc) * 64 + rr;
+                    *reinterpret_cast<float4*>(xr + j0) = make_float4(h[0], h[64], h[128], h[192]);
+                }
             }
             __syncthreads();
             continue;
-        }
+        } else {
         // ---- layer 0: the input row in chunks of 16 columns (each wave makes 4 of them, LDS), all waves multiply -------------------------
         float acc[kGenUnitsPerWave];
         gen_layer(acc, fa.w0p, a.b0, nin, fa.ld0, fC, g, [&](int j0, float (&x)[16]) {
@@ -665,9 +691,14 @@ __global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast
             for (int c = 0; c < 3; ++c) a.rgb_s[t * 3 + c] = 1.f / (1.f + expf(-o[c]));
         }
         __syncthreads();
+        }   // !ROWS
     }
 }
 
+__global__ __launch_bounds__(256) void k_gen_head(const GenArgs a, const GenFast fa) { gen_head_body<false, kGenDimMax>(a, fa); }
+// (three waves per SIMD: <= 168 VGPRs; DMAX = 32 for app_dim <= 32 keeps half the feature accumulators out of the register file)
+template <int DMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_gen_head_rows(const GenArgs a, const GenFast fa) { gen_head_body<true, DMAX>(a, fa); }
 __global__ void k_gen_plan(const unsigned* __restrict__ count, HeadPlanDev* __restrict__ plan) { plan->rows = *count; }
 // layer 2 + sigmoid from h1 [rows_cap][ldh] of one pass: four lanes per row, a quarter of the units each
 __global__ __launch_bounds__(256) void k_gen_out(const GenArgs a, const GenFast fa, const float* __restrict__ h1, int ldh) {
@@ -683,9 +714,19 @@ __global__ __launch_bounds__(256) void k_gen_out(const GenArgs a, const GenFast 
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
     if (in) {
         const float* __restrict__ hr = h1 + (size_t)lrow * ldh;
-        for (int v = v0; v < v1; ++v) {
-            const float hv = hr[v];
-            o0 = fmaf(a.w2[v], hv, o0); o1 = fmaf(a.w2[fC + v], hv, o1); o2 = fmaf(a.w2[2 * fC + v], hv, o2);
+        if ((fC & 15) == 0) {     // a quarter of the row is whole float4s
+            for (int v = v0; v < v1; v += 4) {
+                const float4 hv = *reinterpret_cast<const float4*>(hr + v);
+                const float4 w0 = *reinterpret_cast<const float4*>(a.w2 + v), w1 = *reinterpret_cast<const float4*>(a.w2 + fC + v), w2 = *reinterpret_cast<const float4*>(a.w2 + 2 * fC + v);
+                o0 = fmaf(w0.x, hv.x, o0); o0 = fmaf(w0.y, hv.y, o0); o0 = fmaf(w0.z, hv.z, o0); o0 = fmaf(w0.w, hv.w, o0);
+                o1 = fmaf(w1.x, hv.x, o1); o1 = fmaf(w1.y, hv.y, o1); o1 = fmaf(w1.z, hv.z, o1); o1 = fmaf(w1.w, hv.w, o1);
+                o2 = fmaf(w2.x, hv.x, o2); o2 = fmaf(w2.y, hv.y, o2); o2 = fmaf(w2.z, hv.z, o2); o2 = fmaf(w2.w, hv.w, o2);
+            }
+        } else {
+            for (int v = v0; v < v1; ++v) {
+                const float hv = hr[v];
+                o0 = fmaf(a.w2[v], hv, o0); o1 = fmaf(a.w2[fC + v], hv, o1); o2 = fmaf(a.w2[2 * fC + v], hv, o2);
+            }
         }
     }
     o0 += dpp_quad_xor1(o0); o0 += dpp_quad_xor2(o0);
@@ -782,9 +823,11 @@ static GenStageCarve gen_stage_carve(const t2n_generic_desc* d, int64_t R, int N
     c.total = o;
     return c;
 }
-static size_t gen_head_lds(const t2n_generic_desc* d) {
+// rows_only: the kernel writes the input rows and leaves the layers to k_dense — Hb then holds the feature partials and the staging
+// rounds only (4 D columns rounded up to 16), which lets two workgroups share a CU's LDS (one wave per SIMD hid none of the gather's latency)
+static size_t gen_head_lds(const t2n_generic_desc* d, bool rows_only = false) {
     const size_t ncol = (size_t)d->app_n_comp[0] + d->app_n_comp[1] + d->app_n_comp[2], D = (size_t)d->app_dim;
-    const size_t hb = 4 * D > (size_t)d->feature_c ? 4 * D : (size_t)d->feature_c;
+    const size_t hb = rows_only ? (4 * D + 15) / 16 * 16 : (4 * D > (size_t)d->feature_c ? 4 * D : (size_t)d->feature_c);
     return (ncol * D + D * 64 + 16 * 64 + hb * 64) * sizeof(float);
 }
 
@@ -867,20 +910,25 @@ extern "C" int t2n_generic_forward(const t2n_generic_desc* desc, const t2n_field
         hipLaunchKernelGGL(k_gen_scan, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, s, a);
         hipLaunchKernelGGL(k_gen_compact, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a, fa);
         static bool attr_set = false;
-        if (!attr_set) { T2N_HIP(hipFuncSetAttribute((const void*)k_gen_head, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+        if (!attr_set) { T2N_HIP(hipFuncSetAttribute((const void*)k_gen_head, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                         T2N_HIP(hipFuncSetAttribute((const void*)k_gen_head_rows<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                         T2N_HIP(hipFuncSetAttribute((const void*)k_gen_head_rows<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
         const unsigned long long wt = ((unsigned long long)tot + 63) / 64;
-        fa.x0 = nullptr; fa.ldx = 0; fa.row0 = 0; fa.rows_cap = 0; fa.plan = nullptr;
+        fa.x0 = nullptr; fa.ldx = 0; fa.row0 = 0; fa.rows_cap = 0; fa.plan = nullptr; fa.hbc = 0;
         static const bool valu_head = getenv("T2N_GENERIC_VALU_HEAD") && atoi(getenv("T2N_GENERIC_VALU_HEAD")) != 0;
         if (sc.x0 && fa.w0p && !valu_head) {
             // MLP layers 0 / 1 on the matrix cores: passes of rows_cap list entries, issued for the worst case (every sample an appearance
             // sample) and clipped to the count on the device — a pass beyond the count costs its empty launches
             fa.x0 = (float*)(ws + sc.x0); fa.ldx = sc.ldx; fa.rows_cap = sc.rows_cap; fa.plan = (HeadPlanDev*)(ws + sc.plan);
+            fa.hbc = (4 * a.app_dim + 15) / 16 * 16;
+            const size_t lds_rows = gen_head_lds(desc, true);
             float* h0 = (float*)(ws + sc.h0); float* h1 = (float*)(ws + sc.h1);
             hipLaunchKernelGGL(k_gen_plan, dim3(1), dim3(1), 0, s, (const unsigned*)fa.count, fa.plan);
             const unsigned long long pt = ((unsigned long long)sc.rows_cap + 63) / 64;
             for (long long row0 = 0; row0 < tot; row0 += sc.rows_cap) {
                 fa.row0 = (unsigned)row0;
-                hipLaunchKernelGGL(k_gen_head, dim3((unsigned)(pt < 1024 ? pt : 1024)), dim3(256), lds, s, a, fa);
+                if (a.app_dim <= 32) hipLaunchKernelGGL((k_gen_head_rows<32>), dim3((unsigned)(pt < 2048 ? pt : 2048)), dim3(256), lds_rows, s, a, fa);
+                else hipLaunchKernelGGL((k_gen_head_rows<64>), dim3((unsigned)(pt < 2048 ? pt : 2048)), dim3(256), lds_rows, s, a, fa);
                 if ((rc = launch_dense_rows(fa.x0, sc.ldx, a.w0, a.in0, a.fC, a.b0, 1, sc.rows_cap, h0, sc.ldh, s, fa.plan, row0))) return rc;
                 if ((rc = launch_dense_rows(h0, sc.ldh, a.w1, a.fC, a.fC, a.b1, 1, sc.rows_cap, h1, sc.ldh, s, fa.plan, row0))) return rc;
                 hipLaunchKernelGGL(k_gen_out, dim3((unsigned)min(((unsigned long long)sc.rows_cap * 4 + 255) / 256, 2048ull)), dim3(256), 0, s, a, fa, (const float*)h1, sc.ldh);

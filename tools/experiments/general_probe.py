@@ -30,7 +30,7 @@ def run(tag, dn, an, fc):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
     st = m.stats()     # (last chunk only)
-    print(f"{tag}: general={m._is_general()} N={m.nSamples} frame {ms:.2f} ms, {ms * 1e6 / (rays.shape[0] * m.nSamples):.2f} ns per nominal sample", flush=True)
+    print(f"{tag}: general={m._is_general()} N={m.nSamples} frame {ms:.2f} ms, {ms * 1e6 / (rays.shape[0] * m.nSamples):.2f} ns per nominal sample, stats {st}", flush=True)
     return ms
 a = run("tuned 16/48/128", [16] * 3, [48] * 3, 128)
 b = run("wide [32,20,24]/[96,64,72]/256", [32, 20, 24], [96, 64, 72], 256)
