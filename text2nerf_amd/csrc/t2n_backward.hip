@@ -263,7 +263,9 @@ struct BwdMarchArgs {
 };
 
 // BIN = false: scatter with sliding windows + global atomics (any grid). BIN = true: first pass of the tile-binned scatter.
-template <bool TRAIN, bool BIN, bool LOSS = false>
+// COUNT = false (fused step): the block histogram is counted BEFORE the backward, from the forward's windows (k_den_count on the GEMM
+// stream beside the shade kernel), for every in-box sample whatever its gradient: this kernel then only leaves dL/dfeature
+template <bool TRAIN, bool BIN, bool LOSS = false, bool COUNT = true>
 __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -416,12 +418,15 @@ __global__ __launch_bounds__(256) void k_bwd_march(const BwdMarchArgs a) {
                 const float z = sample_z<TRAIN>(F, ray, i, u);
                 bool ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
                 if (F.alpha && ok) ok = alpha_pass(F, ray, z);
-                if (ok && gf != 0.f) key = block_key(a.geom, xn, yn, zn); else gf = 0.f;
+                if constexpr (COUNT) { if (ok && gf != 0.f) key = block_key(a.geom, xn, yn, zn); else gf = 0.f; }
+                else if (!ok) gf = 0.f;
                 a.gfeat[r * N + i] = gf;
             }
-            bool leader; int runlen, ll;
-            run_leader(key, lane, leader, runlen, ll);
-            if (leader && key >= 0) atomicAdd(&a.hist[copy * (unsigned)a.geom.total + (unsigned)key], (unsigned)runlen);
+            if constexpr (COUNT) {
+                bool leader; int runlen, ll;
+                run_leader(key, lane, leader, runlen, ll);
+                if (leader && key >= 0) atomicAdd(&a.hist[copy * (unsigned)a.geom.total + (unsigned)key], (unsigned)runlen);
+            }
         }
         return;
     }
@@ -605,7 +610,36 @@ struct BinArgs {
     const float* rays; long long n_rays; int ray_stride; int n_samples;
     const float* jitter; const float* gfeat; const int4* ray_app; unsigned* cursor; const unsigned* tile_start; float4* recs;
 };
+// the counting pass on its own (fused step): every in-box sample of the forward's window, same ray -> wave -> copy map as k_bwd_bin<.., true>
 template <bool TRAIN>
+__device__ __forceinline__ void den_count_body(const BinArgs& a, unsigned bx) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const FieldDev& F = a.F;
+    const long long r = (long long)bx * 4 + wid;
+    if (r >= a.n_rays) return;
+    const int4 ra = a.ray_app[r];
+    const int first = ra.w & 2047, Lw = ra.w >> 11;
+    if (Lw <= 0) return;
+    const Ray ray = load_ray(F, a.rays + r * a.ray_stride, a.ray_stride);
+    const float u = (TRAIN && !F.ztab) ? a.jitter[r] : 0.f;
+    const unsigned copy = (unsigned)(r >> 2) & (unsigned)(a.geom.copies - 1);
+    for (int base = 0; base < Lw; base += 64) {
+        const int j = base + lane, i = first + j;
+        int key = -1;
+        if (j < Lw) {
+            float xn, yn, zn;
+            const float z = sample_z<TRAIN>(F, ray, i, u);
+            bool ok = sample_point<TRAIN>(F, ray, z, xn, yn, zn);
+            if (F.alpha && ok) ok = alpha_pass(F, ray, z);
+            if (ok) key = block_key(a.geom, xn, yn, zn);
+        }
+        bool leader; int runlen, ll;
+        run_leader(key, lane, leader, runlen, ll);
+        if (leader && key >= 0) atomicAdd(&a.cursor[copy * (unsigned)a.geom.total + (unsigned)key], (unsigned)runlen);
+    }
+}
+// ALL: a record for every in-box sample (k_den_count's predicate; a zero gradient adds zeros) instead of every non-zero gradient
+template <bool TRAIN, bool ALL = false>
 __global__ __launch_bounds__(256) void k_bwd_bin(const BinArgs a) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const FieldDev& F = a.F;
@@ -624,7 +658,12 @@ __global__ __launch_bounds__(256) void k_bwd_bin(const BinArgs a) {
         float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j < Lw) {
             rec.w = a.gfeat[r * N + i];
-            if (rec.w != 0.f) {
+            if constexpr (ALL) {
+                const float z = sample_z<TRAIN>(F, ray, i, u);
+                bool ok = sample_point<TRAIN>(F, ray, z, rec.x, rec.y, rec.z);
+                if (F.alpha && ok) ok = alpha_pass(F, ray, z);
+                if (ok) key = block_key(a.geom, rec.x, rec.y, rec.z);
+            } else if (rec.w != 0.f) {
                 const float z = sample_z<TRAIN>(F, ray, i, u);
                 (void)sample_point<TRAIN>(F, ray, z, rec.x, rec.y, rec.z);
                 key = block_key(a.geom, rec.x, rec.y, rec.z);
@@ -887,9 +926,9 @@ struct AppBinArgs {
     const BwdPlan* plan;   // when set: tile prefix and row count from device memory (rows = the capacity the grid was sized for)
 };
 template <int PASS>
-__global__ __launch_bounds__(256) void k_app_bin(const AppBinArgs a) {
+__device__ __forceinline__ void app_bin_body(const AppBinArgs& a, unsigned bx) {
     const int lane = threadIdx.x & 63;
-    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long wv = (long long)bx * 4 + (threadIdx.x >> 6);
     const long long row = wv * 64 + lane;
     const long long rows = a.plan ? (long long)a.plan->rows : a.rows;
     if (wv * 64 >= rows) return;
@@ -924,6 +963,14 @@ __global__ __launch_bounds__(256) void k_app_bin(const AppBinArgs a) {
             if (key[k] >= 0) a.recs[pos] = rec;
         }
     }
+}
+template <int PASS>
+__global__ __launch_bounds__(256) void k_app_bin(const AppBinArgs a) { app_bin_body<PASS>(a, blockIdx.x); }
+// fused step: both counting passes that need nothing but the forward's outputs as ONE launch — the appearance records' tile histogram
+// (workgroups [0, nb_app)) and the density samples' block histogram (the rest)
+__global__ __launch_bounds__(256) void k_early_bins(const AppBinArgs ab, const BinArgs ca, unsigned nb_app) {
+    if (blockIdx.x < nb_app) app_bin_body<0>(ab, blockIdx.x);
+    else den_count_body<true>(ca, blockIdx.x - nb_app);
 }
 // doubles: tile + line accumulators; floats: staged values; per-wave tap tables (64 records x 3 float4)
 static size_t tile_accum_lds(int C, int Lmax, int threads = kAccThreads) {
@@ -1902,8 +1949,16 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
     float* vote = A->head_grads + (T2N_TRAIN_HEAD_GRAD_FLOATS - 1);
     const bool do_grad = (A->phases & 1u) != 0, do_opt = (A->phases & 2u) != 0;
     // pipelined form: the early part of this step on `se`, beside the previous step's tail (see include/t2n.h)
+    // density bins counted from the forward's windows, beside the shade kernel, instead of behind the backward march (as t2n_render_backward
+    // does): takes ~110 us of small kernels off the chain backward march -> density scatter -> density Adam -> next march, at the price of
+    // records for zero-gradient samples and a second evaluation of the sample positions. Small batches are bound by that chain (2 048 rays:
+    // 0.404 -> 0.392 ms), large ones by the machine's throughput (16 384 rays: 0.851 -> 0.857): taken up to 4 096 rays
+    // (T2N_DEN_EARLY=0 / 1 forces it; profiles/round6_train_ab.txt)
+    static const int den_env = getenv("T2N_DEN_EARLY") ? atoi(getenv("T2N_DEN_EARLY")) : -1;
+    bool den_early = den_env >= 0 ? den_env != 0 : A->n_rays <= 4096;
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap_status);
+    if (cap_status != hipStreamCaptureStatusNone) den_early = false;   // (the captured step keeps the one DAG its replay was tested with: the early form's extra fork crashed hipStreamEndCapture on ROCm 7.2)
     const bool pipe = (A->flags & T2N_FLAG_PIPELINE) && A->host_batch && do_grad && do_opt && A->workspace_bytes >= 2 * T.total && cap_status == hipStreamCaptureStatusNone;
     const bool chain_prev = f->train_chain;               // the previous call was a full step of this form and left its density-Adam event
     f->train_chain = false;
@@ -1996,7 +2051,21 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
             ab.S = f->dev.app; ab.geom = ageom; ab.app_pos = L.app_pos; ab.counters = L.counters; ab.list_cap = c.list_cap;
             ab.plan = plan; memset(&ab.tp, 0, sizeof(ab.tp)); ab.rows = rows; ab.hist = (unsigned*)(bw + b.a_hist); ab.tile_start = (const unsigned*)(bw + b.a_tile_start); ab.recs = (float4*)(bw + b.a_recs);
             const unsigned nbk = (unsigned)((rows + 255) / 256);
-            hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, sb, ab);
+            if (den_early) {
+                // + the density scatter's block histogram from the forward's windows (positions only, no gradient needed); its reduce + scan
+                // run on sg while the shade kernel runs: behind the backward march only the record pass and the accumulate pass are left
+                // on the density chain (k_bin_reduce + k_bin_scan took ~110 us there under the concurrency of the input-gradient chain)
+                BinArgs ca;
+                ca.F = f->dev; ca.F.ztab = nullptr; ca.geom = bgeom; ca.rays = A->rays; ca.n_rays = R; ca.ray_stride = A->ray_stride; ca.n_samples = N;
+                ca.jitter = A->jitter; ca.gfeat = nullptr; ca.ray_app = (const int4*)(fw + c.ray_app); ca.cursor = (unsigned*)(bw + b.hist); ca.tile_start = nullptr; ca.recs = nullptr;
+                hipLaunchKernelGGL(k_early_bins, dim3(nbk + (unsigned)((R + 3) / 4)), dim3(256), 0, sb, ab, ca, nbk);
+                T2N_HIP(hipEventRecord(ev[10], sb));
+                T2N_HIP(hipStreamWaitEvent(sg, ev[10], 0));
+                launch_bin_scan((unsigned*)(bw + b.hist), bgeom.total, bgeom.copies, (unsigned*)(bw + b.bin_total), (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, kDenSeg,
+                                0u, kDenSeg, sg);
+                T2N_HIP(hipEventRecord(ev[11], sg));
+            } else
+                hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, sb, ab);
             launch_bin_scan(ab.hist, ab.geom.total, kBinCopies, (unsigned*)(bw + b.a_bin_total), (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),
                             b.a_seg_cap, 0u, kAccTargetSegsApp, 512u, sb, true);
             hipLaunchKernelGGL((k_app_bin<1>), dim3(nbk), dim3(256), 0, sb, ab);
@@ -2033,7 +2102,8 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
             const size_t lds = (size_t)4 * 4 * a.npad * sizeof(float);
             const unsigned nb = (unsigned)((R + 3) / 4);
             timing_begin(f, T2N_K_BWD_MARCH, s);
-            hipLaunchKernelGGL((k_bwd_march<true, true, true>), dim3(nb), dim3(256), lds, s, a);
+            if (den_early) hipLaunchKernelGGL((k_bwd_march<true, true, true, false>), dim3(nb), dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((k_bwd_march<true, true, true>), dim3(nb), dim3(256), lds, s, a);
             timing_end(f, T2N_K_BWD_MARCH, s);
             T2N_HIP(hipEventRecord(ev[5], s));
         }
@@ -2050,12 +2120,14 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
             // ---- sa: density scatter (behind the TV seed on the same stream)
             T2N_HIP(hipStreamWaitEvent(sa, ev[5], 0));
             timing_begin(f, T2N_K_BWD_DENSITY, sa);
-            launch_bin_scan((unsigned*)(bw + b.hist), bgeom.total, bgeom.copies, (unsigned*)(bw + b.bin_total), (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, kDenSeg,
-                            0u, kDenSeg, sa);
+            if (den_early) T2N_HIP(hipStreamWaitEvent(sa, ev[11], 0));     // counted, reduced and scanned on sg beside the shade kernel
+            else launch_bin_scan((unsigned*)(bw + b.hist), bgeom.total, bgeom.copies, (unsigned*)(bw + b.bin_total), (unsigned*)(bw + b.tile_start), (int4*)(bw + b.segs), (unsigned*)(bw + b.nseg), b.seg_cap, kDenSeg,
+                                 0u, kDenSeg, sa);
             BinArgs ba;
             ba.F = f->dev; ba.F.ztab = nullptr; ba.geom = bgeom; ba.rays = A->rays; ba.n_rays = R; ba.ray_stride = A->ray_stride; ba.n_samples = N;
             ba.jitter = A->jitter; ba.gfeat = (float*)(fw + c.sigma); ba.ray_app = (const int4*)(fw + c.ray_app); ba.cursor = (unsigned*)(bw + b.hist); ba.tile_start = (const unsigned*)(bw + b.tile_start); ba.recs = (float4*)(bw + b.recs);
-            hipLaunchKernelGGL((k_bwd_bin<true>), dim3(nb), dim3(256), 0, sa, ba);
+            if (den_early) hipLaunchKernelGGL((k_bwd_bin<true, true>), dim3(nb), dim3(256), 0, sa, ba);
+            else hipLaunchKernelGGL((k_bwd_bin<true>), dim3(nb), dim3(256), 0, sa, ba);
             DenBlockArgs da;
             da.S = f->dev.den; for (int k = 0; k < 3; ++k) { da.G.plane[k] = f->gbuf_den_plane[k]; da.G.line[k] = f->gbuf_den_line[k]; } da.geom = bgeom; da.segs = (const int4*)(bw + b.segs);
             da.nseg = (const unsigned*)(bw + b.nseg); da.recs = (const float4*)(bw + b.recs);
