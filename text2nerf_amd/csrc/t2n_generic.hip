@@ -351,8 +351,8 @@ __global__ __launch_bounds__(64) void k_gen_bwd_march(const GenArgs a) {
 //   k_gen_stage      the twelve factor tensors -> channel-last copies in the workspace ([pos][C]: a tap's components are contiguous)
 //   k_gen_sigma      one thread per (ray, sample): depth, box test, density feature (components in the reference's order: the same
 //                    sums as the plain form), sigma
-//   k_gen_scan       one thread per ray: transmittance / weights / opacity / depth from the sigmas
-//   k_gen_compact    the appearance samples (weight > threshold) -> an index list (wave-aggregated append)
+//   k_gen_scan_compact  one wave per ray: transmittance (wave product scan) / weights / opacity / depth from the sigmas, and the appearance
+//                    samples (weight > threshold) -> an index list (one reservation per workgroup of four rays)
 //   k_gen_head       one workgroup per 64 list entries: appearance features (each wave a quarter of the components, basis_mat from LDS),
 //                    then the head — MLP layers as [units of this wave] x [64 samples] outer products on the VALU with the weights as
 //                    wave-uniform (scalar) operands and the activations in LDS; SH / RGB per sample.
@@ -458,6 +458,70 @@ __global__ __launch_bounds__(64) void k_gen_scan(const GenArgs a) {
     a.acc[r] = acc;
     a.depth[r] = dep + (1.f - acc) * ray.last;
     if (a.stats) { atomicAdd(&a.stats[T2N_STAT_EVALUATED], nev); atomicAdd(&a.stats[T2N_STAT_APPEARANCE], napp); }
+}
+// scan + compaction as ONE kernel, a wave per ray: coalesced loads of the ray's sigmas / depths, transmittance by a wave product scan
+// (64 samples per round, carried across rounds), weights, opacity, depth; the ray's appearance samples are appended to the list with one
+// atomic per WORKGROUP (four rays). Replaces k_gen_scan (a thread per ray: lanes a whole ray apart in memory, 2.4 ms per frame of the
+// probe) + k_gen_compact (one atomic per wave of samples on ONE word: 550 K of them, 2.9 ms). The products / sums are formed in scan order
+// instead of sample by sample: equal to rounding (1e-7), like the tuned marcher's.
+__global__ __launch_bounds__(256) void k_gen_scan_compact(const GenArgs a, const GenFast fa) {
+    __shared__ unsigned s_cnt[4];
+    __shared__ unsigned s_base;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const long long r = (long long)blockIdx.x * 4 + wid;
+    const bool live = r < a.n_rays;
+    const int N = a.N;
+    float carry = 1.f, acc = 0.f, dep = 0.f;
+    unsigned nev = 0, napp = 0;
+    if (live) {
+        for (int base = 0; base < N; base += 64) {
+            const int i = base + lane;
+            const bool in = i < N;
+            const long long t = r * N + (in ? i : N - 1);
+            const float z = a.z[t];
+            const float zn = (in && i < N - 1) ? a.z[t + 1] : z;
+            const float sg = in ? a.sigma[t] : 0.f;
+            const bool box = in && a.T[t] != 0.f;
+            const float dist = (in && i < N - 1) ? zn - z : 0.f;
+            const float alpha = 1.f - expf((-sg) * (dist * a.F.dscale));
+            const float f = in ? (1.f - alpha) + 1e-10f : 1.f;
+            const float incl = wave_scan_mul(f, lane);
+            float excl = __shfl_up(incl, 1);
+            if (lane == 0) excl = 1.f;
+            const float T = carry * excl;
+            const float w = in ? alpha * T : 0.f;
+            if (in) { a.T[t] = T; a.w[t] = w; }
+            carry = carry * __shfl(incl, 63);
+            acc += wave_sum(w);
+            dep += wave_sum(w * z);
+            nev += (unsigned)__popcll(__ballot(box));
+            napp += (unsigned)__popcll(__ballot(in && w > a.F.thres));
+        }
+        if (lane == 0) {
+            const Ray ray = load_ray(a.F, a.rays + r * a.ray_stride, a.ray_stride);
+            a.acc[r] = acc;
+            a.depth[r] = dep + (1.f - acc) * ray.last;
+        }
+    }
+    if (lane == 0) s_cnt[wid] = live ? napp : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = tot ? atomicAdd(fa.count, tot) : 0u;
+        if (a.stats && tot) atomicAdd(&a.stats[T2N_STAT_APPEARANCE], (unsigned long long)tot);
+    }
+    if (a.stats && lane == 0 && nev) atomicAdd(&a.stats[T2N_STAT_EVALUATED], (unsigned long long)nev);
+    __syncthreads();
+    if (!live || !napp) return;
+    unsigned pos = s_base;
+    for (int q = 0; q < wid; ++q) pos += s_cnt[q];
+    for (int base = 0; base < N; base += 64) {
+        const int i = base + lane;
+        const bool app = i < N && a.w[r * N + i] > a.F.thres;       // (written above by this lane)
+        const unsigned long long bal = __ballot(app);
+        if (app) fa.list[pos + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = (int)(r * N + i);
+        pos += (unsigned)__popcll(bal);
+    }
 }
 __global__ __launch_bounds__(256) void k_gen_compact(const GenArgs a, const GenFast fa) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -907,8 +971,12 @@ extern "C" int t2n_generic_forward(const t2n_generic_desc* desc, const t2n_field
             hipLaunchKernelGGL(k_gen_padrows, dim3((unsigned)(((long long)a.fC * fa.ld1 + 255) / 256)), dim3(256), 0, s, a.w1, (float*)(ws + sc.w1p), a.fC, a.fC, fa.ld1);
         }
         hipLaunchKernelGGL(k_gen_sigma, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a, fa);
-        hipLaunchKernelGGL(k_gen_scan, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, s, a);
-        hipLaunchKernelGGL(k_gen_compact, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a, fa);
+        static const bool split_scan = getenv("T2N_GENERIC_SPLIT_SCAN") && atoi(getenv("T2N_GENERIC_SPLIT_SCAN")) != 0;   // (A/B: round 6's first form)
+        if (split_scan) {
+            hipLaunchKernelGGL(k_gen_scan, dim3((unsigned)((n_rays + 63) / 64)), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(k_gen_compact, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a, fa);
+        } else
+            hipLaunchKernelGGL(k_gen_scan_compact, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, s, a, fa);
         static bool attr_set = false;
         if (!attr_set) { T2N_HIP(hipFuncSetAttribute((const void*)k_gen_head, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                          T2N_HIP(hipFuncSetAttribute((const void*)k_gen_head_rows<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
