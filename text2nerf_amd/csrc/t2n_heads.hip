@@ -237,8 +237,7 @@ __global__ __launch_bounds__(256) void k_dense(const float* __restrict__ IN, int
         const bool rok = r < rows;
         const float* __restrict__ inr = IN + (rok ? r : 0) * ldin;
         f32x16 acc[2] = {{0}, {0}};
-        for (int k0 = 0; k0 < K4; k0 += 4) {
-            const float4 cur = *reinterpret_cast<const float4*>(inr + k0);
+        auto mac4 = [&](const float4 cur, int k0) {
             const float b0 = h ? cur.y : cur.x, b1 = h ? cur.w : cur.z;
             const float* w0 = sW + (k0 + h) * 65 + s;
             const float* w1 = w0 + 2 * 65;
@@ -246,7 +245,22 @@ __global__ __launch_bounds__(256) void k_dense(const float* __restrict__ IN, int
             for (int m = 0; m < 2; ++m) acc[m] = mfma_h(w0[m * 32], b0, acc[m]);
 #pragma unroll
             for (int m = 0; m < 2; ++m) acc[m] = mfma_h(w1[m * 32], b1, acc[m]);
+        };
+        // the input row in blocks of 16 columns, the NEXT block's four loads in flight under this block's 16 MFMAs (1 024 matrix-pipe cycles):
+        // with one load per four MFMAs issued where it is needed, the wave — alone on its SIMD: the W slab takes the CU's LDS — stood
+        // waiting for memory two thirds of the time (0.32 of the fp32 MFMA rate on the general path's 351 -> 256 -> 256 layers)
+        const int K16 = K4 & ~15;
+        float4 n0, n1, n2, n3;
+        if (K16 > 0) { n0 = *reinterpret_cast<const float4*>(inr); n1 = *reinterpret_cast<const float4*>(inr + 4); n2 = *reinterpret_cast<const float4*>(inr + 8); n3 = *reinterpret_cast<const float4*>(inr + 12); }
+        for (int k0 = 0; k0 < K16; k0 += 16) {
+            const float4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+            if (k0 + 16 < K16) {
+                n0 = *reinterpret_cast<const float4*>(inr + k0 + 16); n1 = *reinterpret_cast<const float4*>(inr + k0 + 20);
+                n2 = *reinterpret_cast<const float4*>(inr + k0 + 24); n3 = *reinterpret_cast<const float4*>(inr + k0 + 28);
+            }
+            mac4(c0, k0); mac4(c1, k0 + 4); mac4(c2, k0 + 8); mac4(c3, k0 + 12);
         }
+        for (int k0 = K16; k0 < K4; k0 += 4) mac4(*reinterpret_cast<const float4*>(inr + k0), k0);
         if (!rok) continue;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
