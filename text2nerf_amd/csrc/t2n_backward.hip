@@ -1093,7 +1093,8 @@ static BwdCarve bwd_carve(int64_t rows, int64_t n_rays, int n_samples, int n_til
     c.h0 = o; o = al256(o + RA * 128 * 4);
     c.h1 = o; o = al256(o + RA * 128 * 4);
     c.go = o; o = al256(o + R * 16);
-    c.xpe = o; o = al256(o + R * (size_t)((k0 + 3) & ~3) * 4);
+    // (fused step: the encoding is never materialised — the rows hold G0 [128] | GF [32] | GX [144] only)
+    c.xpe = o; o = al256(o + R * (size_t)(rows_kept ? 304 : ((k0 + 3) & ~3)) * 4);
     c.part = o; o = al256(o + tn_part_bytes(rows, k0));
     c.gpack = o; o = al256(o + (gemm_h_pack_bytes(k0) > mlp_bwd_ss_pack_bytes() ? gemm_h_pack_bytes(k0) : mlp_bwd_ss_pack_bytes()));   // packed W^T operands of the input-gradient GEMMs (t2n_gemm_h.hip / t2n_mlp_bwd_ss.hip)
     // block-binned density scatter: worst case one record per sample

@@ -203,7 +203,8 @@ class FusedStep:
             self.ws = self.field.__dict__.get("_fused_ws")     # (the field keeps ONE such buffer: a new optimiser / driver takes it over)
             if self.ws is not None and self.ws.device != self.dev:
                 self.ws = None
-        if self.ws is None or self.ws.numel() < need:
+        # grow when it does not fit; shrink when a third would do (after the fog phase of a run the rows fall back by a factor of ~6)
+        if self.ws is None or self.ws.numel() < need or self.ws.numel() > 3 * need + (64 << 20):
             had = self.ws is not None
             self.ws = self.field.__dict__["_fused_ws"] = None
             self._drop_graphs()
