@@ -810,9 +810,23 @@ struct TileAccumArgs {
 // CT = channels of the factor set (texel stride); a workgroup covers the 16 channels [coff, coff + 16).
 // CG = channels per workgroup (16: one workgroup per CU with 138 KB of LDS at 300^3; 8 with NT = 256 threads: 69 KB — two workgroups per CU,
 // one accumulates while the other stages / zeroes / flushes)
+// -DTA_PROF (timing-only build, tools/r6_ta_prof.sh): cycle sums per region of k_bwd_tile_accum, lane 0 of every wave, summed over the launch.
+// [0] stage + zero, [1] barrier, [2] record tables, [3] gradient loads (forced wait), [4] accumulate loop, [5] barrier, [6] flush,
+// [7] segments x waves, [8] batches, [9] records
+#ifdef TA_PROF
+__device__ unsigned long long g_ta_prof[16];
+#define TA_T(i) do { const unsigned long long tn = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) ta_acc[i] += tn - ta_t; ta_t = tn; } while (0)
+#define TA_DECL unsigned long long ta_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ta_t = __builtin_readcyclecounter()
+#else
+#define TA_T(i) do {} while (0)
+#endif
 template <int CT, int K, int CG, int NT>
 __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const int4 sg, int x0, int y0, int coff, const float* Pv,
-                                                   double* Pa, const float* Lv, double* La, float4* tab) {
+                                                   double* Pa, const float* Lv, double* La, float4* tab
+#ifdef TA_PROF
+                                                   , unsigned long long (&ta_acc)[10], unsigned long long& ta_t
+#endif
+                                                   ) {
     constexpr int C = CG;   // 64 / CG records per instruction, CG instructions per batch of 64 records
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, ch = lane & (CG - 1), sub = lane / CG;
     constexpr int NW = NT / 64;
@@ -833,8 +847,10 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
         T[lane * 3 + 2] = make_float4(al.w0, al.w1, 0.f, 0.f);
         if (b0 + 64 + lane < re) p = a.recs[b0 + 64 + lane];   // next batch in flight while this one is accumulated
         wave_lds_sync();
-        // appearance: the 16 per-channel gradients this lane needs for the batch, all in flight before the accumulate loop
-        // (a dependent global load per record inside the loop serialised ~1 us round trips)
+        TA_T(2);
+        // appearance: the CG per-channel gradients this lane needs for the batch, all in flight before the accumulate loop
+        // (a dependent global load per record inside the loop serialised ~1 us round trips). Loading them one batch AHEAD (rows by
+        // bpermute from the next batch's record registers, records two batches ahead) measured slower: 0.830 -> 0.897 ms per 16 384-ray step
         float gpre[CG];
         if (a.gx) {
 #pragma unroll
@@ -843,6 +859,11 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
                 gpre[q] = t0.w != 0.f ? a.gx[(size_t)__float_as_int(t0.z) * a.gx_ld + K * CT + coff + ch] : 0.f;
             }
         }
+#ifdef TA_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TA_T(3);
+        if (lane == 0) { ta_acc[8] += 1; ta_acc[9] += (unsigned long long)min(64, re - b0); }
+#endif
 #pragma unroll
         for (int q = 0; q < CG; ++q) {
             // the RPI records an instruction handles are CG apart in the batch: neighbours in the list are neighbouring
@@ -863,6 +884,10 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
             }
         }
         wave_lds_sync();
+#ifdef TA_PROF
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        TA_T(4);
     }
 }
 // grid: (segments, CT / 16)
@@ -871,8 +896,15 @@ __global__ __launch_bounds__(NT) void k_bwd_tile_accum(const TileAccumArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned nseg = *a.nseg;
     const int coff = blockIdx.y * CG;
+#ifdef TA_PROF
+    TA_DECL;
+#endif
     for (unsigned seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     if (seg != blockIdx.x) __syncthreads();   // the previous segment's flush has finished reading the accumulators
+#ifdef TA_PROF
+    ta_t = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) ta_acc[7] += 1;
+#endif
     const int4 sg = a.segs[seg];
     const int k = sg.x >= a.geom.before[2] ? 2 : (sg.x >= a.geom.before[1] ? 1 : 0);
     const int tile = sg.x - a.geom.before[k];
@@ -888,22 +920,56 @@ __global__ __launch_bounds__(NT) void k_bwd_tile_accum(const TileAccumArgs a) {
     float* Pv = reinterpret_cast<float*>(La + (size_t)(L + 2) * C);
     float* Lv = Pv + TP;
     float4* tab = reinterpret_cast<float4*>(Lv + (size_t)(L + 2) * C);
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int idx = threadIdx.x; idx < TP / 4; idx += NT) {
+    // staging: EVERY load of the segment's plane tile and line issued before the first LDS store (a thread has up to 3 + 4 of them), the
+    // accumulators zeroed underneath. (The form `cond ? *ptr : zero4` made the compiler select between the global pointer and the ADDRESS
+    // of the zero constant — in scratch memory — and load through it: a flat load + a full wait per element, and the zero-fill loop read
+    // its zeros from scratch with a wait per store: staging was 43 % (16 384 rays) to 56 % (2 048 rays) of this kernel's time, TA_PROF
+    // accounting in profiles/round6_tile_accum_accounting.txt.)
+    constexpr int PIT = (TP / 4 + NT - 1) / NT, LIT = 4;
+    float4 pvr[PIT], lvr[LIT];
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+        const int idx = threadIdx.x + it * NT;
         const int cell = idx / C4, q = idx - cell * C4, ly = cell / T1, lx = cell - ly * T1, y = y0 + ly, x = x0 + lx;
-        reinterpret_cast<float4*>(Pv)[idx] = (x >= 0 && x < W && y >= 0 && y < H)
-            ? *reinterpret_cast<const float4*>(P + ((size_t)y * W + x) * CT + coff + q * 4) : zero4;
+        pvr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < TP / 4 && x >= 0 && x < W && y >= 0 && y < H) pvr[it] = *reinterpret_cast<const float4*>(P + ((size_t)y * W + x) * CT + coff + q * 4);
     }
-    for (int idx = threadIdx.x; idx < (L + 2) * C4; idx += NT) {
+    const int nl4 = (L + 2) * C4;
+#pragma unroll
+    for (int it = 0; it < LIT; ++it) {
+        const int idx = threadIdx.x + it * NT;
         const int row = idx / C4 - 1, q = idx % C4;
-        reinterpret_cast<float4*>(Lv)[idx] = (row >= 0 && row < L) ? *reinterpret_cast<const float4*>(Ln + (size_t)row * CT + coff + q * 4) : zero4;
+        lvr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < nl4 && row >= 0 && row < L) lvr[it] = *reinterpret_cast<const float4*>(Ln + (size_t)row * CT + coff + q * 4);
     }
-    for (int idx = threadIdx.x; idx < (TP + (L + 2) * C) / 2; idx += NT) reinterpret_cast<float4*>(Pa)[idx] = zero4;
+    for (int idx = threadIdx.x; idx < (TP + (L + 2) * C) / 2; idx += NT) reinterpret_cast<float4*>(Pa)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) { const int idx = threadIdx.x + it * NT; if (idx < TP / 4) reinterpret_cast<float4*>(Pv)[idx] = pvr[it]; }
+#pragma unroll
+    for (int it = 0; it < LIT; ++it) { const int idx = threadIdx.x + it * NT; if (idx < nl4) reinterpret_cast<float4*>(Lv)[idx] = lvr[it]; }
+    for (int idx = threadIdx.x + LIT * NT; idx < nl4; idx += NT) {     // (lines beyond LIT x NT quads: grids past ~500)
+        const int row = idx / C4 - 1, q = idx % C4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row >= 0 && row < L) v = *reinterpret_cast<const float4*>(Ln + (size_t)row * CT + coff + q * 4);
+        reinterpret_cast<float4*>(Lv)[idx] = v;
+    }
+#ifdef TA_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    TA_T(0);
+    __syncthreads();
+    TA_T(1);
+    if (k == 0) tile_accum_records<CT, 0, CG, NT>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab, ta_acc, ta_t);
+    else if (k == 1) tile_accum_records<CT, 1, CG, NT>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab, ta_acc, ta_t);
+    else tile_accum_records<CT, 2, CG, NT>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab, ta_acc, ta_t);
+    __syncthreads();
+    TA_T(5);
+#else
     __syncthreads();
     if (k == 0) tile_accum_records<CT, 0, CG, NT>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
     else if (k == 1) tile_accum_records<CT, 1, CG, NT>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
     else tile_accum_records<CT, 2, CG, NT>(a, sg, x0, y0, coff, Pv, Pa, Lv, La, tab);
     __syncthreads();
+#endif
     for (int idx = threadIdx.x; idx < TP; idx += NT) {
         const float v = (float)Pa[idx];
         if (v != 0.f) {
@@ -915,8 +981,24 @@ __global__ __launch_bounds__(NT) void k_bwd_tile_accum(const TileAccumArgs a) {
         const float v = (float)La[C + idx];
         if (v != 0.f) atomicAdd(gL + (size_t)(idx / C) * CT + coff + (idx % C), v);
     }
+#ifdef TA_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    TA_T(6);
+#endif
     }   // segments
+#ifdef TA_PROF
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 10; ++i) if (ta_acc[i]) atomicAdd(&g_ta_prof[i], ta_acc[i]);
+#endif
 }
+#ifdef TA_PROF
+}  // namespace t2n
+extern "C" int t2n_debug_ta_prof(unsigned long long out[16], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(t2n::g_ta_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(t2n::g_ta_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+namespace t2n {
+#endif
 
 // Appearance records: one per appearance-list entry and plane. PASS 0 counts, PASS 1 writes (same lane -> entry -> copy map).
 // Row r of the activation buffers <-> list entry: tile r / 32 belongs to sub-list l (tp.t[l] <= tile < tp.t[l + 1]).
@@ -932,7 +1014,11 @@ __device__ __forceinline__ void app_bin_body(const AppBinArgs& a, unsigned bx) {
     const long long row = wv * 64 + lane;
     const long long rows = a.plan ? (long long)a.plan->rows : a.rows;
     if (wv * 64 >= rows) return;
-    const TilePrefix& tp = a.plan ? a.plan->tp : a.tp;
+    // (a COPY from one of the two sources — uniform scalar loads — not a reference picked between them: selecting between the device
+    // pointer and the address of the by-value argument made every thread read the prefix through flat loads)
+    TilePrefix tp;
+    if (a.plan) { for (int q = 0; q <= kLists; ++q) tp.t[q] = a.plan->tp.t[q]; }
+    else tp = a.tp;
     int key[3] = {-1, -1, -1};
     float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < rows) {
