@@ -308,11 +308,12 @@ def _train_bench(dev, iters, warmup, fused_optim, dist, fused_step, batch, resid
     blocks_ms = None
     if dist is None and trace is None:
         # the loop's host side runs under a cgroup CPU quota: one throttled 100-ms period inside a 25-50 ms timed block doubles it.
-        # THREE blocks, each from the same initial parameters and a fresh optimiser (the noisy targets turn the field into fog after
+        # FIVE blocks (three until round 6: one multi-millisecond host stall in a block — seen on some boxes once per few hundred steps —
+        # plus the first block's warm-up cost was enough to move a median of three), each from the same initial parameters and a fresh optimiser (the noisy targets turn the field into fog after
         # ~45 steps — 114 000 appearance samples until step 40, 674 000 at 60, tools/experiments/train_sample_growth.py — so later
-        # steps of one trajectory would be another workload), warm-up included; the MEDIAN is reported and all three are in the line
+        # steps of one trajectory would be another workload), warm-up included; the MEDIAN is reported and all of them are in the line
         blocks = [dt]
-        for _ in range(max(2, int(os.environ.get("T2N_TRAIN_BLOCKS", "3")) - 1)):
+        for _ in range(max(2, int(os.environ.get("T2N_TRAIN_BLOCKS", "5")) - 1)):
             field.load_state_dict(init_state)
             opt = make_opt()
             for k in range(warmup):

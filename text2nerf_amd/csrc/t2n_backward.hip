@@ -1014,11 +1014,9 @@ __device__ __forceinline__ void app_bin_body(const AppBinArgs& a, unsigned bx) {
     const long long row = wv * 64 + lane;
     const long long rows = a.plan ? (long long)a.plan->rows : a.rows;
     if (wv * 64 >= rows) return;
-    // (a COPY from one of the two sources — uniform scalar loads — not a reference picked between them: selecting between the device
-    // pointer and the address of the by-value argument made every thread read the prefix through flat loads)
-    TilePrefix tp;
-    if (a.plan) { for (int q = 0; q <= kLists; ++q) tp.t[q] = a.plan->tp.t[q]; }
-    else tp = a.tp;
+    // (a reference picked between the device plan and the by-value argument: flat loads, but `tp.t[l]` below stays ONE load at a computed
+    // address — a private copy turned it into a dynamically indexed register array and k_app_bin<1> from 12 into 33 us)
+    const TilePrefix& tp = a.plan ? a.plan->tp : a.tp;
     int key[3] = {-1, -1, -1};
     float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < rows) {
