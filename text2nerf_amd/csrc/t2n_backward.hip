@@ -699,15 +699,33 @@ struct DenBlockArgs {
     FactorSet S; GradSet G; BlockGeom geom; const int4* segs; const unsigned* nseg; const float4* recs;
 };
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// -DDB_PROF (timing-only build): cycle sums per region, lane 0 of every wave: [0] zero + line rows, [1] barrier, [2] splat, [3] barrier,
+// [4] plane contractions + flush, [5] line contractions + flush, [6] segments x waves, [7] records (wave 0 counts them)
+#ifdef DB_PROF
+__device__ unsigned long long g_db_prof[16];
+#define DB_T(i) do { const unsigned long long tn = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) db_acc[i] += tn - db_t; db_t = tn; } while (0)
+#else
+#define DB_T(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(kDenThreads) void k_bwd_den_block(const DenBlockArgs a) {
     __shared__ double Gs[kGsize];
     __shared__ float Ls[3][kBlkE][16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const unsigned nseg = *a.nseg;
     const int X = a.geom.size[0], Y = a.geom.size[1], Z = a.geom.size[2];
+#ifdef DB_PROF
+    unsigned long long db_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, db_t = 0;
+#endif
     for (unsigned seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
         if (seg != blockIdx.x) __syncthreads();   // the previous segment's contractions have finished reading G and the lines
+#ifdef DB_PROF
+        db_t = __builtin_readcyclecounter();
+        if (lane == 0) db_acc[6] += 1;
+#endif
         const int4 sg = a.segs[seg];
+#ifdef DB_PROF
+        if (tid == 0) db_acc[7] += (unsigned long long)(sg.z - sg.y);
+#endif
         const int bx = sg.x % a.geom.nb[0], byz = sg.x / a.geom.nb[0], by = byz % a.geom.nb[1], bz = byz / a.geom.nb[1];
         const int ox = bx * kBlk - 1, oy = by * kBlk - 1, oz = bz * kBlk - 1;   // cell of local (0, 0, 0)
         for (int i = tid; i < kGsize; i += kDenThreads) Gs[i] = 0.0;
@@ -718,7 +736,12 @@ __global__ __launch_bounds__(kDenThreads) void k_bwd_den_block(const DenBlockArg
             const float4 v = (g >= 0 && g < n) ? *reinterpret_cast<const float4*>(Ln + (size_t)g * 16 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(&Ls[k][row][q * 4]) = v;
         }
+#ifdef DB_PROF
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        DB_T(0);
         __syncthreads();
+        DB_T(1);
         // ---- phase 1: the trilinear splat of the segment's records ---------------------------------------------------------------
         for (int i = sg.y + tid; i < sg.z; i += kDenThreads) {
             const float4 p = a.recs[i];
@@ -732,7 +755,12 @@ __global__ __launch_bounds__(kDenThreads) void k_bwd_den_block(const DenBlockArg
             atomicAdd(&Gs[b + kGsz], (double)(g1 * w00)); atomicAdd(&Gs[b + kGsz + 1], (double)(g1 * w01));
             atomicAdd(&Gs[b + kGsz + kGsy], (double)(g1 * w10)); atomicAdd(&Gs[b + kGsz + kGsy + 1], (double)(g1 * w11));
         }
+#ifdef DB_PROF
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        DB_T(2);
         __syncthreads();
+        DB_T(3);
         // ---- phase 2: contractions. MFMA 16x16x4 fp32: A lane (i, kk) = A[i][kk], B lane (j, kk) = B[kk][j], D lane (j, q) regs r = D[4q + r][j]
         const int li = lane & 15, kk = lane >> 4;
         // planes: 48 tiles of 16 cells x 16 channels (pair k, tile t): wave w takes tiles w, w + 8, ...
@@ -759,6 +787,10 @@ __global__ __launch_bounds__(kDenThreads) void k_bwd_den_block(const DenBlockArg
                 }
             }
         }
+#ifdef DB_PROF
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        DB_T(4);
         // lines: pair k = w / 2 for waves 0..5, half (w & 1) of the 256 plane cells each: D[line row][channel] += sum_cells G P
         if (w < 6) {
             const int k = w >> 1, half = w & 1;
@@ -769,6 +801,8 @@ __global__ __launch_bounds__(kDenThreads) void k_bwd_den_block(const DenBlockArg
             const int arow = k == 0 ? li * kGsz : (k == 1 ? li * kGsy : li);
             const int au = k == 0 ? kGsy : kGsz, av = k == 2 ? kGsy : 1;
             f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+            // (all 32 plane values in flight at once instead of four groups of eight: 59.8 K -> 43.2 K cycles for this region in the DB_PROF
+            // accounting and nothing off the step: profiles/round6_train_ab.txt)
             for (int s8 = 0; s8 < 32; s8 += 8) {
                 float bv[8];
 #pragma unroll
@@ -791,8 +825,24 @@ __global__ __launch_bounds__(kDenThreads) void k_bwd_den_block(const DenBlockArg
                 if (d[r] != 0.f && g >= 0 && g < n) atomicAdd(gL + (size_t)g * 16 + li, d[r]);
             }
         }
+#ifdef DB_PROF
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        DB_T(5);
     }
+#ifdef DB_PROF
+    if (lane == 0) for (int i = 0; i < 8; ++i) if (db_acc[i]) atomicAdd(&g_db_prof[i], db_acc[i]);
+#endif
 }
+#ifdef DB_PROF
+}  // namespace t2n
+extern "C" int t2n_debug_db_prof(unsigned long long out[16], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(t2n::g_db_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(t2n::g_db_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+namespace t2n {
+#endif
 
 // (4) accumulate one segment of one tile in LDS. Measured on gfx950 (tools/experiments/lds_atomic_bench.hip): ds_add_f32
 // retires ~1 lane per 3 clocks (194 clk per wave instruction, whatever the addresses) while ds_add_f64 / ds_add_u64 run at
@@ -2037,10 +2087,11 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
     // density bins counted from the forward's windows, beside the shade kernel, instead of behind the backward march (as t2n_render_backward
     // does): takes ~110 us of small kernels off the chain backward march -> density scatter -> density Adam -> next march, at the price of
     // records for zero-gradient samples and a second evaluation of the sample positions. Small batches are bound by that chain (2 048 rays:
-    // 0.404 -> 0.392 ms), large ones by the machine's throughput (16 384 rays: 0.851 -> 0.857): taken up to 4 096 rays
+    // 0.404 -> 0.392 ms; 8 192 rays: 0.575 -> 0.564), large ones by the machine's throughput (16 384 rays: 0.851 -> 0.857, later 0.829 / 0.845 ->
+    // 0.838 / 0.826: nothing either way): taken up to 8 192 rays
     // (T2N_DEN_EARLY=0 / 1 forces it; profiles/round6_train_ab.txt)
     static const int den_env = getenv("T2N_DEN_EARLY") ? atoi(getenv("T2N_DEN_EARLY")) : -1;
-    bool den_early = den_env >= 0 ? den_env != 0 : A->n_rays <= 4096;
+    bool den_early = den_env >= 0 ? den_env != 0 : A->n_rays <= 8192;
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap_status);
     if (cap_status != hipStreamCaptureStatusNone) den_early = false;   // (the captured step keeps the one DAG its replay was tested with: the early form's extra fork crashed hipStreamEndCapture on ROCm 7.2)
