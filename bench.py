@@ -555,28 +555,19 @@ def scaling_prediction(field, dev, fused_ms, G=8):
         field.frame_width, field.materialize_weights = keep
     if fused_ms is not None:
         try:
+            # five more train legs (smaller batches, the two data-parallel forms): a CHILD process — what they say is a prediction beside
+            # the headline, and the one GPU fault this script ever died of (once in 32 runs, never reproduced) was inside them
+            import subprocess
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--aux-train-dp", str(G)], stdout=subprocess.PIPE, timeout=900)
+            if cp.returncode != 0:
+                raise RuntimeError(f"auxiliary train legs exited with {cp.returncode}")
+            aux = json.loads(cp.stdout.decode().strip().splitlines()[-1])
             steps = {16384: fused_ms}
             for b in (8192, 4096, 2048):
-                steps[b] = train_bench(dev, iters=20, warmup=3, fused_step=True, batch=b)["ms_per_iter"]
+                steps[b] = aux["steps"][str(b)]
+            dp_flat, dp_shard = aux["dp_flat"], aux["dp_shard"]
             # direct reduce-scatter + all-gather of the 69.6 MB buffer over 7 links per GPU: 2 x (bytes / 8) per link
             ar_ms = 2 * (69.6e6 / G) / (153e9 * 0.7) * 1e3 + 0.05
-
-            # the per-rank COMPUTE of a data-parallel step at 16 384 / G rays, with the exchanges left out (one GPU here): the two-call
-            # form every rank of the flat all-reduce runs (TV + Adam over all 70 MB on every rank), and rank 0 of the sharded optimiser
-            # (parallel.ShardedExchange: seeds / steps 1 / G of the planes, then writes the gathered 7 / 8 into the reference layout)
-            class _NoExchange:
-                def __init__(self, world, rank):
-                    self.world, self.rank = world, rank
-
-                def reduce(self, fs):
-                    pass
-
-                def gather(self, fs):
-                    pass
-            dp_flat = train_bench(dev, iters=20, warmup=3, fused_step=True, batch=16384 // G,
-                                  step_kw=dict(fused=True, graph=False, all_reduce=lambda: None))["ms_per_iter"]
-            dp_shard = train_bench(dev, iters=20, warmup=3, fused_step=True, batch=16384 // G,
-                                   step_kw=dict(fused=True, graph=False, all_reduce=_NoExchange(G, 0)))["ms_per_iter"]
             pred["train_dp"] = {"fused_step_ms_by_rays_per_gpu": {str(k): v for k, v in steps.items()},
                                 "all_reduce_estimate_ms": ar_ms,
                                 "per_rank_compute_ms_flat_all_reduce": dp_flat,
@@ -600,6 +591,34 @@ def scaling_prediction(field, dev, fused_ms, G=8):
     pred["weak_c2"] = {"note": "default --gpus N mode: one independent 800x800 view per GPU, the 10 MB all-gather of frame k overlaps the "
                                "render of frame k + 1 (async): no shared resource but the host; predicted efficiency ~1.0"}
     return pred
+
+
+def aux_train_dp(G):
+    """`bench.py --aux-train-dp G` (child of scaling_prediction): the fused step at 8 192 / 4 096 / 2 048 rays and the per-rank COMPUTE of a
+    data-parallel step at 16 384 / G rays with the exchanges left out (one GPU here) — the two-call form every rank of the flat all-reduce
+    runs (TV + Adam over all 70 MB on every rank), and rank 0 of the sharded optimiser (parallel.ShardedExchange: seeds / steps 1 / G of
+    the planes, then writes the gathered 7 / 8 into the reference layout). One JSON line."""
+    torch.set_num_threads(max(1, min(HOST_CORES, 16)))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+
+    class _NoExchange:
+        def __init__(self, world, rank):
+            self.world, self.rank = world, rank
+
+        def reduce(self, fs):
+            pass
+
+        def gather(self, fs):
+            pass
+    out = {"steps": {}}
+    for b in (8192, 4096, 2048):
+        out["steps"][str(b)] = train_bench(dev, iters=20, warmup=3, fused_step=True, batch=b)["ms_per_iter"]
+    out["dp_flat"] = train_bench(dev, iters=20, warmup=3, fused_step=True, batch=16384 // G,
+                                 step_kw=dict(fused=True, graph=False, all_reduce=lambda: None))["ms_per_iter"]
+    out["dp_shard"] = train_bench(dev, iters=20, warmup=3, fused_step=True, batch=16384 // G,
+                                  step_kw=dict(fused=True, graph=False, all_reduce=_NoExchange(G, 0)))["ms_per_iter"]
+    print(json.dumps(out), flush=True)
 
 
 def count_gpus_sysfs():
@@ -730,7 +749,11 @@ def main():
                     help="no HIP timing events inside the timed region (the head's launch time then comes from the untimed pass behind it)")
     ap.add_argument("--train-iters", type=int, default=20)
     ap.add_argument("--train-warmup", type=int, default=3)
+    ap.add_argument("--aux-train-dp", type=int, default=0, help=argparse.SUPPRESS)   # (internal: child of scaling_prediction)
     args = ap.parse_args()
+    if args.aux_train_dp:
+        aux_train_dp(args.aux_train_dp)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))      # parent of N fresh ranks; has not touched the GPU

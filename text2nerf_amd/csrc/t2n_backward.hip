@@ -2088,10 +2088,10 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
     // does): takes ~110 us of small kernels off the chain backward march -> density scatter -> density Adam -> next march, at the price of
     // records for zero-gradient samples and a second evaluation of the sample positions. Small batches are bound by that chain (2 048 rays:
     // 0.404 -> 0.392 ms; 8 192 rays: 0.575 -> 0.564), large ones by the machine's throughput (16 384 rays: 0.851 -> 0.857, later 0.829 / 0.845 ->
-    // 0.838 / 0.826: nothing either way): taken up to 8 192 rays
+    // 0.838 / 0.826: nothing either way): taken up to 4 096 rays (the configuration every record of the round ran)
     // (T2N_DEN_EARLY=0 / 1 forces it; profiles/round6_train_ab.txt)
     static const int den_env = getenv("T2N_DEN_EARLY") ? atoi(getenv("T2N_DEN_EARLY")) : -1;
-    bool den_early = den_env >= 0 ? den_env != 0 : A->n_rays <= 8192;
+    bool den_early = den_env >= 0 ? den_env != 0 : A->n_rays <= 4096;
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap_status);
     if (cap_status != hipStreamCaptureStatusNone) den_early = false;   // (the captured step keeps the one DAG its replay was tested with: the early form's extra fork crashed hipStreamEndCapture on ROCm 7.2)
