@@ -204,13 +204,14 @@ class FusedStep:
             if self.ws is not None and self.ws.device != self.dev:
                 self.ws = None
         # grow when it does not fit; shrink when a third would do (after the fog phase of a run the rows fall back by a factor of ~6)
-        if self.ws is None or self.ws.numel() < need or self.ws.numel() > 3 * need + (64 << 20):
+        if self.ws is None or self.ws.numel() < need or self.ws.numel() > 3 * need + (64 << 20):     # (hysteresis: 3 x)
             had = self.ws is not None
             self.ws = self.field.__dict__["_fused_ws"] = None
             self._drop_graphs()
             if had:
                 torch.cuda.empty_cache()
-            self.ws = self.field.__dict__["_fused_ws"] = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            # (+ 2 MiB nobody is told about: a buffer that ends where its mapping ends turns any over-read by a few bytes into a GPU fault)
+            self.ws = self.field.__dict__["_fused_ws"] = torch.empty(need + (2 << 20), dtype=torch.uint8, device=self.dev)
         return self.ws
 
     def _drop_graphs(self):
