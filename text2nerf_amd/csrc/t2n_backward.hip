@@ -870,6 +870,9 @@ __device__ unsigned long long g_ta_prof[16];
 #else
 #define TA_T(i) do {} while (0)
 #endif
+#ifndef T2N_TA_PIPE
+#define T2N_TA_PIPE 1
+#endif
 template <int CT, int K, int CG, int NT>
 __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const int4 sg, int x0, int y0, int coff, const float* Pv,
                                                    double* Pa, const float* Lv, double* La, float4* tab
@@ -884,7 +887,29 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
     const int per = ((sg.z - sg.y + NW * 64 - 1) / (NW * 64)) * 64;     // records per wave, whole batches
     const int rb = sg.y + wid * per, re = min(sg.z, rb + per);
     float4* T = tab + wid * 64 * 3;
+#if T2N_TA_PIPE
+    // the gradient rows of a batch are loaded ONE BATCH AHEAD (the row of record ri sits in lane ri's record register: a bpermute), the
+    // records two batches ahead — every load UNCONDITIONAL, at clamped addresses, so that the compiler can count the loads in flight: a first
+    // form with the loads under divergent conditions waited for vmcnt(0) in front of every use and was slower than no prefetch at all
+    // (0.830 -> 0.897 ms per step). Kernel under the train loop: 314.7 -> 292.3 us at 16 384 rays, 89.3 -> 85.4 at 2 048 (tools/r6_kernel_ab.sh);
+    // the per-batch round trip for these rows was a third of the kernel's time (profiles/round6_tile_accum_accounting.txt).
+    // T2N_TA_PIPE=0: the loads at the top of their own batch (both scatter forms pass a gradient array: a.gx is never NULL here)
+    if (rb >= re) return;
+    const int last = re - 1;
+    float4 p = a.recs[min(rb + lane, last)];
+    float4 pn = a.recs[min(rb + 64 + lane, last)];
+    auto issue_g = [&](const float4& rec, float (&g)[CG]) {
+#pragma unroll
+        for (int q = 0; q < CG; ++q) {
+            const int row = __shfl(__float_as_int(rec.w), sub * CG + q);
+            g[q] = a.gx[(size_t)row * a.gx_ld + K * CT + coff + ch];
+        }
+    };
+    float gcur[CG];
+    issue_g(p, gcur);
+#else
     float4 p = rb + lane < re ? a.recs[rb + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     for (int b0 = rb; b0 < re; b0 += 64) {
         float gx, gy, gv;
         plane_line_coords<K>(p.x, p.y, p.z, gx, gy, gv);
@@ -895,6 +920,16 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
                                       live ? p.w : 0.f, live ? 1.f : 0.f);
         T[lane * 3 + 1] = make_float4(ay.w0 * ax.w0, ay.w0 * ax.w1, ay.w1 * ax.w0, ay.w1 * ax.w1);
         T[lane * 3 + 2] = make_float4(al.w0, al.w1, 0.f, 0.f);
+#if T2N_TA_PIPE
+        const float4 pnn = a.recs[min(b0 + 128 + lane, last)];
+        wave_lds_sync();
+        TA_T(2);
+        float gnx[CG];
+        issue_g(pn, gnx);
+        float gpre[CG];
+#pragma unroll
+        for (int q = 0; q < CG; ++q) gpre[q] = gcur[q];
+#else
         if (b0 + 64 + lane < re) p = a.recs[b0 + 64 + lane];   // next batch in flight while this one is accumulated
         wave_lds_sync();
         TA_T(2);
@@ -909,6 +944,7 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
                 gpre[q] = t0.w != 0.f ? a.gx[(size_t)__float_as_int(t0.z) * a.gx_ld + K * CT + coff + ch] : 0.f;
             }
         }
+#endif
 #ifdef TA_PROF
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TA_T(3);
@@ -922,7 +958,11 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
             const float4 t0 = T[ri * 3], wp = T[ri * 3 + 1], wl = T[ri * 3 + 2];
             const int c00 = __float_as_int(t0.x) + ch, c01 = c00 + C, c10 = c00 + (kBinTile + 1) * C, c11 = c10 + C;
             const int r0 = __float_as_int(t0.y) + ch, r1 = r0 + C;
+#if T2N_TA_PIPE
+            const float g2 = t0.w != 0.f ? gpre[q] : 0.f;
+#else
             const float g2 = a.gx ? gpre[q] : t0.z;
+#endif
             if (g2 != 0.f) {
                 float pv = Pv[c00] * wp.x;
                 pv = fmaf(Pv[c01], wp.y, pv); pv = fmaf(Pv[c10], wp.z, pv); pv = fmaf(Pv[c11], wp.w, pv);
@@ -938,6 +978,11 @@ __device__ __forceinline__ void tile_accum_records(const TileAccumArgs& a, const
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         TA_T(4);
+#if T2N_TA_PIPE
+        p = pn; pn = pnn;
+#pragma unroll
+        for (int q = 0; q < CG; ++q) gcur[q] = gnx[q];
+#endif
     }
 }
 // grid: (segments, CT / 16)

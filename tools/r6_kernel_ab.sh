@@ -9,6 +9,11 @@ for lib in main $libs; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$lib -o p -- python3 tools/experiments/train_only.py 2 40 $batch fused_eager > $out/log_$lib.txt 2>&1
   f=$(find $out/prof_$lib -name "*kernel_stats.csv" | head -1)
   echo "== $lib" | tee -a $out/ab.txt
-  grep "$pat" $f | awk -F, '{gsub(/"/,"",$0); print "   calls", $2, "avg ns", $4, "min", $6, "max", $7, "|", substr($1,1,60)}' | tee -a $out/ab.txt
+  python3 - "$f" "$pat" <<PY | tee -a $out/ab.txt
+import csv, sys, re
+for r in csv.DictReader(open(sys.argv[1])):
+    if re.search(sys.argv[2], r["Name"]):
+        print("   calls", r["Calls"], "avg us", round(float(r["AverageNs"]) / 1e3, 1), "min", round(float(r["MinNs"]) / 1e3, 1), "max", round(float(r["MaxNs"]) / 1e3, 1), "|", r["Name"][:70])
+PY
   rm -rf $out/prof_$lib
 done
