@@ -404,3 +404,57 @@ def test_sharded_optimizer_virtual_ranks(tiny_params, world):
                     assert float(seg.abs().max()) == 0.0, (r, t, rr)
             if m[world * sl:].numel():
                 assert float(m[world * sl:].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_fused_step_equals_composed_step_on_random_configurations(seed, forms=(False, True), strict=False):
+    """The one-call step (t2n_train_step: folded loss, device-side plan, binned scatters with their staging / prefetch forms, early density
+    bins, fused TV + Adam) against the composed step (separate render / loss / backward / TVAdam calls) on random grids — anisotropic,
+    9 to 60 texels — boxes, cameras, ray counts (ragged: not multiples of 4 / 32 / 64) and sample counts: three steps from the same
+    parameters, the same jitter. What changes from case to case: the number of appearance tiles and density blocks and how full they are
+    (segments of a few records up to several batches), partial last batches, rays without any sample in the box."""
+    from text2nerf_amd.optim import TVAdam
+    g = np.random.Generator(np.random.PCG64(9000 + seed))
+    grid = [int(g.integers(9, 60)) for _ in range(3)]
+    lo = (-g.uniform(2.0, 9.0, 3)).astype(np.float32)
+    hi = g.uniform(2.0, 9.0, 3).astype(np.float32)
+    aabb = [lo.tolist(), hi.tolist()]
+    near_far = [float(g.uniform(0.05, 1.0)), float(g.uniform(6.0, 14.0))]
+    params = synth.make_field_params(9100 + seed, grid, density_scale=float(g.uniform(0.5, 1.4)), aabb=aabb)
+    centre = tuple(float(v) for v in (lo + (hi - lo) * g.uniform(0.3, 0.7, 3)))
+    H, W = int(g.integers(9, 40)), int(g.integers(9, 40))
+    rays = torch.from_numpy(synth.frame_rays_np(H, W, c2w=synth.look_pose(float(g.uniform(-3, 3)), float(g.uniform(-1, 1)), centre)))
+    n = int(g.integers(5, rays.shape[0]))
+    rays = rays[torch.from_numpy(g.permutation(rays.shape[0])[:n])].contiguous()
+    rgb_t = torch.from_numpy(g.uniform(0, 1, (n, 3)).astype(np.float32))
+    dep_t = torch.from_numpy(g.uniform(1, 9, (n,)).astype(np.float32))
+    N = int(g.integers(16, 120))
+    fa = make_field(params, grid, aabb, near_far)
+    fb = make_field(params, grid, aabb, near_far)
+    oa = TVAdam(fa.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fa)
+    ob = TVAdam(fb.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), field=fb)
+    steps = 3
+    for it in range(steps):
+        tv_a = [(fa.density_plane, 0.1), (fa.app_plane, 0.01)]
+        tv_b = [(fb.density_plane, 0.1), (fb.app_plane, 0.01)]
+        torch.manual_seed(300 + it)
+        la = fa.train_step(rays, rgb_t, dep_t, oa, N_samples=N, white_bg=True, tv=tv_a, fused=forms[0], graph=False).clone()
+        torch.manual_seed(300 + it)
+        lb = fb.train_step(rays, rgb_t, dep_t, ob, N_samples=N, white_bg=True, tv=tv_b, fused=forms[1], graph=False).clone()
+        assert torch.allclose(la, lb, rtol=2e-5, atol=1e-9), (seed, it, la, lb)
+    for f_, fu in ((fa, forms[0]), (fb, forms[1])):     # (forms: the campaign tool also runs a path against ITSELF, the control)
+        if fu:
+            f_.__dict__["_fused_step"].sync()
+    if strict:
+        assert_same_trajectory(fa, fb, steps)
+        return
+    # In the suite: assert_same_trajectory's bound on ALL BUT A HANDFUL of elements. Two runs of the SAME path differ by more than that bound in
+    # a single element in 2-3 % of these random cases (float atomics in a near-cancelling sum, then Adam's division by sqrt(v): the composed step
+    # against itself fails 4 of 200 seeds, fused against composed 4 of 200, the same seeds: profiles/round6_fused_step_campaign.txt) — a lost
+    # tile, a wrong plane or a dropped term moves thousands of elements by whole learning-rate steps.
+    for (k, a), (_, b) in zip(fa.state_dict().items(), fb.state_dict().items()):
+        lr = 0.02 if ("plane" in k or "line" in k) else 1e-3
+        d = (a - b).abs()
+        over = int((d > 2e-3 * lr * steps).sum())
+        assert over <= 4, (k, over, float(d.max()))
+        assert float(d.mean()) <= 2e-5 * lr * steps + 1e-9, (k, float(d.mean()))
