@@ -185,8 +185,13 @@ __device__ __forceinline__ void scatter_win(const FactorSet& S, const GradSet& G
 constexpr int kBinTile = 16;      // texels per tile edge (footprints reach one texel further: 17 staged)
 constexpr int kBinCopies = 32;    // privatised histogram / cursor copies (every ray starts in the camera's tile)
 constexpr int kBinSegApp = 512;   // smallest segment (sizes the segment list); the scan picks the actual size per call
+// (512 work items of >= 512 records until the staging of a segment got cheap — round 6 — and the accounting showed its fixed cost
+// per segment: 256 items of >= 1 024 records now, -1 ... -2 % of the 16 384-ray step; 256-record segments: +8 %; profiles/round6_train_ab.txt)
 #ifndef T2N_ACC_TARGET_SEGS_APP
-#define T2N_ACC_TARGET_SEGS_APP 512
+#define T2N_ACC_TARGET_SEGS_APP 256
+#endif
+#ifndef T2N_ACC_SEG_MIN
+#define T2N_ACC_SEG_MIN 1024
 #endif
 constexpr unsigned kAccTargetSegsApp = T2N_ACC_TARGET_SEGS_APP;   // accumulate work items aimed at: whole rounds over 256 CUs
 constexpr unsigned kAccGrid = 2048;   // accumulate workgroups launched (grid-stride over the segment list)
@@ -1784,7 +1789,7 @@ extern "C" int t2n_render_backward(t2n_field* f, const float* rays, int64_t n_ra
             const unsigned nbk = (unsigned)((rows + 255) / 256);
             hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, s, ab);
             launch_bin_scan(ab.hist, ab.geom.total, kBinCopies, (unsigned*)(bw + b.a_bin_total), (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),
-                            b.a_seg_cap, 0u, kAccTargetSegsApp, 512u, s);
+                            b.a_seg_cap, 0u, kAccTargetSegsApp, (unsigned)T2N_ACC_SEG_MIN, s);
             hipLaunchKernelGGL((k_app_bin<1>), dim3(nbk), dim3(256), 0, s, ab);
             TileAccumArgs ta;
             ta.S = f->dev.app; ta.G = sa.gapp; ta.geom = ab.geom; ta.segs = (const int4*)(bw + b.a_segs);
@@ -2248,7 +2253,7 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
             } else
                 hipLaunchKernelGGL((k_app_bin<0>), dim3(nbk), dim3(256), 0, sb, ab);
             launch_bin_scan(ab.hist, ab.geom.total, kBinCopies, (unsigned*)(bw + b.a_bin_total), (unsigned*)(bw + b.a_tile_start), (int4*)(bw + b.a_segs), (unsigned*)(bw + b.a_nseg),
-                            b.a_seg_cap, 0u, kAccTargetSegsApp, 512u, sb, true);
+                            b.a_seg_cap, 0u, kAccTargetSegsApp, (unsigned)T2N_ACC_SEG_MIN, sb, true);
             hipLaunchKernelGGL((k_app_bin<1>), dim3(nbk), dim3(256), 0, sb, ab);
             T2N_HIP(hipEventRecord(ev[4], sb));
         }
