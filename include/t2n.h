@@ -490,7 +490,7 @@ int t2n_depth_align_global(const float* depth_rendered, const float* depth_est, 
  *                  data-parallel all-reduce of both; a non-zero vote word withholds the update on every rank), 3: both.
  *   losses         device float[4] = {mse, depth loss, transmittance loss, total} of the batch
  * host_batch: the call itself copies host_batch_bytes from pinned host memory to batch_buffer (asynchronously, ahead of everything that
- * reads the batch; a 16-byte-aligned pinned batch is read by the step's zero-fill launch itself, anything else by an engine copy). Pipelined form — an eager call with T2N_FLAG_PIPELINE, phases = 3, host_batch set and a workspace of TWICE
+ * reads the batch, with an engine copy; T2N_COPY_KERNEL=1: a 16-byte-aligned pinned batch is read by the step's zero-fill launch itself). Pipelined form — an eager call with T2N_FLAG_PIPELINE, phases = 3, host_batch set and a workspace of TWICE
  * t2n_train_step_workspace_bytes: the copy and the step's early part (zero fills, the march — it reads the density factors only —, the
  * plan, the appearance binning) are enqueued on the library's side stream right behind the PREVIOUS step's density Adam instead of
  * behind `stream`, i.e. they run beside the previous step's appearance scatter / weight-gradient GEMMs / Adam. The two halves of the

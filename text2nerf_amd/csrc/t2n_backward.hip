@@ -2180,8 +2180,11 @@ extern "C" int t2n_train_step(t2n_field* f, const t2n_train_step_args* A, t2n_st
         const uint4* up_src = nullptr;
         if (A->host_batch) {
             if (!A->batch_buffer || !A->host_batch_bytes) { set_error("t2n_train_step: host_batch without batch_buffer / host_batch_bytes"); return T2N_ERR_INVALID; }
-            // pinned, 16-byte-aligned batches are read by the zero-fill launch itself (below); anything else through the copy engine
-            static const bool engine_copy = getenv("T2N_COPY_ENGINE") != nullptr;
+            // The batch goes through the copy engine. T2N_COPY_KERNEL=1: a pinned, 16-byte-aligned batch is read by the zero-fill launch itself
+            // (no engine packet on the compute stream: its once-per-process ~5 ms stall goes away, the steady state is the same) — NOT the
+            // default: in the pipelined form, as the first fused work of a fresh process, that kernel died of a GPU memory fault in 7 of 56
+            // runs (0 of 44 with the engine copy, 0 of 16 unpipelined; tools/r6_fault_loop.sh, profiles/round6_train_ab.txt); unexplained
+            static const bool engine_copy = !(getenv("T2N_COPY_KERNEL") && atoi(getenv("T2N_COPY_KERNEL")) != 0);
             void* dp = nullptr;
             if (!engine_copy && ((uintptr_t)A->host_batch & 15u) == 0 && ((uintptr_t)A->batch_buffer & 15u) == 0 && (A->host_batch_bytes & 15u) == 0 &&
                 hipHostGetDevicePointer(&dp, const_cast<void*>((const void*)A->host_batch), 0) == hipSuccess && dp) up_src = (const uint4*)dp;
